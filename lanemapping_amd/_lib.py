@@ -1,0 +1,80 @@
+"""ctypes binding of liblanemap_hip.so — the C-ABI declared in include/lanemap_hip.h.
+
+The library is the product: there is no CPU/ATen fallback.  If it is missing, import of any op
+fails loudly with a build hint (run ``python -m lanemapping_amd.build``).
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, 'liblanemap_hip.so')
+
+c_f32p = C.POINTER(C.c_float)
+vp, i32, i64, f32 = C.c_void_p, C.c_int, C.c_long, C.c_float
+
+
+class LmRasterParams(C.Structure):
+    """Per-tile BEV<->LAS parameters (reference utils/io_utils.py:125-150)."""
+    _fields_ = [('quat', C.c_float * 4), ('trans', C.c_float * 3), ('bev_img_offset', C.c_float * 2),
+                ('img_reso', C.c_float * 2), ('local_min_ele', C.c_float), ('ele_reso', C.c_float),
+                ('inten_lo', C.c_float), ('inten_hi', C.c_float)]
+
+
+# name -> (restype, argtypes); every entry must be declared in include/lanemap_hip.h
+SIGNATURES = {
+    'lm_abi_version': (i32, []),
+    'lm_last_error': (C.c_char_p, []),
+    'lm_device_count': (i32, []),
+    'lm_conv2d_nhwc_mfma_f32': (i32, [vp, vp, i32, vp, i32, vp, vp, vp, i32, i32, vp, i32,
+                                      i32, i32, i32, i32, i32, i32, i32, i32, i32, i32, i32, i32]),
+    'lm_stem_conv7x7_bn_relu': (i32, [vp, vp, vp, vp, vp, vp, i32, i32, i32]),
+    'lm_maxpool3x3s2_nhwc': (i32, [vp, vp, vp, i32, i32, i32, i32]),
+    'lm_conv2d_nhwc_small': (i32, [vp, vp, i32, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, i32, i32, i32, i32, i32, i32]),
+    'lm_gn_stats': (i32, [vp, vp, vp, vp, i32, i32, i32, f32]),
+    'lm_gn_stats_workspace_bytes': (i64, [i32, i32, i32]),
+    'lm_gn_relu_upsample': (i32, [vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32]),
+    'lm_upsample_bilinear_nhwc': (i32, [vp, vp, i32, vp, i32, vp, i32, i32, i32, i32, i32, i32, i32]),
+    'lm_upsample_bilinear_to_chw': (i32, [vp, vp, i32, vp, i32, i32, i32, i32, i32, i32]),
+    'lm_layernorm_rows': (i32, [vp, vp, vp, vp, vp, i64, i32, f32]),
+    'lm_unpatchify': (i32, [vp, vp, vp, i32, i32, i32, i32]),
+    'lm_attention_f32': (i32, [vp, vp, vp, i32, i32, i32, i32, f32]),
+    'lm_head_tokens': (i32, [vp, vp, vp, vp, f32, i32, i32, i32, i32, i32, i32]),
+    'lm_head_stage2': (i32, [vp, vp, i32, i32, vp, vp, vp, vp, vp, i64]),
+    'lm_head_proposal_conf': (i32, [vp, vp, vp, vp, vp, i32, i32]),
+    'lm_decode_proposals': (i32, [vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, f32, i32, i32]),
+    'lm_decode_orient': (i32, [vp, vp, i32, i32, vp, i64]),
+    'lm_decode_semantic': (i32, [vp, vp, vp, vp, vp, i32, i32, i32, f32, i32]),
+    'lm_endp_topk_workspace_bytes': (i64, [i32]),
+    'lm_endp_topk': (i32, [vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32]),
+    'lm_bev_raster': (i32, [vp, vp, i64, C.POINTER(LmRasterParams), vp, vp, vp, i32, i32]),
+    'lm_tile_ingest_u8': (i32, [vp, vp, vp, i32, i32, i32, i32]),
+    'lm_endp_cluster': (i32, [vp, i32, i32, i32, i32, i32, i32, i32, i32, vp, i32, vp, vp]),
+    'lm_polyline_assemble': (i32, [vp, vp, vp, vp, vp, i32, i32, i32, f32, i32, vp, vp]),
+}
+
+_lib = None
+
+
+class LanemapHipError(RuntimeError):
+    pass
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise LanemapHipError(
+                f'{LIB_PATH} is missing: the HIP library is the only implementation of this package '
+                '(no CPU fallback). Build it with `python -m lanemapping_amd.build`.')
+        L = C.CDLL(LIB_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(L, name)           # AttributeError if the symbol is not exported
+            fn.restype = res
+            fn.argtypes = args
+        _lib = L
+    return _lib
+
+
+def check(code):
+    if code != 0:
+        raise LanemapHipError(f'lanemap_hip error {code}: {lib().lm_last_error().decode()}')

@@ -1,0 +1,49 @@
+"""Build liblanemap_hip.so (gfx950) in-tree with hipcc.  `python -m lanemapping_amd.build`."""
+import os
+import subprocess
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, 'csrc')
+LIB = os.path.join(HERE, 'liblanemap_hip.so')
+SOURCES = ['errors.cpp', 'conv_mfma.hip', 'conv_direct.hip', 'norm_resize.hip', 'vit.hip', 'head.hip',
+           'decode.hip', 'raster.hip', 'postproc.cpp']
+
+
+def _stale():
+    if not os.path.exists(LIB):
+        return True
+    t = os.path.getmtime(LIB)
+    deps = [os.path.join(CSRC, f) for f in os.listdir(CSRC)]
+    return any(os.path.getmtime(d) > t for d in deps)
+
+
+def build(force=False, verbose=True):
+    if not force and not _stale():
+        return LIB
+    hipcc = os.environ.get('HIPCC', '/opt/rocm/bin/hipcc')
+    objs = []
+    procs = []
+    os.makedirs(os.path.join(HERE, 'build'), exist_ok=True)
+    for src in SOURCES:
+        obj = os.path.join(HERE, 'build', src + '.o')
+        cmd = [hipcc, '--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-fvisibility=hidden',
+               '-x', 'hip', '-c', os.path.join(CSRC, src), '-o', obj]
+        procs.append((src, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)))
+        objs.append(obj)
+    for src, p in procs:
+        out, _ = p.communicate()
+        if p.returncode != 0:
+            sys.stderr.write(out.decode())
+            raise RuntimeError(f'hipcc failed on {src}')
+        if verbose and out.strip():
+            sys.stderr.write(out.decode())
+    cmd = [hipcc, '--offload-arch=gfx950', '-shared', '-fPIC', '-o', LIB] + objs
+    subprocess.check_call(cmd)
+    if verbose:
+        print(f'built {LIB}')
+    return LIB
+
+
+if __name__ == '__main__':
+    build(force='--force' in sys.argv)

@@ -1,0 +1,219 @@
+// Implicit-GEMM convolution / GEMM on the CDNA4 matrix cores, exact fp32.
+//
+//   Y[m, n] = act( (sum_{tap,c} X[pix(m,tap), c] * Wp[tap][n][c]) * scale[n] + shift[n] + R[m % res_rows, n] )
+//
+// m indexes output pixels (b, oy, ox) of an NHWC tensor, n output channels, k = (tap, c).
+// A plain GEMM is the 1x1 / H*W = M special case; the ViT patch embedding is the 8x8 stride-8 case.
+//
+// Replaces (reference, all fp32 cuDNN/cuBLAS via torch.nn): every Conv2d with Cin % 32 == 0 of
+// FPNWrapper (baseline/models/pcencoder/postprojector.py:463-511, 563-655), every nn.Linear of
+// VitSegNet (baseline/models/backbone/vitsegnet.py:51-56,32-35,165) and the shared Conv1d stack of
+// ColumnProposal2 (baseline/models/heads/polyline_fpn_vit_vertex_2.py:206-228).
+//
+// Design (gfx950): 256 threads = 4 waves, one per SIMD; each wave owns a WM x WN output tile made of
+// 32x32 accumulators driven by v_mfma_f32_32x32x2_f32 (exact f32, 64 FLOP/clk/SIMD = chip f32 peak).
+// K is walked one (tap, 32-channel) slab at a time: global -> registers (next slab, issued before the
+// MFMA block) -> LDS [rows][32+4] (double-buffered, one barrier per slab) -> ds_read_b128 fragments:
+// one 16-byte read per operand row feeds 4 MFMAs (lanes 0-31 hold k..k+3, lanes 32-63 k+4..k+7).
+// The +4 float row pad makes both the ds_write_b128 (8-lane groups) and the ds_read_b128 (16-lane
+// groups) bank-conflict free.  The summation order over k is fixed => results are deterministic.
+#include "common.h"
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+namespace {
+
+constexpr int BK = 32;         // k-slab: 32 input channels of one tap
+constexpr int LDS_LD = BK + 4; // padded row (floats)
+
+struct ConvParams {
+    const float* x; const float* wp; const float* scale; const float* shift; const float* res; float* y;
+    int ldx, ldr, ldy, res_rows;
+    int B, H, W, Cin, Cout, CoutP, Ho, Wo;
+    int KH, KW, stride, pad_h, pad_w, dil, act;
+    long M;
+};
+
+__device__ __forceinline__ float gelu_erf(float v) { return 0.5f * v * (1.0f + erff(v * 0.70710678118654752440f)); }
+
+template <int BM, int BN, int WM, int WN>
+__global__ __launch_bounds__(256) void conv_mfma_kernel(ConvParams p) {
+    constexpr int TM = WM / 32, TN = WN / 32;
+    constexpr int WAVES_N = BN / WN;
+    static_assert((BM / WM) * (BN / WN) == 4, "4 waves per block");
+    constexpr int A_LOADS = BM * 8 / 256;   // float4 per thread per slab
+    constexpr int B_LOADS = BN * 8 / 256;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* As = smem;                          // [2][BM][LDS_LD]
+    float* Bs = smem + 2 * BM * LDS_LD;        // [2][BN][LDS_LD]
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = tid >> 6;
+    const int wm0 = (wave / WAVES_N) * WM;
+    const int wn0 = (wave % WAVES_N) * WN;
+    const int n_tiles = p.CoutP / BN;
+    const long m0 = (long)(blockIdx.x / n_tiles) * BM;
+    const int n0 = (blockIdx.x % n_tiles) * BN;
+
+    // --- per-thread gather coordinates (tap independent part) ---
+    const int lrow = tid >> 3;        // 0..31
+    const int lc4 = (tid & 7) * 4;    // channel offset within the slab
+    int a_iy0[A_LOADS], a_ix0[A_LOADS];
+    long a_boff[A_LOADS];
+#pragma unroll
+    for (int i = 0; i < A_LOADS; ++i) {
+        long m = m0 + lrow + i * 32;
+        if (m < p.M) {
+            int ox = (int)(m % p.Wo);
+            long t = m / p.Wo;
+            int oy = (int)(t % p.Ho);
+            int b = (int)(t / p.Ho);
+            a_iy0[i] = oy * p.stride - p.pad_h;
+            a_ix0[i] = ox * p.stride - p.pad_w;
+            a_boff[i] = (long)b * p.H * p.W;
+        } else {
+            a_iy0[i] = -(1 << 28);   // always out of range -> zero rows
+            a_ix0[i] = 0;
+            a_boff[i] = 0;
+        }
+    }
+    const int cslabs = p.Cin / BK;
+    const int KT = p.KH * p.KW * cslabs;
+
+    f32x4 ra[A_LOADS], rb[B_LOADS];
+    auto gload = [&](int kt) {
+        const int tap = kt / cslabs;
+        const int c0 = (kt - tap * cslabs) * BK + lc4;
+        const int dy = (tap / p.KW) * p.dil, dx = (tap % p.KW) * p.dil;
+#pragma unroll
+        for (int i = 0; i < A_LOADS; ++i) {
+            const int iy = a_iy0[i] + dy, ix = a_ix0[i] + dx;
+            f32x4 v = {0.f, 0.f, 0.f, 0.f};
+            if ((unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W)
+                v = *reinterpret_cast<const f32x4*>(p.x + (a_boff[i] + (long)iy * p.W + ix) * p.ldx + c0);
+            ra[i] = v;
+        }
+#pragma unroll
+        for (int i = 0; i < B_LOADS; ++i) {
+            const int n = n0 + lrow + i * 32;
+            rb[i] = *reinterpret_cast<const f32x4*>(p.wp + ((long)tap * p.CoutP + n) * p.Cin + c0);
+        }
+    };
+    auto lstore = [&](int buf) {
+#pragma unroll
+        for (int i = 0; i < A_LOADS; ++i)
+            *reinterpret_cast<f32x4*>(As + (buf * BM + lrow + i * 32) * LDS_LD + lc4) = ra[i];
+#pragma unroll
+        for (int i = 0; i < B_LOADS; ++i)
+            *reinterpret_cast<f32x4*>(Bs + (buf * BN + lrow + i * 32) * LDS_LD + lc4) = rb[i];
+    };
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    gload(0);
+    lstore(0);
+    __syncthreads();
+
+    const int frow = lane & 31;
+    const int fk = (lane >> 5) * 4;
+    for (int kt = 0; kt < KT; ++kt) {
+        const int buf = kt & 1;
+        if (kt + 1 < KT) gload(kt + 1);   // next slab in flight under the MFMA block
+        const float* Ab = As + (buf * BM + wm0 + frow) * LDS_LD + fk;
+        const float* Bb = Bs + (buf * BN + wn0 + frow) * LDS_LD + fk;
+#pragma unroll
+        for (int kk = 0; kk < BK; kk += 8) {
+            f32x4 af[TM], bf[TN];
+#pragma unroll
+            for (int i = 0; i < TM; ++i) af[i] = *reinterpret_cast<const f32x4*>(Ab + i * 32 * LDS_LD + kk);
+#pragma unroll
+            for (int j = 0; j < TN; ++j) bf[j] = *reinterpret_cast<const f32x4*>(Bb + j * 32 * LDS_LD + kk);
+#pragma unroll
+            for (int t = 0; t < 4; ++t)
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int j = 0; j < TN; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i][t], bf[j][t], acc[i][j], 0, 0, 0);
+        }
+        if (kt + 1 < KT) lstore(buf ^ 1);
+        __syncthreads();
+    }
+
+    // --- epilogue: affine, residual, activation, masked store (32 consecutive n per half-wave) ---
+    const int half = lane >> 5;
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+        const int n = n0 + wn0 + j * 32 + frow;
+        const bool nok = n < p.Cout;
+        const float sc = (p.scale && nok) ? p.scale[n] : 1.f;
+        const float sh = (p.shift && nok) ? p.shift[n] : 0.f;
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const long m = m0 + wm0 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+                if (nok && m < p.M) {
+                    float v = acc[i][j][r];
+                    if (p.scale) v = v * sc;
+                    v += sh;
+                    if (p.res) v += p.res[(p.res_rows ? (m % p.res_rows) : m) * p.ldr + n];
+                    if (p.act == LM_ACT_RELU) v = fmaxf(v, 0.f);
+                    else if (p.act == LM_ACT_GELU) v = gelu_erf(v);
+                    p.y[m * p.ldy + n] = v;
+                }
+            }
+        }
+    }
+}
+
+template <int BM, int BN, int WM, int WN>
+int launch(const ConvParams& p, hipStream_t stream) {
+    const size_t lds = (size_t)2 * (BM + BN) * LDS_LD * sizeof(float);
+    static bool attr_set = false;
+    if (!attr_set) {
+        LM_HIP(hipFuncSetAttribute((const void*)conv_mfma_kernel<BM, BN, WM, WN>,
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        attr_set = true;
+    }
+    const long m_tiles = (p.M + BM - 1) / BM;
+    const long blocks = m_tiles * (p.CoutP / BN);
+    LM_REQUIRE(blocks > 0 && blocks < (1L << 31), "conv_mfma: bad grid %ld", blocks);
+    hipLaunchKernelGGL((conv_mfma_kernel<BM, BN, WM, WN>), dim3((unsigned)blocks), dim3(256), lds, stream, p);
+    LM_LAUNCH_CHECK();
+    return LM_OK;
+}
+
+}  // namespace
+
+LM_API int lm_conv2d_nhwc_mfma_f32(void* stream, const float* x, int ldx, const float* wp, int CoutP,
+                                   const float* scale, const float* shift,
+                                   const float* res, int ldr, int res_rows, float* y, int ldy,
+                                   int B, int H, int W, int Cin, int Cout, int KH, int KW,
+                                   int stride, int pad_h, int pad_w, int dil, int act) {
+    LM_REQUIRE(x && wp && y, "conv_mfma: null pointer");
+    LM_REQUIRE(Cin > 0 && Cin % BK == 0, "conv_mfma: Cin=%d must be a multiple of %d", Cin, BK);
+    LM_REQUIRE(CoutP >= Cout && CoutP % 128 == 0, "conv_mfma: CoutP=%d must be Cout=%d rounded up to 128", CoutP, Cout);
+    LM_REQUIRE(ldx >= Cin && ldx % 4 == 0 && ldy >= Cout, "conv_mfma: bad leading dims ldx=%d ldy=%d", ldx, ldy);
+    LM_REQUIRE(stride >= 1 && dil >= 1 && KH >= 1 && KW >= 1, "conv_mfma: bad geometry");
+    ConvParams p;
+    p.x = x; p.wp = wp; p.scale = scale; p.shift = shift; p.res = res; p.y = y;
+    p.ldx = ldx; p.ldr = ldr; p.ldy = ldy; p.res_rows = res_rows;
+    p.B = B; p.H = H; p.W = W; p.Cin = Cin; p.Cout = Cout; p.CoutP = CoutP;
+    p.Ho = (H + 2 * pad_h - dil * (KH - 1) - 1) / stride + 1;
+    p.Wo = (W + 2 * pad_w - dil * (KW - 1) - 1) / stride + 1;
+    LM_REQUIRE(p.Ho > 0 && p.Wo > 0, "conv_mfma: empty output");
+    p.KH = KH; p.KW = KW; p.stride = stride; p.pad_h = pad_h; p.pad_w = pad_w; p.dil = dil; p.act = act;
+    p.M = (long)B * p.Ho * p.Wo;
+    hipStream_t s = (hipStream_t)stream;
+    if (Cout <= 64) return launch<128, 64, 32, 64>(p, s);
+    return launch<128, 128, 64, 64>(p, s);
+}

@@ -1,0 +1,148 @@
+// Column-proposal head glue kernels (ColumnProposal2.forward, live branch only:
+// column_att=False, spatial_att=True; baseline/models/heads/polyline_fpn_vit_vertex_2.py:390-421).
+//
+//  lm_head_tokens       : for every proposal p, row h, window column w and channel c
+//                           tok[(b,p,h), c*10+w] = avg_pool8x8( up_{(288,20)->(1152,80)}( seg_p ) )[h,w] * row_fea_pad[b,c,h,2p+w]
+//                         (:392-405).  seg = bi_seg_proposal(relu(col_fea_up)) is computed once for the whole
+//                         288x288 map; zero-padded columns (:383) evaluate to the conv bias.  The 1152x80
+//                         per-proposal map (prop_bi_seg, 26.5 MB/tile) is never materialised.
+//  lm_head_stage2       : second Conv1d of ext2 / cls2 / offset2 (:210,218,226) on the BN'd hidden rows
+//  lm_head_proposal_conf: proposal_confidence Linear(23040 -> 2) (:200-204)
+#include "common.h"
+
+namespace {
+
+constexpr int FW = 10;      // prop_fea_width = prop_width + 2*half_buff
+constexpr int NCH = 16;     // header_fea_dim
+
+__device__ __forceinline__ void bilin_axis(int o, int in, int out, int& i0, int& i1, float& w0, float& w1) {
+    const float scale = (float)(in - 1) / (float)(out - 1);
+    const float src = scale * (float)o;
+    i0 = (int)src;
+    if (i0 > in - 1) i0 = in - 1;
+    i1 = i0 + ((i0 < in - 1) ? 1 : 0);
+    w1 = fminf(fmaxf(src - (float)i0, 0.f), 1.f);
+    w0 = 1.f - w1;
+}
+
+// seg [B,Hs,Ws] (Hs=Ws=288), row [B,Hr,Wr,16] NHWC (Hr=Wr=144), tok [B*P*Hr, 160]
+__global__ __launch_bounds__(256) void head_tokens_kernel(const float* __restrict__ seg, const float* __restrict__ row,
+                                                          float* __restrict__ tok, float seg_bias, int P, int Hr, int Wr,
+                                                          int prop_width, int half_buff, long total) {
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= total) return;
+    const int w = (int)(i % FW);
+    long t = i / FW;
+    const int h = (int)(t % Hr);
+    t /= Hr;
+    const int p = (int)(t % P);
+    const int b = (int)(t / P);
+    const int Hs = 2 * Hr, Ws = 2 * Wr;
+    const int win = 2 * FW;                             // 20 source columns per proposal
+    const int col0 = 2 * prop_width * p - 2 * half_buff;   // first source column of the window (may be < 0)
+    const float* sb = seg + (long)b * Hs * Ws;
+    float sum = 0.f;
+    for (int r = 0; r < 8; ++r) {
+        int y0, y1;
+        float wy0, wy1;
+        bilin_axis(8 * h + r, Hs, 8 * Hr, y0, y1, wy0, wy1);
+        for (int q = 0; q < 8; ++q) {
+            int x0, x1;
+            float wx0, wx1;
+            bilin_axis(8 * w + q, win, 8 * FW, x0, x1, wx0, wx1);
+            const int c0 = col0 + x0, c1 = col0 + x1;
+            const bool ok0 = (unsigned)c0 < (unsigned)Ws, ok1 = (unsigned)c1 < (unsigned)Ws;
+            const float v00 = ok0 ? sb[(long)y0 * Ws + c0] : seg_bias;
+            const float v01 = ok1 ? sb[(long)y0 * Ws + c1] : seg_bias;
+            const float v10 = ok0 ? sb[(long)y1 * Ws + c0] : seg_bias;
+            const float v11 = ok1 ? sb[(long)y1 * Ws + c1] : seg_bias;
+            sum += wy0 * (wx0 * v00 + wx1 * v01) + wy1 * (wx0 * v10 + wx1 * v11);
+        }
+    }
+    const float pooled = sum * (1.0f / 64.0f);
+    const int rc = prop_width * p + w - half_buff;      // column in the un-padded row feature map
+    float* tr = tok + (((long)b * P + p) * Hr + h) * (NCH * FW) + w;
+    if ((unsigned)rc < (unsigned)Wr) {
+        const float* rp = row + (((long)b * Hr + h) * Wr + rc) * NCH;
+#pragma unroll
+        for (int c = 0; c < NCH; ++c) tr[c * FW] = pooled * rp[c];
+    } else {
+#pragma unroll
+        for (int c = 0; c < NCH; ++c) tr[c * FW] = pooled * 0.f;
+    }
+}
+
+// hid [M, ldh] (ext | cls | off hidden, D each) -> ext2 [M,3], cls2 [M,10], off2 [M,10]
+__global__ __launch_bounds__(256) void head_stage2_kernel(const float* __restrict__ hid, int ldh, int D,
+                                                          const float* __restrict__ w2, const float* __restrict__ b2,
+                                                          float* __restrict__ ext2, float* __restrict__ cls2,
+                                                          float* __restrict__ off2, long M) {
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    const long m = i / 23;
+    const int j = (int)(i % 23);
+    if (m >= M) return;
+    const int br = (j < 3) ? 0 : (j < 13 ? 1 : 2);
+    const float* hr = hid + m * ldh + br * D;
+    const float* wr = w2 + (long)j * D;        // rows: 3 ext, 10 cls, 10 off
+    float acc = 0.f;
+    for (int k = 0; k < D; ++k) acc = fmaf(hr[k], wr[k], acc);
+    acc += b2[j];
+    if (br == 0) ext2[m * 3 + j] = acc;
+    else if (br == 1) cls2[m * 10 + (j - 3)] = acc;
+    else off2[m * 10 + (j - 13)] = acc;
+}
+
+// tok [B*P, L] (L = Hr*160, already in (h, cw) order), wt [2][L] -> conf [B*P, 2]
+__global__ __launch_bounds__(256) void head_conf_kernel(const float* __restrict__ tok, const float* __restrict__ wt,
+                                                        const float* __restrict__ bias, float* __restrict__ conf, int L) {
+    __shared__ float red[2][256];
+    const long bp = blockIdx.x;
+    const float* tr = tok + bp * L;
+    float a0 = 0.f, a1 = 0.f;
+    for (int k = threadIdx.x; k < L; k += 256) {
+        const float v = tr[k];
+        a0 = fmaf(v, wt[k], a0);
+        a1 = fmaf(v, wt[L + k], a1);
+    }
+    red[0][threadIdx.x] = a0;
+    red[1][threadIdx.x] = a1;
+    __syncthreads();
+    for (int s = 128; s > 0; s >>= 1) {
+        if (threadIdx.x < s) {
+            red[0][threadIdx.x] += red[0][threadIdx.x + s];
+            red[1][threadIdx.x] += red[1][threadIdx.x + s];
+        }
+        __syncthreads();
+    }
+    if (threadIdx.x < 2) conf[bp * 2 + threadIdx.x] = red[threadIdx.x][0] + bias[threadIdx.x];
+}
+
+}  // namespace
+
+LM_API int lm_head_tokens(void* stream, const float* seg, const float* row_nhwc16, float* tok, float seg_bias,
+                          int B, int P, int Hr, int Wr, int prop_width, int half_buff) {
+    LM_REQUIRE(seg && row_nhwc16 && tok, "head_tokens: null pointer");
+    LM_REQUIRE(prop_width + 2 * half_buff == FW, "head_tokens: prop_fea_width must be %d", FW);
+    const long total = (long)B * P * Hr * FW;
+    hipLaunchKernelGGL(head_tokens_kernel, dim3(lm_cdiv(total, 256)), dim3(256), 0, (hipStream_t)stream,
+                       seg, row_nhwc16, tok, seg_bias, P, Hr, Wr, prop_width, half_buff, total);
+    LM_LAUNCH_CHECK();
+    return LM_OK;
+}
+
+LM_API int lm_head_stage2(void* stream, const float* hid, int ldh, int D, const float* w2, const float* b2,
+                          float* ext2, float* cls2, float* off2, long M) {
+    LM_REQUIRE(hid && w2 && b2 && ext2 && cls2 && off2, "head_stage2: null pointer");
+    hipLaunchKernelGGL(head_stage2_kernel, dim3(lm_cdiv(M * 23, 256)), dim3(256), 0, (hipStream_t)stream,
+                       hid, ldh, D, w2, b2, ext2, cls2, off2, M);
+    LM_LAUNCH_CHECK();
+    return LM_OK;
+}
+
+LM_API int lm_head_proposal_conf(void* stream, const float* tok, const float* wt, const float* bias, float* conf,
+                                 int BP, int L) {
+    LM_REQUIRE(tok && wt && bias && conf, "head_conf: null pointer");
+    hipLaunchKernelGGL(head_conf_kernel, dim3(BP), dim3(256), 0, (hipStream_t)stream, tok, wt, bias, conf, L);
+    LM_LAUNCH_CHECK();
+    return LM_OK;
+}

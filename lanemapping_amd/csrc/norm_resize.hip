@@ -1,0 +1,294 @@
+// Normalisation and resampling kernels (HBM-bound, NHWC fp32, float4 per lane).
+//
+//  lm_gn_stats                : per-(b,c) mean / rstd of GroupNorm(C groups == C channels)
+//                               (postprojector.py:512-515), deterministic two-level fp64 reduction
+//  lm_gn_relu_upsample        : y (=|+=) bilinear_align_corners(relu(gn(x)))  -> fuses the
+//                               `_upsample(F.relu(gn(conv(..))))` and `s2+s3+s4` steps (postprojector.py:615-651)
+//  lm_upsample_bilinear_nhwc  : F.interpolate(mode='bilinear', align_corners=True) (+ optional add)
+//                               (postprojector.py:541-561; heads/polyline_fpn_vit_vertex_2.py:298-300)
+//  lm_upsample_bilinear_to_chw: same, NHWC source -> planar [B,C,Ho,Wo] destination (bi_seg / endp maps)
+//  lm_layernorm_rows          : nn.LayerNorm(dim) eps 1e-5 over rows (vitsegnet.py:20-26)
+//  lm_unpatchify              : 'b (h w) (p1 p2 c) -> b c (h p1) (w p2)' into NHWC (vitsegnet.py:180)
+//
+// Bilinear source index follows ATen: scale = (in-1)/(out-1) in fp32, src = scale*dst,
+// i0 = floor(src), i1 = min(i0+1, in-1), w1 = src - i0, w0 = 1 - w1.
+#include "common.h"
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+namespace {
+
+__device__ __forceinline__ void bilin_axis(int o, int in, int out, int& i0, int& i1, float& w0, float& w1) {
+    const float scale = (out > 1) ? (float)(in - 1) / (float)(out - 1) : 0.f;
+    const float src = scale * (float)o;
+    i0 = (int)src;
+    if (i0 > in - 1) i0 = in - 1;
+    i1 = i0 + ((i0 < in - 1) ? 1 : 0);
+    w1 = fminf(fmaxf(src - (float)i0, 0.f), 1.f);
+    w0 = 1.f - w1;
+}
+
+// ----------------------------------------------------------------------------- GroupNorm stats
+constexpr int GN_CHUNK = 512;   // pixels per partial block
+
+__global__ __launch_bounds__(256) void gn_partial_kernel(const float* __restrict__ x, double* __restrict__ part,
+                                                         int HW, int C, int nchunk) {
+    __shared__ double red[2][256];
+    const int b = blockIdx.y, chunk = blockIdx.x;
+    const int lanes_p = 256 / C;                 // pixel lanes per block (C in {64,128,256})
+    const int c = threadIdx.x % C, pl = threadIdx.x / C;
+    const int p0 = chunk * GN_CHUNK;
+    const int p1 = min(p0 + GN_CHUNK, HW);
+    double s = 0.0, ss = 0.0;
+    const float* xb = x + (long)b * HW * C;
+    for (int p = p0 + pl; p < p1; p += lanes_p) {
+        const double v = (double)xb[(long)p * C + c];
+        s += v;
+        ss += v * v;
+    }
+    red[0][threadIdx.x] = s;
+    red[1][threadIdx.x] = ss;
+    __syncthreads();
+    if (pl == 0) {
+        for (int q = 1; q < lanes_p; ++q) {       // fixed order
+            s += red[0][q * C + c];
+            ss += red[1][q * C + c];
+        }
+        double* o = part + (((long)b * nchunk + chunk) * C + c) * 2;
+        o[0] = s;
+        o[1] = ss;
+    }
+}
+
+__global__ void gn_final_kernel(const double* __restrict__ part, float* __restrict__ stats, int HW, int C,
+                                int nchunk, float eps) {
+    const int b = blockIdx.x;
+    for (int c = threadIdx.x; c < C; c += blockDim.x) {
+        double s = 0.0, ss = 0.0;
+        for (int k = 0; k < nchunk; ++k) {
+            const double* o = part + (((long)b * nchunk + k) * C + c) * 2;
+            s += o[0];
+            ss += o[1];
+        }
+        const double mean = s / HW;
+        double var = ss / HW - mean * mean;
+        if (var < 0.0) var = 0.0;
+        stats[((long)b * C + c) * 2 + 0] = (float)mean;
+        stats[((long)b * C + c) * 2 + 1] = (float)(1.0 / sqrt(var + (double)eps));
+    }
+}
+
+// ----------------------------------------------------------------------------- GN + ReLU + bilinear (+=)
+__global__ __launch_bounds__(256) void gn_relu_upsample_kernel(const float* __restrict__ x, const float* __restrict__ stats,
+                                                               const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                               float* __restrict__ y, int Hi, int Wi, int Ho, int Wo, int C,
+                                                               int accumulate, long total4) {
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= total4) return;
+    const int c4n = C / 4;
+    const int c = (int)(i % c4n) * 4;
+    long t = i / c4n;
+    const int ox = (int)(t % Wo);
+    t /= Wo;
+    const int oy = (int)(t % Ho);
+    const int b = (int)(t / Ho);
+    int y0, y1, x0, x1;
+    float wy0, wy1, wx0, wx1;
+    bilin_axis(oy, Hi, Ho, y0, y1, wy0, wy1);
+    bilin_axis(ox, Wi, Wo, x0, x1, wx0, wx1);
+    f32x4 a, g;   // per-channel affine of the normalisation: v*a + g
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        const float mean = stats[((long)b * C + c + e) * 2], rstd = stats[((long)b * C + c + e) * 2 + 1];
+        a[e] = rstd * gamma[c + e];
+        g[e] = beta[c + e] - mean * a[e];
+    }
+    const float* xb = x + (long)b * Hi * Wi * C + c;
+    auto tap = [&](int yy, int xx) {
+        f32x4 v = *reinterpret_cast<const f32x4*>(xb + ((long)yy * Wi + xx) * C);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e] * a[e] + g[e], 0.f);
+        return v;
+    };
+    const f32x4 v00 = tap(y0, x0), v01 = tap(y0, x1), v10 = tap(y1, x0), v11 = tap(y1, x1);
+    f32x4 o;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) o[e] = wy0 * (wx0 * v00[e] + wx1 * v01[e]) + wy1 * (wx0 * v10[e] + wx1 * v11[e]);
+    f32x4* yp = reinterpret_cast<f32x4*>(y + i * 4);
+    if (accumulate) {
+        const f32x4 prev = *yp;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) o[e] = prev[e] + o[e];
+    }
+    *yp = o;
+}
+
+// ----------------------------------------------------------------------------- plain bilinear, NHWC -> NHWC slice
+__global__ __launch_bounds__(256) void upsample_nhwc_kernel(const float* __restrict__ x, int ldx, const float* __restrict__ add, int lda,
+                                                            float* __restrict__ y, int ldy, int Hi, int Wi, int Ho, int Wo,
+                                                            int C, long total4) {
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= total4) return;
+    const int c4n = C / 4;
+    const int c = (int)(i % c4n) * 4;
+    long t = i / c4n;
+    const int ox = (int)(t % Wo);
+    t /= Wo;
+    const int oy = (int)(t % Ho);
+    const int b = (int)(t / Ho);
+    int y0, y1, x0, x1;
+    float wy0, wy1, wx0, wx1;
+    bilin_axis(oy, Hi, Ho, y0, y1, wy0, wy1);
+    bilin_axis(ox, Wi, Wo, x0, x1, wx0, wx1);
+    const float* xb = x + (long)b * Hi * Wi * ldx + c;
+    const f32x4 v00 = *reinterpret_cast<const f32x4*>(xb + ((long)y0 * Wi + x0) * ldx);
+    const f32x4 v01 = *reinterpret_cast<const f32x4*>(xb + ((long)y0 * Wi + x1) * ldx);
+    const f32x4 v10 = *reinterpret_cast<const f32x4*>(xb + ((long)y1 * Wi + x0) * ldx);
+    const f32x4 v11 = *reinterpret_cast<const f32x4*>(xb + ((long)y1 * Wi + x1) * ldx);
+    const long opix = ((long)b * Ho + oy) * Wo + ox;
+    f32x4 o;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) o[e] = wy0 * (wx0 * v00[e] + wx1 * v01[e]) + wy1 * (wx0 * v10[e] + wx1 * v11[e]);
+    if (add) {
+        const f32x4 r = *reinterpret_cast<const f32x4*>(add + opix * lda + c);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) o[e] = o[e] + r[e];
+    }
+    *reinterpret_cast<f32x4*>(y + opix * ldy + c) = o;
+}
+
+// NHWC (few channels) -> planar [B,C,Ho,Wo]
+__global__ __launch_bounds__(256) void upsample_to_chw_kernel(const float* __restrict__ x, int ldx, float* __restrict__ y,
+                                                              int Hi, int Wi, int Ho, int Wo, int C, long total) {
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= total) return;
+    const int ox = (int)(i % Wo);
+    long t = i / Wo;
+    const int oy = (int)(t % Ho);
+    t /= Ho;
+    const int c = (int)(t % C);
+    const int b = (int)(t / C);
+    int y0, y1, x0, x1;
+    float wy0, wy1, wx0, wx1;
+    bilin_axis(oy, Hi, Ho, y0, y1, wy0, wy1);
+    bilin_axis(ox, Wi, Wo, x0, x1, wx0, wx1);
+    const float* xb = x + (long)b * Hi * Wi * ldx + c;
+    const float v00 = xb[((long)y0 * Wi + x0) * ldx], v01 = xb[((long)y0 * Wi + x1) * ldx];
+    const float v10 = xb[((long)y1 * Wi + x0) * ldx], v11 = xb[((long)y1 * Wi + x1) * ldx];
+    y[i] = wy0 * (wx0 * v00 + wx1 * v01) + wy1 * (wx0 * v10 + wx1 * v11);
+}
+
+// ----------------------------------------------------------------------------- LayerNorm: one wave per row
+template <int PER>
+__global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict__ x, const float* __restrict__ gamma,
+                                                        const float* __restrict__ beta, float* __restrict__ y, long rows,
+                                                        float eps) {
+    constexpr int D = PER * 64;
+    const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const int lane = threadIdx.x & 63;
+    const float* xr = x + row * D;
+    float v[PER];
+    float s = 0.f;
+#pragma unroll
+    for (int k = 0; k < PER; ++k) {
+        v[k] = xr[k * 64 + lane];
+        s += v[k];
+    }
+    for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
+    const float mean = s / (float)D;
+    float q = 0.f;
+#pragma unroll
+    for (int k = 0; k < PER; ++k) {
+        const float d = v[k] - mean;
+        q += d * d;
+    }
+    for (int o = 32; o > 0; o >>= 1) q += __shfl_xor(q, o);
+    const float rstd = 1.0f / sqrtf(q / (float)D + eps);
+    float* yr = y + row * D;
+#pragma unroll
+    for (int k = 0; k < PER; ++k) {
+        const int c = k * 64 + lane;
+        yr[c] = (v[k] - mean) * rstd * gamma[c] + beta[c];
+    }
+}
+
+__global__ __launch_bounds__(256) void unpatchify_kernel(const float* __restrict__ t, float* __restrict__ y, int G, int P,
+                                                         int C, long total) {
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;   // index into NHWC output [B, G*P, G*P, C]
+    if (i >= total) return;
+    const int c = (int)(i % C);
+    long r = i / C;
+    const int xx = (int)(r % (G * P));
+    r /= (G * P);
+    const int yy = (int)(r % (G * P));
+    const int b = (int)(r / (G * P));
+    const int gh = yy / P, p1 = yy % P, gw = xx / P, p2 = xx % P;
+    y[i] = t[((long)b * G * G + gh * G + gw) * (P * P * C) + (p1 * P + p2) * C + c];
+}
+
+}  // namespace
+
+LM_API int lm_gn_stats(void* stream, const float* x, double* workspace, float* stats, int B, int HW, int C, float eps) {
+    LM_REQUIRE(x && workspace && stats, "gn_stats: null pointer");
+    LM_REQUIRE(C <= 256 && 256 % C == 0, "gn_stats: C=%d must divide 256", C);
+    const int nchunk = lm_cdiv(HW, GN_CHUNK);
+    hipLaunchKernelGGL(gn_partial_kernel, dim3(nchunk, B), dim3(256), 0, (hipStream_t)stream, x, workspace, HW, C, nchunk);
+    LM_LAUNCH_CHECK();
+    hipLaunchKernelGGL(gn_final_kernel, dim3(B), dim3(256), 0, (hipStream_t)stream, workspace, stats, HW, C, nchunk, eps);
+    LM_LAUNCH_CHECK();
+    return LM_OK;
+}
+
+LM_API long lm_gn_stats_workspace_bytes(int B, int HW, int C) {
+    return (long)B * lm_cdiv(HW, GN_CHUNK) * C * 2 * (long)sizeof(double);
+}
+
+LM_API int lm_gn_relu_upsample(void* stream, const float* x, const float* stats, const float* gamma, const float* beta,
+                               float* y, int B, int Hi, int Wi, int Ho, int Wo, int C, int accumulate) {
+    LM_REQUIRE(x && stats && gamma && beta && y && C % 4 == 0, "gn_relu_upsample: bad args");
+    const long total4 = (long)B * Ho * Wo * (C / 4);
+    hipLaunchKernelGGL(gn_relu_upsample_kernel, dim3(lm_cdiv(total4, 256)), dim3(256), 0, (hipStream_t)stream,
+                       x, stats, gamma, beta, y, Hi, Wi, Ho, Wo, C, accumulate, total4);
+    LM_LAUNCH_CHECK();
+    return LM_OK;
+}
+
+LM_API int lm_upsample_bilinear_nhwc(void* stream, const float* x, int ldx, const float* add, int lda, float* y, int ldy,
+                                     int B, int Hi, int Wi, int Ho, int Wo, int C) {
+    LM_REQUIRE(x && y && C % 4 == 0 && ldx % 4 == 0 && ldy % 4 == 0 && (!add || lda % 4 == 0), "upsample_nhwc: bad args");
+    const long total4 = (long)B * Ho * Wo * (C / 4);
+    hipLaunchKernelGGL(upsample_nhwc_kernel, dim3(lm_cdiv(total4, 256)), dim3(256), 0, (hipStream_t)stream,
+                       x, ldx, add, lda, y, ldy, Hi, Wi, Ho, Wo, C, total4);
+    LM_LAUNCH_CHECK();
+    return LM_OK;
+}
+
+LM_API int lm_upsample_bilinear_to_chw(void* stream, const float* x, int ldx, float* y, int B, int Hi, int Wi,
+                                       int Ho, int Wo, int C) {
+    LM_REQUIRE(x && y && C >= 1, "upsample_to_chw: bad args");
+    const long total = (long)B * C * Ho * Wo;
+    hipLaunchKernelGGL(upsample_to_chw_kernel, dim3(lm_cdiv(total, 256)), dim3(256), 0, (hipStream_t)stream,
+                       x, ldx, y, Hi, Wi, Ho, Wo, C, total);
+    LM_LAUNCH_CHECK();
+    return LM_OK;
+}
+
+LM_API int lm_layernorm_rows(void* stream, const float* x, const float* gamma, const float* beta, float* y,
+                             long rows, int D, float eps) {
+    LM_REQUIRE(x && gamma && beta && y && (D == 512 || D == 1024), "layernorm: D=%d must be 512 or 1024", D);
+    if (D == 512)
+        hipLaunchKernelGGL(layernorm_kernel<8>, dim3(lm_cdiv(rows, 4)), dim3(256), 0, (hipStream_t)stream, x, gamma, beta, y, rows, eps);
+    else
+        hipLaunchKernelGGL(layernorm_kernel<16>, dim3(lm_cdiv(rows, 4)), dim3(256), 0, (hipStream_t)stream, x, gamma, beta, y, rows, eps);
+    LM_LAUNCH_CHECK();
+    return LM_OK;
+}
+
+LM_API int lm_unpatchify(void* stream, const float* tokens, float* y_nhwc, int B, int G, int P, int C) {
+    LM_REQUIRE(tokens && y_nhwc, "unpatchify: null pointer");
+    const long total = (long)B * G * P * G * P * C;
+    hipLaunchKernelGGL(unpatchify_kernel, dim3(lm_cdiv(total, 256)), dim3(256), 0, (hipStream_t)stream, tokens, y_nhwc, G, P, C, total);
+    LM_LAUNCH_CHECK();
+    return LM_OK;
+}

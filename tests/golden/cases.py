@@ -1,0 +1,176 @@
+"""Seeded test-case builders shared by make_golden.py (reference side) and tests/ (build side).
+
+Everything is derived from integer seeds through lanemapping_amd.synth, so the golden .npz
+files only need to carry expected outputs.
+"""
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+from lanemapping_amd import synth  # noqa: E402
+
+IMG = 1152
+NUM_POSTPROC_CASES = 24
+
+
+def vit_input(seed):
+    return synth.normalish(seed, 64 * 144 * 144).astype(np.float32).reshape(1, 64, 144, 144)
+
+
+def head_inputs(seed, batch=1):
+    x = synth.normalish(seed, batch * 8 * 144 * 144, 1).astype(np.float32).reshape(batch, 8, 144, 144)
+    x_up = synth.normalish(seed, batch * 8 * 288 * 288, 2).astype(np.float32).reshape(batch, 8, 288, 288)
+    return x, x_up
+
+
+def _blobs(seed, n_blob, stream):
+    par = synth.uniform(seed, n_blob * 3, stream)
+    ys = 60 + par[0::3] * (IMG - 120)
+    xs = 60 + par[1::3] * (IMG - 120)
+    amp = 6.0 + 2.0 * par[2::3]
+    return ys, xs, amp
+
+
+def decode_inputs(seed, batch=1):
+    """Synthetic raw network outputs with planted structure (decode golden G5/G7)."""
+    out = {}
+    out['proposal_conf'] = (2.0 * synth.normalish(seed, batch * 72 * 2, 1)).astype(np.float32).reshape(batch, 72, 2)
+    out['ext2'] = (2.0 * synth.normalish(seed, batch * 72 * 144 * 3, 2)).astype(np.float32).reshape(batch, 72, 144, 3)
+    out['cls2'] = (2.0 * synth.normalish(seed, batch * 72 * 144 * 10, 3)).astype(np.float32).reshape(batch, 72, 144, 10)
+    out['offset2'] = (0.3 * synth.normalish(seed, batch * 72 * 144 * 10, 4)).astype(np.float32).reshape(batch, 72, 144, 10)
+    out['orient'] = (2.0 * synth.normalish(seed, batch * 11 * 144 * 144, 5)).astype(np.float32).reshape(batch, 11, 144, 144)
+    rows = np.arange(IMG, dtype=np.float64)[:, None]
+    cols = np.arange(IMG, dtype=np.float64)[None, :]
+    sem = np.zeros((batch, 3, IMG, IMG), dtype=np.float32)
+    endp = np.zeros((batch, 1, IMG, IMG), dtype=np.float32)
+    for b in range(batch):
+        noise = synth.normalish(seed, 3 * IMG * IMG, 10 + b).reshape(3, IMG, IMG)
+        s = 0.4 * noise
+        s[0] += 2.0
+        par = synth.uniform(seed, 32, 20 + b)
+        for k in range(6):
+            centre = (0.1 + 0.15 * k + 0.03 * par[k]) * IMG + 0.1 * (par[8 + k] - 0.5) * rows
+            near = np.exp(-((cols - centre) ** 2) / (2 * 2.5 ** 2))
+            s[1 + (k % 2)] += 4.0 * near
+        sem[b] = s.astype(np.float32)
+        e = -4.0 + 0.25 * synth.normalish(seed, IMG * IMG, 30 + b).reshape(IMG, IMG)
+        ys, xs, amp = _blobs(seed, 7, 40 + b)
+        for y, x, a in zip(ys, xs, amp):
+            e += a * np.exp(-((rows - y) ** 2 + (cols - x) ** 2) / (2 * 4.0 ** 2))
+        endp[b, 0] = e.astype(np.float32)
+    out['semantic_seg'] = sem
+    out['endp_est'] = endp
+    return out
+
+
+def expand_rows(rows144):
+    """[144,1152] confidence at image rows 3::8 -> full [1152,1152] map (zeros elsewhere)."""
+    full = np.zeros((IMG, IMG), dtype=np.float32)
+    full[3::8, :] = rows144
+    return full
+
+
+def endp_map(pts):
+    m = np.zeros((IMG, IMG), dtype=np.float32)
+    for (h, w) in np.asarray(pts).reshape(-1, 2):
+        m[int(h), int(w)] = 1.0
+    return m
+
+
+def postproc_case(i):
+    """Hand-built / random decode results for the polyline assembly golden (G6).
+
+    Returns dict(prop_conf1 [72] f32, prop_v_ext [72,144] u8, cls_offset [72,144] f64,
+                 bi_seg_rows [144,1152] f32, endp_pts [K,2] int)."""
+    seed = 6000 + i
+    u = synth.uniform(seed, 4096, 0)
+    H = 144
+    hs = np.arange(H, dtype=np.float64)
+    lanes = []   # (col_px(h) array, h0, h1, semantic pattern array)
+    if i == 1:
+        n_lane = 0
+    elif i == 2:                                    # two crossing lanes
+        lanes.append((300 + 3.0 * hs, 0, 143, np.ones(H)))
+        lanes.append((700 - 2.6 * hs, 0, 143, np.full(H, 2.0)))
+        n_lane = 0
+    elif i == 3:                                    # a lane with a >24-row gap and one with a short gap
+        sem = np.ones(H)
+        lanes.append((400 + 0.5 * hs, 0, 143, sem))
+        lanes.append((800 - 0.3 * hs, 0, 143, np.full(H, 2.0)))
+        n_lane = 0
+    elif i == 4:                                    # close parallel lanes (< 10 px and ~12 px apart)
+        lanes.append((500 + 0.2 * hs, 0, 143, np.ones(H)))
+        lanes.append((507 + 0.2 * hs, 10, 130, np.ones(H)))
+        lanes.append((900 + 0.1 * hs, 0, 143, np.full(H, 2.0)))
+        lanes.append((912 + 0.1 * hs, 0, 143, np.full(H, 2.0)))
+        n_lane = 0
+    else:
+        n_lane = 4 if i == 0 else 1 + int(u[0] * 6)
+    for k in range(n_lane):
+        c0 = 80 + (IMG - 160) * (k + 0.3 + 0.4 * u[10 + k]) / max(n_lane, 1)
+        slope = 1.6 * (u[20 + k] - 0.5)
+        curve = 0.006 * (u[30 + k] - 0.5)
+        h0 = int(u[40 + k] * 30) if u[50 + k] < 0.5 else 0
+        h1 = 143 - (int(u[60 + k] * 30) if u[70 + k] < 0.5 else 0)
+        col = c0 + slope * hs + curve * hs * hs
+        kind = int(u[80 + k] * 3)
+        if kind == 0:
+            sem = np.ones(H)
+        elif kind == 1:
+            sem = np.full(H, 2.0)
+        else:                                       # solid -> dashed change in the middle
+            sem = np.where(hs < 40 + 60 * u[90 + k], 1.0, 2.0)
+        lanes.append((col, h0, h1, sem))
+    noise = synth.normalish(seed, 72 * H, 1).reshape(72, H)
+    rnd = synth.uniform(seed, 72 * H, 2).reshape(72, H)
+    rnd2 = synth.uniform(seed, 72 * H, 3).reshape(72, H)
+    rndp = synth.uniform(seed, 72 * 8, 4).reshape(72, 8)
+    ext = np.zeros((72, H), dtype=np.uint8)
+    conf1 = (0.02 + 0.2 * rndp[:, 0]).astype(np.float64)
+    # background: argmax bin + offset + proposal shift, anywhere in the proposal's field
+    off = (np.floor(rnd * 10) + 0.3 * noise) + (2 * np.arange(72)[:, None] - 4)
+    for li, (col, h0, h1, sem) in enumerate(lanes):
+        g = col / 8.0
+        for p in range(72):
+            inside = (g >= 2 * p - 3) & (g < 2 * p + 5) & (hs >= h0) & (hs <= h1) & (col > 8) & (col < IMG - 8)
+            if inside.sum() < 3 or rndp[p, 1 + (li % 6)] < 0.25:      # proposal did not fire for this lane
+                continue
+            conf1[p] = max(conf1[p], 0.55 + 0.44 * rndp[p, 7])
+            rows = np.nonzero(inside & (rnd2[p] > 0.12))[0]           # 12 % vertex dropout
+            if i == 3 and li == 0:
+                rows = rows[(rows < 50) | (rows > 80)]                # 30-row gap
+            if i == 3 and li == 1:
+                rows = rows[(rows < 60) | (rows > 70)]                # 10-row gap
+            flip = rnd[p, rows] < 0.06                                # 6 % wrong semantics
+            s = sem[rows].copy()
+            s[flip] = 3 - s[flip]
+            ext[p, rows] = s.astype(np.uint8)
+            off[p, rows] = g[rows] + 0.04 * noise[p, rows]
+    cols = np.arange(IMG, dtype=np.float64)[None, :]
+    conf = 0.05 + 0.1 * synth.uniform(seed, H * IMG, 5).reshape(H, IMG)
+    for (col, h0, h1, sem) in lanes:
+        on = ((hs >= h0) & (hs <= h1))[:, None]
+        conf = conf + on * 0.8 * np.exp(-((cols - col[:, None]) ** 2) / (2 * 3.0 ** 2))
+    pts = []
+    for li, (col, h0, h1, sem) in enumerate(lanes):
+        for hh in (h0, h1):
+            if 3 <= hh <= 140 and 30 < col[hh] < IMG - 30 and u[200 + 2 * li + (hh == h1)] < 0.8:
+                pts.append((int(8 * hh + 3 + 3 * (u[300 + li] - 0.5)), int(col[hh] + 4 * (u[320 + li] - 0.5))))
+        ch = np.nonzero(np.diff(sem) != 0)[0]
+        for c in ch:
+            pts.append((int(8 * c + 5), int(col[c])))
+        if u[340 + li] < 0.4:                                          # spurious endpoint in mid-line
+            m = (h0 + h1) // 2
+            pts.append((int(8 * m + 3), int(col[m]) + 2))
+    for k in range(int(u[400] * 4)):                                   # endpoints far from any line
+        pts.append((int(30 + u[410 + k] * 1090), int(30 + u[420 + k] * 1090)))
+    if not pts:
+        pts.append((600, 600))
+    pts = np.unique(np.array(pts, dtype=np.int64).reshape(-1, 2), axis=0)
+    pts = pts[(pts[:, 0] >= 20) & (pts[:, 0] < IMG - 20) & (pts[:, 1] >= 20) & (pts[:, 1] < IMG - 20)]
+    return {'prop_conf1': conf1.astype(np.float32), 'prop_v_ext': ext, 'cls_offset': off.astype(np.float64),
+            'bi_seg_rows': conf.astype(np.float32), 'endp_pts': pts}
