@@ -1,0 +1,177 @@
+#!/usr/bin/env python3
+"""Throughput bench of the lane-mapping hot path on MI355X (contract: see DESIGN.md §Measurement).
+
+    python bench.py [--gpus N --steps K --warmup W]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+A step = one batch of 8 pre-rasterised synthetic WHU-Lane-shaped BEV tiles per GPU (BASELINE.json
+configs[1]: configs/Proj_polyline_fpn_vit_vertex_2.py, batch 8), already resident in HBM, taken all
+the way to lane polylines: FPN -> ViT -> column-proposal head -> decode (GPU), endpoint clustering +
+polyline assembly (host C++ threads, overlapped), plus one all-gather of the fixed-shape polyline
+blocks when N > 1.  Rank 0 prints ONE JSON line.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+MFMA_F32_PEAK_TFLOPS = 157.3      # /opt/skills/guides/MI355X_MICROARCH.md: dense fp32 MFMA peak
+BATCH = 8
+
+
+def cpu_baseline(sample_tiles):
+    """Oracle ("port" of the reference's CPU path: torch-CPU fp32 net + NumPy decode/post-proc) timed on this
+    host's cores on a bounded sample of the same workload."""
+    sys.path.insert(0, os.path.join(ROOT, 'tests', 'golden'))
+    from lanemapping_amd import synth
+    from lanemapping_amd.boundary import build_net_from_config
+    from oracle import net_ref, decode_ref, postproc_ref
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    net = build_net_from_config('Proj_polyline_fpn_vit_vertex_2', device='cpu')
+    synth.fill_module_(net, 2021)
+    sd = {k: v for k, v in net.state_dict().items()}
+
+    def one(seed):
+        x = torch.from_numpy(synth.bev_batch([seed], 1152))
+        with torch.no_grad():
+            raw = net_ref.detector_forward(sd, x)
+        d = decode_ref.decode_column_proposals({k: v.numpy() for k, v in raw.items()})
+        postproc_ref.assemble_tile(d['prop_conf'][0, :, 1].numpy(), d['prop_v_ext'][0].numpy(), d['cls_offset'][0].numpy(),
+                                   d['bi_seg'][0].numpy(), d['endp'][0].numpy())
+
+    one(2021)                                   # warm-up
+    t0 = time.perf_counter()
+    for i in range(sample_tiles):
+        one(2022 + i)
+    dt = time.perf_counter() - t0
+    return {'value': sample_tiles / dt, 'unit': 'tiles/s', 'cores': cores, 'kind': 'port',
+            'sample': f'{sample_tiles} synthetic 1152x1152 tiles, batch 1, oracle net_ref+decode_ref+postproc_ref, '
+                      f'torch {torch.get_num_threads()} threads, after 1 warm-up tile'}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=10)
+    ap.add_argument('--warmup', type=int, default=3)
+    ap.add_argument('--cpu-sample-tiles', type=int, default=3)
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--host-threads', type=int, default=8)
+    args = ap.parse_args()
+
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    rank = int(os.environ.get('RANK', '0'))
+    local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+    if world != args.gpus and world > 1:
+        raise SystemExit(f'--gpus {args.gpus} but WORLD_SIZE={world}')
+    import torch.distributed as dist
+    if world > 1:
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group(backend='nccl', device_id=torch.device('cuda', local_rank))
+    dev = torch.device('cuda', local_rank)
+    torch.cuda.set_device(dev)
+
+    from lanemapping_amd import synth, ops, shard
+    from lanemapping_amd._lib import lib
+    from lanemapping_amd.boundary import build_net_from_config
+    from lanemapping_amd.pipeline import TilePipeline
+    lib()                                                    # raises if the HIP library is missing
+    net = build_net_from_config('Proj_polyline_fpn_vit_vertex_2', device='cpu')
+    synth.fill_module_(net, 2021)
+    net = net.to(dev)
+    # weak scaling: every rank owns its own BATCH tiles per step (seeds differ per rank)
+    tiles = torch.from_numpy(synth.bev_batch([2021 + rank * BATCH + i for i in range(BATCH)], 1152)).to(dev)
+    pipe = TilePipeline(net, host_threads=args.host_threads)
+
+    # ---- roofline instrumentation: HIP events (on the launch stream) around every MFMA conv/GEMM launch ----
+    prof = {'on': False, 'pairs': [], 'flops': 0.0, 'launches': 0}
+
+    def hook(kind, flops, launch):
+        if prof['on']:
+            a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            a.record()
+            launch()
+            b.record()
+            prof['pairs'].append((a, b))
+            prof['flops'] += flops
+            prof['launches'] += 1
+        else:
+            launch()
+    ops.set_conv_hook(hook)
+
+    def step():
+        futs = pipe.submit(tiles)
+        res = [f.result() for f in futs]
+        if world > 1 and res:
+            blocks = shard.pack_tile_results([r[0] for r in res], [r[1] for r in res], BATCH, dev)
+            shard.all_gather_results(*blocks)
+        return res
+
+    def drain():
+        res = [f.result() for f in pipe.flush()]
+        if world > 1 and res:
+            blocks = shard.pack_tile_results([r[0] for r in res], [r[1] for r in res], BATCH, dev)
+            shard.all_gather_results(*blocks)
+        return res
+
+    for _ in range(args.warmup):
+        step()
+    drain()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    prof['on'] = True
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    last = drain()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    dt = time.perf_counter() - t0
+    prof['on'] = False
+    if world > 1:
+        t = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+
+    conv_ms = sum(a.elapsed_time(b) for a, b in prof['pairs'])
+    achieved = prof['flops'] / (conv_ms * 1e-3) / 1e12 if conv_ms > 0 else 0.0
+    n_lines = int(np.mean([(np.count_nonzero(l[:, :, 0] > 0, axis=1) >= 2).sum() for l, _ in last])) if last else 0
+    result = {
+        'metric': 'BEV tiles/sec end-to-end (pre-rasterised tile -> polylines)', 'value': world * BATCH * args.steps / dt,
+        'unit': 'tiles/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
+        'ms_per_step': dt / args.steps * 1e3, 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
+        'dtype': 'f32', 'data': 'synthetic',
+        'config': {'workload': 'configs/Proj_polyline_fpn_vit_vertex_2.py inference, batch=8 per GPU, pre-rasterised '
+                               'synthetic 1152x1152 BEV tiles resident in HBM, seeded random weights',
+                   'tiles_per_step_per_gpu': BATCH, 'lines_per_tile': n_lines, 'host_threads': args.host_threads},
+        'roofline': {'bound': 'mfma', 'kernel': 'conv_mfma_kernel (all FPN/ViT/head implicit-GEMM launches)',
+                     'achieved': achieved, 'peak': MFMA_F32_PEAK_TFLOPS, 'unit': 'TFLOP/s',
+                     'frac': achieved / MFMA_F32_PEAK_TFLOPS, 'traffic': None,
+                     'launches_per_step': prof['launches'] / max(args.steps, 1),
+                     'gflop_per_step': prof['flops'] / max(args.steps, 1) / 1e9,
+                     'kernel_ms_per_step': conv_ms / max(args.steps, 1)},
+    }
+    if rank == 0:
+        if world == 1 and not args.no_cpu_baseline:
+            result['cpu_baseline'] = cpu_baseline(args.cpu_sample_tiles)
+        else:
+            result['cpu_baseline'] = None
+        print(json.dumps(result), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

@@ -50,6 +50,7 @@ SIGNATURES = {
     'lm_tile_ingest_u8': (i32, [vp, vp, vp, i32, i32, i32, i32]),
     'lm_endp_cluster': (i32, [vp, i32, i32, i32, i32, i32, i32, i32, i32, vp, i32, vp, vp]),
     'lm_polyline_assemble': (i32, [vp, vp, vp, vp, vp, i32, i32, i32, f32, i32, vp, vp]),
+    'lm_raster_polylines': (i32, [vp, i32, i32, vp]),
 }
 
 _lib = None

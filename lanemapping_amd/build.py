@@ -10,6 +10,10 @@ SOURCES = ['errors.cpp', 'conv_mfma.hip', 'conv_direct.hip', 'norm_resize.hip', 
            'decode.hip', 'raster.hip', 'postproc.cpp']
 
 
+# integer-output kernels whose fp32 index math must match the C oracle bit for bit
+EXACT_FP = {'raster.hip'}
+
+
 def _stale():
     if not os.path.exists(LIB):
         return True
@@ -29,6 +33,8 @@ def build(force=False, verbose=True):
         obj = os.path.join(HERE, 'build', src + '.o')
         cmd = [hipcc, '--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-fvisibility=hidden',
                '-x', 'hip', '-c', os.path.join(CSRC, src), '-o', obj]
+        if src in EXACT_FP:
+            cmd.insert(4, '-ffp-contract=off')
         procs.append((src, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)))
         objs.append(obj)
     for src, p in procs:

@@ -555,3 +555,35 @@ LM_API int lm_polyline_assemble(const float* prop_conf /*[P][2]*/, const float* 
     }
     return LM_OK;
 }
+
+// polyline_utils.py:610-638 (renew_semantic_map) with cv2.line replaced by an own 8-connected Bresenham
+// (thickness 1, both end points drawn).  Parity against OpenCV's rasteriser is unpinned.
+LM_API int lm_raster_polylines(const double* lanes /*[P][R][2]*/, int P, int R, unsigned char* out /*[1152][1152]*/) {
+    LM_REQUIRE(lanes && out && R * 8 == IMG, "raster_polylines: bad args");
+    std::memset(out, 0, (size_t)IMG * IMG);
+    for (int i = 0; i < P; ++i)
+        for (int r = 0; r < R - 1; ++r) {
+            const int c1 = (int)lanes[((size_t)i * R + r) * 2], c2 = (int)lanes[((size_t)i * R + r + 1) * 2];
+            if (c1 < 0 || c2 < 0) continue;
+            const int s1 = (int)lanes[((size_t)i * R + r) * 2 + 1], s2 = (int)lanes[((size_t)i * R + r + 1) * 2 + 1];
+            const unsigned char colour = (s1 == 2 || s2 == 2) ? 2 : 1;
+            int x0 = c1, y0 = r * 8 + 3, x1 = c2, y1 = (r + 1) * 8 + 3;
+            const int dx = std::abs(x1 - x0), dy = -std::abs(y1 - y0);
+            const int sx = x0 < x1 ? 1 : -1, sy = y0 < y1 ? 1 : -1;
+            int err = dx + dy;
+            for (;;) {
+                if ((unsigned)y0 < (unsigned)IMG && (unsigned)x0 < (unsigned)IMG) out[(size_t)y0 * IMG + x0] = colour;
+                if (x0 == x1 && y0 == y1) break;
+                const int e2 = 2 * err;
+                if (e2 >= dy) {
+                    err += dy;
+                    x0 += sx;
+                }
+                if (e2 <= dx) {
+                    err += dx;
+                    y0 += sy;
+                }
+            }
+        }
+    return LM_OK;
+}

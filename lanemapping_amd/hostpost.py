@@ -42,3 +42,11 @@ def assemble_polylines(prop_conf, prop_v_ext, cls_offset, bi_seg_rows, endp_hw, 
     check(lib().lm_polyline_assemble(_p(pc), _p(ve), _p(co), _p(rows), _p(ep), len(ep), P, R, obj_thre, min_vertices,
                                      _p(lanes), _p(keep)))
     return lanes, ep[keep[:len(ep)] > 0].copy()
+
+
+def raster_semantic_map(lanes):
+    """[P,R,2] lanes -> [1152,1152] f64 map with 1 (solid) / 2 (dashed) polylines (reference renew_semantic_map)."""
+    lanes = np.ascontiguousarray(lanes, dtype=np.float64)
+    out = np.empty((IMG, IMG), dtype=np.uint8)
+    check(lib().lm_raster_polylines(_p(lanes), lanes.shape[0], lanes.shape[1], _p(out)))
+    return out.astype(np.float64)

@@ -1,0 +1,341 @@
+"""Thin torch-tensor front end of the C-ABI (plumbing only: pointers, shapes, the current HIP stream).
+
+Activation convention: tensors are *logically* NCHW (same shapes as the reference) but stored
+channels-last (NHWC) — ``x.stride(1) == 1`` — so every kernel sees pixel-major rows with the channel
+vector contiguous.  A channel slice of a wider NHWC buffer is a legal operand (its pixel stride ``ld``
+is read from ``x.stride(3)``).  Every function raises if a tensor is not on a HIP device: there is no
+CPU fallback.
+"""
+import ctypes as C
+
+import torch
+
+from ._lib import lib, check, LmRasterParams, LanemapHipError
+
+ACT_NONE, ACT_RELU, ACT_GELU = 0, 1, 2
+
+
+def _stream():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _ptr(t):
+    if t is None:
+        return None
+    if not t.is_cuda:
+        raise LanemapHipError('lanemapping_amd ops need tensors on an MI355X (HIP) device; no CPU fallback exists')
+    return C.c_void_p(t.data_ptr())
+
+
+def new_act(B, C_, H, W, device, dtype=torch.float32):
+    """Fresh NHWC-stored activation, returned as a logical [B,C,H,W] view."""
+    return torch.empty((B, H, W, C_), device=device, dtype=dtype).permute(0, 3, 1, 2)
+
+
+def as_nhwc(x):
+    """Return (tensor, ld): x itself if it is NHWC-stored (channel stride 1, pixel-major rows, pixel
+    stride ld >= C), else an NHWC copy."""
+    B, C_, H, W = x.shape
+    sb, sc, sh, sw = x.stride()
+    ok = (sc == 1 or C_ == 1) and sw >= C_ and (sh == W * sw or H == 1) and (sb == H * W * sw or B == 1)
+    if not ok:
+        x = x.permute(0, 2, 3, 1).contiguous().permute(0, 3, 1, 2)
+        sw = C_
+    return x, sw
+
+
+# ------------------------------------------------------------------------------- weight packing
+def fold_bn(bn, conv_bias=None, eps=1e-5):
+    """Eval-mode BatchNorm as a per-channel (scale, shift) applied to the raw conv accumulator."""
+    scale = bn.weight / torch.sqrt(bn.running_var + eps)
+    shift = bn.bias - bn.running_mean * scale
+    if conv_bias is not None:
+        shift = shift + conv_bias * scale
+    return scale.float().contiguous(), shift.float().contiguous()
+
+
+def pack_mfma(w):
+    """[Cout,Cin,KH,KW] (or [N,K] linear) -> [KH*KW, CoutP, Cin] with CoutP = Cout rounded up to 128."""
+    if w.dim() == 2:
+        w = w[:, :, None, None]
+    if w.dim() == 3:
+        w = w[:, :, :, None]
+    co, ci, kh, kw = w.shape
+    cop = (co + 127) // 128 * 128
+    p = torch.zeros((kh * kw, cop, ci), device=w.device, dtype=torch.float32)
+    p[:, :co, :] = w.permute(2, 3, 0, 1).reshape(kh * kw, co, ci)
+    return p.contiguous()
+
+
+def pack_small(w):
+    """[Cout<=16,Cin,KH,KW] -> [KH*KW, Cin, 16]."""
+    co, ci, kh, kw = w.shape
+    p = torch.zeros((kh * kw, ci, 16), device=w.device, dtype=torch.float32)
+    p[:, :, :co] = w.permute(2, 3, 1, 0).reshape(kh * kw, ci, co)
+    return p.contiguous()
+
+
+# ------------------------------------------------------------------------------- convolutions / GEMM
+_conv_hook = None   # optional profiler hook: called as hook(kind, flops, launch_fn)
+
+
+def set_conv_hook(fn):
+    global _conv_hook
+    _conv_hook = fn
+
+
+def conv_mfma(x, wp, cout, kh=1, kw=1, stride=1, pad=0, dil=1, scale=None, shift=None, res=None, act=ACT_NONE,
+              out=None, res_rows=0):
+    x, ldx = as_nhwc(x)
+    B, cin, H, W = x.shape
+    ph, pw = (pad, pad) if isinstance(pad, int) else pad
+    Ho = (H + 2 * ph - dil * (kh - 1) - 1) // stride + 1
+    Wo = (W + 2 * pw - dil * (kw - 1) - 1) // stride + 1
+    if out is None:
+        out = new_act(B, cout, Ho, Wo, x.device)
+    out_, ldy = as_nhwc(out)
+    assert out_.data_ptr() == out.data_ptr(), 'conv_mfma: `out` must already be NHWC-stored'
+    ldr = 0
+    if res is not None:
+        if res.dim() == 4:
+            res, ldr = as_nhwc(res)
+        else:
+            ldr = res.stride(0)
+    def launch():
+        check(lib().lm_conv2d_nhwc_mfma_f32(_stream(), _ptr(x), ldx, _ptr(wp), wp.shape[1], _ptr(scale), _ptr(shift),
+                                            _ptr(res), ldr, res_rows, _ptr(out), ldy, B, H, W, cin, cout, kh, kw,
+                                            stride, ph, pw, dil, act))
+    if _conv_hook is not None:
+        _conv_hook('conv_mfma', 2.0 * B * Ho * Wo * cout * cin * kh * kw, launch)
+    else:
+        launch()
+    return out
+
+
+def linear_mfma(x2d, wp, n_out, scale=None, shift=None, res=None, res_rows=0, act=ACT_NONE, out=None):
+    """y[M,n_out] = act((x2d @ W^T) * scale + shift + res).  x2d [M,K] row-major (K % 32 == 0)."""
+    assert x2d.dim() == 2 and x2d.stride(1) == 1
+    M, K = x2d.shape
+    if out is None:
+        out = torch.empty((M, n_out), device=x2d.device, dtype=torch.float32)
+    ldr = res.stride(0) if res is not None else 0
+    def launch():
+        check(lib().lm_conv2d_nhwc_mfma_f32(_stream(), _ptr(x2d), x2d.stride(0), _ptr(wp), wp.shape[1], _ptr(scale),
+                                            _ptr(shift), _ptr(res), ldr, res_rows, _ptr(out), out.stride(0),
+                                            1, 1, M, K, n_out, 1, 1, 1, 0, 0, 1, act))
+    if _conv_hook is not None:
+        _conv_hook('conv_mfma', 2.0 * M * n_out * K, launch)
+    else:
+        launch()
+    return out
+
+
+def conv_small(x, w16, cout, kh=1, kw=1, stride=1, pad=0, scale=None, shift=None, pre_relu=False, act=ACT_NONE, out=None):
+    x, ldx = as_nhwc(x)
+    B, cin, H, W = x.shape
+    ph, pw = (pad, pad) if isinstance(pad, int) else pad
+    Ho = (H + 2 * ph - kh) // stride + 1
+    Wo = (W + 2 * pw - kw) // stride + 1
+    if out is None:
+        out = new_act(B, cout, Ho, Wo, x.device)
+    out_, ldy = as_nhwc(out)
+    assert out_.data_ptr() == out.data_ptr()
+    check(lib().lm_conv2d_nhwc_small(_stream(), _ptr(x), ldx, _ptr(w16), _ptr(scale), _ptr(shift), _ptr(out), ldy,
+                                     B, H, W, cin, cout, kh, kw, stride, ph, pw, int(pre_relu), act))
+    return out
+
+
+def stem(x_chw, w_k64, scale, shift):
+    """proj [B,3,H,W] planar -> relu(bn(conv7x7 s2)) [B,64,H/2,W/2] NHWC-stored."""
+    x_chw = x_chw.contiguous()
+    B, _, H, W = x_chw.shape
+    Ho, Wo = (H - 1) // 2 + 1, (W - 1) // 2 + 1
+    out = new_act(B, 64, Ho, Wo, x_chw.device)
+    check(lib().lm_stem_conv7x7_bn_relu(_stream(), _ptr(x_chw), _ptr(w_k64), _ptr(scale), _ptr(shift), _ptr(out), B, H, W))
+    return out
+
+
+def maxpool3x3s2(x):
+    x, ld = as_nhwc(x)
+    B, C_, H, W = x.shape
+    assert ld == C_
+    out = new_act(B, C_, (H - 1) // 2 + 1, (W - 1) // 2 + 1, x.device)
+    check(lib().lm_maxpool3x3s2_nhwc(_stream(), _ptr(x), _ptr(out), B, H, W, C_))
+    return out
+
+
+# ------------------------------------------------------------------------------- norm / resize
+def gn_stats(x, eps=1e-5):
+    x, ld = as_nhwc(x)
+    B, C_, H, W = x.shape
+    assert ld == C_
+    ws = torch.empty(lib().lm_gn_stats_workspace_bytes(B, H * W, C_) // 8, device=x.device, dtype=torch.float64)
+    stats = torch.empty((B, C_, 2), device=x.device, dtype=torch.float32)
+    check(lib().lm_gn_stats(_stream(), _ptr(x), _ptr(ws), _ptr(stats), B, H * W, C_, eps))
+    return stats
+
+
+def gn_relu_upsample(x, stats, gamma, beta, size, out=None, accumulate=False):
+    x, ld = as_nhwc(x)
+    B, C_, H, W = x.shape
+    assert ld == C_
+    Ho, Wo = size
+    if out is None:
+        assert not accumulate
+        out = new_act(B, C_, Ho, Wo, x.device)
+    check(lib().lm_gn_relu_upsample(_stream(), _ptr(x), _ptr(stats), _ptr(gamma), _ptr(beta), _ptr(out),
+                                    B, H, W, Ho, Wo, C_, int(accumulate)))
+    return out
+
+
+def upsample_nhwc(x, size, add=None, out=None):
+    x, ldx = as_nhwc(x)
+    B, C_, H, W = x.shape
+    Ho, Wo = size
+    if out is None:
+        out = new_act(B, C_, Ho, Wo, x.device)
+    out_, ldy = as_nhwc(out)
+    assert out_.data_ptr() == out.data_ptr()
+    lda = 0
+    if add is not None:
+        add, lda = as_nhwc(add)
+    check(lib().lm_upsample_bilinear_nhwc(_stream(), _ptr(x), ldx, _ptr(add), lda, _ptr(out), ldy, B, H, W, Ho, Wo, C_))
+    return out
+
+
+def upsample_to_chw(x, size):
+    x, ldx = as_nhwc(x)
+    B, C_, H, W = x.shape
+    Ho, Wo = size
+    out = torch.empty((B, C_, Ho, Wo), device=x.device, dtype=torch.float32)
+    check(lib().lm_upsample_bilinear_to_chw(_stream(), _ptr(x), ldx, _ptr(out), B, H, W, Ho, Wo, C_))
+    return out
+
+
+def layernorm(x2d, gamma, beta, eps=1e-5):
+    assert x2d.is_contiguous()
+    out = torch.empty_like(x2d)
+    check(lib().lm_layernorm_rows(_stream(), _ptr(x2d), _ptr(gamma), _ptr(beta), _ptr(out), x2d.shape[0], x2d.shape[1], eps))
+    return out
+
+
+def unpatchify(tokens, B, G, P, C_):
+    out = new_act(B, C_, G * P, G * P, tokens.device)
+    check(lib().lm_unpatchify(_stream(), _ptr(tokens.contiguous()), _ptr(out), B, G, P, C_))
+    return out
+
+
+def attention(qkv, B, N, heads, dim_head, scale):
+    assert qkv.is_contiguous()
+    out = torch.empty((B * N, heads * dim_head), device=qkv.device, dtype=torch.float32)
+    check(lib().lm_attention_f32(_stream(), _ptr(qkv), _ptr(out), B, N, heads, dim_head, float(scale)))
+    return out
+
+
+# ------------------------------------------------------------------------------- head
+def head_tokens(seg, row, P, prop_width, half_buff, seg_bias):
+    """seg [B,1,288,288], row [B,16,144,144] (NHWC-stored) -> tok [B*P*144, 160]."""
+    row, ld = as_nhwc(row)
+    B, C_, Hr, Wr = row.shape
+    assert C_ == 16 and ld == 16
+    seg = seg.reshape(B, 2 * Hr, 2 * Wr).contiguous()
+    tok = torch.empty((B * P * Hr, 160), device=row.device, dtype=torch.float32)
+    check(lib().lm_head_tokens(_stream(), _ptr(seg), _ptr(row), _ptr(tok), float(seg_bias), B, P, Hr, Wr, prop_width, half_buff))
+    return tok
+
+
+def head_stage2(hid, D, w2, b2, B, P, R):
+    M = hid.shape[0]
+    ext2 = torch.empty((B, P, R, 3), device=hid.device, dtype=torch.float32)
+    cls2 = torch.empty((B, P, R, 10), device=hid.device, dtype=torch.float32)
+    off2 = torch.empty((B, P, R, 10), device=hid.device, dtype=torch.float32)
+    check(lib().lm_head_stage2(_stream(), _ptr(hid), hid.stride(0), D, _ptr(w2), _ptr(b2), _ptr(ext2), _ptr(cls2), _ptr(off2), M))
+    return ext2, cls2, off2
+
+
+def head_proposal_conf(tok, wt, bias, B, P):
+    L = tok.numel() // (B * P)
+    conf = torch.empty((B, P, 2), device=tok.device, dtype=torch.float32)
+    check(lib().lm_head_proposal_conf(_stream(), _ptr(tok), _ptr(wt), _ptr(bias), _ptr(conf), B * P, L))
+    return conf
+
+
+# ------------------------------------------------------------------------------- decode
+def decode_proposals(pconf, ext2, cls2, off2, exist_thre, prop_width, half_buff):
+    B, P, R, _ = cls2.shape
+    dev = cls2.device
+    prop_conf = torch.empty((B, P, 2), device=dev, dtype=torch.float32)
+    v_ext = torch.empty((B, P, R), device=dev, dtype=torch.float32)
+    cls_conf = torch.empty((B, P, R, 10), device=dev, dtype=torch.float32)
+    cls_idx = torch.empty((B, P, R), device=dev, dtype=torch.int32)
+    cls_offset = torch.empty((B, P, R), device=dev, dtype=torch.float64)
+    check(lib().lm_decode_proposals(_stream(), _ptr(pconf.contiguous()), _ptr(ext2.contiguous()), _ptr(cls2.contiguous()),
+                                    _ptr(off2.contiguous()), _ptr(prop_conf), _ptr(v_ext), _ptr(cls_conf), _ptr(cls_idx),
+                                    _ptr(cls_offset), B, P, R, float(exist_thre), prop_width, half_buff))
+    return prop_conf, v_ext, cls_conf, cls_idx, cls_offset
+
+
+def decode_orient(orient_logits):
+    x, ld = as_nhwc(orient_logits)
+    B, C_, H, W = x.shape
+    out = torch.empty((B, H, W), device=x.device, dtype=torch.uint8)
+    check(lib().lm_decode_orient(_stream(), _ptr(x), ld, C_, _ptr(out), B * H * W))
+    return out
+
+
+def decode_semantic(logits_chw, thre, raw_mode=False, want_biseg=True):
+    x = logits_chw.contiguous()
+    B, C_, H, W = x.shape
+    assert C_ == 3
+    sem = torch.empty((B, H, W), device=x.device, dtype=torch.uint8)
+    biseg = rows = None
+    if want_biseg:
+        biseg = torch.empty((B, H, W), device=x.device, dtype=torch.float32)
+        rows = torch.empty((B, H // 8, W), device=x.device, dtype=torch.float32)
+    check(lib().lm_decode_semantic(_stream(), _ptr(x), _ptr(sem), _ptr(biseg), _ptr(rows), B, H, W, float(thre), int(raw_mode)))
+    return sem, biseg, rows
+
+
+def endp_topk(endp_logits, K=512, clip=20):
+    x = endp_logits.contiguous()
+    B, C_, H, W = x.shape
+    assert C_ == 1
+    ws = torch.empty(lib().lm_endp_topk_workspace_bytes(B), device=x.device, dtype=torch.uint8)
+    idx = torch.empty((B, K), device=x.device, dtype=torch.int32)
+    score = torch.empty((B, K), device=x.device, dtype=torch.float32)
+    status = torch.empty((B,), device=x.device, dtype=torch.int32)
+    check(lib().lm_endp_topk(_stream(), _ptr(x), _ptr(ws), _ptr(idx), _ptr(score), _ptr(status), B, H, W, clip, K))
+    return idx, score, status
+
+
+# ------------------------------------------------------------------------------- raster / ingest
+def make_raster_params(quat=(1, 0, 0, 0), trans=(0, 0, 0), bev_img_offset=(0, 0), img_reso=(0.05, 0.05),
+                       local_min_ele=0.0, ele_reso=0.05, inten_lo=800.0, inten_hi=33000.0):
+    p = LmRasterParams()
+    p.quat[:] = [float(v) for v in quat]
+    p.trans[:] = [float(v) for v in trans]
+    p.bev_img_offset[:] = [float(v) for v in bev_img_offset]
+    p.img_reso[:] = [float(v) for v in img_reso]
+    p.local_min_ele, p.ele_reso, p.inten_lo, p.inten_hi = float(local_min_ele), float(ele_reso), float(inten_lo), float(inten_hi)
+    return p
+
+
+def bev_raster(points, params, H=1152, W=1152, out=None, want_u8=False, acc=None):
+    """points [N,4] f32 (x,y,z,raw intensity) on device -> proj [3,H,W] f32 (= u8/255), optional u8 HWC."""
+    assert points.dim() == 2 and points.shape[1] == 4 and points.is_contiguous() and points.dtype == torch.float32
+    if acc is None:
+        acc = torch.empty((H, W), device=points.device, dtype=torch.int32)
+    if out is None:
+        out = torch.empty((3, H, W), device=points.device, dtype=torch.float32)
+    u8 = torch.empty((H, W, 3), device=points.device, dtype=torch.uint8) if want_u8 else None
+    check(lib().lm_bev_raster(_stream(), _ptr(points), points.shape[0], C.byref(params), _ptr(acc), _ptr(out), _ptr(u8), H, W))
+    return (out, u8) if want_u8 else out
+
+
+def tile_ingest(u8_hwc):
+    """[B,H,W,C>=3] uint8 (decoded PNG) -> [B,3,H,W] f32 = u8/255 (reference load_img contract)."""
+    x = u8_hwc.contiguous()
+    B, H, W, C_ = x.shape
+    out = torch.empty((B, 3, H, W), device=x.device, dtype=torch.float32)
+    check(lib().lm_tile_ingest_u8(_stream(), _ptr(x), _ptr(out), B, H, W, C_))
+    return out

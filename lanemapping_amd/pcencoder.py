@@ -1,0 +1,216 @@
+"""BEV feature encoder behind the reference's PCENCODER registry name ``PostProjector2``.
+
+Drop-in for baseline/models/pcencoder/postprojector.py: same constructor kwargs (:59-65), same
+``forward(sample) -> (fea_downsample, fea_up, out_binary_seg, out_endp_seg)`` contract (:79-82), same
+state-dict key layout (incl. the never-executed ``fpn.model_buttomup.*`` ResNet-34) so a
+reference checkpoint loads with ``strict=True``.  The arithmetic runs in liblanemap_hip.so:
+
+  stem 7x7+BN+ReLU, max-pool                      -> lm_stem_conv7x7_bn_relu, lm_maxpool3x3s2_nhwc
+  BasicBlocks, lateral/top/smooth/semantic convs  -> lm_conv2d_nhwc_mfma_f32 (BN / bias / residual / ReLU epilogue)
+  GroupNorm(C,C)+ReLU+bilinear(+sum of branches)  -> lm_gn_stats + lm_gn_relu_upsample
+  1x1 heads (128->8, 8->3, 128->1)                -> lm_conv2d_nhwc_small
+  final 4x bilinear to the tile resolution        -> lm_upsample_bilinear_to_chw
+"""
+import torch
+import torch.nn as nn
+
+from . import ops
+from .registry import PCENCODER
+from .packing import PackedModule
+
+_LAYERS = {'resnet18': [2, 2, 2, 2], 'resnet34': [3, 4, 6, 3]}
+
+
+class _ResBlock(nn.Module):
+    """Parameter container of one BasicBlock (reference :299-338)."""
+
+    def __init__(self, cin, cout, stride, dilation, with_down):
+        super().__init__()
+        self.conv1 = nn.Conv2d(cin, cout, 3, stride, dilation, dilation, bias=False)
+        self.bn1 = nn.BatchNorm2d(cout)
+        self.conv2 = nn.Conv2d(cout, cout, 3, 1, dilation, dilation, bias=False)
+        self.bn2 = nn.BatchNorm2d(cout)
+        self.downsample = nn.Sequential(nn.Conv2d(cin, cout, 1, stride, bias=False), nn.BatchNorm2d(cout)) if with_down else None
+        self.stride, self.dilation = stride, dilation
+
+
+def _stage(state, planes, blocks, stride, dilate):
+    """Reference `_make_layer` (:517-539): `state` = [inplanes, dilation]."""
+    prev_dil = state[1]
+    if dilate:
+        state[1] *= stride
+        stride = 1
+    layers = [_ResBlock(state[0], planes, stride, prev_dil, stride != 1 or state[0] != planes)]
+    state[0] = planes
+    for _ in range(1, blocks):
+        layers.append(_ResBlock(planes, planes, 1, state[1], False))
+    return nn.Sequential(*layers)
+
+
+class _BottomUp(nn.Module):
+    """The reference builds a second ResNet (`model_buttomup`, :436-438) that forward never calls;
+    kept only so checkpoints load strictly."""
+
+    def __init__(self, layers, dil, in_channels):
+        super().__init__()
+        self.conv1 = nn.Conv2d(3, 64, 7, 2, 3, bias=False)
+        self.bn1 = nn.BatchNorm2d(64)
+        st = [64, 1]
+        self.layer1 = _stage(st, in_channels[0], layers[0], 1, False)
+        self.layer2 = _stage(st, in_channels[1], layers[1], 2, dil[0])
+        if in_channels[2] > 0:
+            self.layer3 = _stage(st, in_channels[2], layers[2], 2, dil[1])
+        if in_channels[3] > 0:
+            self.layer4 = _stage(st, in_channels[3], layers[3], 2, dil[2])
+
+
+class FPNEncoder(PackedModule):
+    def __init__(self, resnet='resnet34', pretrained=False, replace_stride_with_dilation=(False, True, False),
+                 out_conv=True, in_channels=(64, 128, 256, -1), cfg=None):
+        super().__init__()
+        if resnet not in _LAYERS:
+            raise NotImplementedError(f'{resnet}: only BasicBlock ResNets are on the hot path')
+        if in_channels[2] <= 0 or in_channels[3] > 0:
+            raise NotImplementedError('hot path covers in_channels=[c1,c2,c3,-1] (all BASELINE configs)')
+        dil = list(replace_stride_with_dilation)
+        if len(dil) != 3:
+            raise ValueError(f'replace_stride_with_dilation should be None or a 3-element tuple, got {dil}')
+        layers = _LAYERS[resnet]
+        self.cfg = cfg
+        self.in_channels = list(in_channels)
+        self.model_buttomup = _BottomUp(layers, dil, in_channels)
+        self.conv1 = nn.Conv2d(3, 64, 7, 2, 3, bias=False)
+        self.bn1 = nn.BatchNorm2d(64)
+        st = [64, 1]
+        self.layer1 = _stage(st, in_channels[0], layers[0], 1, False)
+        self.layer2 = _stage(st, in_channels[1], layers[1], 2, dil[0])
+        self.layer3 = _stage(st, in_channels[2], layers[2], 2, dil[1])
+        c = st[0]                                   # 256
+        self.out = nn.Conv2d(c, cfg.featuremap_out_channel, 1, bias=False) if out_conv else None
+        self.toplayer = nn.Conv2d(c, 256, 1)
+        self.smooth1 = nn.Conv2d(c, c, 3, 1, 1)
+        self.smooth2 = nn.Conv2d(c, c, 3, 1, 1)
+        self.smooth3 = nn.Conv2d(c, c, 3, 1, 1)
+        self.latlayer1 = nn.Conv2d(in_channels[1], c, 1)
+        self.latlayer2 = nn.Conv2d(in_channels[0], c, 1)
+        self.semantic_branch = nn.Conv2d(c, c // 2, 3, 1, 1)
+        self.semantic_branch2 = nn.Conv2d(c, c // 2, 3, 1, 1)
+        self.conv2 = nn.Conv2d(c, c, 3, 1, 1)
+        self.conv3 = nn.Conv2d(c, c, 3, 1, 1)
+        self.feature_layer = nn.Conv2d(c // 2, 8, 1)
+        self.output_layer_binary_seg = nn.Conv2d(8, 3, 1)
+        self.output_layer_endp = nn.Conv2d(c // 2, 1, 1)
+        self.gn11 = nn.GroupNorm(c // 2, c // 2)
+        self.gn12 = nn.GroupNorm(c, c)
+        self.gn21 = nn.GroupNorm(c // 2, c // 2)
+        self.gn22 = nn.GroupNorm(c, c)
+
+    # -------------------------------------------------------------------------------- packing
+    def _pack(self):
+        P = {}
+        P['stem_w'] = self.conv1.weight.permute(2, 3, 1, 0).contiguous().float()        # [7,7,3,64]
+        P['stem_s'], P['stem_b'] = ops.fold_bn(self.bn1)
+        for lname in ('layer1', 'layer2', 'layer3'):
+            for i, blk in enumerate(getattr(self, lname)):
+                k = f'{lname}.{i}'
+                P[k + '.w1'] = ops.pack_mfma(blk.conv1.weight)
+                P[k + '.s1'], P[k + '.b1'] = ops.fold_bn(blk.bn1)
+                P[k + '.w2'] = ops.pack_mfma(blk.conv2.weight)
+                P[k + '.s2'], P[k + '.b2'] = ops.fold_bn(blk.bn2)
+                if blk.downsample is not None:
+                    P[k + '.wd'] = ops.pack_mfma(blk.downsample[0].weight)
+                    P[k + '.sd'], P[k + '.bd'] = ops.fold_bn(blk.downsample[1])
+        for name in ('toplayer', 'smooth1', 'smooth2', 'smooth3', 'latlayer1', 'latlayer2', 'semantic_branch',
+                     'semantic_branch2', 'conv2', 'conv3'):
+            m = getattr(self, name)
+            P[name + '.w'] = ops.pack_mfma(m.weight)
+            P[name + '.b'] = m.bias.float().contiguous()
+        if self.out is not None:
+            P['out.w'] = ops.pack_mfma(self.out.weight)
+        for name in ('feature_layer', 'output_layer_binary_seg', 'output_layer_endp'):
+            m = getattr(self, name)
+            P[name + '.w'] = ops.pack_small(m.weight)
+            P[name + '.b'] = m.bias.float().contiguous()
+        for name in ('gn11', 'gn12', 'gn21', 'gn22'):
+            m = getattr(self, name)
+            P[name + '.g'], P[name + '.b'] = m.weight.float().contiguous(), m.bias.float().contiguous()
+        return P
+
+    # -------------------------------------------------------------------------------- forward
+    def _block(self, x, P, key, blk):
+        cout = blk.conv1.out_channels
+        y = ops.conv_mfma(x, P[key + '.w1'], cout, 3, 3, blk.stride, blk.dilation, blk.dilation,
+                          scale=P[key + '.s1'], shift=P[key + '.b1'], act=ops.ACT_RELU)
+        if blk.downsample is not None:
+            x = ops.conv_mfma(x, P[key + '.wd'], cout, 1, 1, blk.stride, 0, 1, scale=P[key + '.sd'], shift=P[key + '.bd'])
+        return ops.conv_mfma(y, P[key + '.w2'], cout, 3, 3, 1, blk.dilation, blk.dilation,
+                             scale=P[key + '.s2'], shift=P[key + '.b2'], res=x, act=ops.ACT_RELU)
+
+    def _conv3(self, x, P, name, cout):
+        return ops.conv_mfma(x, P[name + '.w'], cout, 3, 3, 1, 1, 1, shift=P[name + '.b'])
+
+    def _semantic(self, P, p2, p3, p4, conv_a, gn_a, conv_b, gn_b):
+        """One of the two branches (reference :615-621 / :641-647): returns s2 + s3 + s4 at p2's size."""
+        h, w = p2.shape[2:]
+        c_half = self.semantic_branch.out_channels
+
+        def gn_up(t, gn, out=None, acc=False):
+            st = ops.gn_stats(t, getattr(self, gn).eps)
+            return ops.gn_relu_upsample(t, st, P[gn + '.g'], P[gn + '.b'], (h, w), out=out, accumulate=acc)
+
+        s4 = gn_up(self._conv3(p4, P, conv_a, p4.shape[1]), gn_a)            # 256 ch at 288^2
+        t2 = self._conv3(p2, P, conv_b, c_half)
+        total = gn_up(t2, gn_b)                                               # s2
+        del t2
+        total = gn_up(self._conv3(p3, P, conv_b, c_half), gn_b, out=total, acc=True)    # + s3
+        total = gn_up(self._conv3(s4, P, conv_b, c_half), gn_b, out=total, acc=True)    # + s4
+        return total
+
+    def forward(self, x, fea_up_out=None):
+        P = self.packed()
+        B, _, H, W = x.shape
+        c1 = ops.maxpool3x3s2(ops.stem(x, P['stem_w'], P['stem_s'], P['stem_b']))
+        feats = []
+        t = c1
+        for lname in ('layer1', 'layer2', 'layer3'):
+            for i, blk in enumerate(getattr(self, lname)):
+                t = self._block(t, P, f'{lname}.{i}', blk)
+            feats.append(t)
+        c2, c3, c4 = feats
+        fea = ops.conv_mfma(c4, P['out.w'], self.out.out_channels) if self.out is not None else None
+        p4 = ops.conv_mfma(c4, P['toplayer.w'], 256, shift=P['toplayer.b'])
+        up4 = ops.upsample_nhwc(p4, c3.shape[2:])
+        p3 = ops.conv_mfma(c3, P['latlayer1.w'], 256, shift=P['latlayer1.b'], res=up4)
+        up3 = ops.upsample_nhwc(p3, c2.shape[2:])
+        p2 = ops.conv_mfma(c2, P['latlayer2.w'], 256, shift=P['latlayer2.b'], res=up3)
+        del up4, up3, c1, c2, c3, c4, feats, t
+        p4 = self._conv3(p4, P, 'smooth1', 256)
+        p3 = self._conv3(p3, P, 'smooth2', 256)
+        p2 = self._conv3(p2, P, 'smooth3', 256)
+        sa = self._semantic(P, p2, p3, p4, 'conv2', 'gn12', 'semantic_branch', 'gn11')
+        fea_up = ops.conv_small(sa, P['feature_layer.w'], 8, shift=P['feature_layer.b'], out=fea_up_out)
+        del sa
+        seg288 = ops.conv_small(fea_up, P['output_layer_binary_seg.w'], 3, shift=P['output_layer_binary_seg.b'], pre_relu=True)
+        bi_seg = ops.upsample_to_chw(seg288, (H, W))
+        sb = self._semantic(P, p2, p3, p4, 'conv3', 'gn22', 'semantic_branch2', 'gn21')
+        endp288 = ops.conv_small(sb, P['output_layer_endp.w'], 1, shift=P['output_layer_endp.b'])
+        endp = ops.upsample_to_chw(endp288, (H, W))
+        return fea, fea_up, bi_seg, endp
+
+
+@PCENCODER.register_module
+class PostProjector2(nn.Module):
+    def __init__(self, resnet='resnet50', pretrained=False, replace_stride_with_dilation=[False, True, False],
+                 out_conv=True, in_channels=[64, 128, 256, -1], cfg=None):
+        super().__init__()
+        self.cfg = cfg
+        self.fpn = FPNEncoder(resnet=resnet, pretrained=pretrained, replace_stride_with_dilation=replace_stride_with_dilation,
+                              out_conv=out_conv, in_channels=in_channels, cfg=cfg)
+
+    def forward(self, sample):
+        return self.fpn(sample['proj'])
+
+    def infer_validate(self, preds, seg_thre=None, endp_thre=None, display=None):
+        """Segmentor decode (reference :115-183): raw-logit thresholds + clustered endpoint peaks."""
+        from .decode import segmentor_decode
+        return segmentor_decode(preds['seg'], preds['endp'], seg_thre)

@@ -1,0 +1,61 @@
+"""Multi-GPU data parallelism over BEV tiles: one process per GPU, static contiguous
+block shard of the sorted tile list, no data-path collective; the per-tile results (fixed-shape polyline
+blocks) are combined with ONE all-gather (RCCL over xGMI on GPUs, gloo on CPU in tests).
+
+The reference has no equivalent on its inference path (nn.DataParallel, runner.py:103-104); its own pattern for
+gathering variable-length per-rank results is the two-round pickle all-gather of utils/dist_utils.py:112-152,
+which fixed shapes make unnecessary here.
+"""
+import numpy as np
+import torch
+import torch.distributed as dist
+
+MAX_ENDP = 64   # endpoint slots per tile in the gathered block
+
+
+def shard_range(n_tiles, rank, world):
+    """Contiguous block of the sorted tile list owned by `rank`; every rank gets ceil(T/world) slots,
+    trailing slots beyond the list are padding (returned count < per)."""
+    per = (n_tiles + world - 1) // world
+    lo = min(rank * per, n_tiles)
+    hi = min(lo + per, n_tiles)
+    return lo, hi, per
+
+
+def pack_tile_results(lanes_list, endp_list, per, device):
+    """lanes [72,144,2] f64 per tile, endpoints [k,2] -> fixed-shape f32 / i32 blocks padded to `per` tiles."""
+    T = len(lanes_list)
+    lanes = torch.full((per, 72, 144, 2), -1.0, dtype=torch.float32)
+    lanes[..., 1] = 0.0
+    endp = torch.full((per, MAX_ENDP, 2), -1, dtype=torch.int32)
+    count = torch.zeros((per, 2), dtype=torch.int32)           # [valid tile flag, n endpoints]
+    for t in range(T):
+        lanes[t] = torch.from_numpy(np.asarray(lanes_list[t], dtype=np.float32))
+        e = np.asarray(endp_list[t], dtype=np.int32).reshape(-1, 2)[:MAX_ENDP]
+        endp[t, :len(e)] = torch.from_numpy(e)
+        count[t, 0] = 1
+        count[t, 1] = len(e)
+    return lanes.to(device), endp.to(device), count.to(device)
+
+
+def all_gather_results(lanes, endp, count):
+    """Returns the rank-major concatenation on every rank ([world*per, ...])."""
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+        return lanes, endp, count
+    world = dist.get_world_size()
+    outs = []
+    for t in (lanes, endp, count):
+        out = torch.empty((world * t.shape[0],) + tuple(t.shape[1:]), dtype=t.dtype, device=t.device)
+        dist.all_gather_into_tensor(out, t.contiguous())
+        outs.append(out)
+    return tuple(outs)
+
+
+def unpack_gathered(lanes, endp, count):
+    """-> list of (lanes [72,144,2] f32, endpoints [k,2]) for the valid tiles, in global tile order."""
+    res = []
+    lanes, endp, count = lanes.cpu().numpy(), endp.cpu().numpy(), count.cpu().numpy()
+    for t in range(lanes.shape[0]):
+        if count[t, 0]:
+            res.append((lanes[t], endp[t, :count[t, 1]]))
+    return res

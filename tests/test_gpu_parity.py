@@ -1,0 +1,272 @@
+"""GPU parity tests (-m gpu): the HIP path, called through the C-ABI, against the oracle and against the
+golden vectors generated from the reference.  Tolerances: fp32 features within 1e-4 of the tensor scale
+(different but fixed summation order), final coordinates / confidences within 1e-4 absolute, every integer /
+index output bit-exact."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+import cases
+from lanemapping_amd import synth
+
+pytestmark = pytest.mark.gpu
+
+
+def _close(a, ref, tol=1e-4, name=''):
+    a = a.detach().float().cpu().numpy() if torch.is_tensor(a) else np.asarray(a)
+    ref = ref.detach().float().cpu().numpy() if torch.is_tensor(ref) else np.asarray(ref)
+    assert a.shape == ref.shape, (name, a.shape, ref.shape)
+    scale = max(1.0, float(np.abs(ref).max()))
+    err = float(np.abs(a - ref).max())
+    assert err <= tol * scale, f'{name}: max err {err:.3e} > {tol:.0e} * scale {scale:.3f}'
+    return err
+
+
+@pytest.fixture(scope='module')
+def dev():
+    assert torch.cuda.is_available(), 'these tests need an MI355X'
+    from lanemapping_amd._lib import lib
+    lib()   # fail loudly if the HIP library is missing
+    return torch.device('cuda:0')
+
+
+@pytest.fixture(scope='module')
+def net(dev):
+    from lanemapping_amd.boundary import build_net_from_config
+    n = build_net_from_config('Proj_polyline_fpn_vit_vertex_2', device='cpu')
+    synth.fill_module_(n, 2021)
+    return n.to(dev)
+
+
+# ----------------------------------------------------------------------------------------------- kernels
+@pytest.mark.parametrize('cin,cout,k,stride,dil,hw,bn,res,relu', [
+    (64, 64, 3, 1, 1, (40, 56), True, True, True),
+    (64, 128, 3, 2, 1, (40, 56), True, False, True),
+    (256, 256, 3, 1, 2, (24, 24), True, True, True),
+    (256, 64, 1, 1, 1, (24, 24), False, False, False),
+    (128, 256, 1, 1, 1, (17, 23), False, True, False),      # ragged M (not a multiple of the 128-row tile)
+    (64, 128, 1, 2, 1, (40, 56), True, False, False),
+    (256, 128, 3, 1, 1, (20, 36), False, False, False),
+])
+def test_conv_mfma_vs_torch(dev, cin, cout, k, stride, dil, hw, bn, res, relu):
+    from lanemapping_amd import ops
+    B = 2
+    g = torch.Generator().manual_seed(cin * 7 + cout + k)
+    x = torch.randn(B, cin, *hw, generator=g)
+    w = torch.randn(cout, cin, k, k, generator=g) / (cin * k * k) ** 0.5
+    pad = dil * (k // 2)
+    ref = F.conv2d(x, w, None, stride, pad, dil)
+    scale = shift = None
+    if bn:
+        scale = torch.rand(cout, generator=g) + 0.5
+        shift = torch.randn(cout, generator=g)
+        ref = ref * scale.view(1, -1, 1, 1) + shift.view(1, -1, 1, 1)
+    r = None
+    if res:
+        r = torch.randn(ref.shape, generator=g)
+        ref = ref + r
+    if relu:
+        ref = F.relu(ref)
+    y = ops.conv_mfma(x.to(dev), ops.pack_mfma(w.to(dev)), cout, k, k, stride, pad, dil,
+                      scale=None if scale is None else scale.to(dev), shift=None if shift is None else shift.to(dev),
+                      res=None if r is None else r.to(dev), act=ops.ACT_RELU if relu else ops.ACT_NONE)
+    _close(y, ref, 1e-5, 'conv_mfma')
+    y2 = ops.conv_mfma(x.to(dev), ops.pack_mfma(w.to(dev)), cout, k, k, stride, pad, dil,
+                       scale=None if scale is None else scale.to(dev), shift=None if shift is None else shift.to(dev),
+                       res=None if r is None else r.to(dev), act=ops.ACT_RELU if relu else ops.ACT_NONE)
+    assert torch.equal(y, y2), 'conv_mfma must be deterministic'
+
+
+def test_linear_mfma_gelu_bias_res(dev):
+    from lanemapping_amd import ops
+    g = torch.Generator().manual_seed(5)
+    x = torch.randn(650, 512, generator=g)
+    w = torch.randn(300, 512, generator=g) / 512 ** 0.5
+    b = torch.randn(300, generator=g)
+    ref = F.gelu(F.linear(x, w, b))
+    out = torch.zeros(650, 320, device=dev)
+    ops.linear_mfma(x.to(dev), ops.pack_mfma(w.to(dev)), 300, shift=b.to(dev), act=ops.ACT_GELU, out=out)
+    _close(out[:, :300], ref, 1e-5, 'linear+gelu')
+    assert float(out[:, 300:].abs().max()) == 0.0, 'columns beyond n_out must stay untouched'
+
+
+def test_small_conv_and_stem(dev, synth_sd):
+    from lanemapping_amd import ops
+    g = torch.Generator().manual_seed(9)
+    x = torch.randn(2, 16, 30, 44, generator=g)
+    w = torch.randn(11, 16, 3, 3, generator=g) / 12
+    b = torch.randn(11, generator=g)
+    ref = F.conv2d(F.relu(x), w, b, 2, 1)
+    y = ops.conv_small(x.to(dev), ops.pack_small(w.to(dev)), 11, 3, 3, 2, 1, shift=b.to(dev), pre_relu=True)
+    _close(y, ref, 1e-5, 'small conv')
+    # stem + max-pool against the oracle's first stage
+    xs = torch.from_numpy(synth.bev_batch([7], 96))
+    p = 'pcencoder.fpn'
+    c1 = F.relu(F.batch_norm(F.conv2d(xs, synth_sd[p + '.conv1.weight'], None, 2, 3), synth_sd[p + '.bn1.running_mean'],
+                             synth_sd[p + '.bn1.running_var'], synth_sd[p + '.bn1.weight'], synth_sd[p + '.bn1.bias'], False, 0., 1e-5))
+    ref = F.max_pool2d(c1, 3, 2, 1)
+    bn = torch.nn.BatchNorm2d(64)
+    bn.load_state_dict({k: synth_sd[f'{p}.bn1.{k}'] for k in ('weight', 'bias', 'running_mean', 'running_var', 'num_batches_tracked')})
+    s, sh = ops.fold_bn(bn)
+    y = ops.maxpool3x3s2(ops.stem(xs.to(dev), synth_sd[p + '.conv1.weight'].permute(2, 3, 1, 0).contiguous().to(dev), s.to(dev), sh.to(dev)))
+    _close(y, ref, 1e-5, 'stem+pool')
+
+
+def test_gn_relu_upsample(dev):
+    from lanemapping_amd import ops
+    g = torch.Generator().manual_seed(11)
+    x = torch.randn(2, 128, 20, 28, generator=g) * 3 + 1
+    gamma, beta = torch.rand(128, generator=g) + 0.5, torch.randn(128, generator=g)
+    ref = F.interpolate(F.relu(F.group_norm(x, 128, gamma, beta, 1e-5)), size=(40, 56), mode='bilinear', align_corners=True)
+    xd = x.to(dev)
+    st = ops.gn_stats(xd)
+    y = ops.gn_relu_upsample(xd, st, gamma.to(dev), beta.to(dev), (40, 56))
+    _close(y, ref, 1e-5, 'gn+relu+up')
+    y = ops.gn_relu_upsample(xd, st, gamma.to(dev), beta.to(dev), (40, 56), out=y, accumulate=True)
+    _close(y, 2 * ref, 1e-5, 'accumulate')
+    up = ops.upsample_to_chw(xd[:, :3], (80, 112))
+    _close(up, F.interpolate(x[:, :3], size=(80, 112), mode='bilinear', align_corners=True), 1e-5, 'to_chw')
+
+
+# ----------------------------------------------------------------------------------------------- goldens
+def test_fpn_golden_g2(dev, net, golden):
+    g = golden('g2_fpn.npz')
+    x = torch.from_numpy(synth.bev_batch([int(s) for s in g['seeds']], int(g['size']))).to(dev)
+    with torch.no_grad():
+        out = net.pcencoder({'proj': x})
+    for name, o in zip(('fea', 'fea_up', 'bi_seg', 'endp'), out):
+        _close(o, g[name], 1e-4, name)
+
+
+def test_vit_golden_g3(dev, net, golden):
+    g = golden('g3_vit.npz')
+    with torch.no_grad():
+        y = net.backbone(torch.from_numpy(cases.vit_input(int(g['input_seed']))).to(dev))
+    _close(y, g['out'], 1e-4, 'vit')
+
+
+def test_head_golden_g4(dev, net, golden):
+    g = golden('g4_head.npz')
+    x, x_up = cases.head_inputs(int(g['input_seed']))
+    with torch.no_grad():
+        out = net.heads(torch.from_numpy(x).to(dev), torch.from_numpy(x_up).to(dev), None)
+    for k in ('proposal_conf', 'ext2', 'cls2', 'offset2', 'orient'):
+        _close(out[k], g[k], 1e-4, k)
+    # class indices: bit-exact wherever the reference's own top-2 margin exceeds the fp32 noise floor
+    idx = out['cls2'].argmax(-1).cpu().numpy()
+    ref_idx = g['cls2'].argmax(-1)
+    safe = g['cls2_margin'] > 1e-3
+    assert np.array_equal(idx[safe], ref_idx[safe])
+    assert (idx != ref_idx).sum() == 0, f'{(idx != ref_idx).sum()} argmax flips inside the noise margin'
+
+
+def test_decode_golden_g5(dev, net, golden):
+    g = golden('g5_decode.npz')
+    raw = cases.decode_inputs(int(g['input_seed']), batch=int(g['batch']))
+    out = {k: torch.from_numpy(v).to(dev) for k, v in raw.items()}
+    out['orient'] = out['orient'].contiguous(memory_format=torch.channels_last)
+    d = net.heads.get_exist_coor_endp_dict(out)
+    assert np.array_equal(d['prop_v_ext'].numpy().astype(np.uint8), g['prop_v_ext'])
+    assert np.array_equal(d['orient'].numpy().astype(np.uint8), g['orient'])
+    assert np.array_equal(d['semantic_seg'].numpy().astype(np.uint8), g['semantic_seg'])
+    _close(d['prop_conf'], g['prop_conf'], 1e-5, 'prop_conf')
+    _close(d['prop_cls_conf'], g['prop_cls_conf'], 1e-5, 'prop_cls_conf')
+    np.testing.assert_allclose(d['cls_offset'].numpy(), g['cls_offset'], rtol=0, atol=1e-6)
+    _close(d['bi_seg'][:, 3::8, :], g['bi_seg_rows'], 1e-5, 'bi_seg')
+    for b in range(2):
+        assert np.array_equal(np.stack(np.nonzero(d['endp'][b].numpy()), axis=1), g[f'endp{b}'])
+
+
+def test_segmentor_golden_g7(dev, golden):
+    from lanemapping_amd.decode import segmentor_decode
+    g = golden('g7_segmentor.npz')
+    raw = cases.decode_inputs(int(g['input_seed']), batch=1)
+    r = segmentor_decode(torch.from_numpy(raw['semantic_seg']).to(dev), torch.from_numpy(raw['endp_est']).to(dev), 0.1)
+    assert np.array_equal(r['seg'].numpy().astype(np.uint8), g['seg'])
+    assert np.array_equal(np.stack(np.nonzero(r['endp'][0].numpy()), axis=1), g['endp'])
+
+
+def test_end_to_end_golden_g10(dev, net, golden):
+    """One full 1152^2 tile through Detector1stage (config 2) vs the reference's own end-to-end run."""
+    g = golden('g10_e2e.npz')
+    x = torch.from_numpy(synth.bev_batch([int(g['tile_seed'])], 1152)).to(dev)
+    with torch.no_grad():
+        raw = net.forward_raw({'proj': x})
+        for k, gk in (('proposal_conf', 'proposal_conf'), ('ext2', 'ext2'), ('cls2', 'cls2'), ('offset2', 'offset2'),
+                      ('orient', 'orient_logits')):
+            _close(raw[k], g[gk], 1e-4, k)
+        o = net({'proj': x})
+    assert np.array_equal(o['prop_v_ext'].numpy().astype(np.uint8), g['prop_v_ext'])
+    assert np.array_equal(o['orient'].numpy().astype(np.uint8), g['orient'])
+    sem_diff = int((o['semantic_seg'].numpy().astype(np.uint8) != g['semantic_seg']).sum())
+    assert sem_diff == 0, f'{sem_diff} semantic pixels differ'
+    np.testing.assert_allclose(o['cls_offset'].numpy(), g['cls_offset'], rtol=0, atol=1e-4)
+    _close(o['prop_conf'], g['prop_conf'], 1e-4, 'prop_conf')
+    assert np.array_equal(np.stack(np.nonzero(o['endp'][0].numpy()), axis=1), g['endp'])
+    V = o['lane_maps']['cls_offset_smooth'][0]
+    np.testing.assert_allclose(V, g['cls_offset_smooth'], rtol=0, atol=1e-4)
+    assert np.array_equal(V[:, :, 1], g['cls_offset_smooth'][:, :, 1]), 'vertex semantics must match exactly'
+    assert np.array_equal(np.stack(np.nonzero(o['lane_maps']['endp_by_cls'][0]), axis=1).reshape(-1, 2), g['endp_final'].reshape(-1, 2))
+
+
+def test_net_vs_oracle_batch2(dev, net, synth_sd):
+    """Seeded inputs not covered by a golden: HIP raw outputs vs the oracle at batch 2, 576^2 tiles."""
+    from oracle import net_ref
+    x = torch.from_numpy(synth.bev_batch([101, 102], 576))
+    with torch.no_grad():
+        fea, fea_up, bi_seg, endp = net_ref.fpn_forward(synth_sd, x)
+        mine = net.pcencoder({'proj': x.to(dev)})
+    for name, a, b in zip(('fea', 'fea_up', 'bi_seg', 'endp'), mine, (fea, fea_up, bi_seg, endp)):
+        _close(a, b, 1e-4, name)
+
+
+# ----------------------------------------------------------------------------------------------- raster / ingest
+def test_raster_vs_oracle_and_roundtrip(dev):
+    from lanemapping_amd import ops
+    from oracle import raster_ref
+    n = 1 << 20
+    pts = synth.las_points(33, n)
+    kw = dict(quat=(0.9238795, 0.0, 0.0, 0.3826834), trans=(3.0, -2.0, 0.5), bev_img_offset=(-20.0, -30.0),
+              img_reso=(0.05, 0.05), local_min_ele=-3.0, ele_reso=0.05)
+    # place the synthetic tile-frame points into the "LAS" frame with the reference's forward formula
+    ref_p = raster_ref.params(**kw)
+    q = np.array(kw['quat'], dtype=np.float64)
+    q /= np.linalg.norm(q)
+    w, x, y, z = q
+    R = np.array([[1 - 2 * (y * y + z * z), 2 * (x * y - z * w), 2 * (x * z + y * w)],
+                  [2 * (x * y + z * w), 1 - 2 * (x * x + z * z), 2 * (y * z - x * w)],
+                  [2 * (x * z - y * w), 2 * (y * z + x * w), 1 - 2 * (x * x + y * y)]])
+    local = pts[:, :3].astype(np.float64) + np.array([kw['bev_img_offset'][0], kw['bev_img_offset'][1], 0.0])
+    world = (local @ R.T + np.array(kw['trans'])).astype(np.float32)
+    rec = np.concatenate([world, pts[:, 3:4]], axis=1).astype(np.float32)
+    want = raster_ref.raster(rec, ref_p)
+    proj, u8 = ops.bev_raster(torch.from_numpy(rec).to(dev), ops.make_raster_params(**kw), want_u8=True)
+    assert np.array_equal(u8.cpu().numpy(), want), 'rasteriser must match the C oracle bit for bit'
+    assert torch.equal(proj.cpu(), torch.from_numpy(want.astype(np.float32) / np.float32(255.0)).permute(2, 0, 1))
+    # determinism (scatter-max is order independent)
+    proj2 = ops.bev_raster(torch.from_numpy(rec).to(dev), ops.make_raster_params(**kw))
+    assert torch.equal(proj, proj2)
+    # round trip through the reference's inverse transform: every occupied pixel maps back to within one
+    # pixel pitch / one elevation step of a point that fell into it
+    occ = np.argwhere(want.sum(2) > 0)
+    sel = occ[:: max(1, len(occ) // 200)]
+    rows = np.floor((pts[:, 0].astype(np.float64)) / 0.05 + 0.5).astype(int)
+    cols = np.floor((pts[:, 1].astype(np.float64)) / 0.05 + 0.5).astype(int)
+    for r, c in sel:
+        back = raster_ref.pixel_to_point(ref_p, r, c, want[r, c, 1])
+        m = (rows == r) & (cols == c)
+        assert m.any()
+        d = np.abs(world[m].astype(np.float64) - back)
+        assert d[:, :2].min(axis=0).max() <= 0.05 + 1e-3 and d[:, 2].min() <= 0.05 + 1e-3
+    # empty input -> empty tile
+    empty = ops.bev_raster(torch.zeros((0, 4), device=dev), ops.make_raster_params(**kw))
+    assert float(empty.abs().max()) == 0.0
+
+
+def test_tile_ingest(dev):
+    from lanemapping_amd import ops
+    u8 = synth.bev_tile_u8(5, 96)
+    rgba = np.concatenate([u8, np.full((96, 96, 1), 255, np.uint8)], axis=2)
+    out = ops.tile_ingest(torch.from_numpy(rgba[None]).to(dev))
+    assert torch.equal(out.cpu()[0], torch.from_numpy(synth.bev_tile(5, 96)))

@@ -1,0 +1,110 @@
+"""CPU: pin the oracle (oracle/) against golden vectors produced by the reference itself
+(tests/golden/make_golden.py).  These tests never touch the HIP library."""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+import cases
+from lanemapping_amd import synth
+from oracle import net_ref, decode_ref, postproc_ref
+
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden')
+
+
+def _t(d):
+    return {k: torch.from_numpy(np.asarray(v)) for k, v in d.items()}
+
+
+def test_g2_fpn_bitwise(golden, synth_sd):
+    g = golden('g2_fpn.npz')
+    x = torch.from_numpy(synth.bev_batch([int(s) for s in g['seeds']], int(g['size'])))
+    with torch.no_grad():
+        out = net_ref.fpn_forward(synth_sd, x)
+    for name, o in zip(('fea', 'fea_up', 'bi_seg', 'endp'), out):
+        np.testing.assert_allclose(o.numpy(), g[name], rtol=0, atol=1e-5, err_msg=name)
+
+
+def test_g3_vit(golden, synth_sd):
+    g = golden('g3_vit.npz')
+    with torch.no_grad():
+        y = net_ref.vit_forward(synth_sd, torch.from_numpy(cases.vit_input(int(g['input_seed']))))
+    np.testing.assert_allclose(y.numpy(), g['out'], rtol=0, atol=1e-5)
+
+
+def test_g4_head(golden, synth_sd):
+    g = golden('g4_head.npz')
+    x, x_up = cases.head_inputs(int(g['input_seed']))
+    with torch.no_grad():
+        out = net_ref.head_forward(synth_sd, torch.from_numpy(x), torch.from_numpy(x_up))
+    for k in ('proposal_conf', 'ext2', 'cls2', 'offset2', 'orient'):
+        np.testing.assert_allclose(out[k].numpy(), g[k], rtol=0, atol=1e-5, err_msg=k)
+
+
+def test_g5_decode(golden):
+    g = golden('g5_decode.npz')
+    raw = cases.decode_inputs(int(g['input_seed']), batch=int(g['batch']))
+    d = decode_ref.decode_column_proposals(raw)
+    np.testing.assert_array_equal(d['prop_v_ext'].numpy().astype(np.uint8), g['prop_v_ext'])
+    np.testing.assert_array_equal(d['orient'].numpy().astype(np.uint8), g['orient'])
+    np.testing.assert_array_equal(d['semantic_seg'].numpy().astype(np.uint8), g['semantic_seg'])
+    np.testing.assert_allclose(d['prop_conf'].numpy(), g['prop_conf'], atol=1e-6)
+    np.testing.assert_allclose(d['prop_cls_conf'].numpy(), g['prop_cls_conf'], atol=1e-6)
+    np.testing.assert_array_equal(d['cls_offset'].numpy(), g['cls_offset'])
+    np.testing.assert_allclose(d['bi_seg'].numpy()[:, 3::8, :], g['bi_seg_rows'], atol=1e-6)
+    for b in range(2):
+        pts = np.stack(np.nonzero(d['endp'][b].numpy()), axis=1)
+        np.testing.assert_array_equal(pts, g[f'endp{b}'])
+
+
+def test_g7_segmentor_decode(golden):
+    g = golden('g7_segmentor.npz')
+    raw = cases.decode_inputs(int(g['input_seed']), batch=1)
+    r = decode_ref.segmentor_decode(raw['semantic_seg'], raw['endp_est'], seg_thre=0.1)
+    np.testing.assert_array_equal(r['seg'].numpy().astype(np.uint8), g['seg'])
+    np.testing.assert_array_equal(np.stack(np.nonzero(r['endp'][0].numpy()), axis=1), g['endp'])
+
+
+@pytest.mark.parametrize('i', range(cases.NUM_POSTPROC_CASES))
+def test_g6_postproc(golden, i):
+    g = golden('g6_postproc.npz')
+    c = cases.postproc_case(i)
+    V, E, _ = postproc_ref.assemble_tile(c['prop_conf1'], c['prop_v_ext'].astype(np.float32), c['cls_offset'],
+                                         cases.expand_rows(c['bi_seg_rows']), cases.endp_map(c['endp_pts']))
+    np.testing.assert_array_equal(V, g[f'V{i}'])
+    np.testing.assert_array_equal(np.stack(np.nonzero(E), axis=1), g[f'E{i}'])
+
+
+def test_g9_json_records(golden):
+    g = golden('g6_postproc.npz')
+    with open(os.path.join(GOLDEN, 'g9_lanes.json')) as f:
+        ref = json.load(f)
+    mine = postproc_ref.lanes_to_json_records(g['V0'])
+    assert len(mine) == len(ref)
+    for a, b in zip(mine, ref):
+        assert a['seq_len'] == b['seq_len']
+        np.testing.assert_array_equal(np.array(a['seq']), np.array(b['seq']))
+        np.testing.assert_array_equal(np.array(a['init_vertex']), np.array(b['init_vertex']))
+        np.testing.assert_array_equal(np.array(a['end_vertex']), np.array(b['end_vertex']))
+
+
+def test_g10_end_to_end(golden, synth_sd):
+    """Whole oracle chain on one 1152^2 synthetic tile vs the reference's own end-to-end run."""
+    g = golden('g10_e2e.npz')
+    x = torch.from_numpy(synth.bev_batch([int(g['tile_seed'])], 1152))
+    with torch.no_grad():
+        raw = net_ref.detector_forward(synth_sd, x)
+    np.testing.assert_allclose(raw['cls2'].numpy(), g['cls2'], atol=2e-5)
+    np.testing.assert_allclose(raw['ext2'].numpy(), g['ext2'], atol=2e-5)
+    d = decode_ref.decode_column_proposals({k: v.numpy() for k, v in raw.items()})
+    np.testing.assert_array_equal(d['prop_v_ext'].numpy().astype(np.uint8), g['prop_v_ext'])
+    np.testing.assert_array_equal(d['orient'].numpy().astype(np.uint8), g['orient'])
+    np.testing.assert_array_equal(d['semantic_seg'].numpy().astype(np.uint8), g['semantic_seg'])
+    np.testing.assert_allclose(d['cls_offset'].numpy(), g['cls_offset'], atol=1e-4)
+    np.testing.assert_array_equal(np.stack(np.nonzero(d['endp'][0].numpy()), axis=1), g['endp'])
+    V, E, _ = postproc_ref.assemble_tile(d['prop_conf'][0, :, 1].numpy(), d['prop_v_ext'][0].numpy(),
+                                         d['cls_offset'][0].numpy(), d['bi_seg'][0].numpy(), d['endp'][0].numpy())
+    np.testing.assert_allclose(V, g['cls_offset_smooth'], atol=1e-4)
+    np.testing.assert_array_equal(np.stack(np.nonzero(E), axis=1).reshape(-1, 2), g['endp_final'].reshape(-1, 2))
