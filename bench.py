@@ -26,14 +26,27 @@ MFMA_F32_PEAK_TFLOPS = 157.3      # /opt/skills/guides/MI355X_MICROARCH.md: dens
 BATCH = 8
 
 
-def cpu_baseline(sample_tiles):
+def usable_cores():
+    """Cores this process may actually use: affinity mask, capped by the cgroup CPU quota if there is one."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, 'sched_getaffinity') else (os.cpu_count() or 1)
+    try:
+        with open('/sys/fs/cgroup/cpu.max') as f:
+            quota, period = f.read().split()
+        if quota != 'max':
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except (OSError, ValueError):
+        pass
+    return max(1, n)
+
+
+def cpu_baseline(budget_s=25.0, max_threads=64):
     """Oracle ("port" of the reference's CPU path: torch-CPU fp32 net + NumPy decode/post-proc) timed on this
-    host's cores on a bounded sample of the same workload."""
+    host's cores on a bounded sample of the same workload (about `budget_s` seconds of CPU work)."""
     sys.path.insert(0, os.path.join(ROOT, 'tests', 'golden'))
     from lanemapping_amd import synth
     from lanemapping_amd.boundary import build_net_from_config
     from oracle import net_ref, decode_ref, postproc_ref
-    cores = os.cpu_count() or 1
+    cores = min(usable_cores(), max_threads)
     torch.set_num_threads(cores)
     net = build_net_from_config('Proj_polyline_fpn_vit_vertex_2', device='cpu')
     synth.fill_module_(net, 2021)
@@ -41,20 +54,22 @@ def cpu_baseline(sample_tiles):
 
     def one(seed):
         x = torch.from_numpy(synth.bev_batch([seed], 1152))
+        t = time.perf_counter()
         with torch.no_grad():
             raw = net_ref.detector_forward(sd, x)
         d = decode_ref.decode_column_proposals({k: v.numpy() for k, v in raw.items()})
         postproc_ref.assemble_tile(d['prop_conf'][0, :, 1].numpy(), d['prop_v_ext'][0].numpy(), d['cls_offset'][0].numpy(),
                                    d['bi_seg'][0].numpy(), d['endp'][0].numpy())
+        return time.perf_counter() - t
 
-    one(2021)                                   # warm-up
-    t0 = time.perf_counter()
-    for i in range(sample_tiles):
-        one(2022 + i)
-    dt = time.perf_counter() - t0
-    return {'value': sample_tiles / dt, 'unit': 'tiles/s', 'cores': cores, 'kind': 'port',
-            'sample': f'{sample_tiles} synthetic 1152x1152 tiles, batch 1, oracle net_ref+decode_ref+postproc_ref, '
-                      f'torch {torch.get_num_threads()} threads, after 1 warm-up tile'}
+    warm = one(2021)                            # warm-up tile (also sizes the sample)
+    n = int(max(1, min(8, budget_s // max(warm, 1e-3))))
+    times = [one(2022 + i) for i in range(n)] if warm < budget_s else [warm]
+    dt = sum(times)
+    return {'value': len(times) / dt, 'unit': 'tiles/s', 'cores': cores, 'kind': 'port',
+            'sample': f'{len(times)} synthetic 1152x1152 tiles, batch 1, oracle net_ref+decode_ref+postproc_ref (tile '
+                      f'generation excluded), torch {torch.get_num_threads()} threads of {os.cpu_count()} logical CPUs, '
+                      f'after 1 warm-up tile ({warm:.1f} s)'}
 
 
 def main():
@@ -62,9 +77,10 @@ def main():
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=10)
     ap.add_argument('--warmup', type=int, default=3)
-    ap.add_argument('--cpu-sample-tiles', type=int, default=3)
+    ap.add_argument('--cpu-budget-s', type=float, default=25.0)
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--host-threads', type=int, default=8)
+    ap.add_argument('--no-roofline-events', action='store_true', help='skip the per-launch HIP events')
     args = ap.parse_args()
 
     world = int(os.environ.get('WORLD_SIZE', '1'))
@@ -164,7 +180,7 @@ def main():
     }
     if rank == 0:
         if world == 1 and not args.no_cpu_baseline:
-            result['cpu_baseline'] = cpu_baseline(args.cpu_sample_tiles)
+            result['cpu_baseline'] = cpu_baseline(args.cpu_budget_s)
         else:
             result['cpu_baseline'] = None
         print(json.dumps(result), flush=True)

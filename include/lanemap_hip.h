@@ -1,0 +1,126 @@
+/* lanemap_hip.h — C ABI of liblanemap_hip.so (MI355X / gfx950 only).
+ *
+ * Drop-in boundary for the inference hot path of WHU-USI3DV/LaneMapping.  The reference is pure Python
+ * (torch.nn modules built through a registry); what a maintainer binds from the reference side
+ * is therefore a ctypes stub per torch.nn call site.  Every entry point:
+ *   - takes plain pointers + sizes (device pointers unless the name says host), no torch types;
+ *   - launches on the hipStream_t passed as `stream` (NULL = default stream) and returns immediately;
+ *   - returns 0 on success, non-zero on error (lm_last_error() gives the message; nothing is thrown);
+ *   - borrows its inputs (const), never frees or allocates caller-visible memory.
+ * Activations are fp32, NHWC ("pixel-major rows", channel stride 1); `ld*` = floats between consecutive pixels.
+ * Citations are file:line in the reference (relative to its repo root).
+ */
+#ifndef LANEMAP_HIP_H
+#define LANEMAP_HIP_H
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+enum { LM_OK = 0, LM_ERR_ARG = 1, LM_ERR_HIP = 2, LM_ERR_NO_DEVICE = 3 };
+enum { LM_ACT_NONE = 0, LM_ACT_RELU = 1, LM_ACT_GELU = 2 };
+
+int lm_abi_version(void);
+const char* lm_last_error(void);          /* thread-local, valid until the next failing call */
+int lm_device_count(void);
+
+/* ---- matrix-core convolution / GEMM -------------------------------------------------------------------------
+ * y[m,n] = act((sum_{tap,c} x[pix(m,tap),c] * wp[tap][n][c]) * scale[n] + shift[n] + res[m % res_rows, n])
+ * Replaces every nn.Conv2d with Cin%32==0 of FPNWrapper (baseline/models/pcencoder/postprojector.py:463-511,
+ * 563-655; BasicBlock :299-338 with BN folded into scale/shift), every nn.Linear of VitSegNet
+ * (baseline/models/backbone/vitsegnet.py:32-35,51-56,165; patch embedding = 8x8 stride-8 case) and the first
+ * Conv1d+BN1d of ext2/cls2/offset2 (baseline/models/heads/polyline_fpn_vit_vertex_2.py:206-228).
+ * wp: [KH*KW][CoutP][Cin], CoutP = Cout rounded up to 128 (zero rows).  scale/shift/res may be NULL.
+ * res_rows == 0: residual has one row per output pixel; > 0: row index is m % res_rows (positional embedding). */
+int lm_conv2d_nhwc_mfma_f32(void* stream, const float* x, int ldx, const float* wp, int CoutP,
+                            const float* scale, const float* shift, const float* res, int ldr, int res_rows,
+                            float* y, int ldy, int B, int H, int W, int Cin, int Cout, int KH, int KW,
+                            int stride, int pad_h, int pad_w, int dil, int act);
+
+/* ---- thin layers ---------------------------------------------------------------------------------------------
+ * stem: relu(bn1(conv1(x))) for planar x [B,3,H,W] -> NHWC [B,H/2,W/2,64]; w_k64 = [7][7][3][64]
+ * (postprojector.py:458-460,566).  maxpool: 3x3 stride 2 pad 1 (:461,567).
+ * small: direct conv for Cout <= 16 (feature_layer/output_layer_* :509-511,628-651; head_common_layers,
+ * orient, bi_seg_proposal heads/polyline_fpn_vit_vertex_2.py:183-189,232-237,249); w_tc16 = [KH*KW][Cin][16];
+ * y = act(conv(pre_relu ? relu(x) : x) * scale + shift). */
+int lm_stem_conv7x7_bn_relu(void* stream, const float* x_chw, const float* w_k64, const float* scale,
+                            const float* shift, float* y_nhwc, int B, int H, int W);
+int lm_maxpool3x3s2_nhwc(void* stream, const float* x, float* y, int B, int H, int W, int C);
+int lm_conv2d_nhwc_small(void* stream, const float* x, int ldx, const float* w_tc16, const float* scale,
+                         const float* shift, float* y, int ldy, int B, int H, int W, int Cin, int Cout,
+                         int KH, int KW, int stride, int pad_h, int pad_w, int pre_relu, int act);
+
+/* ---- normalisation / resampling (postprojector.py:512-515,541-561,608-651; vitsegnet.py:20-26,180) ----------
+ * gn_stats: per-(b,c) mean, rstd of GroupNorm(C,C) -> stats [B][C][2]; workspace from lm_gn_stats_workspace_bytes.
+ * gn_relu_upsample: y (= | +=) bilinear_align_corners(relu(gn(x))) to Ho x Wo.
+ * upsample_bilinear_*: F.interpolate(mode='bilinear', align_corners=True); `add` (optional) is summed in. */
+int lm_gn_stats(void* stream, const float* x, double* workspace, float* stats, int B, int HW, int C, float eps);
+long lm_gn_stats_workspace_bytes(int B, int HW, int C);
+int lm_gn_relu_upsample(void* stream, const float* x, const float* stats, const float* gamma, const float* beta,
+                        float* y, int B, int Hi, int Wi, int Ho, int Wo, int C, int accumulate);
+int lm_upsample_bilinear_nhwc(void* stream, const float* x, int ldx, const float* add, int lda, float* y, int ldy,
+                              int B, int Hi, int Wi, int Ho, int Wo, int C);
+int lm_upsample_bilinear_to_chw(void* stream, const float* x, int ldx, float* y_chw, int B, int Hi, int Wi,
+                                int Ho, int Wo, int C);
+int lm_layernorm_rows(void* stream, const float* x, const float* gamma, const float* beta, float* y,
+                      long rows, int D, float eps);
+int lm_unpatchify(void* stream, const float* tokens, float* y_nhwc, int B, int G, int P, int C);
+
+/* ---- attention core: softmax(q k^T * scale) v per (batch, head); qkv = [B*N][3*heads*64] (vitsegnet.py:58-68) */
+int lm_attention_f32(void* stream, const float* qkv, float* out, int B, int N, int heads, int dim_head, float scale);
+
+/* ---- column-proposal head (heads/polyline_fpn_vit_vertex_2.py:390-421) ----------------------------------------
+ * tokens: tok[(b,p,h), c*10+w] = avg_pool8(up(seg window p))[h,w] * row_fea_pad[b,c,h,2p+w]   (:392-405)
+ * stage2: second Conv1d of ext2/cls2/offset2 (:210,218,226); proposal_conf: Linear(23040 -> 2) (:200-204) */
+int lm_head_tokens(void* stream, const float* seg, const float* row_nhwc16, float* tok, float seg_bias,
+                   int B, int P, int Hr, int Wr, int prop_width, int half_buff);
+int lm_head_stage2(void* stream, const float* hid, int ldh, int D, const float* w2, const float* b2,
+                   float* ext2, float* cls2, float* off2, long M);
+int lm_head_proposal_conf(void* stream, const float* tok, const float* wt, const float* bias, float* conf,
+                          int BP, int L);
+
+/* ---- decode (heads/polyline_fpn_vit_vertex_2.py:602-759; postprojector.py:115-183) ---------------------------
+ * proposals: :610, :694-697, :701-702, :726-738.  orient: :615.  semantic: :627-632 (raw_mode=1: :122-127).
+ * endp_topk: sigmoid of logits cropped by `clip` px, K best in (score desc, flat index asc) order (:647-668);
+ * out_status[b] = 1 if more tied scores than the candidate buffer holds. */
+int lm_decode_proposals(void* stream, const float* pconf, const float* ext2, const float* cls2, const float* off2,
+                        float* prop_conf, float* v_ext, float* cls_conf, int* cls_idx, double* cls_offset,
+                        int B, int P, int R, float exist_thre, int prop_width, int half_buff);
+int lm_decode_orient(void* stream, const float* x_nhwc, int ldx, int C, unsigned char* y, long pixels);
+int lm_decode_semantic(void* stream, const float* logit_chw3, unsigned char* sem, float* biseg, float* rows,
+                       int B, int H, int W, float thre, int raw_mode);
+long lm_endp_topk_workspace_bytes(int B);
+int lm_endp_topk(void* stream, const float* endp_logit, void* workspace, int* out_idx, float* out_score,
+                 int* out_status, int B, int H, int W, int clip, int K);
+
+/* ---- LAS -> BEV rasteriser and tile ingest (build-defined, parity unpinned: the reference has no rasteriser;
+ * pinned pieces: datasets/laserlane_proposals.py:85-98,618-636; utils/coor_img2pc.py:127-183;
+ * utils/io_utils.py:125-150) */
+typedef struct {
+    float quat[4];            /* [w,x,y,z] = las_rotation_trans_quan[3:7] */
+    float trans[3];           /* las_rotation_trans_quan[0:3] */
+    float bev_img_offset[2];
+    float img_reso[2];
+    float local_min_ele;
+    float ele_reso;
+    float inten_lo, inten_hi; /* 800, 33000 */
+} LmRasterParams;
+int lm_bev_raster(void* stream, const float* points_xyzi, long n_points, const LmRasterParams* params /*host*/,
+                  unsigned* acc_workspace /*H*W u32*/, float* out_chw, unsigned char* out_hwc_u8, int H, int W);
+int lm_tile_ingest_u8(void* stream, const unsigned char* src_hwc, float* dst_chw, int B, int H, int W, int C);
+
+/* ---- host-side tail (HOST pointers; no GPU is touched) --------------------------------------------------------
+ * endp_cluster: heads/polyline_fpn_vit_vertex_2.py:661-688 + :903-924.
+ * polyline_assemble: :805-861 + baseline/utils/polyline_utils.py (whole file) + :1091-1115.
+ * raster_polylines: polyline_utils.py:610-638 (own Bresenham instead of cv2.line). */
+int lm_endp_cluster(const int* topk_idx, int n_avail, int Wc, int clip, int k0, int k_step, int k_max, int radius,
+                    int min_clusters, int* out_hw, int max_out, int* n_out, int* k_used);
+int lm_polyline_assemble(const float* prop_conf, const float* prop_v_ext, const double* cls_offset,
+                         const float* bi_seg_rows, const int* endp_hw, int n_endp, int P, int R, float obj_thre,
+                         int min_vertices, double* out_lanes, int* endp_keep);
+int lm_raster_polylines(const double* lanes, int P, int R, unsigned char* out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* LANEMAP_HIP_H */

@@ -179,6 +179,7 @@ def g10(cfg, net):
     orig = net.heads.get_exist_coor_endp_dict
 
     def spy(out):
+        cap['sem_logits'] = out['semantic_seg'].detach().clone()
         d = orig(out)
         cap['dec'] = {k: (v.detach().clone() if torch.is_tensor(v) else v) for k, v in d.items()}
         return d
@@ -189,10 +190,21 @@ def g10(cfg, net):
     raw, dec = cap['raw'], cap['dec']
     V = o['lane_maps']['cls_offset_smooth'][0]
     top2 = torch.topk(raw['cls2'], 2, dim=-1).values
+    # decision margins of the thresholded outputs, so a consumer can tell an fp32-noise flip from a bug:
+    # flat indices of pixels / rows whose class decision sits within 1e-4 of a tie or of the threshold
+    sm = cap['sem_logits'].softmax(1)[0]
+    s1, s2 = sm[1], sm[2]
+    sem_margin = torch.minimum((s1 - s2).abs(), (torch.maximum(s1, s2) - cfg.coor_thre).abs())
+    e = raw['ext2'].softmax(3)[0]
+    ext_margin = torch.minimum((e[..., 1] - e[..., 2]).abs(), (torch.maximum(e[..., 1], e[..., 2]) - cfg.exist_thre).abs())
+    otop = torch.topk(raw['orient'], 2, dim=1).values[0]
     save('g10_e2e.npz', tile_seed=2021, weight_seed=2021,
          proposal_conf=raw['proposal_conf'].numpy(), ext2=raw['ext2'].numpy(), cls2=raw['cls2'].numpy(),
          offset2=raw['offset2'].numpy(), orient_logits=raw['orient'].numpy(),
          cls2_margin=(top2[..., 0] - top2[..., 1]).numpy(),
+         sem_lowmargin=torch.nonzero(sem_margin.flatten() < 1e-4).flatten().numpy().astype(np.int64),
+         ext_lowmargin=torch.nonzero(ext_margin.flatten() < 1e-4).flatten().numpy().astype(np.int64),
+         orient_lowmargin=torch.nonzero((otop[0] - otop[1]).flatten() < 1e-4).flatten().numpy().astype(np.int64),
          prop_conf=dec['prop_conf'].numpy(), prop_v_ext=dec['prop_v_ext'].numpy().astype(np.uint8),
          cls_offset=dec['cls_offset'].numpy(), orient=dec['orient'].numpy().astype(np.uint8),
          semantic_seg=dec['semantic_seg'].numpy().astype(np.uint8),

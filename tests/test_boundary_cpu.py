@@ -1,0 +1,159 @@
+"""CPU: the drop-in boundary (registries, config loader, state-dict layout), the C-ABI library surface, and the
+host-side C++ tail (endpoint clustering + polyline assembly) against the reference-generated goldens."""
+import ctypes
+import os
+import re
+
+import numpy as np
+import pytest
+import torch
+
+import cases
+from lanemapping_amd import hostpost, synth
+from lanemapping_amd._lib import lib, SIGNATURES, LanemapHipError
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_library_exports_every_declared_symbol():
+    header = open(os.path.join(ROOT, 'include', 'lanemap_hip.h')).read()
+    declared = set(re.findall(r'\b(lm_[a-z0-9_]+)\s*\(', header))
+    L = lib()
+    assert declared == set(SIGNATURES), (declared ^ set(SIGNATURES))
+    for name in declared:
+        assert hasattr(L, name), name
+    assert L.lm_abi_version() == 1
+
+
+def test_c_abi_reports_errors_without_a_gpu():
+    L = lib()
+    rc = L.lm_conv2d_nhwc_mfma_f32(None, None, 64, None, 128, None, None, None, 0, 0, None, 64,
+                                   1, 8, 8, 64, 64, 3, 3, 1, 1, 1, 1, 0)
+    assert rc == 1 and b'null pointer' in L.lm_last_error()
+
+
+def test_registry_semantics():
+    from lanemapping_amd.registry import Registry, build_from_cfg, NET, HEADS
+    from lanemapping_amd import boundary  # noqa: F401
+    assert {'Detector1stage', 'Segmentor'} <= set(NET.module_dict)
+    assert 'ColumnProposal2' in HEADS.module_dict
+    r = Registry('x')
+
+    @r.register_module
+    class A:
+        def __init__(self, a=1, cfg=None):
+            self.a, self.cfg = a, cfg
+    with pytest.raises(KeyError):
+        r.register_module(A)
+    with pytest.raises(TypeError):
+        r.register_module(3)
+    obj = build_from_cfg({'type': 'A', 'a': 5}, r, default_args={'cfg': 'c'})
+    assert (obj.a, obj.cfg) == (5, 'c')
+    with pytest.raises(KeyError):
+        build_from_cfg({'type': 'Missing'}, r)
+    with pytest.raises(TypeError):
+        build_from_cfg({'type': 3}, r)
+
+
+def test_config_loader(tmp_path):
+    from lanemapping_amd.boundary import load_config
+    cfg = load_config('Proj_polyline_fpn_vit_vertex_2')
+    assert cfg.heads.type == 'ColumnProposal2' and cfg.heads.num_prop == 72 and cfg.backbone.depth == 3
+    assert cfg.pcencoder.pretrained is False and cfg.vit_seg is True
+    with pytest.raises(AttributeError):
+        cfg.no_such_key
+    p = tmp_path / 'c.py'
+    p.write_text("import os\nnet = dict(type='Segmentor')\npcencoder = dict(type='PostProjector2', pretrained=True)\nseg_thre = 0.3\n")
+    c2 = load_config(str(p))
+    assert c2.seg_thre == 0.3 and c2.is_gt_avai is False and 'os' not in c2 and c2.pcencoder.pretrained is False
+
+
+def test_state_dict_layout_matches_reference_checkpoints(synth_sd, tmp_path):
+    """600 entries for config 2, incl. dead parameters; DataParallel 'module.' prefix accepted."""
+    from lanemapping_amd.boundary import build_net_from_config, load_reference_checkpoint
+    assert len(synth_sd) == 600
+    for k, shape in {'conv1.weight': (144, 144, 3, 3), 'pcencoder.fpn.model_buttomup.layer3.5.bn2.running_var': (256,),
+                     'pcencoder.fpn.layer3.0.downsample.0.weight': (256, 128, 1, 1), 'backbone.pos_embedding': (1, 324, 512),
+                     'backbone.transformer.layers.2.1.fn.net.3.weight': (512, 2048), 'heads.emb_71': (512,),
+                     'heads.proposal_confidence.1.weight': (2, 23040), 'heads.endpoint.0.weight': (4, 17, 3, 3),
+                     'heads.generate_line_proposal.0.layers.1.2.weight': (16, 8, 3, 3)}.items():
+        assert tuple(synth_sd[k].shape) == shape, k
+    path = tmp_path / 'best.pth'
+    torch.save({'net': {'module.' + k: v for k, v in synth_sd.items()}, 'epoch': 3}, path)
+    net = build_net_from_config('Proj_polyline_fpn_vit_vertex_2', device='cpu')
+    res = load_reference_checkpoint(net, str(path), strict=True)
+    assert not res.missing_keys and not res.unexpected_keys
+    assert torch.equal(net.state_dict()['heads.ext2.0.weight'], synth_sd['heads.ext2.0.weight'])
+
+
+def test_product_path_fails_loudly_without_gpu():
+    from lanemapping_amd.boundary import build_net_from_config
+    net = build_net_from_config('Proj_FPN_Seg', device='cpu')
+    with pytest.raises((LanemapHipError, RuntimeError, AssertionError)):
+        net({'proj': torch.zeros(1, 3, 64, 64)})
+
+
+@pytest.mark.parametrize('i', range(cases.NUM_POSTPROC_CASES))
+def test_cpp_polyline_assembly_vs_reference_golden(golden, i):
+    g = golden('g6_postproc.npz')
+    c = cases.postproc_case(i)
+    pc = np.stack([1 - c['prop_conf1'], c['prop_conf1']], 1).astype(np.float32)
+    V, E = hostpost.assemble_polylines(pc, c['prop_v_ext'].astype(np.float32), c['cls_offset'], c['bi_seg_rows'], c['endp_pts'])
+    E = E[np.lexsort((E[:, 1], E[:, 0]))] if len(E) else E.reshape(0, 2)
+    assert np.array_equal(V, g[f'V{i}'])
+    assert np.array_equal(E, g[f'E{i}'].reshape(-1, 2))
+
+
+def test_cpp_assembly_on_reference_e2e_decode(golden):
+    g = golden('g10_e2e.npz')
+    V, E = hostpost.assemble_polylines(g['prop_conf'][0], g['prop_v_ext'][0].astype(np.float32), g['cls_offset'][0],
+                                       g['bi_seg_rows'][0], g['endp'])
+    assert np.array_equal(V, g['cls_offset_smooth'])
+    assert np.array_equal(E[np.lexsort((E[:, 1], E[:, 0]))], g['endp_final'])
+
+
+def test_postproc_is_chaotic_on_g10(golden):
+    """Documents why end-to-end vertex parity is pinned stage-wise: 1e-7 of input noise already changes the
+    polyline set on the random-weight tile (the reference's algorithm, not an implementation artefact)."""
+    g = golden('g10_e2e.npz')
+    rng = np.random.default_rng(0)
+    V, _ = hostpost.assemble_polylines(g['prop_conf'][0], g['prop_v_ext'][0].astype(np.float32),
+                                       g['cls_offset'][0] + 1e-7 * rng.standard_normal(g['cls_offset'][0].shape),
+                                       g['bi_seg_rows'][0], g['endp'])
+    assert np.abs(V - g['cls_offset_smooth']).max() > 1.0
+
+
+def test_cpp_endpoint_clustering_vs_oracle(golden):
+    from oracle import decode_ref
+    g = golden('g5_decode.npz')
+    raw = cases.decode_inputs(int(g['input_seed']), batch=2)
+    for b in range(2):
+        _, K, order = decode_ref.select_endpoints(raw['endp_est'][b, 0], k0=240)
+        full = decode_ref.select_endpoints(raw['endp_est'][b, 0], k0=240)[0]
+        sig = torch.sigmoid(torch.from_numpy(raw['endp_est'][b, 0, 20:-20, 20:-20])).numpy().reshape(-1)
+        top = np.lexsort((np.arange(sig.size), -sig.astype(np.float64)))[:512].astype(np.int32)
+        pts, k_used = hostpost.cluster_endpoints(top)
+        assert k_used == K
+        assert np.array_equal(pts[np.lexsort((pts[:, 1], pts[:, 0]))], g[f'endp{b}'])
+        assert np.array_equal(np.stack(np.nonzero(full), 1), g[f'endp{b}'])
+    with pytest.raises(LanemapHipError):
+        hostpost.cluster_endpoints(np.arange(10, dtype=np.int32))       # fewer scores than K=240 -> loud error
+
+
+def test_semantic_raster_vs_oracle(golden):
+    from oracle import postproc_ref
+    g = golden('g6_postproc.npz')
+    for i in (0, 2, 12):
+        assert np.array_equal(hostpost.raster_semantic_map(g[f'V{i}']), postproc_ref.raster_semantic_map(g[f'V{i}']))
+
+
+def test_empty_and_degenerate_tiles():
+    z = np.zeros((72, 144), dtype=np.float32)
+    V, E = hostpost.assemble_polylines(np.zeros((72, 2), np.float32), z, z.astype(np.float64), np.zeros((144, 1152), np.float32),
+                                       np.zeros((0, 2), np.int32))
+    assert (V[:, :, 0] == -1).all() and (V[:, :, 1] == 0).all() and len(E) == 0
+    # every proposal firing on every row at the same column: must terminate and give a single line
+    pc = np.tile(np.array([[0.1, 0.9]], np.float32), (72, 1))
+    V, _ = hostpost.assemble_polylines(pc, np.ones((72, 144), np.float32), np.full((72, 144), 70.0), np.ones((144, 1152), np.float32),
+                                       np.array([[600, 560]], np.int32))
+    assert ((V[:, :, 0] > 0).sum(1) >= 2).sum() == 1
