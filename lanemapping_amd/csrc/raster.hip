@@ -104,7 +104,7 @@ __global__ __launch_bounds__(256) void ingest_kernel(const unsigned char* __rest
 
 LM_API int lm_bev_raster(void* stream, const float* points_xyzi, long n_points, const LmRasterParams* params,
                          unsigned* acc_workspace, float* out_chw, unsigned char* out_hwc_u8, int H, int W) {
-    LM_REQUIRE(points_xyzi && params && acc_workspace && (out_chw || out_hwc_u8), "bev_raster: null pointer");
+    LM_REQUIRE((points_xyzi || n_points == 0) && params && acc_workspace && (out_chw || out_hwc_u8), "bev_raster: null pointer");
     LM_REQUIRE(n_points >= 0 && H > 0 && W > 0, "bev_raster: bad sizes");
     LM_REQUIRE(params->img_reso[0] > 0 && params->img_reso[1] > 0 && params->ele_reso > 0, "bev_raster: bad resolution");
     hipStream_t s = (hipStream_t)stream;
