@@ -105,8 +105,12 @@ typedef struct {
     float ele_reso;
     float inten_lo, inten_hi; /* 800, 33000 */
 } LmRasterParams;
-int lm_bev_raster(void* stream, const float* points_xyzi, long n_points, const LmRasterParams* params /*host*/,
-                  unsigned* acc_workspace /*H*W u32*/, float* out_chw, unsigned char* out_hwc_u8, int H, int W);
+/* points: device [sum N][4] f32 {x,y,z,raw intensity}; tile_offsets: HOST [B+1] point index of each tile's first
+ * record; params: HOST [B]; out_chw [B][3][H][W] f32 (= u8/255), out_hwc_u8 [B][H][W][3] (either may be NULL). */
+long lm_bev_raster_workspace_bytes(int B, long max_points_per_tile, int H, int W);
+int lm_bev_raster_batch(void* stream, const float* points_xyzi, const long* tile_offsets, const LmRasterParams* params,
+                        int B, void* workspace, long workspace_bytes, float* out_chw, unsigned char* out_hwc_u8,
+                        int H, int W);
 int lm_tile_ingest_u8(void* stream, const unsigned char* src_hwc, float* dst_chw, int B, int H, int W, int C);
 
 /* ---- host-side tail (HOST pointers; no GPU is touched) --------------------------------------------------------

@@ -7,19 +7,33 @@
 //     [800, 33000] then (i-800)/33000;
 //   * the INVERSE geometry, image -> point cloud (baseline/utils/coor_img2pc.py:127-183):
 //     X = row*img_reso[0] + bev_img_offset[0], Y = col*img_reso[1] + bev_img_offset[1],
-//     Z = G*ele_reso + local_min_ele, then rotate by quaternion [w,x,y,z], + translation (+ las_read_offset);
+//     Z = G*ele_reso + local_min_ele, then rotate by quaternion [w,x,y,z] (q v q* / |q|), + translation;
 //   * the tile contract of `load_img` (laserlane_proposals.py:85-98): u8 HWC -> f32 CHW / 255, and
 //     "pixel empty <=> R+G+B < 1" (coor_img2pc.py:78,106).
 // Rule implemented here (scatter-max, order independent => deterministic):
-//   v = R(q)^-1 (p - t);  row = floor((v.x-off0)/reso0 + .5), col likewise;  I = round(255*norm_int) in 1..255;
-//   G = clamp(round((v.z-min_ele)/ele_reso), 0, 255);  pixel keeps max over its points of key = I<<8 | G,
-//   i.e. R = B = brightest return, G = its elevation.  Untouched pixels stay 0 (empty).
+//   v = M (p - t) with M = R(q)^T / |q| (the exact inverse of the reference's rotation), evaluated in fp32 as
+//   (M0*dx + M1*dy) + M2*dz;  row = floor((v.x-off0)/reso0 + .5), col likewise;  I = round(255*(clip(i)-lo)/hi)
+//   in 1..255;  G = clamp(round((v.z-min_ele)/ele_reso), 0, 255);  a pixel keeps the max over its points of
+//   key = I<<8 | G, i.e. R = B = brightest return, G = its elevation.  Untouched pixels stay 0 (empty).
 //
-// Kernel: one coalesced 16-byte read per point, one 4-byte atomicMax into a 1152x1152 u32 accumulation
-// image (5.3 MB: L2 / Infinity-Cache resident), then a finalise pass writing the fp32 CHW tile.
+// Kernel design (HBM-bound; points arrive in acquisition order, i.e. spatially unsorted, so a workgroup cannot
+// own a pixel region directly; one device-scope atomicMax per point (v0) ran at 0.45 TB/s):
+//   pass 1  partition: every workgroup streams 8192 points with coalesced 16-byte non-temporal loads (8 in flight per
+//           lane), turns each into a 4-byte record {pixel-in-band:16 | I:8 | G:8}, counting-sorts the records by 16-row
+//           band in LDS (rank = LDS atomic add on 8x replicated counters) and writes each band's run, padded to 16 bytes,
+//           with aligned dwordx4 stores into its own static slot [tile][band][workgroup][8192] plus a count.
+//           No global atomics, no memset, no inter-workgroup communication.
+//   pass 2  one 1024-thread workgroup per (tile, band): the band's 16 x W u32 image lives in LDS (73.7 KB); the band's
+//           runs are read 16 lanes per run and applied with LDS atomic max, then the band is written once as fp32 CHW
+//           (+ u8 HWC).
+// HBM traffic per tile = 16 N (points) + 4 N (records out) + 4 N (records in) + 3 H W 4 = 1.4x the algorithmic bytes
+// (16 N + 3 H W 4): the two-pass ceiling is ~0.79 * 8 TB/s / 1.4 = 56 % of peak.
 #include "common.h"
 
+#include <cmath>
+
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 
 struct LmRasterParams {      // mirrors the reference's per-tile parameter file (utils/io_utils.py:125-150)
     float quat[4];           // las_rotation_trans_quan[3:7] = [w,x,y,z]
@@ -33,57 +47,202 @@ struct LmRasterParams {      // mirrors the reference's per-tile parameter file 
 
 namespace {
 
-__device__ __forceinline__ void quat_mul(const float a[4], const float b[4], float o[4]) {
-    o[0] = a[0] * b[0] - a[1] * b[1] - a[2] * b[2] - a[3] * b[3];
-    o[1] = a[0] * b[1] + a[1] * b[0] + a[2] * b[3] - a[3] * b[2];
-    o[2] = a[0] * b[2] - a[1] * b[3] + a[2] * b[0] + a[3] * b[1];
-    o[3] = a[0] * b[3] + a[1] * b[2] - a[2] * b[1] + a[3] * b[0];
+constexpr int BAND_ROWS = 16;
+constexpr int CHUNK = 8192;            // points per pass-1 workgroup = record capacity of one (tile, band, workgroup) slot
+constexpr int PER_THREAD = CHUNK / 256;
+constexpr int MAX_BANDS = 96;             // H <= 1520; keeps pass-1 LDS at 39.5 KB = 4 workgroups per CU
+constexpr int MAX_TILES = 16;          // tiles per launch (kernel-argument block)
+constexpr int REP = 8;                 // replication of the LDS rank counters (fewer same-address collisions)
+
+struct TileXf {                        // derived per-tile constants (host, double -> float)
+    float m[9], t[3], off[2], irow, icol, min_ele, iele, lo, hi, iscale;
+    long start, count;                 // point range of the tile in the concatenated buffer
+};
+struct BatchArgs {
+    TileXf tile[MAX_TILES];
+};
+
+__device__ __forceinline__ bool point_record(const f32x4 p, const TileXf& X, int H, int W, int& band, unsigned& rec) {
+    const float dx = p[0] - X.t[0], dy = p[1] - X.t[1], dz = p[2] - X.t[2];
+    const float vx = (X.m[0] * dx + X.m[1] * dy) + X.m[2] * dz;
+    const float vy = (X.m[3] * dx + X.m[4] * dy) + X.m[5] * dz;
+    const float vz = (X.m[6] * dx + X.m[7] * dy) + X.m[8] * dz;
+    const int row = (int)floorf((vx - X.off[0]) * X.irow + 0.5f);
+    const int col = (int)floorf((vy - X.off[1]) * X.icol + 0.5f);
+    if ((unsigned)row >= (unsigned)H || (unsigned)col >= (unsigned)W) return false;
+    const float it = fminf(fmaxf(p[3], X.lo), X.hi) - X.lo;
+    int I = (int)floorf(it * X.iscale + 0.5f);
+    I = I < 1 ? 1 : (I > 255 ? 255 : I);
+    int G = (int)floorf((vz - X.min_ele) * X.iele + 0.5f);
+    G = G < 0 ? 0 : (G > 255 ? 255 : G);
+    band = row / BAND_ROWS;
+    rec = ((unsigned)((row - band * BAND_ROWS) * W + col) << 16) | (unsigned)((I << 8) | G);
+    return true;
 }
 
-__global__ __launch_bounds__(256) void raster_scatter_kernel(const f32x4* __restrict__ pts, long n, LmRasterParams P,
-                                                             unsigned* __restrict__ acc, int H, int W) {
-    // inverse rotation: v = q^-1 d q  (reference applies v' = q v q^-1 / |q|)
-    const float nq = P.quat[0] * P.quat[0] + P.quat[1] * P.quat[1] + P.quat[2] * P.quat[2] + P.quat[3] * P.quat[3];
-    const float inv = 1.0f / (nq * sqrtf(nq));   // reference rotation is q v q* / |q|  =>  inverse is q* d q / |q|^3
-    const float qc[4] = {P.quat[0], -P.quat[1], -P.quat[2], -P.quat[3]};   // conjugate
-    const float qn[4] = {P.quat[0], P.quat[1], P.quat[2], P.quat[3]};
-    const float irow = 1.0f / P.img_reso[0], icol = 1.0f / P.img_reso[1], iele = 1.0f / P.ele_reso;
-    const float iscale = 255.0f / P.inten_hi;
-    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
-        const f32x4 p = __builtin_nontemporal_load(pts + i);
-        const float d[4] = {0.f, p[0] - P.trans[0], p[1] - P.trans[1], p[2] - P.trans[2]};
-        float t[4], v[4];
-        quat_mul(qc, d, t);
-        quat_mul(t, qn, v);
-        const float vx = v[1] * inv, vy = v[2] * inv, vz = v[3] * inv;
-        const int row = (int)floorf((vx - P.bev_img_offset[0]) * irow + 0.5f);
-        const int col = (int)floorf((vy - P.bev_img_offset[1]) * icol + 0.5f);
-        if ((unsigned)row >= (unsigned)H || (unsigned)col >= (unsigned)W) continue;
-        const float it = fminf(fmaxf(p[3], P.inten_lo), P.inten_hi) - P.inten_lo;
-        int I = (int)floorf(it * iscale + 0.5f);
-        I = I < 1 ? 1 : (I > 255 ? 255 : I);
-        int G = (int)floorf((vz - P.local_min_ele) * iele + 0.5f);
-        G = G < 0 ? 0 : (G > 255 ? 255 : G);
-        atomicMax(acc + (long)row * W + col, (unsigned)((I << 8) | G));
+// records: [tile][band][blk][CHUNK] u32 (zero padded to 16 B per run), counts: [tile][band][nblk_max]
+// grid: (nblk_max, tiles)
+__global__ __launch_bounds__(256) void raster_partition_kernel(const f32x4* __restrict__ pts, BatchArgs A, unsigned* __restrict__ counts,
+                                                               unsigned* __restrict__ records, int nblk_max, int H, int W, int nbands) {
+    constexpr int CAPQ = (CHUNK + MAX_BANDS * 3 + 3) / 4;
+    __shared__ unsigned hist[MAX_BANDS * REP];                 // [band][replica] count, then start offset in `sorted`
+    __shared__ unsigned qstart[MAX_BANDS + 1];                 // first 16-byte quad of each band's run
+    __shared__ __attribute__((aligned(16))) unsigned sorted[CAPQ * 4];
+    __shared__ unsigned char qband[CAPQ];
+    const int tile = blockIdx.y, blk = blockIdx.x, tid = threadIdx.x;
+    const TileXf& X = A.tile[tile];
+    const long first = (long)blk * CHUNK;
+    if (first >= X.count) return;                              // pass 2 never looks at slots beyond the tile's last chunk
+    for (int i = tid; i < MAX_BANDS * REP; i += 256) hist[i] = 0;
+    for (int i = tid; i < CAPQ * 4; i += 256) sorted[i] = 0;   // padding records must be 0
+    __syncthreads();
+    unsigned rec[PER_THREAD];
+    unsigned meta[PER_THREAD];                                 // slot << 16 | rank, 0xFFFFFFFF = dropped
+    const f32x4* base = pts + X.start + first;
+    const long left = X.count - first;
+    const int rep = tid & (REP - 1);
+    constexpr int LB = 8;                                      // loads kept in flight per thread
+#pragma unroll
+    for (int j0 = 0; j0 < PER_THREAD; j0 += LB) {
+        f32x4 p[LB];
+#pragma unroll
+        for (int j = 0; j < LB; ++j) {
+            const long i = (long)(j0 + j) * 256 + tid;
+            p[j] = (i < left) ? __builtin_nontemporal_load(base + i) : f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+#pragma unroll
+        for (int j = 0; j < LB; ++j) {
+            const long i = (long)(j0 + j) * 256 + tid;
+            meta[j0 + j] = 0xFFFFFFFFu;
+            int band;
+            if (i < left && point_record(p[j], X, H, W, band, rec[j0 + j])) {
+                const unsigned slot = (unsigned)band * REP + rep;
+                meta[j0 + j] = (slot << 16) | atomicAdd(&hist[slot], 1u);
+            }
+        }
+    }
+    __syncthreads();
+    if (tid < 64) {   // wave 0: exclusive scan over bands (lane owns bands tid and tid+64); every run starts on a quad
+        unsigned bc[2], bq[2];
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+            const int b = tid + 64 * k;
+            unsigned c = 0;
+            if (b < nbands)
+                for (int r = 0; r < REP; ++r) c += hist[b * REP + r];
+            bc[k] = c;
+            bq[k] = (c + 3) / 4;
+        }
+        unsigned incl0 = bq[0], incl1 = bq[1];
+        for (int o = 1; o < 64; o <<= 1) {
+            const unsigned v0 = __shfl_up(incl0, o), v1 = __shfl_up(incl1, o);
+            if (tid >= o) {
+                incl0 += v0;
+                incl1 += v1;
+            }
+        }
+        const unsigned tot0 = __shfl(incl0, 63);
+        const unsigned start[2] = {incl0 - bq[0], tot0 + incl1 - bq[1]};
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+            const int b = tid + 64 * k;
+            if (b < nbands) {
+                qstart[b] = start[k];
+                unsigned run = start[k] * 4;
+                for (int r = 0; r < REP; ++r) {
+                    const unsigned c = hist[b * REP + r];
+                    hist[b * REP + r] = run;
+                    run += c;
+                }
+                counts[((long)tile * nbands + b) * nblk_max + blk] = bc[k];
+            }
+        }
+        if (tid == 63) qstart[nbands] = tot0 + incl1;          // total quads (bands >= nbands contribute 0)
+    }
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < PER_THREAD; ++j)
+        if (meta[j] != 0xFFFFFFFFu) sorted[hist[meta[j] >> 16] + (meta[j] & 0xFFFFu)] = rec[j];
+    for (int b = tid; b < nbands; b += 256)
+        for (unsigned q = qstart[b]; q < qstart[b + 1]; ++q) qband[q] = (unsigned char)b;
+    __syncthreads();
+    const unsigned totq = qstart[nbands];
+    const u32x4* s4 = reinterpret_cast<const u32x4*>(sorted);
+    for (unsigned q = tid; q < totq; q += 256) {
+        const unsigned b = qband[q];
+        u32x4* dst = reinterpret_cast<u32x4*>(records + (((long)tile * nbands + b) * nblk_max + blk) * CHUNK) + (q - qstart[b]);
+        *dst = s4[q];
     }
 }
 
-__global__ __launch_bounds__(256) void raster_finalize_kernel(const unsigned* __restrict__ acc, float* __restrict__ chw,
-                                                              unsigned char* __restrict__ hwc_u8, long HW) {
-    const long i = (long)blockIdx.x * 256 + threadIdx.x;
-    if (i >= HW) return;
-    const unsigned k = acc[i];
-    const unsigned I = (k >> 8) & 255u, G = k & 255u;
-    if (chw) {
-        const float fi = (float)I / 255.0f, fg = (float)G / 255.0f;   // == torchvision to_tensor: u8 / 255
-        chw[i] = fi;
-        chw[HW + i] = fg;
-        chw[2 * HW + i] = fi;
+// grid: (bands, tiles); dynamic LDS = BAND_ROWS * W * 4 bytes; 1024 threads = 64 groups of 16 lanes, one run per group
+constexpr int BT = 1024;
+
+struct BandArgs {
+    int nblk[MAX_TILES];                                       // valid chunks per tile
+};
+
+__device__ __forceinline__ void apply4(unsigned* img, const u32x4 v) {
+#pragma unroll
+    for (int e = 0; e < 4; ++e)
+        if (v[e]) atomicMax(&img[v[e] >> 16], v[e] & 0xFFFFu);   // a real record has key >= 256; padding is 0
+}
+
+__global__ __launch_bounds__(BT) void raster_band_kernel(const unsigned* __restrict__ counts, const unsigned* __restrict__ records,
+                                                         BandArgs A, int nblk_max, float* __restrict__ out_chw,
+                                                         unsigned char* __restrict__ out_u8, int H, int W, int nbands) {
+    extern __shared__ __attribute__((aligned(16))) unsigned img[];
+    const int band = blockIdx.x, tile = blockIdx.y;
+    const int npix = BAND_ROWS * W;
+    for (int i = threadIdx.x; i < npix; i += BT) img[i] = 0;
+    __syncthreads();
+    const int nblk = A.nblk[tile];
+    const unsigned* cnt = counts + ((long)tile * nbands + band) * nblk_max;
+    const unsigned* rbase = records + ((long)tile * nbands + band) * (long)nblk_max * CHUNK;
+    const int grp = threadIdx.x >> 4, gl = threadIdx.x & 15;
+    for (int b0 = grp; b0 < nblk; b0 += 128) {                 // two runs in flight per 16-lane group
+        u32x4 v[2][2];
+        unsigned nq[2];
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const int b = b0 + 64 * u;
+            nq[u] = b < nblk ? (cnt[b] + 3) / 4 : 0;
+            const u32x4* r4 = reinterpret_cast<const u32x4*>(rbase + (long)b * CHUNK);
+#pragma unroll
+            for (int k = 0; k < 2; ++k)
+                v[u][k] = ((unsigned)(gl + 16 * k) < nq[u]) ? __builtin_nontemporal_load(r4 + gl + 16 * k) : u32x4{0u, 0u, 0u, 0u};
+        }
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            apply4(img, v[u][0]);
+            apply4(img, v[u][1]);
+            if (nq[u] > 32) {                                  // long run (spatially skewed chunk): finish it here
+                const u32x4* r4 = reinterpret_cast<const u32x4*>(rbase + (long)(b0 + 64 * u) * CHUNK);
+                for (unsigned q = 32 + gl; q < nq[u]; q += 16) apply4(img, r4[q]);
+            }
+        }
     }
-    if (hwc_u8) {
-        hwc_u8[i * 3 + 0] = (unsigned char)I;
-        hwc_u8[i * 3 + 1] = (unsigned char)G;
-        hwc_u8[i * 3 + 2] = (unsigned char)I;
+    __syncthreads();
+    const long HW = (long)H * W;
+    const long pix0 = (long)band * npix;
+    if (out_chw) {
+        float* o = out_chw + (long)tile * 3 * HW + pix0;
+        for (int i = threadIdx.x; i < npix; i += BT) {
+            const unsigned k = img[i];
+            const float fi = (float)(k >> 8) / 255.0f, fg = (float)(k & 255u) / 255.0f;   // == u8 / 255 (to_tensor)
+            o[i] = fi;
+            o[HW + i] = fg;
+            o[2 * HW + i] = fi;
+        }
+    }
+    if (out_u8) {
+        unsigned char* o = out_u8 + ((long)tile * HW + pix0) * 3;
+        for (int i = threadIdx.x; i < npix; i += BT) {
+            const unsigned k = img[i];
+            o[3 * i + 0] = (unsigned char)(k >> 8);
+            o[3 * i + 1] = (unsigned char)(k & 255u);
+            o[3 * i + 2] = (unsigned char)(k >> 8);
+        }
     }
 }
 
@@ -100,25 +259,92 @@ __global__ __launch_bounds__(256) void ingest_kernel(const unsigned char* __rest
     d[2 * HW] = (float)s[2] / 255.0f;
 }
 
+void derive(const LmRasterParams& P, long start, long count, TileXf& X) {
+    // inverse of the reference's rotation r(v) = q v q* / |q| = |q| R(q^) v   =>   M = R(q^)^T / |q|
+    const double n = std::sqrt((double)P.quat[0] * P.quat[0] + (double)P.quat[1] * P.quat[1] + (double)P.quat[2] * P.quat[2] +
+                               (double)P.quat[3] * P.quat[3]);
+    const double w = P.quat[0] / n, x = P.quat[1] / n, y = P.quat[2] / n, z = P.quat[3] / n;
+    const double R[9] = {1 - 2 * (y * y + z * z), 2 * (x * y - z * w), 2 * (x * z + y * w),
+                         2 * (x * y + z * w), 1 - 2 * (x * x + z * z), 2 * (y * z - x * w),
+                         2 * (x * z - y * w), 2 * (y * z + x * w), 1 - 2 * (x * x + y * y)};
+    for (int i = 0; i < 3; ++i)
+        for (int j = 0; j < 3; ++j) X.m[i * 3 + j] = (float)(R[j * 3 + i] / n);
+    for (int i = 0; i < 3; ++i) X.t[i] = P.trans[i];
+    X.off[0] = P.bev_img_offset[0];
+    X.off[1] = P.bev_img_offset[1];
+    X.irow = 1.0f / P.img_reso[0];
+    X.icol = 1.0f / P.img_reso[1];
+    X.min_ele = P.local_min_ele;
+    X.iele = 1.0f / P.ele_reso;
+    X.lo = P.inten_lo;
+    X.hi = P.inten_hi;
+    X.iscale = 255.0f / P.inten_hi;
+    X.start = start;
+    X.count = count;
+}
+
 }  // namespace
 
-LM_API int lm_bev_raster(void* stream, const float* points_xyzi, long n_points, const LmRasterParams* params,
-                         unsigned* acc_workspace, float* out_chw, unsigned char* out_hwc_u8, int H, int W) {
-    LM_REQUIRE((points_xyzi || n_points == 0) && params && acc_workspace && (out_chw || out_hwc_u8), "bev_raster: null pointer");
-    LM_REQUIRE(n_points >= 0 && H > 0 && W > 0, "bev_raster: bad sizes");
-    LM_REQUIRE(params->img_reso[0] > 0 && params->img_reso[1] > 0 && params->ele_reso > 0, "bev_raster: bad resolution");
+static long nblk_of(long n) { return (n + CHUNK - 1) / CHUNK; }
+
+LM_API long lm_bev_raster_workspace_bytes(int B, long max_points_per_tile, int H, int W) {
+    const long nbands = H / BAND_ROWS, nblk = nblk_of(max_points_per_tile) > 0 ? nblk_of(max_points_per_tile) : 1;
+    const long head = (((long)B * nbands * nblk * (long)sizeof(unsigned) + 255) / 256) * 256;
+    return head + (long)B * nbands * nblk * CHUNK * (long)sizeof(unsigned);
+}
+
+// points: device [sum N, 4] f32; tile_offsets: HOST [B+1] (point index of each tile's first record); params: HOST [B]
+LM_API int lm_bev_raster_batch(void* stream, const float* points_xyzi, const long* tile_offsets, const LmRasterParams* params,
+                               int B, void* workspace, long workspace_bytes, float* out_chw, unsigned char* out_hwc_u8,
+                               int H, int W) {
+    LM_REQUIRE(tile_offsets && params && workspace && (out_chw || out_hwc_u8) && B >= 1, "bev_raster: null pointer");
+    LM_REQUIRE(H % BAND_ROWS == 0 && H / BAND_ROWS < MAX_BANDS && BAND_ROWS * W <= 65536 && W > 0,
+               "bev_raster: H=%d must be a multiple of %d (< %d bands) and 16*W <= 65536", H, BAND_ROWS, MAX_BANDS);
+    const int nbands = H / BAND_ROWS;
+    long nmax = 0;
+    for (int b = 0; b < B; ++b) {
+        const long n = tile_offsets[b + 1] - tile_offsets[b];
+        LM_REQUIRE(n >= 0, "bev_raster: tile offsets must be non-decreasing");
+        LM_REQUIRE(params[b].img_reso[0] > 0 && params[b].img_reso[1] > 0 && params[b].ele_reso > 0, "bev_raster: bad resolution");
+        nmax = n > nmax ? n : nmax;
+    }
+    LM_REQUIRE(points_xyzi || nmax == 0, "bev_raster: null points");
+    LM_REQUIRE(lm_bev_raster_workspace_bytes(B, nmax, H, W) <= workspace_bytes, "bev_raster: workspace too small (%ld B needed)",
+               lm_bev_raster_workspace_bytes(B, nmax, H, W));
+    const int nblk_max = (int)(nblk_of(nmax) > 0 ? nblk_of(nmax) : 1);
     hipStream_t s = (hipStream_t)stream;
+    unsigned* counts = (unsigned*)workspace;
+    unsigned* records = (unsigned*)((char*)workspace + (((long)B * nbands * nblk_max * sizeof(unsigned) + 255) / 256) * 256);
+    const size_t lds = (size_t)BAND_ROWS * W * sizeof(unsigned);
+    static size_t lds_set = 0;
+    if (lds > lds_set) {
+        LM_HIP(hipFuncSetAttribute((const void*)raster_band_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        lds_set = lds;
+    }
     const long HW = (long)H * W;
-    LM_HIP(hipMemsetAsync(acc_workspace, 0, HW * sizeof(unsigned), s));
-    if (n_points > 0) {
-        long blocks = (n_points + 255) / 256;
-        if (blocks > 256 * 16) blocks = 256 * 16;     // grid-stride: 16 workgroups per CU
-        hipLaunchKernelGGL(raster_scatter_kernel, dim3((unsigned)blocks), dim3(256), 0, s,
-                           reinterpret_cast<const f32x4*>(points_xyzi), n_points, *params, acc_workspace, H, W);
+    for (int b0 = 0; b0 < B; b0 += MAX_TILES) {
+        const int nb = (B - b0) < MAX_TILES ? (B - b0) : MAX_TILES;
+        BatchArgs A;
+        BandArgs BA;
+        long maxn = 0;
+        for (int b = 0; b < nb; ++b) {
+            const long n = tile_offsets[b0 + b + 1] - tile_offsets[b0 + b];
+            derive(params[b0 + b], tile_offsets[b0 + b], n, A.tile[b]);
+            BA.nblk[b] = (int)nblk_of(n);
+            maxn = n > maxn ? n : maxn;
+        }
+        unsigned* cnt = counts + (long)b0 * nbands * nblk_max;
+        unsigned* rec = records + (long)b0 * nbands * nblk_max * CHUNK;
+        if (maxn > 0) {
+            hipLaunchKernelGGL(raster_partition_kernel, dim3((unsigned)nblk_of(maxn), nb), dim3(256), 0, s,
+                               reinterpret_cast<const f32x4*>(points_xyzi), A, cnt, rec, nblk_max, H, W, nbands);
+            LM_LAUNCH_CHECK();
+        }
+        hipLaunchKernelGGL(raster_band_kernel, dim3(nbands, nb), dim3(BT), lds, s, cnt, rec, BA, nblk_max,
+                           out_chw ? out_chw + (long)b0 * 3 * HW : nullptr, out_hwc_u8 ? out_hwc_u8 + (long)b0 * 3 * HW : nullptr,
+                           H, W, nbands);
         LM_LAUNCH_CHECK();
     }
-    hipLaunchKernelGGL(raster_finalize_kernel, dim3(lm_cdiv(HW, 256)), dim3(256), 0, s, acc_workspace, out_chw, out_hwc_u8, HW);
-    LM_LAUNCH_CHECK();
     return LM_OK;
 }
 

@@ -320,16 +320,35 @@ def make_raster_params(quat=(1, 0, 0, 0), trans=(0, 0, 0), bev_img_offset=(0, 0)
     return p
 
 
-def bev_raster(points, params, H=1152, W=1152, out=None, want_u8=False, acc=None):
-    """points [N,4] f32 (x,y,z,raw intensity) on device -> proj [3,H,W] f32 (= u8/255), optional u8 HWC."""
+_raster_ws = {}
+
+
+def bev_raster_batch(points, tile_offsets, params, H=1152, W=1152, out=None, want_u8=False):
+    """points [sum N,4] f32 (x,y,z,raw intensity) on device, tile_offsets: B+1 ints, params: list of LmRasterParams
+    -> proj [B,3,H,W] f32 (= u8/255), optional u8 [B,H,W,3]."""
     assert points.dim() == 2 and points.shape[1] == 4 and points.is_contiguous() and points.dtype == torch.float32
-    if acc is None:
-        acc = torch.empty((H, W), device=points.device, dtype=torch.int32)
+    B = len(params)
+    assert len(tile_offsets) == B + 1
+    offs = (C.c_long * (B + 1))(*[int(o) for o in tile_offsets])
+    par = (LmRasterParams * B)(*params)
+    cap = max([offs[b + 1] - offs[b] for b in range(B)] + [0])
+    need = lib().lm_bev_raster_workspace_bytes(B, cap, H, W)
+    key = (points.device, torch.cuda.current_stream().cuda_stream)
+    ws = _raster_ws.get(key)
+    if ws is None or ws.numel() < need:
+        ws = _raster_ws[key] = torch.empty(need, device=points.device, dtype=torch.uint8)
     if out is None:
-        out = torch.empty((3, H, W), device=points.device, dtype=torch.float32)
-    u8 = torch.empty((H, W, 3), device=points.device, dtype=torch.uint8) if want_u8 else None
-    check(lib().lm_bev_raster(_stream(), _ptr(points), points.shape[0], C.byref(params), _ptr(acc), _ptr(out), _ptr(u8), H, W))
+        out = torch.empty((B, 3, H, W), device=points.device, dtype=torch.float32)
+    u8 = torch.empty((B, H, W, 3), device=points.device, dtype=torch.uint8) if want_u8 else None
+    check(lib().lm_bev_raster_batch(_stream(), _ptr(points) if points.numel() else None, offs, par, B, _ptr(ws), ws.numel(),
+                                    _ptr(out), _ptr(u8), H, W))
     return (out, u8) if want_u8 else out
+
+
+def bev_raster(points, params, H=1152, W=1152, want_u8=False):
+    """Single tile convenience wrapper: points [N,4] -> proj [3,H,W] (and u8 [H,W,3])."""
+    r = bev_raster_batch(points, [0, points.shape[0]], [params], H, W, want_u8=want_u8)
+    return (r[0][0], r[1][0]) if want_u8 else r[0]
 
 
 def tile_ingest(u8_hwc):

@@ -15,29 +15,27 @@ typedef struct {
     float quat[4], trans[3], bev_img_offset[2], img_reso[2], local_min_ele, ele_reso, inten_lo, inten_hi;
 } RasterParams;
 
-static void quat_mul(const float a[4], const float b[4], float o[4]) {
-    o[0] = a[0] * b[0] - a[1] * b[1] - a[2] * b[2] - a[3] * b[3];
-    o[1] = a[0] * b[1] + a[1] * b[0] + a[2] * b[3] - a[3] * b[2];
-    o[2] = a[0] * b[2] - a[1] * b[3] + a[2] * b[0] + a[3] * b[1];
-    o[3] = a[0] * b[3] + a[1] * b[2] - a[2] * b[1] + a[3] * b[0];
-}
-
 /* acc: [H*W] u32 keys (intensity<<8 | elevation), out_u8: [H][W][3] */
 void raster_ref(const float* pts, long n, const RasterParams* P, uint32_t* acc, uint8_t* out_u8, int H, int W) {
     memset(acc, 0, (size_t)H * W * sizeof(uint32_t));
-    const float nq = P->quat[0] * P->quat[0] + P->quat[1] * P->quat[1] + P->quat[2] * P->quat[2] + P->quat[3] * P->quat[3];
-    const float inv = 1.0f / (nq * sqrtf(nq));
-    const float qc[4] = {P->quat[0], -P->quat[1], -P->quat[2], -P->quat[3]};
-    const float qn[4] = {P->quat[0], P->quat[1], P->quat[2], P->quat[3]};
+    /* inverse of the reference's rotation r(v) = q v q* / |q| = |q| R(q^) v   =>   M = R(q^)^T / |q|  (double -> float) */
+    const double nq = sqrt((double)P->quat[0] * P->quat[0] + (double)P->quat[1] * P->quat[1] + (double)P->quat[2] * P->quat[2] +
+                           (double)P->quat[3] * P->quat[3]);
+    const double w = P->quat[0] / nq, x = P->quat[1] / nq, y = P->quat[2] / nq, z = P->quat[3] / nq;
+    const double R[9] = {1 - 2 * (y * y + z * z), 2 * (x * y - z * w), 2 * (x * z + y * w),
+                         2 * (x * y + z * w), 1 - 2 * (x * x + z * z), 2 * (y * z - x * w),
+                         2 * (x * z - y * w), 2 * (y * z + x * w), 1 - 2 * (x * x + y * y)};
+    float m[9];
+    for (int i = 0; i < 3; ++i)
+        for (int j = 0; j < 3; ++j) m[i * 3 + j] = (float)(R[j * 3 + i] / nq);
     const float irow = 1.0f / P->img_reso[0], icol = 1.0f / P->img_reso[1], iele = 1.0f / P->ele_reso;
     const float iscale = 255.0f / P->inten_hi;
     for (long i = 0; i < n; ++i) {
         const float* p = pts + 4 * i;
-        const float d[4] = {0.f, p[0] - P->trans[0], p[1] - P->trans[1], p[2] - P->trans[2]};
-        float t[4], v[4];
-        quat_mul(qc, d, t);
-        quat_mul(t, qn, v);
-        const float vx = v[1] * inv, vy = v[2] * inv, vz = v[3] * inv;
+        const float dx = p[0] - P->trans[0], dy = p[1] - P->trans[1], dz = p[2] - P->trans[2];
+        const float vx = (m[0] * dx + m[1] * dy) + m[2] * dz;
+        const float vy = (m[3] * dx + m[4] * dy) + m[5] * dz;
+        const float vz = (m[6] * dx + m[7] * dy) + m[8] * dz;
         const int row = (int)floorf((vx - P->bev_img_offset[0]) * irow + 0.5f);
         const int col = (int)floorf((vy - P->bev_img_offset[1]) * icol + 0.5f);
         if (row < 0 || row >= H || col < 0 || col >= W) continue;

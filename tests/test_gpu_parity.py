@@ -268,6 +268,14 @@ def test_raster_vs_oracle_and_roundtrip(dev):
     # determinism (scatter-max is order independent)
     proj2 = ops.bev_raster(torch.from_numpy(rec).to(dev), ops.make_raster_params(**kw))
     assert torch.equal(proj, proj2)
+    # ragged batch: tile 0 = first 300k points, tile 1 = empty, tile 2 = the rest, different parameters per tile
+    kw2 = dict(kw, quat=(1, 0, 0, 0), trans=(0, 0, 0), bev_img_offset=(-25.0, -35.0))
+    offs = [0, 300000, 300000, n]
+    pars = [ops.make_raster_params(**kw), ops.make_raster_params(**kw), ops.make_raster_params(**kw2)]
+    _, bu8 = ops.bev_raster_batch(torch.from_numpy(rec).to(dev), offs, pars, want_u8=True)
+    assert np.array_equal(bu8[0].cpu().numpy(), raster_ref.raster(rec[:300000], ref_p))
+    assert int(bu8[1].max()) == 0
+    assert np.array_equal(bu8[2].cpu().numpy(), raster_ref.raster(rec[300000:], raster_ref.params(**kw2)))
     # round trip through the reference's inverse transform: every occupied pixel maps back to within one
     # pixel pitch / one elevation step of a point that fell into it
     occ = np.argwhere(want.sum(2) > 0)
