@@ -80,6 +80,7 @@ def main():
     ap.add_argument('--cpu-budget-s', type=float, default=25.0)
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--host-threads', type=int, default=8)
+    ap.add_argument('--conv-detail', action='store_true', help='per-shape table of the MFMA launches on stderr')
     ap.add_argument('--no-roofline-events', action='store_true', help='skip the per-launch HIP events')
     args = ap.parse_args()
 
@@ -117,7 +118,7 @@ def main():
             a.record()
             launch()
             b.record()
-            prof['pairs'].append((a, b))
+            prof['pairs'].append((a, b, kind, flops))
             prof['flops'] += flops
             prof['launches'] += 1
         else:
@@ -160,7 +161,16 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
 
-    conv_ms = sum(a.elapsed_time(b) for a, b in prof['pairs'])
+    conv_ms = sum(p[0].elapsed_time(p[1]) for p in prof['pairs'])
+    if args.conv_detail and rank == 0:
+        agg = {}
+        for a, b, kind, fl in prof['pairs']:
+            e = agg.setdefault(kind, [0, 0.0, 0.0])
+            e[0] += 1
+            e[1] += a.elapsed_time(b)
+            e[2] += fl
+        for kind, (n, ms, fl) in sorted(agg.items(), key=lambda kv: -kv[1][1]):
+            print(f'# {kind:44s} x{n // args.steps:3d}/step {ms / args.steps:8.3f} ms/step {fl / ms / 1e9:7.1f} TFLOP/s', file=sys.stderr)
     achieved = prof['flops'] / (conv_ms * 1e-3) / 1e12 if conv_ms > 0 else 0.0
     n_lines = int(np.mean([(np.count_nonzero(l[:, :, 0] > 0, axis=1) >= 2).sum() for l, _ in last])) if last else 0
     result = {

@@ -38,12 +38,14 @@ struct ConvParams {
 __device__ __forceinline__ float gelu_erf(float v) { return 0.5f * v * (1.0f + erff(v * 0.70710678118654752440f)); }
 
 template <int BM, int BN, int WM, int WN>
-__global__ __launch_bounds__(256) void conv_mfma_kernel(ConvParams p) {
+__global__ __launch_bounds__((BM / WM) * (BN / WN) * 64) void conv_mfma_kernel(ConvParams p) {
     constexpr int TM = WM / 32, TN = WN / 32;
     constexpr int WAVES_N = BN / WN;
-    static_assert((BM / WM) * (BN / WN) == 4, "4 waves per block");
-    constexpr int A_LOADS = BM * 8 / 256;   // float4 per thread per slab
-    constexpr int B_LOADS = BN * 8 / 256;
+    constexpr int NT = (BM / WM) * (BN / WN) * 64;   // threads: one wave per WM x WN sub-tile
+    constexpr int RPP = NT / 8;                       // rows covered by one load pass (8 lanes x 16 B per row)
+    constexpr int A_LOADS = BM / RPP;                 // float4 per thread per slab
+    constexpr int B_LOADS = BN / RPP;
+    static_assert(BM % RPP == 0 && BN % RPP == 0, "tile rows must be a multiple of the load pass");
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* As = smem;                          // [2][BM][LDS_LD]
     float* Bs = smem + 2 * BM * LDS_LD;        // [2][BN][LDS_LD]
@@ -53,18 +55,18 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(ConvParams p) {
     const int wave = tid >> 6;
     const int wm0 = (wave / WAVES_N) * WM;
     const int wn0 = (wave % WAVES_N) * WN;
-    const int n_tiles = p.CoutP / BN;
+    const int n_tiles = (p.Cout + BN - 1) / BN;   // CoutP only guarantees that weight rows up to the tile edge exist
     const long m0 = (long)(blockIdx.x / n_tiles) * BM;
     const int n0 = (blockIdx.x % n_tiles) * BN;
 
     // --- per-thread gather coordinates (tap independent part) ---
-    const int lrow = tid >> 3;        // 0..31
+    const int lrow = tid >> 3;        // 0..RPP-1
     const int lc4 = (tid & 7) * 4;    // channel offset within the slab
     int a_iy0[A_LOADS], a_ix0[A_LOADS];
     long a_boff[A_LOADS];
 #pragma unroll
     for (int i = 0; i < A_LOADS; ++i) {
-        long m = m0 + lrow + i * 32;
+        long m = m0 + lrow + i * RPP;
         if (m < p.M) {
             int ox = (int)(m % p.Wo);
             long t = m / p.Wo;
@@ -97,17 +99,17 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(ConvParams p) {
         }
 #pragma unroll
         for (int i = 0; i < B_LOADS; ++i) {
-            const int n = n0 + lrow + i * 32;
+            const int n = n0 + lrow + i * RPP;
             rb[i] = *reinterpret_cast<const f32x4*>(p.wp + ((long)tap * p.CoutP + n) * p.Cin + c0);
         }
     };
     auto lstore = [&](int buf) {
 #pragma unroll
         for (int i = 0; i < A_LOADS; ++i)
-            *reinterpret_cast<f32x4*>(As + (buf * BM + lrow + i * 32) * LDS_LD + lc4) = ra[i];
+            *reinterpret_cast<f32x4*>(As + (buf * BM + lrow + i * RPP) * LDS_LD + lc4) = ra[i];
 #pragma unroll
         for (int i = 0; i < B_LOADS; ++i)
-            *reinterpret_cast<f32x4*>(Bs + (buf * BN + lrow + i * 32) * LDS_LD + lc4) = rb[i];
+            *reinterpret_cast<f32x4*>(Bs + (buf * BN + lrow + i * RPP) * LDS_LD + lc4) = rb[i];
     };
 
     f32x16 acc[TM][TN];
@@ -148,27 +150,62 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(ConvParams p) {
         __syncthreads();
     }
 
-    // --- epilogue: affine, residual, activation, masked store (32 consecutive n per half-wave) ---
+    // --- epilogue: each wave transposes its WM x WN accumulator tile through (now idle) LDS so that every lane owns 4
+    // consecutive output channels of one pixel: residual loads and output stores become coalesced 16-byte accesses
+    // (the raw MFMA layout gives 4-byte stores, which made the thin 1x1 layers store-issue bound).
+    constexpr int ELD = WN + 4;
+    static_assert((NT / 64) * WM * ELD <= 2 * (BM + BN) * LDS_LD, "epilogue staging must fit the K-loop LDS");
+    float* stage = smem + wave * (WM * ELD);
     const int half = lane >> 5;
 #pragma unroll
-    for (int j = 0; j < TN; ++j) {
-        const int n = n0 + wn0 + j * 32 + frow;
-        const bool nok = n < p.Cout;
-        const float sc = (p.scale && nok) ? p.scale[n] : 1.f;
-        const float sh = (p.shift && nok) ? p.shift[n] : 0.f;
+    for (int i = 0; i < TM; ++i)
 #pragma unroll
-        for (int i = 0; i < TM; ++i) {
+        for (int j = 0; j < TN; ++j)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const long m = m0 + wm0 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
-                if (nok && m < p.M) {
-                    float v = acc[i][j][r];
-                    if (p.scale) v = v * sc;
-                    v += sh;
-                    if (p.res) v += p.res[(p.res_rows ? (m % p.res_rows) : m) * p.ldr + n];
-                    if (p.act == LM_ACT_RELU) v = fmaxf(v, 0.f);
-                    else if (p.act == LM_ACT_GELU) v = gelu_erf(v);
-                    p.y[m * p.ldy + n] = v;
+            for (int r = 0; r < 16; ++r)
+                stage[(i * 32 + (r & 3) + 8 * (r >> 2) + 4 * half) * ELD + j * 32 + frow] = acc[i][j][r];
+    __syncthreads();
+    constexpr int LPR = WN / 4;            // lanes per output row
+    constexpr int RPI = 64 / LPR;          // rows per pass
+    const int c4 = (lane % LPR) * 4;
+    const int n = n0 + wn0 + c4;
+    if (n < p.Cout) {
+        const bool vec = (n + 3 < p.Cout) && ((p.ldy & 3) == 0) && (!p.res || (p.ldr & 3) == 0);
+        f32x4 sc = {1.f, 1.f, 1.f, 1.f}, sh = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+            if (n + e < p.Cout) {
+                if (p.scale) sc[e] = p.scale[n + e];
+                if (p.shift) sh[e] = p.shift[n + e];
+            }
+#pragma unroll
+        for (int pass = 0; pass < WM / RPI; ++pass) {
+            const int row = pass * RPI + lane / LPR;
+            const long m = m0 + wm0 + row;
+            if (m >= p.M) continue;
+            f32x4 v = *reinterpret_cast<const f32x4*>(stage + row * ELD + c4);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = p.scale ? v[e] * sc[e] + sh[e] : v[e] + sh[e];
+            const long rrow = p.res_rows ? (m % p.res_rows) : m;
+            if (vec) {
+                if (p.res) {
+                    const f32x4 rr = *reinterpret_cast<const f32x4*>(p.res + rrow * p.ldr + n);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] += rr[e];
+                }
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    if (p.act == LM_ACT_RELU) v[e] = fmaxf(v[e], 0.f);
+                    else if (p.act == LM_ACT_GELU) v[e] = gelu_erf(v[e]);
+                }
+                *reinterpret_cast<f32x4*>(p.y + m * p.ldy + n) = v;
+            } else {
+                for (int e = 0; e < 4 && n + e < p.Cout; ++e) {
+                    float u = v[e];
+                    if (p.res) u += p.res[rrow * p.ldr + n + e];
+                    if (p.act == LM_ACT_RELU) u = fmaxf(u, 0.f);
+                    else if (p.act == LM_ACT_GELU) u = gelu_erf(u);
+                    p.y[m * p.ldy + n + e] = u;
                 }
             }
         }
@@ -185,9 +222,9 @@ int launch(const ConvParams& p, hipStream_t stream) {
         attr_set = true;
     }
     const long m_tiles = (p.M + BM - 1) / BM;
-    const long blocks = m_tiles * (p.CoutP / BN);
+    const long blocks = m_tiles * ((p.Cout + BN - 1) / BN);
     LM_REQUIRE(blocks > 0 && blocks < (1L << 31), "conv_mfma: bad grid %ld", blocks);
-    hipLaunchKernelGGL((conv_mfma_kernel<BM, BN, WM, WN>), dim3((unsigned)blocks), dim3(256), lds, stream, p);
+    hipLaunchKernelGGL((conv_mfma_kernel<BM, BN, WM, WN>), dim3((unsigned)blocks), dim3((BM / WM) * (BN / WN) * 64), lds, stream, p);
     LM_LAUNCH_CHECK();
     return LM_OK;
 }
@@ -215,5 +252,8 @@ LM_API int lm_conv2d_nhwc_mfma_f32(void* stream, const float* x, int ldx, const 
     p.M = (long)B * p.Ho * p.Wo;
     hipStream_t s = (hipStream_t)stream;
     if (Cout <= 64) return launch<128, 64, 32, 64>(p, s);
+    // small-M GEMMs (ViT tokens): 128x128 tiles would leave most of the 256 CUs idle -> 64x64 tiles, 4x the workgroups
+    const long big_blocks = ((p.M + 127) / 128) * ((Cout + 127) / 128);
+    if (big_blocks < 512) return launch<64, 64, 32, 32>(p, s);
     return launch<128, 128, 64, 64>(p, s);
 }

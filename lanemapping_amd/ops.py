@@ -106,7 +106,7 @@ def conv_mfma(x, wp, cout, kh=1, kw=1, stride=1, pad=0, dil=1, scale=None, shift
                                             _ptr(res), ldr, res_rows, _ptr(out), ldy, B, H, W, cin, cout, kh, kw,
                                             stride, ph, pw, dil, act))
     if _conv_hook is not None:
-        _conv_hook('conv_mfma', 2.0 * B * Ho * Wo * cout * cin * kh * kw, launch)
+        _conv_hook(f'conv {cin}->{cout} k{kh}x{kw} s{stride} d{dil} @{H}x{W} B{B}', 2.0 * B * Ho * Wo * cout * cin * kh * kw, launch)
     else:
         launch()
     return out
@@ -124,7 +124,7 @@ def linear_mfma(x2d, wp, n_out, scale=None, shift=None, res=None, res_rows=0, ac
                                             _ptr(shift), _ptr(res), ldr, res_rows, _ptr(out), out.stride(0),
                                             1, 1, M, K, n_out, 1, 1, 1, 0, 0, 1, act))
     if _conv_hook is not None:
-        _conv_hook('conv_mfma', 2.0 * M * n_out * K, launch)
+        _conv_hook(f'gemm M{M} K{K} N{n_out}', 2.0 * M * n_out * K, launch)
     else:
         launch()
     return out
