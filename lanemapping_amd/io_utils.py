@@ -1,0 +1,78 @@
+"""Per-tile polyline output / tile parameter input, format-compatible with the reference.
+
+  save_lane_seq_2d               <- baseline/utils/io_utils.py:58-93 (+ save_seqs_json :11-15, save_seqs_txt :17-26)
+  load_lane_seq                  <- baseline/utils/io_utils.py:100-123
+  load_pc_2_img_transform_paras  <- baseline/utils/io_utils.py:125-150 (values on lines 1,3,5,...,13 of the file)
+  pack_lane_vertices             <- heads/polyline_fpn_vit_vertex_2.py:997-1000 (row = 3 + 8 i, col, semantic)
+The JSON text equals the reference's byte for byte (json.dump(indent=4) of python floats / ints).
+"""
+import json
+import os
+
+import numpy as np
+
+
+def pack_lane_vertices(lanes, row_size=144):
+    v = np.zeros((lanes.shape[0], row_size, 3))
+    v[:, :, 0] = np.arange(3, row_size * 8, 8)
+    v[:, :, 1:] = lanes
+    return v
+
+
+def lane_records(lane_vertexes, with_pervertex_semantics=True):
+    recs = []
+    for lane in np.asarray(lane_vertexes):
+        pv = lane[lane[:, 1] > 0]
+        if pv.shape[0] < 2:
+            continue
+        if not with_pervertex_semantics:
+            pv = pv[:, :-1]
+        recs.append({'seq_len': int(pv.shape[0]), 'seq': pv.tolist(), 'init_vertex': pv[0].tolist(),
+                     'end_vertex': pv[-1].tolist()})
+    return recs
+
+
+def save_lane_seq_2d(lane_vertexes, lane_seq_path, with_pervertex_semantics=True):
+    recs = lane_records(lane_vertexes, with_pervertex_semantics)
+    if os.path.splitext(lane_seq_path)[1] == '.txt':
+        with open(lane_seq_path, 'w') as f:
+            for i, line in enumerate(recs):
+                for vtx in line['seq']:
+                    f.write(' '.join(str(item) for item in vtx) + ' ' + str(i) + '\n')
+    else:
+        with open(lane_seq_path, 'w') as f:
+            json.dump(recs, f, indent=4)
+
+
+def load_lane_seq(seqfile_path, dim_coor=2):
+    with open(seqfile_path) as f:
+        data = json.load(f)
+    seq_lens = [a['seq_len'] for a in data]
+    init_points = [a['init_vertex'] for a in data]
+    end_points = [a['end_vertex'] for a in data]
+    if len(seq_lens) < 2:          # reference quirk: a single line yields an empty list
+        return [], seq_lens, init_points, end_points
+    seq = np.zeros((len(seq_lens), max(seq_lens), dim_coor))
+    for i, a in enumerate(data):
+        if seq_lens[i]:
+            seq[i, :seq_lens[i]] = [x[0:dim_coor] for x in a['seq']]
+    return seq, seq_lens, init_points, end_points
+
+
+def load_pc_2_img_transform_paras(param_path):
+    with open(param_path) as f:
+        lines = f.read().split('\n')
+    fl = lambda s: [float(t) for t in s.split(' ')]
+    return {'coor_las_path': lines[1], 'las_read_offset': fl(lines[3]), 'las_rotation_trans_quan': fl(lines[5]),
+            'bev_img_offset': fl(lines[7]), 'img_reso': fl(lines[9]), 'local_min_ele': float(lines[11]),
+            'ele_reso': float(lines[13])}
+
+
+def raster_params_from_file(param_path):
+    """Reference parameter file -> LmRasterParams for lm_bev_raster_batch (points must already have
+    `las_read_offset` subtracted, as the reference's LAS reader hands them over)."""
+    from .ops import make_raster_params
+    p = load_pc_2_img_transform_paras(param_path)
+    q = p['las_rotation_trans_quan']
+    return make_raster_params(quat=q[3:7], trans=q[0:3], bev_img_offset=p['bev_img_offset'], img_reso=p['img_reso'],
+                              local_min_ele=p['local_min_ele'], ele_reso=p['ele_reso'])

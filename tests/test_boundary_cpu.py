@@ -157,3 +157,30 @@ def test_empty_and_degenerate_tiles():
     V, _ = hostpost.assemble_polylines(pc, np.ones((72, 144), np.float32), np.full((72, 144), 70.0), np.ones((144, 1152), np.float32),
                                        np.array([[600, 560]], np.int32))
     assert ((V[:, :, 0] > 0).sum(1) >= 2).sum() == 1
+
+
+def test_json_output_is_byte_identical_to_reference(golden, tmp_path):
+    from lanemapping_amd import io_utils
+    g = golden('g6_postproc.npz')
+    p = tmp_path / 'tile.json'
+    io_utils.save_lane_seq_2d(io_utils.pack_lane_vertices(g['V0']), str(p))
+    assert p.read_text() == open(os.path.join(ROOT, 'tests', 'golden', 'g9_lanes.json')).read()
+    seq, lens, init, end = io_utils.load_lane_seq(str(p), dim_coor=3)
+    assert seq.shape[0] == len(lens) == 4 and seq.shape[2] == 3
+    t = tmp_path / 'tile.txt'
+    io_utils.save_lane_seq_2d(io_utils.pack_lane_vertices(g['V0']), str(t))
+    first = t.read_text().splitlines()[0].split(' ')
+    assert len(first) == 4 and first[-1] == '0'
+
+
+def test_param_file_parser(tmp_path):
+    from lanemapping_amd import io_utils
+    p = tmp_path / '181013_0130.txt'
+    p.write_text('las path:\n/data/a.las\nlas read offset:\n1000.5 2000.25 10\nrotation translation quaternion:\n'
+                 '1 2 3 0.7071068 0 0 0.7071068\nbev image offset:\n-28.8 -28.8\nimage resolution:\n0.05 0.05\n'
+                 'local min elevation:\n-2.5\nelevation resolution:\n0.02\n')
+    d = io_utils.load_pc_2_img_transform_paras(str(p))
+    assert d['coor_las_path'] == '/data/a.las' and d['las_read_offset'] == [1000.5, 2000.25, 10.0]
+    assert d['las_rotation_trans_quan'][3:] == [0.7071068, 0.0, 0.0, 0.7071068] and d['ele_reso'] == 0.02
+    rp = io_utils.raster_params_from_file(str(p))
+    assert abs(rp.quat[0] - 0.7071068) < 1e-7 and list(rp.trans) == [1.0, 2.0, 3.0] and abs(rp.local_min_ele + 2.5) < 1e-7

@@ -299,3 +299,45 @@ def test_tile_ingest(dev):
     rgba = np.concatenate([u8, np.full((96, 96, 1), 255, np.uint8)], axis=2)
     out = ops.tile_ingest(torch.from_numpy(rgba[None]).to(dev))
     assert torch.equal(out.cpu()[0], torch.from_numpy(synth.bev_tile(5, 96)))
+
+
+def test_runner_png_tiles_to_json(dev, net, tmp_path):
+    """test_gpu_0.py-style entry: PNG tiles on disk -> per-tile JSON, identical to driving the pipeline directly."""
+    import json
+    from PIL import Image
+    from lanemapping_amd import io_utils
+    from lanemapping_amd.pipeline import TilePipeline
+    from lanemapping_amd.runner import Runner
+    seeds = [301, 302, 303]
+    for s in seeds:
+        Image.fromarray(synth.bev_tile_u8(s, 1152)).save(tmp_path / f'1901{s}_0001_extra.png')
+    r = Runner(net.cfg, device=dev)
+    r.net = net
+    out = tmp_path / 'out'
+    res = r.infer_lane_coordinate_endpoint_semantics(tiles=str(tmp_path), batch_size=2, work_dirs=str(out))
+    assert sorted(res) == [f'1901{s}_000' for s in seeds]          # image_name[0:11]
+    direct = TilePipeline(net).run_batch(torch.from_numpy(synth.bev_batch(seeds, 1152)).to(dev))
+    for s, (lanes, endp) in zip(seeds, direct):
+        assert np.array_equal(res[f'1901{s}_000'][0], lanes)
+        recs = json.load(open(out / f'1901{s}_000.json'))
+        assert recs == io_utils.lane_records(io_utils.pack_lane_vertices(lanes))
+
+
+def test_segmentor_config1_end_to_end(dev, synth_sd):
+    """BASELINE config 1 (Proj_FPN_Seg, batch 1): Segmentor through the boundary vs the oracle chain."""
+    from lanemapping_amd.boundary import build_net_from_config
+    from oracle import net_ref, decode_ref
+    seg_net = build_net_from_config('Proj_FPN_Seg', device='cpu')
+    sd = {k: v for k, v in synth_sd.items() if k.startswith('pcencoder.')}
+    seg_net.load_state_dict(sd, strict=True)
+    seg_net = seg_net.to(dev)
+    x = torch.from_numpy(synth.bev_batch([2021], 1152))
+    out = seg_net({'proj': x.to(dev)})
+    with torch.no_grad():
+        _, _, bi_seg, endp = net_ref.fpn_forward(synth_sd, x)
+    ref = decode_ref.segmentor_decode(bi_seg.numpy(), endp.numpy(), seg_thre=0.1)
+    bad = np.flatnonzero(out['seg'].numpy().reshape(-1) != ref['seg'].numpy().reshape(-1))
+    l1, l2 = bi_seg[0, 1].reshape(-1)[bad], bi_seg[0, 2].reshape(-1)[bad]
+    margin = torch.minimum((l1 - l2).abs(), (torch.maximum(l1, l2) - 0.1).abs())
+    assert bad.size <= 32 and (bad.size == 0 or float(margin.max()) < 1e-4), f'{bad.size} seg flips, max margin {float(margin.max()) if bad.size else 0}'
+    assert np.array_equal(np.stack(np.nonzero(out['endp'][0].numpy()), 1), np.stack(np.nonzero(ref['endp'][0].numpy()), 1))
