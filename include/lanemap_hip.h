@@ -123,6 +123,19 @@ int lm_polyline_assemble(const float* prop_conf, const float* prop_v_ext, const 
                          const float* bi_seg_rows, const int* endp_hw, int n_endp, int P, int R, float obj_thre,
                          int min_vertices, double* out_lanes, int* endp_keep);
 int lm_raster_polylines(const double* lanes, int P, int R, unsigned char* out);
+int lm_trace_lines(const double* cols, int n, int R, const float* seg_rows, double* out);   /* polyline_utils.py:222-387 */
+
+/* ---- K-Lane "RowRef" head, config 4 (baseline/models/heads/row_shared_not_reduc_ref.py) ------------------------
+ * softmax_rows :179-180,239-240 (in place); select :199-204; gather :207-211; scatter :227-230 (shrinking-range quirk);
+ * decode :334-363.  Layouts: x [B,H,W,8] NHWC, ext [B,H,L,2], cls [B,H,L,W], tokens [T][8*H*5] in (c h w) order,
+ * sel [T][2] = (b, lane), bstart [B+1] token ranges. */
+int lm_softmax_rows(void* stream, float* x, long rows, int cols);
+int lm_rowref_select(void* stream, const float* ext, const float* cls, float* mean_out, int* corr, int B, int H, int W, int L);
+int lm_rowref_gather(void* stream, const float* x_nhwc8, const int* corr, const int* sel, float* tok, int T, int H, int W, int L);
+int lm_rowref_scatter(void* stream, const float* x_nhwc8, const float* tok, const int* corr, const int* sel,
+                      const int* bstart, float* y_nhwc8, int B, int H, int W, int L);
+int lm_rowref_decode(void* stream, const float* ext2, const float* cls2, unsigned char* conf, unsigned char* cls_map,
+                     int* col_idx, int B, int H, int W, int L);
 
 #ifdef __cplusplus
 }

@@ -587,3 +587,14 @@ LM_API int lm_raster_polylines(const double* lanes /*[P][R][2]*/, int P, int R, 
         }
     return LM_OK;
 }
+
+// smooth_cls_line_per_batch alone (polyline_utils.py:222-387): used by the RowRef head (config 4), which calls it with
+// no segmentation confidence (seg_rows == NULL -> no occupancy filter) on its 12 lane rows.
+LM_API int lm_trace_lines(const double* cols /*[n][R]*/, int n, int R, const float* seg_rows /*[R][1152] or NULL*/, double* out) {
+    LM_REQUIRE(cols && out && n >= 1 && R * 8 == IMG, "trace_lines: bad args");
+    Lines C(n, R, 0.0);
+    std::memcpy(C.v.data(), cols, sizeof(double) * (size_t)n * R);
+    Lines L = trace_lines(C, seg_rows);
+    std::memcpy(out, L.v.data(), sizeof(double) * (size_t)n * R);
+    return LM_OK;
+}

@@ -50,3 +50,12 @@ def raster_semantic_map(lanes):
     out = np.empty((IMG, IMG), dtype=np.uint8)
     check(lib().lm_raster_polylines(_p(lanes), lanes.shape[0], lanes.shape[1], _p(out)))
     return out.astype(np.float64)
+
+
+def trace_lines(cols, seg_rows=None):
+    """[n,R] f64 column px (<= 0 = none) -> traced / merged / gap-filled lines [n,R] (reference smooth_cls_line_per_batch)."""
+    c = np.ascontiguousarray(cols, dtype=np.float64)
+    out = np.empty_like(c)
+    seg = None if seg_rows is None else np.ascontiguousarray(seg_rows, dtype=np.float32)
+    check(lib().lm_trace_lines(_p(c), c.shape[0], c.shape[1], None if seg is None else _p(seg), _p(out)))
+    return out

@@ -214,6 +214,54 @@ def g10(cfg, net):
          cls_offset_smooth=V)
 
 
+def g8(cfg, net):
+    """RowRef head (config 4): forward incl. the shrinking-range scatter, decode, label-free line assembly."""
+    cfg4 = _refload.load_cfg('configs/Proj28_GFC-T3_RowRef_82_73_laser.py', vit_seg=True, is_gt_avai=False)
+    from baseline.models.registry import build_heads
+    torch.manual_seed(2021)
+    head = build_heads(cfg4).eval()
+    synth.fill_module_(head, 2021, prefix='heads.')
+    x = cases.head_inputs(81, batch=2)[0]
+    with torch.no_grad():
+        out = head(torch.from_numpy(x))
+        dec = head.get_exist_coor_endp_dict(out)
+    keep = {}
+    for c in range(12):
+        keep[f'ext_mean_{c}'] = out[f'ext_{c}'][:, :, 0].mean(dim=1).numpy()
+        keep[f'ext2_{c}'] = out[f'ext2_{c}'].numpy()
+        keep[f'cls2_arg_{c}'] = out[f'cls2_{c}'].argmax(dim=2).numpy().astype(np.int16)
+        top2 = torch.topk(out[f'cls2_{c}'], 2, dim=2).values
+        keep[f'cls2_margin_{c}'] = (top2[..., 0] - top2[..., 1]).numpy()
+        keep[f'cls2_max_{c}'] = top2[..., 0].numpy()
+    conf, cls = dec['conf'].numpy(), dec['cls'].numpy()
+    # label-free part of get_lane_map_numpy_with_label (:487-516)
+    from baseline.utils.polyline_utils import smooth_cls_line_per_batch
+    lines = []
+    for b in range(2):
+        conf_pred = np.where(conf[b] > cfg4.conf_thr, 1, 0)
+        cls_idx = np.argmax(torch.nn.functional.softmax(torch.from_numpy(cls[b]), dim=0).numpy(), axis=0)
+        cls_idx[np.where(cls_idx == 12)] = 255
+        cci = cls_idx.copy()
+        cci[np.where(conf_pred == 0)] = 255
+        pl = np.zeros((12, 144)) - 1.0
+        for l in range(12):
+            px = np.where(cci == l)
+            pl[l, px[0]] = px[1] / 144 * 1152. + 4
+        lines.append(smooth_cls_line_per_batch(pl, np.zeros((144, 144)) + 5, complete_inner_nodes=True))
+    # second run with thr_ext = 0.5 so that only part of the lanes goes through the token transformer
+    head.thr_ext = 0.5
+    with torch.no_grad():
+        out5 = head(torch.from_numpy(x))
+        dec5 = head.get_exist_coor_endp_dict(out5)
+    keep['t5_selected'] = np.array([[float(out5[f'ext_{c}'][b, :, 0].mean()) > 0.5 for c in range(12)] for b in range(2)])
+    keep['t5_conf'] = dec5['conf'].numpy().astype(np.uint8)
+    keep['t5_cls'] = dec5['cls'].numpy().astype(np.uint8)
+    for c in range(12):
+        keep[f't5_ext2_{c}'] = out5[f'ext2_{c}'].numpy()
+    save('g8_rowref.npz', input_seed=81, weight_seed=2021, conf=conf.astype(np.uint8), cls=cls.astype(np.uint8),
+         pred_lines=np.stack(lines), **keep)
+
+
 def main():
     which = sys.argv[1:] or ['g2', 'g3', 'g4', 'g5', 'g6', 'g7', 'g10']
     _stable_sorts(True)

@@ -184,3 +184,28 @@ def test_param_file_parser(tmp_path):
     assert d['las_rotation_trans_quan'][3:] == [0.7071068, 0.0, 0.0, 0.7071068] and d['ele_reso'] == 0.02
     rp = io_utils.raster_params_from_file(str(p))
     assert abs(rp.quat[0] - 0.7071068) < 1e-7 and list(rp.trans) == [1.0, 2.0, 3.0] and abs(rp.local_min_ele + 2.5) < 1e-7
+
+
+def test_cpp_trace_lines_vs_rowref_golden(golden):
+    from oracle import rowref_ref
+    g = golden('g8_rowref.npz')
+    for b in range(2):
+        conf_pred = np.where(g['conf'][b] > 0.5, 1, 0)
+        cls_idx = np.argmax(torch.softmax(torch.from_numpy(g['cls'][b].astype(np.float64)), 0).numpy(), 0)
+        cls_idx[cls_idx == 12] = 255
+        cls_idx[conf_pred == 0] = 255
+        lines = np.zeros((12, 144)) - 1.0
+        for c in range(12):
+            r, w = np.nonzero(cls_idx == c)
+            lines[c, r] = w / 144 * 1152. + 4
+        assert np.array_equal(hostpost.trace_lines(lines), g['pred_lines'][b])
+
+
+def test_rowref_state_dict_layout():
+    from lanemapping_amd.boundary import build_net_from_config
+    net = build_net_from_config('Proj28_GFC-T3_RowRef_82_73_laser', device='cpu')
+    sd = net.state_dict()
+    assert tuple(sd['heads.cls2_11.2.weight'].shape) == (144, 512, 1) and tuple(sd['heads.to_token.1.weight'].shape) == (1024, 5760)
+    assert tuple(sd['heads.tr_lane_correlator.2.weight'].shape) == (5760, 1024)
+    assert not any('emb_' in k for k in sd)          # as on a real GPU in the reference: emb_c never reach a checkpoint
+    assert len([k for k in sd if k.startswith('heads.')]) == 449

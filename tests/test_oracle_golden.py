@@ -108,3 +108,36 @@ def test_g10_end_to_end(golden, synth_sd):
                                          d['cls_offset'][0].numpy(), d['bi_seg'][0].numpy(), d['endp'][0].numpy())
     np.testing.assert_allclose(V, g['cls_offset_smooth'], atol=1e-4)
     np.testing.assert_array_equal(np.stack(np.nonzero(E), axis=1).reshape(-1, 2), g['endp_final'].reshape(-1, 2))
+
+
+def test_g8_rowref_oracle(golden):
+    """RowRef head (config 4) oracle vs the reference: forward incl. the shrinking-range scatter, decode, lines."""
+    from lanemapping_amd.boundary import load_config
+    from lanemapping_amd.registry import build_heads
+    from oracle import rowref_ref
+    g = golden('g8_rowref.npz')
+    head = build_heads(load_config('Proj28_GFC-T3_RowRef_82_73_laser')).eval()
+    synth.fill_module_(head, 2021, prefix='heads.')
+
+    class Emb(torch.nn.Module):
+        def __init__(self):
+            super().__init__()
+            for c in range(12):
+                setattr(self, f'emb_{c}', torch.nn.Parameter(torch.zeros(1024)))
+    e = synth.fill_module_(Emb(), 2021, prefix='heads.')
+    sd = {'heads.' + k: v for k, v in head.state_dict().items()}
+    sd.update({f'heads.emb_{c}': getattr(e, f'emb_{c}').detach() for c in range(12)})
+    x = torch.from_numpy(cases.head_inputs(int(g['input_seed']), batch=2)[0])
+    with torch.no_grad():
+        out = rowref_ref.rowref_forward(sd, x)
+    for c in range(12):
+        np.testing.assert_allclose(out[f'ext2_{c}'].numpy(), g[f'ext2_{c}'], atol=1e-6)
+        np.testing.assert_array_equal(out[f'cls2_{c}'].argmax(dim=2).numpy(), g[f'cls2_arg_{c}'])
+    conf, cls = rowref_ref.rowref_decode(out)
+    np.testing.assert_array_equal(conf.astype(np.uint8), g['conf'])
+    np.testing.assert_array_equal(cls.astype(np.uint8), g['cls'])
+    for b in range(2):
+        np.testing.assert_array_equal(rowref_ref.rowref_pred_lines(conf[b], cls[b]), g['pred_lines'][b])
+    with torch.no_grad():
+        out5 = rowref_ref.rowref_forward(sd, x, thr_ext=0.5)
+    np.testing.assert_array_equal(rowref_ref.rowref_decode(out5)[0].astype(np.uint8), g['t5_conf'])
