@@ -80,6 +80,8 @@ def main():
     ap.add_argument('--cpu-budget-s', type=float, default=25.0)
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--host-threads', type=int, default=8)
+    ap.add_argument('--workload', choices=['tiles', 'fused'], default='tiles',
+                    help="tiles = BASELINE configs[1] (pre-rasterised, batch 8); fused = configs[2] (on-GPU LAS->BEV raster + net, batch 16)")
     ap.add_argument('--conv-detail', action='store_true', help='per-shape table of the MFMA launches on stderr')
     ap.add_argument('--no-roofline-events', action='store_true', help='skip the per-launch HIP events')
     args = ap.parse_args()
@@ -106,8 +108,18 @@ def main():
     synth.fill_module_(net, 2021)
     net = net.to(dev)
     # weak scaling: every rank owns its own BATCH tiles per step (seeds differ per rank)
-    tiles = torch.from_numpy(synth.bev_batch([2021 + rank * BATCH + i for i in range(BATCH)], 1152)).to(dev)
+    batch = BATCH if args.workload == 'tiles' else 16
+    N_PTS = 4194304
+    if args.workload == 'tiles':
+        tiles = torch.from_numpy(synth.bev_batch([2021 + rank * batch + i for i in range(batch)], 1152)).to(dev)
+    else:       # 4,194,304 LAS-shaped points per tile, resident in HBM (4 distinct clouds, repeated)
+        clouds = [torch.from_numpy(synth.las_points(2021 + rank * 4 + i, N_PTS)) for i in range(4)]
+        points = torch.cat([clouds[i % 4] for i in range(batch)]).to(dev)
+        offs = [i * N_PTS for i in range(batch + 1)]
+        rpar = [ops.make_raster_params(local_min_ele=-0.5, ele_reso=0.02)] * batch
+        tiles = torch.empty((batch, 3, 1152, 1152), device=dev)
     pipe = TilePipeline(net, host_threads=args.host_threads)
+    rast = {'pairs': []}
 
     # ---- roofline instrumentation: HIP events (on the launch stream) around every MFMA conv/GEMM launch ----
     prof = {'on': False, 'pairs': [], 'flops': 0.0, 'launches': 0}
@@ -126,17 +138,24 @@ def main():
     ops.set_conv_hook(hook)
 
     def step():
+        if args.workload == 'fused':
+            a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            a.record()
+            ops.bev_raster_batch(points, offs, rpar, out=tiles)
+            b.record()
+            if prof['on']:
+                rast['pairs'].append((a, b))
         futs = pipe.submit(tiles)
         res = [f.result() for f in futs]
         if world > 1 and res:
-            blocks = shard.pack_tile_results([r[0] for r in res], [r[1] for r in res], BATCH, dev)
+            blocks = shard.pack_tile_results([r[0] for r in res], [r[1] for r in res], batch, dev)
             shard.all_gather_results(*blocks)
         return res
 
     def drain():
         res = [f.result() for f in pipe.flush()]
         if world > 1 and res:
-            blocks = shard.pack_tile_results([r[0] for r in res], [r[1] for r in res], BATCH, dev)
+            blocks = shard.pack_tile_results([r[0] for r in res], [r[1] for r in res], batch, dev)
             shard.all_gather_results(*blocks)
         return res
 
@@ -174,13 +193,15 @@ def main():
     achieved = prof['flops'] / (conv_ms * 1e-3) / 1e12 if conv_ms > 0 else 0.0
     n_lines = int(np.mean([(np.count_nonzero(l[:, :, 0] > 0, axis=1) >= 2).sum() for l, _ in last])) if last else 0
     result = {
-        'metric': 'BEV tiles/sec end-to-end (pre-rasterised tile -> polylines)', 'value': world * BATCH * args.steps / dt,
+        'metric': 'BEV tiles/sec end-to-end (pre-rasterised tile -> polylines)', 'value': world * batch * args.steps / dt,
         'unit': 'tiles/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
         'ms_per_step': dt / args.steps * 1e3, 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
         'dtype': 'f32', 'data': 'synthetic',
-        'config': {'workload': 'configs/Proj_polyline_fpn_vit_vertex_2.py inference, batch=8 per GPU, pre-rasterised '
-                               'synthetic 1152x1152 BEV tiles resident in HBM, seeded random weights',
-                   'tiles_per_step_per_gpu': BATCH, 'lines_per_tile': n_lines, 'host_threads': args.host_threads},
+        'config': {'workload': ('configs/Proj_polyline_fpn_vit_vertex_2.py inference, batch=8 per GPU, pre-rasterised '
+                                'synthetic 1152x1152 BEV tiles resident in HBM, seeded random weights') if args.workload == 'tiles'
+                   else ('on-GPU LAS->BEV raster (4,194,304 points/tile resident in HBM) + configs/Proj_polyline_fpn_vit_vertex_2.py, '
+                         'batch=16 per GPU, seeded random weights'),
+                   'tiles_per_step_per_gpu': batch, 'lines_per_tile': n_lines, 'host_threads': args.host_threads},
         'roofline': {'bound': 'mfma', 'kernel': 'conv_mfma_kernel (all FPN/ViT/head implicit-GEMM launches)',
                      'achieved': achieved, 'peak': MFMA_F32_PEAK_TFLOPS, 'unit': 'TFLOP/s',
                      'frac': achieved / MFMA_F32_PEAK_TFLOPS, 'traffic': None,
@@ -188,6 +209,12 @@ def main():
                      'gflop_per_step': prof['flops'] / max(args.steps, 1) / 1e9,
                      'kernel_ms_per_step': conv_ms / max(args.steps, 1)},
     }
+    if args.workload == 'fused' and rast['pairs']:
+        rms = sum(a.elapsed_time(b) for a, b in rast['pairs']) / len(rast['pairs'])
+        alg = (16.0 * N_PTS + 3 * 1152 * 1152 * 4) * batch
+        result['raster_roofline'] = {'bound': 'hbm', 'kernel': 'raster_partition_kernel + raster_band_kernel',
+                                     'achieved': alg / (rms * 1e-3) / 1e9, 'peak': 8000.0, 'unit': 'GB/s',
+                                     'frac': alg / (rms * 1e-3) / 1e9 / 8000.0, 'traffic': None, 'ms_per_step': rms}
     if rank == 0:
         if world == 1 and not args.no_cpu_baseline:
             result['cpu_baseline'] = cpu_baseline(args.cpu_budget_s)
