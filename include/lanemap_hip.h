@@ -37,6 +37,13 @@ int lm_conv2d_nhwc_mfma_f32(void* stream, const float* x, int ldx, const float* 
                             float* y, int ldy, int B, int H, int W, int Cin, int Cout, int KH, int KW,
                             int stride, int pad_h, int pad_w, int dil, int act);
 
+/* Same convolution + first pass of GroupNorm(C,C) (postprojector.py:512-515,608-647): also writes per (image, 64-row
+ * chunk, channel) sum / sum of squares of the outputs, gn_partial [B][Ho*Wo/64][Cout][2] doubles -> lm_gn_finalize. */
+int lm_conv2d_nhwc_mfma_f32_gnstats(void* stream, const float* x, int ldx, const float* wp, int CoutP, const float* shift,
+                                    float* y, int ldy, double* gn_partial, int B, int H, int W, int Cin, int Cout,
+                                    int KH, int KW, int stride, int pad_h, int pad_w, int dil);
+int lm_gn_finalize(void* stream, const double* partial, float* stats, int B, int HW, int C, int nchunk, float eps);
+
 /* ---- thin layers ---------------------------------------------------------------------------------------------
  * stem: relu(bn1(conv1(x))) for planar x [B,3,H,W] -> NHWC [B,H/2,W/2,64]; w_k64 = [7][7][3][64]
  * (postprojector.py:458-460,566).  maxpool: 3x3 stride 2 pad 1 (:461,567).

@@ -33,6 +33,8 @@ struct ConvParams {
     int B, H, W, Cin, Cout, CoutP, Ho, Wo;
     int KH, KW, stride, pad_h, pad_w, dil, act;
     long M;
+    double* gn_part;   // optional [B][chunks][Cout][2] per-channel (sum, sum of squares) of the outputs of each wave tile
+    int gn_chunks;     // chunks per batch element = (Ho*Wo / BM) * (BM / WM)
 };
 
 __device__ __forceinline__ float gelu_erf(float v) { return 0.5f * v * (1.0f + erff(v * 0.70710678118654752440f)); }
@@ -178,6 +180,7 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64) void conv_mfma_kernel(C
                 if (p.scale) sc[e] = p.scale[n + e];
                 if (p.shift) sh[e] = p.shift[n + e];
             }
+        f32x4 gs = {0.f, 0.f, 0.f, 0.f}, gq = {0.f, 0.f, 0.f, 0.f};   // GroupNorm(C,C) statistics of this wave tile
 #pragma unroll
         for (int pass = 0; pass < WM / RPI; ++pass) {
             const int row = pass * RPI + lane / LPR;
@@ -186,6 +189,13 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64) void conv_mfma_kernel(C
             f32x4 v = *reinterpret_cast<const f32x4*>(stage + row * ELD + c4);
 #pragma unroll
             for (int e = 0; e < 4; ++e) v[e] = p.scale ? v[e] * sc[e] + sh[e] : v[e] + sh[e];
+            if (p.gn_part) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    gs[e] += v[e];
+                    gq[e] = fmaf(v[e], v[e], gq[e]);
+                }
+            }
             const long rrow = p.res_rows ? (m % p.res_rows) : m;
             if (vec) {
                 if (p.res) {
@@ -206,6 +216,26 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64) void conv_mfma_kernel(C
                     if (p.act == LM_ACT_RELU) u = fmaxf(u, 0.f);
                     else if (p.act == LM_ACT_GELU) u = gelu_erf(u);
                     p.y[m * p.ldy + n + e] = u;
+                }
+            }
+        }
+        if (p.gn_part) {   // fixed-order reduction over the RPI lanes that share a channel quad, then one writer lane
+#pragma unroll
+            for (int o = LPR; o < 64; o <<= 1)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    gs[e] += __shfl_xor(gs[e], o);
+                    gq[e] += __shfl_xor(gq[e], o);
+                }
+            if (lane < LPR) {
+                const long hw = (long)p.Ho * p.Wo;
+                const long mt = m0 + wm0;                       // first row of this wave tile (tiles never straddle images)
+                const long b = mt / hw;
+                const long chunk = (mt - b * hw) / WM;
+                double* o = p.gn_part + ((b * p.gn_chunks + chunk) * p.Cout + n) * 2;
+                for (int e = 0; e < 4 && n + e < p.Cout; ++e) {
+                    o[2 * e] = (double)gs[e];
+                    o[2 * e + 1] = (double)gq[e];
                 }
             }
         }
@@ -231,11 +261,9 @@ int launch(const ConvParams& p, hipStream_t stream) {
 
 }  // namespace
 
-LM_API int lm_conv2d_nhwc_mfma_f32(void* stream, const float* x, int ldx, const float* wp, int CoutP,
-                                   const float* scale, const float* shift,
-                                   const float* res, int ldr, int res_rows, float* y, int ldy,
-                                   int B, int H, int W, int Cin, int Cout, int KH, int KW,
-                                   int stride, int pad_h, int pad_w, int dil, int act) {
+static int conv_dispatch(void* stream, const float* x, int ldx, const float* wp, int CoutP, const float* scale, const float* shift,
+                         const float* res, int ldr, int res_rows, float* y, int ldy, int B, int H, int W, int Cin, int Cout,
+                         int KH, int KW, int stride, int pad_h, int pad_w, int dil, int act, double* gn_part) {
     LM_REQUIRE(x && wp && y, "conv_mfma: null pointer");
     LM_REQUIRE(Cin > 0 && Cin % BK == 0, "conv_mfma: Cin=%d must be a multiple of %d", Cin, BK);
     LM_REQUIRE(CoutP >= Cout && CoutP % 128 == 0, "conv_mfma: CoutP=%d must be Cout=%d rounded up to 128", CoutP, Cout);
@@ -250,10 +278,38 @@ LM_API int lm_conv2d_nhwc_mfma_f32(void* stream, const float* x, int ldx, const 
     LM_REQUIRE(p.Ho > 0 && p.Wo > 0, "conv_mfma: empty output");
     p.KH = KH; p.KW = KW; p.stride = stride; p.pad_h = pad_h; p.pad_w = pad_w; p.dil = dil; p.act = act;
     p.M = (long)B * p.Ho * p.Wo;
+    p.gn_part = gn_part;
+    p.gn_chunks = 0;
     hipStream_t s = (hipStream_t)stream;
+    if (gn_part) {   // statistics mode: 128x128 tiles of 64-row wave tiles, images must be whole numbers of tiles
+        LM_REQUIRE(Cout > 64 && Cout % 4 == 0 && ((long)p.Ho * p.Wo) % 128 == 0 && res == nullptr && act == LM_ACT_NONE,
+                   "conv_mfma(gn stats): needs Cout > 64, Ho*Wo %% 128 == 0, no residual / activation");
+        p.gn_chunks = (int)((long)p.Ho * p.Wo / 64);
+        return launch<128, 128, 64, 64>(p, s);
+    }
     if (Cout <= 64) return launch<128, 64, 32, 64>(p, s);
     // small-M GEMMs (ViT tokens): 128x128 tiles would leave most of the 256 CUs idle -> 64x64 tiles, 4x the workgroups
     const long big_blocks = ((p.M + 127) / 128) * ((Cout + 127) / 128);
     if (big_blocks < 512) return launch<64, 64, 32, 32>(p, s);
     return launch<128, 128, 64, 64>(p, s);
+}
+
+LM_API int lm_conv2d_nhwc_mfma_f32(void* stream, const float* x, int ldx, const float* wp, int CoutP,
+                                   const float* scale, const float* shift,
+                                   const float* res, int ldr, int res_rows, float* y, int ldy,
+                                   int B, int H, int W, int Cin, int Cout, int KH, int KW,
+                                   int stride, int pad_h, int pad_w, int dil, int act) {
+    return conv_dispatch(stream, x, ldx, wp, CoutP, scale, shift, res, ldr, res_rows, y, ldy, B, H, W, Cin, Cout, KH, KW, stride,
+                         pad_h, pad_w, dil, act, nullptr);
+}
+
+// Same convolution, additionally emitting the per-(image, 64-row chunk, channel) sum / sum of squares of its outputs:
+// the first pass of GroupNorm(C groups == C channels) (postprojector.py:512-515) without re-reading the tensor.
+// gn_partial: [B][Ho*Wo/64][Cout][2] doubles; finish with lm_gn_finalize.
+LM_API int lm_conv2d_nhwc_mfma_f32_gnstats(void* stream, const float* x, int ldx, const float* wp, int CoutP, const float* shift,
+                                           float* y, int ldy, double* gn_partial, int B, int H, int W, int Cin, int Cout,
+                                           int KH, int KW, int stride, int pad_h, int pad_w, int dil) {
+    LM_REQUIRE(gn_partial, "conv_mfma(gn stats): null partial buffer");
+    return conv_dispatch(stream, x, ldx, wp, CoutP, nullptr, shift, nullptr, 0, 0, y, ldy, B, H, W, Cin, Cout, KH, KW, stride,
+                         pad_h, pad_w, dil, LM_ACT_NONE, gn_partial);
 }

@@ -60,15 +60,27 @@ __global__ __launch_bounds__(256) void gn_partial_kernel(const float* __restrict
     }
 }
 
-__global__ void gn_final_kernel(const double* __restrict__ part, float* __restrict__ stats, int HW, int C,
-                                int nchunk, float eps) {
-    const int b = blockIdx.x;
-    for (int c = threadIdx.x; c < C; c += blockDim.x) {
-        double s = 0.0, ss = 0.0;
-        for (int k = 0; k < nchunk; ++k) {
+// grid (ceil(C/32), B), 256 threads = 8 chunk lanes x 32 channels; fixed summation order => deterministic
+__global__ __launch_bounds__(256) void gn_final_kernel(const double* __restrict__ part, float* __restrict__ stats, int HW, int C,
+                                                       int nchunk, float eps) {
+    __shared__ double red[2][8][32];
+    const int b = blockIdx.y;
+    const int cl = threadIdx.x & 31, kl = threadIdx.x >> 5;
+    const int c = blockIdx.x * 32 + cl;
+    double s = 0.0, ss = 0.0;
+    if (c < C)
+        for (int k = kl; k < nchunk; k += 8) {
             const double* o = part + (((long)b * nchunk + k) * C + c) * 2;
             s += o[0];
             ss += o[1];
+        }
+    red[0][kl][cl] = s;
+    red[1][kl][cl] = ss;
+    __syncthreads();
+    if (kl == 0 && c < C) {
+        for (int q = 1; q < 8; ++q) {
+            s += red[0][q][cl];
+            ss += red[1][q][cl];
         }
         const double mean = s / HW;
         double var = ss / HW - mean * mean;
@@ -235,7 +247,15 @@ LM_API int lm_gn_stats(void* stream, const float* x, double* workspace, float* s
     const int nchunk = lm_cdiv(HW, GN_CHUNK);
     hipLaunchKernelGGL(gn_partial_kernel, dim3(nchunk, B), dim3(256), 0, (hipStream_t)stream, x, workspace, HW, C, nchunk);
     LM_LAUNCH_CHECK();
-    hipLaunchKernelGGL(gn_final_kernel, dim3(B), dim3(256), 0, (hipStream_t)stream, workspace, stats, HW, C, nchunk, eps);
+    hipLaunchKernelGGL(gn_final_kernel, dim3(lm_cdiv(C, 32), B), dim3(256), 0, (hipStream_t)stream, workspace, stats, HW, C, nchunk, eps);
+    LM_LAUNCH_CHECK();
+    return LM_OK;
+}
+
+// second pass for partials produced by lm_conv2d_nhwc_mfma_f32_gnstats ([B][nchunk][C][2] doubles)
+LM_API int lm_gn_finalize(void* stream, const double* partial, float* stats, int B, int HW, int C, int nchunk, float eps) {
+    LM_REQUIRE(partial && stats && nchunk >= 1, "gn_finalize: bad args");
+    hipLaunchKernelGGL(gn_final_kernel, dim3(lm_cdiv(C, 32), B), dim3(256), 0, (hipStream_t)stream, partial, stats, HW, C, nchunk, eps);
     LM_LAUNCH_CHECK();
     return LM_OK;
 }

@@ -112,6 +112,27 @@ def conv_mfma(x, wp, cout, kh=1, kw=1, stride=1, pad=0, dil=1, scale=None, shift
     return out
 
 
+def conv_mfma_gnstats(x, wp, cout, kh, kw, stride, pad, dil, shift, eps=1e-5):
+    """conv (+bias) and, from the same kernel, the GroupNorm(C,C) statistics of its output -> (y, stats [B,C,2])."""
+    x, ldx = as_nhwc(x)
+    B, cin, H, W = x.shape
+    Ho = (H + 2 * pad - dil * (kh - 1) - 1) // stride + 1
+    Wo = (W + 2 * pad - dil * (kw - 1) - 1) // stride + 1
+    out = new_act(B, cout, Ho, Wo, x.device)
+    nchunk = Ho * Wo // 64
+    part = torch.empty((B, nchunk, cout, 2), device=x.device, dtype=torch.float64)
+    stats = torch.empty((B, cout, 2), device=x.device, dtype=torch.float32)
+    def launch():
+        check(lib().lm_conv2d_nhwc_mfma_f32_gnstats(_stream(), _ptr(x), ldx, _ptr(wp), wp.shape[1], _ptr(shift), _ptr(out), cout,
+                                                    _ptr(part), B, H, W, cin, cout, kh, kw, stride, pad, pad, dil))
+    if _conv_hook is not None:
+        _conv_hook(f'conv+gn {cin}->{cout} k{kh}x{kw} s{stride} d{dil} @{H}x{W} B{B}', 2.0 * B * Ho * Wo * cout * cin * kh * kw, launch)
+    else:
+        launch()
+    check(lib().lm_gn_finalize(_stream(), _ptr(part), _ptr(stats), B, Ho * Wo, cout, nchunk, eps))
+    return out, stats
+
+
 def linear_mfma(x2d, wp, n_out, scale=None, shift=None, res=None, res_rows=0, act=ACT_NONE, out=None):
     """y[M,n_out] = act((x2d @ W^T) * scale + shift + res).  x2d [M,K] row-major (K % 32 == 0)."""
     assert x2d.dim() == 2 and x2d.stride(1) == 1

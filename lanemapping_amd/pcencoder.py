@@ -7,7 +7,8 @@ reference checkpoint loads with ``strict=True``.  The arithmetic runs in liblane
 
   stem 7x7+BN+ReLU, max-pool                      -> lm_stem_conv7x7_bn_relu, lm_maxpool3x3s2_nhwc
   BasicBlocks, lateral/top/smooth/semantic convs  -> lm_conv2d_nhwc_mfma_f32 (BN / bias / residual / ReLU epilogue)
-  GroupNorm(C,C)+ReLU+bilinear(+sum of branches)  -> lm_gn_stats + lm_gn_relu_upsample
+  GroupNorm(C,C)+ReLU+bilinear(+sum of branches)  -> lm_conv2d_nhwc_mfma_f32_gnstats + lm_gn_finalize (statistics out of the
+                                                     conv epilogue) / lm_gn_stats, then lm_gn_relu_upsample
   1x1 heads (128->8, 8->3, 128->1)                -> lm_conv2d_nhwc_small
   final 4x bilinear to the tile resolution        -> lm_upsample_bilinear_to_chw
 """
@@ -154,16 +155,20 @@ class FPNEncoder(PackedModule):
         h, w = p2.shape[2:]
         c_half = self.semantic_branch.out_channels
 
-        def gn_up(t, gn, out=None, acc=False):
-            st = ops.gn_stats(t, getattr(self, gn).eps)
+        def conv_gn_up(src, conv, cout, gn, out=None, acc=False):
+            # conv3x3 + bias with the GroupNorm statistics coming out of the conv epilogue, then GN + ReLU + bilinear (+=)
+            eps = getattr(self, gn).eps
+            if (src.shape[2] * src.shape[3]) % 128 == 0:      # whole 128-row tiles per image: statistics from the epilogue
+                t, st = ops.conv_mfma_gnstats(src, P[conv + '.w'], cout, 3, 3, 1, 1, 1, P[conv + '.b'], eps)
+            else:                                              # ragged image size: separate statistics kernel
+                t = self._conv3(src, P, conv, cout)
+                st = ops.gn_stats(t, eps)
             return ops.gn_relu_upsample(t, st, P[gn + '.g'], P[gn + '.b'], (h, w), out=out, accumulate=acc)
 
-        s4 = gn_up(self._conv3(p4, P, conv_a, p4.shape[1]), gn_a)            # 256 ch at 288^2
-        t2 = self._conv3(p2, P, conv_b, c_half)
-        total = gn_up(t2, gn_b)                                               # s2
-        del t2
-        total = gn_up(self._conv3(p3, P, conv_b, c_half), gn_b, out=total, acc=True)    # + s3
-        total = gn_up(self._conv3(s4, P, conv_b, c_half), gn_b, out=total, acc=True)    # + s4
+        s4 = conv_gn_up(p4, conv_a, p4.shape[1], gn_a)                        # 256 ch at 288^2
+        total = conv_gn_up(p2, conv_b, c_half, gn_b)                          # s2
+        total = conv_gn_up(p3, conv_b, c_half, gn_b, out=total, acc=True)     # + s3
+        total = conv_gn_up(s4, conv_b, c_half, gn_b, out=total, acc=True)     # + s4
         return total
 
     def forward(self, x, fea_up_out=None):
