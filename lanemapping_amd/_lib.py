@@ -7,7 +7,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, 'liblanemap_hip.so')
+LIB_PATH = os.environ.get('LANEMAP_HIP_LIB') or os.path.join(_HERE, 'liblanemap_hip.so')   # override: kernel experiments only
 
 c_f32p = C.POINTER(C.c_float)
 vp, i32, i64, f32 = C.c_void_p, C.c_int, C.c_long, C.c_float

@@ -12,11 +12,13 @@
 //
 // Design (gfx950): 256 threads = 4 waves, one per SIMD; each wave owns a WM x WN output tile made of
 // 32x32 accumulators driven by v_mfma_f32_32x32x2_f32 (exact f32, 64 FLOP/clk/SIMD = chip f32 peak).
-// K is walked one (tap, 32-channel) slab at a time: global -> registers (next slab, issued before the
-// MFMA block) -> LDS [rows][32+4] (double-buffered, one barrier per slab) -> ds_read_b128 fragments:
-// one 16-byte read per operand row feeds 4 MFMAs (lanes 0-31 hold k..k+3, lanes 32-63 k+4..k+7).
-// The +4 float row pad makes both the ds_write_b128 (8-lane groups) and the ds_read_b128 (16-lane
-// groups) bank-conflict free.  The summation order over k is fixed => results are deterministic.
+// K is walked one (tap, 32-channel) slab at a time.  The next slab goes global -> LDS directly
+// (global_load_lds_dwordx4: no staging registers, no ds_write; ablation showed the register-staged ds_write pass
+// alone cost 9 % of the MFMA issue slots), double-buffered, one barrier per slab.  The LDS image is lane-linear
+// ([rows][32] floats, 8 lanes x 16 B per row), so bank conflicts are avoided by an XOR swizzle applied to the SOURCE
+// address (lane p of row r fetches 16-byte chunk p ^ ((r>>1)&7)) and to the ds_read_b128 fragment address.
+// One 16-byte read per operand row feeds 4 MFMAs (lanes 0-31 hold k..k+3, lanes 32-63 k+4..k+7).  Out-of-image taps
+// (zero padding) fetch from a 16-byte zero block.  The summation order over k is fixed => deterministic results.
 #include "common.h"
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -25,7 +27,9 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 namespace {
 
 constexpr int BK = 32;         // k-slab: 32 input channels of one tap
-constexpr int LDS_LD = BK + 4; // padded row (floats)
+constexpr int LDS_LD = BK;     // unpadded, lane-linear rows (floats): required by global_load_lds
+
+__device__ __attribute__((aligned(16))) float g_zero_chunk[4] = {0.f, 0.f, 0.f, 0.f};   // source of zero-padding taps
 
 struct ConvParams {
     const float* x; const float* wp; const float* scale; const float* shift; const float* res; float* y;
@@ -62,8 +66,9 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64) void conv_mfma_kernel(C
     const int n0 = (blockIdx.x % n_tiles) * BN;
 
     // --- per-thread gather coordinates (tap independent part) ---
-    const int lrow = tid >> 3;        // 0..RPP-1
-    const int lc4 = (tid & 7) * 4;    // channel offset within the slab
+    static_assert(RPP == 32, "swizzle below assumes 32 rows per load pass (256 threads)");
+    const int lrow = tid >> 3;                               // 0..31: row inside a load pass
+    const int lc4 = (((tid & 7) ^ ((lrow >> 1) & 7))) * 4;   // swizzled source chunk (floats) for LDS slot tid & 7
     int a_iy0[A_LOADS], a_ix0[A_LOADS];
     long a_boff[A_LOADS];
 #pragma unroll
@@ -86,32 +91,25 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64) void conv_mfma_kernel(C
     const int cslabs = p.Cin / BK;
     const int KT = p.KH * p.KW * cslabs;
 
-    f32x4 ra[A_LOADS], rb[B_LOADS];
-    auto gload = [&](int kt) {
+    typedef __attribute__((address_space(1))) const void gptr_t;
+    typedef __attribute__((address_space(3))) void lptr_t;
+    auto gload = [&](int kt, int buf) {   // global -> LDS, one 1 KiB (8 rows x 128 B) piece per wave-instruction
         const int tap = kt / cslabs;
         const int c0 = (kt - tap * cslabs) * BK + lc4;
         const int dy = (tap / p.KW) * p.dil, dx = (tap % p.KW) * p.dil;
 #pragma unroll
         for (int i = 0; i < A_LOADS; ++i) {
             const int iy = a_iy0[i] + dy, ix = a_ix0[i] + dx;
-            f32x4 v = {0.f, 0.f, 0.f, 0.f};
-            if ((unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W)
-                v = *reinterpret_cast<const f32x4*>(p.x + (a_boff[i] + (long)iy * p.W + ix) * p.ldx + c0);
-            ra[i] = v;
+            const bool ok = (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W;
+            const float* src = ok ? p.x + (a_boff[i] + (long)iy * p.W + ix) * p.ldx + c0 : g_zero_chunk;
+            __builtin_amdgcn_global_load_lds((gptr_t*)src, (lptr_t*)(As + (buf * BM + i * RPP + wave * 8) * LDS_LD), 16, 0, 0);
         }
 #pragma unroll
         for (int i = 0; i < B_LOADS; ++i) {
             const int n = n0 + lrow + i * RPP;
-            rb[i] = *reinterpret_cast<const f32x4*>(p.wp + ((long)tap * p.CoutP + n) * p.Cin + c0);
+            const float* src = p.wp + ((long)tap * p.CoutP + n) * p.Cin + c0;
+            __builtin_amdgcn_global_load_lds((gptr_t*)src, (lptr_t*)(Bs + (buf * BN + i * RPP + wave * 8) * LDS_LD), 16, 0, 0);
         }
-    };
-    auto lstore = [&](int buf) {
-#pragma unroll
-        for (int i = 0; i < A_LOADS; ++i)
-            *reinterpret_cast<f32x4*>(As + (buf * BM + lrow + i * RPP) * LDS_LD + lc4) = ra[i];
-#pragma unroll
-        for (int i = 0; i < B_LOADS; ++i)
-            *reinterpret_cast<f32x4*>(Bs + (buf * BN + lrow + i * RPP) * LDS_LD + lc4) = rb[i];
     };
 
     f32x16 acc[TM][TN];
@@ -122,24 +120,25 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64) void conv_mfma_kernel(C
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-    gload(0);
-    lstore(0);
+    gload(0, 0);
     __syncthreads();
 
     const int frow = lane & 31;
-    const int fk = (lane >> 5) * 4;
+    const int fswz = (frow >> 1) & 7;          // wm0, wn0 and i*32 are multiples of 32: the swizzle depends on frow only
+    const int fhalf = lane >> 5;
     for (int kt = 0; kt < KT; ++kt) {
         const int buf = kt & 1;
-        if (kt + 1 < KT) gload(kt + 1);   // next slab in flight under the MFMA block
-        const float* Ab = As + (buf * BM + wm0 + frow) * LDS_LD + fk;
-        const float* Bb = Bs + (buf * BN + wn0 + frow) * LDS_LD + fk;
+        if (kt + 1 < KT) gload(kt + 1, buf ^ 1);   // next slab lands in the other buffer under the MFMA block
+        const float* Ab = As + (buf * BM + wm0 + frow) * LDS_LD;
+        const float* Bb = Bs + (buf * BN + wn0 + frow) * LDS_LD;
 #pragma unroll
         for (int kk = 0; kk < BK; kk += 8) {
+            const int fo = (((kk >> 2) + fhalf) ^ fswz) * 4;   // physical position of logical 16-byte chunk kk/4 + half
             f32x4 af[TM], bf[TN];
 #pragma unroll
-            for (int i = 0; i < TM; ++i) af[i] = *reinterpret_cast<const f32x4*>(Ab + i * 32 * LDS_LD + kk);
+            for (int i = 0; i < TM; ++i) af[i] = *reinterpret_cast<const f32x4*>(Ab + i * 32 * LDS_LD + fo);
 #pragma unroll
-            for (int j = 0; j < TN; ++j) bf[j] = *reinterpret_cast<const f32x4*>(Bb + j * 32 * LDS_LD + kk);
+            for (int j = 0; j < TN; ++j) bf[j] = *reinterpret_cast<const f32x4*>(Bb + j * 32 * LDS_LD + fo);
 #pragma unroll
             for (int t = 0; t < 4; ++t)
 #pragma unroll
@@ -148,15 +147,14 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64) void conv_mfma_kernel(C
                     for (int j = 0; j < TN; ++j)
                         acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i][t], bf[j][t], acc[i][j], 0, 0, 0);
         }
-        if (kt + 1 < KT) lstore(buf ^ 1);
-        __syncthreads();
+        __syncthreads();   // drains the global_load_lds queue (vmcnt 0) and fences the buffer swap
     }
 
     // --- epilogue: each wave transposes its WM x WN accumulator tile through (now idle) LDS so that every lane owns 4
     // consecutive output channels of one pixel: residual loads and output stores become coalesced 16-byte accesses
     // (the raw MFMA layout gives 4-byte stores, which made the thin 1x1 layers store-issue bound).
     constexpr int ELD = WN + 4;
-    static_assert((NT / 64) * WM * ELD <= 2 * (BM + BN) * LDS_LD, "epilogue staging must fit the K-loop LDS");
+    // (the launch sizes the dynamic LDS as max(K-loop buffers, 4 staging tiles))
     float* stage = smem + wave * (WM * ELD);
     const int half = lane >> 5;
 #pragma unroll
@@ -244,7 +242,8 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64) void conv_mfma_kernel(C
 
 template <int BM, int BN, int WM, int WN>
 int launch(const ConvParams& p, hipStream_t stream) {
-    const size_t lds = (size_t)2 * (BM + BN) * LDS_LD * sizeof(float);
+    const size_t kloop = (size_t)2 * (BM + BN) * LDS_LD, stage = (size_t)4 * WM * (WN + 4);   // floats
+    const size_t lds = (kloop > stage ? kloop : stage) * sizeof(float);
     static bool attr_set = false;
     if (!attr_set) {
         LM_HIP(hipFuncSetAttribute((const void*)conv_mfma_kernel<BM, BN, WM, WN>,
