@@ -82,6 +82,7 @@ def main():
     ap.add_argument('--host-threads', type=int, default=8)
     ap.add_argument('--workload', choices=['tiles', 'fused'], default='tiles',
                     help="tiles = BASELINE configs[1] (pre-rasterised, batch 8); fused = configs[2] (on-GPU LAS->BEV raster + net, batch 16)")
+    ap.add_argument('--streams', type=int, default=2, help='split every batch over this many HIP streams (fills launch tails)')
     ap.add_argument('--conv-detail', action='store_true', help='per-shape table of the MFMA launches on stderr')
     ap.add_argument('--no-roofline-events', action='store_true', help='skip the per-launch HIP events')
     args = ap.parse_args()
@@ -119,7 +120,10 @@ def main():
         rpar = [ops.make_raster_params(local_min_ele=-0.5, ele_reso=0.02)] * batch
         tiles = torch.empty((batch, 3, 1152, 1152), device=dev)
     pipe = TilePipeline(net, host_threads=args.host_threads)
-    rast = {'pairs': []}
+    nstream = max(1, args.streams)
+    extra_streams = [torch.cuda.Stream(device=dev) for _ in range(nstream - 1)]
+    extra_pipes = [TilePipeline(net, host_threads=args.host_threads) for _ in range(nstream - 1)]
+    rast = {'pairs': [], 'on': False}
 
     # ---- roofline instrumentation: HIP events (on the launch stream) around every MFMA conv/GEMM launch ----
     prof = {'on': False, 'pairs': [], 'flops': 0.0, 'launches': 0}
@@ -137,15 +141,49 @@ def main():
             launch()
     ops.set_conv_hook(hook)
 
+    # Stream choreography: sub-batches are independent, so streams never wait for each other in the tiles workload.
+    # Fused workload: the raster (main stream) fills one of two alternating tile buffers; a sub-stream waits for the
+    # raster's event, and the raster waits for the sub-streams' readers of the same buffer from two steps earlier.
+    tile_bufs = [tiles, torch.empty_like(tiles)] if args.workload == 'fused' else [tiles, tiles]
+    done = [[None, None] for _ in extra_streams]
+    state = {'i': 0}
+
     def step():
+        par = state['i'] & 1
+        state['i'] += 1
+        cur = tile_bufs[par]
+        main = torch.cuda.current_stream()
+        ready = None
         if args.workload == 'fused':
+            for d in done:
+                if d[par] is not None:
+                    main.wait_event(d[par])
             a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             a.record()
-            ops.bev_raster_batch(points, offs, rpar, out=tiles)
+            ops.bev_raster_batch(points, offs, rpar, out=cur)
             b.record()
-            if prof['on']:
+            ready = b
+            if rast['on']:
                 rast['pairs'].append((a, b))
-        futs = pipe.submit(tiles)
+        if nstream == 1:
+            futs = pipe.submit(cur)
+        else:       # independent sub-batches on separate streams: kernels of one fill the partial last wave of the other
+            per = batch // nstream
+            futs = []
+            for si in range(nstream):
+                sub = cur[si * per:(si + 1) * per]
+                if si == 0:
+                    futs += pipe.submit(sub)
+                else:
+                    es = extra_streams[si - 1]
+                    if ready is not None:
+                        es.wait_event(ready)
+                    with torch.cuda.stream(es):
+                        futs += extra_pipes[si - 1].submit(sub)
+                        if args.workload == 'fused':
+                            ev = torch.cuda.Event()
+                            ev.record()
+                            done[si - 1][par] = ev
         res = [f.result() for f in futs]
         if world > 1 and res:
             blocks = shard.pack_tile_results([r[0] for r in res], [r[1] for r in res], batch, dev)
@@ -153,7 +191,11 @@ def main():
         return res
 
     def drain():
-        res = [f.result() for f in pipe.flush()]
+        futs = pipe.flush()
+        for si, ep in enumerate(extra_pipes):
+            with torch.cuda.stream(extra_streams[si]):
+                futs += ep.flush()
+        res = [f.result() for f in futs]
         if world > 1 and res:
             blocks = shard.pack_tile_results([r[0] for r in res], [r[1] for r in res], batch, dev)
             shard.all_gather_results(*blocks)
@@ -165,7 +207,8 @@ def main():
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
-    prof['on'] = True
+    rast['on'] = True
+    prof['on'] = nstream == 1      # with >1 streams kernels overlap: the roofline is measured in its own pass below
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
@@ -175,11 +218,27 @@ def main():
         dist.barrier()
     dt = time.perf_counter() - t0
     prof['on'] = False
+    rast['on'] = False
     if world > 1:
         t = torch.tensor([dt], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
 
+    roof_steps = args.steps
+    roof_scope = 'HIP events around every launch inside the timed region (single stream)'
+    if nstream > 1:
+        # per-launch durations are only meaningful when launches do not share the GPU: instrumented single-stream steps
+        roof_steps = 2
+        roof_scope = (f'{roof_steps} instrumented single-stream steps right after the timed region (in the timed region the batch is '
+                      f'split over {nstream} streams whose kernels overlap, so per-launch durations are not additive)')
+        prof['on'] = True
+        for _ in range(roof_steps):
+            for f in pipe.submit(tiles):
+                f.result()
+        for f in pipe.flush():
+            f.result()
+        torch.cuda.synchronize()
+        prof['on'] = False
     conv_ms = sum(p[0].elapsed_time(p[1]) for p in prof['pairs'])
     if args.conv_detail and rank == 0:
         agg = {}
@@ -189,7 +248,7 @@ def main():
             e[1] += a.elapsed_time(b)
             e[2] += fl
         for kind, (n, ms, fl) in sorted(agg.items(), key=lambda kv: -kv[1][1]):
-            print(f'# {kind:44s} x{n // args.steps:3d}/step {ms / args.steps:8.3f} ms/step {fl / ms / 1e9:7.1f} TFLOP/s', file=sys.stderr)
+            print(f'# {kind:44s} x{n // roof_steps:3d}/step {ms / roof_steps:8.3f} ms/step {fl / ms / 1e9:7.1f} TFLOP/s', file=sys.stderr)
     achieved = prof['flops'] / (conv_ms * 1e-3) / 1e12 if conv_ms > 0 else 0.0
     n_lines = int(np.mean([(np.count_nonzero(l[:, :, 0] > 0, axis=1) >= 2).sum() for l, _ in last])) if last else 0
     result = {
@@ -201,13 +260,13 @@ def main():
                                 'synthetic 1152x1152 BEV tiles resident in HBM, seeded random weights') if args.workload == 'tiles'
                    else ('on-GPU LAS->BEV raster (4,194,304 points/tile resident in HBM) + configs/Proj_polyline_fpn_vit_vertex_2.py, '
                          'batch=16 per GPU, seeded random weights'),
-                   'tiles_per_step_per_gpu': batch, 'lines_per_tile': n_lines, 'host_threads': args.host_threads},
+                   'tiles_per_step_per_gpu': batch, 'lines_per_tile': n_lines, 'host_threads': args.host_threads, 'streams': nstream},
         'roofline': {'bound': 'mfma', 'kernel': 'conv_mfma_kernel (all FPN/ViT/head implicit-GEMM launches)',
                      'achieved': achieved, 'peak': MFMA_F32_PEAK_TFLOPS, 'unit': 'TFLOP/s',
                      'frac': achieved / MFMA_F32_PEAK_TFLOPS, 'traffic': None,
-                     'launches_per_step': prof['launches'] / max(args.steps, 1),
-                     'gflop_per_step': prof['flops'] / max(args.steps, 1) / 1e9,
-                     'kernel_ms_per_step': conv_ms / max(args.steps, 1)},
+                     'scope': roof_scope, 'launches_per_step': prof['launches'] / max(roof_steps, 1),
+                     'gflop_per_step': prof['flops'] / max(roof_steps, 1) / 1e9,
+                     'kernel_ms_per_step': conv_ms / max(roof_steps, 1)},
     }
     if args.workload == 'fused' and rast['pairs']:
         rms = sum(a.elapsed_time(b) for a, b in rast['pairs']) / len(rast['pairs'])
