@@ -1,0 +1,43 @@
+# Inference-relevant subset of the reference's config of the same name (config 5: sparse-conv LiDAR encoder path).
+# The loader also reads the reference's own configs/Proj_*.py unchanged.
+seed = 2021
+view = False
+number_lanes = 12
+number_orients = 11
+gt_downsample_ratio = 8
+flip_label = False
+use_lidar = True
+is_gt_avai = False
+net = dict(type='Detector1stage', head_type='row', loss_type='row_ce')
+lidar_point_cloud_range = [-15., -25., -2., 15., 25., 2.]
+grid_size = [576, 576, 10]
+pcencoder = dict(
+    type='LidarEncoder', Xn=144, Yn=144, out_channels=64,
+    lidar_encoder=dict(
+        voxelize=dict(point_cloud_range=lidar_point_cloud_range, max_num_points=10, grid_shape=grid_size, max_voxels=1000000),
+        backnone=dict(type='SparseEncoder', in_channels=4, sparse_shape=[21, 600, 600], output_channels=128,
+                      order=('conv', 'norm', 'act'),
+                      encoder_channels=((16, 16, 32), (32, 32, 64), (64, 64, 128), (128, 128)),
+                      encoder_paddings=([0, 0, 1], [0, 0, 1], [0, 0, [1, 1, 0]], [0, 0]),
+                      block_type='basicblock')))
+featuremap_out_channel = 64
+list_img_size_xy = [1152, 1152]
+backbone = dict(type='VitSegNet', image_size=144, patch_h_size=8, patch_w_size=8, channels=64, dim=512, depth=3,
+                heads=16, output_channels=8, expansion_factor=4, dim_head=64, dropout=0., emb_dropout=0.,
+                is_with_shared_mlp=False, is_with_llm=False)
+heads = dict(type='ColumnProposal2', dim_feat=8, row_size=144, dim_shared=100, num_prop=72, prop_width=2,
+             prop_half_buff=4, dim_token=512, tr_depth=1, tr_heads=16, tr_dim_head=64, tr_mlp_dim=512,
+             row_dim_token=96, row_tr_depth=1, row_tr_heads=12, row_tr_dim_head=8, row_tr_mlp_dim=144,
+             endp_mode='endp_est', cls_exp=True)
+proposal_obj_thre = 0.3
+exist_thre = 0.2
+coor_thre = 0.2
+endp_thre = 0.08
+show_result = False
+view_detail = False
+dataset_type = 'LaserLaneProposalEgo'
+vit_seg = True
+column_att = False
+column_transformer_decoder = False
+spatial_att = True
+cls_smooth = False

@@ -144,6 +144,32 @@ int lm_rowref_scatter(void* stream, const float* x_nhwc8, const float* tok, cons
 int lm_rowref_decode(void* stream, const float* ext2, const float* cls2, unsigned char* conf, unsigned char* cls_map,
                      int* col_idx, int B, int H, int W, int L);
 
+/* ---- sparse-voxel LiDAR encoder, config 5 (baseline/models/pcencoder/lidarencoder.py) ----------------------------
+ * PARITY UNPINNED for voxelize / sparse convolutions: the reference only instantiates and calls mmdet3d's
+ * VoxelizationByGridShape (:29) and SparseEncoder (:33, called :93,:102); their published behaviour is restated.
+ * voxelize_hard replaces :104-129 for one sample (hard voxelisation + mean of the kept points + batch index);
+ * row_base / row_end are DEVICE ints (row range of this sample in the batch's feats / coords).
+ * sparse_grid_build / sparse_conv_outputs / sparse_rulebook / conv_gather_mfma_f32 replace the SparseEncoder call :93
+ * (SubMConv3d and SparseConv3d, BatchNorm1d folded, ReLU, residual); ksp_zyx9 = {kz,ky,kx, sz,sy,sx, pz,py,px}.
+ * sparse_to_dense_nhwc = SparseConvTensor.dense().view(N, C*D, H, W) + torch.flip(dims=[2]) (:70);
+ * upsample_bicubic_nhwc = F.interpolate(mode='bicubic', align_corners=False) (:72). */
+long lm_voxelize_workspace_bytes(long n_points);
+int lm_voxelize_hard(void* stream, const float* points, long n, const float* range_lo_xyz, const float* voxel_size_xyz,
+                     const int* grid_xyz, int max_points, int max_voxels, int batch_idx, const int* row_base, int cap_rows,
+                     float* feats, int ldf, int* coords, int* row_end, void* workspace, long workspace_bytes);
+int lm_sparse_grid_build(void* stream, const int* coords, long n, int* grid, int B, int D, int H, int W);
+long lm_sparse_conv_outputs_workspace_bytes(long out_cells);
+int lm_sparse_conv_outputs(void* stream, const int* in_coords, long n_in, int B, const int* ksp_zyx9, int Do, int Ho, int Wo,
+                           int* out_grid, int* out_coords, int cap_rows, int* out_count, void* workspace, long workspace_bytes);
+int lm_sparse_rulebook(void* stream, const int* out_coords, long n_out, const int* in_grid, int B, int D, int H, int W,
+                       const int* ksp_zyx9, int* nbr);
+int lm_conv_gather_mfma_f32(void* stream, const float* x, int ldx, const int* nbr, int taps, const float* wp, int CoutP,
+                            const float* scale, const float* shift, const float* res, int ldr, float* y, int ldy,
+                            long M, int Cin, int Cout, int act);
+int lm_sparse_to_dense_nhwc(void* stream, const float* feats, int ldf, const int* coords, long n, float* out, int B, int D,
+                            int H, int W, int C, int flip_h);
+int lm_upsample_bicubic_nhwc(void* stream, const float* x, float* y, int B, int H, int W, int C, int Ho, int Wo);
+
 #ifdef __cplusplus
 }
 #endif

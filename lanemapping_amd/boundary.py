@@ -6,7 +6,7 @@ import torch
 
 from .config import Config, apply_inference_defaults
 from .registry import build_net, PCENCODER, BACKBONE, HEADS, NET   # noqa: F401
-from . import pcencoder, backbone, heads, rowref, net   # noqa: F401  (registration side effects)
+from . import pcencoder, lidarencoder, backbone, heads, rowref, net   # noqa: F401  (registration side effects)
 
 REPO_ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 

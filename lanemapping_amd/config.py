@@ -67,6 +67,6 @@ def apply_inference_defaults(cfg):
     for k, v in _DEFAULTS.items():
         if k not in cfg:
             cfg[k] = v
-    if 'pcencoder' in cfg:
+    if 'pcencoder' in cfg and 'pretrained' in cfg.pcencoder:
         cfg.pcencoder['pretrained'] = False   # no network: weights always come from a checkpoint
     return cfg

@@ -37,13 +37,14 @@ struct ConvParams {
     int B, H, W, Cin, Cout, CoutP, Ho, Wo;
     int KH, KW, stride, pad_h, pad_w, dil, act;
     long M;
+    const int* nbr;    // gather mode (sparse convolution): [M][taps] input row of every (output row, tap), -1 = inactive site
     double* gn_part;   // optional [B][chunks][Cout][2] per-channel (sum, sum of squares) of the outputs of each wave tile
     int gn_chunks;     // chunks per batch element = (Ho*Wo / BM) * (BM / WM)
 };
 
 __device__ __forceinline__ float gelu_erf(float v) { return 0.5f * v * (1.0f + erff(v * 0.70710678118654752440f)); }
 
-template <int BM, int BN, int WM, int WN>
+template <int BM, int BN, int WM, int WN, bool GATHER = false>
 __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64) void conv_mfma_kernel(ConvParams p) {
     constexpr int TM = WM / 32, TN = WN / 32;
     constexpr int WAVES_N = BN / WN;
@@ -74,7 +75,11 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64) void conv_mfma_kernel(C
 #pragma unroll
     for (int i = 0; i < A_LOADS; ++i) {
         long m = m0 + lrow + i * RPP;
-        if (m < p.M) {
+        if (GATHER) {
+            a_iy0[i] = 0;
+            a_ix0[i] = 0;
+            a_boff[i] = m < p.M ? m : -1;   // output row; its input rows come from the rulebook
+        } else if (m < p.M) {
             int ox = (int)(m % p.Wo);
             long t = m / p.Wo;
             int oy = (int)(t % p.Ho);
@@ -90,6 +95,13 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64) void conv_mfma_kernel(C
     }
     const int cslabs = p.Cin / BK;
     const int KT = p.KH * p.KW * cslabs;
+    const int taps = p.KH * p.KW;
+    int nb[A_LOADS];                      // gather mode: input rows of the slab that is loaded next
+    auto nbr_fetch = [&](int kt) {
+        const int tap = kt / cslabs;
+#pragma unroll
+        for (int i = 0; i < A_LOADS; ++i) nb[i] = a_boff[i] >= 0 ? p.nbr[a_boff[i] * taps + tap] : -1;
+    };
 
     typedef __attribute__((address_space(1))) const void gptr_t;
     typedef __attribute__((address_space(3))) void lptr_t;
@@ -99,9 +111,14 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64) void conv_mfma_kernel(C
         const int dy = (tap / p.KW) * p.dil, dx = (tap % p.KW) * p.dil;
 #pragma unroll
         for (int i = 0; i < A_LOADS; ++i) {
-            const int iy = a_iy0[i] + dy, ix = a_ix0[i] + dx;
-            const bool ok = (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W;
-            const float* src = ok ? p.x + (a_boff[i] + (long)iy * p.W + ix) * p.ldx + c0 : g_zero_chunk;
+            const float* src;
+            if (GATHER) {
+                src = nb[i] >= 0 ? p.x + (long)nb[i] * p.ldx + c0 : g_zero_chunk;
+            } else {
+                const int iy = a_iy0[i] + dy, ix = a_ix0[i] + dx;
+                const bool ok = (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W;
+                src = ok ? p.x + (a_boff[i] + (long)iy * p.W + ix) * p.ldx + c0 : g_zero_chunk;
+            }
             __builtin_amdgcn_global_load_lds((gptr_t*)src, (lptr_t*)(As + (buf * BM + i * RPP + wave * 8) * LDS_LD), 16, 0, 0);
         }
 #pragma unroll
@@ -120,7 +137,9 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64) void conv_mfma_kernel(C
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
+    if (GATHER) nbr_fetch(0);
     gload(0, 0);
+    if (GATHER && KT > 1) nbr_fetch(1);
     __syncthreads();
 
     const int frow = lane & 31;
@@ -129,6 +148,7 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64) void conv_mfma_kernel(C
     for (int kt = 0; kt < KT; ++kt) {
         const int buf = kt & 1;
         if (kt + 1 < KT) gload(kt + 1, buf ^ 1);   // next slab lands in the other buffer under the MFMA block
+        if (GATHER && kt + 2 < KT) nbr_fetch(kt + 2);   // rulebook entries of the slab after that (latency under the MFMAs)
         const float* Ab = As + (buf * BM + wm0 + frow) * LDS_LD;
         const float* Bb = Bs + (buf * BN + wn0 + frow) * LDS_LD;
 #pragma unroll
@@ -240,20 +260,20 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64) void conv_mfma_kernel(C
     }
 }
 
-template <int BM, int BN, int WM, int WN>
+template <int BM, int BN, int WM, int WN, bool GATHER = false>
 int launch(const ConvParams& p, hipStream_t stream) {
     const size_t kloop = (size_t)2 * (BM + BN) * LDS_LD, stage = (size_t)4 * WM * (WN + 4);   // floats
     const size_t lds = (kloop > stage ? kloop : stage) * sizeof(float);
     static bool attr_set = false;
     if (!attr_set) {
-        LM_HIP(hipFuncSetAttribute((const void*)conv_mfma_kernel<BM, BN, WM, WN>,
+        LM_HIP(hipFuncSetAttribute((const void*)conv_mfma_kernel<BM, BN, WM, WN, GATHER>,
                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         attr_set = true;
     }
     const long m_tiles = (p.M + BM - 1) / BM;
     const long blocks = m_tiles * ((p.Cout + BN - 1) / BN);
     LM_REQUIRE(blocks > 0 && blocks < (1L << 31), "conv_mfma: bad grid %ld", blocks);
-    hipLaunchKernelGGL((conv_mfma_kernel<BM, BN, WM, WN>), dim3((unsigned)blocks), dim3((BM / WM) * (BN / WN) * 64), lds, stream, p);
+    hipLaunchKernelGGL((conv_mfma_kernel<BM, BN, WM, WN, GATHER>), dim3((unsigned)blocks), dim3((BM / WM) * (BN / WN) * 64), lds, stream, p);
     LM_LAUNCH_CHECK();
     return LM_OK;
 }
@@ -279,6 +299,7 @@ static int conv_dispatch(void* stream, const float* x, int ldx, const float* wp,
     p.M = (long)B * p.Ho * p.Wo;
     p.gn_part = gn_part;
     p.gn_chunks = 0;
+    p.nbr = nullptr;
     hipStream_t s = (hipStream_t)stream;
     if (gn_part) {   // statistics mode: 128x128 tiles of 64-row wave tiles, images must be whole numbers of tiles
         LM_REQUIRE(Cout > 64 && Cout % 4 == 0 && ((long)p.Ho * p.Wo) % 128 == 0 && res == nullptr && act == LM_ACT_NONE,
@@ -311,4 +332,30 @@ LM_API int lm_conv2d_nhwc_mfma_f32_gnstats(void* stream, const float* x, int ldx
     LM_REQUIRE(gn_partial, "conv_mfma(gn stats): null partial buffer");
     return conv_dispatch(stream, x, ldx, wp, CoutP, nullptr, shift, nullptr, 0, 0, y, ldy, B, H, W, Cin, Cout, KH, KW, stride,
                          pad_h, pad_w, dil, LM_ACT_NONE, gn_partial);
+}
+
+// Sparse (rulebook) convolution on the same MFMA pipeline: output row m accumulates, for every kernel tap t, the feature row
+// nbr[m][t] of x (skipped when -1).  Covers spconv's SubMConv3d and SparseConv3d as used by mmdet3d's SparseEncoder, which
+// the reference's LidarEncoder instantiates (baseline/models/pcencoder/lidarencoder.py:29-35,93-102); the rulebook comes
+// from lm_sparse_rulebook (lidar.hip).  Epilogue = BatchNorm1d(eval) scale/shift, optional residual rows, ReLU.
+LM_API int lm_conv_gather_mfma_f32(void* stream, const float* x, int ldx, const int* nbr, int taps, const float* wp, int CoutP,
+                                   const float* scale, const float* shift, const float* res, int ldr, float* y, int ldy,
+                                   long M, int Cin, int Cout, int act) {
+    LM_REQUIRE(x && nbr && wp && y, "conv_gather: null pointer");
+    LM_REQUIRE(M > 0 && taps >= 1, "conv_gather: empty problem (M=%ld taps=%d)", M, taps);
+    LM_REQUIRE(Cin > 0 && Cin % BK == 0, "conv_gather: Cin=%d must be a multiple of %d (zero-pad the feature rows)", Cin, BK);
+    LM_REQUIRE(CoutP >= Cout && CoutP % 128 == 0, "conv_gather: CoutP=%d must be Cout=%d rounded up to 128", CoutP, Cout);
+    LM_REQUIRE(ldx >= Cin && ldx % 4 == 0 && ldy >= Cout, "conv_gather: bad leading dims ldx=%d ldy=%d", ldx, ldy);
+    ConvParams p;
+    p.x = x; p.wp = wp; p.scale = scale; p.shift = shift; p.res = res; p.y = y;
+    p.ldx = ldx; p.ldr = ldr; p.ldy = ldy; p.res_rows = 0;
+    p.B = 1; p.H = 1; p.W = 1; p.Cin = Cin; p.Cout = Cout; p.CoutP = CoutP; p.Ho = 1; p.Wo = 1;
+    p.KH = 1; p.KW = taps; p.stride = 1; p.pad_h = 0; p.pad_w = 0; p.dil = 1; p.act = act;
+    p.M = M;
+    p.gn_part = nullptr;
+    p.gn_chunks = 0;
+    p.nbr = nbr;
+    hipStream_t s = (hipStream_t)stream;
+    if (Cout <= 64) return launch<128, 64, 32, 64, true>(p, s);
+    return launch<128, 128, 64, 64, true>(p, s);
 }

@@ -24,11 +24,11 @@ class Detector1stage(nn.Module):
 
     def forward_raw(self, batch):
         """pcencoder -> backbone -> heads, raw outputs (detector1stage.py:28-51)."""
-        proj = batch['proj']
-        B, _, H, W = proj.shape
         fused = hasattr(self.pcencoder, 'fpn') and self.cfg.heads.type == 'ColumnProposal2'
         col = None
         if fused:   # FPN writes fea_up straight into channels 8..15 of the head's concat buffer
+            proj = batch['proj']
+            B, _, H, W = proj.shape
             col = ops.new_act(B, 16, H // 4, W // 4, proj.device)
             fea, fea_up, bi_seg, endp_est = self.pcencoder.fpn(proj, fea_up_out=col[:, 8:16])
         else:

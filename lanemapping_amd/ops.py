@@ -379,3 +379,131 @@ def tile_ingest(u8_hwc):
     out = torch.empty((B, 3, H, W), device=x.device, dtype=torch.float32)
     check(lib().lm_tile_ingest_u8(_stream(), _ptr(x), _ptr(out), B, H, W, C_))
     return out
+
+
+# ------------------------------------------------------------------------------- sparse-voxel LiDAR encoder (config 5)
+_vox_ws = {}
+
+
+def voxelize_batch(points, range_lo, voxel_size, grid_xyz, max_points, max_voxels, ldf=32):
+    """Hard-voxelise a list of [N_i,4] device tensors -> (feats [V,ldf] (mean x,y,z,i; rest 0), coords [V,4] i32 (b,z,y,x),
+    row_ends list).  One host sync at the end (the row count sizes every later launch)."""
+    dev = points[0].device
+    B = len(points)
+    cells = int(grid_xyz[0]) * int(grid_xyz[1]) * int(grid_xyz[2])
+    caps = [min(int(p.shape[0]), int(max_voxels), cells) for p in points]
+    cap = max(1, sum(caps))
+    feats = torch.empty((cap, ldf), device=dev, dtype=torch.float32)
+    coords = torch.empty((cap, 4), device=dev, dtype=torch.int32)
+    ends = torch.zeros((B,), device=dev, dtype=torch.int32)
+    nmax = max(int(p.shape[0]) for p in points)
+    need = lib().lm_voxelize_workspace_bytes(nmax)
+    key = (dev.index, torch.cuda.current_stream().cuda_stream)
+    ws = _vox_ws.get(key)
+    if ws is None or ws.numel() < need:
+        ws = torch.empty((need,), device=dev, dtype=torch.uint8)
+        _vox_ws[key] = ws
+    lo = (C.c_float * 3)(*[float(v) for v in range_lo])
+    vs = (C.c_float * 3)(*[float(v) for v in voxel_size])
+    g = (C.c_int * 3)(*[int(v) for v in grid_xyz])
+    for b, p in enumerate(points):
+        if not p.is_cuda:
+            raise LanemapHipError('voxelize_batch needs device tensors; no CPU fallback exists')
+        p = p.contiguous().float()
+        assert p.dim() == 2 and p.shape[1] == 4
+        base = C.c_void_p(ends[b - 1:b].data_ptr()) if b > 0 else None
+        check(lib().lm_voxelize_hard(_stream(), _ptr(p) if p.shape[0] else None, p.shape[0], lo, vs, g, int(max_points),
+                                     int(max_voxels), b, base, cap, _ptr(feats), ldf, _ptr(coords),
+                                     C.c_void_p(ends[b:b + 1].data_ptr()), _ptr(ws), ws.numel()))
+    row_ends = [int(v) for v in ends.cpu()]
+    V = row_ends[-1]
+    return feats[:V], coords[:V], row_ends
+
+
+def _ksp(kernel, stride, padding):
+    return (C.c_int * 9)(*[int(v) for v in (*kernel, *stride, *padding)])
+
+
+def sparse_grid(coords, B, shape):
+    D, H, W = shape
+    grid = torch.empty((B, D, H, W), device=coords.device, dtype=torch.int32)
+    check(lib().lm_sparse_grid_build(_stream(), _ptr(coords), coords.shape[0], _ptr(grid), B, D, H, W))
+    return grid
+
+
+def sparse_conv_outputs(in_coords, B, in_shape, kernel, stride, padding):
+    """Active output sites of a SparseConv3d -> (out_grid [B,Do,Ho,Wo] i32, out_coords [Vo,4] i32, out_shape).  Host sync."""
+    out_shape = tuple((in_shape[a] + 2 * padding[a] - kernel[a]) // stride[a] + 1 for a in range(3))
+    Do, Ho, Wo = out_shape
+    dev = in_coords.device
+    cells = B * Do * Ho * Wo
+    n_in = in_coords.shape[0]
+    taps_per_axis = [(kernel[a] + stride[a] - 1) // stride[a] for a in range(3)]
+    cap = max(1, min(cells, n_in * taps_per_axis[0] * taps_per_axis[1] * taps_per_axis[2]))
+    grid = torch.empty((B, Do, Ho, Wo), device=dev, dtype=torch.int32)
+    coords = torch.empty((cap, 4), device=dev, dtype=torch.int32)
+    count = torch.zeros((1,), device=dev, dtype=torch.int32)
+    need = lib().lm_sparse_conv_outputs_workspace_bytes(cells)
+    ws = torch.empty((need,), device=dev, dtype=torch.uint8)
+    check(lib().lm_sparse_conv_outputs(_stream(), _ptr(in_coords), n_in, B, _ksp(kernel, stride, padding), Do, Ho, Wo,
+                                       _ptr(grid), _ptr(coords), cap, _ptr(count), _ptr(ws), need))
+    n = int(count.item())
+    if n > cap:
+        raise LanemapHipError(f'sparse_conv_outputs: {n} active sites exceed the bound {cap}')
+    return grid, coords[:n], out_shape
+
+
+def sparse_rulebook(out_coords, in_grid, kernel, stride, padding):
+    B, D, H, W = in_grid.shape
+    taps = kernel[0] * kernel[1] * kernel[2]
+    nbr = torch.empty((out_coords.shape[0], taps), device=out_coords.device, dtype=torch.int32)
+    check(lib().lm_sparse_rulebook(_stream(), _ptr(out_coords), out_coords.shape[0], _ptr(in_grid), B, D, H, W,
+                                   _ksp(kernel, stride, padding), _ptr(nbr)))
+    return nbr
+
+
+def pack_sparse(w):
+    """spconv weight [kD,kH,kW,Cin,Cout] -> [taps, CoutP, CinP] (CoutP up to 128s, CinP up to 32s, zero filled)."""
+    kd, kh, kw, ci, co = w.shape
+    cop, cip = (co + 127) // 128 * 128, (ci + 31) // 32 * 32
+    p = torch.zeros((kd * kh * kw, cop, cip), device=w.device, dtype=torch.float32)
+    p[:, :co, :ci] = w.reshape(kd * kh * kw, ci, co).permute(0, 2, 1)
+    return p.contiguous()
+
+
+def conv_gather(x, nbr, wp, cout, scale=None, shift=None, res=None, act=ACT_NONE):
+    """Rulebook convolution: y[m, :cout] = act(bn(sum_t W[t] x[nbr[m, t]]) + res[m]).  x [V, ld] (ld % 32 == 0, padding
+    channels zero); y [M, max(32, cout rounded to 32)] zero padded the same way."""
+    M, taps = nbr.shape
+    cin = wp.shape[2]
+    assert x.stride(1) == 1 and x.stride(0) >= cin
+    ldy = (cout + 31) // 32 * 32
+    y = torch.zeros((M, ldy), device=x.device, dtype=torch.float32) if ldy != cout else \
+        torch.empty((M, ldy), device=x.device, dtype=torch.float32)
+    def launch():
+        check(lib().lm_conv_gather_mfma_f32(_stream(), _ptr(x), x.stride(0), _ptr(nbr), taps, _ptr(wp), wp.shape[1], _ptr(scale),
+                                            _ptr(shift), _ptr(res), res.stride(0) if res is not None else 0, _ptr(y), ldy,
+                                            M, cin, cout, act))
+    if _conv_hook is not None:
+        _conv_hook(f'spconv M{M} taps{taps} {cin}->{cout}', 2.0 * M * taps * cin * cout, launch)
+    else:
+        launch()
+    return y
+
+
+def sparse_to_dense(feats, coords, B, shape, C_, flip_h):
+    """-> logical [B, C*D, H, W] tensor stored NHWC."""
+    D, H, W = shape
+    out = new_act(B, C_ * D, H, W, feats.device)
+    check(lib().lm_sparse_to_dense_nhwc(_stream(), _ptr(feats), feats.stride(0), _ptr(coords), feats.shape[0], _ptr(out),
+                                        B, D, H, W, C_, int(flip_h)))
+    return out
+
+
+def upsample_bicubic(x, size):
+    x, ld = as_nhwc(x)
+    B, C_, H, W = x.shape
+    assert ld == C_
+    out = new_act(B, C_, size[0], size[1], x.device)
+    check(lib().lm_upsample_bicubic_nhwc(_stream(), _ptr(x), _ptr(out), B, H, W, C_, size[0], size[1]))
+    return out

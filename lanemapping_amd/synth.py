@@ -99,10 +99,25 @@ def fill_module_(module, seed=2021, prefix=''):
                 v = normalish(key, n) * (1.0 / np.sqrt(fan_in))
             else:
                 v = 0.05 * normalish(key, n)
+        elif pname == 'weight' and t.dim() == 5:      # spconv layout [kD,kH,kW,Cin,Cout]: He-normal over the window
+            v = normalish(key, n) * np.sqrt(2.0 / int(np.prod(t.shape[:4])))
         else:
             v = 0.1 * normalish(key, n)
         _fill(t, v.astype(np.float32))
     return module
+
+
+def lidar_points(seed, n=4194304, extent=57.6):
+    """[N,4] float32 ego-frame points for the sparse-conv path: the `las_points` cloud centred on
+    the sensor (x, y in +-extent/2, road sheet ~1.6 m below it), intensity normalised like `read_las`
+    ((clip(i,800,33000)-800)/33000).  The cloud is larger than the [-15,15]x[-25,25]x[-2,2] crop on purpose."""
+    p = las_points(seed, n, extent).astype(np.float64)
+    out = np.empty_like(p)
+    out[:, 0] = p[:, 0] - extent / 2
+    out[:, 1] = p[:, 1] - extent / 2
+    out[:, 2] = p[:, 2] - 2.2
+    out[:, 3] = (np.clip(p[:, 3], 800.0, 33000.0) - 800.0) / 33000.0
+    return out.astype(np.float32)
 
 
 # --------------------------------------------------------------------------------------

@@ -262,6 +262,31 @@ def g8(cfg, net):
          pred_lines=np.stack(lines), **keep)
 
 
+def g11(cfg, net):
+    """In-repo tail of LidarEncoder.forward (lidarencoder.py:70-81): flip, bicubic, fea_aligner, fea_conv, 1x1 heads,
+    bilinear.  mmdet3d is absent, so the voxeliser / SparseEncoder are replaced by nn.Identity at construction and the
+    backbone's dense output is injected (extract_lidar_feat patched) - those two stay PARITY UNPINNED."""
+    import importlib
+    import types
+    _refload.install()
+    le_mod = importlib.import_module('baseline.models.pcencoder.lidarencoder')
+    le_mod.VoxelizationByGridShape = lambda **k: torch.nn.Identity()
+    le_mod.MODELS = types.SimpleNamespace(build=lambda c: torch.nn.Identity())
+    D = _refload._AttrDict
+    lcfg = D(gt_downsample_ratio=8)
+    lidar_encoder = D(voxelize=dict(point_cloud_range=[-15., -25., -2., 15., 25., 2.], max_num_points=10,
+                                    grid_shape=[96, 96, 10], max_voxels=100000),
+                      backnone=dict(type='SparseEncoder', in_channels=4, sparse_shape=[21, 100, 100], output_channels=128))
+    m = le_mod.LidarEncoder(Xn=24, Yn=24, out_channels=64, lidar_encoder=lidar_encoder, cfg=lcfg).eval()
+    synth.fill_module_(m, 2021, prefix='pcencoder.')
+    dense = cases.lidar_tail_input(111)
+    m.extract_lidar_feat = lambda pts: torch.from_numpy(dense)
+    with torch.no_grad():
+        fea, fea_up, bi, en = m({'points': [types.SimpleNamespace(data=None)] * dense.shape[0]})
+    save('g11_lidar_tail.npz', input_seed=111, weight_seed=2021, Xn=24, Yn=24, fea=fea.numpy(), fea_up=fea_up.numpy(),
+         bi_seg=bi.numpy().astype(np.float32), endp=en.numpy().astype(np.float32))
+
+
 def main():
     which = sys.argv[1:] or ['g2', 'g3', 'g4', 'g5', 'g6', 'g7', 'g10']
     _stable_sorts(True)

@@ -209,3 +209,97 @@ def test_rowref_state_dict_layout():
     assert tuple(sd['heads.tr_lane_correlator.2.weight'].shape) == (5760, 1024)
     assert not any('emb_' in k for k in sd)          # as on a real GPU in the reference: emb_c never reach a checkpoint
     assert len([k for k in sd if k.startswith('heads.')]) == 449
+
+
+# ----------------------------------------------------------------------------------------------- config 5 (LiDAR encoder)
+def test_lidar_encoder_state_dict_layout():
+    """mmdet3d SparseEncoder naming + mmcv.ops spconv weight layout [kD,kH,kW,Cin,Cout] under the reference's keys."""
+    from lanemapping_amd.boundary import build_net_from_config
+    net5 = build_net_from_config('Proj_polyline_lidarconv_vit_vertex_2', device='cpu')
+    sd = net5.state_dict()
+    bb = 'pcencoder.lidar_modal_extractor.backbone.'
+    want = {
+        bb + 'conv_input.0.weight': (3, 3, 3, 4, 16), bb + 'conv_input.1.running_var': (16,),
+        bb + 'encoder_layers.encoder_layer1.0.conv1.weight': (3, 3, 3, 16, 16),
+        bb + 'encoder_layers.encoder_layer1.1.bn2.bias': (16,),
+        bb + 'encoder_layers.encoder_layer1.2.0.weight': (3, 3, 3, 16, 32),
+        bb + 'encoder_layers.encoder_layer3.2.0.weight': (3, 3, 3, 64, 128),
+        bb + 'encoder_layers.encoder_layer4.1.conv2.weight': (3, 3, 3, 128, 128),
+        bb + 'conv_out.0.weight': (3, 1, 1, 128, 128), bb + 'conv_out.1.weight': (128,),
+        'pcencoder.fea_aligner.0.weight': (64, 128, 3, 3), 'pcencoder.fea_conv.0.bias': (64,),
+        'pcencoder.output_layer_binary_seg.weight': (3, 64, 1, 1), 'pcencoder.output_layer_endp.bias': (1,),
+    }
+    for k, shp in want.items():
+        assert k in sd and tuple(sd[k].shape) == shp, k
+    assert not any('encoder_layer4.2' in k for k in sd)            # last stage has no down-sampling conv
+    assert not any(k.endswith('.0.bias') and 'lidar_modal_extractor' in k for k in sd)   # spconv layers carry no bias
+    vox = net5.pcencoder.lidar_modal_extractor['voxelize']
+    assert vox.grid_xyz == [575, 575, 9] and abs(vox.voxel_size[0] - 30.0 / 575) < 1e-7
+    net5.load_state_dict(sd, strict=True)
+
+
+def test_voxelize_ref_known_answers():
+    from oracle import lidar_ref
+    lo, vs, grid = [0., 0., 0.], [1., 1., 1.], [4, 4, 2]
+    pts = np.array([[2.5, 1.5, 0.5, 1.0],     # voxel A (z0,y1,x2)  first
+                    [0.5, 0.5, 1.5, 2.0],     # voxel B (1,0,0)
+                    [2.2, 1.1, 0.9, 3.0],     # A
+                    [4.0, 1.0, 0.0, 9.0],     # x == grid edge -> dropped
+                    [-0.1, 1.0, 0.0, 9.0],    # below range -> dropped
+                    [2.9, 1.9, 0.1, 5.0],     # A (third point: dropped by max_points=2)
+                    [3.5, 3.5, 1.5, 4.0]],    # voxel C (1,3,3)
+                   np.float32)
+    f, c = lidar_ref.voxelize_ref([pts, pts[:2]], lo, vs, grid, max_points=2, max_voxels=10)
+    assert c.tolist() == [[0, 0, 1, 2], [0, 1, 0, 0], [0, 1, 3, 3], [1, 0, 1, 2], [1, 1, 0, 0]]
+    assert np.allclose(f[0], (pts[0] + pts[2]) / 2) and np.allclose(f[1], pts[1]) and np.allclose(f[2], pts[6])
+    f2, c2 = lidar_ref.voxelize_ref([pts], lo, vs, grid, max_points=10, max_voxels=2)
+    assert c2.tolist() == [[0, 0, 1, 2], [0, 1, 0, 0]]             # first-appearance numbering, capped
+    assert np.allclose(f2[0], (pts[0] + pts[2] + pts[5]) / 3)
+    f3, c3 = lidar_ref.voxelize_ref([np.zeros((0, 4), np.float32)], lo, vs, grid, 2, 10)
+    assert f3.shape == (0, 4) and c3.shape == (0, 4)
+
+
+def test_sparse_encoder_ref_against_sitewise_definition():
+    """The oracle evaluates spconv layers as masked dense conv3d; check that against the site-wise (rulebook) definition
+    on a tiny active set: SubMConv3d keeps the set, SparseConv3d activates every window holding an active input."""
+    import torch
+    from oracle import lidar_ref
+    rng = np.random.RandomState(3)
+    D, H, W, cin, cout = 5, 6, 7, 3, 4
+    act = rng.rand(D, H, W) > 0.7
+    zs, ys, xs = np.nonzero(act)
+    feats = rng.randn(len(zs), cin).astype(np.float32)
+    w = rng.randn(3, 3, 3, cin, cout).astype(np.float32)
+    x = torch.zeros(1, cin, D, H, W)
+    m = torch.zeros(1, 1, D, H, W)
+    x[0, :, zs, ys, xs] = torch.from_numpy(feats).t()
+    m[0, 0, zs, ys, xs] = 1
+    sd = {'w': torch.from_numpy(w)}
+    site = {(z, y, x_): i for i, (z, y, x_) in enumerate(zip(zs, ys, xs))}
+    got = lidar_ref._subm(x, m, sd, 'w')[0]
+    for (z, y, x_), i in site.items():
+        acc = np.zeros(cout)
+        for kz in range(3):
+            for ky in range(3):
+                for kx in range(3):
+                    j = site.get((z - 1 + kz, y - 1 + ky, x_ - 1 + kx))
+                    if j is not None:
+                        acc += feats[j].astype(np.float64) @ w[kz, ky, kx]
+        assert np.allclose(got[:, z, y, x_].numpy(), acc, atol=1e-5)
+    assert float((got * (1 - m[0])).abs().max()) == 0.0
+    pad, stride = (1, 1, 0), (2, 2, 2)
+    got2, m2 = lidar_ref._spconv(x, m, sd, 'w', (3, 3, 3), stride, pad)
+    Do, Ho, Wo = got2.shape[2:]
+    for oz in range(Do):
+        for oy in range(Ho):
+            for ox in range(Wo):
+                acc, hit = np.zeros(cout), False
+                for kz in range(3):
+                    for ky in range(3):
+                        for kx in range(3):
+                            j = site.get((oz * 2 - pad[0] + kz, oy * 2 - pad[1] + ky, ox * 2 - pad[2] + kx))
+                            if j is not None:
+                                hit = True
+                                acc += feats[j].astype(np.float64) @ w[kz, ky, kx]
+                assert bool(m2[0, 0, oz, oy, ox]) == hit
+                assert np.allclose(got2[0, :, oz, oy, ox].numpy(), acc if hit else 0, atol=1e-5)

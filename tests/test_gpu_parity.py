@@ -413,3 +413,104 @@ def test_rowref_detector_config4_vs_oracle(dev, synth_sd):
     assert bad <= 4, f'{bad} conf pixels differ from the oracle'
     if bad == 0:
         assert np.array_equal(o['lane_maps']['cls_offset_smooth'][0], rowref_ref.rowref_pred_lines(conf[0], cls[0]))
+
+
+# ----------------------------------------------------------------------------------------------- config 5 (LiDAR encoder)
+# voxeliser + sparse convolutions: PARITY UNPINNED (third-party arithmetic, oracle = restated published behaviour);
+# dense tail: pinned by G11 (generated from the reference).
+def _lidar_module(dev, cfg, seed=2021):
+    from lanemapping_amd import lidarencoder  # noqa: F401
+    from lanemapping_amd.registry import build_pcencoder
+    m = build_pcencoder(cfg).eval()
+    synth.fill_module_(m, seed, prefix='pcencoder.')
+    sd = {k: v.clone() for k, v in m.state_dict().items()}
+    return m.to(dev), sd
+
+
+@pytest.mark.parametrize('max_points,max_voxels', [(10, 100000), (3, 700)])
+def test_voxelize_vs_oracle(dev, max_points, max_voxels):
+    from lanemapping_amd import ops
+    from oracle import lidar_ref
+    lo, vs, grid = lidar_ref.voxel_geometry([-15., -25., -2., 15., 25., 2.], grid_shape=[96, 96, 10])
+    pts = [synth.lidar_points(31, 60000), np.zeros((0, 4), np.float32), synth.lidar_points(32, 20000),
+           np.array([[100., 0., 0., 1.]], np.float32)]                      # ragged batch: empty sample, all-outside sample
+    f_ref, c_ref = lidar_ref.voxelize_ref(pts, lo, vs, grid, max_points, max_voxels)
+    f, c, ends = ops.voxelize_batch([torch.from_numpy(p).to(dev) for p in pts], lo, vs, grid, max_points, max_voxels)
+    assert c.shape[0] == c_ref.shape[0] and ends[1] == ends[0] and ends[3] == ends[2]
+    assert np.array_equal(c.cpu().numpy(), c_ref)                           # same voxels in the same (first-appearance) order
+    assert float((f[:, :4].cpu() - torch.from_numpy(f_ref)).abs().max()) <= 1e-6
+    assert float(f[:, 4:].abs().max()) == 0.0
+
+
+def test_sparse_backbone_vs_oracle(dev):
+    import cases
+    from lanemapping_amd import ops
+    from oracle import lidar_ref
+    cfg = cases.small_lidar_cfg()
+    m, sd = _lidar_module(dev, cfg)
+    le = cfg.pcencoder['lidar_encoder']
+    lo, vs, grid = lidar_ref.voxel_geometry(le['voxelize']['point_cloud_range'], grid_shape=le['voxelize']['grid_shape'])
+    pts = [synth.lidar_points(41, 40000), synth.lidar_points(42, 25000)]
+    f_ref, c_ref = lidar_ref.voxelize_ref(pts, lo, vs, grid, 10, 100000)
+    bb = le['backnone']
+    ref = lidar_ref.sparse_encoder_ref(f_ref, c_ref, 2, sd, 'lidar_modal_extractor.backbone.', bb['sparse_shape'],
+                                       bb['encoder_channels'], bb['encoder_paddings'], bb['block_type'])
+    feats = torch.zeros((f_ref.shape[0], 32))
+    feats[:, :4] = torch.from_numpy(f_ref)
+    with torch.no_grad():
+        got = m.sparse_backbone(feats.to(dev), torch.from_numpy(c_ref).to(dev), 2, flip_h=False)
+    assert float(ref.abs().max()) > 1e-2
+    _close(got, ref, 1e-4, 'sparse encoder dense output')
+    assert np.array_equal((got.cpu() != 0).any(dim=1).numpy(), (ref != 0).any(dim=1).numpy())   # same active sites
+
+
+def test_lidar_tail_golden_g11(dev, golden):
+    import cases
+    g = golden('g11_lidar_tail.npz')
+    m, _ = _lidar_module(dev, cases.small_lidar_cfg(), int(g['weight_seed']))
+    dense = torch.from_numpy(cases.lidar_tail_input(int(g['input_seed'])))
+    with torch.no_grad():
+        outs = m.dense_tail(torch.flip(dense, dims=[2]).to(dev))
+    for name, o in zip(('fea', 'fea_up', 'bi_seg', 'endp'), outs):
+        _close(o, g[name], 1e-4, name)
+
+
+def test_lidar_encoder_forward_vs_oracle(dev):
+    import cases
+    from oracle import lidar_ref
+    cfg = cases.small_lidar_cfg()
+    m, sd = _lidar_module(dev, cfg)
+    pts = [synth.lidar_points(51, 50000), synth.lidar_points(52, 30000)]
+    pc = dict(cfg.pcencoder)
+    pc['gt_downsample_ratio'] = 8
+    ref = lidar_ref.lidar_encoder_ref(pts, sd, pc)
+    with torch.no_grad():
+        got = m({'points': [torch.from_numpy(p).to(dev) for p in pts]})
+    for name, a, b in zip(('fea', 'fea_up', 'bi_seg', 'endp'), got, ref):
+        _close(a, b, 1e-4, name)
+
+
+def test_detector_config5_end_to_end(dev):
+    """Detector1stage on the sparse-conv path at the real config-5 sizes (grid 576x576x10, sparse shape 21x600x600):
+    raw head outputs vs the oracle chain, and the full forward (decode + polylines) runs."""
+    from lanemapping_amd.boundary import build_net_from_config
+    from oracle import lidar_ref, net_ref
+    net5 = build_net_from_config('Proj_polyline_lidarconv_vit_vertex_2', device='cpu')
+    synth.fill_module_(net5, 2021)
+    sd = {k: v.clone() for k, v in net5.state_dict().items()}
+    net5 = net5.to(dev)
+    pts = [synth.lidar_points(61, 1 << 20)]
+    pc = dict(net5.cfg.pcencoder)
+    pc['gt_downsample_ratio'] = 8
+    sd_pc = {k[len('pcencoder.'):]: v for k, v in sd.items() if k.startswith('pcencoder.')}
+    with torch.no_grad():
+        fea, fea_up, bi, en = lidar_ref.lidar_encoder_ref(pts, sd_pc, pc)
+        ref = net_ref.head_forward(sd, net_ref.vit_forward(sd, fea), fea_up)
+        batch = {'points': [torch.from_numpy(p).to(dev) for p in pts]}
+        raw = net5.forward_raw(batch)
+        _close(raw['semantic_seg'], bi, 1e-4, 'bi_seg')
+        _close(raw['endp_est'], en, 1e-4, 'endp')
+        for k in ('proposal_conf', 'ext2', 'cls2', 'offset2', 'orient'):
+            _close(raw[k], ref[k], 2e-4, k)
+        out = net5(batch)
+    assert out['lane_maps']['cls_offset_smooth'][0].shape == (72, 144, 2)

@@ -141,3 +141,21 @@ def test_g8_rowref_oracle(golden):
     with torch.no_grad():
         out5 = rowref_ref.rowref_forward(sd, x, thr_ext=0.5)
     np.testing.assert_array_equal(rowref_ref.rowref_decode(out5)[0].astype(np.uint8), g['t5_conf'])
+
+
+# ----------------------------------------------------------------------------------------------- G11 (config 5 tail)
+def test_g11_lidar_dense_tail(golden):
+    """oracle/lidar_ref.dense_tail_ref vs the reference's LidarEncoder.forward with the backbone output injected."""
+    import cases
+    from lanemapping_amd import synth
+    from lanemapping_amd.registry import build_pcencoder
+    from lanemapping_amd import lidarencoder  # noqa: F401  (registration)
+    from oracle import lidar_ref
+    g = golden('g11_lidar_tail.npz')
+    m = build_pcencoder(cases.small_lidar_cfg()).eval()
+    synth.fill_module_(m, int(g['weight_seed']), prefix='pcencoder.')
+    dense = torch.from_numpy(cases.lidar_tail_input(int(g['input_seed'])))
+    outs = lidar_ref.dense_tail_ref(dense, m.state_dict(), int(g['Xn']), int(g['Yn']), 8)
+    for name, o in zip(('fea', 'fea_up', 'bi_seg', 'endp'), outs):
+        assert o.shape == g[name].shape
+        assert float((o - torch.from_numpy(g[name])).abs().max()) <= 1e-6, name
