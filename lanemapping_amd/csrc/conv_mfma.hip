@@ -37,6 +37,7 @@ struct ConvParams {
     int B, H, W, Cin, Cout, CoutP, Ho, Wo;
     int KH, KW, stride, pad_h, pad_w, dil, act;
     long M;
+    const float* zero; // 16 zero bytes: source of padding taps / inactive sites (kernel argument: no GOT load in the loop)
     const int* nbr;    // gather mode (sparse convolution): [M][taps] input row of every (output row, tap), -1 = inactive site
     double* gn_part;   // optional [B][chunks][Cout][2] per-channel (sum, sum of squares) of the outputs of each wave tile
     int gn_chunks;     // chunks per batch element = (Ho*Wo / BM) * (BM / WM)
@@ -70,15 +71,20 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64) void conv_mfma_kernel(C
     static_assert(RPP == 32, "swizzle below assumes 32 rows per load pass (256 threads)");
     const int lrow = tid >> 3;                               // 0..31: row inside a load pass
     const int lc4 = (((tid & 7) ^ ((lrow >> 1) & 7))) * 4;   // swizzled source chunk (floats) for LDS slot tid & 7
+    // Everything that does not depend on the tap is folded into one 32-bit element offset per row (the launcher checks
+    // that the tensors stay below 2^31 elements), so a slab costs a handful of full-rate VALU ops per load: the previous
+    // 64-bit multiply per (row, tap), two integer divisions and a GOT load of the zero block per slab sat in front of every
+    // MFMA block.
     int a_iy0[A_LOADS], a_ix0[A_LOADS];
-    long a_boff[A_LOADS];
+    int a_off[A_LOADS];                       // dense: ((b*H + iy0)*W + ix0)*ldx + lc4;  gather: output row or -1
+    int b_off[B_LOADS];
 #pragma unroll
     for (int i = 0; i < A_LOADS; ++i) {
         long m = m0 + lrow + i * RPP;
         if (GATHER) {
             a_iy0[i] = 0;
             a_ix0[i] = 0;
-            a_boff[i] = m < p.M ? m : -1;   // output row; its input rows come from the rulebook
+            a_off[i] = m < p.M ? (int)m : -1;   // output row; its input rows come from the rulebook
         } else if (m < p.M) {
             int ox = (int)(m % p.Wo);
             long t = m / p.Wo;
@@ -86,46 +92,63 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64) void conv_mfma_kernel(C
             int b = (int)(t / p.Ho);
             a_iy0[i] = oy * p.stride - p.pad_h;
             a_ix0[i] = ox * p.stride - p.pad_w;
-            a_boff[i] = (long)b * p.H * p.W;
+            a_off[i] = ((b * p.H + a_iy0[i]) * p.W + a_ix0[i]) * p.ldx + lc4;
         } else {
             a_iy0[i] = -(1 << 28);   // always out of range -> zero rows
             a_ix0[i] = 0;
-            a_boff[i] = 0;
+            a_off[i] = 0;
         }
     }
+#pragma unroll
+    for (int i = 0; i < B_LOADS; ++i) b_off[i] = (n0 + lrow + i * RPP) * p.Cin + lc4;
     const int cslabs = p.Cin / BK;
     const int KT = p.KH * p.KW * cslabs;
     const int taps = p.KH * p.KW;
+    const float* const zero = p.zero;
+
+    // load cursor: walks (tap, channel slab) in k order without divisions
+    int cur_cs = 0, cur_kx = 0, cur_ky = 0, cur_tap = 0;
     int nb[A_LOADS];                      // gather mode: input rows of the slab that is loaded next
-    auto nbr_fetch = [&](int kt) {
-        const int tap = kt / cslabs;
+    int nb_cs = 0, nb_tap = 0;            // cursor of the rulebook prefetch (runs one slab ahead of the load cursor)
+    auto nbr_fetch = [&]() {
 #pragma unroll
-        for (int i = 0; i < A_LOADS; ++i) nb[i] = a_boff[i] >= 0 ? p.nbr[a_boff[i] * taps + tap] : -1;
+        for (int i = 0; i < A_LOADS; ++i) nb[i] = a_off[i] >= 0 ? p.nbr[(long)a_off[i] * taps + nb_tap] : -1;
+        if (++nb_cs == cslabs) {
+            nb_cs = 0;
+            ++nb_tap;
+        }
     };
 
     typedef __attribute__((address_space(1))) const void gptr_t;
     typedef __attribute__((address_space(3))) void lptr_t;
-    auto gload = [&](int kt, int buf) {   // global -> LDS, one 1 KiB (8 rows x 128 B) piece per wave-instruction
-        const int tap = kt / cslabs;
-        const int c0 = (kt - tap * cslabs) * BK + lc4;
-        const int dy = (tap / p.KW) * p.dil, dx = (tap % p.KW) * p.dil;
+    auto gload = [&](int buf) {   // global -> LDS, one 1 KiB (8 rows x 128 B) piece per wave-instruction
+        const int dy = cur_ky * p.dil, dx = cur_kx * p.dil;
+        const int cbase = cur_cs * BK;
+        const int adelta = (dy * p.W + dx) * p.ldx + cbase;
+        const int bdelta = cur_tap * p.CoutP * p.Cin + cbase;
 #pragma unroll
         for (int i = 0; i < A_LOADS; ++i) {
             const float* src;
             if (GATHER) {
-                src = nb[i] >= 0 ? p.x + (long)nb[i] * p.ldx + c0 : g_zero_chunk;
+                src = nb[i] >= 0 ? p.x + ((long)nb[i] * p.ldx + (cbase + lc4)) : zero;
             } else {
-                const int iy = a_iy0[i] + dy, ix = a_ix0[i] + dx;
-                const bool ok = (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W;
-                src = ok ? p.x + (a_boff[i] + (long)iy * p.W + ix) * p.ldx + c0 : g_zero_chunk;
+                const bool ok = (unsigned)(a_iy0[i] + dy) < (unsigned)p.H && (unsigned)(a_ix0[i] + dx) < (unsigned)p.W;
+                src = ok ? p.x + (a_off[i] + adelta) : zero;
             }
             __builtin_amdgcn_global_load_lds((gptr_t*)src, (lptr_t*)(As + (buf * BM + i * RPP + wave * 8) * LDS_LD), 16, 0, 0);
         }
 #pragma unroll
         for (int i = 0; i < B_LOADS; ++i) {
-            const int n = n0 + lrow + i * RPP;
-            const float* src = p.wp + ((long)tap * p.CoutP + n) * p.Cin + c0;
+            const float* src = p.wp + (b_off[i] + bdelta);
             __builtin_amdgcn_global_load_lds((gptr_t*)src, (lptr_t*)(Bs + (buf * BN + i * RPP + wave * 8) * LDS_LD), 16, 0, 0);
+        }
+        if (++cur_cs == cslabs) {
+            cur_cs = 0;
+            ++cur_tap;
+            if (++cur_kx == p.KW) {
+                cur_kx = 0;
+                ++cur_ky;
+            }
         }
     };
 
@@ -137,9 +160,9 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64) void conv_mfma_kernel(C
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-    if (GATHER) nbr_fetch(0);
-    gload(0, 0);
-    if (GATHER && KT > 1) nbr_fetch(1);
+    if (GATHER) nbr_fetch();
+    gload(0);
+    if (GATHER && KT > 1) nbr_fetch();
     __syncthreads();
 
     const int frow = lane & 31;
@@ -147,8 +170,8 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64) void conv_mfma_kernel(C
     const int fhalf = lane >> 5;
     for (int kt = 0; kt < KT; ++kt) {
         const int buf = kt & 1;
-        if (kt + 1 < KT) gload(kt + 1, buf ^ 1);   // next slab lands in the other buffer under the MFMA block
-        if (GATHER && kt + 2 < KT) nbr_fetch(kt + 2);   // rulebook entries of the slab after that (latency under the MFMAs)
+        if (kt + 1 < KT) gload(buf ^ 1);            // next slab lands in the other buffer under the MFMA block
+        if (GATHER && kt + 2 < KT) nbr_fetch();     // rulebook entries of the slab after that (latency under the MFMAs)
         const float* Ab = As + (buf * BM + wm0 + frow) * LDS_LD;
         const float* Bb = Bs + (buf * BN + wn0 + frow) * LDS_LD;
 #pragma unroll
@@ -278,6 +301,17 @@ int launch(const ConvParams& p, hipStream_t stream) {
     return LM_OK;
 }
 
+int zero_block(const float** out) {   // device address of the 16 zero bytes, resolved once
+    static const float* ptr = nullptr;
+    if (!ptr) {
+        void* sym = nullptr;
+        LM_HIP(hipGetSymbolAddress(&sym, HIP_SYMBOL(g_zero_chunk)));
+        ptr = (const float*)sym;
+    }
+    *out = ptr;
+    return LM_OK;
+}
+
 }  // namespace
 
 static int conv_dispatch(void* stream, const float* x, int ldx, const float* wp, int CoutP, const float* scale, const float* shift,
@@ -297,9 +331,12 @@ static int conv_dispatch(void* stream, const float* x, int ldx, const float* wp,
     LM_REQUIRE(p.Ho > 0 && p.Wo > 0, "conv_mfma: empty output");
     p.KH = KH; p.KW = KW; p.stride = stride; p.pad_h = pad_h; p.pad_w = pad_w; p.dil = dil; p.act = act;
     p.M = (long)B * p.Ho * p.Wo;
+    LM_REQUIRE(((long)B * H * W + (long)(KH * dil + pad_h + 1) * W) * ldx < (1L << 31) && (long)KH * KW * CoutP * Cin < (1L << 31),
+               "conv_mfma: tensor too large for 32-bit element offsets (B*H*W*ld = %ld)", (long)B * H * W * ldx);
     p.gn_part = gn_part;
     p.gn_chunks = 0;
     p.nbr = nullptr;
+    if (int e = zero_block(&p.zero)) return e;
     hipStream_t s = (hipStream_t)stream;
     if (gn_part) {   // statistics mode: 128x128 tiles of 64-row wave tiles, images must be whole numbers of tiles
         LM_REQUIRE(Cout > 64 && Cout % 4 == 0 && ((long)p.Ho * p.Wo) % 128 == 0 && res == nullptr && act == LM_ACT_NONE,
@@ -352,9 +389,11 @@ LM_API int lm_conv_gather_mfma_f32(void* stream, const float* x, int ldx, const 
     p.B = 1; p.H = 1; p.W = 1; p.Cin = Cin; p.Cout = Cout; p.CoutP = CoutP; p.Ho = 1; p.Wo = 1;
     p.KH = 1; p.KW = taps; p.stride = 1; p.pad_h = 0; p.pad_w = 0; p.dil = 1; p.act = act;
     p.M = M;
+    LM_REQUIRE(M < (1L << 31) && (long)taps * CoutP * Cin < (1L << 31), "conv_gather: problem too large (M=%ld)", M);
     p.gn_part = nullptr;
     p.gn_chunks = 0;
     p.nbr = nbr;
+    if (int e = zero_block(&p.zero)) return e;
     hipStream_t s = (hipStream_t)stream;
     if (Cout <= 64) return launch<128, 64, 32, 64, true>(p, s);
     return launch<128, 128, 64, 64, true>(p, s);
