@@ -82,7 +82,7 @@ def main():
     ap.add_argument('--host-threads', type=int, default=8)
     ap.add_argument('--workload', choices=['tiles', 'fused'], default='tiles',
                     help="tiles = BASELINE configs[1] (pre-rasterised, batch 8); fused = configs[2] (on-GPU LAS->BEV raster + net, batch 16)")
-    ap.add_argument('--streams', type=int, default=2, help='split every batch over this many HIP streams (fills launch tails)')
+    ap.add_argument('--streams', type=int, default=4, help='split every batch over this many HIP streams (fills launch tails)')
     ap.add_argument('--conv-detail', action='store_true', help='per-shape table of the MFMA launches on stderr')
     ap.add_argument('--no-roofline-events', action='store_true', help='skip the per-launch HIP events')
     args = ap.parse_args()

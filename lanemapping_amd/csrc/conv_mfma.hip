@@ -64,8 +64,15 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64) void conv_mfma_kernel(C
     const int wm0 = (wave / WAVES_N) * WM;
     const int wn0 = (wave % WAVES_N) * WN;
     const int n_tiles = (p.Cout + BN - 1) / BN;   // CoutP only guarantees that weight rows up to the tile edge exist
-    const long m0 = (long)(blockIdx.x / n_tiles) * BM;
-    const int n0 = (blockIdx.x % n_tiles) * BN;
+    // XCD-aware tile order: workgroups are dealt round-robin to the 8 XCDs (private L2 each), so give every XCD one
+    // contiguous run of tiles - neighbouring output rows (shared 3x3 halos) and the N tiles of one M tile share an L2.
+    unsigned bid = blockIdx.x;
+    {
+        const unsigned nb = gridDim.x, per = nb / 8, full = per * 8;
+        if (bid < full) bid = (bid % 8) * per + bid / 8;
+    }
+    const long m0 = (long)(bid / n_tiles) * BM;
+    const int n0 = (bid % n_tiles) * BN;
 
     // --- per-thread gather coordinates (tap independent part) ---
     static_assert(RPP == 32, "swizzle below assumes 32 rows per load pass (256 threads)");
@@ -106,16 +113,19 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64) void conv_mfma_kernel(C
     const int taps = p.KH * p.KW;
     const float* const zero = p.zero;
 
-    // load cursor: walks (tap, channel slab) in k order without divisions
+    // load cursor: k order = (channel slab, tap), taps innermost, without divisions.  A 128-byte line is exactly one
+    // (pixel, 32-channel slab): with the taps innermost the up to 9 uses of a line (by this tile and its neighbours) fall
+    // within 9 consecutive slabs, so the 64 tiles resident on an XCD keep a ~3 MB working set that fits its 4 MB L2
+    // (tap-major order spread the re-use over 24 slabs = 25 MB per XCD and sent every tap to the Infinity Cache).
     int cur_cs = 0, cur_kx = 0, cur_ky = 0, cur_tap = 0;
     int nb[A_LOADS];                      // gather mode: input rows of the slab that is loaded next
     int nb_cs = 0, nb_tap = 0;            // cursor of the rulebook prefetch (runs one slab ahead of the load cursor)
     auto nbr_fetch = [&]() {
 #pragma unroll
         for (int i = 0; i < A_LOADS; ++i) nb[i] = a_off[i] >= 0 ? p.nbr[(long)a_off[i] * taps + nb_tap] : -1;
-        if (++nb_cs == cslabs) {
-            nb_cs = 0;
-            ++nb_tap;
+        if (++nb_tap == taps) {
+            nb_tap = 0;
+            ++nb_cs;
         }
     };
 
@@ -142,12 +152,13 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64) void conv_mfma_kernel(C
             const float* src = p.wp + (b_off[i] + bdelta);
             __builtin_amdgcn_global_load_lds((gptr_t*)src, (lptr_t*)(Bs + (buf * BN + i * RPP + wave * 8) * LDS_LD), 16, 0, 0);
         }
-        if (++cur_cs == cslabs) {
-            cur_cs = 0;
-            ++cur_tap;
-            if (++cur_kx == p.KW) {
-                cur_kx = 0;
-                ++cur_ky;
+        ++cur_tap;
+        if (++cur_kx == p.KW) {
+            cur_kx = 0;
+            if (++cur_ky == p.KH) {
+                cur_ky = 0;
+                cur_tap = 0;
+                ++cur_cs;
             }
         }
     };
