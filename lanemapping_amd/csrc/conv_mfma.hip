@@ -38,6 +38,7 @@ struct ConvParams {
     int KH, KW, stride, pad_h, pad_w, dil, act;
     long M;
     const float* zero; // 16 zero bytes: source of padding taps / inactive sites (kernel argument: no GOT load in the loop)
+    int taps_real;     // gather mode: taps per rulebook row (KW counts K slabs: taps, or tap pairs when TPS == 2)
     const int* nbr;    // gather mode (sparse convolution): [M][taps] input row of every (output row, tap), -1 = inactive site
     double* gn_part;   // optional [B][chunks][Cout][2] per-channel (sum, sum of squares) of the outputs of each wave tile
     int gn_chunks;     // chunks per batch element = (Ho*Wo / BM) * (BM / WM)
@@ -45,7 +46,7 @@ struct ConvParams {
 
 __device__ __forceinline__ float gelu_erf(float v) { return 0.5f * v * (1.0f + erff(v * 0.70710678118654752440f)); }
 
-template <int BM, int BN, int WM, int WN, bool GATHER = false>
+template <int BM, int BN, int WM, int WN, bool GATHER = false, int TPS = 1>
 __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64) void conv_mfma_kernel(ConvParams p) {
     constexpr int TM = WM / 32, TN = WN / 32;
     constexpr int WAVES_N = BN / WN;
@@ -110,7 +111,7 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64) void conv_mfma_kernel(C
     for (int i = 0; i < B_LOADS; ++i) b_off[i] = (n0 + lrow + i * RPP) * p.Cin + lc4;
     const int cslabs = p.Cin / BK;
     const int KT = p.KH * p.KW * cslabs;
-    const int taps = p.KH * p.KW;
+    const int taps = GATHER ? p.taps_real : p.KH * p.KW;   // row stride of the rulebook
     const float* const zero = p.zero;
 
     // load cursor: k order = (channel slab, tap), taps innermost, without divisions.  A 128-byte line is exactly one
@@ -122,8 +123,12 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64) void conv_mfma_kernel(C
     int nb_cs = 0, nb_tap = 0;            // cursor of the rulebook prefetch (runs one slab ahead of the load cursor)
     auto nbr_fetch = [&]() {
 #pragma unroll
-        for (int i = 0; i < A_LOADS; ++i) nb[i] = a_off[i] >= 0 ? p.nbr[(long)a_off[i] * taps + nb_tap] : -1;
-        if (++nb_tap == taps) {
+        for (int i = 0; i < A_LOADS; ++i) {
+            // TPS == 2 (16-channel features): a 32-float K slab holds two taps; lanes of chunks 4..7 fetch the odd one
+            const int t = TPS == 2 ? 2 * nb_tap + (lc4 >> 4) : nb_tap;
+            nb[i] = (a_off[i] >= 0 && t < taps) ? p.nbr[(long)a_off[i] * taps + t] : -1;
+        }
+        if (++nb_tap == p.KW) {
             nb_tap = 0;
             ++nb_cs;
         }
@@ -140,7 +145,7 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64) void conv_mfma_kernel(C
         for (int i = 0; i < A_LOADS; ++i) {
             const float* src;
             if (GATHER) {
-                src = nb[i] >= 0 ? p.x + ((long)nb[i] * p.ldx + (cbase + lc4)) : zero;
+                src = nb[i] >= 0 ? p.x + ((long)nb[i] * p.ldx + (TPS == 2 ? (lc4 & 15) : cbase + lc4)) : zero;
             } else {
                 const bool ok = (unsigned)(a_iy0[i] + dy) < (unsigned)p.H && (unsigned)(a_ix0[i] + dx) < (unsigned)p.W;
                 src = ok ? p.x + (a_off[i] + adelta) : zero;
@@ -294,20 +299,20 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64) void conv_mfma_kernel(C
     }
 }
 
-template <int BM, int BN, int WM, int WN, bool GATHER = false>
+template <int BM, int BN, int WM, int WN, bool GATHER = false, int TPS = 1>
 int launch(const ConvParams& p, hipStream_t stream) {
     const size_t kloop = (size_t)2 * (BM + BN) * LDS_LD, stage = (size_t)4 * WM * (WN + 4);   // floats
     const size_t lds = (kloop > stage ? kloop : stage) * sizeof(float);
     static bool attr_set = false;
     if (!attr_set) {
-        LM_HIP(hipFuncSetAttribute((const void*)conv_mfma_kernel<BM, BN, WM, WN, GATHER>,
+        LM_HIP(hipFuncSetAttribute((const void*)conv_mfma_kernel<BM, BN, WM, WN, GATHER, TPS>,
                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         attr_set = true;
     }
     const long m_tiles = (p.M + BM - 1) / BM;
     const long blocks = m_tiles * ((p.Cout + BN - 1) / BN);
     LM_REQUIRE(blocks > 0 && blocks < (1L << 31), "conv_mfma: bad grid %ld", blocks);
-    hipLaunchKernelGGL((conv_mfma_kernel<BM, BN, WM, WN, GATHER>), dim3((unsigned)blocks), dim3((BM / WM) * (BN / WN) * 64), lds, stream, p);
+    hipLaunchKernelGGL((conv_mfma_kernel<BM, BN, WM, WN, GATHER, TPS>), dim3((unsigned)blocks), dim3((BM / WM) * (BN / WN) * 64), lds, stream, p);
     LM_LAUNCH_CHECK();
     return LM_OK;
 }
@@ -347,6 +352,7 @@ static int conv_dispatch(void* stream, const float* x, int ldx, const float* wp,
     p.gn_part = gn_part;
     p.gn_chunks = 0;
     p.nbr = nullptr;
+    p.taps_real = 0;
     if (int e = zero_block(&p.zero)) return e;
     hipStream_t s = (hipStream_t)stream;
     if (gn_part) {   // statistics mode: 128x128 tiles of 64-row wave tiles, images must be whole numbers of tiles
@@ -386,26 +392,37 @@ LM_API int lm_conv2d_nhwc_mfma_f32_gnstats(void* stream, const float* x, int ldx
 // nbr[m][t] of x (skipped when -1).  Covers spconv's SubMConv3d and SparseConv3d as used by mmdet3d's SparseEncoder, which
 // the reference's LidarEncoder instantiates (baseline/models/pcencoder/lidarencoder.py:29-35,93-102); the rulebook comes
 // from lm_sparse_rulebook (lidar.hip).  Epilogue = BatchNorm1d(eval) scale/shift, optional residual rows, ReLU.
+// Weights: Cin % 32 == 0 -> [taps][CoutP][Cin];  Cin == 16 -> tap pairs [ceil(taps/2)][CoutP][32] (k = (tap & 1) * 16 + c,
+// the odd half of the last pair zero) so that a 32-float K slab of the MFMA pipeline carries two taps of 16 channels.
 LM_API int lm_conv_gather_mfma_f32(void* stream, const float* x, int ldx, const int* nbr, int taps, const float* wp, int CoutP,
                                    const float* scale, const float* shift, const float* res, int ldr, float* y, int ldy,
                                    long M, int Cin, int Cout, int act) {
     LM_REQUIRE(x && nbr && wp && y, "conv_gather: null pointer");
     LM_REQUIRE(M > 0 && taps >= 1, "conv_gather: empty problem (M=%ld taps=%d)", M, taps);
-    LM_REQUIRE(Cin > 0 && Cin % BK == 0, "conv_gather: Cin=%d must be a multiple of %d (zero-pad the feature rows)", Cin, BK);
+    LM_REQUIRE(Cin == 16 || (Cin > 0 && Cin % BK == 0), "conv_gather: Cin=%d must be 16 or a multiple of %d (zero-pad the feature rows)",
+               Cin, BK);
     LM_REQUIRE(CoutP >= Cout && CoutP % 128 == 0, "conv_gather: CoutP=%d must be Cout=%d rounded up to 128", CoutP, Cout);
     LM_REQUIRE(ldx >= Cin && ldx % 4 == 0 && ldy >= Cout, "conv_gather: bad leading dims ldx=%d ldy=%d", ldx, ldy);
+    const bool pairs = Cin == 16;                     // two taps share one 32-float K slab
+    const int slabs = pairs ? (taps + 1) / 2 : taps;
     ConvParams p;
     p.x = x; p.wp = wp; p.scale = scale; p.shift = shift; p.res = res; p.y = y;
     p.ldx = ldx; p.ldr = ldr; p.ldy = ldy; p.res_rows = 0;
-    p.B = 1; p.H = 1; p.W = 1; p.Cin = Cin; p.Cout = Cout; p.CoutP = CoutP; p.Ho = 1; p.Wo = 1;
-    p.KH = 1; p.KW = taps; p.stride = 1; p.pad_h = 0; p.pad_w = 0; p.dil = 1; p.act = act;
+    p.B = 1; p.H = 1; p.W = 1; p.Cin = pairs ? BK : Cin; p.Cout = Cout; p.CoutP = CoutP; p.Ho = 1; p.Wo = 1;
+    p.KH = 1; p.KW = slabs; p.stride = 1; p.pad_h = 0; p.pad_w = 0; p.dil = 1; p.act = act;
     p.M = M;
-    LM_REQUIRE(M < (1L << 31) && (long)taps * CoutP * Cin < (1L << 31), "conv_gather: problem too large (M=%ld)", M);
+    LM_REQUIRE(M < (1L << 31) && (long)slabs * CoutP * p.Cin < (1L << 31), "conv_gather: problem too large (M=%ld)", M);
     p.gn_part = nullptr;
     p.gn_chunks = 0;
     p.nbr = nbr;
+    p.taps_real = taps;
     if (int e = zero_block(&p.zero)) return e;
     hipStream_t s = (hipStream_t)stream;
+    if (pairs) {
+        if (Cout <= 32) return launch<128, 32, 32, 32, true, 2>(p, s);
+        return launch<128, 64, 32, 64, true, 2>(p, s);
+    }
+    if (Cout <= 32) return launch<128, 32, 32, 32, true>(p, s);
     if (Cout <= 64) return launch<128, 64, 32, 64, true>(p, s);
     return launch<128, 128, 64, 64, true>(p, s);
 }

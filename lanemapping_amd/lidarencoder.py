@@ -187,7 +187,7 @@ class LidarEncoder(PackedModule):
 
     # -------------------------------------------------------------------------------- forward
     def voxelize(self, points):
-        """reference :104-129 -> (feats [V, 32] (mean x,y,z,i | zeros), coords [V,4] i32 (b,z,y,x), row_ends)."""
+        """reference :104-129 -> (feats [V, 16] (mean x,y,z,i | zeros), coords [V,4] i32 (b,z,y,x), row_ends)."""
         v = self.lidar_modal_extractor['voxelize']
         return ops.voxelize_batch(points, v.range_lo, v.voxel_size, v.grid_xyz, v.max_num_points, v.max_voxels)
 
@@ -205,18 +205,20 @@ class LidarEncoder(PackedModule):
         for kind, name, layer in bb.layers():
             if kind == 'block':
                 c = layer.conv1.out_channels
-                h = ops.conv_gather(x, nbr, P[name + '.w1'], c, P[name + '.s1'], P[name + '.b1'], act=ops.ACT_RELU)
-                x = ops.conv_gather(h, nbr, P[name + '.w2'], c, P[name + '.s2'], P[name + '.b2'], res=x, act=ops.ACT_RELU)
+                h = ops.conv_gather(x, nbr, P[name + '.w1'], c, c, P[name + '.s1'], P[name + '.b1'], act=ops.ACT_RELU)
+                x = ops.conv_gather(h, nbr, P[name + '.w2'], c, c, P[name + '.s2'], P[name + '.b2'], res=x, act=ops.ACT_RELU)
                 continue
             conv = layer[0]
             if conv.subm:
                 if conv.kernel != (3, 3, 3):
                     raise NotImplementedError('submanifold kernels other than 3x3x3')
-                x = ops.conv_gather(x, nbr, P[name + '.w'], conv.out_channels, P[name + '.s'], P[name + '.b'], act=ops.ACT_RELU)
+                x = ops.conv_gather(x, nbr, P[name + '.w'], conv.in_channels, conv.out_channels, P[name + '.s'], P[name + '.b'],
+                                    act=ops.ACT_RELU)
                 continue
             out_grid, out_coords, out_shape = ops.sparse_conv_outputs(coords, batch_size, shape, conv.kernel, conv.stride, conv.padding)
             rb = ops.sparse_rulebook(out_coords, grid, conv.kernel, conv.stride, conv.padding)
-            x = ops.conv_gather(x, rb, P[name + '.w'], conv.out_channels, P[name + '.s'], P[name + '.b'], act=ops.ACT_RELU)
+            x = ops.conv_gather(x, rb, P[name + '.w'], conv.in_channels, conv.out_channels, P[name + '.s'], P[name + '.b'],
+                                act=ops.ACT_RELU)
             coords, grid, shape = out_coords, out_grid, out_shape
             nbr = None
             if name != 'conv_out':

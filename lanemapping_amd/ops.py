@@ -385,7 +385,7 @@ def tile_ingest(u8_hwc):
 _vox_ws = {}
 
 
-def voxelize_batch(points, range_lo, voxel_size, grid_xyz, max_points, max_voxels, ldf=32):
+def voxelize_batch(points, range_lo, voxel_size, grid_xyz, max_points, max_voxels, ldf=16):
     """Hard-voxelise a list of [N_i,4] device tensors -> (feats [V,ldf] (mean x,y,z,i; rest 0), coords [V,4] i32 (b,z,y,x),
     row_ends list).  One host sync at the end (the row count sizes every later launch)."""
     dev = points[0].device
@@ -463,27 +463,40 @@ def sparse_rulebook(out_coords, in_grid, kernel, stride, padding):
 
 
 def pack_sparse(w):
-    """spconv weight [kD,kH,kW,Cin,Cout] -> [taps, CoutP, CinP] (CoutP up to 128s, CinP up to 32s, zero filled)."""
+    """spconv weight [kD,kH,kW,Cin,Cout] -> kernel layout of lm_conv_gather_mfma_f32: Cin > 16: [taps, CoutP, CinP]
+    (CinP = Cin up to 32s); Cin <= 16: tap pairs [ceil(taps/2), CoutP, 32] with k = (tap & 1) * 16 + c.  Zero filled."""
     kd, kh, kw, ci, co = w.shape
-    cop, cip = (co + 127) // 128 * 128, (ci + 31) // 32 * 32
-    p = torch.zeros((kd * kh * kw, cop, cip), device=w.device, dtype=torch.float32)
-    p[:, :co, :ci] = w.reshape(kd * kh * kw, ci, co).permute(0, 2, 1)
+    taps = kd * kh * kw
+    cop = (co + 127) // 128 * 128
+    wt = w.reshape(taps, ci, co).permute(0, 2, 1).float()          # [taps, co, ci]
+    if ci <= 16:
+        p = torch.zeros(((taps + 1) // 2 * 2, cop, 16), device=w.device, dtype=torch.float32)
+        p[:taps, :co, :ci] = wt
+        return p.reshape(-1, 2, cop, 16).permute(0, 2, 1, 3).reshape(-1, cop, 32).contiguous()
+    cip = (ci + 31) // 32 * 32
+    p = torch.zeros((taps, cop, cip), device=w.device, dtype=torch.float32)
+    p[:, :co, :ci] = wt
     return p.contiguous()
 
 
-def conv_gather(x, nbr, wp, cout, scale=None, shift=None, res=None, act=ACT_NONE):
-    """Rulebook convolution: y[m, :cout] = act(bn(sum_t W[t] x[nbr[m, t]]) + res[m]).  x [V, ld] (ld % 32 == 0, padding
-    channels zero); y [M, max(32, cout rounded to 32)] zero padded the same way."""
+def sparse_ld(c):
+    """Row stride of a c-channel sparse feature matrix: 16 for <= 16 channels (tap-pair kernel), else c up to 32s."""
+    return 16 if c <= 16 else (c + 31) // 32 * 32
+
+
+def conv_gather(x, nbr, wp, cin, cout, scale=None, shift=None, res=None, act=ACT_NONE):
+    """Rulebook convolution: y[m, :cout] = act(bn(sum_t W[t] x[nbr[m, t]]) + res[m]).  x [V, sparse_ld(cin)] with zero padding
+    channels; returns y [M, sparse_ld(cout)] padded the same way."""
     M, taps = nbr.shape
-    cin = wp.shape[2]
-    assert x.stride(1) == 1 and x.stride(0) >= cin
-    ldy = (cout + 31) // 32 * 32
+    cin_k = sparse_ld(cin)
+    assert x.stride(1) == 1 and x.stride(0) >= cin_k
+    ldy = sparse_ld(cout)
     y = torch.zeros((M, ldy), device=x.device, dtype=torch.float32) if ldy != cout else \
         torch.empty((M, ldy), device=x.device, dtype=torch.float32)
     def launch():
         check(lib().lm_conv_gather_mfma_f32(_stream(), _ptr(x), x.stride(0), _ptr(nbr), taps, _ptr(wp), wp.shape[1], _ptr(scale),
                                             _ptr(shift), _ptr(res), res.stride(0) if res is not None else 0, _ptr(y), ldy,
-                                            M, cin, cout, act))
+                                            M, cin_k, cout, act))
     if _conv_hook is not None:
         _conv_hook(f'spconv M{M} taps{taps} {cin}->{cout}', 2.0 * M * taps * cin * cout, launch)
     else:

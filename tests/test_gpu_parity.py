@@ -455,7 +455,7 @@ def test_sparse_backbone_vs_oracle(dev):
     bb = le['backnone']
     ref = lidar_ref.sparse_encoder_ref(f_ref, c_ref, 2, sd, 'lidar_modal_extractor.backbone.', bb['sparse_shape'],
                                        bb['encoder_channels'], bb['encoder_paddings'], bb['block_type'])
-    feats = torch.zeros((f_ref.shape[0], 32))
+    feats = torch.zeros((f_ref.shape[0], 16))
     feats[:, :4] = torch.from_numpy(f_ref)
     with torch.no_grad():
         got = m.sparse_backbone(feats.to(dev), torch.from_numpy(c_ref).to(dev), 2, flip_h=False)
