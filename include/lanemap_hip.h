@@ -156,7 +156,8 @@ int lm_rowref_decode(void* stream, const float* ext2, const float* cls2, unsigne
 long lm_voxelize_workspace_bytes(long n_points);
 int lm_voxelize_hard(void* stream, const float* points, long n, const float* range_lo_xyz, const float* voxel_size_xyz,
                      const int* grid_xyz, int max_points, int max_voxels, int batch_idx, const int* row_base, int cap_rows,
-                     float* feats, int ldf, int* coords, int* row_end, void* workspace, long workspace_bytes);
+                     float* feats, int ldf, int* coords, int* row_end, int raster_order, void* workspace,
+                     long workspace_bytes);
 int lm_sparse_grid_build(void* stream, const int* coords, long n, int* grid, int B, int D, int H, int W);
 long lm_sparse_conv_outputs_workspace_bytes(long out_cells);
 int lm_sparse_conv_outputs(void* stream, const int* in_coords, long n_in, int B, const int* ksp_zyx9, int Do, int Ho, int Wo,

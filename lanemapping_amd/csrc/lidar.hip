@@ -59,7 +59,8 @@ __global__ __launch_bounds__(256) void vox_heads_kernel(const unsigned* __restri
 // rank[] = exclusive scan of flags in point order = voxel number in first-appearance order
 __global__ __launch_bounds__(256) void vox_emit_kernel(const float4* __restrict__ pts, const unsigned* __restrict__ keys,
                                                        const unsigned* __restrict__ vals, const unsigned* __restrict__ rank,
-                                                       const unsigned* __restrict__ flags, long n, VoxGeom G, int max_points,
+                                                       const unsigned* __restrict__ flags, const unsigned* __restrict__ rrank,
+                                                       long n, VoxGeom G, int max_points,
                                                        int max_voxels, int batch_idx, const int* __restrict__ row_base, int cap_rows,
                                                        float* __restrict__ feats, int ldf, int* __restrict__ coords,
                                                        int* __restrict__ row_end) {
@@ -73,8 +74,10 @@ __global__ __launch_bounds__(256) void vox_emit_kernel(const float4* __restrict_
         *row_end = base + nv;
     }
     if (!is_head(keys, i)) return;
-    const unsigned v = rank[vals[i]];
-    if (v >= (unsigned)max_voxels || base + (long)v >= cap_rows) return;
+    unsigned v = rank[vals[i]];
+    if (v >= (unsigned)max_voxels) return;                // the cap is defined on the first-appearance numbering
+    if (rrank) v = rrank[i];                              // raster-order numbering of the kept voxels
+    if (base + (long)v >= cap_rows) return;
     const unsigned k = keys[i];
     float sx = 0.f, sy = 0.f, sz = 0.f, sw = 0.f;
     int cnt = 0;
@@ -99,6 +102,15 @@ __global__ __launch_bounds__(256) void vox_emit_kernel(const float4* __restrict_
     o[1] = (int)(t / (unsigned)G.g[1]);
     o[2] = (int)(t % (unsigned)G.g[1]);
     o[3] = cx;
+}
+
+// kept[i] (sorted position) = head of a voxel that survives the max_voxels cap; its exclusive scan numbers the kept
+// voxels in (z, y, x) raster order, which is the order the radix sort left them in
+__global__ __launch_bounds__(256) void vox_kept_kernel(const unsigned* __restrict__ keys, const unsigned* __restrict__ vals,
+                                                       const unsigned* __restrict__ rank, long n, int max_voxels,
+                                                       unsigned* __restrict__ kept) {
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i < n) kept[i] = (is_head(keys, i) && rank[vals[i]] < (unsigned)max_voxels) ? 1u : 0u;
 }
 
 __global__ __launch_bounds__(256) void fill_i32_kernel(int* __restrict__ p, long n, int v) {
@@ -267,15 +279,18 @@ size_t scan_temp_bytes(long n) {
 LM_API long lm_voxelize_workspace_bytes(long n_points) {
     const long n = n_points > 0 ? n_points : 1;
     const size_t t1 = sort_temp_bytes(n), t2 = scan_temp_bytes(n);
-    return (long)(6 * align256((size_t)n * 4) + align256(t1 > t2 ? t1 : t2));
+    return (long)(8 * align256((size_t)n * 4) + align256(t1 > t2 ? t1 : t2));
 }
 
 // points [n,4] f32 (x, y, z, intensity) of ONE sample -> rows [*row_base, *row_end) of feats [cap_rows, ldf] (mean of the
 // kept points, channels 4.. zero) and coords [cap_rows, 4] int32 (batch_idx, z, y, x).  row_base / row_end are DEVICE ints
-// so that the samples of a batch chain without a host round trip (row_base == NULL means 0).
+// so that the samples of a batch chain without a host round trip (row_base == NULL means 0).  Row order inside the sample:
+// raster_order == 0: the reference's (voxels numbered by their first point); 1: (z, y, x) raster order of the same voxel set
+// (what the sparse convolutions want: spatial neighbours are row neighbours, so rulebook gathers hit in L2).
 LM_API int lm_voxelize_hard(void* stream, const float* points, long n, const float* range_lo_xyz, const float* voxel_size_xyz,
                             const int* grid_xyz, int max_points, int max_voxels, int batch_idx, const int* row_base, int cap_rows,
-                            float* feats, int ldf, int* coords, int* row_end, void* workspace, long workspace_bytes) {
+                            float* feats, int ldf, int* coords, int* row_end, int raster_order, void* workspace,
+                            long workspace_bytes) {
     LM_REQUIRE(range_lo_xyz && voxel_size_xyz && grid_xyz && feats && coords && row_end && workspace, "voxelize: null pointer");
     LM_REQUIRE(points || n == 0, "voxelize: null points");
     LM_REQUIRE(n >= 0 && n < (1L << 31) && ldf >= 4 && max_points >= 1 && max_voxels >= 1 && cap_rows >= 1, "voxelize: bad sizes");
@@ -300,7 +315,8 @@ LM_API int lm_voxelize_hard(void* stream, const float* points, long n, const flo
     char* w = (char*)workspace;
     unsigned *keys_in = (unsigned*)w, *keys_out = (unsigned*)(w + seg), *vals_in = (unsigned*)(w + 2 * seg),
              *vals_out = (unsigned*)(w + 3 * seg), *flags = (unsigned*)(w + 4 * seg), *rank = (unsigned*)(w + 5 * seg);
-    void* temp = w + 6 * seg;
+    unsigned *kept = (unsigned*)(w + 6 * seg), *rrank = (unsigned*)(w + 7 * seg);
+    void* temp = w + 8 * seg;
     size_t t1 = sort_temp_bytes(n), t2 = scan_temp_bytes(n);
     const int blocks = lm_cdiv(n, 256);
     const float4* p4 = reinterpret_cast<const float4*>(points);
@@ -310,7 +326,13 @@ LM_API int lm_voxelize_hard(void* stream, const float* points, long n, const flo
     hipLaunchKernelGGL(vox_heads_kernel, dim3(blocks), dim3(256), 0, s, keys_out, vals_out, n, flags);
     LM_LAUNCH_CHECK();
     LM_HIP(hipcub::DeviceScan::ExclusiveSum(temp, t2, flags, rank, (int)n, s));
-    hipLaunchKernelGGL(vox_emit_kernel, dim3(blocks), dim3(256), 0, s, p4, keys_out, vals_out, rank, flags, n, G, max_points, max_voxels,
+    if (raster_order) {
+        hipLaunchKernelGGL(vox_kept_kernel, dim3(blocks), dim3(256), 0, s, keys_out, vals_out, rank, n, max_voxels, kept);
+        LM_LAUNCH_CHECK();
+        LM_HIP(hipcub::DeviceScan::ExclusiveSum(temp, t2, kept, rrank, (int)n, s));
+    }
+    hipLaunchKernelGGL(vox_emit_kernel, dim3(blocks), dim3(256), 0, s, p4, keys_out, vals_out, rank, flags,
+                       raster_order ? rrank : (const unsigned*)nullptr, n, G, max_points, max_voxels,
                        batch_idx, row_base, cap_rows, feats, ldf, coords, row_end);
     LM_LAUNCH_CHECK();
     return LM_OK;

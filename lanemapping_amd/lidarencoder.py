@@ -186,10 +186,12 @@ class LidarEncoder(PackedModule):
         return P
 
     # -------------------------------------------------------------------------------- forward
-    def voxelize(self, points):
-        """reference :104-129 -> (feats [V, 16] (mean x,y,z,i | zeros), coords [V,4] i32 (b,z,y,x), row_ends)."""
+    def voxelize(self, points, raster_order=False):
+        """reference :104-129 -> (feats [V, 16] (mean x,y,z,i | zeros), coords [V,4] i32 (b,z,y,x), row_ends).  Default row
+        order = the reference's; forward() asks for raster order (same voxels, neighbours adjacent: L2-friendly gathers)."""
         v = self.lidar_modal_extractor['voxelize']
-        return ops.voxelize_batch(points, v.range_lo, v.voxel_size, v.grid_xyz, v.max_num_points, v.max_voxels)
+        return ops.voxelize_batch(points, v.range_lo, v.voxel_size, v.grid_xyz, v.max_num_points, v.max_voxels,
+                                  raster_order=raster_order)
 
     def sparse_backbone(self, feats, coords, batch_size, flip_h=True):
         """SparseEncoder.forward + dense().view(N, C*D, H, W) (+ the H flip of :70) -> logical [B, C*D, H, W]."""
@@ -241,5 +243,5 @@ class LidarEncoder(PackedModule):
 
     def forward(self, sample):
         pts = [getattr(item, 'data', item) for item in sample['points']]
-        feats, coords, _ = self.voxelize(pts)
+        feats, coords, _ = self.voxelize(pts, raster_order=True)
         return self.dense_tail(self.sparse_backbone(feats, coords, len(pts)))

@@ -385,9 +385,10 @@ def tile_ingest(u8_hwc):
 _vox_ws = {}
 
 
-def voxelize_batch(points, range_lo, voxel_size, grid_xyz, max_points, max_voxels, ldf=16):
+def voxelize_batch(points, range_lo, voxel_size, grid_xyz, max_points, max_voxels, ldf=16, raster_order=False):
     """Hard-voxelise a list of [N_i,4] device tensors -> (feats [V,ldf] (mean x,y,z,i; rest 0), coords [V,4] i32 (b,z,y,x),
-    row_ends list).  One host sync at the end (the row count sizes every later launch)."""
+    row_ends list).  One host sync at the end (the row count sizes every later launch).  Rows of a sample come in the
+    reference's order (voxels numbered by first point) or, with raster_order, sorted by (z, y, x) - same voxel set."""
     dev = points[0].device
     B = len(points)
     cells = int(grid_xyz[0]) * int(grid_xyz[1]) * int(grid_xyz[2])
@@ -414,7 +415,7 @@ def voxelize_batch(points, range_lo, voxel_size, grid_xyz, max_points, max_voxel
         base = C.c_void_p(ends[b - 1:b].data_ptr()) if b > 0 else None
         check(lib().lm_voxelize_hard(_stream(), _ptr(p) if p.shape[0] else None, p.shape[0], lo, vs, g, int(max_points),
                                      int(max_voxels), b, base, cap, _ptr(feats), ldf, _ptr(coords),
-                                     C.c_void_p(ends[b:b + 1].data_ptr()), _ptr(ws), ws.numel()))
+                                     C.c_void_p(ends[b:b + 1].data_ptr()), int(raster_order), _ptr(ws), ws.numel()))
     row_ends = [int(v) for v in ends.cpu()]
     V = row_ends[-1]
     return feats[:V], coords[:V], row_ends

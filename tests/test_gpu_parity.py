@@ -440,6 +440,17 @@ def test_voxelize_vs_oracle(dev, max_points, max_voxels):
     assert np.array_equal(c.cpu().numpy(), c_ref)                           # same voxels in the same (first-appearance) order
     assert float((f[:, :4].cpu() - torch.from_numpy(f_ref)).abs().max()) <= 1e-6
     assert float(f[:, 4:].abs().max()) == 0.0
+    # raster-order mode: the same voxel set (same cap), rows of every sample sorted by (z, y, x)
+    f2, c2, ends2 = ops.voxelize_batch([torch.from_numpy(p).to(dev) for p in pts], lo, vs, grid, max_points, max_voxels,
+                                       raster_order=True)
+    assert ends2 == ends
+    c2n, f2n = c2.cpu().numpy().astype(np.int64), f2.cpu().numpy()
+    key_ref = ((c_ref[:, 0].astype(np.int64) * 64 + c_ref[:, 1]) * 4096 + c_ref[:, 2]) * 4096 + c_ref[:, 3]
+    key2 = ((c2n[:, 0] * 64 + c2n[:, 1]) * 4096 + c2n[:, 2]) * 4096 + c2n[:, 3]
+    assert np.all(np.diff(key2) > 0)
+    order = np.argsort(key_ref)
+    assert np.array_equal(key_ref[order], key2)
+    assert float(np.abs(f2n[:, :4] - f_ref[order]).max()) <= 1e-6
 
 
 def test_sparse_backbone_vs_oracle(dev):

@@ -35,7 +35,7 @@ def timed(fn, rep=3):
 
 
 with torch.no_grad():
-    t_vox, (feats, coords, ends) = timed(lambda: enc.voxelize(pts))
+    t_vox, (feats, coords, ends) = timed(lambda: enc.voxelize(pts, raster_order=True))
     t_sp, dense = timed(lambda: enc.sparse_backbone(feats, coords, B))
     t_tail, _ = timed(lambda: enc.dense_tail(dense))
     t_raw, _ = timed(lambda: net.forward_raw({'points': pts}))
