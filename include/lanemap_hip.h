@@ -131,6 +131,11 @@ int lm_polyline_assemble(const float* prop_conf, const float* prop_v_ext, const 
                          int min_vertices, double* out_lanes, int* endp_keep);
 int lm_raster_polylines(const double* lanes, int P, int R, unsigned char* out);
 int lm_trace_lines(const double* cols, int n, int R, const float* seg_rows, double* out);   /* polyline_utils.py:222-387 */
+/* BEV polylines -> LAS frame: baseline/utils/coor_img2pc.py:127-183 (+ :22-53, :59-73, :94-122).  bev_hwc [H][W][C] u8 is
+ * modified in place (elevation fill of empty vertex pixels, like the reference); img_seqs [L][Vmax][2] (row, col);
+ * params13 = img_reso[2], bev_img_offset[2], ele_reso, local_min_ele, las_rotation_trans_quan[7]; out [L][Vmax][3]. */
+int lm_polyline_backproject(unsigned char* bev_hwc, int H, int W, int C, const double* img_seqs, const int* seq_lens, int L,
+                            int Vmax, const double* params13, const double* las_read_offset, double* out);
 
 /* ---- K-Lane "RowRef" head, config 4 (baseline/models/heads/row_shared_not_reduc_ref.py) ------------------------
  * softmax_rows :179-180,239-240 (in place); select :199-204; gather :207-211; scatter :227-230 (shrinking-range quirk);

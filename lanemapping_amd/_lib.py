@@ -55,6 +55,7 @@ SIGNATURES = {
     'lm_polyline_assemble': (i32, [vp, vp, vp, vp, vp, i32, i32, i32, f32, i32, vp, vp]),
     'lm_raster_polylines': (i32, [vp, i32, i32, vp]),
     'lm_trace_lines': (i32, [vp, i32, i32, vp, vp]),
+    'lm_polyline_backproject': (i32, [vp, i32, i32, i32, vp, vp, i32, i32, vp, vp, vp]),
     'lm_softmax_rows': (i32, [vp, vp, i64, i32]),
     'lm_rowref_select': (i32, [vp, vp, vp, vp, vp, i32, i32, i32, i32]),
     'lm_rowref_gather': (i32, [vp, vp, vp, vp, vp, i32, i32, i32, i32]),

@@ -7,11 +7,11 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, 'csrc')
 LIB = os.path.join(HERE, 'liblanemap_hip.so')
 SOURCES = ['errors.cpp', 'conv_mfma.hip', 'conv_direct.hip', 'norm_resize.hip', 'vit.hip', 'head.hip',
-           'decode.hip', 'raster.hip', 'rowref.hip', 'lidar.hip', 'postproc.cpp']
+           'decode.hip', 'raster.hip', 'rowref.hip', 'lidar.hip', 'postproc.cpp', 'backproject.cpp']
 
 
 # integer-output kernels whose fp32 index math must match the C oracle bit for bit
-EXACT_FP = {'raster.hip', 'lidar.hip'}
+EXACT_FP = {'raster.hip', 'lidar.hip', 'backproject.cpp'}
 
 
 def _stale():

@@ -1,6 +1,7 @@
 """Per-tile polyline output / tile parameter input, format-compatible with the reference.
 
   save_lane_seq_2d               <- baseline/utils/io_utils.py:58-93 (+ save_seqs_json :11-15, save_seqs_txt :17-26)
+  save_seqs_json/txt/list        <- baseline/utils/io_utils.py:11-56 (3-D polylines after the back-projection / merge)
   load_lane_seq                  <- baseline/utils/io_utils.py:100-123
   load_pc_2_img_transform_paras  <- baseline/utils/io_utils.py:125-150 (values on lines 1,3,5,...,13 of the file)
   pack_lane_vertices             <- heads/polyline_fpn_vit_vertex_2.py:997-1000 (row = 3 + 8 i, col, semantic)
@@ -42,6 +43,43 @@ def save_lane_seq_2d(lane_vertexes, lane_seq_path, with_pervertex_semantics=True
     else:
         with open(lane_seq_path, 'w') as f:
             json.dump(recs, f, indent=4)
+
+
+class NpEncoder(json.JSONEncoder):
+    """data/convert_data.py:15-23: numpy scalars / arrays -> JSON numbers / lists."""
+
+    def default(self, obj):
+        if isinstance(obj, np.integer):
+            return int(obj)
+        if isinstance(obj, np.floating):
+            return float(obj)
+        if isinstance(obj, np.ndarray):
+            return obj.tolist()
+        return super().default(obj)
+
+
+def save_seqs_json(seq_list, seq_path):
+    """baseline/utils/io_utils.py:11-15."""
+    with open(seq_path, 'w') as f:
+        json.dump(seq_list, f, indent=4, cls=NpEncoder)
+
+
+def save_seqs_txt(seq_list, seq_path):
+    """baseline/utils/io_utils.py:17-26: one vertex per line, trailing line id."""
+    with open(seq_path, 'w') as f:
+        for i, seq in enumerate(seq_list):
+            for vtx in seq['seq']:
+                f.write(' '.join(str(item) for item in vtx) + ' ' + str(i) + '\n')
+
+
+def save_seqs_list(lane_vertexes, lane_seq_path):
+    """baseline/utils/io_utils.py:28-56: list of [n_i, d] arrays -> records of the lines with >= 2 vertices."""
+    lines = [{'seq_len': v.shape[0], 'seq': v, 'init_vertex': v[0, :], 'end_vertex': v[-1, :]}
+             for v in lane_vertexes if v.shape[0] >= 2]
+    if os.path.splitext(lane_seq_path)[1] == '.txt':
+        save_seqs_txt(lines, lane_seq_path)
+    else:
+        save_seqs_json(lines, lane_seq_path)
 
 
 def load_lane_seq(seqfile_path, dim_coor=2):

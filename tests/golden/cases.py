@@ -197,3 +197,48 @@ def small_lidar_cfg(Xn=24, grid=96, sparse_hw=100, max_voxels=100000, max_points
                           order=('conv', 'norm', 'act'),
                           encoder_channels=((16, 16, 32), (32, 32, 64), (64, 64, 128), (128, 128)),
                           encoder_paddings=([0, 0, 1], [0, 0, 1], [0, 0, [1, 1, 0]], [0, 0]), block_type='basicblock'))))
+
+
+# ---------------------------------------------------------------------------------------------- f1 (BEV polylines -> LAS frame)
+def img2pc_case(seed, n_line=6, max_len=40, size=384):
+    """(params, img_seqs [L,V,2], lens, tile u8 HWC) with empty regions under some vertices (big enough that the fill of one
+    vertex feeds the window of the next), padding slots at (0, 0) and a non-unit quaternion."""
+    from lanemapping_amd import synth
+    tile = synth.bev_tile_u8(seed, size).copy()
+    u = synth.uniform(seed, 64, 77)
+    tile[int(60 + 40 * u[0]):int(150 + 40 * u[1]), int(40 + 30 * u[2]):int(200 + 60 * u[3]), :] = 0     # large hole
+    tile[int(250 + 20 * u[4]):int(270 + 30 * u[5]), :, :] = 0                                              # empty band
+    tile[300:303, 100:103, :] = [[[1, 0, 0]] * 3] * 3                                                      # channel sum == 1: "empty"
+    lens = [int(2 + (max_len - 2) * u[8 + l]) for l in range(n_line)]
+    lens[1] = 1                                                                                            # degenerate fit (q == 0)
+    lens[2] = max_len
+    seqs = np.zeros((n_line, max_len, 2))
+    for l in range(n_line):
+        r0 = 3 + 8 * int(4 * u[20 + l])
+        rows = r0 + 8 * np.arange(lens[l])
+        cols = 30 + (size - 60) * u[30 + l] + 0.15 * (rows - r0) * (u[40 + l] - 0.5) + synth.uniform(seed + l, lens[l], 78) * 3
+        seqs[l, :lens[l], 0] = np.minimum(rows, size - 1)
+        seqs[l, :lens[l], 1] = np.clip(cols, 1, size - 1)
+    seqs[3, 2] = (301., 101.)                                                                              # lands on the sum == 1 pixel
+    params = {'img_reso': [0.05, 0.0499], 'bev_img_offset': [-12.5 + u[50], 7.25 - u[51]], 'ele_reso': 0.0213,
+              'local_min_ele': -3.4 + u[52], 'las_read_offset': [351200.0, 3433000.0, 12.0],
+              'las_rotation_trans_quan': [18.25 + u[53], -7.5, 1.125, 0.92 + 0.1 * u[54], 0.013, -0.021, 0.38 + 0.1 * u[55]]}
+    return params, seqs, lens, tile
+
+
+def write_img2pc_files(d, seed):
+    """Inputs of the per-tile driver: t.json (2-D polylines, reference writer format), t.png, t.txt (parameter file)."""
+    import json
+    from PIL import Image
+    params, seqs, lens, tile = img2pc_case(seed)
+    recs = [{'seq_len': int(n), 'seq': [[float(r), float(c), 1.0] for r, c in seqs[l, :n]], 'init_vertex': seqs[l, 0].tolist(),
+             'end_vertex': seqs[l, n - 1].tolist()} for l, n in enumerate(lens)]
+    with open(f'{d}/t.json', 'w') as f:
+        json.dump(recs, f, indent=4)
+    Image.fromarray(tile).save(f'{d}/t.png')
+    sp = lambda v: ' '.join(repr(float(x)) for x in v)
+    with open(f'{d}/t.txt', 'w') as f:
+        f.write('\n'.join(['coor_las_path', 'synthetic.las', 'las_read_offset', sp(params['las_read_offset']),
+                           'las_rotation_trans_quan', sp(params['las_rotation_trans_quan']), 'bev_img_offset',
+                           sp(params['bev_img_offset']), 'img_reso', sp(params['img_reso']), 'local_min_ele',
+                           repr(float(params['local_min_ele'])), 'ele_reso', repr(float(params['ele_reso'])), '']))

@@ -287,6 +287,26 @@ def g11(cfg, net):
          bi_seg=bi.numpy().astype(np.float32), endp=en.numpy().astype(np.float32))
 
 
+def g12(cfg, net):
+    """f1: transform_coordinate_from_img_2_pc of the reference (baseline/utils/coor_img2pc.py) on 3 seeded cases."""
+    _refload.install()
+    sys.path.insert(0, os.path.join(_refload.REF_ROOT, 'baseline', 'utils'))
+    import coor_img2pc as ref
+    keep = {}
+    for i, seed in enumerate((501, 502, 503)):
+        params, seqs, lens, tile = cases.img2pc_case(seed)
+        keep[f'out_{i}'] = ref.transform_coordinate_from_img_2_pc(params, seqs.copy(), list(lens), tile.copy())
+    # file-level driver (:185-220): 2-D JSON + PNG + parameter file -> 3-D JSON / TXT
+    import tempfile
+    from PIL import Image
+    with tempfile.TemporaryDirectory() as d:
+        cases.write_img2pc_files(d, 501)
+        ref.transform_coordinate_from_img_2_pc_single(f'{d}/t.json', f'{d}/t.png', f'{d}/t.txt', f'{d}/o.json', f'{d}/o.txt')
+        keep['file_json'] = np.array(open(f'{d}/o.json').read())
+        keep['file_txt'] = np.array(open(f'{d}/o.txt').read())
+    save('g12_img2pc.npz', seeds=np.array([501, 502, 503]), **keep)
+
+
 def main():
     which = sys.argv[1:] or ['g2', 'g3', 'g4', 'g5', 'g6', 'g7', 'g10']
     _stable_sorts(True)

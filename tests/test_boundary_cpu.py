@@ -303,3 +303,52 @@ def test_sparse_encoder_ref_against_sitewise_definition():
                                 acc += feats[j].astype(np.float64) @ w[kz, ky, kx]
                 assert bool(m2[0, 0, oz, oy, ox]) == hit
                 assert np.allclose(got2[0, :, oz, oy, ox].numpy(), acc if hit else 0, atol=1e-5)
+
+
+# ----------------------------------------------------------------------------------------------- f1: BEV polylines -> LAS frame
+def test_polyline_backproject_golden_g12(golden, tmp_path):
+    """lm_polyline_backproject (host C++) vs the reference's transform_coordinate_from_img_2_pc: bit-identical float64,
+    and the per-tile file driver reproduces the reference's JSON / TXT text."""
+    import cases
+    from lanemapping_amd import coor_img2pc
+    g = golden('g12_img2pc.npz')
+    for i, seed in enumerate(g['seeds']):
+        params, seqs, lens, tile = cases.img2pc_case(int(seed))
+        keep = tile.copy()
+        out = coor_img2pc.transform_coordinate_from_img_2_pc(params, seqs.copy(), lens, tile)
+        assert np.array_equal(out, g[f'out_{i}'])
+        assert np.array_equal(tile, keep)                       # the caller's tile is not modified
+    cases.write_img2pc_files(str(tmp_path), 501)
+    coor_img2pc.transform_coordinate_from_img_2_pc_single(f'{tmp_path}/t.json', f'{tmp_path}/t.png', f'{tmp_path}/t.txt',
+                                                          f'{tmp_path}/o.json', f'{tmp_path}/o.txt')
+    assert open(f'{tmp_path}/o.json').read() == str(g['file_json'])
+    assert open(f'{tmp_path}/o.txt').read() == str(g['file_txt'])
+
+
+def test_polyline_backproject_errors_and_roundtrip():
+    """Error behaviour + LAS -> BEV -> LAS closure against the rasteriser's C oracle: every vertex placed on an occupied
+    pixel maps back to within one pixel pitch / one elevation step of a point that landed in that pixel."""
+    from lanemapping_amd import coor_img2pc, synth
+    from lanemapping_amd._lib import LanemapHipError
+    from oracle import raster_ref
+    params = {'img_reso': [0.05, 0.05], 'bev_img_offset': [0.0, 0.0], 'ele_reso': 0.02, 'local_min_ele': -0.5,
+              'las_read_offset': [0.0, 0.0, 0.0], 'las_rotation_trans_quan': [1.5, -2.0, 0.25, 0.9, 0.02, -0.03, 0.4]}
+    with pytest.raises(LanemapHipError):                         # an all-empty tile has no elevation to borrow
+        coor_img2pc.transform_coordinate_from_img_2_pc(params, np.array([[[5., 5.], [13., 6.]]]), [2], np.zeros((32, 32, 3), np.uint8))
+    with pytest.raises(LanemapHipError):                         # vertex outside the tile
+        coor_img2pc.transform_coordinate_from_img_2_pc(params, np.array([[[5., 40.], [13., 6.]]]), [2], np.ones((32, 32, 3), np.uint8))
+    H = W = 128
+    q = np.array(params['las_rotation_trans_quan'][3:])
+    pts_tile = synth.las_points(7, 60000, extent=H * 0.05)
+    # move the tile-frame points into the LAS frame with the reference's forward transform (rotate, translate)
+    from oracle import img2pc_ref
+    las = np.stack([img2pc_ref.rotate(q, p[:3]) + np.array(params['las_rotation_trans_quan'][:3]) for p in pts_tile[:4000]])
+    pts = np.concatenate([las, pts_tile[:4000, 3:4]], axis=1).astype(np.float32)
+    rp = raster_ref.params(quat=q, trans=params['las_rotation_trans_quan'][:3], bev_img_offset=(0, 0), img_reso=(0.05, 0.05),
+                                local_min_ele=-0.5, ele_reso=0.02)
+    img = raster_ref.raster(pts, rp, H, W)
+    occ = np.argwhere(img.sum(axis=2) > 1)[:80]
+    seqs = occ[None].astype(np.float64)
+    out = coor_img2pc.transform_coordinate_from_img_2_pc(params, seqs, [len(occ)], img)
+    d = np.sqrt(((out[0][:, None, :2] - las[None, :, :2]) ** 2).sum(-1)).min(axis=1)
+    assert float(d.max()) <= 0.05 * 1.5

@@ -159,3 +159,15 @@ def test_g11_lidar_dense_tail(golden):
     for name, o in zip(('fea', 'fea_up', 'bi_seg', 'endp'), outs):
         assert o.shape == g[name].shape
         assert float((o - torch.from_numpy(g[name])).abs().max()) <= 1e-6, name
+
+
+# ----------------------------------------------------------------------------------------------- G12 (f1: BEV -> LAS frame)
+def test_g12_img2pc_oracle(golden):
+    from oracle import img2pc_ref
+    g = golden('g12_img2pc.npz')
+    for i, seed in enumerate(g['seeds']):
+        params, seqs, lens, tile = cases.img2pc_case(int(seed))
+        n_empty = sum(int(tile[int(r), int(c)].sum()) <= 1 for l, n in enumerate(lens) for r, c in seqs[l, :n])
+        assert n_empty >= 5                                     # the elevation fill is exercised
+        out = img2pc_ref.img_to_pc_ref(params, seqs.copy(), lens, tile.copy())
+        assert np.array_equal(out, g[f'out_{i}'])               # float64, same operation order: bit-identical
