@@ -176,6 +176,20 @@ int lm_sparse_to_dense_nhwc(void* stream, const float* feats, int ldf, const int
                             int H, int W, int C, int flip_h);
 int lm_upsample_bicubic_nhwc(void* stream, const float* x, float* y, int B, int H, int W, int C, int Ho, int Wo);
 
+/* ---- LAS ingest (replaces laspy in `read_las`, baseline/datasets/laserlane_proposals.py:618-636; ASPRS LAS 1.0-1.4,
+ * point data record formats 0-10, uncompressed).  parse_header: HOST bytes of the file.  decode_points: records = DEVICE
+ * copy of the point data (4-byte aligned, padded to a multiple of 4 bytes); out [n][4] f32 = X*scale + (offset - shift)
+ * in f64, intensity raw (normalise 0) or (clip(i, lo, hi) - lo) / hi (normalise 1, read_las). */
+typedef struct {
+    int version_major, version_minor, point_format, record_len;
+    long n_points, offset_to_points;
+    double scale[3], offset[3], min_xyz[3], max_xyz[3];
+} LmLasHeader;
+int lm_las_parse_header(const unsigned char* bytes, long len, LmLasHeader* out);
+int lm_las_decode_points(void* stream, const unsigned char* records, int record_len, long n, const double* scale,
+                         const double* offset, const double* shift, float inten_lo, float inten_hi, int normalise,
+                         float* out_xyzi);
+
 #ifdef __cplusplus
 }
 #endif

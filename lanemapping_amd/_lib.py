@@ -20,6 +20,13 @@ class LmRasterParams(C.Structure):
                 ('inten_lo', C.c_float), ('inten_hi', C.c_float)]
 
 
+class LmLasHeader(C.Structure):
+    """Fields of the LAS public header block the ingest needs (include/lanemap_hip.h)."""
+    _fields_ = [('version_major', C.c_int), ('version_minor', C.c_int), ('point_format', C.c_int), ('record_len', C.c_int),
+                ('n_points', C.c_long), ('offset_to_points', C.c_long), ('scale', C.c_double * 3), ('offset', C.c_double * 3),
+                ('min_xyz', C.c_double * 3), ('max_xyz', C.c_double * 3)]
+
+
 # name -> (restype, argtypes); every entry must be declared in include/lanemap_hip.h
 SIGNATURES = {
     'lm_abi_version': (i32, []),
@@ -70,6 +77,9 @@ SIGNATURES = {
     'lm_conv_gather_mfma_f32': (i32, [vp, vp, i32, vp, i32, vp, i32, vp, vp, vp, i32, vp, i32, i64, i32, i32, i32]),
     'lm_sparse_to_dense_nhwc': (i32, [vp, vp, i32, vp, i64, vp, i32, i32, i32, i32, i32, i32]),
     'lm_upsample_bicubic_nhwc': (i32, [vp, vp, vp, i32, i32, i32, i32, i32, i32]),
+    'lm_las_parse_header': (i32, [vp, i64, C.POINTER(LmLasHeader)]),
+    'lm_las_decode_points': (i32, [vp, vp, i32, i64, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_double), f32, f32,
+                                   i32, vp]),
 }
 
 _lib = None

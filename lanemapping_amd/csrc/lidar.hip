@@ -430,3 +430,101 @@ LM_API int lm_upsample_bicubic_nhwc(void* stream, const float* x, float* y, int 
     LM_LAUNCH_CHECK();
     return LM_OK;
 }
+
+// ------------------------------------------------------------------------------------------------------------------------
+// LAS point records -> [N,4] f32 in HBM (the reference reads LAS through laspy on the host,
+// baseline/datasets/laserlane_proposals.py:618-636 `read_las`: positions = X * scale + offset, intensity clipped to
+// [800, 33000] then (i - 800) / 33000).  ASPRS LAS 1.0-1.4, point data record formats 0-10: every format starts with
+// X, Y, Z (int32 LE) and intensity (uint16 LE); the rest of the record is skipped.  HBM-bound byte work: a workgroup stages
+// 256 records with coalesced dword loads into LDS and each lane decodes one record from there.
+namespace {
+
+__global__ __launch_bounds__(256) void las_decode_kernel(const unsigned* __restrict__ rec, int record_len, long n, double sx, double sy,
+                                                         double sz, double ox, double oy, double oz, float lo, float hi, int normalise,
+                                                         float4* __restrict__ out) {
+    extern __shared__ unsigned stage[];
+    const long first = (long)blockIdx.x * 256;
+    const long cnt = n - first < 256 ? n - first : 256;
+    const long byte0 = first * record_len;                       // multiple of 256 * record_len => 4-byte aligned
+    const long words = (cnt * record_len + 3) / 4;
+    const unsigned* src = rec + byte0 / 4;
+    for (long w = threadIdx.x; w < words; w += 256) stage[w] = src[w];
+    __syncthreads();
+    if (threadIdx.x >= cnt) return;
+    const unsigned char* r = reinterpret_cast<const unsigned char*>(stage) + (long)threadIdx.x * record_len;
+    auto i32 = [&](int o) { return (int)((unsigned)r[o] | ((unsigned)r[o + 1] << 8) | ((unsigned)r[o + 2] << 16) | ((unsigned)r[o + 3] << 24)); };
+    const double x = (double)i32(0) * sx + ox, y = (double)i32(4) * sy + oy, z = (double)i32(8) * sz + oz;
+    const double raw = (double)((unsigned)r[12] | ((unsigned)r[13] << 8));
+    const double it = normalise ? (fmin(fmax(raw, (double)lo), (double)hi) - (double)lo) / (double)hi : raw;   // f64 like read_las
+    out[first + threadIdx.x] = float4{(float)x, (float)y, (float)z, (float)it};
+}
+
+unsigned short rd16(const unsigned char* p) { return (unsigned short)(p[0] | (p[1] << 8)); }
+unsigned rd32(const unsigned char* p) { return (unsigned)p[0] | ((unsigned)p[1] << 8) | ((unsigned)p[2] << 16) | ((unsigned)p[3] << 24); }
+unsigned long rd64(const unsigned char* p) { return (unsigned long)rd32(p) | ((unsigned long)rd32(p + 4) << 32); }
+double rdf64(const unsigned char* p) {
+    unsigned long v = rd64(p);
+    double d;
+    __builtin_memcpy(&d, &v, 8);
+    return d;
+}
+
+}  // namespace
+
+struct LmLasHeader {          // the fields of the public header block the ingest needs
+    int version_major, version_minor, point_format, record_len;
+    long n_points, offset_to_points;
+    double scale[3], offset[3], min_xyz[3], max_xyz[3];
+};
+
+// Parse the LAS public header block (HOST bytes).  Errors: not a LAS file, truncated, compressed (LAZ) or unknown format.
+LM_API int lm_las_parse_header(const unsigned char* bytes, long len, LmLasHeader* h) {
+    LM_REQUIRE(bytes && h, "las_parse_header: null pointer");
+    LM_REQUIRE(len >= 227 && bytes[0] == 'L' && bytes[1] == 'A' && bytes[2] == 'S' && bytes[3] == 'F', "las_parse_header: not a LAS file");
+    h->version_major = bytes[24];
+    h->version_minor = bytes[25];
+    const int header_size = rd16(bytes + 94);
+    h->offset_to_points = rd32(bytes + 96);
+    const int fmt = bytes[104];
+    LM_REQUIRE((fmt & 0x80) == 0 && (fmt & 0x40) == 0, "las_parse_header: compressed (LAZ) point data is not supported");
+    h->point_format = fmt & 0x3F;
+    LM_REQUIRE(h->point_format <= 10, "las_parse_header: unknown point data record format %d", h->point_format);
+    h->record_len = rd16(bytes + 105);
+    h->n_points = rd32(bytes + 107);                              // legacy count
+    for (int a = 0; a < 3; ++a) {
+        h->scale[a] = rdf64(bytes + 131 + 8 * a);
+        h->offset[a] = rdf64(bytes + 155 + 8 * a);
+        h->max_xyz[a] = rdf64(bytes + 179 + 16 * a);
+        h->min_xyz[a] = rdf64(bytes + 187 + 16 * a);
+    }
+    if (h->version_major == 1 && h->version_minor >= 4) {
+        LM_REQUIRE(len >= 375 && header_size >= 375, "las_parse_header: truncated LAS 1.4 header");
+        const long n64 = (long)rd64(bytes + 247);
+        if (n64 > 0) h->n_points = n64;
+    }
+    static const int min_len[11] = {20, 28, 26, 34, 57, 63, 30, 36, 38, 59, 67};
+    LM_REQUIRE(h->record_len >= min_len[h->point_format], "las_parse_header: record length %d too short for format %d", h->record_len,
+               h->point_format);
+    LM_REQUIRE(h->offset_to_points >= header_size && h->offset_to_points + h->n_points * h->record_len <= len,
+               "las_parse_header: point data (%ld records of %d B at %ld) exceeds the file (%ld B)", h->n_points, h->record_len,
+               h->offset_to_points, len);
+    return LM_OK;
+}
+
+// records: DEVICE copy of the point data (4-byte aligned, n * record_len bytes rounded up to a multiple of 4).
+// out [n,4] f32 = X*scale + (offset - shift) evaluated in f64 (shift = the tile's las_read_offset keeps f32 exact to the mm), intensity raw (normalise == 0, what lm_bev_raster_batch takes) or read_las's (clip - lo) / hi.
+LM_API int lm_las_decode_points(void* stream, const unsigned char* records, int record_len, long n, const double* scale,
+                                const double* offset, const double* shift, float inten_lo, float inten_hi, int normalise,
+                                float* out_xyzi) {
+    LM_REQUIRE(scale && offset && out_xyzi && (records || n == 0), "las_decode_points: null pointer");
+    LM_REQUIRE(record_len >= 20 && record_len <= 160 && n >= 0, "las_decode_points: bad record length %d", record_len);
+    LM_REQUIRE(((uintptr_t)records & 3) == 0 && ((uintptr_t)out_xyzi & 15) == 0, "las_decode_points: buffers must be 4 / 16-byte aligned");
+    if (n == 0) return LM_OK;
+    const double sh[3] = {shift ? shift[0] : 0.0, shift ? shift[1] : 0.0, shift ? shift[2] : 0.0};
+    const size_t lds = ((size_t)256 * record_len + 3) / 4 * 4;
+    hipLaunchKernelGGL(las_decode_kernel, dim3(lm_cdiv(n, 256)), dim3(256), lds, (hipStream_t)stream,
+                       reinterpret_cast<const unsigned*>(records), record_len, n, scale[0], scale[1], scale[2], offset[0] - sh[0],
+                       offset[1] - sh[1], offset[2] - sh[2], inten_lo, inten_hi, normalise, reinterpret_cast<float4*>(out_xyzi));
+    LM_LAUNCH_CHECK();
+    return LM_OK;
+}

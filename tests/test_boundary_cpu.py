@@ -352,3 +352,30 @@ def test_polyline_backproject_errors_and_roundtrip():
     out = coor_img2pc.transform_coordinate_from_img_2_pc(params, seqs, [len(occ)], img)
     d = np.sqrt(((out[0][:, None, :2] - las[None, :, :2]) ** 2).sum(-1)).min(axis=1)
     assert float(d.max()) <= 0.05 * 1.5
+
+
+# ----------------------------------------------------------------------------------------------- f4: LAS header (host part)
+def test_las_header_parse(tmp_path):
+    from lanemapping_amd import las_io
+    from lanemapping_amd._lib import LanemapHipError
+    from oracle import las_ref
+    rng = np.random.RandomState(5)
+    xyz = rng.rand(1000, 3) * [50, 50, 3] + [351200.0, 3433000.0, 10.0]
+    inten = rng.randint(0, 65535, 1000)
+    p12 = str(tmp_path / 'a.las')
+    las_ref.write_las(p12, xyz, inten, point_format=1, version=(1, 2), offset=(351200.0, 3433000.0, 0.0), vlr_bytes=54)
+    h = las_io.parse_header(open(p12, 'rb').read())
+    assert h['version'] == (1, 2) and h['point_format'] == 1 and h['record_len'] == 28 and h['n_points'] == 1000
+    assert h['offset_to_points'] == 227 + 54 and h['scale'] == [0.001] * 3 and h['offset'] == [351200.0, 3433000.0, 0.0]
+    p14 = str(tmp_path / 'b.las')
+    las_ref.write_las(p14, xyz, inten, point_format=6, version=(1, 4), extra_bytes=3, offset=(351200.0, 3433000.0, 0.0))
+    h = las_io.parse_header(np.fromfile(p14, dtype=np.uint8))
+    assert h['version'] == (1, 4) and h['record_len'] == 33 and h['n_points'] == 1000 and h['offset_to_points'] == 375
+    raw = bytearray(open(p12, 'rb').read())
+    with pytest.raises(LanemapHipError):
+        las_io.parse_header(b'LAZY' + bytes(raw[4:]))
+    with pytest.raises(LanemapHipError):
+        las_io.parse_header(bytes(raw[:5000]))                  # truncated point data
+    raw[104] |= 0x80                                            # LAZ-compressed marker
+    with pytest.raises(LanemapHipError):
+        las_io.parse_header(bytes(raw))
