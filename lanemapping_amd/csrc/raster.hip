@@ -108,7 +108,9 @@ __global__ __launch_bounds__(256) void raster_partition_kernel(const f32x4* __re
 #pragma unroll
         for (int j = 0; j < LB; ++j) {
             const long i = (long)(j0 + j) * 256 + tid;
-            p[j] = (i < left) ? __builtin_nontemporal_load(base + i) : f32x4{0.f, 0.f, 0.f, 0.f};
+            // unconditional (index clamped into the chunk): a predicated load made the compiler wait for each load before
+            // issuing the next one, i.e. 1 load in flight per lane instead of 8; the tail lanes are masked below
+            p[j] = __builtin_nontemporal_load(base + (i < left ? i : left - 1));
         }
 #pragma unroll
         for (int j = 0; j < LB; ++j) {

@@ -13,7 +13,12 @@ from lanemapping_amd import ops, synth  # noqa: E402
 N = int(sys.argv[1]) if len(sys.argv) > 1 else 4194304
 TILES = 16
 dev = torch.device('cuda:0')
-pts = torch.cat([torch.from_numpy(synth.las_points(2021 + (i % 4), N)) for i in range(TILES)]).to(dev)
+if os.environ.get('RASTER_UNIFORM'):      # uniform x, y instead of the config-3 cloud (30 % of the points on 6 lane stripes)
+    g = torch.Generator().manual_seed(1)
+    one = torch.rand((N, 4), generator=g) * torch.tensor([57.6, 57.6, 1.0, 30000.0]) + torch.tensor([0, 0, 0, 800.0])
+    pts = torch.cat([one] * TILES).to(dev)
+else:
+    pts = torch.cat([torch.from_numpy(synth.las_points(2021 + (i % 4), N)) for i in range(TILES)]).to(dev)
 par = [ops.make_raster_params(local_min_ele=-0.5, ele_reso=0.02)] * TILES
 offs = [i * N for i in range(TILES + 1)]
 out = torch.empty((TILES, 3, 1152, 1152), device=dev)
