@@ -211,7 +211,11 @@ def test_end_to_end_golden_g10(dev, net, golden):
     flips_inside_noise(o['semantic_seg'].numpy().astype(np.uint8)[0], g['semantic_seg'][0], g['sem_lowmargin'], 'semantic_seg', 32)
     cls_idx = net.heads._compact['cls_idx'].cpu().numpy()[0]
     assert np.array_equal(cls_idx, g['cls2'][0].argmax(-1)), 'column-bin argmax must match the reference exactly'
-    np.testing.assert_allclose(o['cls_offset'].numpy(), g['cls_offset'], rtol=0, atol=1e-4)
+    # cls_offset = bin index + offset2[bin] + proposal origin: exact integers plus one fp32 regression output, so its error
+    # IS offset2's; with the seeded random weights |offset2| reaches ~30 (a trained head keeps it inside one bin), hence the
+    # same "1e-4 of the tensor scale" bound as for offset2 itself (= 1e-4 absolute for a head with |offset2| <= 1)
+    off_scale = max(1.0, float(np.abs(g['offset2']).max()))
+    np.testing.assert_allclose(o['cls_offset'].numpy(), g['cls_offset'], rtol=0, atol=1e-4 * off_scale)
     _close(o['prop_conf'], g['prop_conf'], 1e-4, 'prop_conf')
     assert np.array_equal(np.stack(np.nonzero(o['endp'][0].numpy()), axis=1), g['endp'])
     # Polyline assembly is a discontinuous function of its inputs (greedy tracing, int() truncation, confidence
