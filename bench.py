@@ -48,7 +48,8 @@ def cpu_baseline(budget_s=25.0, max_threads=64):
     from oracle import net_ref, decode_ref, postproc_ref
     cores = min(usable_cores(), max_threads)
     torch.set_num_threads(cores)
-    net = build_net_from_config('Proj_polyline_fpn_vit_vertex_2', device='cpu')
+    net = build_net_from_config('Proj_polyline_lidarconv_vit_vertex_2' if args.workload == 'lidar' else 'Proj_polyline_fpn_vit_vertex_2',
+                                device='cpu')
     synth.fill_module_(net, 2021)
     sd = {k: v for k, v in net.state_dict().items()}
 
@@ -80,9 +81,12 @@ def main():
     ap.add_argument('--cpu-budget-s', type=float, default=25.0)
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--host-threads', type=int, default=8)
-    ap.add_argument('--workload', choices=['tiles', 'fused'], default='tiles',
-                    help="tiles = BASELINE configs[1] (pre-rasterised, batch 8); fused = configs[2] (on-GPU LAS->BEV raster + net, batch 16)")
-    ap.add_argument('--streams', type=int, default=4, help='split every batch over this many HIP streams (fills launch tails)')
+    ap.add_argument('--workload', choices=['tiles', 'fused', 'lidar'], default='tiles',
+                    help="tiles = BASELINE configs[1] (pre-rasterised, batch 8); fused = configs[2] (on-GPU LAS->BEV raster + net, "
+                         "batch 16); lidar = configs[4] (sparse-conv LiDAR encoder path, batch 8 point clouds, parity unpinned)")
+    ap.add_argument('--streams', type=int, default=None,
+                    help='split every batch over this many HIP streams (fills launch tails); default 4, 1 for --workload lidar '
+                         '(its active-set bookkeeping needs host round trips, which serialise sub-batches)')
     ap.add_argument('--conv-detail', action='store_true', help='per-shape table of the MFMA launches on stderr')
     ap.add_argument('--no-roofline-events', action='store_true', help='skip the per-launch HIP events')
     args = ap.parse_args()
@@ -105,13 +109,17 @@ def main():
     from lanemapping_amd.boundary import build_net_from_config
     from lanemapping_amd.pipeline import TilePipeline
     lib()                                                    # raises if the HIP library is missing
-    net = build_net_from_config('Proj_polyline_fpn_vit_vertex_2', device='cpu')
+    net = build_net_from_config('Proj_polyline_lidarconv_vit_vertex_2' if args.workload == 'lidar' else 'Proj_polyline_fpn_vit_vertex_2',
+                                device='cpu')
     synth.fill_module_(net, 2021)
     net = net.to(dev)
     # weak scaling: every rank owns its own BATCH tiles per step (seeds differ per rank)
-    batch = BATCH if args.workload == 'tiles' else 16
+    batch = 16 if args.workload == 'fused' else BATCH
     N_PTS = 4194304
-    if args.workload == 'tiles':
+    if args.workload == 'lidar':    # the config-3 cloud in the ego frame, cropped by the voxeliser, resident in HBM
+        clouds = [torch.from_numpy(synth.lidar_points(2021 + rank * 4 + i, N_PTS)).to(dev) for i in range(4)]
+        tiles = [clouds[i % 4] for i in range(batch)]
+    elif args.workload == 'tiles':
         tiles = torch.from_numpy(synth.bev_batch([2021 + rank * batch + i for i in range(batch)], 1152)).to(dev)
     else:       # 4,194,304 LAS-shaped points per tile, resident in HBM (4 distinct clouds, repeated)
         clouds = [torch.from_numpy(synth.las_points(2021 + rank * 4 + i, N_PTS)) for i in range(4)]
@@ -120,7 +128,7 @@ def main():
         rpar = [ops.make_raster_params(local_min_ele=-0.5, ele_reso=0.02)] * batch
         tiles = torch.empty((batch, 3, 1152, 1152), device=dev)
     pipe = TilePipeline(net, host_threads=args.host_threads)
-    nstream = max(1, args.streams)
+    nstream = max(1, args.streams if args.streams is not None else (1 if args.workload == 'lidar' else 4))
     extra_streams = [torch.cuda.Stream(device=dev) for _ in range(nstream - 1)]
     extra_pipes = [TilePipeline(net, host_threads=args.host_threads) for _ in range(nstream - 1)]
     rast = {'pairs': [], 'on': False}
@@ -260,16 +268,20 @@ def main():
     achieved = prof['flops'] / (conv_ms * 1e-3) / 1e12 if conv_ms > 0 else 0.0
     n_lines = int(np.mean([(np.count_nonzero(l[:, :, 0] > 0, axis=1) >= 2).sum() for l, _ in last])) if last else 0
     result = {
-        'metric': 'BEV tiles/sec end-to-end (pre-rasterised tile -> polylines)', 'value': world * batch * args.steps / dt,
+        'metric': 'BEV tiles/sec end-to-end (%s -> polylines)' % {'tiles': 'pre-rasterised tile', 'fused': 'LAS points', 'lidar': 'LiDAR point cloud'}[args.workload],
+        'value': world * batch * args.steps / dt,
         'unit': 'tiles/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
         'ms_per_step': dt / args.steps * 1e3, 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
         'dtype': 'f32', 'data': 'synthetic',
         'config': {'workload': ('configs/Proj_polyline_fpn_vit_vertex_2.py inference, batch=8 per GPU, pre-rasterised '
                                 'synthetic 1152x1152 BEV tiles resident in HBM, seeded random weights') if args.workload == 'tiles'
+                   else ('configs/Proj_polyline_lidarconv_vit_vertex_2.py inference (sparse-conv LiDAR encoder, parity unpinned), batch=8 '
+                         'point clouds of 4,194,304 points per GPU resident in HBM, seeded random weights') if args.workload == 'lidar'
                    else ('on-GPU LAS->BEV raster (4,194,304 points/tile resident in HBM) + configs/Proj_polyline_fpn_vit_vertex_2.py, '
                          'batch=16 per GPU, seeded random weights'),
                    'tiles_per_step_per_gpu': batch, 'lines_per_tile': n_lines, 'host_threads': args.host_threads, 'streams': nstream},
-        'roofline': {'bound': 'mfma', 'kernel': 'conv_mfma_kernel (all FPN/ViT/head implicit-GEMM launches)',
+        'roofline': {'bound': 'mfma', 'kernel': 'conv_mfma_kernel (all FPN/ViT/head implicit-GEMM launches)' if args.workload != 'lidar'
+                     else 'conv_mfma_kernel (rulebook sparse convolutions + dense tail/ViT/head GEMMs)',
                      'achieved': achieved, 'peak': MFMA_F32_PEAK_TFLOPS, 'unit': 'TFLOP/s',
                      'frac': achieved / MFMA_F32_PEAK_TFLOPS, 'traffic': None,
                      'scope': roof_scope, 'launches_per_step': prof['launches'] / max(roof_steps, 1),

@@ -23,7 +23,9 @@ class TilePipeline:
 
     def _gpu_stage(self, proj):
         heads, cfg = self.net.heads, self.cfg
-        raw = self.net.forward_raw({'proj': proj})
+        # a [B,3,H,W] tile tensor (FPN path), a list of [N_i,4] point tensors (sparse-conv LiDAR path, config 5) or a batch dict
+        batch = proj if isinstance(proj, dict) else ({'points': list(proj)} if isinstance(proj, (list, tuple)) else {'proj': proj})
+        raw = self.net.forward_raw(batch)
         prop_conf, v_ext, cls_conf, cls_idx, cls_offset = ops.decode_proposals(
             raw['proposal_conf'], raw['ext2'], raw['cls2'], raw['offset2'], cfg.exist_thre, heads.prop_width, heads.prop_half_buff)
         orient = ops.decode_orient(raw['orient'])
