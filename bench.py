@@ -279,7 +279,9 @@ def main():
                          'point clouds of 4,194,304 points per GPU resident in HBM, seeded random weights') if args.workload == 'lidar'
                    else ('on-GPU LAS->BEV raster (4,194,304 points/tile resident in HBM) + configs/Proj_polyline_fpn_vit_vertex_2.py, '
                          'batch=16 per GPU, seeded random weights'),
-                   'tiles_per_step_per_gpu': batch, 'lines_per_tile': n_lines, 'host_threads': args.host_threads, 'streams': nstream},
+                   'tiles_per_step_per_gpu': batch, 'lines_per_tile': n_lines, 'host_threads': args.host_threads, 'streams': nstream,
+                   'host_postproc_ms_per_tile': 1e3 * sum(p_.host_seconds for p_ in [pipe] + extra_pipes) /
+                   max(1, sum(p_.host_tiles for p_ in [pipe] + extra_pipes))},
         'roofline': {'bound': 'mfma', 'kernel': 'conv_mfma_kernel (all FPN/ViT/head implicit-GEMM launches)' if args.workload != 'lidar'
                      else 'conv_mfma_kernel (rulebook sparse convolutions + dense tail/ViT/head GEMMs)',
                      'achieved': achieved, 'peak': MFMA_F32_PEAK_TFLOPS, 'unit': 'TFLOP/s',
@@ -293,7 +295,10 @@ def main():
         alg = (16.0 * N_PTS + 3 * 1152 * 1152 * 4) * batch
         result['raster_roofline'] = {'bound': 'hbm', 'kernel': 'raster_partition_kernel + raster_band_kernel',
                                      'achieved': alg / (rms * 1e-3) / 1e9, 'peak': 8000.0, 'unit': 'GB/s',
-                                     'frac': alg / (rms * 1e-3) / 1e9 / 8000.0, 'traffic': None, 'ms_per_step': rms,
+                                     'frac': alg / (rms * 1e-3) / 1e9 / 8000.0,
+                                     # PMC FETCH_SIZE (x2, gfx950 correction) + WRITE_SIZE of both kernels, measured offline on this
+                                     # workload (profiles/r1_raster_pmc.txt): 120.7 MB per tile = 1.45 x the algorithmic bytes
+                                     'traffic': 120.7e6 * batch, 'ms_per_step': rms,
                                      'scope': roof_scope}
     if rank == 0:
         if world == 1 and not args.no_cpu_baseline:

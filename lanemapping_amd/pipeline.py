@@ -5,6 +5,7 @@ in C++ (ctypes releases the GIL), fanned out over a thread pool, one task per ti
 GPU work of the next batch.  Replaces the per-batch body of Runner.infer_lane_coordinate_endpoint_semantics
 (reference engine/runner.py:725-828) minus metrics / overlays.
 """
+import time
 from concurrent.futures import ThreadPoolExecutor
 
 import numpy as np
@@ -20,6 +21,8 @@ class TilePipeline:
         self.cfg = net.cfg
         self.pool = ThreadPoolExecutor(max_workers=host_threads)
         self._pending = None
+        self.host_seconds = 0.0      # accumulated wall time of the per-tile host tasks (all threads) and their count
+        self.host_tiles = 0
 
     def _gpu_stage(self, proj):
         heads, cfg = self.net.heads, self.cfg
@@ -41,11 +44,14 @@ class TilePipeline:
         return host, ev, keep, raw['endp_est'].shape[-1]
 
     def _tile_task(self, host, b, crop_w):
+        t0 = time.perf_counter()
         pts, _ = hostpost.cluster_endpoints(host['idx'][b].numpy(), crop_w=crop_w, clip=decode.CLIP,
                                             k0=self.net.heads.num_cls * 2 * 10, k_max=500)
         lanes, kept = hostpost.assemble_polylines(host['prop_conf'][b].numpy(), host['v_ext'][b].numpy(),
                                                   host['cls_offset'][b].numpy(), host['rows'][b].numpy(), pts,
                                                   self.cfg.proposal_obj_thre)
+        self.host_seconds += time.perf_counter() - t0      # (benign race between pool threads: statistics only)
+        self.host_tiles += 1
         return lanes, kept
 
     def _finish(self, pending):
