@@ -242,3 +242,41 @@ def write_img2pc_files(d, seed):
                            'las_rotation_trans_quan', sp(params['las_rotation_trans_quan']), 'bev_img_offset',
                            sp(params['bev_img_offset']), 'img_reso', sp(params['img_reso']), 'local_min_ele',
                            repr(float(params['local_min_ele'])), 'ele_reso', repr(float(params['ele_reso'])), '']))
+
+
+# ---------------------------------------------------------------------------------------------- f2 (cross-tile merge)
+def merge_case_files(d, seed=701, n_tiles=5):
+    """Writes tile_00.json .. (3-D polylines in the map frame, reference writer format) for a gently curving road seen by
+    overlapping tiles: 3 lanes, lane 1 is digitised backwards in tile 2, lane 2 is missing from tile 3 (retired, then
+    restarted), a 2-vertex stub appears in tile 1, a 4th lane starts in tile 2.  Returns the file list (unsorted)."""
+    import json
+    import os
+    from lanemapping_amd import synth
+    u = synth.uniform(seed, 4096, 91)
+    files = []
+    k = 0
+    for t in range(n_tiles):
+        x0, x1 = 20.0 * t, 20.0 * t + 31.0
+        recs = []
+        lanes = [0, 1, 2] + ([3] if t >= 2 else [])
+        for lane in lanes:
+            if lane == 2 and t == 3:
+                continue
+            xs = np.arange(x0 + 0.3 * lane, x1, 0.4)
+            noise = (u[k:k + len(xs)] - 0.5) * 0.06
+            k += len(xs)
+            ys = 3.5 * lane + 0.002 * (xs - 40.0) ** 2 + noise
+            zs = 12.0 + 0.01 * xs + (u[k:k + len(xs)] - 0.5) * 0.02
+            k += len(xs)
+            seq = np.stack([xs, ys, zs], axis=1)
+            if lane == 1 and t == 2:
+                seq = seq[::-1].copy()
+            recs.append({'seq_len': int(len(seq)), 'seq': seq.tolist(), 'init_vertex': seq[0].tolist(), 'end_vertex': seq[-1].tolist()})
+        if t == 1:
+            stub = np.array([[x0 + 5.0, -6.0, 12.0], [x0 + 5.4, -6.0, 12.0]])
+            recs.append({'seq_len': 2, 'seq': stub.tolist(), 'init_vertex': stub[0].tolist(), 'end_vertex': stub[1].tolist()})
+        path = os.path.join(d, 'tile_%02d.json' % t)
+        with open(path, 'w') as f:
+            json.dump(recs, f, indent=4)
+        files.append(path)
+    return files[::-1]

@@ -307,6 +307,23 @@ def g12(cfg, net):
     save('g12_img2pc.npz', seeds=np.array([501, 502, 503]), **keep)
 
 
+def g13(cfg, net):
+    """f2: merge_lines + downsample_seqs of the reference (baseline/utils/merge_lines.py) on a seeded 5-tile road."""
+    import tempfile
+    _refload.install()
+    sys.path.insert(0, os.path.join(_refload.REF_ROOT, 'baseline', 'utils'))
+    import merge_lines as ref
+    keep = {}
+    with tempfile.TemporaryDirectory() as d:
+        merged = _quiet(ref.merge_lines, cases.merge_case_files(d))
+    keep['n'] = np.array(len(merged))
+    for i, sq in enumerate(merged):
+        keep[f'merged_{i}'] = sq
+        keep[f'down_{i}'] = ref.downsample_seqs(sq)
+    save('g13_merge.npz', **keep)
+    print('merged lines:', [len(m) for m in merged])
+
+
 def main():
     which = sys.argv[1:] or ['g2', 'g3', 'g4', 'g5', 'g6', 'g7', 'g10']
     _stable_sorts(True)
