@@ -5,6 +5,8 @@
   Runner.infer_lane_coordinate_endpoint_semantics()  <- :690-867 minus metrics / cv2 overlays: every tile ->
                                                         <work_dirs>/<image_name[0:11]>.json via save_lane_seq_2d
   Runner.infer_lane_geometry_segmentation_segmentor()<- :945-1036 minus overlays (Segmentor config)
+  Runner.infer_las_to_map()                          <- the offline chain LAS -> BEV -> polylines -> LAS frame -> merged map
+                                                        (read_las, Las2BEV, Runner, coor_img2pc.py, merge_lines.py) in one call
 Tiles are PNG files (load_img contract, datasets/laserlane_proposals.py:85-98): decoded on the host with PIL,
 converted u8 -> f32/255 on the GPU (lm_tile_ingest_u8).  With torch.distributed initialised, tiles are sharded
 over the ranks (lanemapping_amd/shard.py) and rank 0 writes every file after one all-gather per batch.
@@ -91,6 +93,73 @@ class Runner:
                 io_utils.save_lane_seq_2d(io_utils.pack_lane_vertices(np.asarray(lanes, dtype=np.float64)),
                                           os.path.join(out_dir, name + '.json'), with_pervertex_semantics=True)
         return results
+
+    def infer_las_to_map(self, las_and_params, work_dirs=None, path_ckpt=None, batch_size=None, merge=True):
+        """LAS tiles -> map-level 3-D lane lines, every stage of the reference's offline chain on this stack:
+
+          LAS file + tile parameter file (utils/io_utils.py:125-150)
+            -> points in HBM (las_io.read_las_raw, shifted by las_read_offset)          [laspy read_las in the reference]
+            -> BEV tile on the GPU (lm_bev_raster_batch)                                [external Las2BEV tool]
+            -> polylines (TilePipeline) -> <name>.json                                  [Runner :690-867]
+            -> LAS-frame polylines (coor_img2pc, elevation from the tile) -> pc/<name>.json / .txt   [coor_img2pc.py]
+            -> merged + 0.6 m down-sampled lines -> merged.txt / merged_downsample.txt  [merge_lines.py __main__]
+
+        las_and_params: list of (las_path, param_path) in tile order.  Returns (per-tile dict name -> 3-D lines, merged list).
+        Single rank (the merge is sequential over the sorted tiles)."""
+        from . import coor_img2pc, las_io, merge_lines as ml
+        if path_ckpt:
+            self.load_ckpt(path_ckpt)
+        out_dir = work_dirs or self.cfg.get('work_dirs', './work_dirs')
+        pc_dir = os.path.join(out_dir, 'out_pc_seq_json_dir')
+        os.makedirs(pc_dir, exist_ok=True)
+        B = int(batch_size or self.cfg.get('batch_size', 8))
+        pipe = TilePipeline(self.net)
+        H, W = self.cfg.list_img_size_xy[1], self.cfg.list_img_size_xy[0]
+        queue, lines3d, pc_files = [], {}, []
+
+        def finish(futs):
+            for f in futs:
+                name, params, u8 = queue.pop(0)
+                lanes, _ = f.result()
+                packed = io_utils.pack_lane_vertices(np.asarray(lanes, dtype=np.float64))
+                io_utils.save_lane_seq_2d(packed, os.path.join(out_dir, name + '.json'), with_pervertex_semantics=True)
+                recs = io_utils.lane_records(packed)
+                if len(recs) < 2:                       # load_lane_seq yields nothing for < 2 lines: the reference skips the tile
+                    continue
+                lens = [r['seq_len'] for r in recs]
+                seqs = np.zeros((len(recs), max(lens), 2))
+                for i, r in enumerate(recs):
+                    seqs[i, :lens[i]] = np.asarray(r['seq'])[:, 0:2]
+                pc = coor_img2pc.transform_coordinate_from_img_2_pc(params, seqs, lens, u8)
+                lines = [{'seq': pc[i, :lens[i], :], 'seq_len': lens[i], 'init_vertex': pc[i, 0, :], 'end_vertex': pc[i, lens[i] - 1, :]}
+                         for i in range(len(recs))]
+                io_utils.save_seqs_json(lines, os.path.join(pc_dir, name + '.json'))
+                io_utils.save_seqs_txt(lines, os.path.join(pc_dir, name + '.txt'))
+                pc_files.append(os.path.join(pc_dir, name + '.json'))
+                lines3d[name] = [l['seq'] for l in lines]
+
+        for i in range(0, len(las_and_params), B):
+            chunk = las_and_params[i:i + B]
+            pts, offs, rpar = [], [0], []
+            for las_path, param_path in chunk:
+                params = io_utils.load_pc_2_img_transform_paras(param_path)
+                p, _ = las_io.read_las_raw(las_path, self.device, shift=params['las_read_offset'])
+                pts.append(p)
+                offs.append(offs[-1] + p.shape[0])
+                rpar.append(io_utils.raster_params_from_file(param_path))
+                queue.append([os.path.splitext(os.path.basename(las_path))[0][0:11], params, None])
+            tiles, u8 = ops.bev_raster_batch(torch.cat(pts), offs, rpar, H, W, want_u8=True)
+            u8_host = u8.cpu().numpy()
+            for j in range(len(chunk)):
+                queue[len(queue) - len(chunk) + j][2] = u8_host[j]
+            finish(pipe.submit(tiles))
+        finish(pipe.flush())
+        merged = []
+        if merge and pc_files:
+            merged = ml.merge_lines(pc_files)
+            io_utils.save_seqs_list(merged, os.path.join(pc_dir, 'merged.txt'))
+            io_utils.save_seqs_list([ml.downsample_seqs(m) for m in merged], os.path.join(pc_dir, 'merged_downsample.txt'))
+        return lines3d, merged
 
     def infer_lane_geometry_segmentation_segmentor(self, tiles=None, path_ckpt=None, batch_size=None, **_ignored):
         """Segmentor config: {image_name: (seg [1152,1152] u8-valued f32, endpoints [k,2])}."""

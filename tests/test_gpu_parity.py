@@ -2,6 +2,8 @@
 golden vectors generated from the reference.  Tolerances: fp32 features within 1e-4 of the tensor scale
 (different but fixed summation order), final coordinates / confidences within 1e-4 absolute, every integer /
 index output bit-exact."""
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -566,3 +568,48 @@ def test_las_file_to_bev_tile(dev, tmp_path):
     out, u8 = ops.bev_raster(dev_pts, par, want_u8=True)
     ref = raster_ref.raster(host_pts, raster_ref.params(local_min_ele=-0.5, ele_reso=0.02))
     assert np.array_equal(u8.cpu().numpy(), ref)
+
+
+def test_runner_las_to_map_chain(dev, net, tmp_path):
+    """Runner.infer_las_to_map: LAS + parameter files -> BEV (GPU) -> polylines -> LAS-frame lines -> merged map.  The 3-D
+    lines of every tile equal the oracle chain (numpy LAS reader -> C raster oracle -> reference-pinned img2pc restatement)
+    applied to the product's own 2-D polylines."""
+    import json
+    from lanemapping_amd import io_utils
+    from lanemapping_amd.runner import Runner
+    from oracle import las_ref, raster_ref, img2pc_ref
+    pairs = []
+    for t in range(3):
+        pts = synth.las_points(900 + t, 250000)
+        off = np.array([351200.0 + 40.0 * t, 3433000.0, 12.0])
+        quat_trans = [3.0 + 40.0 * t, -2.0, 0.5, 0.999, 0.01, -0.02, 0.03]
+        par = raster_ref.params(quat=quat_trans[3:], trans=quat_trans[:3], local_min_ele=-0.5, ele_reso=0.02)
+        # tile-frame cloud -> LAS frame: rotate by q, translate, add the read offset (what the param file describes)
+        world = np.stack([img2pc_ref.rotate(np.array(quat_trans[3:]), p[:3]) for p in pts[:, :3].astype(np.float64)]) + quat_trans[:3] + off
+        las = str(tmp_path / f'18101{t}_0209_a.las')
+        las_ref.write_las(las, world, pts[:, 3], point_format=1, offset=tuple(off))
+        sp = lambda v: ' '.join(repr(float(x)) for x in v)
+        prm = str(tmp_path / f'18101{t}_0209_a.txt')
+        with open(prm, 'w') as f:
+            f.write('\n'.join(['coor_las_path', las, 'las_read_offset', sp(off), 'las_rotation_trans_quan', sp(quat_trans),
+                               'bev_img_offset', '0.0 0.0', 'img_reso', '0.05 0.05', 'local_min_ele', '-0.5', 'ele_reso', '0.02', '']))
+        pairs.append((las, prm))
+    r = Runner.__new__(Runner)
+    r.cfg, r.device, r.net = net.cfg, dev, net
+    out = str(tmp_path / 'out')
+    lines3d, merged = r.infer_las_to_map(pairs, work_dirs=out, batch_size=2)
+    assert len(lines3d) == 3
+    for las, prm in pairs:
+        name = os.path.basename(las)[0:11]
+        params = io_utils.load_pc_2_img_transform_paras(prm)
+        host_pts = las_ref.read_las_ref(las, shift=params['las_read_offset'], normalise=False).astype(np.float32)
+        q = params['las_rotation_trans_quan']
+        tile = raster_ref.raster(host_pts, raster_ref.params(quat=q[3:], trans=q[:3], local_min_ele=-0.5, ele_reso=0.02))
+        assert int((tile.sum(axis=2) > 0).sum()) > 100000                       # the cloud really lands on the tile
+        seqs, lens, _, _ = io_utils.load_lane_seq(os.path.join(out, name + '.json'))
+        want = img2pc_ref.img_to_pc_ref(params, seqs, lens, tile)
+        got = json.load(open(os.path.join(out, 'out_pc_seq_json_dir', name + '.json')))
+        assert len(got) == len(lens)
+        for i, rec in enumerate(got):
+            assert np.array_equal(np.asarray(rec['seq']), want[i, :lens[i]])
+    assert os.path.exists(os.path.join(out, 'out_pc_seq_json_dir', 'merged.txt')) and len(merged) >= 1
