@@ -76,7 +76,7 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64) void conv_mfma_kernel(C
     const int n0 = (bid % n_tiles) * BN;
 
     // --- per-thread gather coordinates (tap independent part) ---
-    static_assert(RPP == 32, "swizzle below assumes 32 rows per load pass (256 threads)");
+    static_assert(RPP % 32 == 0, "one load pass covers whole 32-row swizzle periods");
     const int lrow = tid >> 3;                               // 0..31: row inside a load pass
     const int lc4 = (((tid & 7) ^ ((lrow >> 1) & 7))) * 4;   // swizzled source chunk (floats) for LDS slot tid & 7
     // Everything that does not depend on the tap is folded into one 32-bit element offset per row (the launcher checks
@@ -365,7 +365,11 @@ static int conv_dispatch(void* stream, const float* x, int ldx, const float* wp,
     // small-M GEMMs (ViT tokens): 128x128 tiles would leave most of the 256 CUs idle -> 64x64 tiles, 4x the workgroups
     const long big_blocks = ((p.M + 127) / 128) * ((Cout + 127) / 128);
     if (big_blocks < 512) return launch<64, 64, 32, 32>(p, s);
+#ifdef LM_CONV_8WAVES
+    return launch<128, 128, 64, 32>(p, s);
+#else
     return launch<128, 128, 64, 64>(p, s);
+#endif
 }
 
 LM_API int lm_conv2d_nhwc_mfma_f32(void* stream, const float* x, int ldx, const float* wp, int CoutP,
