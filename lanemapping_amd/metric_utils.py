@@ -1,0 +1,71 @@
+"""Evaluation metrics of the reference's test loop, SURVEY §8f row f3 (the part that needs no skeletonisation).
+
+  cal_coor_measures(arr_label, arr_pred, 'conf', offset_thre)   <- baseline/utils/metric_utils.py:47-64 + :112-166
+      vertex precision / recall / F1: a predicted vertex is a true positive when some GT lane has a vertex on the same row
+      strictly inside (col - r, col + r) clipped to [0, 1151]; symmetric for recall.
+  eval_metric_endp_detector(endp_pred, endp_gt, r_thre)         <- :483-513
+      endpoint precision / recall / F1 with nearest-neighbour distance < r_thre (the reference uses a cKDTree; the point
+      sets hold a few dozen pixels, so an exact all-pairs distance gives the same counts).
+Same return tuples as the reference.  `eval_metric_line_segmentor` (:415-481) needs skimage's Lee skeletonisation and is
+not restated.  Host-side numpy: these run once per tile on a few hundred numbers, far from the hot path.
+"""
+import numpy as np
+
+EPS = 1e-16      # baseline/utils/metric_utils.py:11
+_W = 1152
+
+
+def _hits(a, b, r):
+    """For every positive entry of a [La, H]: does any row-mate in b [Lb, H] fall strictly inside its clipped buffer?"""
+    lo = np.maximum(0, a - r)[:, None, :]
+    hi = np.minimum(_W - 1, a + r)[:, None, :]
+    inside = (b[None, :, :] > lo) & (b[None, :, :] < hi)
+    return inside.any(axis=1) & (a > 0)
+
+
+def calc_coor_measures_conf_metric2(arr_label, arr_pred, buff_radius=2):
+    arr_label, arr_pred = np.asarray(arr_label), np.asarray(arr_pred)
+    n_pred_pts = int((arr_pred > 0).sum())
+    n_gt_pts = int((arr_label > 0).sum())
+    tp = int(_hits(arr_pred, arr_label, buff_radius).sum())
+    dg = int(_hits(arr_label, arr_pred, buff_radius).sum())
+    return tp, n_pred_pts, dg, n_gt_pts
+
+
+def calc_coor_measures_cls(arr_label, arr_pred, offset_thre=8):
+    dist = np.abs(arr_label - arr_pred)
+    tp = int(((dist < offset_thre) & (arr_label > 0) & (arr_pred > 0)).sum())
+    fp = int((((dist >= offset_thre) | (arr_label < 0)) & (arr_pred > 0)).sum())
+    fn = int((((dist >= offset_thre) | (arr_pred < 0)) & (arr_label > 0)).sum())
+    return tp, fp, fn
+
+
+def cal_coor_measures(arr_label, arr_pred, mode='conf', offset_thre=8):
+    if mode != 'conf':
+        raise NotImplementedError("cal_coor_measures: only mode='conf' is well defined (the reference's other branch "
+                                  'unpacks three values into four names)')
+    TP, num_seg_pts, DG, num_gt_pts = calc_coor_measures_conf_metric2(arr_label, arr_pred, buff_radius=offset_thre)
+    acc = TP / (num_seg_pts + EPS)
+    recall = DG / (num_gt_pts + EPS)
+    f1 = 2.0 * acc * recall / (acc + recall + EPS)
+    return acc, recall, f1, TP, num_seg_pts, DG, num_gt_pts
+
+
+def _nearest(a, b):
+    d = np.sqrt(((a[:, None, :].astype(np.float64) - b[None, :, :]) ** 2).sum(-1))
+    return d.min(axis=1)
+
+
+def eval_metric_endp_detector(endp_pred, endp_gt, r_thre=10):
+    gt = np.argwhere(np.asarray(endp_gt) > 0.99)
+    pr = np.argwhere(np.asarray(endp_pred) > 0.99)
+    TPs = DGs = seg_pts = gt_pts = 0
+    if len(gt) > 0 and len(pr) > 0:
+        DGs = int((_nearest(gt, pr) < r_thre).sum())
+        gt_pts = len(gt)
+        TPs = int((_nearest(pr, gt) < r_thre).sum())
+        seg_pts = len(pr)
+    acc = TPs / seg_pts if seg_pts > 0 else 0.
+    rec = DGs / gt_pts if gt_pts > 0 else 0.
+    f = 2 * rec * acc / (acc + rec) if (acc + rec) > 0. else 0
+    return acc, rec, f, TPs, seg_pts, DGs, gt_pts

@@ -280,3 +280,31 @@ def merge_case_files(d, seed=701, n_tiles=5):
             json.dump(recs, f, indent=4)
         files.append(path)
     return files[::-1]
+
+
+# ---------------------------------------------------------------------------------------------- f3 (metrics)
+def metric_case(seed):
+    """(coor_label [12,144], cls_coors [72,144] with -1 = no vertex, endp_gt [1152,1152], endp_pred [1152,1152])."""
+    from lanemapping_amd import synth
+    u = synth.uniform(seed, 20000, 55)
+    label = np.full((12, 144), -1.0)
+    pred = np.full((72, 144), -1.0)
+    rows = np.arange(144)
+    for l in range(int(3 + 6 * u[0])):
+        lo, hi = int(40 * u[10 + l]), 144 - int(40 * u[30 + l])
+        col = 80 + 1000 * u[50 + l] + (rows - 72) * (u[70 + l] - 0.5)
+        label[l, lo:hi] = np.clip(col[lo:hi], 1, 1151)
+        if u[90 + l] > 0.2:                                                  # predicted, shifted by up to +-20 px, partly missing
+            shift = 40 * (u[110 + l] - 0.5)
+            plo, phi = lo + int(10 * u[130 + l]), hi - int(10 * u[150 + l])
+            pred[4 + 5 * l, plo:phi] = np.clip(col[plo:phi] + shift + 6 * (u[200 + l * 144:200 + l * 144 + 144][plo:phi] - 0.5), 1, 1151)
+    pred[70, 20:60] = 600.0 + 3 * (rows[20:60] % 3)                          # a false-positive lane
+    egt = np.zeros((1152, 1152), np.float32)
+    epr = np.zeros((1152, 1152), np.float32)
+    for k in range(int(2 + 10 * u[3])):
+        r, c = int(20 + 1100 * u[5000 + k]), int(20 + 1100 * u[5100 + k])
+        egt[r, c] = 1.0
+        if u[5200 + k] > 0.3:
+            epr[min(1151, r + int(24 * (u[5300 + k] - 0.5))), min(1151, c + int(24 * (u[5400 + k] - 0.5)))] = 1.0
+    epr[5, 5] = 1.0
+    return label, pred, egt, epr

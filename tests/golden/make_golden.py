@@ -324,6 +324,18 @@ def g13(cfg, net):
     print('merged lines:', [len(m) for m in merged])
 
 
+def g14(cfg, net):
+    """f3: cal_coor_measures ('conf') and eval_metric_endp_detector of the reference on seeded pred / GT pairs."""
+    _refload.install()
+    from baseline.utils import metric_utils as ref
+    keep = {}
+    for i, seed in enumerate((801, 802, 803, 804)):
+        label, pred, egt, epr = cases.metric_case(seed)
+        keep[f'coor_{i}'] = np.array(ref.cal_coor_measures(label, pred, 'conf', offset_thre=8 if i % 2 else 16), dtype=np.float64)
+        keep[f'endp_{i}'] = np.array(ref.eval_metric_endp_detector(epr, egt, r_thre=10), dtype=np.float64)
+    save('g14_metrics.npz', seeds=np.array([801, 802, 803, 804]), **keep)
+
+
 def main():
     which = sys.argv[1:] or ['g2', 'g3', 'g4', 'g5', 'g6', 'g7', 'g10']
     _stable_sorts(True)

@@ -400,3 +400,19 @@ def test_merge_lines_golden_g13(golden, tmp_path):
     assert len(rows) == sum(len(m) for m in merged) and rows[0].endswith(' 0')
     back, lens, _, _ = io_utils.load_lane_seq(str(tmp_path / 'merged.json'), dim_coor=3)
     assert len(lens) == len(merged) and np.array_equal(back[0, :lens[0]], ml.downsample_seqs(merged[0]))
+
+
+# ----------------------------------------------------------------------------------------------- f3: metrics
+def test_metrics_golden_g14(golden):
+    """Vertex and endpoint precision / recall / F1 vs the reference's metric_utils on seeded pred / GT pairs: identical."""
+    import cases
+    from lanemapping_amd import metric_utils as mu
+    g = golden('g14_metrics.npz')
+    for i, seed in enumerate(g['seeds']):
+        label, pred, egt, epr = cases.metric_case(int(seed))
+        assert np.array_equal(np.array(mu.cal_coor_measures(label, pred, 'conf', offset_thre=8 if i % 2 else 16)), g[f'coor_{i}'])
+        assert np.array_equal(np.array(mu.eval_metric_endp_detector(epr, egt, r_thre=10)), g[f'endp_{i}'])
+    z = np.zeros((1152, 1152), np.float32)
+    assert mu.eval_metric_endp_detector(z, z) == (0., 0., 0, 0, 0, 0, 0)
+    with pytest.raises(NotImplementedError):
+        mu.cal_coor_measures(np.zeros((2, 144)), np.zeros((2, 144)), 'cls')
