@@ -235,6 +235,13 @@ def test_end_to_end_golden_g10(dev, net, golden):
     ref_lines = {tuple(np.round(l[:, 0], 3)) for l in g['cls_offset_smooth'] if (l[:, 0] > 0).sum() >= 2}
     my_lines = {tuple(np.round(l[:, 0], 3)) for l in V if (l[:, 0] > 0).sum() >= 2}
     print(f'polylines identical to the reference run: {len(ref_lines & my_lines)} of {len(ref_lines)} (informational)')
+    # accuracy-level view of the same thing, with the reference's own vertex metric (metric_utils.cal_coor_measures):
+    # the reference's polylines as ground truth, 2 px buffer
+    from lanemapping_amd import metric_utils
+    acc, rec, f1, *_ = metric_utils.cal_coor_measures(np.where(g['cls_offset_smooth'][:, :, 0] > 0, g['cls_offset_smooth'][:, :, 0], -1.0),
+                                                      np.where(V[:, :, 0] > 0, V[:, :, 0], -1.0), 'conf', offset_thre=2)
+    print(f'vertex precision / recall / F1 vs the reference polylines at 2 px: {acc:.4f} / {rec:.4f} / {f1:.4f}')
+    assert f1 > 0.9
 
 
 def test_net_vs_oracle_batch2(dev, net, synth_sd):
