@@ -663,3 +663,20 @@ def test_raster_edge_cases(dev):
         assert np.array_equal(u8.cpu().numpy(), raster_ref.raster(pts, rp)), name
     _, u8 = ops.bev_raster(torch.from_numpy(cases_['outside']).to(dev), par, want_u8=True)
     assert int(u8.sum()) == 0
+
+
+def test_c_abi_from_plain_c(dev, tmp_path):
+    """A plain C program (tests/c_abi/smoke.c: no Python, no torch types) drives liblanemap_hip.so through
+    include/lanemap_hip.h: rasteriser bit-exact vs the C oracle, MFMA convolution vs a scalar loop, error reporting."""
+    import subprocess
+    from lanemapping_amd._lib import LIB_PATH
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = str(tmp_path / 'c_abi_smoke')
+    lib_dir = os.path.dirname(LIB_PATH)
+    cmd = ['gcc', os.path.join(root, 'tests', 'c_abi', 'smoke.c'), os.path.join(root, 'oracle', 'raster_ref.c'), '-O2', '-ffp-contract=off',
+           '-std=gnu11', '-I', os.path.join(root, 'include'), '-I', '/opt/rocm/include', '-D__HIP_PLATFORM_AMD__', '-L', lib_dir,
+           '-llanemap_hip', '-L/opt/rocm/lib', '-lamdhip64', f'-Wl,-rpath,{lib_dir}', '-Wl,-rpath,/opt/rocm/lib', '-lm', '-o', exe]
+    subprocess.run(cmd, check=True, capture_output=True, text=True)
+    r = subprocess.run([exe], capture_output=True, text=True, timeout=120)
+    print(r.stdout)
+    assert r.returncode == 0 and 'C-ABI smoke OK' in r.stdout, r.stdout + r.stderr
