@@ -37,6 +37,14 @@ int lm_conv2d_nhwc_mfma_f32(void* stream, const float* x, int ldx, const float* 
                             float* y, int ldy, int B, int H, int W, int Cin, int Cout, int KH, int KW,
                             int stride, int pad_h, int pad_w, int dil, int act);
 
+/* 3x3 / stride 1 / pad == dilation convolution through Winograd F(2x2,3x3) (same layers, 2.25x fewer multiplies; fp32 error
+ * at the level of a re-ordered direct sum).  wu: transformed weights [16][CoutP][Cin] = (G g G^T)[xi = 4i + j];
+ * workspace: the transformed input V, lm_conv3x3_winograd_workspace_bytes(B, H, W, Cin, dil) bytes.  act: none / ReLU. */
+long lm_conv3x3_winograd_workspace_bytes(int B, int H, int W, int Cin, int dil);
+int lm_conv3x3_winograd_f32(void* stream, const float* x, int ldx, const float* wu, int CoutP, const float* scale,
+                            const float* shift, const float* res, int ldr, float* y, int ldy, int B, int H, int W, int Cin,
+                            int Cout, int dil, int act, void* workspace, long workspace_bytes);
+
 /* Same convolution + first pass of GroupNorm(C,C) (postprojector.py:512-515,608-647): also writes per (image, 64-row
  * chunk, channel) sum / sum of squares of the outputs, gn_partial [B][Ho*Wo/64][Cout][2] doubles -> lm_gn_finalize. */
 int lm_conv2d_nhwc_mfma_f32_gnstats(void* stream, const float* x, int ldx, const float* wp, int CoutP, const float* shift,

@@ -6,7 +6,7 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, 'csrc')
 LIB = os.path.join(HERE, 'liblanemap_hip.so')
-SOURCES = ['errors.cpp', 'conv_mfma.hip', 'conv_direct.hip', 'norm_resize.hip', 'vit.hip', 'head.hip',
+SOURCES = ['errors.cpp', 'conv_mfma.hip', 'conv_wino.hip', 'conv_direct.hip', 'norm_resize.hip', 'vit.hip', 'head.hip',
            'decode.hip', 'raster.hip', 'rowref.hip', 'lidar.hip', 'postproc.cpp', 'backproject.cpp']
 
 

@@ -1,0 +1,355 @@
+// Winograd F(2x2, 3x3) convolution on the matrix cores, fp32: 3x3 / stride 1 / pad == dilation layers of the FPN
+// (baseline/models/pcencoder/postprojector.py:322-338 BasicBlock convs, :597-599 smooth*, :615-647 conv2/conv3/
+// semantic_branch*) need 16 instead of 36 multiplies per 2x2 output block and (cin, cout) pair.
+//
+//   Y = A^T [ sum_cin (G g G^T) .* (B^T d B) ] A        (Lavin & Gray; transform matrices below)
+//
+// fp32 error of F(2,3) stays at the level of a re-ordered direct sum (transforms use only 0, +-1, 1/2): measured through the
+// whole network 1e-6 .. 3e-6 of the tensor scale, the same as the direct kernel against the reference.
+//
+// Two kernels:
+//   wino_input_kernel   V[xi][tile][c] = (B^T d B)[xi] for every 4x4 input patch (stride 2, zero padded); memory bound,
+//                       writes 4x the input.  A dilated layer is d x d interleaved plain convolutions: the tile index runs
+//                       over (image, phase, ty, tx) and the patch samples the input with pitch d.
+//   wino_gemm_kernel    one workgroup = 128 tiles (= 512 output pixels) x BN output channels.  For xi = 0..15 it runs the K
+//                       loop over the input channels (same global->LDS double-buffered slab pipeline and 32x32x2 MFMA
+//                       fragment scheme as conv_mfma.hip) into a temporary accumulator and folds it with the +-1
+//                       coefficients of A^T . A into FOUR output accumulators (the 2x2 pixels of every tile), so the
+//                       transformed products M[xi] never go to memory.  Epilogue = BN scale/shift, residual, ReLU, NHWC.
+// U = G g G^T is computed at weight-packing time ([16][CoutP][Cin], lanemapping_amd/ops.py pack_wino).
+#include "common.h"
+
+#include <cstdlib>
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+namespace {
+
+constexpr int BK = 32;
+constexpr int LDS_LD = BK;
+
+__device__ __attribute__((aligned(16))) float g_wino_zero[4] = {0.f, 0.f, 0.f, 0.f};
+
+struct WinoGeom {
+    int B, H, W, dil, Ty, Tx;   // Ty x Tx tiles per (image, phase); dil*dil phases
+    long T;                     // tiles in total
+};
+
+__device__ __forceinline__ void tile_decode(const WinoGeom& g, long m, int& b, int& pa, int& pb, int& ty, int& tx) {
+    tx = (int)(m % g.Tx);
+    long t = m / g.Tx;
+    ty = (int)(t % g.Ty);
+    t /= g.Ty;
+    const int ph = (int)(t % (g.dil * g.dil));
+    b = (int)(t / (g.dil * g.dil));
+    pa = ph / g.dil;
+    pb = ph % g.dil;
+}
+
+// grid: ceil(T * C/4 / 256)
+__global__ __launch_bounds__(256) void wino_input_kernel(const float* __restrict__ x, int ldx, WinoGeom g, int C, float* __restrict__ V) {
+    const int c4n = C / 4;
+    const long e = (long)blockIdx.x * 256 + threadIdx.x;
+    if (e >= g.T * c4n) return;
+    const int c4 = (int)(e % c4n) * 4;
+    const long m = e / c4n;
+    int b, pa, pb, ty, tx;
+    tile_decode(g, m, b, pa, pb, ty, tx);
+    f32x4 d[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int y = (2 * ty + i - 1) * g.dil + pa;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int xx = (2 * tx + j - 1) * g.dil + pb;
+            d[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+            if ((unsigned)y < (unsigned)g.H && (unsigned)xx < (unsigned)g.W && (2 * ty + i - 1) >= 0 && (2 * tx + j - 1) >= 0)
+                d[i][j] = *reinterpret_cast<const f32x4*>(x + (((long)b * g.H + y) * g.W + xx) * ldx + c4);
+        }
+    }
+    // B^T d B with B^T = [1 0 -1 0; 0 1 1 0; 0 -1 1 0; 0 1 0 -1]: rows first, then columns
+    f32x4 r[4][4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        r[0][j] = d[0][j] - d[2][j];
+        r[1][j] = d[1][j] + d[2][j];
+        r[2][j] = d[2][j] - d[1][j];
+        r[3][j] = d[1][j] - d[3][j];
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const f32x4 v0 = r[i][0] - r[i][2], v1 = r[i][1] + r[i][2], v2 = r[i][2] - r[i][1], v3 = r[i][1] - r[i][3];
+        float* o = V + ((long)(4 * i) * g.T + m) * C + c4;
+        *reinterpret_cast<f32x4*>(o) = v0;
+        *reinterpret_cast<f32x4*>(o + g.T * C) = v1;
+        *reinterpret_cast<f32x4*>(o + 2 * g.T * C) = v2;
+        *reinterpret_cast<f32x4*>(o + 3 * g.T * C) = v3;
+    }
+}
+
+struct WinoParams {
+    const float* V; const float* U; const float* scale; const float* shift; const float* res; float* y; const float* zero;
+    int ldr, ldy, C, Cout, CoutP, act;
+    WinoGeom g;
+};
+
+template <int BM, int BN, int WM, int WN>
+__global__ __launch_bounds__((BM / WM) * (BN / WN) * 64) void wino_gemm_kernel(WinoParams p) {
+    constexpr int TM = WM / 32, TN = WN / 32;
+    constexpr int WAVES_N = BN / WN;
+    constexpr int NT = (BM / WM) * (BN / WN) * 64;
+    constexpr int RPP = NT / 8;
+    constexpr int A_LOADS = BM / RPP, B_LOADS = BN / RPP;
+    static_assert(RPP % 32 == 0 && BM % RPP == 0 && BN % RPP == 0, "tile rows must be a multiple of the load pass");
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* As = smem;
+    float* Bs = smem + 2 * BM * LDS_LD;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm0 = (wave / WAVES_N) * WM, wn0 = (wave % WAVES_N) * WN;
+    const int n_tiles = (p.Cout + BN - 1) / BN;
+    unsigned bid = blockIdx.x;
+    {
+        const unsigned nb = gridDim.x, per = nb / 8, full = per * 8;   // XCD-aware order (see conv_mfma.hip)
+        if (bid < full) bid = (bid % 8) * per + bid / 8;
+    }
+    const long m0 = (long)(bid / n_tiles) * BM;
+    const int n0 = (bid % n_tiles) * BN;
+    const int lrow = tid >> 3;
+    const int lc4 = ((tid & 7) ^ ((lrow >> 1) & 7)) * 4;
+    const long T = p.g.T;
+    long a_off[A_LOADS];
+    int b_off[B_LOADS];
+#pragma unroll
+    for (int i = 0; i < A_LOADS; ++i) {
+        const long m = m0 + lrow + i * RPP;
+        a_off[i] = m < T ? m * p.C + lc4 : -1;
+    }
+#pragma unroll
+    for (int i = 0; i < B_LOADS; ++i) b_off[i] = (n0 + lrow + i * RPP) * p.C + lc4;
+    const int cslabs = p.C / BK;
+    const long xi_stride_a = T * p.C;
+    const int xi_stride_b = p.CoutP * p.C;
+    int cur_cs = 0, cur_xi = 0;
+    typedef __attribute__((address_space(1))) const void gptr_t;
+    typedef __attribute__((address_space(3))) void lptr_t;
+    auto gload = [&](int buf) {
+        const long adelta = cur_xi * xi_stride_a + cur_cs * BK;
+        const int bdelta = cur_xi * xi_stride_b + cur_cs * BK;
+#pragma unroll
+        for (int i = 0; i < A_LOADS; ++i) {
+            const float* src = a_off[i] >= 0 ? p.V + (a_off[i] + adelta) : p.zero;
+            __builtin_amdgcn_global_load_lds((gptr_t*)src, (lptr_t*)(As + (buf * BM + i * RPP + wave * 8) * LDS_LD), 16, 0, 0);
+        }
+#pragma unroll
+        for (int i = 0; i < B_LOADS; ++i) {
+            const float* src = p.U + (b_off[i] + bdelta);
+            __builtin_amdgcn_global_load_lds((gptr_t*)src, (lptr_t*)(Bs + (buf * BN + i * RPP + wave * 8) * LDS_LD), 16, 0, 0);
+        }
+        if (++cur_cs == cslabs) {
+            cur_cs = 0;
+            ++cur_xi;
+        }
+    };
+
+    f32x16 out[2][2][TM][TN];      // [a][b]: output pixel (2 ty + a, 2 tx + b) of every tile
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) out[a][b][i][j][r] = 0.f;
+
+    gload(0);
+    __syncthreads();
+    const int frow = lane & 31, fswz = (frow >> 1) & 7, fhalf = lane >> 5;
+    int kt = 0;
+    const int KT = 16 * cslabs;
+    for (int xi = 0; xi < 16; ++xi) {
+        f32x16 acc[TM][TN];
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+        for (int cs = 0; cs < cslabs; ++cs, ++kt) {
+            const int buf = kt & 1;
+            if (kt + 1 < KT) gload(buf ^ 1);
+            const float* Ab = As + (buf * BM + wm0 + frow) * LDS_LD;
+            const float* Bb = Bs + (buf * BN + wn0 + frow) * LDS_LD;
+#pragma unroll
+            for (int kk = 0; kk < BK; kk += 8) {
+                const int fo = (((kk >> 2) + fhalf) ^ fswz) * 4;
+                f32x4 af[TM], bf[TN];
+#pragma unroll
+                for (int i = 0; i < TM; ++i) af[i] = *reinterpret_cast<const f32x4*>(Ab + i * 32 * LDS_LD + fo);
+#pragma unroll
+                for (int j = 0; j < TN; ++j) bf[j] = *reinterpret_cast<const f32x4*>(Bb + j * 32 * LDS_LD + fo);
+#pragma unroll
+                for (int t = 0; t < 4; ++t)
+#pragma unroll
+                    for (int i = 0; i < TM; ++i)
+#pragma unroll
+                        for (int j = 0; j < TN; ++j)
+                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i][t], bf[j][t], acc[i][j], 0, 0, 0);
+            }
+            __syncthreads();
+        }
+        // fold M[xi] into the 2x2 outputs: Y[a][b] += AT[a][i] * AT[b][j] * M[i][j],  A^T = [1 1 1 0; 0 1 -1 -1].
+        // The coefficients are 0 / +1 / -1, so the multiply-adds below are exact additions (or no-ops).
+        const int wi = xi >> 2, wj = xi & 3;
+        const float ca[2] = {wi < 3 ? 1.f : 0.f, wi == 0 ? 0.f : (wi == 1 ? 1.f : -1.f)};
+        const float cb[2] = {wj < 3 ? 1.f : 0.f, wj == 0 ? 0.f : (wj == 1 ? 1.f : -1.f)};
+#pragma unroll
+        for (int a = 0; a < 2; ++a)
+#pragma unroll
+            for (int b = 0; b < 2; ++b) {
+                const float c = ca[a] * cb[b];
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int j = 0; j < TN; ++j)
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) out[a][b][i][j][r] = fmaf(acc[i][j][r], c, out[a][b][i][j][r]);
+            }
+    }
+
+    // --- epilogue: per output position (a, b) transpose the wave tile through LDS (16-byte coalesced channel vectors)
+    constexpr int ELD = WN + 4;
+    float* stage = smem + wave * (WM * ELD);
+    const int half = lane >> 5;
+    constexpr int LPR = WN / 4, RPI = 64 / LPR;
+    const int c4 = (lane % LPR) * 4;
+    const int n = n0 + wn0 + c4;
+    f32x4 sc = {1.f, 1.f, 1.f, 1.f}, sh = {0.f, 0.f, 0.f, 0.f};
+    if (n < p.Cout) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+            if (n + e < p.Cout) {
+                if (p.scale) sc[e] = p.scale[n + e];
+                if (p.shift) sh[e] = p.shift[n + e];
+            }
+    }
+    const bool vec = (n + 3 < p.Cout) && ((p.ldy & 3) == 0) && (!p.res || (p.ldr & 3) == 0);
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b) {
+            __syncthreads();
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r)
+                        stage[(i * 32 + (r & 3) + 8 * (r >> 2) + 4 * half) * ELD + j * 32 + frow] = out[a][b][i][j][r];
+            __syncthreads();
+            if (n >= p.Cout) continue;
+#pragma unroll
+            for (int pass = 0; pass < WM / RPI; ++pass) {
+                const int row = pass * RPI + lane / LPR;
+                const long m = m0 + wm0 + row;
+                if (m >= T) continue;
+                int bi, pa, pb, ty, tx;
+                tile_decode(p.g, m, bi, pa, pb, ty, tx);
+                const int oy = (2 * ty + a) * p.g.dil + pa, ox = (2 * tx + b) * p.g.dil + pb;
+                if (oy >= p.g.H || ox >= p.g.W) continue;
+                const long pix = ((long)bi * p.g.H + oy) * p.g.W + ox;
+                f32x4 v = *reinterpret_cast<const f32x4*>(stage + row * ELD + c4);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] = p.scale ? v[e] * sc[e] + sh[e] : v[e] + sh[e];
+                if (vec) {
+                    if (p.res) {
+                        const f32x4 rr = *reinterpret_cast<const f32x4*>(p.res + pix * p.ldr + n);
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) v[e] += rr[e];
+                    }
+                    if (p.act == LM_ACT_RELU) {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
+                    }
+                    *reinterpret_cast<f32x4*>(p.y + pix * p.ldy + n) = v;
+                } else {
+                    for (int e = 0; e < 4 && n + e < p.Cout; ++e) {
+                        float u = v[e];
+                        if (p.res) u += p.res[pix * p.ldr + n + e];
+                        if (p.act == LM_ACT_RELU) u = fmaxf(u, 0.f);
+                        p.y[pix * p.ldy + n + e] = u;
+                    }
+                }
+            }
+        }
+}
+
+template <int BM, int BN, int WM, int WN>
+int launch_wino(const WinoParams& p, hipStream_t stream) {
+    const size_t kloop = (size_t)2 * (BM + BN) * LDS_LD, stage = (size_t)(BM / WM) * (BN / WN) * WM * (WN + 4);
+    const size_t lds = (kloop > stage ? kloop : stage) * sizeof(float);
+    static bool attr_set = false;
+    if (!attr_set) {
+        LM_HIP(hipFuncSetAttribute((const void*)wino_gemm_kernel<BM, BN, WM, WN>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        attr_set = true;
+    }
+    const long blocks = ((p.g.T + BM - 1) / BM) * ((p.Cout + BN - 1) / BN);
+    LM_REQUIRE(blocks > 0 && blocks < (1L << 31), "conv_wino: bad grid %ld", blocks);
+    hipLaunchKernelGGL((wino_gemm_kernel<BM, BN, WM, WN>), dim3((unsigned)blocks), dim3((BM / WM) * (BN / WN) * 64), lds, stream, p);
+    LM_LAUNCH_CHECK();
+    return LM_OK;
+}
+
+WinoGeom geom(int B, int H, int W, int dil) {
+    WinoGeom g;
+    g.B = B; g.H = H; g.W = W; g.dil = dil;
+    g.Ty = ((H + dil - 1) / dil + 1) / 2;
+    g.Tx = ((W + dil - 1) / dil + 1) / 2;
+    g.T = (long)B * dil * dil * g.Ty * g.Tx;
+    return g;
+}
+
+}  // namespace
+
+LM_API long lm_conv3x3_winograd_workspace_bytes(int B, int H, int W, int Cin, int dil) {
+    if (dil < 1) return 0;
+    return 16 * geom(B, H, W, dil).T * (long)Cin * (long)sizeof(float);
+}
+
+// y = act((conv3x3(x, w; stride 1, pad = dil, dilation dil)) * scale + shift + res), NHWC, via Winograd F(2x2,3x3).
+// wu: transformed weights [16][CoutP][Cin] (xi = 4 i + j of G g G^T); workspace: V, lm_conv3x3_winograd_workspace_bytes.
+LM_API int lm_conv3x3_winograd_f32(void* stream, const float* x, int ldx, const float* wu, int CoutP, const float* scale,
+                                   const float* shift, const float* res, int ldr, float* y, int ldy, int B, int H, int W, int Cin,
+                                   int Cout, int dil, int act, void* workspace, long workspace_bytes) {
+    LM_REQUIRE(x && wu && y && workspace, "conv_wino: null pointer");
+    LM_REQUIRE(Cin > 0 && Cin % BK == 0 && dil >= 1 && B > 0 && H > 0 && W > 0, "conv_wino: bad shape (Cin=%d must be a multiple of %d)", Cin, BK);
+    LM_REQUIRE(CoutP >= Cout && CoutP % 128 == 0, "conv_wino: CoutP=%d must be Cout=%d rounded up to 128", CoutP, Cout);
+    LM_REQUIRE(ldx >= Cin && ldx % 4 == 0 && ldy >= Cout, "conv_wino: bad leading dims ldx=%d ldy=%d", ldx, ldy);
+    LM_REQUIRE(act == LM_ACT_NONE || act == LM_ACT_RELU, "conv_wino: activation %d not supported", act);
+    LM_REQUIRE(lm_conv3x3_winograd_workspace_bytes(B, H, W, Cin, dil) <= workspace_bytes, "conv_wino: workspace too small");
+    LM_REQUIRE((long)16 * CoutP * Cin < (1L << 31), "conv_wino: weights too large");
+    hipStream_t s = (hipStream_t)stream;
+    WinoParams p;
+    p.g = geom(B, H, W, dil);
+    p.V = (const float*)workspace; p.U = wu; p.scale = scale; p.shift = shift; p.res = res; p.y = y;
+    p.ldr = ldr; p.ldy = ldy; p.C = Cin; p.Cout = Cout; p.CoutP = CoutP; p.act = act;
+    static const float* zero = nullptr;
+    if (!zero) {
+        void* sym = nullptr;
+        LM_HIP(hipGetSymbolAddress(&sym, HIP_SYMBOL(g_wino_zero)));
+        zero = (const float*)sym;
+    }
+    p.zero = zero;
+    const long in_threads = p.g.T * (Cin / 4);
+    hipLaunchKernelGGL(wino_input_kernel, dim3((unsigned)((in_threads + 255) / 256)), dim3(256), 0, s, x, ldx, p.g, Cin, (float*)workspace);
+    LM_LAUNCH_CHECK();
+    static const int force = [] { const char* e = getenv("LM_WINO_TILE"); return e ? atoi(e) : 0; }();   // experiments only
+    if (force == 1) return launch_wino<128, 128, 64, 64>(p, s);
+    if (force == 2) return launch_wino<128, 64, 32, 64>(p, s);
+    if (force == 3) return launch_wino<64, 128, 32, 64>(p, s);
+    // 128 x 64 tiles: 4 output + 1 temporary accumulator sets = 246 registers -> two workgroups per CU.  The 128 x 128 tile
+    // (471 registers, one workgroup per CU) measured 1.32x over the direct kernel on 256->256@288^2, this one 1.52x.
+    return launch_wino<128, 64, 32, 64>(p, s);
+}

@@ -67,6 +67,18 @@ def pack_mfma(w):
     return p.contiguous()
 
 
+def pack_wino(w):
+    """[Cout,Cin,3,3] -> Winograd F(2x2,3x3) weights U = G g G^T as [16, CoutP, Cin] (xi = 4 i + j), fp32."""
+    co, ci, kh, kw = w.shape
+    assert kh == 3 and kw == 3
+    G = torch.tensor([[1., 0., 0.], [.5, .5, .5], [.5, -.5, .5], [0., 0., 1.]], device=w.device, dtype=torch.float32)
+    U = torch.einsum('ij,ocjk,lk->iloc', G, w.float(), G).reshape(16, co, ci)
+    cop = (co + 127) // 128 * 128
+    p = torch.zeros((16, cop, ci), device=w.device, dtype=torch.float32)
+    p[:, :co, :] = U
+    return p.contiguous()
+
+
 def pack_small(w):
     """[Cout<=16,Cin,KH,KW] -> [KH*KW, Cin, 16]."""
     co, ci, kh, kw = w.shape
@@ -107,6 +119,35 @@ def conv_mfma(x, wp, cout, kh=1, kw=1, stride=1, pad=0, dil=1, scale=None, shift
                                             stride, ph, pw, dil, act))
     if _conv_hook is not None:
         _conv_hook(f'conv {cin}->{cout} k{kh}x{kw} s{stride} d{dil} @{H}x{W} B{B}', 2.0 * B * Ho * Wo * cout * cin * kh * kw, launch)
+    else:
+        launch()
+    return out
+
+
+_wino_ws = {}
+
+
+def conv_wino(x, wu, cout, dil=1, scale=None, shift=None, res=None, act=ACT_NONE, out=None):
+    """3x3 / stride 1 / pad = dil convolution via Winograd F(2x2,3x3) (lm_conv3x3_winograd_f32)."""
+    x, ldx = as_nhwc(x)
+    B, cin, H, W = x.shape
+    if out is None:
+        out = new_act(B, cout, H, W, x.device)
+    out_, ldy = as_nhwc(out)
+    assert out_.data_ptr() == out.data_ptr(), 'conv_wino: `out` must already be NHWC-stored'
+    ldr = 0
+    if res is not None:
+        res, ldr = as_nhwc(res)
+    need = lib().lm_conv3x3_winograd_workspace_bytes(B, H, W, cin, dil)
+    key = (x.device, torch.cuda.current_stream().cuda_stream)
+    ws = _wino_ws.get(key)
+    if ws is None or ws.numel() < need:
+        ws = _wino_ws[key] = torch.empty(need, device=x.device, dtype=torch.uint8)
+    def launch():
+        check(lib().lm_conv3x3_winograd_f32(_stream(), _ptr(x), ldx, _ptr(wu), wu.shape[1], _ptr(scale), _ptr(shift), _ptr(res), ldr,
+                                            _ptr(out), ldy, B, H, W, cin, cout, dil, act, _ptr(ws), ws.numel()))
+    if _conv_hook is not None:
+        _conv_hook(f'wino {cin}->{cout} k3x3 d{dil} @{H}x{W} B{B}', 2.0 * B * H * W * cout * cin * 9, launch)
     else:
         launch()
     return out

@@ -12,6 +12,8 @@ reference checkpoint loads with ``strict=True``.  The arithmetic runs in liblane
   1x1 heads (128->8, 8->3, 128->1)                -> lm_conv2d_nhwc_small
   final 4x bilinear to the tile resolution        -> lm_upsample_bilinear_to_chw
 """
+import os
+
 import torch
 import torch.nn as nn
 
@@ -20,6 +22,10 @@ from .registry import PCENCODER
 from .packing import PackedModule
 
 _LAYERS = {'resnet18': [2, 2, 2, 2], 'resnet34': [3, 4, 6, 3]}
+# 3x3 / stride-1 convolutions with >= WINO_MIN_CIN input channels go through Winograd F(2x2,3x3) (csrc/conv_wino.hip:
+# 1.25-1.66x the direct MFMA kernel on those shapes; the 64-channel layers stay direct).  LANEMAP_WINOGRAD=0 disables it.
+USE_WINOGRAD = os.environ.get('LANEMAP_WINOGRAD', '1') != '0'
+WINO_MIN_CIN = 128
 
 
 class _ResBlock(nn.Module):
@@ -118,6 +124,11 @@ class FPNEncoder(PackedModule):
                 P[k + '.s1'], P[k + '.b1'] = ops.fold_bn(blk.bn1)
                 P[k + '.w2'] = ops.pack_mfma(blk.conv2.weight)
                 P[k + '.s2'], P[k + '.b2'] = ops.fold_bn(blk.bn2)
+                if USE_WINOGRAD:
+                    if blk.stride == 1 and blk.conv1.in_channels >= WINO_MIN_CIN:
+                        P[k + '.w1u'] = ops.pack_wino(blk.conv1.weight)
+                    if blk.conv2.in_channels >= WINO_MIN_CIN:
+                        P[k + '.w2u'] = ops.pack_wino(blk.conv2.weight)
                 if blk.downsample is not None:
                     P[k + '.wd'] = ops.pack_mfma(blk.downsample[0].weight)
                     P[k + '.sd'], P[k + '.bd'] = ops.fold_bn(blk.downsample[1])
@@ -126,6 +137,8 @@ class FPNEncoder(PackedModule):
             m = getattr(self, name)
             P[name + '.w'] = ops.pack_mfma(m.weight)
             P[name + '.b'] = m.bias.float().contiguous()
+            if USE_WINOGRAD and m.kernel_size == (3, 3) and m.in_channels >= WINO_MIN_CIN:
+                P[name + '.wu'] = ops.pack_wino(m.weight)
         if self.out is not None:
             P['out.w'] = ops.pack_mfma(self.out.weight)
         for name in ('feature_layer', 'output_layer_binary_seg', 'output_layer_endp'):
@@ -138,17 +151,22 @@ class FPNEncoder(PackedModule):
         return P
 
     # -------------------------------------------------------------------------------- forward
+    @staticmethod
+    def _c3(x, P, wkey, cout, stride, dil, **epi):
+        """3x3 convolution, pad = dilation: Winograd when its transformed weights were packed, else the direct kernel."""
+        if (wkey + 'u') in P and stride == 1:
+            return ops.conv_wino(x, P[wkey + 'u'], cout, dil, **epi)
+        return ops.conv_mfma(x, P[wkey], cout, 3, 3, stride, dil, dil, **epi)
+
     def _block(self, x, P, key, blk):
         cout = blk.conv1.out_channels
-        y = ops.conv_mfma(x, P[key + '.w1'], cout, 3, 3, blk.stride, blk.dilation, blk.dilation,
-                          scale=P[key + '.s1'], shift=P[key + '.b1'], act=ops.ACT_RELU)
+        y = self._c3(x, P, key + '.w1', cout, blk.stride, blk.dilation, scale=P[key + '.s1'], shift=P[key + '.b1'], act=ops.ACT_RELU)
         if blk.downsample is not None:
             x = ops.conv_mfma(x, P[key + '.wd'], cout, 1, 1, blk.stride, 0, 1, scale=P[key + '.sd'], shift=P[key + '.bd'])
-        return ops.conv_mfma(y, P[key + '.w2'], cout, 3, 3, 1, blk.dilation, blk.dilation,
-                             scale=P[key + '.s2'], shift=P[key + '.b2'], res=x, act=ops.ACT_RELU)
+        return self._c3(y, P, key + '.w2', cout, 1, blk.dilation, scale=P[key + '.s2'], shift=P[key + '.b2'], res=x, act=ops.ACT_RELU)
 
     def _conv3(self, x, P, name, cout):
-        return ops.conv_mfma(x, P[name + '.w'], cout, 3, 3, 1, 1, 1, shift=P[name + '.b'])
+        return self._c3(x, P, name + '.w', cout, 1, 1, shift=P[name + '.b'])
 
     def _semantic(self, P, p2, p3, p4, conv_a, gn_a, conv_b, gn_b):
         """One of the two branches (reference :615-621 / :641-647): returns s2 + s3 + s4 at p2's size."""
@@ -158,7 +176,10 @@ class FPNEncoder(PackedModule):
         def conv_gn_up(src, conv, cout, gn, out=None, acc=False):
             # conv3x3 + bias with the GroupNorm statistics coming out of the conv epilogue, then GN + ReLU + bilinear (+=)
             eps = getattr(self, gn).eps
-            if (src.shape[2] * src.shape[3]) % 128 == 0:      # whole 128-row tiles per image: statistics from the epilogue
+            if (conv + '.wu') in P:                             # Winograd conv, statistics in their own pass
+                t = self._conv3(src, P, conv, cout)
+                st = ops.gn_stats(t, eps)
+            elif (src.shape[2] * src.shape[3]) % 128 == 0:    # whole 128-row tiles per image: statistics from the epilogue
                 t, st = ops.conv_mfma_gnstats(src, P[conv + '.w'], cout, 3, 3, 1, 1, 1, P[conv + '.b'], eps)
             else:                                              # ragged image size: separate statistics kernel
                 t = self._conv3(src, P, conv, cout)
