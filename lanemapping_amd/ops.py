@@ -88,7 +88,7 @@ def pack_small(w):
 
 
 # ------------------------------------------------------------------------------- convolutions / GEMM
-_conv_hook = None   # optional profiler hook: called as hook(kind, flops, launch_fn)
+_conv_hook = None   # optional profiler hook: called as hook(kind, algorithmic_flops, launch_fn[, executed_flops])
 
 
 def set_conv_hook(fn):
@@ -147,7 +147,9 @@ def conv_wino(x, wu, cout, dil=1, scale=None, shift=None, res=None, act=ACT_NONE
         check(lib().lm_conv3x3_winograd_f32(_stream(), _ptr(x), ldx, _ptr(wu), wu.shape[1], _ptr(scale), _ptr(shift), _ptr(res), ldr,
                                             _ptr(out), ldy, B, H, W, cin, cout, dil, act, _ptr(ws), ws.numel()))
     if _conv_hook is not None:
-        _conv_hook(f'wino {cin}->{cout} k3x3 d{dil} @{H}x{W} B{B}', 2.0 * B * H * W * cout * cin * 9, launch)
+        tiles = need // (64 * cin)          # 16 transform points x tiles x Cin floats
+        _conv_hook(f'wino {cin}->{cout} k3x3 d{dil} @{H}x{W} B{B}', 2.0 * B * H * W * cout * cin * 9, launch,
+                   2.0 * 16 * tiles * cin * cout)
     else:
         launch()
     return out
