@@ -48,8 +48,7 @@ def cpu_baseline(budget_s=25.0, max_threads=64):
     from oracle import net_ref, decode_ref, postproc_ref
     cores = min(usable_cores(), max_threads)
     torch.set_num_threads(cores)
-    net = build_net_from_config('Proj_polyline_lidarconv_vit_vertex_2' if args.workload == 'lidar' else 'Proj_polyline_fpn_vit_vertex_2',
-                                device='cpu')
+    net = build_net_from_config('Proj_polyline_fpn_vit_vertex_2', device='cpu')     # the CPU baseline is always the config-2 chain
     synth.fill_module_(net, 2021)
     sd = {k: v for k, v in net.state_dict().items()}
 

@@ -416,3 +416,39 @@ def test_metrics_golden_g14(golden):
     assert mu.eval_metric_endp_detector(z, z) == (0., 0., 0, 0, 0, 0, 0)
     with pytest.raises(NotImplementedError):
         mu.cal_coor_measures(np.zeros((2, 144)), np.zeros((2, 144)), 'cls')
+
+
+def test_entry_scripts_have_no_undefined_names():
+    """bench.py / __graft_entry__.py are only executed end to end on the GPU box: catch NameErrors (a function using a name
+    that exists only in another function's scope) here, on the CPU."""
+    import ast
+    import builtins
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    for script in ('bench.py', '__graft_entry__.py'):
+        tree = ast.parse(open(os.path.join(root, script)).read())
+        glob = {n.id for n in ast.walk(tree) if isinstance(n, ast.Name) and isinstance(n.ctx, ast.Store) and False}
+        for n in tree.body:
+            if isinstance(n, (ast.Import, ast.ImportFrom)):
+                glob |= {(a.asname or a.name).split('.')[0] for a in n.names}
+            elif isinstance(n, (ast.FunctionDef, ast.ClassDef)):
+                glob.add(n.name)
+            elif isinstance(n, ast.Assign):
+                glob |= {t.id for t in n.targets if isinstance(t, ast.Name)}
+        for fn in [n for n in tree.body if isinstance(n, ast.FunctionDef)]:
+            local = set()
+            for n in ast.walk(fn):
+                if isinstance(n, ast.Name) and isinstance(n.ctx, ast.Store):
+                    local.add(n.id)
+                elif isinstance(n, (ast.Import, ast.ImportFrom)):
+                    local |= {(a.asname or a.name).split('.')[0] for a in n.names}
+                elif isinstance(n, (ast.FunctionDef, ast.Lambda)):
+                    local |= {a.arg for a in n.args.args + n.args.kwonlyargs}
+                    if isinstance(n, ast.FunctionDef):
+                        local.add(n.name)
+                elif isinstance(n, ast.ExceptHandler) and n.name:
+                    local.add(n.name)
+                elif isinstance(n, ast.comprehension):
+                    local |= {t.id for t in ast.walk(n.target) if isinstance(t, ast.Name)}
+            used = {n.id for n in ast.walk(fn) if isinstance(n, ast.Name) and isinstance(n.ctx, ast.Load)}
+            missing = sorted(u for u in used if u not in local and u not in glob and not hasattr(builtins, u))
+            assert not missing, f'{script}:{fn.name} uses undefined names {missing}'

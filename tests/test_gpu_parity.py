@@ -680,3 +680,24 @@ def test_c_abi_from_plain_c(dev, tmp_path):
     r = subprocess.run([exe], capture_output=True, text=True, timeout=120)
     print(r.stdout)
     assert r.returncode == 0 and 'C-ABI smoke OK' in r.stdout, r.stdout + r.stderr
+
+
+def test_bench_default_command(dev):
+    """The driver's command line (`python bench.py` with its defaults, shortened) prints ONE JSON line with the contract's
+    keys, including the roofline and cpu_baseline objects."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, 'bench.py'), '--steps', '2', '--warmup', '1', '--cpu-budget-s', '3'],
+                       capture_output=True, text=True, timeout=900, cwd=root)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.strip().split('\n') if l.startswith('{')]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    for k in ('metric', 'value', 'unit', 'n_gpus', 'steps', 'warmup', 'ms_per_step', 'higher_is_better', 'scaling', 'vs_baseline', 'dtype',
+              'data', 'config', 'roofline', 'cpu_baseline'):
+        assert k in d, k
+    assert d['steps'] == 2 and d['n_gpus'] == 1 and d['value'] > 10 and 'workload' in d['config']
+    assert {'bound', 'achieved', 'peak', 'unit', 'frac', 'traffic'} <= set(d['roofline'])
+    assert {'value', 'unit', 'cores', 'kind', 'sample'} <= set(d['cpu_baseline']) and d['cpu_baseline']['value'] > 0
