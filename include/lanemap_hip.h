@@ -41,6 +41,15 @@ int lm_conv2d_nhwc_mfma_f32(void* stream, const float* x, int ldx, const float* 
  * at the level of a re-ordered direct sum).  wu: transformed weights [16][CoutP][Cin] = (G g G^T)[xi = 4i + j];
  * workspace: the transformed input V, lm_conv3x3_winograd_workspace_bytes(B, H, W, Cin, dil) bytes.  act: none / ReLU. */
 long lm_conv3x3_winograd_workspace_bytes(int B, int H, int W, int Cin, int dil);
+/* The two halves separately: several convolutions reading the same tensor share one input transform V; the GEMM can also
+ * emit the GroupNorm(C,C) partial sums of its output (gn_partial [B][lm_winograd_gn_chunks][Cout][2] doubles, NULL = off;
+ * finish with lm_gn_finalize) like lm_conv2d_nhwc_mfma_f32_gnstats does for the direct kernel. */
+int lm_winograd_gn_chunks(int H, int W, int dil);
+int lm_winograd_input_transform_f32(void* stream, const float* x, int ldx, int B, int H, int W, int Cin, int dil, void* V,
+                                    long V_bytes);
+int lm_winograd_gemm_f32(void* stream, const void* V, const float* wu, int CoutP, const float* scale, const float* shift,
+                         const float* res, int ldr, float* y, int ldy, int B, int H, int W, int Cin, int Cout, int dil, int act,
+                         double* gn_partial);
 int lm_conv3x3_winograd_f32(void* stream, const float* x, int ldx, const float* wu, int CoutP, const float* scale,
                             const float* shift, const float* res, int ldr, float* y, int ldy, int B, int H, int W, int Cin,
                             int Cout, int dil, int act, void* workspace, long workspace_bytes);

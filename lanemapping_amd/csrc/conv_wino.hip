@@ -33,18 +33,22 @@ __device__ __attribute__((aligned(16))) float g_wino_zero[4] = {0.f, 0.f, 0.f, 0
 
 struct WinoGeom {
     int B, H, W, dil, Ty, Tx;   // Ty x Tx tiles per (image, phase); dil*dil phases
-    long T;                     // tiles in total
+    int Timg, Tpad;             // real tiles per image, and that count rounded up to 128 (a workgroup never straddles images)
+    long T;                     // B * Tpad rows of V
 };
 
-__device__ __forceinline__ void tile_decode(const WinoGeom& g, long m, int& b, int& pa, int& pb, int& ty, int& tx) {
-    tx = (int)(m % g.Tx);
-    long t = m / g.Tx;
-    ty = (int)(t % g.Ty);
-    t /= g.Ty;
-    const int ph = (int)(t % (g.dil * g.dil));
-    b = (int)(t / (g.dil * g.dil));
+// row m of V -> tile; false for the padding rows at the end of every image
+__device__ __forceinline__ bool tile_decode(const WinoGeom& g, long m, int& b, int& pa, int& pb, int& ty, int& tx) {
+    b = (int)(m / g.Tpad);
+    int t = (int)(m - (long)b * g.Tpad);
+    if (t >= g.Timg) return false;
+    tx = t % g.Tx;
+    t /= g.Tx;
+    ty = t % g.Ty;
+    const int ph = t / g.Ty;
     pa = ph / g.dil;
     pb = ph % g.dil;
+    return true;
 }
 
 // grid: ceil(T * C/4 / 256)
@@ -55,7 +59,7 @@ __global__ __launch_bounds__(256) void wino_input_kernel(const float* __restrict
     const int c4 = (int)(e % c4n) * 4;
     const long m = e / c4n;
     int b, pa, pb, ty, tx;
-    tile_decode(g, m, b, pa, pb, ty, tx);
+    if (!tile_decode(g, m, b, pa, pb, ty, tx)) return;      // padding row: never read (the GEMM substitutes zeros)
     f32x4 d[4][4];
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
@@ -91,6 +95,7 @@ __global__ __launch_bounds__(256) void wino_input_kernel(const float* __restrict
 struct WinoParams {
     const float* V; const float* U; const float* scale; const float* shift; const float* res; float* y; const float* zero;
     int ldr, ldy, C, Cout, CoutP, act;
+    double* gn_part;   // optional [B][Tpad/32][Cout][2]: per (image, 32-tile chunk, channel) sum / sum of squares of the outputs
     WinoGeom g;
 };
 
@@ -123,7 +128,7 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64) void wino_gemm_kernel(W
 #pragma unroll
     for (int i = 0; i < A_LOADS; ++i) {
         const long m = m0 + lrow + i * RPP;
-        a_off[i] = m < T ? m * p.C + lc4 : -1;
+        a_off[i] = (m < T && (m % p.g.Tpad) < p.g.Timg) ? m * p.C + lc4 : -1;
     }
 #pragma unroll
     for (int i = 0; i < B_LOADS; ++i) b_off[i] = (n0 + lrow + i * RPP) * p.C + lc4;
@@ -236,6 +241,7 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64) void wino_gemm_kernel(W
             }
     }
     const bool vec = (n + 3 < p.Cout) && ((p.ldy & 3) == 0) && (!p.res || (p.ldr & 3) == 0);
+    f32x4 gs = {0.f, 0.f, 0.f, 0.f}, gq = {0.f, 0.f, 0.f, 0.f};   // GroupNorm(C,C) statistics of this wave tile (all 4 positions)
 #pragma unroll
     for (int a = 0; a < 2; ++a)
 #pragma unroll
@@ -256,13 +262,20 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64) void wino_gemm_kernel(W
                 const long m = m0 + wm0 + row;
                 if (m >= T) continue;
                 int bi, pa, pb, ty, tx;
-                tile_decode(p.g, m, bi, pa, pb, ty, tx);
+                if (!tile_decode(p.g, m, bi, pa, pb, ty, tx)) continue;
                 const int oy = (2 * ty + a) * p.g.dil + pa, ox = (2 * tx + b) * p.g.dil + pb;
                 if (oy >= p.g.H || ox >= p.g.W) continue;
                 const long pix = ((long)bi * p.g.H + oy) * p.g.W + ox;
                 f32x4 v = *reinterpret_cast<const f32x4*>(stage + row * ELD + c4);
 #pragma unroll
                 for (int e = 0; e < 4; ++e) v[e] = p.scale ? v[e] * sc[e] + sh[e] : v[e] + sh[e];
+                if (p.gn_part) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        gs[e] += v[e];
+                        gq[e] = fmaf(v[e], v[e], gq[e]);
+                    }
+                }
                 if (vec) {
                     if (p.res) {
                         const f32x4 rr = *reinterpret_cast<const f32x4*>(p.res + pix * p.ldr + n);
@@ -284,6 +297,25 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64) void wino_gemm_kernel(W
                 }
             }
         }
+    if (p.gn_part && n < p.Cout) {   // fixed-order reduction over the RPI lanes that share a channel quad, then one writer lane
+#pragma unroll
+        for (int o = LPR; o < 64; o <<= 1)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                gs[e] += __shfl_xor(gs[e], o);
+                gq[e] += __shfl_xor(gq[e], o);
+            }
+        if (lane < LPR) {
+            const long mt = m0 + wm0;                          // first row of this wave tile: one image (Tpad % 128 == 0)
+            const long bi = mt / p.g.Tpad;
+            const long chunk = (mt - bi * p.g.Tpad) / WM;
+            double* o = p.gn_part + ((bi * (p.g.Tpad / WM) + chunk) * p.Cout + n) * 2;
+            for (int e = 0; e < 4 && n + e < p.Cout; ++e) {
+                o[2 * e] = (double)gs[e];
+                o[2 * e + 1] = (double)gq[e];
+            }
+        }
+    }
 }
 
 template <int BM, int BN, int WM, int WN>
@@ -307,7 +339,9 @@ WinoGeom geom(int B, int H, int W, int dil) {
     g.B = B; g.H = H; g.W = W; g.dil = dil;
     g.Ty = ((H + dil - 1) / dil + 1) / 2;
     g.Tx = ((W + dil - 1) / dil + 1) / 2;
-    g.T = (long)B * dil * dil * g.Ty * g.Tx;
+    g.Timg = dil * dil * g.Ty * g.Tx;
+    g.Tpad = (g.Timg + 127) / 128 * 128;
+    g.T = (long)B * g.Tpad;
     return g;
 }
 
@@ -318,23 +352,43 @@ LM_API long lm_conv3x3_winograd_workspace_bytes(int B, int H, int W, int Cin, in
     return 16 * geom(B, H, W, dil).T * (long)Cin * (long)sizeof(float);
 }
 
-// y = act((conv3x3(x, w; stride 1, pad = dil, dilation dil)) * scale + shift + res), NHWC, via Winograd F(2x2,3x3).
-// wu: transformed weights [16][CoutP][Cin] (xi = 4 i + j of G g G^T); workspace: V, lm_conv3x3_winograd_workspace_bytes.
-LM_API int lm_conv3x3_winograd_f32(void* stream, const float* x, int ldx, const float* wu, int CoutP, const float* scale,
-                                   const float* shift, const float* res, int ldr, float* y, int ldy, int B, int H, int W, int Cin,
-                                   int Cout, int dil, int act, void* workspace, long workspace_bytes) {
-    LM_REQUIRE(x && wu && y && workspace, "conv_wino: null pointer");
+// 32-tile chunks per image of the GroupNorm partial sums written by lm_winograd_gemm_f32 (-> lm_gn_finalize's nchunk)
+LM_API int lm_winograd_gn_chunks(int H, int W, int dil) { return dil < 1 ? 0 : geom(1, H, W, dil).Tpad / 32; }
+
+// V = B^T d B of every 4x4 patch: [16][B * Tpad][Cin] (lm_conv3x3_winograd_workspace_bytes).  Several convolutions that
+// read the same tensor (the two semantic branches of the FPN) share one transform.
+LM_API int lm_winograd_input_transform_f32(void* stream, const float* x, int ldx, int B, int H, int W, int Cin, int dil, void* V,
+                                           long V_bytes) {
+    LM_REQUIRE(x && V, "wino_input: null pointer");
+    LM_REQUIRE(Cin > 0 && Cin % BK == 0 && dil >= 1 && B > 0 && H > 0 && W > 0, "wino_input: bad shape (Cin=%d must be a multiple of %d)", Cin, BK);
+    LM_REQUIRE(ldx >= Cin && ldx % 4 == 0, "wino_input: bad leading dim ldx=%d", ldx);
+    LM_REQUIRE(lm_conv3x3_winograd_workspace_bytes(B, H, W, Cin, dil) <= V_bytes, "wino_input: V buffer too small");
+    const WinoGeom g = geom(B, H, W, dil);
+    const long in_threads = g.T * (Cin / 4);
+    hipLaunchKernelGGL(wino_input_kernel, dim3((unsigned)((in_threads + 255) / 256)), dim3(256), 0, (hipStream_t)stream, x, ldx, g, Cin,
+                       (float*)V);
+    LM_LAUNCH_CHECK();
+    return LM_OK;
+}
+
+// y = act((sum_xi V[xi] U[xi]^T folded by A^T . A) * scale + shift + res), NHWC.  wu: [16][CoutP][Cin] = (G g G^T)[xi = 4i + j].
+// gn_partial (optional, needs res == NULL and act == none): [B][lm_winograd_gn_chunks][Cout][2] doubles, sum / sum of squares
+// of the outputs per (image, chunk, channel) -> lm_gn_finalize (first pass of GroupNorm(C,C) without re-reading y).
+LM_API int lm_winograd_gemm_f32(void* stream, const void* V, const float* wu, int CoutP, const float* scale, const float* shift,
+                                const float* res, int ldr, float* y, int ldy, int B, int H, int W, int Cin, int Cout, int dil, int act,
+                                double* gn_partial) {
+    LM_REQUIRE(V && wu && y, "conv_wino: null pointer");
     LM_REQUIRE(Cin > 0 && Cin % BK == 0 && dil >= 1 && B > 0 && H > 0 && W > 0, "conv_wino: bad shape (Cin=%d must be a multiple of %d)", Cin, BK);
     LM_REQUIRE(CoutP >= Cout && CoutP % 128 == 0, "conv_wino: CoutP=%d must be Cout=%d rounded up to 128", CoutP, Cout);
-    LM_REQUIRE(ldx >= Cin && ldx % 4 == 0 && ldy >= Cout, "conv_wino: bad leading dims ldx=%d ldy=%d", ldx, ldy);
+    LM_REQUIRE(ldy >= Cout, "conv_wino: bad leading dim ldy=%d", ldy);
     LM_REQUIRE(act == LM_ACT_NONE || act == LM_ACT_RELU, "conv_wino: activation %d not supported", act);
-    LM_REQUIRE(lm_conv3x3_winograd_workspace_bytes(B, H, W, Cin, dil) <= workspace_bytes, "conv_wino: workspace too small");
     LM_REQUIRE((long)16 * CoutP * Cin < (1L << 31), "conv_wino: weights too large");
-    hipStream_t s = (hipStream_t)stream;
+    LM_REQUIRE(!gn_partial || (res == nullptr && act == LM_ACT_NONE && Cout % 4 == 0), "conv_wino(gn stats): no residual / activation");
     WinoParams p;
     p.g = geom(B, H, W, dil);
-    p.V = (const float*)workspace; p.U = wu; p.scale = scale; p.shift = shift; p.res = res; p.y = y;
+    p.V = (const float*)V; p.U = wu; p.scale = scale; p.shift = shift; p.res = res; p.y = y;
     p.ldr = ldr; p.ldy = ldy; p.C = Cin; p.Cout = Cout; p.CoutP = CoutP; p.act = act;
+    p.gn_part = gn_partial;
     static const float* zero = nullptr;
     if (!zero) {
         void* sym = nullptr;
@@ -342,14 +396,19 @@ LM_API int lm_conv3x3_winograd_f32(void* stream, const float* x, int ldx, const 
         zero = (const float*)sym;
     }
     p.zero = zero;
-    const long in_threads = p.g.T * (Cin / 4);
-    hipLaunchKernelGGL(wino_input_kernel, dim3((unsigned)((in_threads + 255) / 256)), dim3(256), 0, s, x, ldx, p.g, Cin, (float*)workspace);
-    LM_LAUNCH_CHECK();
+    hipStream_t s = (hipStream_t)stream;
     static const int force = [] { const char* e = getenv("LM_WINO_TILE"); return e ? atoi(e) : 0; }();   // experiments only
-    if (force == 1) return launch_wino<128, 128, 64, 64>(p, s);
-    if (force == 2) return launch_wino<128, 64, 32, 64>(p, s);
-    if (force == 3) return launch_wino<64, 128, 32, 64>(p, s);
+    if (force == 1 && !gn_partial) return launch_wino<128, 128, 64, 64>(p, s);
+    if (force == 3 && !gn_partial) return launch_wino<64, 128, 32, 64>(p, s);
     // 128 x 64 tiles: 4 output + 1 temporary accumulator sets = 246 registers -> two workgroups per CU.  The 128 x 128 tile
     // (471 registers, one workgroup per CU) measured 1.32x over the direct kernel on 256->256@288^2, this one 1.52x.
     return launch_wino<128, 64, 32, 64>(p, s);
+}
+
+// Transform + GEMM in one call (workspace = V).
+LM_API int lm_conv3x3_winograd_f32(void* stream, const float* x, int ldx, const float* wu, int CoutP, const float* scale,
+                                   const float* shift, const float* res, int ldr, float* y, int ldy, int B, int H, int W, int Cin,
+                                   int Cout, int dil, int act, void* workspace, long workspace_bytes) {
+    if (int e = lm_winograd_input_transform_f32(stream, x, ldx, B, H, W, Cin, dil, workspace, workspace_bytes)) return e;
+    return lm_winograd_gemm_f32(stream, workspace, wu, CoutP, scale, shift, res, ldr, y, ldy, B, H, W, Cin, Cout, dil, act, nullptr);
 }

@@ -127,32 +127,64 @@ def conv_mfma(x, wp, cout, kh=1, kw=1, stride=1, pad=0, dil=1, scale=None, shift
 _wino_ws = {}
 
 
-def conv_wino(x, wu, cout, dil=1, scale=None, shift=None, res=None, act=ACT_NONE, out=None):
-    """3x3 / stride 1 / pad = dil convolution via Winograd F(2x2,3x3) (lm_conv3x3_winograd_f32)."""
+class WinoInput:
+    """Winograd-transformed input V = B^T d B of one NHWC tensor (lm_winograd_input_transform_f32); may feed several
+    convolutions.  `buf` is either a dedicated tensor (shared transforms) or the per-stream scratch buffer."""
+
+    def __init__(self, buf, B, cin, H, W, dil):
+        self.buf, self.B, self.cin, self.H, self.W, self.dil = buf, B, cin, H, W, dil
+
+
+def wino_transform(x, dil=1, dedicated=False):
     x, ldx = as_nhwc(x)
     B, cin, H, W = x.shape
-    if out is None:
-        out = new_act(B, cout, H, W, x.device)
-    out_, ldy = as_nhwc(out)
-    assert out_.data_ptr() == out.data_ptr(), 'conv_wino: `out` must already be NHWC-stored'
-    ldr = 0
-    if res is not None:
-        res, ldr = as_nhwc(res)
     need = lib().lm_conv3x3_winograd_workspace_bytes(B, H, W, cin, dil)
-    key = (x.device, torch.cuda.current_stream().cuda_stream)
-    ws = _wino_ws.get(key)
-    if ws is None or ws.numel() < need:
-        ws = _wino_ws[key] = torch.empty(need, device=x.device, dtype=torch.uint8)
-    def launch():
-        check(lib().lm_conv3x3_winograd_f32(_stream(), _ptr(x), ldx, _ptr(wu), wu.shape[1], _ptr(scale), _ptr(shift), _ptr(res), ldr,
-                                            _ptr(out), ldy, B, H, W, cin, cout, dil, act, _ptr(ws), ws.numel()))
-    if _conv_hook is not None:
-        tiles = need // (64 * cin)          # 16 transform points x tiles x Cin floats
-        _conv_hook(f'wino {cin}->{cout} k3x3 d{dil} @{H}x{W} B{B}', 2.0 * B * H * W * cout * cin * 9, launch,
-                   2.0 * 16 * tiles * cin * cout)
+    if dedicated:
+        ws = torch.empty(need, device=x.device, dtype=torch.uint8)
     else:
-        launch()
-    return out
+        key = (x.device, torch.cuda.current_stream().cuda_stream)
+        ws = _wino_ws.get(key)
+        if ws is None or ws.numel() < need:
+            ws = _wino_ws[key] = torch.empty(need, device=x.device, dtype=torch.uint8)
+    check(lib().lm_winograd_input_transform_f32(_stream(), _ptr(x), ldx, B, H, W, cin, dil, _ptr(ws), ws.numel()))
+    return WinoInput(ws, B, cin, H, W, dil)
+
+
+def conv_wino(x, wu, cout, dil=1, scale=None, shift=None, res=None, act=ACT_NONE, out=None, gn_eps=None):
+    """3x3 / stride 1 / pad = dil convolution via Winograd F(2x2,3x3).  x: an NHWC-stored tensor or a WinoInput (shared
+    transform).  With gn_eps the GroupNorm(C,C) statistics of the output come out of the GEMM epilogue: returns (y, stats)."""
+    v = x if isinstance(x, WinoInput) else None
+    hook = _conv_hook
+
+    def run():
+        vi = v if v is not None else wino_transform(x, dil)
+        B, cin, H, W = vi.B, vi.cin, vi.H, vi.W
+        y = out if out is not None else new_act(B, cout, H, W, vi.buf.device)
+        y_, ldy = as_nhwc(y)
+        assert y_.data_ptr() == y.data_ptr(), 'conv_wino: `out` must already be NHWC-stored'
+        r, ldr = (None, 0) if res is None else as_nhwc(res)
+        part = None
+        if gn_eps is not None:
+            nchunk = lib().lm_winograd_gn_chunks(H, W, vi.dil)
+            part = torch.zeros((B, nchunk, cout, 2), device=vi.buf.device, dtype=torch.float64)   # padding chunks stay 0
+        check(lib().lm_winograd_gemm_f32(_stream(), _ptr(vi.buf), _ptr(wu), wu.shape[1], _ptr(scale), _ptr(shift), _ptr(r), ldr,
+                                         _ptr(y), ldy, B, H, W, cin, cout, vi.dil, act, _ptr(part)))
+        if gn_eps is None:
+            return y
+        stats = torch.empty((B, cout, 2), device=vi.buf.device, dtype=torch.float32)
+        check(lib().lm_gn_finalize(_stream(), _ptr(part), _ptr(stats), B, H * W, cout, part.shape[1], gn_eps))
+        return y, stats
+
+    if hook is None:
+        return run()
+    src = v if v is not None else x
+    B, cin = (src.B, src.cin) if v is not None else (src.shape[0], src.shape[1])
+    H, W = (src.H, src.W) if v is not None else src.shape[2:]
+    tiles = lib().lm_conv3x3_winograd_workspace_bytes(B, H, W, cin, dil) // (64 * cin)
+    box = {}
+    hook(f'wino {cin}->{cout} k3x3 d{dil} @{H}x{W} B{B}' + (' (shared V)' if v is not None else ''), 2.0 * B * H * W * cout * cin * 9,
+         lambda: box.setdefault('r', run()), 2.0 * 16 * tiles * cin * cout)
+    return box['r']
 
 
 def conv_mfma_gnstats(x, wp, cout, kh, kw, stride, pad, dil, shift, eps=1e-5):

@@ -168,17 +168,21 @@ class FPNEncoder(PackedModule):
     def _conv3(self, x, P, name, cout):
         return self._c3(x, P, name + '.w', cout, 1, 1, shift=P[name + '.b'])
 
-    def _semantic(self, P, p2, p3, p4, conv_a, gn_a, conv_b, gn_b):
-        """One of the two branches (reference :615-621 / :641-647): returns s2 + s3 + s4 at p2's size."""
+    def _semantic(self, P, p2, p3, p4, conv_a, gn_a, conv_b, gn_b, shared):
+        """One of the two branches (reference :615-621 / :641-647): returns s2 + s3 + s4 at p2's size.  `shared` caches the
+        Winograd input transforms of p2 / p3 / p4, which both branches convolve (with different weights)."""
         h, w = p2.shape[2:]
         c_half = self.semantic_branch.out_channels
 
-        def conv_gn_up(src, conv, cout, gn, out=None, acc=False):
+        def conv_gn_up(src, conv, cout, gn, out=None, acc=False, share=None):
             # conv3x3 + bias with the GroupNorm statistics coming out of the conv epilogue, then GN + ReLU + bilinear (+=)
             eps = getattr(self, gn).eps
-            if (conv + '.wu') in P:                             # Winograd conv, statistics in their own pass
-                t = self._conv3(src, P, conv, cout)
-                st = ops.gn_stats(t, eps)
+            if (conv + '.wu') in P:                             # Winograd; p2/p3/p4 are transformed once for both branches
+                if share is not None:
+                    if share not in shared:
+                        shared[share] = ops.wino_transform(src, 1, dedicated=True)
+                    src = shared[share]
+                t, st = ops.conv_wino(src, P[conv + '.wu'], cout, 1, shift=P[conv + '.b'], gn_eps=eps)
             elif (src.shape[2] * src.shape[3]) % 128 == 0:    # whole 128-row tiles per image: statistics from the epilogue
                 t, st = ops.conv_mfma_gnstats(src, P[conv + '.w'], cout, 3, 3, 1, 1, 1, P[conv + '.b'], eps)
             else:                                              # ragged image size: separate statistics kernel
@@ -186,10 +190,10 @@ class FPNEncoder(PackedModule):
                 st = ops.gn_stats(t, eps)
             return ops.gn_relu_upsample(t, st, P[gn + '.g'], P[gn + '.b'], (h, w), out=out, accumulate=acc)
 
-        s4 = conv_gn_up(p4, conv_a, p4.shape[1], gn_a)                        # 256 ch at 288^2
-        total = conv_gn_up(p2, conv_b, c_half, gn_b)                          # s2
-        total = conv_gn_up(p3, conv_b, c_half, gn_b, out=total, acc=True)     # + s3
-        total = conv_gn_up(s4, conv_b, c_half, gn_b, out=total, acc=True)     # + s4
+        s4 = conv_gn_up(p4, conv_a, p4.shape[1], gn_a, share='p4')                       # 256 ch at 288^2
+        total = conv_gn_up(p2, conv_b, c_half, gn_b, share='p2')                        # s2
+        total = conv_gn_up(p3, conv_b, c_half, gn_b, out=total, acc=True, share='p3')   # + s3
+        total = conv_gn_up(s4, conv_b, c_half, gn_b, out=total, acc=True)               # + s4
         return total
 
     def forward(self, x, fea_up_out=None):
@@ -213,12 +217,14 @@ class FPNEncoder(PackedModule):
         p4 = self._conv3(p4, P, 'smooth1', 256)
         p3 = self._conv3(p3, P, 'smooth2', 256)
         p2 = self._conv3(p2, P, 'smooth3', 256)
-        sa = self._semantic(P, p2, p3, p4, 'conv2', 'gn12', 'semantic_branch', 'gn11')
+        shared = {}
+        sa = self._semantic(P, p2, p3, p4, 'conv2', 'gn12', 'semantic_branch', 'gn11', shared)
         fea_up = ops.conv_small(sa, P['feature_layer.w'], 8, shift=P['feature_layer.b'], out=fea_up_out)
         del sa
         seg288 = ops.conv_small(fea_up, P['output_layer_binary_seg.w'], 3, shift=P['output_layer_binary_seg.b'], pre_relu=True)
         bi_seg = ops.upsample_to_chw(seg288, (H, W))
-        sb = self._semantic(P, p2, p3, p4, 'conv3', 'gn22', 'semantic_branch2', 'gn21')
+        sb = self._semantic(P, p2, p3, p4, 'conv3', 'gn22', 'semantic_branch2', 'gn21', shared)
+        del shared
         endp288 = ops.conv_small(sb, P['output_layer_endp.w'], 1, shift=P['output_layer_endp.b'])
         endp = ops.upsample_to_chw(endp288, (H, W))
         return fea, fea_up, bi_seg, endp
