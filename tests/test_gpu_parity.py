@@ -701,3 +701,36 @@ def test_bench_default_command(dev):
     assert d['steps'] == 2 and d['n_gpus'] == 1 and d['value'] > 10 and 'workload' in d['config']
     assert {'bound', 'achieved', 'peak', 'unit', 'frac', 'traffic'} <= set(d['roofline'])
     assert {'value', 'unit', 'cores', 'kind', 'sample'} <= set(d['cpu_baseline']) and d['cpu_baseline']['value'] > 0
+
+
+# ----------------------------------------------------------------------------------------------- Winograd convolution
+@pytest.mark.parametrize('B,cin,cout,H,W,dil', [(2, 128, 128, 36, 36, 1), (1, 256, 200, 37, 29, 1), (2, 128, 64, 40, 44, 2),
+                                                (1, 160, 256, 31, 33, 2), (1, 128, 96, 23, 50, 3)])
+def test_conv_winograd_vs_fp64_reference(dev, B, cin, cout, H, W, dil):
+    """lm_conv3x3_winograd_f32 (odd sizes, dilations, Cout not a multiple of 64, BN scale/shift, residual, ReLU) vs torch fp64,
+    and vs the direct MFMA kernel; GroupNorm statistics out of the GEMM epilogue vs the standalone statistics kernel."""
+    from lanemapping_amd import ops
+    g = torch.Generator().manual_seed(B * 1000 + cin + H)
+    x = torch.randn((B, cin, H, W), generator=g)
+    w = torch.randn((cout, cin, 3, 3), generator=g) / (cin * 9) ** 0.5
+    scale, shift = torch.rand(cout, generator=g) + 0.5, torch.randn(cout, generator=g)
+    res = torch.randn((B, cout, H, W), generator=g)
+    want = F.relu(F.conv2d(x.double(), w.double(), None, 1, dil, dil) * scale.double().view(1, -1, 1, 1) + shift.double().view(1, -1, 1, 1)
+                  + res.double()).float()
+    xd = x.to(dev).permute(0, 2, 3, 1).contiguous().permute(0, 3, 1, 2)
+    rd = res.to(dev).permute(0, 2, 3, 1).contiguous().permute(0, 3, 1, 2)
+    wu, wp = ops.pack_wino(w.to(dev)), ops.pack_mfma(w.to(dev))
+    y = ops.conv_wino(xd, wu, cout, dil, scale=scale.to(dev), shift=shift.to(dev), res=rd, act=ops.ACT_RELU)
+    _close(y, want, 2e-5, 'winograd vs fp64')
+    yd = ops.conv_mfma(xd, wp, cout, 3, 3, 1, dil, dil, scale=scale.to(dev), shift=shift.to(dev), res=rd, act=ops.ACT_RELU)
+    _close(y, yd, 2e-5, 'winograd vs direct')
+    # shared transform + statistics from the epilogue
+    v = ops.wino_transform(xd, dil, dedicated=True)
+    t, st = ops.conv_wino(v, wu, cout, dil, shift=shift.to(dev), gn_eps=1e-5)
+    t2 = ops.conv_wino(v, wu, cout, dil, shift=shift.to(dev))
+    assert torch.equal(t, t2)
+    td = t.double()
+    mean = td.mean(dim=(2, 3))
+    rstd = 1.0 / torch.sqrt(td.var(dim=(2, 3), unbiased=False) + 1e-5)
+    _close(st[:, :, 0], mean.float(), 1e-5, 'GN mean')
+    _close(st[:, :, 1], rstd.float(), 1e-5, 'GN rstd')
