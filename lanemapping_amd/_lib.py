@@ -101,6 +101,8 @@ def lib():
             raise LanemapHipError(
                 f'{LIB_PATH} is missing: the HIP library is the only implementation of this package '
                 '(no CPU fallback). Build it with `python -m lanemapping_amd.build`.')
+        import torch  # noqa: F401  first: the process must hold ONE HIP runtime, the one torch loads (loading ours before
+        #                     torch's made every later launch fail with "no ROCm-capable device is detected")
         L = C.CDLL(LIB_PATH)
         for name, (res, args) in SIGNATURES.items():
             fn = getattr(L, name)           # AttributeError if the symbol is not exported
