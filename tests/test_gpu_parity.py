@@ -734,3 +734,16 @@ def test_conv_winograd_vs_fp64_reference(dev, B, cin, cout, H, W, dil):
     rstd = 1.0 / torch.sqrt(td.var(dim=(2, 3), unbiased=False) + 1e-5)
     _close(st[:, :, 0], mean.float(), 1e-5, 'GN mean')
     _close(st[:, :, 1], rstd.float(), 1e-5, 'GN rstd')
+
+
+@pytest.mark.parametrize('N', [12, 320, 321, 324, 352])
+def test_attention_vs_torch(dev, N):
+    """lm_attention_f32: the MFMA kernel (321..352 tokens, padded keys masked) and the VALU kernel (other lengths) vs torch."""
+    from lanemapping_amd import ops
+    B, heads, dh = 2, 16, 64
+    g = torch.Generator().manual_seed(N)
+    qkv = torch.randn((B * N, 3 * heads * dh), generator=g) * 1.5
+    q, k, v = [z.reshape(B, N, heads, dh).transpose(1, 2).double() for z in qkv.chunk(3, dim=-1)]
+    want = (torch.softmax(q @ k.transpose(-1, -2) * dh ** -0.5, dim=-1) @ v).transpose(1, 2).reshape(B * N, heads * dh).float()
+    got = ops.attention(qkv.to(dev).contiguous(), B, N, heads, dh, dh ** -0.5)
+    _close(got, want, 1e-5, f'attention N={N}')
