@@ -34,7 +34,7 @@ def decode_points(records_u8, record_len, n, scale, offset, shift=None, normalis
         raise LanemapHipError('las_io.decode_points needs the records on an MI355X (HIP) device; no CPU fallback exists')
     out = torch.empty((n, 4), device=records_u8.device, dtype=torch.float32)
     d3 = lambda v: (C.c_double * 3)(*[float(x) for x in v])
-    check(lib().lm_las_decode_points(C.c_void_p(torch.cuda.current_stream().cuda_stream), C.c_void_p(records_u8.data_ptr()),
+    check(lib().lm_las_decode_points(C.c_void_p(torch._C._cuda_getCurrentRawStream(records_u8.device.index)), C.c_void_p(records_u8.data_ptr()),
                                      int(record_len), int(n), d3(scale), d3(offset), d3(shift) if shift is not None else None,
                                      INTEN_MIN, INTEN_MAX, int(normalise), C.c_void_p(out.data_ptr())))
     return out
