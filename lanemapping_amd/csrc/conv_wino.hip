@@ -401,6 +401,7 @@ LM_API int lm_winograd_gemm_f32(void* stream, const void* V, const float* wu, in
     if (force == 1 && !gn_partial) return launch_wino<128, 128, 64, 64>(p, s);
     if (force == 3 && !gn_partial) return launch_wino<64, 128, 32, 64>(p, s);
     if (force == 4) return launch_wino<256, 64, 32, 64>(p, s);
+    if (force == 5) return launch_wino<128, 128, 64, 32>(p, s);
     // 128 x 64 tiles: 4 output + 1 temporary accumulator sets = 246 registers -> two workgroups per CU.  The 128 x 128 tile
     // (471 registers, one workgroup per CU) measured 1.32x over the direct kernel on 256->256@288^2, this one 1.52x.
     return launch_wino<128, 64, 32, 64>(p, s);
