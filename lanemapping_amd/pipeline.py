@@ -19,6 +19,9 @@ class TilePipeline:
     def __init__(self, net, host_threads=8):
         self.net = net
         self.cfg = net.cfg
+        if net.cfg.heads.type != 'ColumnProposal2':
+            raise NotImplementedError(f"TilePipeline drives the ColumnProposal2 decode / polyline tail; for heads.type="
+                                      f"{net.cfg.heads.type!r} call the net directly (Detector1stage.forward returns its lane_maps)")
         self.pool = ThreadPoolExecutor(max_workers=host_threads)
         self._pending = None
         self.host_seconds = 0.0      # accumulated wall time of the per-tile host tasks (all threads) and their count

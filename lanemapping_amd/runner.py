@@ -70,15 +70,28 @@ class Runner:
         rank = torch.distributed.get_rank() if torch.distributed.is_initialized() else 0
         lo, hi, per = shard.shard_range(len(paths), rank, world)
         mine = paths[lo:hi]
-        pipe = TilePipeline(self.net)
         results = {}
         lanes_all, endp_all = [], []
-        for i in range(0, len(mine), B):
-            futs = pipe.submit(self._load_batch(mine[i:i + B]))
-            for f in futs:
+        if self.cfg.heads.type == 'RowSharNotReducRef':
+            # config 4: the head's own decode + per-lane tracing inside Detector1stage.forward; 12 lanes x 144 rows of columns
+            # are padded into the [72,144,2] block the JSON writer / all-gather use (semantic 1 = line present)
+            for i in range(0, len(mine), B):
+                out = self.net({'proj': self._load_batch(mine[i:i + B])})
+                for cols in out['lane_maps']['cls_offset_smooth']:
+                    lanes = np.full((72, 144, 2), -1.0)
+                    lanes[:, :, 1] = 0.0
+                    lanes[:cols.shape[0], :, 0] = cols
+                    lanes[:cols.shape[0], :, 1] = (cols > 0).astype(np.float64)
+                    lanes_all.append(lanes)
+                    endp_all.append(np.zeros((0, 2), dtype=np.int32))
+        else:
+            pipe = TilePipeline(self.net)
+            for i in range(0, len(mine), B):
+                futs = pipe.submit(self._load_batch(mine[i:i + B]))
+                for f in futs:
+                    lanes_all.append(f.result()[0]); endp_all.append(f.result()[1])
+            for f in pipe.flush():
                 lanes_all.append(f.result()[0]); endp_all.append(f.result()[1])
-        for f in pipe.flush():
-            lanes_all.append(f.result()[0]); endp_all.append(f.result()[1])
         if world > 1:
             blocks = shard.pack_tile_results(lanes_all, endp_all, per, self.device)
             gathered = shard.unpack_gathered(*shard.all_gather_results(*blocks))
