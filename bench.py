@@ -96,11 +96,17 @@ def main():
     if world != args.gpus and world > 1:
         raise SystemExit(f'--gpus {args.gpus} but WORLD_SIZE={world}')
     import torch.distributed as dist
+    # test hooks (tests/test_gpu_parity.py exercises the N>1 code path on a 1-GPU box): every rank on one device, gloo backend
+    dev_index = int(os.environ.get('LANEMAP_BENCH_DEVICE', local_rank))
+    backend = os.environ.get('LANEMAP_BENCH_BACKEND', 'nccl')
     if world > 1:
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group(backend='nccl', device_id=torch.device('cuda', local_rank))
-    dev = torch.device('cuda', local_rank)
+        torch.cuda.set_device(dev_index)
+        if backend == 'nccl':
+            dist.init_process_group(backend='nccl', device_id=torch.device('cuda', dev_index))
+        else:
+            dist.init_process_group(backend=backend)
+    dev = torch.device('cuda', dev_index)
     torch.cuda.set_device(dev)
 
     from lanemapping_amd import synth, ops, shard
@@ -195,10 +201,20 @@ def main():
                             ev.record()
                             done[si - 1][par] = ev
         res = [f.result() for f in futs]
-        if world > 1 and res:
-            blocks = shard.pack_tile_results([r[0] for r in res], [r[1] for r in res], batch, dev)
-            shard.all_gather_results(*blocks)
+        gather(res)
         return res
+
+    comm = torch.cuda.Stream(device=dev) if world > 1 else None
+    inflight = []
+
+    def gather(res):
+        """One all-gather of the fixed-shape polyline blocks per batch, on its own stream: neither the staging copy nor the
+        collective queues behind (or in front of) the compute streams, and the host does not wait for them."""
+        if world > 1 and res:
+            with torch.cuda.stream(comm):
+                blocks = shard.pack_tile_results([r[0] for r in res], [r[1] for r in res], batch, dev, pinned=True)
+                inflight.append((blocks, shard.all_gather_results(*blocks)))
+            del inflight[:-4]
 
     def drain():
         futs = pipe.flush()
@@ -206,9 +222,7 @@ def main():
             with torch.cuda.stream(extra_streams[si]):
                 futs += ep.flush()
         res = [f.result() for f in futs]
-        if world > 1 and res:
-            blocks = shard.pack_tile_results([r[0] for r in res], [r[1] for r in res], batch, dev)
-            shard.all_gather_results(*blocks)
+        gather(res)
         return res
 
     for _ in range(args.warmup):

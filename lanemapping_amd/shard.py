@@ -22,19 +22,28 @@ def shard_range(n_tiles, rank, world):
     return lo, hi, per
 
 
-def pack_tile_results(lanes_list, endp_list, per, device):
-    """lanes [72,144,2] f64 per tile, endpoints [k,2] -> fixed-shape f32 / i32 blocks padded to `per` tiles."""
+def pack_tile_results(lanes_list, endp_list, per, device, pinned=False):
+    """lanes [72,144,2] f64 per tile, endpoints [k,2] -> fixed-shape f32 / i32 blocks padded to `per` tiles.
+    pinned: stage in page-locked memory and copy asynchronously on the current stream (the caller keeps the returned
+    tensors alive until that stream has run the copies), so the host never waits for the compute queued before it."""
     T = len(lanes_list)
-    lanes = torch.full((per, 72, 144, 2), -1.0, dtype=torch.float32)
+    pin = bool(pinned) and torch.device(device).type == 'cuda'
+    lanes = torch.full((per, 72, 144, 2), -1.0, dtype=torch.float32, pin_memory=pin)
     lanes[..., 1] = 0.0
-    endp = torch.full((per, MAX_ENDP, 2), -1, dtype=torch.int32)
-    count = torch.zeros((per, 2), dtype=torch.int32)           # [valid tile flag, n endpoints]
+    endp = torch.full((per, MAX_ENDP, 2), -1, dtype=torch.int32, pin_memory=pin)
+    count = torch.zeros((per, 2), dtype=torch.int32, pin_memory=pin)           # [valid tile flag, n endpoints]
     for t in range(T):
         lanes[t] = torch.from_numpy(np.asarray(lanes_list[t], dtype=np.float32))
         e = np.asarray(endp_list[t], dtype=np.int32).reshape(-1, 2)[:MAX_ENDP]
         endp[t, :len(e)] = torch.from_numpy(e)
         count[t, 0] = 1
         count[t, 1] = len(e)
+    if pin:
+        host = (lanes, endp, count)
+        dev = tuple(t.to(device, non_blocking=True) for t in host)
+        for d, h in zip(dev, host):
+            d._host_staging = h          # keep the pinned source alive as long as the device copy
+        return dev
     return lanes.to(device), endp.to(device), count.to(device)
 
 

@@ -767,3 +767,27 @@ def test_runner_config4_rowref_json(dev, tmp_path):
         assert lanes.shape == (72, 144, 2)
         recs = json.load(open(tmp_path / 'out' / (name + '.json')))
         assert len(recs) == int(((lanes[:, :, 0] > 0).sum(axis=1) >= 2).sum())
+
+
+def test_bench_two_ranks_code_path(dev):
+    """The N>1 path of bench.py (torch.distributed.run, per-rank shards, barrier + max-over-ranks timing, one all-gather of
+    the polyline blocks per batch on the side stream) with two ranks sharing this box's single GPU over gloo; on the 8-GPU
+    node the same code runs one rank per GPU over RCCL."""
+    import json
+    import socket
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    port = s.getsockname()[1]
+    s.close()
+    env = dict(os.environ, LANEMAP_BENCH_DEVICE='0', LANEMAP_BENCH_BACKEND='gloo')
+    r = subprocess.run([sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2', '--master-addr', '127.0.0.1',
+                        '--master-port', str(port), os.path.join(root, 'bench.py'), '--gpus', '2', '--steps', '3', '--warmup', '1'],
+                       capture_output=True, text=True, timeout=900, cwd=root, env=env)
+    assert r.returncode == 0, (r.stdout + r.stderr)[-3000:]
+    lines = [l for l in r.stdout.strip().split('\n') if l.startswith('{')]
+    assert len(lines) == 1                                           # rank 0 only
+    d = json.loads(lines[0])
+    assert d['n_gpus'] == 2 and d['steps'] == 3 and d['cpu_baseline'] is None and d['value'] > 10
