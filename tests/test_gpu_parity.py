@@ -825,3 +825,37 @@ def test_full_tiles_other_seeds_vs_oracle(dev, net, synth_sd, seed):
     n4 = outside_noise(net.heads._compact['cls_idx'][0].cpu().numpy(), d['cls_idx'][0].numpy(), (ct[..., 0] - ct[..., 1]).flatten(), 'cls_idx')
     print(f'seed {seed}: flips inside the noise margin: ext {n1}, orient {n2}, semantic {n3}, column bin {n4}')
     assert n1 + n2 + n4 <= 4 and n3 <= 64
+
+
+@pytest.mark.parametrize('seed', [11, 12, 13, 14])
+def test_raster_fuzz_vs_c_oracle(dev, seed):
+    """Random tile geometry (rotation, non-unit quaternion, offsets, resolutions, tile size), ragged point counts that are
+    not multiples of the 8192-point chunk, points partly outside: bit-exact u8 tiles and f32 = u8 / 255 vs the C oracle."""
+    from lanemapping_amd import ops
+    from oracle import raster_ref
+    rng = np.random.RandomState(seed)
+    H, W = 16 * rng.randint(4, 40), 16 * rng.randint(4, 40)
+    B = rng.randint(1, 4)
+    pars, rps, clouds = [], [], []
+    for b in range(B):
+        q = rng.randn(4) * [1.0, 0.05, 0.05, 0.3]
+        q[0] = abs(q[0]) + 0.5
+        kw = dict(quat=q, trans=rng.randn(3) * 5, bev_img_offset=rng.randn(2), img_reso=(0.04 + 0.03 * rng.rand(), 0.04 + 0.03 * rng.rand()),
+                  local_min_ele=-1.0 + rng.rand(), ele_reso=0.01 + 0.03 * rng.rand())
+        pars.append(ops.make_raster_params(**kw))
+        rps.append(raster_ref.params(**kw))
+        n = int(rng.choice([0, 1, 777, 8192, 8193, 50000 + rng.randint(0, 9000)]))
+        uv = rng.rand(n, 2) * [H * kw['img_reso'][0] * 1.2, W * kw['img_reso'][1] * 1.2] - 0.1 + kw['bev_img_offset']
+        tile_xyz = np.concatenate([uv, rng.rand(n, 1) * 3 - 1.0], axis=1)
+        from oracle import img2pc_ref
+        world = np.stack([img2pc_ref.rotate(q, p) for p in tile_xyz]) + kw['trans'] if n else np.zeros((0, 3))
+        clouds.append(np.concatenate([world, rng.randint(0, 65535, (n, 1))], axis=1).astype(np.float32))
+    offs = np.concatenate([[0], np.cumsum([len(c) for c in clouds])])
+    allp = torch.from_numpy(np.concatenate(clouds) if sum(len(c) for c in clouds) else np.zeros((0, 4), np.float32)).to(dev)
+    if allp.shape[0] == 0:
+        allp = torch.zeros((1, 4), device=dev)[:0]
+    out, u8 = ops.bev_raster_batch(allp.contiguous(), offs.tolist(), pars, H, W, want_u8=True)
+    for b in range(B):
+        want = raster_ref.raster(clouds[b], rps[b], H, W)
+        assert np.array_equal(u8[b].cpu().numpy(), want), f'tile {b} of seed {seed}'
+        assert np.array_equal(out[b].cpu().numpy(), (want.astype(np.float32) / np.float32(255.0)).transpose(2, 0, 1))
