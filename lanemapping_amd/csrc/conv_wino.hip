@@ -26,8 +26,7 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 namespace {
 
-constexpr int BK = 32;
-constexpr int LDS_LD = BK;
+constexpr int BK = 32;            // channel granularity of the path (Cin % 32 == 0); the GEMM's K slab is KB = 32 or 64 floats
 
 __device__ __attribute__((aligned(16))) float g_wino_zero[4] = {0.f, 0.f, 0.f, 0.f};
 
@@ -99,14 +98,16 @@ struct WinoParams {
     WinoGeom g;
 };
 
-template <int BM, int BN, int WM, int WN>
+template <int BM, int BN, int WM, int WN, int KB = 32>
 __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64) void wino_gemm_kernel(WinoParams p) {
+    constexpr int LDS_LD = KB;                        // unpadded, lane-linear rows (required by global_load_lds)
+    constexpr int LPRW = KB / 4;                      // lanes (16-byte chunks) per row: 8 or 16
     constexpr int TM = WM / 32, TN = WN / 32;
     constexpr int WAVES_N = BN / WN;
     constexpr int NT = (BM / WM) * (BN / WN) * 64;
-    constexpr int RPP = NT / 8;
+    constexpr int RPP = NT / LPRW;                    // rows covered by one load pass
     constexpr int A_LOADS = BM / RPP, B_LOADS = BN / RPP;
-    static_assert(RPP % 32 == 0 && BM % RPP == 0 && BN % RPP == 0, "tile rows must be a multiple of the load pass");
+    static_assert(RPP % 16 == 0 && BM % RPP == 0 && BN % RPP == 0, "a load pass covers whole swizzle periods (16 rows)");
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* As = smem;
     float* Bs = smem + 2 * BM * LDS_LD;
@@ -120,8 +121,11 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64) void wino_gemm_kernel(W
     }
     const long m0 = (long)(bid / n_tiles) * BM;
     const int n0 = (bid % n_tiles) * BN;
-    const int lrow = tid >> 3;
-    const int lc4 = ((tid & 7) ^ ((lrow >> 1) & 7)) * 4;
+    // XOR swizzle of the 16-byte chunks, applied to the SOURCE address (the LDS image is lane-linear) and to the fragment
+    // reads: 128-byte rows (KB 32) repeat banks every 2 rows -> key (row >> 1) & 7; 256-byte rows (KB 64) every row -> row & 7
+    auto swz = [](int row) { return KB == 32 ? (row >> 1) & 7 : row & 7; };
+    const int lrow = tid / LPRW;
+    const int lc4 = ((tid % LPRW) ^ swz(lrow)) * 4;
     const long T = p.g.T;
     long a_off[A_LOADS];
     int b_off[B_LOADS];
@@ -132,24 +136,24 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64) void wino_gemm_kernel(W
     }
 #pragma unroll
     for (int i = 0; i < B_LOADS; ++i) b_off[i] = (n0 + lrow + i * RPP) * p.C + lc4;
-    const int cslabs = p.C / BK;
+    const int cslabs = p.C / KB;
     const long xi_stride_a = T * p.C;
     const int xi_stride_b = p.CoutP * p.C;
     int cur_cs = 0, cur_xi = 0;
     typedef __attribute__((address_space(1))) const void gptr_t;
     typedef __attribute__((address_space(3))) void lptr_t;
     auto gload = [&](int buf) {
-        const long adelta = cur_xi * xi_stride_a + cur_cs * BK;
-        const int bdelta = cur_xi * xi_stride_b + cur_cs * BK;
+        const long adelta = cur_xi * xi_stride_a + cur_cs * KB;
+        const int bdelta = cur_xi * xi_stride_b + cur_cs * KB;
 #pragma unroll
         for (int i = 0; i < A_LOADS; ++i) {
             const float* src = a_off[i] >= 0 ? p.V + (a_off[i] + adelta) : p.zero;
-            __builtin_amdgcn_global_load_lds((gptr_t*)src, (lptr_t*)(As + (buf * BM + i * RPP + wave * 8) * LDS_LD), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((gptr_t*)src, (lptr_t*)(As + (buf * BM + i * RPP + wave * (64 / LPRW)) * LDS_LD), 16, 0, 0);
         }
 #pragma unroll
         for (int i = 0; i < B_LOADS; ++i) {
             const float* src = p.U + (b_off[i] + bdelta);
-            __builtin_amdgcn_global_load_lds((gptr_t*)src, (lptr_t*)(Bs + (buf * BN + i * RPP + wave * 8) * LDS_LD), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((gptr_t*)src, (lptr_t*)(Bs + (buf * BN + i * RPP + wave * (64 / LPRW)) * LDS_LD), 16, 0, 0);
         }
         if (++cur_cs == cslabs) {
             cur_cs = 0;
@@ -171,7 +175,7 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64) void wino_gemm_kernel(W
 
     gload(0);
     __syncthreads();
-    const int frow = lane & 31, fswz = (frow >> 1) & 7, fhalf = lane >> 5;
+    const int frow = lane & 31, fswz = swz(frow), fhalf = lane >> 5;
     int kt = 0;
     const int KT = 16 * cslabs;
     for (int xi = 0; xi < 16; ++xi) {
@@ -188,7 +192,7 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64) void wino_gemm_kernel(W
             const float* Ab = As + (buf * BM + wm0 + frow) * LDS_LD;
             const float* Bb = Bs + (buf * BN + wn0 + frow) * LDS_LD;
 #pragma unroll
-            for (int kk = 0; kk < BK; kk += 8) {
+            for (int kk = 0; kk < KB; kk += 8) {
                 const int fo = (((kk >> 2) + fhalf) ^ fswz) * 4;
                 f32x4 af[TM], bf[TN];
 #pragma unroll
@@ -318,18 +322,19 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64) void wino_gemm_kernel(W
     }
 }
 
-template <int BM, int BN, int WM, int WN>
+template <int BM, int BN, int WM, int WN, int KB = 32>
 int launch_wino(const WinoParams& p, hipStream_t stream) {
-    const size_t kloop = (size_t)2 * (BM + BN) * LDS_LD, stage = (size_t)(BM / WM) * (BN / WN) * WM * (WN + 4);
+    LM_REQUIRE(p.C % KB == 0, "conv_wino: Cin=%d must be a multiple of the %d-float K slab", p.C, KB);
+    const size_t kloop = (size_t)2 * (BM + BN) * KB, stage = (size_t)(BM / WM) * (BN / WN) * WM * (WN + 4);
     const size_t lds = (kloop > stage ? kloop : stage) * sizeof(float);
     static bool attr_set = false;
     if (!attr_set) {
-        LM_HIP(hipFuncSetAttribute((const void*)wino_gemm_kernel<BM, BN, WM, WN>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        LM_HIP(hipFuncSetAttribute((const void*)wino_gemm_kernel<BM, BN, WM, WN, KB>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         attr_set = true;
     }
     const long blocks = ((p.g.T + BM - 1) / BM) * ((p.Cout + BN - 1) / BN);
     LM_REQUIRE(blocks > 0 && blocks < (1L << 31), "conv_wino: bad grid %ld", blocks);
-    hipLaunchKernelGGL((wino_gemm_kernel<BM, BN, WM, WN>), dim3((unsigned)blocks), dim3((BM / WM) * (BN / WN) * 64), lds, stream, p);
+    hipLaunchKernelGGL((wino_gemm_kernel<BM, BN, WM, WN, KB>), dim3((unsigned)blocks), dim3((BM / WM) * (BN / WN) * 64), lds, stream, p);
     LM_LAUNCH_CHECK();
     return LM_OK;
 }
@@ -402,6 +407,8 @@ LM_API int lm_winograd_gemm_f32(void* stream, const void* V, const float* wu, in
     if (force == 3 && !gn_partial) return launch_wino<64, 128, 32, 64>(p, s);
     if (force == 4) return launch_wino<256, 64, 32, 64>(p, s);
     if (force == 5) return launch_wino<128, 128, 64, 32>(p, s);
+    if (force == 6 && Cin % 64 == 0) return launch_wino<128, 128, 64, 32, 64>(p, s);   // 8 waves, 64-float K slabs, 128 KB LDS
+    if (force == 7 && Cin % 64 == 0) return launch_wino<128, 64, 32, 64, 64>(p, s);    // 4 waves, 64-float K slabs, 96 KB LDS
     // 128 x 64 tiles: 4 output + 1 temporary accumulator sets = 246 registers -> two workgroups per CU.  The 128 x 128 tile
     // (471 registers, one workgroup per CU) measured 1.32x over the direct kernel on 256->256@288^2, this one 1.52x.
     return launch_wino<128, 64, 32, 64>(p, s);
