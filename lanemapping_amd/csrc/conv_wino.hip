@@ -339,13 +339,19 @@ int launch_wino(const WinoParams& p, hipStream_t stream) {
     return LM_OK;
 }
 
+int wino_force() {   // LM_WINO_TILE: tile-variant experiments only
+    static const int force = [] { const char* e = getenv("LM_WINO_TILE"); return e ? atoi(e) : 0; }();
+    return force;
+}
+
 WinoGeom geom(int B, int H, int W, int dil) {
     WinoGeom g;
     g.B = B; g.H = H; g.W = W; g.dil = dil;
     g.Ty = ((H + dil - 1) / dil + 1) / 2;
     g.Tx = ((W + dil - 1) / dil + 1) / 2;
     g.Timg = dil * dil * g.Ty * g.Tx;
-    g.Tpad = (g.Timg + 127) / 128 * 128;
+    const int unit = wino_force() == 8 ? 384 : 128;      // rows per workgroup (192-row variant: lcm with the 128 of the others)
+    g.Tpad = (g.Timg + unit - 1) / unit * unit;
     g.T = (long)B * g.Tpad;
     return g;
 }
@@ -402,7 +408,8 @@ LM_API int lm_winograd_gemm_f32(void* stream, const void* V, const float* wu, in
     }
     p.zero = zero;
     hipStream_t s = (hipStream_t)stream;
-    static const int force = [] { const char* e = getenv("LM_WINO_TILE"); return e ? atoi(e) : 0; }();   // experiments only
+    const int force = wino_force();
+    if (force == 8) return launch_wino<192, 64, 96, 32>(p, s);     // 4 waves of 96x32: three accumulator tiles (chains) per wave
     if (force == 1 && !gn_partial) return launch_wino<128, 128, 64, 64>(p, s);
     if (force == 3 && !gn_partial) return launch_wino<64, 128, 32, 64>(p, s);
     if (force == 4) return launch_wino<256, 64, 32, 64>(p, s);
