@@ -98,7 +98,7 @@ struct WinoParams {
     WinoGeom g;
 };
 
-template <int BM, int BN, int WM, int WN, int KB = 32>
+template <int BM, int BN, int WM, int WN, int KB = 32, int NBUF = 2>
 __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64) void wino_gemm_kernel(WinoParams p) {
     constexpr int LDS_LD = KB;                        // unpadded, lane-linear rows (required by global_load_lds)
     constexpr int LPRW = KB / 4;                      // lanes (16-byte chunks) per row: 8 or 16
@@ -110,7 +110,7 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64) void wino_gemm_kernel(W
     static_assert(RPP % 16 == 0 && BM % RPP == 0 && BN % RPP == 0, "a load pass covers whole swizzle periods (16 rows)");
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* As = smem;
-    float* Bs = smem + 2 * BM * LDS_LD;
+    float* Bs = smem + NBUF * BM * LDS_LD;     // As [NBUF][BM][KB], Bs [NBUF][BN][KB]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm0 = (wave / WAVES_N) * WM, wn0 = (wave % WAVES_N) * WN;
     const int n_tiles = (p.Cout + BN - 1) / BN;
@@ -173,11 +173,26 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64) void wino_gemm_kernel(W
 #pragma unroll
                     for (int r = 0; r < 16; ++r) out[a][b][i][j][r] = 0.f;
 
+    // NBUF == 3: the loads run TWO slabs ahead (a 32-MFMA slab is only ~0.9 us of matrix work, less than an L2 / Infinity
+    // Cache round trip under load), so the end-of-slab wait leaves the youngest slab's loads in flight: explicit
+    // s_waitcnt vmcnt(loads per slab) + s_barrier instead of __syncthreads() (which always waits for vmcnt(0)).
+    constexpr int LOADS = A_LOADS + B_LOADS;
+    static_assert(NBUF == 2 || (NBUF == 3 && LOADS == 6), "the vmcnt immediates below assume 6 loads per slab");
+    const int KT = 16 * cslabs;
     gload(0);
-    __syncthreads();
+    if (NBUF == 3) {
+        if (KT > 1) {
+            gload(1);
+            asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+        } else {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+        __builtin_amdgcn_s_barrier();
+    } else {
+        __syncthreads();
+    }
     const int frow = lane & 31, fswz = swz(frow), fhalf = lane >> 5;
     int kt = 0;
-    const int KT = 16 * cslabs;
     for (int xi = 0; xi < 16; ++xi) {
         f32x16 acc[TM][TN];
 #pragma unroll
@@ -187,8 +202,12 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64) void wino_gemm_kernel(W
 #pragma unroll
                 for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
         for (int cs = 0; cs < cslabs; ++cs, ++kt) {
-            const int buf = kt & 1;
-            if (kt + 1 < KT) gload(buf ^ 1);
+            const int buf = NBUF == 2 ? (kt & 1) : kt % 3;
+            if (NBUF == 2) {
+                if (kt + 1 < KT) gload(buf ^ 1);
+            } else if (kt + 2 < KT) {
+                gload((kt + 2) % 3);
+            }
             const float* Ab = As + (buf * BM + wm0 + frow) * LDS_LD;
             const float* Bb = Bs + (buf * BN + wn0 + frow) * LDS_LD;
 #pragma unroll
@@ -207,7 +226,13 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64) void wino_gemm_kernel(W
                         for (int j = 0; j < TN; ++j)
                             acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i][t], bf[j][t], acc[i][j], 0, 0, 0);
             }
-            __syncthreads();
+            if (NBUF == 3) {
+                if (kt + 2 < KT) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");     // slab kt+1 has landed, kt+2 may be in flight
+                else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                __builtin_amdgcn_s_barrier();
+            } else {
+                __syncthreads();
+            }
         }
         // fold M[xi] into the 2x2 outputs: Y[a][b] += AT[a][i] * AT[b][j] * M[i][j],  A^T = [1 1 1 0; 0 1 -1 -1].
         // The coefficients are 0 / +1 / -1, so the multiply-adds below are exact additions (or no-ops).
@@ -322,19 +347,19 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64) void wino_gemm_kernel(W
     }
 }
 
-template <int BM, int BN, int WM, int WN, int KB = 32>
+template <int BM, int BN, int WM, int WN, int KB = 32, int NBUF = 2>
 int launch_wino(const WinoParams& p, hipStream_t stream) {
     LM_REQUIRE(p.C % KB == 0, "conv_wino: Cin=%d must be a multiple of the %d-float K slab", p.C, KB);
-    const size_t kloop = (size_t)2 * (BM + BN) * KB, stage = (size_t)(BM / WM) * (BN / WN) * WM * (WN + 4);
+    const size_t kloop = (size_t)NBUF * (BM + BN) * KB, stage = (size_t)(BM / WM) * (BN / WN) * WM * (WN + 4);
     const size_t lds = (kloop > stage ? kloop : stage) * sizeof(float);
     static bool attr_set = false;
     if (!attr_set) {
-        LM_HIP(hipFuncSetAttribute((const void*)wino_gemm_kernel<BM, BN, WM, WN, KB>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        LM_HIP(hipFuncSetAttribute((const void*)wino_gemm_kernel<BM, BN, WM, WN, KB, NBUF>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         attr_set = true;
     }
     const long blocks = ((p.g.T + BM - 1) / BM) * ((p.Cout + BN - 1) / BN);
     LM_REQUIRE(blocks > 0 && blocks < (1L << 31), "conv_wino: bad grid %ld", blocks);
-    hipLaunchKernelGGL((wino_gemm_kernel<BM, BN, WM, WN, KB>), dim3((unsigned)blocks), dim3((BM / WM) * (BN / WN) * 64), lds, stream, p);
+    hipLaunchKernelGGL((wino_gemm_kernel<BM, BN, WM, WN, KB, NBUF>), dim3((unsigned)blocks), dim3((BM / WM) * (BN / WN) * 64), lds, stream, p);
     LM_LAUNCH_CHECK();
     return LM_OK;
 }
@@ -409,7 +434,8 @@ LM_API int lm_winograd_gemm_f32(void* stream, const void* V, const float* wu, in
     p.zero = zero;
     hipStream_t s = (hipStream_t)stream;
     const int force = wino_force();
-    if (force == 8) return launch_wino<192, 64, 96, 32>(p, s);     // 4 waves of 96x32: three accumulator tiles (chains) per wave
+    if (force == 8) return launch_wino<192, 64, 96, 32>(p, s);
+    if (force == 9) return launch_wino<128, 64, 32, 64, 32, 3>(p, s);   // loads two slabs ahead (72 KB LDS, still 2 workgroups/CU)     // 4 waves of 96x32: three accumulator tiles (chains) per wave
     if (force == 1 && !gn_partial) return launch_wino<128, 128, 64, 64>(p, s);
     if (force == 3 && !gn_partial) return launch_wino<64, 128, 32, 64>(p, s);
     if (force == 4) return launch_wino<256, 64, 32, 64>(p, s);
