@@ -859,3 +859,20 @@ def test_raster_fuzz_vs_c_oracle(dev, seed):
         want = raster_ref.raster(clouds[b], rps[b], H, W)
         assert np.array_equal(u8[b].cpu().numpy(), want), f'tile {b} of seed {seed}'
         assert np.array_equal(out[b].cpu().numpy(), (want.astype(np.float32) / np.float32(255.0)).transpose(2, 0, 1))
+
+
+@pytest.mark.parametrize('workload', ['fused', 'lidar'])
+def test_bench_other_workloads(dev, workload):
+    """`bench.py --workload fused` (BASELINE configs[2]) and `--workload lidar` (configs[4]) run and print a contract line."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, 'bench.py'), '--workload', workload, '--steps', '2', '--warmup', '1',
+                        '--no-cpu-baseline'], capture_output=True, text=True, timeout=900, cwd=root)
+    assert r.returncode == 0, r.stderr[-2000:]
+    d = json.loads([l for l in r.stdout.strip().split('\n') if l.startswith('{')][-1])
+    assert d['value'] > 10 and d['roofline']['achieved'] > 0
+    if workload == 'fused':
+        rr = d['raster_roofline']
+        assert rr['bound'] == 'hbm' and 0.1 < rr['frac'] < 1.0 and rr['traffic'] > rr['achieved'] * rr['ms_per_step'] * 1e6 * 0.9
