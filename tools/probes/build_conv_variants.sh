@@ -4,7 +4,7 @@ set -e
 cd "$(dirname "$0")/../.."
 python -m lanemapping_amd.build > /dev/null 2>&1 || true
 OBJS=""
-for f in errors.cpp conv_direct.hip norm_resize.hip vit.hip head.hip decode.hip raster.hip rowref.hip lidar.hip postproc.cpp backproject.cpp; do OBJS="$OBJS lanemapping_amd/build/$f.o"; done
+for f in errors.cpp conv_wino.hip conv_direct.hip norm_resize.hip vit.hip head.hip decode.hip raster.hip rowref.hip lidar.hip postproc.cpp backproject.cpp; do OBJS="$OBJS lanemapping_amd/build/$f.o"; done
 # usage: build_conv_variants.sh name:"-DFLAG=.. -DFLAG2=.." ...
 for spec in "$@"; do
   v=${spec%%:*}; flags=${spec#*:}
