@@ -127,34 +127,30 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64) void wino_gemm_kernel(W
     const int lrow = tid / LPRW;
     const int lc4 = ((tid % LPRW) ^ swz(lrow)) * 4;
     const long T = p.g.T;
-    long a_off[A_LOADS];
-    int b_off[B_LOADS];
-#pragma unroll
-    for (int i = 0; i < A_LOADS; ++i) {
-        const long m = m0 + lrow + i * RPP;
-        a_off[i] = (m < T && (m % p.g.Tpad) < p.g.Timg) ? m * p.C + lc4 : -1;
-    }
-#pragma unroll
-    for (int i = 0; i < B_LOADS; ++i) b_off[i] = (n0 + lrow + i * RPP) * p.C + lc4;
+    // Address generation: ONE per-lane pointer per operand; everything else (load pass, xi, channel slab) is a wave-uniform
+    // byte offset kept in scalar registers, so a load costs one 64-bit add.  Every row m0 .. m0+BM-1 exists in V (T is a
+    // multiple of BM and the allocation covers the padding rows of each image): padding rows are read as they are (never
+    // written, arbitrary bits) - MFMA rows are independent and the epilogue discards those rows, so no zero substitution.
+    const float* const pa = p.V + ((m0 + lrow) * p.C + lc4);
+    const float* const pb = p.U + ((long)(n0 + lrow) * p.C + lc4);
     const int cslabs = p.C / KB;
     const long xi_stride_a = T * p.C;
     const int xi_stride_b = p.CoutP * p.C;
+    const long pass_stride_a = (long)RPP * p.C, pass_stride_b = (long)RPP * p.C;
     int cur_cs = 0, cur_xi = 0;
     typedef __attribute__((address_space(1))) const void gptr_t;
     typedef __attribute__((address_space(3))) void lptr_t;
     auto gload = [&](int buf) {
         const long adelta = cur_xi * xi_stride_a + cur_cs * KB;
-        const int bdelta = cur_xi * xi_stride_b + cur_cs * KB;
+        const long bdelta = (long)cur_xi * xi_stride_b + cur_cs * KB;
 #pragma unroll
-        for (int i = 0; i < A_LOADS; ++i) {
-            const float* src = a_off[i] >= 0 ? p.V + (a_off[i] + adelta) : p.zero;
-            __builtin_amdgcn_global_load_lds((gptr_t*)src, (lptr_t*)(As + (buf * BM + i * RPP + wave * (64 / LPRW)) * LDS_LD), 16, 0, 0);
-        }
+        for (int i = 0; i < A_LOADS; ++i)
+            __builtin_amdgcn_global_load_lds((gptr_t*)(pa + (adelta + i * pass_stride_a)),
+                                             (lptr_t*)(As + (buf * BM + i * RPP + wave * (64 / LPRW)) * LDS_LD), 16, 0, 0);
 #pragma unroll
-        for (int i = 0; i < B_LOADS; ++i) {
-            const float* src = p.U + (b_off[i] + bdelta);
-            __builtin_amdgcn_global_load_lds((gptr_t*)src, (lptr_t*)(Bs + (buf * BN + i * RPP + wave * (64 / LPRW)) * LDS_LD), 16, 0, 0);
-        }
+        for (int i = 0; i < B_LOADS; ++i)
+            __builtin_amdgcn_global_load_lds((gptr_t*)(pb + (bdelta + i * pass_stride_b)),
+                                             (lptr_t*)(Bs + (buf * BN + i * RPP + wave * (64 / LPRW)) * LDS_LD), 16, 0, 0);
         if (++cur_cs == cslabs) {
             cur_cs = 0;
             ++cur_xi;
@@ -179,6 +175,19 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64) void wino_gemm_kernel(W
     constexpr int LOADS = A_LOADS + B_LOADS;
     static_assert(NBUF == 2 || (NBUF == 3 && LOADS == 6), "the vmcnt immediates below assume 6 loads per slab");
     const int KT = 16 * cslabs;
+#ifdef LM_PRIO
+    // asymmetric wave priority: the two workgroups on a CU otherwise share the MFMA pipe round-robin and drift into lockstep
+    // (both load / barrier / fold at the same time and the pipe idles); with the odd hardware slot always preferred, its
+    // MFMA phases run exclusively and the other workgroup's MFMAs fill exactly its non-MFMA phases
+    if (__builtin_amdgcn_s_getreg(6148) & 1) __builtin_amdgcn_s_setprio(LM_PRIO);
+#endif
+#ifdef LM_STAGGER
+    // The two workgroups resident on a CU start together and stay in lockstep (the MFMA pipe is shared, so whoever is ahead
+    // is slowed down until the other catches up only partially - any initial offset persists, and the initial offset is 0):
+    // both then do their loads / address math / barrier at the same time and the pipe idles.  Delay the wave in the odd
+    // hardware slot by half a slab period so that one workgroup's non-MFMA phase falls into the other's MFMA phase.
+    if (__builtin_amdgcn_s_getreg(6148) & 1) __builtin_amdgcn_s_sleep(LM_STAGGER);   // HW_ID[3:0] = wave slot in the SIMD
+#endif
     gload(0);
     if (NBUF == 3) {
         if (KT > 1) {
@@ -193,7 +202,10 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64) void wino_gemm_kernel(W
     }
     const int frow = lane & 31, fswz = swz(frow), fhalf = lane >> 5;
     int kt = 0;
-    for (int xi = 0; xi < 16; ++xi) {
+#ifndef LM_ABL_XI
+#define LM_ABL_XI 16
+#endif
+    for (int xi = 0; xi < LM_ABL_XI; ++xi) {      // (timing ablations shorten the loop)
         f32x16 acc[TM][TN];
 #pragma unroll
         for (int i = 0; i < TM; ++i)
@@ -203,21 +215,62 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64) void wino_gemm_kernel(W
                 for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
         for (int cs = 0; cs < cslabs; ++cs, ++kt) {
             const int buf = NBUF == 2 ? (kt & 1) : kt % 3;
+#ifdef LM_ABL_NOLOAD
+            if (false) {
+#else
             if (NBUF == 2) {
+#endif
                 if (kt + 1 < KT) gload(buf ^ 1);
             } else if (kt + 2 < KT) {
                 gload((kt + 2) % 3);
             }
             const float* Ab = As + (buf * BM + wm0 + frow) * LDS_LD;
             const float* Bb = Bs + (buf * BN + wn0 + frow) * LDS_LD;
+#ifdef LM_FRAG_PIPE
+            // explicit two-deep fragment pipeline: the ds_reads of k-step q+1 are issued BEFORE the MFMAs of step q (the
+            // compiler's own schedule sinks them to one MFMA before their use, which exposes the LDS latency every 8 MFMAs)
+            f32x4 af[2][TM], bf[2][TN];
+            auto frags = [&](int q) {
+                const int fo = (((2 * q) + fhalf) ^ fswz) * 4;
+#pragma unroll
+                for (int i = 0; i < TM; ++i) af[q & 1][i] = *reinterpret_cast<const f32x4*>(Ab + i * 32 * LDS_LD + fo);
+#pragma unroll
+                for (int j = 0; j < TN; ++j) bf[q & 1][j] = *reinterpret_cast<const f32x4*>(Bb + j * 32 * LDS_LD + fo);
+            };
+            frags(0);
+#pragma unroll
+            for (int q = 0; q < KB / 8; ++q) {
+                if (q + 1 < KB / 8) frags(q + 1);
+#pragma unroll
+                for (int t = 0; t < 4; ++t)
+#pragma unroll
+                    for (int i = 0; i < TM; ++i)
+#pragma unroll
+                        for (int j = 0; j < TN; ++j)
+                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[q & 1][i][t], bf[q & 1][j][t], acc[i][j], 0, 0, 0);
+            }
+            // desired order inside the slab: reads(0) reads(1) | 8 MFMA | reads(2) | 8 MFMA | reads(3) | 8 MFMA | 8 MFMA
+            __builtin_amdgcn_sched_group_barrier(0x100, 2 * (TM + TN), 0);
+#pragma unroll
+            for (int q = 0; q < KB / 8; ++q) {
+                __builtin_amdgcn_sched_group_barrier(0x008, 4 * TM * TN, 0);
+                if (q + 2 < KB / 8) __builtin_amdgcn_sched_group_barrier(0x100, TM + TN, 0);
+            }
+#else
 #pragma unroll
             for (int kk = 0; kk < KB; kk += 8) {
                 const int fo = (((kk >> 2) + fhalf) ^ fswz) * 4;
                 f32x4 af[TM], bf[TN];
 #pragma unroll
+#ifdef LM_ABL_NOLDS
+                for (int i = 0; i < TM; ++i) af[i] = f32x4{(float)kk, 1.f, (float)fo, (float)lane};
+#pragma unroll
+                for (int j = 0; j < TN; ++j) bf[j] = f32x4{1.f, (float)kt, 3.f, (float)lane};
+#else
                 for (int i = 0; i < TM; ++i) af[i] = *reinterpret_cast<const f32x4*>(Ab + i * 32 * LDS_LD + fo);
 #pragma unroll
                 for (int j = 0; j < TN; ++j) bf[j] = *reinterpret_cast<const f32x4*>(Bb + j * 32 * LDS_LD + fo);
+#endif
 #pragma unroll
                 for (int t = 0; t < 4; ++t)
 #pragma unroll
@@ -226,14 +279,18 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64) void wino_gemm_kernel(W
                         for (int j = 0; j < TN; ++j)
                             acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i][t], bf[j][t], acc[i][j], 0, 0, 0);
             }
+#endif
             if (NBUF == 3) {
                 if (kt + 2 < KT) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");     // slab kt+1 has landed, kt+2 may be in flight
                 else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                 __builtin_amdgcn_s_barrier();
             } else {
+#ifndef LM_ABL_NOBAR
                 __syncthreads();
+#endif
             }
         }
+#ifndef LM_ABL_NOFOLD
         // fold M[xi] into the 2x2 outputs: Y[a][b] += AT[a][i] * AT[b][j] * M[i][j],  A^T = [1 1 1 0; 0 1 -1 -1].
         // The coefficients are 0 / +1 / -1, so the multiply-adds below are exact additions (or no-ops).
         const int wi = xi >> 2, wj = xi & 3;
@@ -251,6 +308,14 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64) void wino_gemm_kernel(W
 #pragma unroll
                         for (int r = 0; r < 16; ++r) out[a][b][i][j][r] = fmaf(acc[i][j][r], c, out[a][b][i][j][r]);
             }
+#else
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) out[0][0][i][j][r] += acc[i][j][r];     // ablation: keep the accumulator live, skip the fold
+#endif
     }
 
     // --- epilogue: per output position (a, b) transpose the wave tile through LDS (16-byte coalesced channel vectors)
@@ -359,6 +424,7 @@ int launch_wino(const WinoParams& p, hipStream_t stream) {
     }
     const long blocks = ((p.g.T + BM - 1) / BM) * ((p.Cout + BN - 1) / BN);
     LM_REQUIRE(blocks > 0 && blocks < (1L << 31), "conv_wino: bad grid %ld", blocks);
+    LM_REQUIRE(p.g.T % BM == 0, "conv_wino: %ld rows of V are not a multiple of the %d-row tile", p.g.T, BM);   // loads are unguarded
     hipLaunchKernelGGL((wino_gemm_kernel<BM, BN, WM, WN, KB, NBUF>), dim3((unsigned)blocks), dim3((BM / WM) * (BN / WN) * 64), lds, stream, p);
     LM_LAUNCH_CHECK();
     return LM_OK;
