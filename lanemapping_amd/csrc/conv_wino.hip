@@ -53,7 +53,14 @@ __device__ __forceinline__ bool tile_decode(const WinoGeom& g, long m, int& b, i
 // grid: ceil(T * C/4 / 256)
 __global__ __launch_bounds__(256) void wino_input_kernel(const float* __restrict__ x, int ldx, WinoGeom g, int C, float* __restrict__ V) {
     const int c4n = C / 4;
-    const long e = (long)blockIdx.x * 256 + threadIdx.x;
+    // XCD-aware order: workgroups are dealt round-robin to the 8 XCDs; give every XCD one contiguous run of tiles so that the
+    // 4-fold overlap of neighbouring 4x4 patches is served by ITS L2 (otherwise each input pixel reaches the fabric ~2.6 times)
+    unsigned bid = blockIdx.x;
+    {
+        const unsigned nb = gridDim.x, per = nb / 8, full = per * 8;
+        if (bid < full) bid = (bid % 8) * per + bid / 8;
+    }
+    const long e = (long)bid * 256 + threadIdx.x;
     if (e >= g.T * c4n) return;
     const int c4 = (int)(e % c4n) * 4;
     const long m = e / c4n;
