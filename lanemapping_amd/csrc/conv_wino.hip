@@ -38,8 +38,8 @@ struct WinoGeom {
 
 // row m of V -> tile; false for the padding rows at the end of every image
 __device__ __forceinline__ bool tile_decode(const WinoGeom& g, long m, int& b, int& pa, int& pb, int& ty, int& tx) {
-    b = (int)(m / g.Tpad);
-    int t = (int)(m - (long)b * g.Tpad);
+    b = (int)((unsigned)m / (unsigned)g.Tpad);                  // T < 2^31 (checked at launch): 32-bit divisions only
+    int t = (int)((unsigned)m - (unsigned)b * (unsigned)g.Tpad);
     if (t >= g.Timg) return false;
     tx = t % g.Tx;
     t /= g.Tx;
@@ -118,7 +118,8 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64) void wino_gemm_kernel(W
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* As = smem;
     float* Bs = smem + NBUF * BM * LDS_LD;     // As [NBUF][BM][KB], Bs [NBUF][BN][KB]
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // wave-uniform by construction: keeps the LDS destinations of the loads in SGPRs
     const int wm0 = (wave / WAVES_N) * WM, wn0 = (wave % WAVES_N) * WN;
     const int n_tiles = (p.Cout + BN - 1) / BN;
     unsigned bid = blockIdx.x;
@@ -148,16 +149,24 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64) void wino_gemm_kernel(W
     typedef __attribute__((address_space(1))) const void gptr_t;
     typedef __attribute__((address_space(3))) void lptr_t;
     auto gload = [&](int buf) {
+#ifdef LM_ABL_LOADSAME                                          // timing ablation: every slab re-reads the first one (cache resident)
+        const long adelta = 0, bdelta = 0;
+#else
         const long adelta = cur_xi * xi_stride_a + cur_cs * KB;
         const long bdelta = (long)cur_xi * xi_stride_b + cur_cs * KB;
+#endif
+#ifndef LM_ABL_NOALOAD
 #pragma unroll
         for (int i = 0; i < A_LOADS; ++i)
             __builtin_amdgcn_global_load_lds((gptr_t*)(pa + (adelta + i * pass_stride_a)),
                                              (lptr_t*)(As + (buf * BM + i * RPP + wave * (64 / LPRW)) * LDS_LD), 16, 0, 0);
+#endif
+#ifndef LM_ABL_NOBLOAD
 #pragma unroll
         for (int i = 0; i < B_LOADS; ++i)
             __builtin_amdgcn_global_load_lds((gptr_t*)(pb + (bdelta + i * pass_stride_b)),
                                              (lptr_t*)(Bs + (buf * BN + i * RPP + wave * (64 / LPRW)) * LDS_LD), 16, 0, 0);
+#endif
         if (++cur_cs == cslabs) {
             cur_cs = 0;
             ++cur_xi;
@@ -222,15 +231,13 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64) void wino_gemm_kernel(W
                 for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
         for (int cs = 0; cs < cslabs; ++cs, ++kt) {
             const int buf = NBUF == 2 ? (kt & 1) : kt % 3;
-#ifdef LM_ABL_NOLOAD
-            if (false) {
-#else
+#ifndef LM_ABL_NOLOAD
             if (NBUF == 2) {
-#endif
                 if (kt + 1 < KT) gload(buf ^ 1);
             } else if (kt + 2 < KT) {
                 gload((kt + 2) % 3);
             }
+#endif
             const float* Ab = As + (buf * BM + wm0 + frow) * LDS_LD;
             const float* Bb = Bs + (buf * BN + wn0 + frow) * LDS_LD;
 #ifdef LM_FRAG_PIPE
@@ -308,6 +315,7 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64) void wino_gemm_kernel(W
 #pragma unroll
             for (int b = 0; b < 2; ++b) {
                 const float c = ca[a] * cb[b];
+                if (c == 0.f) continue;                        // (wave-uniform) 28 of the 64 (xi, position) pairs
 #pragma unroll
                 for (int i = 0; i < TM; ++i)
 #pragma unroll
@@ -325,6 +333,23 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64) void wino_gemm_kernel(W
 #endif
     }
 
+#ifdef LM_ABL_NOEPI
+    {   // timing ablation: no output transform / stores, one value per thread keeps the accumulators live
+        float sum = 0.f;
+#pragma unroll
+        for (int a = 0; a < 2; ++a)
+#pragma unroll
+            for (int b = 0; b < 2; ++b)
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int j = 0; j < TN; ++j)
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) sum += out[a][b][i][j][r];
+        p.y[(long)bid * 256 + tid] = sum;
+        return;
+    }
+#endif
     // --- epilogue: per output position (a, b) transpose the wave tile through LDS (16-byte coalesced channel vectors)
     constexpr int ELD = WN + 4;
     float* stage = smem + wave * (WM * ELD);
@@ -343,6 +368,38 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64) void wino_gemm_kernel(W
     }
     const bool vec = (n + 3 < p.Cout) && ((p.ldy & 3) == 0) && (!p.res || (p.ldr & 3) == 0);
     f32x4 gs = {0.f, 0.f, 0.f, 0.f}, gq = {0.f, 0.f, 0.f, 0.f};   // GroupNorm(C,C) statistics of this wave tile (all 4 positions)
+    // Output pixel of every row this lane stores, decoded ONCE (the four positions (a, b) of a tile differ by constant pixel
+    // offsets): one division-based decode for the lane's first row, then carries - the rows of a lane are RPI tiles apart.
+    // (Decoding per position and row cost ~250 VALU instructions x 32 per lane = 6 % of the kernel.)
+    constexpr int NP = WM / RPI;
+    int pix0[NP];
+    unsigned vmask = 0;                                        // 3 bits per row: tile exists | a = 1 inside | b = 1 inside
+    {
+        const int bi = (int)(m0 / p.g.Tpad);                   // a workgroup tile never straddles images (Tpad % BM == 0)
+        int t = (int)(m0 - (long)bi * p.g.Tpad) + wm0 + lane / LPR;
+        int tx = t % p.g.Tx, q = t / p.g.Tx;
+        int ty = q % p.g.Ty, ph = q / p.g.Ty;
+        int pa = ph / p.g.dil, pb = ph % p.g.dil;
+#pragma unroll
+        for (int pass = 0; pass < NP; ++pass) {
+            const int oy = 2 * ty * p.g.dil + pa, ox = 2 * tx * p.g.dil + pb;
+            pix0[pass] = (bi * p.g.H + oy) * p.g.W + ox;
+            if (t < p.g.Timg && oy < p.g.H && ox < p.g.W)
+                vmask |= (1u | (oy + p.g.dil < p.g.H ? 2u : 0u) | (ox + p.g.dil < p.g.W ? 4u : 0u)) << (3 * pass);
+            t += RPI;
+            tx += RPI;
+            while (tx >= p.g.Tx) {
+                tx -= p.g.Tx;
+                if (++ty >= p.g.Ty) {
+                    ty = 0;
+                    ++ph;
+                    pa = ph / p.g.dil;
+                    pb = ph % p.g.dil;
+                }
+            }
+        }
+    }
+    const int step_a = p.g.dil * p.g.W, step_b = p.g.dil;
 #pragma unroll
     for (int a = 0; a < 2; ++a)
 #pragma unroll
@@ -360,13 +417,9 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64) void wino_gemm_kernel(W
 #pragma unroll
             for (int pass = 0; pass < WM / RPI; ++pass) {
                 const int row = pass * RPI + lane / LPR;
-                const long m = m0 + wm0 + row;
-                if (m >= T) continue;
-                int bi, pa, pb, ty, tx;
-                if (!tile_decode(p.g, m, bi, pa, pb, ty, tx)) continue;
-                const int oy = (2 * ty + a) * p.g.dil + pa, ox = (2 * tx + b) * p.g.dil + pb;
-                if (oy >= p.g.H || ox >= p.g.W) continue;
-                const long pix = ((long)bi * p.g.H + oy) * p.g.W + ox;
+                const unsigned vm = vmask >> (3 * pass);
+                if (!(vm & 1u) || (a && !(vm & 2u)) || (b && !(vm & 4u))) continue;
+                const long pix = pix0[pass] + a * step_a + b * step_b;
                 f32x4 v = *reinterpret_cast<const f32x4*>(stage + row * ELD + c4);
 #pragma unroll
                 for (int e = 0; e < 4; ++e) v[e] = p.scale ? v[e] * sc[e] + sh[e] : v[e] + sh[e];
@@ -432,6 +485,8 @@ int launch_wino(const WinoParams& p, hipStream_t stream) {
     const long blocks = ((p.g.T + BM - 1) / BM) * ((p.Cout + BN - 1) / BN);
     LM_REQUIRE(blocks > 0 && blocks < (1L << 31), "conv_wino: bad grid %ld", blocks);
     LM_REQUIRE(p.g.T % BM == 0, "conv_wino: %ld rows of V are not a multiple of the %d-row tile", p.g.T, BM);   // loads are unguarded
+    LM_REQUIRE(p.g.Tpad % BM == 0, "conv_wino: %d tiles per image are not a multiple of the %d-row tile", p.g.Tpad, BM);   // epilogue decode
+    LM_REQUIRE((long)p.g.B * p.g.H * p.g.W < (1L << 31) && p.g.T < (1L << 31), "conv_wino: output too large for 32-bit pixel indices");
     hipLaunchKernelGGL((wino_gemm_kernel<BM, BN, WM, WN, KB, NBUF>), dim3((unsigned)blocks), dim3((BM / WM) * (BN / WN) * 64), lds, stream, p);
     LM_LAUNCH_CHECK();
     return LM_OK;
@@ -473,6 +528,7 @@ LM_API int lm_winograd_input_transform_f32(void* stream, const float* x, int ldx
     LM_REQUIRE(ldx >= Cin && ldx % 4 == 0, "wino_input: bad leading dim ldx=%d", ldx);
     LM_REQUIRE(lm_conv3x3_winograd_workspace_bytes(B, H, W, Cin, dil) <= V_bytes, "wino_input: V buffer too small");
     const WinoGeom g = geom(B, H, W, dil);
+    LM_REQUIRE(g.T < (1L << 31), "wino_input: too many tiles");
     const long in_threads = g.T * (Cin / 4);
     hipLaunchKernelGGL(wino_input_kernel, dim3((unsigned)((in_threads + 255) / 256)), dim3(256), 0, (hipStream_t)stream, x, ldx, g, Cin,
                        (float*)V);
@@ -507,9 +563,9 @@ LM_API int lm_winograd_gemm_f32(void* stream, const void* V, const float* wu, in
     p.zero = zero;
     hipStream_t s = (hipStream_t)stream;
     const int force = wino_force();
-    if (force == 8) return launch_wino<192, 64, 96, 32>(p, s);
-    if (force == 9) return launch_wino<128, 64, 32, 64, 32, 3>(p, s);
-    if (force == 10) return launch_wino<64, 64, 32, 32>(p, s);     // 4 waves of 32x32: ~120 registers, 4 workgroups/CU   // loads two slabs ahead (72 KB LDS, still 2 workgroups/CU)     // 4 waves of 96x32: three accumulator tiles (chains) per wave
+    if (force == 8) return launch_wino<192, 64, 96, 32>(p, s);         // 4 waves of 96x32: three accumulator tiles (chains) per wave
+    if (force == 9) return launch_wino<128, 64, 32, 64, 32, 3>(p, s);   // loads two slabs ahead (72 KB LDS, still 2 workgroups/CU)
+    if (force == 10) return launch_wino<64, 64, 32, 32>(p, s);     // 4 waves of 32x32: ~120 registers, 4 workgroups/CU
     if (force == 1 && !gn_partial) return launch_wino<128, 128, 64, 64>(p, s);
     if (force == 3 && !gn_partial) return launch_wino<64, 128, 32, 64>(p, s);
     if (force == 4) return launch_wino<256, 64, 32, 64>(p, s);
