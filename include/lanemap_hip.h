@@ -82,6 +82,10 @@ int lm_gn_stats(void* stream, const float* x, double* workspace, float* stats, i
 long lm_gn_stats_workspace_bytes(int B, int HW, int C);
 int lm_gn_relu_upsample(void* stream, const float* x, const float* stats, const float* gamma, const float* beta,
                         float* y, int B, int Hi, int Wi, int Ho, int Wo, int C, int accumulate);
+/* y = ((t0 + t1) + t2), t_k = bilinear_align_corners(relu(gn(x[k]; stats[k], gamma, beta))) from Hi[k] x Wi[k] to Ho x Wo, n <= 3
+ * terms sharing gamma / beta: `s2 + s3 + s4` of one semantic branch (postprojector.py:615-621, :641-647) in one pass. */
+int lm_gn_relu_upsample_sum(void* stream, int n, const float* const* x, const float* const* stats, const int* Hi, const int* Wi,
+                            const float* gamma, const float* beta, float* y, int B, int Ho, int Wo, int C);
 int lm_upsample_bilinear_nhwc(void* stream, const float* x, int ldx, const float* add, int lda, float* y, int ldy,
                               int B, int Hi, int Wi, int Ho, int Wo, int C);
 int lm_upsample_bilinear_to_chw(void* stream, const float* x, int ldx, float* y_chw, int B, int Hi, int Wi,

@@ -4,6 +4,7 @@
 //                               (postprojector.py:512-515), deterministic two-level fp64 reduction
 //  lm_gn_relu_upsample        : y (=|+=) bilinear_align_corners(relu(gn(x)))  -> fuses the
 //                               `_upsample(F.relu(gn(conv(..))))` and `s2+s3+s4` steps (postprojector.py:615-651)
+//  lm_gn_relu_upsample_sum    : y = ((t0 + t1) + t2) of up to three such terms in one pass (the `s2 + s3 + s4` sum)
 //  lm_upsample_bilinear_nhwc  : F.interpolate(mode='bilinear', align_corners=True) (+ optional add)
 //                               (postprojector.py:541-561; heads/polyline_fpn_vit_vertex_2.py:298-300)
 //  lm_upsample_bilinear_to_chw: same, NHWC source -> planar [B,C,Ho,Wo] destination (bi_seg / endp maps)
@@ -133,6 +134,74 @@ __global__ __launch_bounds__(256) void gn_relu_upsample_kernel(const float* __re
         for (int e = 0; e < 4; ++e) o[e] = prev[e] + o[e];
     }
     *yp = o;
+}
+
+// ----------------------------------------------------------------------------- sum of up to 3 GN + ReLU + bilinear terms
+// y = ((t0 + t1) + t2), t_k = bilinear(relu(gn_k(x_k))): the reference's `s2 + s3 + s4` (postprojector.py:621,647) in one pass
+// instead of one write and two read-modify-writes of y.  Same per-term arithmetic and summation order as three calls of the
+// kernel above.  32-bit index math (the launch checks the sizes).
+struct GnTerm {
+    const float* x;
+    const float* stats;
+    int Hi, Wi;
+};
+struct GnSum {
+    GnTerm t[3];
+    int n;
+};
+
+__global__ __launch_bounds__(256) void gn_relu_upsample_sum_kernel(GnSum P, const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                                   float* __restrict__ y, int Ho, int Wo, int C, unsigned total4) {
+    const unsigned i = blockIdx.x * 256u + threadIdx.x;
+    if (i >= total4) return;
+    const unsigned c4n = (unsigned)C / 4;
+    const int c = (int)(i % c4n) * 4;
+    unsigned t = i / c4n;
+    const int ox = (int)(t % (unsigned)Wo);
+    t /= (unsigned)Wo;
+    const int oy = (int)(t % (unsigned)Ho);
+    const int b = (int)(t / (unsigned)Ho);
+    f32x4 gm, bt;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        gm[e] = gamma[c + e];
+        bt[e] = beta[c + e];
+    }
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        if (k >= P.n) break;
+        const GnTerm& T = P.t[k];
+        int y0, y1, x0, x1;
+        float wy0, wy1, wx0, wx1;
+        bilin_axis(oy, T.Hi, Ho, y0, y1, wy0, wy1);
+        bilin_axis(ox, T.Wi, Wo, x0, x1, wx0, wx1);
+        f32x4 a, g;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const float mean = T.stats[((long)b * C + c + e) * 2], rstd = T.stats[((long)b * C + c + e) * 2 + 1];
+            a[e] = rstd * gm[e];
+            g[e] = bt[e] - mean * a[e];
+        }
+        const float* xb = T.x + (long)b * T.Hi * T.Wi * C + c;
+        auto tap = [&](int yy, int xx) {
+            f32x4 v = *reinterpret_cast<const f32x4*>(xb + ((long)yy * T.Wi + xx) * C);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e] * a[e] + g[e], 0.f);
+            return v;
+        };
+        const f32x4 v00 = tap(y0, x0), v01 = tap(y0, x1), v10 = tap(y1, x0), v11 = tap(y1, x1);
+        f32x4 o;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) o[e] = wy0 * (wx0 * v00[e] + wx1 * v01[e]) + wy1 * (wx0 * v10[e] + wx1 * v11[e]);
+        if (k == 0) {
+            acc = o;
+        } else {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) acc[e] = acc[e] + o[e];
+        }
+    }
+    *reinterpret_cast<f32x4*>(y + (long)i * 4) = acc;
 }
 
 // ----------------------------------------------------------------------------- plain bilinear, NHWC -> NHWC slice
@@ -270,6 +339,24 @@ LM_API int lm_gn_relu_upsample(void* stream, const float* x, const float* stats,
     const long total4 = (long)B * Ho * Wo * (C / 4);
     hipLaunchKernelGGL(gn_relu_upsample_kernel, dim3(lm_cdiv(total4, 256)), dim3(256), 0, (hipStream_t)stream,
                        x, stats, gamma, beta, y, Hi, Wi, Ho, Wo, C, accumulate, total4);
+    LM_LAUNCH_CHECK();
+    return LM_OK;
+}
+
+LM_API int lm_gn_relu_upsample_sum(void* stream, int n, const float* const* x, const float* const* stats, const int* Hi, const int* Wi,
+                                   const float* gamma, const float* beta, float* y, int B, int Ho, int Wo, int C) {
+    LM_REQUIRE(n >= 1 && n <= 3 && x && stats && Hi && Wi && gamma && beta && y && C % 4 == 0, "gn_relu_upsample_sum: bad args");
+    const long total4 = (long)B * Ho * Wo * (C / 4);
+    LM_REQUIRE(total4 > 0 && total4 < (1L << 31), "gn_relu_upsample_sum: %ld output quads do not fit 32-bit indices", total4);
+    GnSum P;
+    P.n = n;
+    for (int k = 0; k < 3; ++k) {
+        const int q = k < n ? k : 0;
+        LM_REQUIRE(x[q] && stats[q] && Hi[q] > 0 && Wi[q] > 0, "gn_relu_upsample_sum: bad term %d", q);
+        P.t[k] = GnTerm{x[q], stats[q], Hi[q], Wi[q]};
+    }
+    hipLaunchKernelGGL(gn_relu_upsample_sum_kernel, dim3((unsigned)lm_cdiv(total4, 256)), dim3(256), 0, (hipStream_t)stream, P, gamma, beta,
+                       y, Ho, Wo, C, (unsigned)total4);
     LM_LAUNCH_CHECK();
     return LM_OK;
 }

@@ -286,6 +286,23 @@ def gn_relu_upsample(x, stats, gamma, beta, size, out=None, accumulate=False):
     return out
 
 
+def gn_relu_upsample_sum(terms, gamma, beta, size, out=None):
+    """((t0 + t1) + t2) with t_k = bilinear(relu(gn(x_k))) for terms = [(x_k, stats_k), ...] (at most 3) in one pass."""
+    n = len(terms)
+    xs = [as_nhwc(x) for x, _ in terms]
+    B, C_ = xs[0][0].shape[:2]
+    for (x, ld) in xs:
+        assert ld == C_ and x.shape[0] == B and x.shape[1] == C_
+    Ho, Wo = size
+    if out is None:
+        out = new_act(B, C_, Ho, Wo, xs[0][0].device)
+    vp_arr, i_arr = C.c_void_p * n, C.c_int * n
+    check(lib().lm_gn_relu_upsample_sum(_stream(), n, vp_arr(*[_ptr(x) for x, _ in xs]), vp_arr(*[_ptr(st) for _, st in terms]),
+                                        i_arr(*[x.shape[2] for x, _ in xs]), i_arr(*[x.shape[3] for x, _ in xs]),
+                                        _ptr(gamma), _ptr(beta), _ptr(out), B, Ho, Wo, C_))
+    return out
+
+
 def upsample_nhwc(x, size, add=None, out=None):
     x, ldx = as_nhwc(x)
     B, C_, H, W = x.shape

@@ -174,8 +174,8 @@ class FPNEncoder(PackedModule):
         h, w = p2.shape[2:]
         c_half = self.semantic_branch.out_channels
 
-        def conv_gn_up(src, conv, cout, gn, out=None, acc=False, share=None):
-            # conv3x3 + bias with the GroupNorm statistics coming out of the conv epilogue, then GN + ReLU + bilinear (+=)
+        def conv_stats(src, conv, cout, gn, share=None):
+            # conv3x3 + bias with the GroupNorm statistics coming out of the conv epilogue
             eps = getattr(self, gn).eps
             if (conv + '.wu') in P:                             # Winograd; p2/p3/p4 are transformed once for both branches
                 if share is not None:
@@ -188,13 +188,15 @@ class FPNEncoder(PackedModule):
             else:                                              # ragged image size: separate statistics kernel
                 t = self._conv3(src, P, conv, cout)
                 st = ops.gn_stats(t, eps)
-            return ops.gn_relu_upsample(t, st, P[gn + '.g'], P[gn + '.b'], (h, w), out=out, accumulate=acc)
+            return t, st
 
-        s4 = conv_gn_up(p4, conv_a, p4.shape[1], gn_a, share='p4')                       # 256 ch at 288^2
-        total = conv_gn_up(p2, conv_b, c_half, gn_b, share='p2')                        # s2
-        total = conv_gn_up(p3, conv_b, c_half, gn_b, out=total, acc=True, share='p3')   # + s3
-        total = conv_gn_up(s4, conv_b, c_half, gn_b, out=total, acc=True)               # + s4
-        return total
+        t, st = conv_stats(p4, conv_a, p4.shape[1], gn_a, share='p4')
+        s4 = ops.gn_relu_upsample(t, st, P[gn_a + '.g'], P[gn_a + '.b'], (h, w))        # 256 ch at 288^2
+        terms = [conv_stats(p2, conv_b, c_half, gn_b, share='p2'),                      # s2
+                 conv_stats(p3, conv_b, c_half, gn_b, share='p3'),                      # s3
+                 conv_stats(s4, conv_b, c_half, gn_b)]                                  # s4
+        # (s2 + s3) + s4, each term GN + ReLU + bilinear to p2's size, in one pass over the output
+        return ops.gn_relu_upsample_sum(terms, P[gn_b + '.g'], P[gn_b + '.b'], (h, w))
 
     def forward(self, x, fea_up_out=None):
         P = self.packed()

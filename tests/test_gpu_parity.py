@@ -131,6 +131,28 @@ def test_gn_relu_upsample(dev):
     _close(up, F.interpolate(x[:, :3], size=(80, 112), mode='bilinear', align_corners=True), 1e-5, 'to_chw')
 
 
+def test_gn_relu_upsample_sum(dev):
+    """`s2 + s3 + s4` of a semantic branch in one pass: equals the torch expression and, bit for bit, three accumulating calls."""
+    from lanemapping_amd import ops
+    g = torch.Generator().manual_seed(12)
+    shapes = [(40, 56), (20, 28), (40, 56)]
+    xs = [torch.randn(2, 64, h, w, generator=g) * (k + 1) + 0.5 * k for k, (h, w) in enumerate(shapes)]
+    gamma, beta = torch.rand(64, generator=g) + 0.5, torch.randn(64, generator=g)
+    ref = sum(F.interpolate(F.relu(F.group_norm(x, 64, gamma, beta, 1e-5)), size=(40, 56), mode='bilinear', align_corners=True) for x in xs)
+    xd = [x.to(dev) for x in xs]
+    terms = [(x, ops.gn_stats(x)) for x in xd]
+    gd, bd = gamma.to(dev), beta.to(dev)
+    y = ops.gn_relu_upsample_sum(terms, gd, bd, (40, 56))
+    _close(y, ref, 1e-5, 'sum of 3 terms')
+    z = ops.gn_relu_upsample(terms[0][0], terms[0][1], gd, bd, (40, 56))
+    for x, st in terms[1:]:
+        z = ops.gn_relu_upsample(x, st, gd, bd, (40, 56), out=z, accumulate=True)
+    assert torch.equal(y, z), float((y - z).abs().max())
+    y2 = ops.gn_relu_upsample_sum(terms[:2], gd, bd, (40, 56))
+    _close(y2, ref - F.interpolate(F.relu(F.group_norm(xs[2], 64, gamma, beta, 1e-5)), size=(40, 56), mode='bilinear', align_corners=True),
+           1e-5, 'sum of 2 terms')
+
+
 # ----------------------------------------------------------------------------------------------- goldens
 def test_fpn_golden_g2(dev, net, golden):
     g = golden('g2_fpn.npz')
