@@ -191,19 +191,6 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64) void wino_gemm_kernel(W
     constexpr int LOADS = A_LOADS + B_LOADS;
     static_assert(NBUF == 2 || (NBUF == 3 && LOADS == 6), "the vmcnt immediates below assume 6 loads per slab");
     const int KT = 16 * cslabs;
-#ifdef LM_PRIO
-    // asymmetric wave priority: the two workgroups on a CU otherwise share the MFMA pipe round-robin and drift into lockstep
-    // (both load / barrier / fold at the same time and the pipe idles); with the odd hardware slot always preferred, its
-    // MFMA phases run exclusively and the other workgroup's MFMAs fill exactly its non-MFMA phases
-    if (__builtin_amdgcn_s_getreg(6148) & 1) __builtin_amdgcn_s_setprio(LM_PRIO);
-#endif
-#ifdef LM_STAGGER
-    // The two workgroups resident on a CU start together and stay in lockstep (the MFMA pipe is shared, so whoever is ahead
-    // is slowed down until the other catches up only partially - any initial offset persists, and the initial offset is 0):
-    // both then do their loads / address math / barrier at the same time and the pipe idles.  Delay the wave in the odd
-    // hardware slot by half a slab period so that one workgroup's non-MFMA phase falls into the other's MFMA phase.
-    if (__builtin_amdgcn_s_getreg(6148) & 1) __builtin_amdgcn_s_sleep(LM_STAGGER);   // HW_ID[3:0] = wave slot in the SIMD
-#endif
     gload(0);
     if (NBUF == 3) {
         if (KT > 1) {
@@ -240,37 +227,6 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64) void wino_gemm_kernel(W
 #endif
             const float* Ab = As + (buf * BM + wm0 + frow) * LDS_LD;
             const float* Bb = Bs + (buf * BN + wn0 + frow) * LDS_LD;
-#ifdef LM_FRAG_PIPE
-            // explicit two-deep fragment pipeline: the ds_reads of k-step q+1 are issued BEFORE the MFMAs of step q (the
-            // compiler's own schedule sinks them to one MFMA before their use, which exposes the LDS latency every 8 MFMAs)
-            f32x4 af[2][TM], bf[2][TN];
-            auto frags = [&](int q) {
-                const int fo = (((2 * q) + fhalf) ^ fswz) * 4;
-#pragma unroll
-                for (int i = 0; i < TM; ++i) af[q & 1][i] = *reinterpret_cast<const f32x4*>(Ab + i * 32 * LDS_LD + fo);
-#pragma unroll
-                for (int j = 0; j < TN; ++j) bf[q & 1][j] = *reinterpret_cast<const f32x4*>(Bb + j * 32 * LDS_LD + fo);
-            };
-            frags(0);
-#pragma unroll
-            for (int q = 0; q < KB / 8; ++q) {
-                if (q + 1 < KB / 8) frags(q + 1);
-#pragma unroll
-                for (int t = 0; t < 4; ++t)
-#pragma unroll
-                    for (int i = 0; i < TM; ++i)
-#pragma unroll
-                        for (int j = 0; j < TN; ++j)
-                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[q & 1][i][t], bf[q & 1][j][t], acc[i][j], 0, 0, 0);
-            }
-            // desired order inside the slab: reads(0) reads(1) | 8 MFMA | reads(2) | 8 MFMA | reads(3) | 8 MFMA | 8 MFMA
-            __builtin_amdgcn_sched_group_barrier(0x100, 2 * (TM + TN), 0);
-#pragma unroll
-            for (int q = 0; q < KB / 8; ++q) {
-                __builtin_amdgcn_sched_group_barrier(0x008, 4 * TM * TN, 0);
-                if (q + 2 < KB / 8) __builtin_amdgcn_sched_group_barrier(0x100, TM + TN, 0);
-            }
-#else
 #pragma unroll
             for (int kk = 0; kk < KB; kk += 8) {
                 const int fo = (((kk >> 2) + fhalf) ^ fswz) * 4;
@@ -293,7 +249,6 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64) void wino_gemm_kernel(W
                         for (int j = 0; j < TN; ++j)
                             acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i][t], bf[j][t], acc[i][j], 0, 0, 0);
             }
-#endif
             if (NBUF == 3) {
                 if (kt + 2 < KT) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");     // slab kt+1 has landed, kt+2 may be in flight
                 else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
