@@ -211,6 +211,15 @@ int lm_las_decode_points(void* stream, const unsigned char* records, int record_
                          const double* offset, const double* shift, float inten_lo, float inten_hi, int normalise,
                          float* out_xyzi);
 
+/* ---- PNG tile ingest (replaces PIL in `load_img`, baseline/datasets/laserlane_proposals.py:85-98 and laserlane.py:214-219:
+ * np.array(Image.open(path)) -> uint8 HWC).  Host code (zlib), 8-bit non-interlaced grey / grey+alpha / RGB / RGBA only; palette,
+ * 16-bit and Adam7 files are refused; chunk CRCs and the zlib checksum are verified.  C = channels (1, 2, 3, 4).
+ * lm_png_decode_files_u8 inflates n files of identical geometry on `threads` host threads into out [n][H][W][C], the layout
+ * lm_tile_ingest_u8 takes. */
+int lm_png_info(const unsigned char* data, long size, int* H, int* W, int* C);
+int lm_png_decode_u8(const unsigned char* data, long size, unsigned char* out_hwc, long out_bytes);
+int lm_png_decode_files_u8(const char* const* paths, int n, unsigned char* out_nhwc, int H, int W, int C, int threads);
+
 #ifdef __cplusplus
 }
 #endif

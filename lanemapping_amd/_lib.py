@@ -86,6 +86,9 @@ SIGNATURES = {
     'lm_las_parse_header': (i32, [vp, i64, C.POINTER(LmLasHeader)]),
     'lm_las_decode_points': (i32, [vp, vp, i32, i64, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_double), f32, f32,
                                    i32, vp]),
+    'lm_png_info': (i32, [vp, i64, C.POINTER(i32), C.POINTER(i32), C.POINTER(i32)]),
+    'lm_png_decode_u8': (i32, [vp, i64, vp, i64]),
+    'lm_png_decode_files_u8': (i32, [C.POINTER(C.c_char_p), i32, vp, i32, i32, i32, i32]),
 }
 
 _lib = None

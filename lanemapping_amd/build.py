@@ -7,7 +7,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, 'csrc')
 LIB = os.path.join(HERE, 'liblanemap_hip.so')
 SOURCES = ['errors.cpp', 'conv_mfma.hip', 'conv_wino.hip', 'conv_direct.hip', 'norm_resize.hip', 'vit.hip', 'head.hip',
-           'decode.hip', 'raster.hip', 'rowref.hip', 'lidar.hip', 'postproc.cpp', 'backproject.cpp']
+           'decode.hip', 'raster.hip', 'rowref.hip', 'lidar.hip', 'postproc.cpp', 'backproject.cpp', 'png_reader.cpp']
 
 
 # integer-output kernels whose fp32 index math must match the C oracle bit for bit
@@ -44,7 +44,7 @@ def build(force=False, verbose=True):
             raise RuntimeError(f'hipcc failed on {src}')
         if verbose and out.strip():
             sys.stderr.write(out.decode())
-    cmd = [hipcc, '--offload-arch=gfx950', '-shared', '-fPIC', '-o', LIB] + objs
+    cmd = [hipcc, '--offload-arch=gfx950', '-shared', '-fPIC', '-o', LIB] + objs + ['-lz']   # zlib: PNG tile reader
     subprocess.check_call(cmd)
     if verbose:
         print(f'built {LIB}')

@@ -41,12 +41,12 @@ def transform_coordinate_from_img_2_pc(params, img_seqs, img_seq_lens, bev_img):
 def transform_coordinate_from_img_2_pc_single(img_seqfile_path, bev_img_path, pc_img_params_path, pc_seqfile_path,
                                               pc_seqfile_txt_path):
     """One tile: 2-D polyline JSON + BEV PNG + parameter file -> 3-D polyline JSON / TXT (reference :185-220)."""
-    from PIL import Image
+    from .png_io import read_png
     img_seqs, img_seq_lens, _, _ = load_lane_seq(img_seqfile_path)
     if len(img_seqs) < 1:
         return
     params = load_pc_2_img_transform_paras(pc_img_params_path)
-    pc_seqs = transform_coordinate_from_img_2_pc(params, img_seqs, img_seq_lens, Image.open(bev_img_path))
+    pc_seqs = transform_coordinate_from_img_2_pc(params, img_seqs, img_seq_lens, read_png(bev_img_path))
     lines = []
     for i in range(pc_seqs.shape[0]):
         sub = pc_seqs[i, :img_seq_lens[i], :]

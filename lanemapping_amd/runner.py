@@ -7,7 +7,7 @@
   Runner.infer_lane_geometry_segmentation_segmentor()<- :945-1036 minus overlays (Segmentor config)
   Runner.infer_las_to_map()                          <- the offline chain LAS -> BEV -> polylines -> LAS frame -> merged map
                                                         (read_las, Las2BEV, Runner, coor_img2pc.py, merge_lines.py) in one call
-Tiles are PNG files (load_img contract, datasets/laserlane_proposals.py:85-98): decoded on the host with PIL,
+Tiles are PNG files (load_img contract, datasets/laserlane_proposals.py:85-98): decoded on the host by the library's own PNG reader (png_io, zlib on the host thread pool),
 converted u8 -> f32/255 on the GPU (lm_tile_ingest_u8).  With torch.distributed initialised, tiles are sharded
 over the ranks (lanemapping_amd/shard.py) and rank 0 writes every file after one all-gather per batch.
 """
@@ -50,10 +50,15 @@ class Runner:
         return sorted(glob.glob(os.path.join(source, '*.png')))
 
     def _load_batch(self, paths):
-        from PIL import Image
-        arrs = [np.asarray(Image.open(p), dtype=np.uint8) for p in paths]
-        arrs = [a[:, :, None].repeat(3, 2) if a.ndim == 2 else a for a in arrs]
-        u8 = torch.from_numpy(np.stack(arrs)).to(self.device, non_blocking=True)
+        # native PNG reader of the C-ABI library: the whole batch is inflated on host threads into one pinned [n,H,W,C] buffer
+        from .png_io import read_png_batch, png_info
+        with open(paths[0], 'rb') as f:
+            h, w, c = png_info(f.read(64))
+        pinned = torch.empty((len(paths), h, w, c), dtype=torch.uint8, pin_memory=self.device.type == 'cuda')
+        read_png_batch(paths, threads=int(self.cfg.get('host_threads', 8)), out=pinned.numpy())
+        u8 = pinned.to(self.device, non_blocking=True)
+        if c < 3:                                              # greyscale tiles: replicate into the 3 input channels
+            u8 = u8[..., :1].expand(-1, -1, -1, 3).contiguous()
         return ops.tile_ingest(u8)
 
     # ------------------------------------------------------------------------------------------------ inference

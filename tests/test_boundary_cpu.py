@@ -382,6 +382,108 @@ def test_las_header_parse(tmp_path):
 
 
 # ----------------------------------------------------------------------------------------------- f2: cross-tile merge
+@pytest.mark.parametrize('mode,shape', [('RGB', (97, 131, 3)), ('RGBA', (64, 50, 4)), ('L', (33, 77)), ('LA', (40, 41, 2)),
+                                        ('RGB', (1, 1, 3)), ('RGB', (3, 1152, 3))])
+def test_png_reader_matches_pil(mode, shape):
+    """png_io (csrc/png_reader.cpp, host code) == np.array(Image.open()) of the reference's load_img, for every scanline filter."""
+    import io
+    from PIL import Image
+    from lanemapping_amd import png_io
+    rng = np.random.default_rng(5)
+    noise = rng.integers(0, 256, shape, dtype=np.uint8)
+    ramp = (np.add.outer(np.arange(shape[0]) * 3, np.arange(shape[1]) * 2) % 251).astype(np.uint8)
+    smooth = noise.copy()
+    if smooth.ndim == 3:
+        smooth[..., 0] = ramp
+        smooth[..., 1] = ramp // 2
+    else:
+        smooth = ramp
+    seen = set()
+    for arr in (noise, smooth, np.zeros(shape, np.uint8)):
+        for level in (1, 6, 9):
+            buf = io.BytesIO()
+            Image.fromarray(arr, mode).save(buf, 'PNG', compress_level=level)
+            data = buf.getvalue()
+            ref = np.array(Image.open(io.BytesIO(data)))
+            got = png_io.decode_png(data)
+            assert got.dtype == np.uint8 and got.shape == ref.shape and np.array_equal(got, ref)
+            assert png_io.png_info(data) == (shape[0], shape[1], 1 if len(shape) == 2 else shape[2])
+            import struct
+            import zlib
+            pos, z = 8, b''
+            while pos < len(data):
+                n, t = struct.unpack('>I', data[pos:pos + 4])[0], data[pos + 4:pos + 8]
+                z += data[pos + 8:pos + 8 + n] if t == b'IDAT' else b''
+                pos += 12 + n
+            raw = zlib.decompress(z)
+            st = shape[1] * (1 if len(shape) == 2 else shape[2]) + 1
+            seen |= {raw[i * st] for i in range(shape[0])}
+    if shape[0] > 30:
+        assert {1, 2, 4} <= seen or {0, 1, 2} <= seen, seen        # the encoder really exercised several filter types
+
+
+def test_png_reader_hand_filtered_rows_and_errors(tmp_path):
+    """Every filter type incl. Average (which PIL's encoder rarely picks), multi-IDAT streams, and the refusals."""
+    import struct
+    import zlib
+    from lanemapping_amd import png_io
+    from lanemapping_amd._lib import LanemapHipError
+    rng = np.random.default_rng(6)
+    H, W, Cn = 10, 23, 3
+    img = rng.integers(0, 256, (H, W, Cn), dtype=np.uint8)
+    stride = W * Cn
+
+    def paeth(a, b, c):
+        p = a + b - c
+        pa, pb, pc = abs(p - a), abs(p - b), abs(p - c)
+        return a if (pa <= pb and pa <= pc) else (b if pb <= pc else c)
+
+    raw = bytearray()
+    for y in range(H):
+        ft = y % 5
+        cur = img[y].reshape(-1).astype(int)
+        up = img[y - 1].reshape(-1).astype(int) if y else np.zeros(stride, int)
+        raw.append(ft)
+        for i in range(stride):
+            a = cur[i - Cn] if i >= Cn else 0
+            b, c = up[i], (up[i - Cn] if i >= Cn else 0)
+            pred = [0, a, b, (a + b) >> 1, paeth(a, b, c)][ft]
+            raw.append((cur[i] - pred) & 255)
+
+    def chunk(t, d):
+        return struct.pack('>I', len(d)) + t + d + struct.pack('>I', zlib.crc32(t + d) & 0xffffffff)
+
+    def png(depth=8, color=2, interlace=0, idat_split=3, z=None, w=W, h=H):
+        z = zlib.compress(bytes(raw)) if z is None else z
+        k = max(1, len(z) // idat_split)
+        idats = b''.join(chunk(b'IDAT', z[i:i + k]) for i in range(0, len(z), k))
+        return (b'\x89PNG\r\n\x1a\n' + chunk(b'IHDR', struct.pack('>IIBBBBB', w, h, depth, color, 0, 0, interlace)) + chunk(b'tEXt', b'k\0v')
+                + idats + chunk(b'IEND', b''))
+
+    good = png()
+    assert np.array_equal(png_io.decode_png(good), img)
+    assert np.array_equal(png_io.decode_png(png(idat_split=1)), img)
+    (tmp_path / 'a.png').write_bytes(good)
+    (tmp_path / 'b.png').write_bytes(png(idat_split=7))
+    batch = png_io.read_png_batch([tmp_path / 'a.png', tmp_path / 'b.png'], threads=2)
+    assert batch.shape == (2, H, W, Cn) and np.array_equal(batch[0], img) and np.array_equal(batch[1], img)
+    assert np.array_equal(png_io.read_png(tmp_path / 'a.png'), img)
+
+    bad_crc = bytearray(good)
+    bad_crc[60] ^= 1
+    cases = {'signature': b'JUNK' + good[4:], 'CRC': bytes(bad_crc), '8-bit': png(depth=16), 'palette': png(color=3),
+             'interlaced': png(interlace=1), 'truncated': good[:len(good) - 20], 'shorter': png(h=H + 1),
+             'larger': png(h=H - 1), 'corrupt': png(z=zlib.compress(bytes(raw))[:-6] + b'\0\0\0\0\0\0')}
+    for word, data in cases.items():
+        with pytest.raises(LanemapHipError, match=word):
+            png_io.decode_png(data)
+    (tmp_path / 'c.png').write_bytes(png(w=W + 1, z=zlib.compress(bytes(H * ((W + 1) * Cn + 1)))))
+    with pytest.raises(LanemapHipError, match='c.png.*geometry'):
+        png_io.read_png_batch([tmp_path / 'a.png', tmp_path / 'c.png'], threads=2)
+    with pytest.raises(LanemapHipError, match='cannot open'):
+        png_io.read_png_batch([tmp_path / 'a.png', tmp_path / 'missing.png'], threads=1)
+
+
 def test_merge_lines_golden_g13(golden, tmp_path):
     """merge_lines / downsample_seqs vs the reference's own output on a 5-tile road (same-heading weave, reversed merge,
     new lines, retirement incl. the pop-while-enumerating skip): identical arrays."""
