@@ -220,6 +220,13 @@ int lm_png_info(const unsigned char* data, long size, int* H, int* W, int* C);
 int lm_png_decode_u8(const unsigned char* data, long size, unsigned char* out_hwc, long out_bytes);
 int lm_png_decode_files_u8(const char* const* paths, int n, unsigned char* out_nhwc, int H, int W, int C, int threads);
 
+/* ---- per-tile polyline JSON (save_lane_seq_2d, baseline/utils/io_utils.py:58-93: json.dump(records, indent=4)) ----------------
+ * lane_vertexes [n_lines][row_size][3] doubles = (row, col, semantic), a vertex exists iff col > 0, lines with < 2 vertices are dropped.
+ * The text is byte-identical to the reference's (numbers formatted like CPython's float repr).  lm_lane_json_text returns the text
+ * length; it writes (NUL-terminated) only if cap is large enough, so call it with out = NULL first.  Host code. */
+long lm_lane_json_text(const double* lane_vertexes, int n_lines, int row_size, int with_pervertex_semantics, char* out, long cap);
+int lm_lane_json_write(const double* lane_vertexes, int n_lines, int row_size, int with_pervertex_semantics, const char* path);
+
 #ifdef __cplusplus
 }
 #endif

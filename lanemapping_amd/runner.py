@@ -49,17 +49,49 @@ class Runner:
             return sorted(source)
         return sorted(glob.glob(os.path.join(source, '*.png')))
 
-    def _load_batch(self, paths):
-        # native PNG reader of the C-ABI library: the whole batch is inflated on host threads into one pinned [n,H,W,C] buffer
+    def _decode_batch(self, paths, slot):
+        """Host part of the tile ingest: the library's PNG reader inflates the batch on host threads into one of two pinned
+        [n,H,W,C] buffers (pure C, no GIL, so it can run one batch ahead on a helper thread)."""
         from .png_io import read_png_batch, png_info
         with open(paths[0], 'rb') as f:
             h, w, c = png_info(f.read(64))
-        pinned = torch.empty((len(paths), h, w, c), dtype=torch.uint8, pin_memory=self.device.type == 'cuda')
-        read_png_batch(paths, threads=int(self.cfg.get('host_threads', 8)), out=pinned.numpy())
-        u8 = pinned.to(self.device, non_blocking=True)
-        if c < 3:                                              # greyscale tiles: replicate into the 3 input channels
+        pinned = self.__dict__.setdefault('_pinned', {})      # slot -> (pinned uint8 buffer, event of the last copy out of it)
+        buf, ev = pinned.get(slot, (None, None))
+        if ev is not None:
+            ev.synchronize()                                   # the previous copy out of this buffer has finished
+        if buf is None or tuple(buf.shape[1:]) != (h, w, c) or buf.shape[0] < len(paths):
+            buf = torch.empty((len(paths), h, w, c), dtype=torch.uint8, pin_memory=self.device.type == 'cuda')
+        view = buf[:len(paths)]
+        read_png_batch(paths, threads=int(self.cfg.get('host_threads', 8)), out=view.numpy())
+        pinned[slot] = (buf, None)
+        return view
+
+    def _to_device(self, view, slot):
+        u8 = view.to(self.device, non_blocking=True)
+        if self.device.type == 'cuda':
+            ev = torch.cuda.Event()
+            ev.record()
+            self._pinned[slot] = (self._pinned[slot][0], ev)
+        if u8.shape[-1] < 3:                                   # greyscale tiles: replicate into the 3 input channels
             u8 = u8[..., :1].expand(-1, -1, -1, 3).contiguous()
         return ops.tile_ingest(u8)
+
+    def _load_batch(self, paths):
+        return self._to_device(self._decode_batch(paths, 0), 0)
+
+    def _batches(self, paths, B):
+        """Yields the device tensor of every batch; batch i+1 is decoded on a helper thread while batch i is enqueued and runs."""
+        from concurrent.futures import ThreadPoolExecutor
+        chunks = [paths[i:i + B] for i in range(0, len(paths), B)]
+        if not chunks:
+            return
+        with ThreadPoolExecutor(max_workers=1) as pool:
+            fut = pool.submit(self._decode_batch, chunks[0], 0)
+            for k in range(len(chunks)):
+                view = fut.result()
+                if k + 1 < len(chunks):
+                    fut = pool.submit(self._decode_batch, chunks[k + 1], (k + 1) & 1)
+                yield self._to_device(view, k & 1)
 
     # ------------------------------------------------------------------------------------------------ inference
     def infer_lane_coordinate_endpoint_semantics(self, tiles=None, path_ckpt=None, write_lane_vertex=True, batch_size=None,
@@ -80,8 +112,8 @@ class Runner:
         if self.cfg.heads.type == 'RowSharNotReducRef':
             # config 4: the head's own decode + per-lane tracing inside Detector1stage.forward; 12 lanes x 144 rows of columns
             # are padded into the [72,144,2] block the JSON writer / all-gather use (semantic 1 = line present)
-            for i in range(0, len(mine), B):
-                out = self.net({'proj': self._load_batch(mine[i:i + B])})
+            for proj in self._batches(mine, B):
+                out = self.net({'proj': proj})
                 for cols in out['lane_maps']['cls_offset_smooth']:
                     lanes = np.full((72, 144, 2), -1.0)
                     lanes[:, :, 1] = 0.0
@@ -91,8 +123,8 @@ class Runner:
                     endp_all.append(np.zeros((0, 2), dtype=np.int32))
         else:
             pipe = TilePipeline(self.net)
-            for i in range(0, len(mine), B):
-                futs = pipe.submit(self._load_batch(mine[i:i + B]))
+            for proj in self._batches(mine, B):
+                futs = pipe.submit(proj)
                 for f in futs:
                     lanes_all.append(f.result()[0]); endp_all.append(f.result()[1])
             for f in pipe.flush():

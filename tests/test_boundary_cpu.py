@@ -484,6 +484,43 @@ def test_png_reader_hand_filtered_rows_and_errors(tmp_path):
         png_io.read_png_batch([tmp_path / 'a.png', tmp_path / 'missing.png'], threads=1)
 
 
+def test_native_lane_json_is_json_dump_byte_for_byte(tmp_path):
+    """csrc/lane_json.cpp == json.dump(lane_records(..), indent=4): random bit patterns, the repr() format switches, empty files."""
+    import json
+    from lanemapping_amd import io_utils
+    rng = np.random.default_rng(1)
+    special = [1e16, 9999999999999998.0, 1e-5, 0.0001, 0.00012345, 123456789012345680.0, 5e-324, 1.7976931348623157e308, 1e22,
+               2.0 ** -24, 2.0 ** -1074, 2.0 ** 60, 0.1 + 0.2, 1 / 3, 100.0, 1152.0, 3.0, 1e15, 123456789.123, 0.5, 2.5e-7, 1e21, 1e-4,
+               9.999999999999999e-05, 2 ** 53 + 2.0, float('inf')]
+    for trial in range(120):
+        L = int(rng.integers(0, 7))
+        v = np.zeros((L, 40, 3))
+        kind = trial % 3
+        for l in range(L):
+            n = int(rng.integers(0, 40))
+            rows = np.sort(rng.choice(40, n, replace=False))
+            if kind == 0:
+                cols = rng.random(n) * 1151 + 1e-9
+            elif kind == 1:
+                cols = np.frombuffer(rng.bytes(8 * n), dtype=np.float64).copy()
+                cols = np.abs(np.where(np.isfinite(cols), cols, 1.0)) + 5e-324
+            else:
+                cols = np.array([special[int(i)] for i in rng.integers(0, len(special), n)])
+            v[l, rows, 1] = cols
+            first = np.arange(3, 40 * 8, 8) if kind == 0 else -np.frombuffer(rng.bytes(8 * 40), dtype=np.float64)
+            v[l, :, 0] = np.where(np.isnan(first), -2.5, first)
+            v[l, rows, 2] = rng.integers(0, 3, n) if kind == 0 else np.float32(rng.random(n)).astype(np.float64)
+        for sem in (True, False):
+            ref = json.dumps(io_utils.lane_records(v, sem), indent=4)
+            assert io_utils.lane_json_text(v, sem) == ref, (trial, sem)
+            io_utils.save_lane_seq_2d(v, str(tmp_path / 't.json'), sem)
+            assert (tmp_path / 't.json').read_text() == ref
+    assert io_utils.lane_json_text(np.zeros((72, 144, 3))) == '[]'
+    from lanemapping_amd._lib import LanemapHipError
+    with pytest.raises(LanemapHipError, match='cannot open'):
+        io_utils.save_lane_seq_2d(np.zeros((1, 4, 3)), str(tmp_path / 'no_such_dir' / 't.json'))
+
+
 def test_merge_lines_golden_g13(golden, tmp_path):
     """merge_lines / downsample_seqs vs the reference's own output on a 5-tile road (same-heading weave, reversed merge,
     new lines, retirement incl. the pop-while-enumerating skip): identical arrays."""

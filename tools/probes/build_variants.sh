@@ -6,7 +6,7 @@ cd "$(dirname "$0")/../.."
 python -m lanemapping_amd.build > /dev/null 2>&1 || true
 SRC=$1; shift
 OBJS=""
-for f in errors.cpp conv_mfma.hip conv_wino.hip conv_direct.hip norm_resize.hip vit.hip head.hip decode.hip raster.hip rowref.hip lidar.hip postproc.cpp backproject.cpp png_reader.cpp; do
+for f in errors.cpp conv_mfma.hip conv_wino.hip conv_direct.hip norm_resize.hip vit.hip head.hip decode.hip raster.hip rowref.hip lidar.hip postproc.cpp backproject.cpp png_reader.cpp lane_json.cpp; do
   [ "$f" = "$SRC" ] || OBJS="$OBJS lanemapping_amd/build/$f.o"
 done
 for spec in "$@"; do
