@@ -727,7 +727,9 @@ def test_bench_default_command(dev):
 
 # ----------------------------------------------------------------------------------------------- Winograd convolution
 @pytest.mark.parametrize('B,cin,cout,H,W,dil', [(2, 128, 128, 36, 36, 1), (1, 256, 200, 37, 29, 1), (2, 128, 64, 40, 44, 2),
-                                                (1, 160, 256, 31, 33, 2), (1, 128, 96, 23, 50, 3)])
+                                                (1, 160, 256, 31, 33, 2), (1, 128, 96, 23, 50, 3),
+                                                (3, 128, 64, 5, 3, 1), (1, 128, 64, 2, 7, 2), (2, 128, 64, 1, 1, 1), (1, 128, 64, 9, 4, 3),
+                                                (5, 128, 64, 6, 300, 1)])
 def test_conv_winograd_vs_fp64_reference(dev, B, cin, cout, H, W, dil):
     """lm_conv3x3_winograd_f32 (odd sizes, dilations, Cout not a multiple of 64, BN scale/shift, residual, ReLU) vs torch fp64,
     and vs the direct MFMA kernel; GroupNorm statistics out of the GEMM epilogue vs the standalone statistics kernel."""
@@ -755,7 +757,8 @@ def test_conv_winograd_vs_fp64_reference(dev, B, cin, cout, H, W, dil):
     mean = td.mean(dim=(2, 3))
     rstd = 1.0 / torch.sqrt(td.var(dim=(2, 3), unbiased=False) + 1e-5)
     _close(st[:, :, 0], mean.float(), 1e-5, 'GN mean')
-    _close(st[:, :, 1], rstd.float(), 1e-5, 'GN rstd')
+    if H * W > 1:    # (one sample per channel: the variance is 0 up to the fp32 rounding of x*x and rstd = eps^-1/2 amplifies that 1e7-fold)
+        _close(st[:, :, 1], rstd.float(), 1e-5, 'GN rstd')
 
 
 @pytest.mark.parametrize('N', [12, 320, 321, 324, 352])
