@@ -520,6 +520,7 @@ LM_API int lm_winograd_gemm_f32(void* stream, const void* V, const float* wu, in
     const int force = wino_force();
     if (force == 8) return launch_wino<192, 64, 96, 32>(p, s);         // 4 waves of 96x32: three accumulator tiles (chains) per wave
     if (force == 9) return launch_wino<128, 64, 32, 64, 32, 3>(p, s);   // loads two slabs ahead (72 KB LDS, still 2 workgroups/CU)
+    if (force == 11) return launch_wino<128, 64, 32, 32>(p, s);    // 8 waves of 32x32: half the loads per wave, 4 waves per SIMD if <= 128 registers
     if (force == 10) return launch_wino<64, 64, 32, 32>(p, s);     // 4 waves of 32x32: ~120 registers, 4 workgroups/CU
     if (force == 1 && !gn_partial) return launch_wino<128, 128, 64, 64>(p, s);
     if (force == 3 && !gn_partial) return launch_wino<64, 128, 32, 64>(p, s);
