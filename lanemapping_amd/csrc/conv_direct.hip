@@ -22,12 +22,14 @@ constexpr int SPP = 40;            // padded patch row
 __global__ __launch_bounds__(256) void stem_kernel(const float* __restrict__ x, const float* __restrict__ w,
                                                    const float* __restrict__ scale, const float* __restrict__ shift,
                                                    float* __restrict__ y, int H, int W, int Ho, int Wo) {
-    __shared__ __attribute__((aligned(16))) float wl[147 * 64];
+    // The weights are wave-uniform: they are read with SCALAR loads (uniform index into a __restrict__ const pointer -> s_load into
+    // SGPRs, served by the scalar cache) and enter the packed FMAs as scalar operands: 74 VGPRs, 6 waves per SIMD.  Staging them in
+    // LDS made the kernel LDS-issue bound (16 broadcast ds_read_b128 per 64 FMAs and lane, 8 waves per CU sharing one LDS, 254 VGPRs):
+    // 0.90 -> 0.69 ms for 8 tiles.  Two pixels per thread (half the scalar traffic per FMA, 141 VGPRs) measured slower: 0.87 ms.
     __shared__ float in[3][SP][SPP];
     const int tid = threadIdx.x;
     const int b = blockIdx.z;
     const int oy0 = blockIdx.y * ST, ox0 = blockIdx.x * ST;
-    for (int i = tid; i < 147 * 64; i += 256) wl[i] = w[i];
     const int iy0 = oy0 * 2 - 3, ix0 = ox0 * 2 - 3;
     for (int i = tid; i < 3 * SP * SP; i += 256) {
         const int c = i / (SP * SP), r = (i / SP) % SP, q = i % SP;
@@ -46,15 +48,9 @@ __global__ __launch_bounds__(256) void stem_kernel(const float* __restrict__ x, 
 #pragma unroll
             for (int c = 0; c < 3; ++c) {
                 const float v = in[c][2 * py + ky][2 * px + kx];
-                const f32x4* wr = reinterpret_cast<const f32x4*>(wl + ((ky * 7 + kx) * 3 + c) * 64);
+                const float* wr = w + ((ky * 7 + kx) * 3 + c) * 64;
 #pragma unroll
-                for (int q = 0; q < 16; ++q) {
-                    const f32x4 w4 = wr[q];
-                    acc[4 * q + 0] = fmaf(v, w4[0], acc[4 * q + 0]);
-                    acc[4 * q + 1] = fmaf(v, w4[1], acc[4 * q + 1]);
-                    acc[4 * q + 2] = fmaf(v, w4[2], acc[4 * q + 2]);
-                    acc[4 * q + 3] = fmaf(v, w4[3], acc[4 * q + 3]);
-                }
+                for (int q = 0; q < 64; ++q) acc[q] = fmaf(v, wr[q], acc[q]);
             }
     const int oy = oy0 + py, ox = ox0 + px;
     if (oy < Ho && ox < Wo) {
@@ -106,10 +102,8 @@ struct SmallConvParams {
 };
 
 __global__ __launch_bounds__(256) void small_conv_kernel(SmallConvParams p) {
-    extern __shared__ __attribute__((aligned(16))) float wl[];   // [taps*Cin][16]
-    const int nw = p.KH * p.KW * p.Cin * 16;
-    for (int i = threadIdx.x; i < nw; i += 256) wl[i] = p.w[i];
-    __syncthreads();
+    // weights [taps*Cin][16] are wave-uniform: scalar loads (see stem_kernel), no LDS staging
+    const float* __restrict__ wl = p.w;
     const long m = (long)blockIdx.x * 256 + threadIdx.x;
     if (m >= p.M) return;
     const int ox = (int)(m % p.Wo);
@@ -135,15 +129,9 @@ __global__ __launch_bounds__(256) void small_conv_kernel(SmallConvParams p) {
                 }
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
-                    const f32x4* wr = reinterpret_cast<const f32x4*>(wt + (c + e) * 16);
+                    const float* wr = wt + (c + e) * 16;
 #pragma unroll
-                    for (int q = 0; q < 4; ++q) {
-                        const f32x4 w4 = wr[q];
-                        acc[4 * q + 0] = fmaf(v[e], w4[0], acc[4 * q + 0]);
-                        acc[4 * q + 1] = fmaf(v[e], w4[1], acc[4 * q + 1]);
-                        acc[4 * q + 2] = fmaf(v[e], w4[2], acc[4 * q + 2]);
-                        acc[4 * q + 3] = fmaf(v[e], w4[3], acc[4 * q + 3]);
-                    }
+                    for (int q = 0; q < 16; ++q) acc[q] = fmaf(v[e], wr[q], acc[q]);
                 }
             }
         }
@@ -195,9 +183,7 @@ LM_API int lm_conv2d_nhwc_small(void* stream, const float* x, int ldx, const flo
     p.Ho = (H + 2 * pad_h - KH) / stride + 1;
     p.Wo = (W + 2 * pad_w - KW) / stride + 1;
     p.M = (long)B * p.Ho * p.Wo;
-    const size_t lds = (size_t)KH * KW * Cin * 16 * sizeof(float);
-    LM_REQUIRE(lds <= 64 * 1024, "small_conv: weights do not fit LDS (%zu B)", lds);
-    hipLaunchKernelGGL(small_conv_kernel, dim3(lm_cdiv(p.M, 256)), dim3(256), lds, (hipStream_t)stream, p);
+    hipLaunchKernelGGL(small_conv_kernel, dim3(lm_cdiv(p.M, 256)), dim3(256), 0, (hipStream_t)stream, p);
     LM_LAUNCH_CHECK();
     return LM_OK;
 }

@@ -150,10 +150,25 @@ struct GnSum {
     int n;
 };
 
+// Optional fused 1x1 projection (feature_layer 128 -> 8, output_layer_endp 128 -> 1; postprojector.py:628-651): the C/4 lanes of a
+// pixel sit in one wave (C/4 a power of two <= 64), each multiplies its 4 channels into `cout` partial sums, a butterfly over those lanes
+// adds them up and the first lane stores y1[pixel][0..cout) (+ bias).  With y == nullptr the summed tensor itself is never written.
+struct Proj1x1 {
+    const float* w;      // [C][16] (pack_small layout), nullptr = no projection
+    const float* bias;   // [cout] or nullptr
+    float* y1;           // [B*Ho*Wo][ldy1]
+    int cout, ldy1;
+};
+
 __global__ __launch_bounds__(256) void gn_relu_upsample_sum_kernel(GnSum P, const float* __restrict__ gamma, const float* __restrict__ beta,
-                                                                   float* __restrict__ y, int Ho, int Wo, int C, unsigned total4) {
+                                                                   float* __restrict__ y, int Ho, int Wo, int C, unsigned total4, Proj1x1 Q) {
+    __shared__ __attribute__((aligned(16))) float wl[256 * 8];   // projection weights [C][8] (cout padded with zeros)
+    if (Q.w) {
+        for (int k = threadIdx.x; k < C * 8; k += 256) wl[k] = (k & 7) < Q.cout ? Q.w[(k >> 3) * 16 + (k & 7)] : 0.f;
+        __syncthreads();
+    }
     const unsigned i = blockIdx.x * 256u + threadIdx.x;
-    if (i >= total4) return;
+    if (i >= total4) return;                                  // (total4 is a multiple of C/4: the lanes of a pixel leave together)
     const unsigned c4n = (unsigned)C / 4;
     const int c = (int)(i % c4n) * 4;
     unsigned t = i / c4n;
@@ -201,7 +216,38 @@ __global__ __launch_bounds__(256) void gn_relu_upsample_sum_kernel(GnSum P, cons
             for (int e = 0; e < 4; ++e) acc[e] = acc[e] + o[e];
         }
     }
-    *reinterpret_cast<f32x4*>(y + (long)i * 4) = acc;
+    if (y) *reinterpret_cast<f32x4*>(y + (long)i * 4) = acc;
+    if (Q.w) {
+        // partial sums of this lane's 4 channels for the 8 (padded) outputs, weights from the LDS copy [C][8]
+        float part[8];
+#pragma unroll
+        for (int n = 0; n < 8; ++n) part[n] = 0.f;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const f32x4 w0 = *reinterpret_cast<const f32x4*>(wl + (c + e) * 8), w1 = *reinterpret_cast<const f32x4*>(wl + (c + e) * 8 + 4);
+#pragma unroll
+            for (int n = 0; n < 4; ++n) {
+                part[n] = fmaf(acc[e], w0[n], part[n]);
+                part[4 + n] = fmaf(acc[e], w1[n], part[4 + n]);
+            }
+        }
+        // transpose-reduce over the C/4 lanes of the pixel: each of the first three steps halves the outputs a lane keeps while doubling
+        // the lanes summed (4 + 2 + 1 shuffles), then plain butterflies: 9-10 shuffles instead of 8 x log2(C/4)
+        const int lane = threadIdx.x & 63;
+#pragma unroll
+        for (int half = 4, mask = 1; half >= 1; half >>= 1, mask <<= 1) {
+            const bool upper = (lane & mask) != 0;
+#pragma unroll
+            for (int j = 0; j < half; ++j) {
+                const float send = upper ? part[j] : part[j + half], keep = upper ? part[j + half] : part[j];
+                part[j] = keep + __shfl_xor(send, mask);
+            }
+        }
+        for (unsigned o = 8; o < c4n; o <<= 1) part[0] += __shfl_xor(part[0], (int)o);
+        const unsigned li = i % c4n;
+        const int n = 4 * (int)(li & 1) + 2 * (int)((li >> 1) & 1) + (int)((li >> 2) & 1);
+        if (li < 8 && n < Q.cout) Q.y1[(long)(i / c4n) * Q.ldy1 + n] = part[0] + (Q.bias ? Q.bias[n] : 0.f);
+    }
 }
 
 // ----------------------------------------------------------------------------- plain bilinear, NHWC -> NHWC slice
@@ -343,9 +389,10 @@ LM_API int lm_gn_relu_upsample(void* stream, const float* x, const float* stats,
     return LM_OK;
 }
 
-LM_API int lm_gn_relu_upsample_sum(void* stream, int n, const float* const* x, const float* const* stats, const int* Hi, const int* Wi,
-                                   const float* gamma, const float* beta, float* y, int B, int Ho, int Wo, int C) {
-    LM_REQUIRE(n >= 1 && n <= 3 && x && stats && Hi && Wi && gamma && beta && y && C % 4 == 0, "gn_relu_upsample_sum: bad args");
+namespace {
+int launch_gn_sum(void* stream, int n, const float* const* x, const float* const* stats, const int* Hi, const int* Wi, const float* gamma,
+                  const float* beta, float* y, int B, int Ho, int Wo, int C, Proj1x1 Q) {
+    LM_REQUIRE(n >= 1 && n <= 3 && x && stats && Hi && Wi && gamma && beta && C > 0 && C % 4 == 0, "gn_relu_upsample_sum: bad args");
     const long total4 = (long)B * Ho * Wo * (C / 4);
     LM_REQUIRE(total4 > 0 && total4 < (1L << 31), "gn_relu_upsample_sum: %ld output quads do not fit 32-bit indices", total4);
     GnSum P;
@@ -356,9 +403,28 @@ LM_API int lm_gn_relu_upsample_sum(void* stream, int n, const float* const* x, c
         P.t[k] = GnTerm{x[q], stats[q], Hi[q], Wi[q]};
     }
     hipLaunchKernelGGL(gn_relu_upsample_sum_kernel, dim3((unsigned)lm_cdiv(total4, 256)), dim3(256), 0, (hipStream_t)stream, P, gamma, beta,
-                       y, Ho, Wo, C, (unsigned)total4);
+                       y, Ho, Wo, C, (unsigned)total4, Q);
     LM_LAUNCH_CHECK();
     return LM_OK;
+}
+}  // namespace
+
+LM_API int lm_gn_relu_upsample_sum(void* stream, int n, const float* const* x, const float* const* stats, const int* Hi, const int* Wi,
+                                   const float* gamma, const float* beta, float* y, int B, int Ho, int Wo, int C) {
+    LM_REQUIRE(y, "gn_relu_upsample_sum: null output");
+    return launch_gn_sum(stream, n, x, stats, Hi, Wi, gamma, beta, y, B, Ho, Wo, C, Proj1x1{nullptr, nullptr, nullptr, 0, 0});
+}
+
+// Same sum followed by a 1x1 convolution y1 = sum @ w + bias (cout <= 8, w in the [C][16] layout of lm_conv2d_nhwc_small) computed from
+// registers; y may be NULL, in which case the C-channel sum is never written (feature_layer / output_layer_endp read nothing else).
+LM_API int lm_gn_relu_upsample_sum_conv1x1(void* stream, int n, const float* const* x, const float* const* stats, const int* Hi,
+                                           const int* Wi, const float* gamma, const float* beta, float* y, int B, int Ho, int Wo, int C,
+                                           const float* w_c16, const float* bias, int cout, float* y1, int ldy1) {
+    LM_REQUIRE(w_c16 && y1 && cout >= 1 && cout <= 8 && ldy1 >= cout, "gn_relu_upsample_sum_conv1x1: bad projection (cout=%d)", cout);
+    const int c4n = C / 4;
+    LM_REQUIRE(C % 4 == 0 && c4n >= 8 && c4n <= 64 && (c4n & (c4n - 1)) == 0,
+               "gn_relu_upsample_sum_conv1x1: C=%d: C/4 must be a power of two in [8, 64] (one pixel per wave segment)", C);
+    return launch_gn_sum(stream, n, x, stats, Hi, Wi, gamma, beta, y, B, Ho, Wo, C, Proj1x1{w_c16, bias, y1, cout, ldy1});
 }
 
 LM_API int lm_upsample_bilinear_nhwc(void* stream, const float* x, int ldx, const float* add, int lda, float* y, int ldy,

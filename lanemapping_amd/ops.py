@@ -286,21 +286,32 @@ def gn_relu_upsample(x, stats, gamma, beta, size, out=None, accumulate=False):
     return out
 
 
-def gn_relu_upsample_sum(terms, gamma, beta, size, out=None):
-    """((t0 + t1) + t2) with t_k = bilinear(relu(gn(x_k))) for terms = [(x_k, stats_k), ...] (at most 3) in one pass."""
+def gn_relu_upsample_sum(terms, gamma, beta, size, out=None, proj=None, keep_sum=True):
+    """((t0 + t1) + t2) with t_k = bilinear(relu(gn(x_k))) for terms = [(x_k, stats_k), ...] (at most 3) in one pass.
+    proj = (w16, bias, cout[, out1]): also returns the 1x1 convolution of the sum (cout <= 8, weights packed by pack_small), computed
+    from registers; with keep_sum=False the sum itself is never written and only the projection is returned."""
     n = len(terms)
     xs = [as_nhwc(x) for x, _ in terms]
     B, C_ = xs[0][0].shape[:2]
     for (x, ld) in xs:
         assert ld == C_ and x.shape[0] == B and x.shape[1] == C_
     Ho, Wo = size
-    if out is None:
-        out = new_act(B, C_, Ho, Wo, xs[0][0].device)
+    dev = xs[0][0].device
+    if out is None and (keep_sum or proj is None):
+        out = new_act(B, C_, Ho, Wo, dev)
     vp_arr, i_arr = C.c_void_p * n, C.c_int * n
-    check(lib().lm_gn_relu_upsample_sum(_stream(), n, vp_arr(*[_ptr(x) for x, _ in xs]), vp_arr(*[_ptr(st) for _, st in terms]),
-                                        i_arr(*[x.shape[2] for x, _ in xs]), i_arr(*[x.shape[3] for x, _ in xs]),
-                                        _ptr(gamma), _ptr(beta), _ptr(out), B, Ho, Wo, C_))
-    return out
+    head = (_stream(), n, vp_arr(*[_ptr(x) for x, _ in xs]), vp_arr(*[_ptr(st) for _, st in terms]),
+            i_arr(*[x.shape[2] for x, _ in xs]), i_arr(*[x.shape[3] for x, _ in xs]), _ptr(gamma), _ptr(beta))
+    if proj is None:
+        check(lib().lm_gn_relu_upsample_sum(*head, _ptr(out), B, Ho, Wo, C_))
+        return out
+    w16, bias, cout = proj[:3]
+    out1 = proj[3] if len(proj) > 3 and proj[3] is not None else new_act(B, cout, Ho, Wo, dev)
+    o1, ldy1 = as_nhwc(out1)
+    assert o1.data_ptr() == out1.data_ptr()
+    check(lib().lm_gn_relu_upsample_sum_conv1x1(*head, _ptr(out) if keep_sum else None, B, Ho, Wo, C_, _ptr(w16), _ptr(bias), cout,
+                                                _ptr(out1), ldy1))
+    return (out, out1) if keep_sum else out1
 
 
 def upsample_nhwc(x, size, add=None, out=None):

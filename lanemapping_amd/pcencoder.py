@@ -168,9 +168,11 @@ class FPNEncoder(PackedModule):
     def _conv3(self, x, P, name, cout):
         return self._c3(x, P, name + '.w', cout, 1, 1, shift=P[name + '.b'])
 
-    def _semantic(self, P, p2, p3, p4, conv_a, gn_a, conv_b, gn_b, shared):
-        """One of the two branches (reference :615-621 / :641-647): returns s2 + s3 + s4 at p2's size.  `shared` caches the
-        Winograd input transforms of p2 / p3 / p4, which both branches convolve (with different weights)."""
+    def _semantic(self, P, p2, p3, p4, conv_a, gn_a, conv_b, gn_b, shared, proj):
+        """One of the two branches (reference :615-621 / :641-647): s2 + s3 + s4 at p2's size, followed by the branch's 1x1 output
+        layer `proj` = (packed weight, bias, cout, out) - the only consumer of the sum, so the 128-channel sum is never written
+        (lm_gn_relu_upsample_sum_conv1x1).  `shared` caches the Winograd input transforms of p2 / p3 / p4, which both branches
+        convolve (with different weights)."""
         h, w = p2.shape[2:]
         c_half = self.semantic_branch.out_channels
 
@@ -195,8 +197,8 @@ class FPNEncoder(PackedModule):
         terms = [conv_stats(p2, conv_b, c_half, gn_b, share='p2'),                      # s2
                  conv_stats(p3, conv_b, c_half, gn_b, share='p3'),                      # s3
                  conv_stats(s4, conv_b, c_half, gn_b)]                                  # s4
-        # (s2 + s3) + s4, each term GN + ReLU + bilinear to p2's size, in one pass over the output
-        return ops.gn_relu_upsample_sum(terms, P[gn_b + '.g'], P[gn_b + '.b'], (h, w))
+        # (s2 + s3) + s4, each term GN + ReLU + bilinear to p2's size, and the 1x1 output layer, in one pass
+        return ops.gn_relu_upsample_sum(terms, P[gn_b + '.g'], P[gn_b + '.b'], (h, w), proj=proj, keep_sum=False)
 
     def forward(self, x, fea_up_out=None):
         P = self.packed()
@@ -220,14 +222,13 @@ class FPNEncoder(PackedModule):
         p3 = self._conv3(p3, P, 'smooth2', 256)
         p2 = self._conv3(p2, P, 'smooth3', 256)
         shared = {}
-        sa = self._semantic(P, p2, p3, p4, 'conv2', 'gn12', 'semantic_branch', 'gn11', shared)
-        fea_up = ops.conv_small(sa, P['feature_layer.w'], 8, shift=P['feature_layer.b'], out=fea_up_out)
-        del sa
+        fea_up = self._semantic(P, p2, p3, p4, 'conv2', 'gn12', 'semantic_branch', 'gn11', shared,
+                                (P['feature_layer.w'], P['feature_layer.b'], 8, fea_up_out))
         seg288 = ops.conv_small(fea_up, P['output_layer_binary_seg.w'], 3, shift=P['output_layer_binary_seg.b'], pre_relu=True)
         bi_seg = ops.upsample_to_chw(seg288, (H, W))
-        sb = self._semantic(P, p2, p3, p4, 'conv3', 'gn22', 'semantic_branch2', 'gn21', shared)
+        endp288 = self._semantic(P, p2, p3, p4, 'conv3', 'gn22', 'semantic_branch2', 'gn21', shared,
+                                 (P['output_layer_endp.w'], P['output_layer_endp.b'], 1, None))
         del shared
-        endp288 = ops.conv_small(sb, P['output_layer_endp.w'], 1, shift=P['output_layer_endp.b'])
         endp = ops.upsample_to_chw(endp288, (H, W))
         return fea, fea_up, bi_seg, endp
 

@@ -148,6 +148,18 @@ def test_gn_relu_upsample_sum(dev):
     for x, st in terms[1:]:
         z = ops.gn_relu_upsample(x, st, gd, bd, (40, 56), out=z, accumulate=True)
     assert torch.equal(y, z), float((y - z).abs().max())
+    # fused 1x1 output layer (feature_layer 64 -> 8 here, and a single-channel one) with and without writing the sum
+    for cout in (8, 1, 5):
+        w = torch.randn(cout, 64, 1, 1, generator=g) / 8
+        b = torch.randn(cout, generator=g)
+        want = F.conv2d(ref, w, b)
+        w16 = ops.pack_small(w.to(dev))
+        ysum, y1 = ops.gn_relu_upsample_sum(terms, gd, bd, (40, 56), proj=(w16, b.to(dev), cout))
+        assert torch.equal(ysum, y)
+        _close(y1, want, 1e-5, f'fused 1x1 ({cout})')
+        only = ops.gn_relu_upsample_sum(terms, gd, bd, (40, 56), proj=(w16, b.to(dev), cout), keep_sum=False)
+        assert torch.equal(only, y1)
+        _close(ops.conv_small(y, w16, cout, shift=b.to(dev)), want, 1e-5, 'unfused 1x1')
     y2 = ops.gn_relu_upsample_sum(terms[:2], gd, bd, (40, 56))
     _close(y2, ref - F.interpolate(F.relu(F.group_norm(xs[2], 64, gamma, beta, 1e-5)), size=(40, 56), mode='bilinear', align_corners=True),
            1e-5, 'sum of 2 terms')
