@@ -47,6 +47,7 @@ const char* parse_header(const unsigned char* d, long n, PngHeader& h) {
         case 3: return "palette PNG is not supported (BEV tiles are RGB)";
         default: return "bad colour type";
     }
+    if ((unsigned long long)w * hh * (unsigned)h.channels > (1ull << 30)) return "image larger than 2^30 bytes (not a BEV tile)";
     return nullptr;
 }
 

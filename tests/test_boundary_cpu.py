@@ -484,6 +484,55 @@ def test_png_reader_hand_filtered_rows_and_errors(tmp_path):
         png_io.read_png_batch([tmp_path / 'a.png', tmp_path / 'missing.png'], threads=1)
 
 
+def test_png_reader_survives_damaged_files():
+    """Untrusted input: random byte flips / truncations (with and without repaired chunk CRCs, so that the zlib and unfilter paths are
+    reached) must end in an array of the declared shape or a LanemapHipError - never a crash, a hang or an out-of-bounds write."""
+    import io
+    import struct
+    import zlib
+    from PIL import Image
+    from lanemapping_amd import png_io
+    from lanemapping_amd._lib import LanemapHipError
+    rng = np.random.default_rng(9)
+    img = rng.integers(0, 256, (48, 61, 3), dtype=np.uint8)
+    img[:, :, 0] = (np.add.outer(np.arange(48), np.arange(61)) % 251).astype(np.uint8)
+    buf = io.BytesIO()
+    Image.fromarray(img).save(buf, 'PNG')
+    good = buf.getvalue()
+    assert np.array_equal(png_io.decode_png(good), img)
+
+    def fix_crcs(data):
+        out, pos = bytearray(data[:8]), 8
+        while pos + 12 <= len(data):
+            n = struct.unpack('>I', data[pos:pos + 4])[0]
+            if pos + 12 + n > len(data):
+                break
+            body = data[pos + 4:pos + 8 + n]
+            out += data[pos:pos + 4] + body + struct.pack('>I', zlib.crc32(body) & 0xffffffff)
+            pos += 12 + n
+        return bytes(out + data[pos:])
+
+    ok = bad = 0
+    for trial in range(400):
+        data = bytearray(good)
+        kind = trial % 4
+        if kind == 0:                                           # truncation
+            data = data[:int(rng.integers(0, len(data)))]
+        else:
+            for _ in range(int(rng.integers(1, 4))):
+                data[int(rng.integers(8 if kind == 3 else 0, len(data)))] ^= int(rng.integers(1, 256))
+        data = bytes(data)
+        if kind >= 2:
+            data = fix_crcs(data)
+        try:
+            out = png_io.decode_png(data)
+            assert out.dtype == np.uint8 and out.ndim in (2, 3)
+            ok += 1
+        except LanemapHipError:
+            bad += 1
+    assert bad > 300 and ok + bad == 400
+
+
 def test_native_lane_json_is_json_dump_byte_for_byte(tmp_path):
     """csrc/lane_json.cpp == json.dump(lane_records(..), indent=4): random bit patterns, the repr() format switches, empty files."""
     import json
