@@ -232,6 +232,9 @@ int lm_png_decode_files_u8(const char* const* paths, int n, unsigned char* out_n
  * length; it writes (NUL-terminated) only if cap is large enough, so call it with out = NULL first.  Host code. */
 long lm_lane_json_text(const double* lane_vertexes, int n_lines, int row_size, int with_pervertex_semantics, char* out, long cap);
 int lm_lane_json_write(const double* lane_vertexes, int n_lines, int row_size, int with_pervertex_semantics, const char* path);
+/* 3-D polylines after the back-projection / merge (save_seqs_json, utils/io_utils.py:11-15, records built at coor_img2pc.py:205-212):
+ * seqs [L][Vmax][D] doubles, lens [L] in [1, Vmax]; keys "seq", "seq_len", "init_vertex", "end_vertex"; same text as json.dump(indent=4). */
+int lm_seqs_json_write(const double* seqs, const int* lens, int L, int Vmax, int D, const char* path);
 
 #ifdef __cplusplus
 }

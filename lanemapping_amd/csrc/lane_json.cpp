@@ -107,6 +107,34 @@ void build(const double* lv, int n_lines, int row_size, int with_sem, std::strin
     o += first ? "[]" : "\n]";
 }
 
+// records of the 3-D / merged polyline files: keys in the order the reference builds its dicts (coor_img2pc.py:205-212)
+void build_seqs(const double* seqs, const int* lens, int L, int Vmax, int D, std::string& o) {
+    if (L == 0) { o += "[]"; return; }
+    for (int l = 0; l < L; ++l) {
+        const double* sq = seqs + (size_t)l * Vmax * D;
+        const int n = lens[l];
+        o += l ? ",\n    {\n" : "[\n    {\n";
+        o += "        \"seq\": [";
+        if (n == 0) {
+            o += "]";
+        } else {
+            o += "\n";
+            for (int i = 0; i < n; ++i) {
+                o.append(12, ' ');
+                vertex_list(sq + (size_t)i * D, D, 12, o);
+                o += i + 1 < n ? ",\n" : "\n";
+            }
+            o += "        ]";
+        }
+        o += ",\n        \"seq_len\": " + std::to_string(n) + ",\n        \"init_vertex\": ";
+        vertex_list(sq, D, 8, o);
+        o += ",\n        \"end_vertex\": ";
+        vertex_list(sq + (size_t)(n > 0 ? n - 1 : 0) * D, D, 8, o);
+        o += "\n    }";
+    }
+    o += "\n]";
+}
+
 }  // namespace
 
 // lane_vertexes: [n_lines][row_size][3] doubles = (row, col, semantic) per vertex, the layout of pack_lane_vertices; a vertex exists iff
@@ -135,5 +163,22 @@ LM_API int lm_lane_json_write(const double* lane_vertexes, int n_lines, int row_
     const size_t w = fwrite(s.data(), 1, s.size(), f);
     const int rc = fclose(f);
     LM_REQUIRE(w == s.size() && rc == 0, "lane_json_write: short write to %s", path);
+    return LM_OK;
+}
+
+// 3-D (or any D >= 1) polylines: seqs [L][Vmax][D] doubles, lens [L] (1 <= lens[l] <= Vmax) -> the text of
+// json.dump([{"seq": .., "seq_len": n, "init_vertex": seq[0], "end_vertex": seq[n-1]}, ..], indent=4) (save_seqs_json,
+// baseline/utils/io_utils.py:11-15, as called from coor_img2pc.py:205-214), written to `path`.
+LM_API int lm_seqs_json_write(const double* seqs, const int* lens, int L, int Vmax, int D, const char* path) {
+    LM_REQUIRE(path && L >= 0 && Vmax >= 0 && D >= 1 && (L == 0 || (seqs && lens)), "seqs_json_write: bad arguments");
+    for (int l = 0; l < L; ++l) LM_REQUIRE(lens[l] >= 1 && lens[l] <= Vmax, "seqs_json_write: lens[%d]=%d out of range", l, lens[l]);
+    std::string s;
+    s.reserve((size_t)L * Vmax * D * 40 + 64);
+    build_seqs(seqs, lens, L, Vmax, D, s);
+    FILE* f = fopen(path, "wb");
+    LM_REQUIRE(f, "seqs_json_write: cannot open %s for writing", path);
+    const size_t w = fwrite(s.data(), 1, s.size(), f);
+    const int rc = fclose(f);
+    LM_REQUIRE(w == s.size() && rc == 0, "seqs_json_write: short write to %s", path);
     return LM_OK;
 }

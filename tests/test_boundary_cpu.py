@@ -570,6 +570,30 @@ def test_native_lane_json_is_json_dump_byte_for_byte(tmp_path):
         io_utils.save_lane_seq_2d(np.zeros((1, 4, 3)), str(tmp_path / 'no_such_dir' / 't.json'))
 
 
+def test_native_seqs_json_is_json_dump_byte_for_byte(tmp_path):
+    """save_seqs_json (3-D polylines after the back-projection): native writer == json.dump(.., indent=4, cls=NpEncoder); other
+    structures fall through to json.dump."""
+    import json
+    from lanemapping_amd import io_utils
+    rng = np.random.default_rng(3)
+    p = str(tmp_path / 'a.json')
+    for trial in range(60):
+        lines = []
+        for l in range(int(rng.integers(0, 6))):
+            n = int(rng.integers(1, 30))
+            sq = rng.random((n, 3)) * 10.0 ** rng.integers(-6, 7, (n, 3)) * rng.choice([-1, 1], (n, 3))
+            if trial % 3 == 0:
+                sq = np.frombuffer(rng.bytes(8 * n * 3), dtype=np.float64).reshape(n, 3).copy()
+                sq = np.where(np.isnan(sq), 1.5, sq)
+            lines.append({'seq': sq, 'seq_len': n if l % 2 else np.int64(n), 'init_vertex': sq[0, :], 'end_vertex': sq[n - 1, :]})
+        io_utils.save_seqs_json(lines, p)
+        assert open(p).read() == json.dumps(lines, indent=4, cls=io_utils.NpEncoder), trial
+    for other in ([{'a': 1}], [{'seq': np.ones((2, 3)), 'seq_len': 2, 'init_vertex': np.zeros(3), 'end_vertex': np.ones(3)}],
+                  [{'seq_len': 1, 'seq': np.ones((1, 2)), 'init_vertex': np.ones(2), 'end_vertex': np.ones(2)}]):
+        io_utils.save_seqs_json(other, p)
+        assert open(p).read() == json.dumps(other, indent=4, cls=io_utils.NpEncoder)
+
+
 def test_merge_lines_golden_g13(golden, tmp_path):
     """merge_lines / downsample_seqs vs the reference's own output on a 5-tile road (same-heading weave, reversed merge,
     new lines, retirement incl. the pop-while-enumerating skip): identical arrays."""
