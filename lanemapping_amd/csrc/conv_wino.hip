@@ -50,6 +50,27 @@ __device__ __forceinline__ bool tile_decode(const WinoGeom& g, long m, int& b, i
     return true;
 }
 
+// B^T d B with B^T = [1 0 -1 0; 0 1 1 0; 0 -1 1 0; 0 1 0 -1] (rows first, then columns) of one 4x4 patch x 4 channels -> V[xi][m][c4..]
+__device__ __forceinline__ void transform_store(const f32x4 (&d)[4][4], float* __restrict__ V, long T, long m, int C, int c4) {
+    f32x4 r[4][4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        r[0][j] = d[0][j] - d[2][j];
+        r[1][j] = d[1][j] + d[2][j];
+        r[2][j] = d[2][j] - d[1][j];
+        r[3][j] = d[1][j] - d[3][j];
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const f32x4 v0 = r[i][0] - r[i][2], v1 = r[i][1] + r[i][2], v2 = r[i][2] - r[i][1], v3 = r[i][1] - r[i][3];
+        float* o = V + ((long)(4 * i) * T + m) * C + c4;
+        *reinterpret_cast<f32x4*>(o) = v0;
+        *reinterpret_cast<f32x4*>(o + T * C) = v1;
+        *reinterpret_cast<f32x4*>(o + 2 * T * C) = v2;
+        *reinterpret_cast<f32x4*>(o + 3 * T * C) = v3;
+    }
+}
+
 // grid: ceil(T * C/4 / 256)
 __global__ __launch_bounds__(256) void wino_input_kernel(const float* __restrict__ x, int ldx, WinoGeom g, int C, float* __restrict__ V) {
     const int c4n = C / 4;
@@ -78,24 +99,90 @@ __global__ __launch_bounds__(256) void wino_input_kernel(const float* __restrict
                 d[i][j] = *reinterpret_cast<const f32x4*>(x + (((long)b * g.H + y) * g.W + xx) * ldx + c4);
         }
     }
-    // B^T d B with B^T = [1 0 -1 0; 0 1 1 0; 0 -1 1 0; 0 1 0 -1]: rows first, then columns
-    f32x4 r[4][4];
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        r[0][j] = d[0][j] - d[2][j];
-        r[1][j] = d[1][j] + d[2][j];
-        r[2][j] = d[2][j] - d[1][j];
-        r[3][j] = d[1][j] - d[3][j];
+    transform_store(d, V, g.T, m, C, c4);
+}
+
+// ---- fused producer: V of  bilinear_x2(relu(gn(t)))  without materialising the upsampled tensor ----------------------------------
+// The FPN's s4 = _upsample(relu(gn(conv(p4)))) (postprojector.py:615-618) is consumed by exactly one 3x3 convolution; this kernel
+// writes that convolution's Winograd input straight from the low-resolution tensor t [B][Hi][Wi][C]: the GN + ReLU'd source pixels a
+// group of tiles needs are staged in LDS once, every thread blends the 4x4 patch of its (tile, 4 channels) from them with the same
+// fixed-order arithmetic as lm_gn_relu_upsample (common.h helpers: identical bits) and applies B^T d B.  Saves the 0.68 GB write
+// and re-read of the upsampled tensor per call (B = 8).  Exact x2 geometry only (Ho = 2 Hi, Wo = 2 Wi, dilation 1).
+// block = 256 threads = TXB tiles of one tile row x C/4 channel quads; grid = B * Ty * ceil(Tx / TXB)
+template <int C4N>
+__global__ __launch_bounds__(256) void wino_input_gn_up2_kernel(const float* __restrict__ t, const float* __restrict__ stats,
+                                                                const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                                int Hi, int Wi, WinoGeom g, float* __restrict__ V) {
+    constexpr int TXB = 256 / C4N, RC = TXB + 3, C = C4N * 4;    // region: 4 source rows x (TXB + 3) source columns (scale < 1/2)
+    __shared__ __attribute__((aligned(16))) float S[4 * RC * C];
+    unsigned bid = blockIdx.x;
+    {
+        const unsigned nb = gridDim.x, per = nb / 8, full = per * 8;   // XCD-contiguous order, as in wino_input_kernel
+        if (bid < full) bid = (bid % 8) * per + bid / 8;
     }
+    const int gx = (g.Tx + TXB - 1) / TXB;
+    const int txg = (int)(bid % (unsigned)gx);
+    const int ty = (int)((bid / (unsigned)gx) % (unsigned)g.Ty);
+    const int b = (int)(bid / ((unsigned)gx * (unsigned)g.Ty));
+    const int tx0 = txg * TXB;
+    const int tid = threadIdx.x;
+    // region origin = first source tap of the first output row / column this block touches
+    int yb, xb, i1_, dummy;
+    float w0_, w1_;
+    lm_bilin_axis(max(2 * ty - 1, 0), Hi, g.H, yb, i1_, w0_, w1_);
+    lm_bilin_axis(max(2 * tx0 - 1, 0), Wi, g.W, xb, dummy, w0_, w1_);
+    {
+        const int c4 = (tid % C4N) * 4;
+        f32x4 a, gg;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            float ae, ge;
+            lm_gn_affine(stats[((long)b * C + c4 + e) * 2], stats[((long)b * C + c4 + e) * 2 + 1], gamma[c4 + e], beta[c4 + e], ae, ge);
+            a[e] = ae;
+            gg[e] = ge;
+        }
+        for (int p = tid / C4N; p < 4 * RC; p += TXB) {          // (a thread keeps its channel quad: one affine for all its pixels)
+            const int ry = p / RC, rx = p % RC;
+            const int sy = min(yb + ry, Hi - 1), sx = min(xb + rx, Wi - 1);
+            f32x4 v = *reinterpret_cast<const f32x4*>(t + (((long)b * Hi + sy) * Wi + sx) * C + c4);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = lm_gn_relu(v[e], a[e], gg[e]);
+            *reinterpret_cast<f32x4*>(S + (ry * RC + rx) * C + c4) = v;
+        }
+    }
+    __syncthreads();
+    const int tx = tx0 + tid / C4N, c4 = (tid % C4N) * 4;
+    if (tx >= g.Tx) return;
+    f32x4 d[4][4];
+    int ry0[4], ry1[4], rx0[4], rx1[4];
+    float wy0[4], wy1[4], wx0[4], wx1[4];
+    bool oky[4], okx[4];
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-        const f32x4 v0 = r[i][0] - r[i][2], v1 = r[i][1] + r[i][2], v2 = r[i][2] - r[i][1], v3 = r[i][1] - r[i][3];
-        float* o = V + ((long)(4 * i) * g.T + m) * C + c4;
-        *reinterpret_cast<f32x4*>(o) = v0;
-        *reinterpret_cast<f32x4*>(o + g.T * C) = v1;
-        *reinterpret_cast<f32x4*>(o + 2 * g.T * C) = v2;
-        *reinterpret_cast<f32x4*>(o + 3 * g.T * C) = v3;
+        const int oy = 2 * ty + i - 1, ox = 2 * tx + i - 1;
+        oky[i] = (unsigned)oy < (unsigned)g.H;
+        okx[i] = (unsigned)ox < (unsigned)g.W;
+        int y0, y1, x0, x1;
+        lm_bilin_axis(oky[i] ? oy : 0, Hi, g.H, y0, y1, wy0[i], wy1[i]);
+        lm_bilin_axis(okx[i] ? ox : 0, Wi, g.W, x0, x1, wx0[i], wx1[i]);
+        ry0[i] = y0 - yb; ry1[i] = y1 - yb; rx0[i] = x0 - xb; rx1[i] = x1 - xb;
     }
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            d[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+            if (oky[i] && okx[j]) {
+                const f32x4 v00 = *reinterpret_cast<const f32x4*>(S + (ry0[i] * RC + rx0[j]) * C + c4);
+                const f32x4 v01 = *reinterpret_cast<const f32x4*>(S + (ry0[i] * RC + rx1[j]) * C + c4);
+                const f32x4 v10 = *reinterpret_cast<const f32x4*>(S + (ry1[i] * RC + rx0[j]) * C + c4);
+                const f32x4 v11 = *reinterpret_cast<const f32x4*>(S + (ry1[i] * RC + rx1[j]) * C + c4);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) d[i][j][e] = lm_bilerp(v00[e], v01[e], v10[e], v11[e], wy0[i], wy1[i], wx0[j], wx1[j]);
+            }
+        }
+    const long m = (long)b * g.Tpad + (long)ty * g.Tx + tx;      // dilation 1: one phase, row-major tiles (tile_decode)
+    transform_store(d, V, g.T, m, C, c4);
 }
 
 struct WinoParams {
@@ -487,6 +574,27 @@ LM_API int lm_winograd_input_transform_f32(void* stream, const float* x, int ldx
     const long in_threads = g.T * (Cin / 4);
     hipLaunchKernelGGL(wino_input_kernel, dim3((unsigned)((in_threads + 255) / 256)), dim3(256), 0, (hipStream_t)stream, x, ldx, g, Cin,
                        (float*)V);
+    LM_LAUNCH_CHECK();
+    return LM_OK;
+}
+
+// V of the tensor  bilinear_align_corners_x2(relu(gn(t; stats, gamma, beta)))  [B][2 Hi][2 Wi][C] that is never materialised
+// (lm_gn_relu_upsample followed by lm_winograd_input_transform_f32, bit-identical to that pair).  C = 128 or 256, dilation 1.
+LM_API int lm_winograd_input_transform_gn_up2_f32(void* stream, const float* t, const float* stats, const float* gamma, const float* beta,
+                                                  int B, int Hi, int Wi, int C, void* V, long V_bytes) {
+    LM_REQUIRE(t && stats && gamma && beta && V, "wino_input_gn_up2: null pointer");
+    LM_REQUIRE((C == 128 || C == 256) && B > 0 && Hi > 1 && Wi > 1, "wino_input_gn_up2: C=%d must be 128 or 256, source at least 2x2", C);
+    const int H = 2 * Hi, W = 2 * Wi;
+    LM_REQUIRE(lm_conv3x3_winograd_workspace_bytes(B, H, W, C, 1) <= V_bytes, "wino_input_gn_up2: V buffer too small");
+    const WinoGeom g = geom(B, H, W, 1);
+    LM_REQUIRE(g.T < (1L << 31), "wino_input_gn_up2: too many tiles");
+    const int txb = 256 / (C / 4);
+    const long blocks = (long)B * g.Ty * ((g.Tx + txb - 1) / txb);
+    LM_REQUIRE(blocks < (1L << 31), "wino_input_gn_up2: bad grid");
+    if (C == 256)
+        hipLaunchKernelGGL(wino_input_gn_up2_kernel<64>, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, t, stats, gamma, beta, Hi, Wi, g, (float*)V);
+    else
+        hipLaunchKernelGGL(wino_input_gn_up2_kernel<32>, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, t, stats, gamma, beta, Hi, Wi, g, (float*)V);
     LM_LAUNCH_CHECK();
     return LM_OK;
 }

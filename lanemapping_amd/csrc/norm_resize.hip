@@ -20,13 +20,7 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 namespace {
 
 __device__ __forceinline__ void bilin_axis(int o, int in, int out, int& i0, int& i1, float& w0, float& w1) {
-    const float scale = (out > 1) ? (float)(in - 1) / (float)(out - 1) : 0.f;
-    const float src = scale * (float)o;
-    i0 = (int)src;
-    if (i0 > in - 1) i0 = in - 1;
-    i1 = i0 + ((i0 < in - 1) ? 1 : 0);
-    w1 = fminf(fmaxf(src - (float)i0, 0.f), 1.f);
-    w0 = 1.f - w1;
+    lm_bilin_axis(o, in, out, i0, i1, w0, w1);
 }
 
 // ----------------------------------------------------------------------------- GroupNorm stats
@@ -112,21 +106,22 @@ __global__ __launch_bounds__(256) void gn_relu_upsample_kernel(const float* __re
     f32x4 a, g;   // per-channel affine of the normalisation: v*a + g
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
-        const float mean = stats[((long)b * C + c + e) * 2], rstd = stats[((long)b * C + c + e) * 2 + 1];
-        a[e] = rstd * gamma[c + e];
-        g[e] = beta[c + e] - mean * a[e];
+        float ae, ge;
+        lm_gn_affine(stats[((long)b * C + c + e) * 2], stats[((long)b * C + c + e) * 2 + 1], gamma[c + e], beta[c + e], ae, ge);
+        a[e] = ae;
+        g[e] = ge;
     }
     const float* xb = x + (long)b * Hi * Wi * C + c;
     auto tap = [&](int yy, int xx) {
         f32x4 v = *reinterpret_cast<const f32x4*>(xb + ((long)yy * Wi + xx) * C);
 #pragma unroll
-        for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e] * a[e] + g[e], 0.f);
+        for (int e = 0; e < 4; ++e) v[e] = lm_gn_relu(v[e], a[e], g[e]);
         return v;
     };
     const f32x4 v00 = tap(y0, x0), v01 = tap(y0, x1), v10 = tap(y1, x0), v11 = tap(y1, x1);
     f32x4 o;
 #pragma unroll
-    for (int e = 0; e < 4; ++e) o[e] = wy0 * (wx0 * v00[e] + wx1 * v01[e]) + wy1 * (wx0 * v10[e] + wx1 * v11[e]);
+    for (int e = 0; e < 4; ++e) o[e] = lm_bilerp(v00[e], v01[e], v10[e], v11[e], wy0, wy1, wx0, wx1);
     f32x4* yp = reinterpret_cast<f32x4*>(y + i * 4);
     if (accumulate) {
         const f32x4 prev = *yp;
@@ -194,21 +189,22 @@ __global__ __launch_bounds__(256) void gn_relu_upsample_sum_kernel(GnSum P, cons
         f32x4 a, g;
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
-            const float mean = T.stats[((long)b * C + c + e) * 2], rstd = T.stats[((long)b * C + c + e) * 2 + 1];
-            a[e] = rstd * gm[e];
-            g[e] = bt[e] - mean * a[e];
+            float ae, ge;
+            lm_gn_affine(T.stats[((long)b * C + c + e) * 2], T.stats[((long)b * C + c + e) * 2 + 1], gm[e], bt[e], ae, ge);
+            a[e] = ae;
+            g[e] = ge;
         }
         const float* xb = T.x + (long)b * T.Hi * T.Wi * C + c;
         auto tap = [&](int yy, int xx) {
             f32x4 v = *reinterpret_cast<const f32x4*>(xb + ((long)yy * T.Wi + xx) * C);
 #pragma unroll
-            for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e] * a[e] + g[e], 0.f);
+            for (int e = 0; e < 4; ++e) v[e] = lm_gn_relu(v[e], a[e], g[e]);
             return v;
         };
         const f32x4 v00 = tap(y0, x0), v01 = tap(y0, x1), v10 = tap(y1, x0), v11 = tap(y1, x1);
         f32x4 o;
 #pragma unroll
-        for (int e = 0; e < 4; ++e) o[e] = wy0 * (wx0 * v00[e] + wx1 * v01[e]) + wy1 * (wx0 * v10[e] + wx1 * v11[e]);
+        for (int e = 0; e < 4; ++e) o[e] = lm_bilerp(v00[e], v01[e], v10[e], v11[e], wy0, wy1, wx0, wx1);
         if (k == 0) {
             acc = o;
         } else {

@@ -26,6 +26,7 @@ _LAYERS = {'resnet18': [2, 2, 2, 2], 'resnet34': [3, 4, 6, 3]}
 # 1.25-1.66x the direct MFMA kernel on those shapes; the 64-channel layers stay direct).  LANEMAP_WINOGRAD=0 disables it.
 USE_WINOGRAD = os.environ.get('LANEMAP_WINOGRAD', '1') != '0'
 WINO_MIN_CIN = 128
+FUSE_UP_WINO = os.environ.get('LANEMAP_FUSE_UP_WINO', '1') != '0'    # s4: GN + ReLU + x2 upsample fused into the Winograd input transform
 
 
 class _ResBlock(nn.Module):
@@ -193,7 +194,11 @@ class FPNEncoder(PackedModule):
             return t, st
 
         t, st = conv_stats(p4, conv_a, p4.shape[1], gn_a, share='p4')
-        s4 = ops.gn_relu_upsample(t, st, P[gn_a + '.g'], P[gn_a + '.b'], (h, w))        # 256 ch at 288^2
+        if (FUSE_UP_WINO and (conv_b + '.wu') in P and (h, w) == (2 * t.shape[2], 2 * t.shape[3]) and t.shape[1] in (128, 256)):
+            # s4 feeds only conv_b: its Winograd input comes straight from t, the upsampled 256-channel tensor is never written
+            s4 = ops.wino_transform_gn_up2(t, st, P[gn_a + '.g'], P[gn_a + '.b'])
+        else:
+            s4 = ops.gn_relu_upsample(t, st, P[gn_a + '.g'], P[gn_a + '.b'], (h, w))    # 256 ch at 288^2
         terms = [conv_stats(p2, conv_b, c_half, gn_b, share='p2'),                      # s2
                  conv_stats(p3, conv_b, c_half, gn_b, share='p3'),                      # s3
                  conv_stats(s4, conv_b, c_half, gn_b)]                                  # s4

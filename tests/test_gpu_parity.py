@@ -773,6 +773,32 @@ def test_conv_winograd_vs_fp64_reference(dev, B, cin, cout, H, W, dil):
         _close(st[:, :, 1], rstd.float(), 1e-5, 'GN rstd')
 
 
+@pytest.mark.parametrize('B,C,Hi,Wi', [(2, 256, 9, 11), (1, 128, 16, 7), (3, 256, 2, 2), (1, 128, 37, 40)])
+def test_winograd_input_from_gn_relu_upsample(dev, B, C, Hi, Wi):
+    """lm_winograd_input_transform_gn_up2_f32 == lm_gn_relu_upsample followed by lm_winograd_input_transform_f32, bit for bit
+    (every real tile row of V), and the convolution fed by it matches torch."""
+    from lanemapping_amd import ops
+    g = torch.Generator().manual_seed(31)
+    t = (torch.randn(B, C, Hi, Wi, generator=g) * 2 + 0.3).to(dev).permute(0, 2, 3, 1).contiguous().permute(0, 3, 1, 2)
+    gamma, beta = (torch.rand(C, generator=g) + 0.5).to(dev), torch.randn(C, generator=g).to(dev)
+    st = ops.gn_stats(t)
+    H, W = 2 * Hi, 2 * Wi
+    up = ops.gn_relu_upsample(t, st, gamma, beta, (H, W))
+    v_ref = ops.wino_transform(up, 1, dedicated=True)
+    v_fused = ops.wino_transform_gn_up2(t, st, gamma, beta, dedicated=True)
+    Ty, Tx = (H + 1) // 2, (W + 1) // 2
+    timg = Ty * Tx
+    tpad = (timg + 127) // 128 * 128
+    a = v_ref.buf.view(torch.float32).view(16, B, tpad, C)[:, :, :timg]
+    b = v_fused.buf.view(torch.float32).view(16, B, tpad, C)[:, :, :timg]
+    assert torch.equal(a, b), float((a - b).abs().max())
+    w = torch.randn(64, C, 3, 3, generator=g) / (C * 9) ** 0.5
+    y = ops.conv_wino(v_fused, ops.pack_wino(w.to(dev)), 64, 1)
+    want = F.conv2d(F.interpolate(F.relu(F.group_norm(t.cpu().double(), C, gamma.cpu().double(), beta.cpu().double(), 1e-5)),
+                                  size=(H, W), mode='bilinear', align_corners=True), w.double(), None, 1, 1)
+    _close(y, want.float(), 2e-5, 'conv on the fused transform')
+
+
 @pytest.mark.parametrize('N', [12, 320, 321, 324, 352])
 def test_attention_vs_torch(dev, N):
     """lm_attention_f32: the MFMA kernel (321..352 tokens, padded keys masked) and the VALU kernel (other lengths) vs torch."""
