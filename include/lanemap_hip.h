@@ -36,6 +36,13 @@ int lm_conv2d_nhwc_mfma_f32(void* stream, const float* x, int ldx, const float* 
                             const float* scale, const float* shift, const float* res, int ldr, int res_rows,
                             float* y, int ldy, int B, int H, int W, int Cin, int Cout, int KH, int KW,
                             int stride, int pad_h, int pad_w, int dil, int act);
+/* Same convolution with a COARSE residual [B][Hr][Wr][ldr] added through bilinear (align_corners=True) interpolation to Ho x Wo:
+ * `_upsample_add(p_coarse, latlayer(c))` of the FPN (postprojector.py:549-561, 595-601) without writing the upsampled map.
+ * Cout, ldy, ldr multiples of 4.  Bit-identical to lm_upsample_bilinear_nhwc + lm_conv2d_nhwc_mfma_f32(res = that map). */
+int lm_conv2d_nhwc_mfma_resup_f32(void* stream, const float* x, int ldx, const float* wp, int CoutP, const float* scale,
+                                  const float* shift, const float* res_coarse, int ldr, int Hr, int Wr, float* y, int ldy,
+                                  int B, int H, int W, int Cin, int Cout, int KH, int KW, int stride, int pad_h, int pad_w,
+                                  int dil, int act);
 
 /* 3x3 / stride 1 / pad == dilation convolution through Winograd F(2x2,3x3) (same layers, 2.25x fewer multiplies; fp32 error
  * at the level of a re-ordered direct sum).  wu: transformed weights [16][CoutP][Cin] = (G g G^T)[xi = 4i + j];

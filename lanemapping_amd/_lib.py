@@ -34,6 +34,8 @@ SIGNATURES = {
     'lm_device_count': (i32, []),
     'lm_conv2d_nhwc_mfma_f32': (i32, [vp, vp, i32, vp, i32, vp, vp, vp, i32, i32, vp, i32,
                                       i32, i32, i32, i32, i32, i32, i32, i32, i32, i32, i32, i32]),
+    'lm_conv2d_nhwc_mfma_resup_f32': (i32, [vp, vp, i32, vp, i32, vp, vp, vp, i32, i32, i32, vp, i32,
+                                            i32, i32, i32, i32, i32, i32, i32, i32, i32, i32, i32, i32]),
     'lm_conv3x3_winograd_workspace_bytes': (i64, [i32, i32, i32, i32, i32]),
     'lm_winograd_gn_chunks': (i32, [i32, i32, i32]),
     'lm_winograd_input_transform_f32': (i32, [vp, vp, i32, i32, i32, i32, i32, i32, vp, i64]),

@@ -41,26 +41,31 @@ static inline int lm_cdiv(long a, long b) { return (int)((a + b - 1) / b); }
 enum { LM_ACT_NONE = 0, LM_ACT_RELU = 1, LM_ACT_GELU = 2 };
 
 #ifdef __HIPCC__
-// GroupNorm(C,C) + ReLU + bilinear (align_corners=True) building blocks with a FIXED operation order (explicit mul / add / fma, no
-// compiler contraction): the same bits in every kernel that uses them (norm_resize.hip, the fused Winograd input transform).
+// GroupNorm(C,C) + ReLU + bilinear (align_corners=True) building blocks with a FIXED operation order: `#pragma clang fp contract(off)`
+// keeps the compiler from fusing their multiplies and adds differently in different kernels (HIP's __fmul_rn / __fadd_rn are plain
+// operators and do not prevent that), explicit fmaf where a fused multiply-add is wanted.  The same bits in every kernel that uses
+// them (norm_resize.hip, the fused Winograd input transform, the bilinear residual of the convolution epilogue).
 // Source index follows ATen: scale = (in-1)/(out-1) in fp32, src = scale*dst, i0 = floor(src), i1 = min(i0+1, in-1), w1 = src - i0.
 __device__ __forceinline__ void lm_bilin_axis(int o, int in, int out, int& i0, int& i1, float& w0, float& w1) {
+#pragma clang fp contract(off)
     const float scale = (out > 1) ? (float)(in - 1) / (float)(out - 1) : 0.f;
-    const float src = __fmul_rn(scale, (float)o);
+    const float src = scale * (float)o;
     i0 = (int)src;
     if (i0 > in - 1) i0 = in - 1;
     i1 = i0 + ((i0 < in - 1) ? 1 : 0);
-    w1 = fminf(fmaxf(__fsub_rn(src, (float)i0), 0.f), 1.f);
-    w0 = __fsub_rn(1.f, w1);
+    w1 = fminf(fmaxf(src - (float)i0, 0.f), 1.f);
+    w0 = 1.f - w1;
 }
 __device__ __forceinline__ void lm_gn_affine(float mean, float rstd, float gamma, float beta, float& a, float& g) {
-    a = __fmul_rn(rstd, gamma);              // gn(v) = v * a + g
-    g = __fmaf_rn(-mean, a, beta);
+#pragma clang fp contract(off)
+    a = rstd * gamma;                        // gn(v) = v * a + g
+    g = __builtin_fmaf(-mean, a, beta);
 }
-__device__ __forceinline__ float lm_gn_relu(float v, float a, float g) { return fmaxf(__fmaf_rn(v, a, g), 0.f); }
+__device__ __forceinline__ float lm_gn_relu(float v, float a, float g) { return fmaxf(__builtin_fmaf(v, a, g), 0.f); }
 __device__ __forceinline__ float lm_bilerp(float v00, float v01, float v10, float v11, float wy0, float wy1, float wx0, float wx1) {
-    const float top = __fadd_rn(__fmul_rn(wx0, v00), __fmul_rn(wx1, v01));
-    const float bot = __fadd_rn(__fmul_rn(wx0, v10), __fmul_rn(wx1, v11));
-    return __fadd_rn(__fmul_rn(wy0, top), __fmul_rn(wy1, bot));
+#pragma clang fp contract(off)
+    const float top = wx0 * v00 + wx1 * v01;
+    const float bot = wx0 * v10 + wx1 * v11;
+    return wy0 * top + wy1 * bot;
 }
 #endif

@@ -42,6 +42,7 @@ struct ConvParams {
     const int* nbr;    // gather mode (sparse convolution): [M][taps] input row of every (output row, tap), -1 = inactive site
     double* gn_part;   // optional [B][chunks][Cout][2] per-channel (sum, sum of squares) of the outputs of each wave tile
     int gn_chunks;     // chunks per batch element = (Ho*Wo / BM) * (BM / WM)
+    int res_hi, res_wi; // > 0: `res` is a coarse [B][res_hi][res_wi][ldr] map added through bilinear (align_corners) interpolation
 };
 
 __device__ __forceinline__ float gelu_erf(float v) { return 0.5f * v * (1.0f + erff(v * 0.70710678118654752440f)); }
@@ -255,7 +256,25 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64) void conv_mfma_kernel(C
             }
             const long rrow = p.res_rows ? (m % p.res_rows) : m;
             if (vec) {
-                if (p.res) {
+                if (p.res && p.res_hi) {
+                    // residual = F.interpolate(coarse, size=(Ho, Wo), bilinear, align_corners=True)[m]: `_upsample_add` of the FPN
+                    // (postprojector.py:549-561) without materialising the upsampled map; same fixed-order blend as
+                    // lm_upsample_bilinear_nhwc (common.h), so the sum is bit-identical to adding that kernel's output
+                    const unsigned mm = (unsigned)m;
+                    const int ox = (int)(mm % (unsigned)p.Wo), q = (int)(mm / (unsigned)p.Wo);
+                    const int oy = q % p.Ho, bi = q / p.Ho;
+                    int y0, y1, x0, x1;
+                    float wy0, wy1, wx0, wx1;
+                    lm_bilin_axis(oy, p.res_hi, p.Ho, y0, y1, wy0, wy1);
+                    lm_bilin_axis(ox, p.res_wi, p.Wo, x0, x1, wx0, wx1);
+                    const float* rb = p.res + (long)bi * p.res_hi * p.res_wi * p.ldr + n;
+                    const f32x4 r00 = *reinterpret_cast<const f32x4*>(rb + ((long)y0 * p.res_wi + x0) * p.ldr);
+                    const f32x4 r01 = *reinterpret_cast<const f32x4*>(rb + ((long)y0 * p.res_wi + x1) * p.ldr);
+                    const f32x4 r10 = *reinterpret_cast<const f32x4*>(rb + ((long)y1 * p.res_wi + x0) * p.ldr);
+                    const f32x4 r11 = *reinterpret_cast<const f32x4*>(rb + ((long)y1 * p.res_wi + x1) * p.ldr);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] += lm_bilerp(r00[e], r01[e], r10[e], r11[e], wy0, wy1, wx0, wx1);
+                } else if (p.res) {
                     const f32x4 rr = *reinterpret_cast<const f32x4*>(p.res + rrow * p.ldr + n);
 #pragma unroll
                     for (int e = 0; e < 4; ++e) v[e] += rr[e];
@@ -332,7 +351,8 @@ int zero_block(const float** out) {   // device address of the 16 zero bytes, re
 
 static int conv_dispatch(void* stream, const float* x, int ldx, const float* wp, int CoutP, const float* scale, const float* shift,
                          const float* res, int ldr, int res_rows, float* y, int ldy, int B, int H, int W, int Cin, int Cout,
-                         int KH, int KW, int stride, int pad_h, int pad_w, int dil, int act, double* gn_part) {
+                         int KH, int KW, int stride, int pad_h, int pad_w, int dil, int act, double* gn_part, int res_hi = 0,
+                         int res_wi = 0) {
     LM_REQUIRE(x && wp && y, "conv_mfma: null pointer");
     LM_REQUIRE(Cin > 0 && Cin % BK == 0, "conv_mfma: Cin=%d must be a multiple of %d", Cin, BK);
     LM_REQUIRE(CoutP >= Cout && CoutP % 128 == 0, "conv_mfma: CoutP=%d must be Cout=%d rounded up to 128", CoutP, Cout);
@@ -341,6 +361,7 @@ static int conv_dispatch(void* stream, const float* x, int ldx, const float* wp,
     ConvParams p;
     p.x = x; p.wp = wp; p.scale = scale; p.shift = shift; p.res = res; p.y = y;
     p.ldx = ldx; p.ldr = ldr; p.ldy = ldy; p.res_rows = res_rows;
+    p.res_hi = res_hi; p.res_wi = res_wi;
     p.B = B; p.H = H; p.W = W; p.Cin = Cin; p.Cout = Cout; p.CoutP = CoutP;
     p.Ho = (H + 2 * pad_h - dil * (KH - 1) - 1) / stride + 1;
     p.Wo = (W + 2 * pad_w - dil * (KW - 1) - 1) / stride + 1;
@@ -392,6 +413,22 @@ LM_API int lm_conv2d_nhwc_mfma_f32_gnstats(void* stream, const float* x, int ldx
                          pad_h, pad_w, dil, LM_ACT_NONE, gn_partial);
 }
 
+// Convolution whose residual is a COARSE map added through bilinear interpolation (align_corners=True): the FPN's
+// `_upsample_add(p_coarse, latlayer(c))` (postprojector.py:549-561, 595-601) in one kernel - the upsampled map is never written.
+// res_coarse: [B][Hr][Wr][ldr]; vector path only (Cout, ldy, ldr multiples of 4).  Bit-identical to lm_upsample_bilinear_nhwc
+// followed by lm_conv2d_nhwc_mfma_f32 with that map as the residual.
+LM_API int lm_conv2d_nhwc_mfma_resup_f32(void* stream, const float* x, int ldx, const float* wp, int CoutP, const float* scale,
+                                         const float* shift, const float* res_coarse, int ldr, int Hr, int Wr, float* y, int ldy,
+                                         int B, int H, int W, int Cin, int Cout, int KH, int KW, int stride, int pad_h, int pad_w,
+                                         int dil, int act) {
+    LM_REQUIRE(res_coarse && Hr > 0 && Wr > 0, "conv_mfma(resup): missing coarse residual");
+    LM_REQUIRE(Cout % 4 == 0 && ldy % 4 == 0 && ldr % 4 == 0 && ldr >= Cout, "conv_mfma(resup): Cout=%d, ldy=%d, ldr=%d must be multiples of 4", Cout, ldy, ldr);
+    const long Ho = (H + 2 * pad_h - dil * (KH - 1) - 1) / stride + 1, Wo = (W + 2 * pad_w - dil * (KW - 1) - 1) / stride + 1;
+    LM_REQUIRE((long)B * Ho * Wo < (1L << 31), "conv_mfma(resup): too many output pixels for 32-bit indices");
+    return conv_dispatch(stream, x, ldx, wp, CoutP, scale, shift, res_coarse, ldr, 0, y, ldy, B, H, W, Cin, Cout, KH, KW, stride,
+                         pad_h, pad_w, dil, act, nullptr, Hr, Wr);
+}
+
 // Sparse (rulebook) convolution on the same MFMA pipeline: output row m accumulates, for every kernel tap t, the feature row
 // nbr[m][t] of x (skipped when -1).  Covers spconv's SubMConv3d and SparseConv3d as used by mmdet3d's SparseEncoder, which
 // the reference's LidarEncoder instantiates (baseline/models/pcencoder/lidarencoder.py:29-35,93-102); the rulebook comes
@@ -412,6 +449,7 @@ LM_API int lm_conv_gather_mfma_f32(void* stream, const float* x, int ldx, const 
     ConvParams p;
     p.x = x; p.wp = wp; p.scale = scale; p.shift = shift; p.res = res; p.y = y;
     p.ldx = ldx; p.ldr = ldr; p.ldy = ldy; p.res_rows = 0;
+    p.res_hi = 0; p.res_wi = 0;
     p.B = 1; p.H = 1; p.W = 1; p.Cin = pairs ? BK : Cin; p.Cout = Cout; p.CoutP = CoutP; p.Ho = 1; p.Wo = 1;
     p.KH = 1; p.KW = slabs; p.stride = 1; p.pad_h = 0; p.pad_w = 0; p.dil = 1; p.act = act;
     p.M = M;

@@ -275,7 +275,7 @@ __global__ __launch_bounds__(256) void upsample_nhwc_kernel(const float* __restr
     const long opix = ((long)b * Ho + oy) * Wo + ox;
     f32x4 o;
 #pragma unroll
-    for (int e = 0; e < 4; ++e) o[e] = wy0 * (wx0 * v00[e] + wx1 * v01[e]) + wy1 * (wx0 * v10[e] + wx1 * v11[e]);
+    for (int e = 0; e < 4; ++e) o[e] = lm_bilerp(v00[e], v01[e], v10[e], v11[e], wy0, wy1, wx0, wx1);
     if (add) {
         const f32x4 r = *reinterpret_cast<const f32x4*>(add + opix * lda + c);
 #pragma unroll

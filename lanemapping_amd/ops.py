@@ -99,7 +99,9 @@ def set_conv_hook(fn):
 
 
 def conv_mfma(x, wp, cout, kh=1, kw=1, stride=1, pad=0, dil=1, scale=None, shift=None, res=None, act=ACT_NONE,
-              out=None, res_rows=0):
+              out=None, res_rows=0, res_up=None):
+    """res_up: a COARSE [B,cout,Hr,Wr] map that is added through bilinear (align_corners) interpolation to the output size inside the
+    epilogue (`_upsample_add` of the FPN) - the upsampled map is never written."""
     x, ldx = as_nhwc(x)
     B, cin, H, W = x.shape
     ph, pw = (pad, pad) if isinstance(pad, int) else pad
@@ -115,7 +117,17 @@ def conv_mfma(x, wp, cout, kh=1, kw=1, stride=1, pad=0, dil=1, scale=None, shift
             res, ldr = as_nhwc(res)
         else:
             ldr = res.stride(0)
+    if res_up is not None:
+        assert res is None and res_rows == 0
+        ru, ldu = as_nhwc(res_up)
+        assert ru.shape[0] == B and ru.shape[1] == cout
+
     def launch():
+        if res_up is not None:
+            check(lib().lm_conv2d_nhwc_mfma_resup_f32(_stream(), _ptr(x), ldx, _ptr(wp), wp.shape[1], _ptr(scale), _ptr(shift),
+                                                      _ptr(ru), ldu, ru.shape[2], ru.shape[3], _ptr(out), ldy, B, H, W, cin, cout,
+                                                      kh, kw, stride, ph, pw, dil, act))
+            return
         check(lib().lm_conv2d_nhwc_mfma_f32(_stream(), _ptr(x), ldx, _ptr(wp), wp.shape[1], _ptr(scale), _ptr(shift),
                                             _ptr(res), ldr, res_rows, _ptr(out), ldy, B, H, W, cin, cout, kh, kw,
                                             stride, ph, pw, dil, act))

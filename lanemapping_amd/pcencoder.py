@@ -218,11 +218,16 @@ class FPNEncoder(PackedModule):
         c2, c3, c4 = feats
         fea = ops.conv_mfma(c4, P['out.w'], self.out.out_channels) if self.out is not None else None
         p4 = ops.conv_mfma(c4, P['toplayer.w'], 256, shift=P['toplayer.b'])
-        up4 = ops.upsample_nhwc(p4, c3.shape[2:])
-        p3 = ops.conv_mfma(c3, P['latlayer1.w'], 256, shift=P['latlayer1.b'], res=up4)
-        up3 = ops.upsample_nhwc(p3, c2.shape[2:])
-        p2 = ops.conv_mfma(c2, P['latlayer2.w'], 256, shift=P['latlayer2.b'], res=up3)
-        del up4, up3, c1, c2, c3, c4, feats, t
+        # _upsample_add: the coarse map enters the lateral 1x1 convolution's epilogue through bilinear interpolation (a plain residual
+        # when the sizes agree, as for p4 -> c3 under the dilated layer3)
+        def lateral(c, name, coarse):
+            if tuple(coarse.shape[2:]) == tuple(c.shape[2:]):
+                return ops.conv_mfma(c, P[name + '.w'], 256, shift=P[name + '.b'], res=coarse)
+            return ops.conv_mfma(c, P[name + '.w'], 256, shift=P[name + '.b'], res_up=coarse)
+
+        p3 = lateral(c3, 'latlayer1', p4)
+        p2 = lateral(c2, 'latlayer2', p3)
+        del c1, c2, c3, c4, feats, t
         p4 = self._conv3(p4, P, 'smooth1', 256)
         p3 = self._conv3(p3, P, 'smooth2', 256)
         p2 = self._conv3(p2, P, 'smooth3', 256)

@@ -773,6 +773,25 @@ def test_conv_winograd_vs_fp64_reference(dev, B, cin, cout, H, W, dil):
         _close(st[:, :, 1], rstd.float(), 1e-5, 'GN rstd')
 
 
+@pytest.mark.parametrize('B,cin,cout,H,W,Hr,Wr,k', [(2, 64, 256, 24, 28, 12, 14, 1), (1, 32, 64, 17, 9, 5, 4, 1), (1, 64, 128, 20, 20, 7, 20, 3)])
+def test_conv_with_upsampled_residual(dev, B, cin, cout, H, W, Hr, Wr, k):
+    """lm_conv2d_nhwc_mfma_resup_f32 (`_upsample_add` in the epilogue) == upsample kernel + conv with that residual, bit for bit, and
+    == torch within fp32 tolerance."""
+    from lanemapping_amd import ops
+    g = torch.Generator().manual_seed(41)
+    nhwc = lambda t: t.to(dev).permute(0, 2, 3, 1).contiguous().permute(0, 3, 1, 2)
+    x, coarse = torch.randn(B, cin, H, W, generator=g), torch.randn(B, cout, Hr, Wr, generator=g)
+    w = torch.randn(cout, cin, k, k, generator=g) / (cin * k * k) ** 0.5
+    bias = torch.randn(cout, generator=g)
+    wp = ops.pack_mfma(w.to(dev))
+    xd, cd = nhwc(x), nhwc(coarse)
+    fused = ops.conv_mfma(xd, wp, cout, k, k, 1, k // 2, shift=bias.to(dev), res_up=cd, act=ops.ACT_RELU)
+    two = ops.conv_mfma(xd, wp, cout, k, k, 1, k // 2, shift=bias.to(dev), res=ops.upsample_nhwc(cd, (H, W)), act=ops.ACT_RELU)
+    assert torch.equal(fused, two), float((fused - two).abs().max())
+    want = F.relu(F.conv2d(x, w, bias, 1, k // 2) + F.interpolate(coarse, size=(H, W), mode='bilinear', align_corners=True))
+    _close(fused, want, 2e-5, 'conv + upsampled residual')
+
+
 @pytest.mark.parametrize('B,C,Hi,Wi', [(2, 256, 9, 11), (1, 128, 16, 7), (3, 256, 2, 2), (1, 128, 37, 40)])
 def test_winograd_input_from_gn_relu_upsample(dev, B, C, Hi, Wi):
     """lm_winograd_input_transform_gn_up2_f32 == lm_gn_relu_upsample followed by lm_winograd_input_transform_f32, bit for bit
