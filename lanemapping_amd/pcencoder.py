@@ -25,7 +25,7 @@ _LAYERS = {'resnet18': [2, 2, 2, 2], 'resnet34': [3, 4, 6, 3]}
 # 3x3 / stride-1 convolutions with >= WINO_MIN_CIN input channels go through Winograd F(2x2,3x3) (csrc/conv_wino.hip:
 # 1.25-1.66x the direct MFMA kernel on those shapes; the 64-channel layers stay direct).  LANEMAP_WINOGRAD=0 disables it.
 USE_WINOGRAD = os.environ.get('LANEMAP_WINOGRAD', '1') != '0'
-WINO_MIN_CIN = 128
+WINO_MIN_CIN = int(os.environ.get('LANEMAP_WINO_MIN_CIN', '128'))
 FUSE_UP_WINO = os.environ.get('LANEMAP_FUSE_UP_WINO', '1') != '0'    # s4: GN + ReLU + x2 upsample fused into the Winograd input transform
 
 
