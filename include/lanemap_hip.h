@@ -97,13 +97,14 @@ int lm_gn_relu_upsample(void* stream, const float* x, const float* stats, const 
 /* y = ((t0 + t1) + t2), t_k = bilinear_align_corners(relu(gn(x[k]; stats[k], gamma, beta))) from Hi[k] x Wi[k] to Ho x Wo, n <= 3
  * terms sharing gamma / beta: `s2 + s3 + s4` of one semantic branch (postprojector.py:615-621, :641-647) in one pass. */
 int lm_gn_relu_upsample_sum(void* stream, int n, const float* const* x, const float* const* stats, const int* Hi, const int* Wi,
-                            const float* gamma, const float* beta, float* y, int B, int Ho, int Wo, int C);
+                            const int* ldx /* floats between pixels per term, NULL = C */, const float* gamma, const float* beta,
+                            float* y, int B, int Ho, int Wo, int C);
 /* The same sum followed by a 1x1 convolution y1[pixel][0..cout) = sum[pixel][:] @ w + bias (cout <= 8; w_c16 = [C][16] layout of
  * lm_conv2d_nhwc_small; C/4 a power of two <= 64): feature_layer / output_layer_endp (postprojector.py:628-651).  y may be NULL: the
  * C-channel sum is then never written. */
 int lm_gn_relu_upsample_sum_conv1x1(void* stream, int n, const float* const* x, const float* const* stats, const int* Hi, const int* Wi,
-                                    const float* gamma, const float* beta, float* y, int B, int Ho, int Wo, int C, const float* w_c16,
-                                    const float* bias, int cout, float* y1, int ldy1);
+                                    const int* ldx, const float* gamma, const float* beta, float* y, int B, int Ho, int Wo, int C,
+                                    const float* w_c16, const float* bias, int cout, float* y1, int ldy1);
 int lm_upsample_bilinear_nhwc(void* stream, const float* x, int ldx, const float* add, int lda, float* y, int ldy,
                               int B, int Hi, int Wi, int Ho, int Wo, int C);
 int lm_upsample_bilinear_to_chw(void* stream, const float* x, int ldx, float* y_chw, int B, int Hi, int Wi,

@@ -50,8 +50,8 @@ SIGNATURES = {
     'lm_gn_stats': (i32, [vp, vp, vp, vp, i32, i32, i32, f32]),
     'lm_gn_stats_workspace_bytes': (i64, [i32, i32, i32]),
     'lm_gn_relu_upsample': (i32, [vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32]),
-    'lm_gn_relu_upsample_sum': (i32, [vp, i32, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32]),
-    'lm_gn_relu_upsample_sum_conv1x1': (i32, [vp, i32, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, vp, vp, i32, vp, i32]),
+    'lm_gn_relu_upsample_sum': (i32, [vp, i32, vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32]),
+    'lm_gn_relu_upsample_sum_conv1x1': (i32, [vp, i32, vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, vp, vp, i32, vp, i32]),
     'lm_upsample_bilinear_nhwc': (i32, [vp, vp, i32, vp, i32, vp, i32, i32, i32, i32, i32, i32, i32]),
     'lm_upsample_bilinear_to_chw': (i32, [vp, vp, i32, vp, i32, i32, i32, i32, i32, i32]),
     'lm_layernorm_rows': (i32, [vp, vp, vp, vp, vp, i64, i32, f32]),

@@ -138,7 +138,7 @@ __global__ __launch_bounds__(256) void gn_relu_upsample_kernel(const float* __re
 struct GnTerm {
     const float* x;
     const float* stats;
-    int Hi, Wi;
+    int Hi, Wi, ld;      // ld: floats between pixels of x (>= C: a term may be a channel slice of a wider tensor)
 };
 struct GnSum {
     GnTerm t[3];
@@ -194,9 +194,9 @@ __global__ __launch_bounds__(256) void gn_relu_upsample_sum_kernel(GnSum P, cons
             a[e] = ae;
             g[e] = ge;
         }
-        const float* xb = T.x + (long)b * T.Hi * T.Wi * C + c;
+        const float* xb = T.x + (long)b * T.Hi * T.Wi * T.ld + c;
         auto tap = [&](int yy, int xx) {
-            f32x4 v = *reinterpret_cast<const f32x4*>(xb + ((long)yy * T.Wi + xx) * C);
+            f32x4 v = *reinterpret_cast<const f32x4*>(xb + ((long)yy * T.Wi + xx) * T.ld);
 #pragma unroll
             for (int e = 0; e < 4; ++e) v[e] = lm_gn_relu(v[e], a[e], g[e]);
             return v;
@@ -390,8 +390,8 @@ LM_API int lm_gn_relu_upsample(void* stream, const float* x, const float* stats,
 }
 
 namespace {
-int launch_gn_sum(void* stream, int n, const float* const* x, const float* const* stats, const int* Hi, const int* Wi, const float* gamma,
-                  const float* beta, float* y, int B, int Ho, int Wo, int C, Proj1x1 Q) {
+int launch_gn_sum(void* stream, int n, const float* const* x, const float* const* stats, const int* Hi, const int* Wi, const int* ldx,
+                  const float* gamma, const float* beta, float* y, int B, int Ho, int Wo, int C, Proj1x1 Q) {
     LM_REQUIRE(n >= 1 && n <= 3 && x && stats && Hi && Wi && gamma && beta && C > 0 && C % 4 == 0, "gn_relu_upsample_sum: bad args");
     const long total4 = (long)B * Ho * Wo * (C / 4);
     LM_REQUIRE(total4 > 0 && total4 < (1L << 31), "gn_relu_upsample_sum: %ld output quads do not fit 32-bit indices", total4);
@@ -400,7 +400,9 @@ int launch_gn_sum(void* stream, int n, const float* const* x, const float* const
     for (int k = 0; k < 3; ++k) {
         const int q = k < n ? k : 0;
         LM_REQUIRE(x[q] && stats[q] && Hi[q] > 0 && Wi[q] > 0, "gn_relu_upsample_sum: bad term %d", q);
-        P.t[k] = GnTerm{x[q], stats[q], Hi[q], Wi[q]};
+        const int ld = ldx ? ldx[q] : C;
+        LM_REQUIRE(ld >= C && ld % 4 == 0, "gn_relu_upsample_sum: bad leading dimension %d of term %d", ld, q);
+        P.t[k] = GnTerm{x[q], stats[q], Hi[q], Wi[q], ld};
     }
     hipLaunchKernelGGL(gn_relu_upsample_sum_kernel, dim3((unsigned)lm_cdiv(total4, 256)), dim3(256), 0, (hipStream_t)stream, P, gamma, beta,
                        y, Ho, Wo, C, (unsigned)total4, Q);
@@ -410,21 +412,21 @@ int launch_gn_sum(void* stream, int n, const float* const* x, const float* const
 }  // namespace
 
 LM_API int lm_gn_relu_upsample_sum(void* stream, int n, const float* const* x, const float* const* stats, const int* Hi, const int* Wi,
-                                   const float* gamma, const float* beta, float* y, int B, int Ho, int Wo, int C) {
+                                   const int* ldx, const float* gamma, const float* beta, float* y, int B, int Ho, int Wo, int C) {
     LM_REQUIRE(y, "gn_relu_upsample_sum: null output");
-    return launch_gn_sum(stream, n, x, stats, Hi, Wi, gamma, beta, y, B, Ho, Wo, C, Proj1x1{nullptr, nullptr, nullptr, 0, 0});
+    return launch_gn_sum(stream, n, x, stats, Hi, Wi, ldx, gamma, beta, y, B, Ho, Wo, C, Proj1x1{nullptr, nullptr, nullptr, 0, 0});
 }
 
 // Same sum followed by a 1x1 convolution y1 = sum @ w + bias (cout <= 8, w in the [C][16] layout of lm_conv2d_nhwc_small) computed from
 // registers; y may be NULL, in which case the C-channel sum is never written (feature_layer / output_layer_endp read nothing else).
 LM_API int lm_gn_relu_upsample_sum_conv1x1(void* stream, int n, const float* const* x, const float* const* stats, const int* Hi,
-                                           const int* Wi, const float* gamma, const float* beta, float* y, int B, int Ho, int Wo, int C,
-                                           const float* w_c16, const float* bias, int cout, float* y1, int ldy1) {
+                                           const int* Wi, const int* ldx, const float* gamma, const float* beta, float* y, int B, int Ho,
+                                           int Wo, int C, const float* w_c16, const float* bias, int cout, float* y1, int ldy1) {
     LM_REQUIRE(w_c16 && y1 && cout >= 1 && cout <= 8 && ldy1 >= cout, "gn_relu_upsample_sum_conv1x1: bad projection (cout=%d)", cout);
     const int c4n = C / 4;
     LM_REQUIRE(C % 4 == 0 && c4n >= 8 && c4n <= 64 && (c4n & (c4n - 1)) == 0,
                "gn_relu_upsample_sum_conv1x1: C=%d: C/4 must be a power of two in [8, 64] (one pixel per wave segment)", C);
-    return launch_gn_sum(stream, n, x, stats, Hi, Wi, gamma, beta, y, B, Ho, Wo, C, Proj1x1{w_c16, bias, y1, cout, ldy1});
+    return launch_gn_sum(stream, n, x, stats, Hi, Wi, ldx, gamma, beta, y, B, Ho, Wo, C, Proj1x1{w_c16, bias, y1, cout, ldy1});
 }
 
 LM_API int lm_upsample_bilinear_nhwc(void* stream, const float* x, int ldx, const float* add, int lda, float* y, int ldy,

@@ -323,17 +323,18 @@ def gn_relu_upsample_sum(terms, gamma, beta, size, out=None, proj=None, keep_sum
     proj = (w16, bias, cout[, out1]): also returns the 1x1 convolution of the sum (cout <= 8, weights packed by pack_small), computed
     from registers; with keep_sum=False the sum itself is never written and only the projection is returned."""
     n = len(terms)
-    xs = [as_nhwc(x) for x, _ in terms]
+    xs = [as_nhwc(x) for x, _ in terms]             # a term may be a channel slice of a wider NHWC tensor (ld > C)
     B, C_ = xs[0][0].shape[:2]
     for (x, ld) in xs:
-        assert ld == C_ and x.shape[0] == B and x.shape[1] == C_
+        assert ld >= C_ and ld % 4 == 0 and x.shape[0] == B and x.shape[1] == C_
     Ho, Wo = size
     dev = xs[0][0].device
     if out is None and (keep_sum or proj is None):
         out = new_act(B, C_, Ho, Wo, dev)
     vp_arr, i_arr = C.c_void_p * n, C.c_int * n
     head = (_stream(), n, vp_arr(*[_ptr(x) for x, _ in xs]), vp_arr(*[_ptr(st) for _, st in terms]),
-            i_arr(*[x.shape[2] for x, _ in xs]), i_arr(*[x.shape[3] for x, _ in xs]), _ptr(gamma), _ptr(beta))
+            i_arr(*[x.shape[2] for x, _ in xs]), i_arr(*[x.shape[3] for x, _ in xs]), i_arr(*[ld for _, ld in xs]),
+            _ptr(gamma), _ptr(beta))
     if proj is None:
         check(lib().lm_gn_relu_upsample_sum(*head, _ptr(out), B, Ho, Wo, C_))
         return out

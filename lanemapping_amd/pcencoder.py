@@ -26,6 +26,7 @@ _LAYERS = {'resnet18': [2, 2, 2, 2], 'resnet34': [3, 4, 6, 3]}
 # 1.25-1.66x the direct MFMA kernel on those shapes; the 64-channel layers stay direct).  LANEMAP_WINOGRAD=0 disables it.
 USE_WINOGRAD = os.environ.get('LANEMAP_WINOGRAD', '1') != '0'
 WINO_MIN_CIN = int(os.environ.get('LANEMAP_WINO_MIN_CIN', '128'))
+MERGE_BRANCH_CONVS = os.environ.get('LANEMAP_MERGE_BRANCH_CONVS', '1') != '0'   # conv_b of both semantic branches on p2 / p3 as one GEMM
 FUSE_UP_WINO = os.environ.get('LANEMAP_FUSE_UP_WINO', '1') != '0'    # s4: GN + ReLU + x2 upsample fused into the Winograd input transform
 
 
@@ -140,6 +141,13 @@ class FPNEncoder(PackedModule):
             P[name + '.b'] = m.bias.float().contiguous()
             if USE_WINOGRAD and m.kernel_size == (3, 3) and m.in_channels >= WINO_MIN_CIN:
                 P[name + '.wu'] = ops.pack_wino(m.weight)
+        # the two branches convolve p2 and p3 with different weights: one GEMM with the output channels concatenated reads V once
+        # per 4 N tiles instead of per 2 (same values per channel: an output column does not depend on its neighbours)
+        a, b2 = self.semantic_branch, self.semantic_branch2
+        if (MERGE_BRANCH_CONVS and 'semantic_branch.wu' in P and 'semantic_branch2.wu' in P and a.out_channels == b2.out_channels
+                and self.gn11.eps == self.gn21.eps):
+            P['semantic_branch_ab.wu'] = ops.pack_wino(torch.cat([a.weight, b2.weight], dim=0))
+            P['semantic_branch_ab.b'] = torch.cat([a.bias, b2.bias]).float().contiguous()
         if self.out is not None:
             P['out.w'] = ops.pack_mfma(self.out.weight)
         for name in ('feature_layer', 'output_layer_binary_seg', 'output_layer_endp'):
@@ -169,7 +177,7 @@ class FPNEncoder(PackedModule):
     def _conv3(self, x, P, name, cout):
         return self._c3(x, P, name + '.w', cout, 1, 1, shift=P[name + '.b'])
 
-    def _semantic(self, P, p2, p3, p4, conv_a, gn_a, conv_b, gn_b, shared, proj):
+    def _semantic(self, P, p2, p3, p4, conv_a, gn_a, conv_b, gn_b, shared, proj, pre=None):
         """One of the two branches (reference :615-621 / :641-647): s2 + s3 + s4 at p2's size, followed by the branch's 1x1 output
         layer `proj` = (packed weight, bias, cout, out) - the only consumer of the sum, so the 128-channel sum is never written
         (lm_gn_relu_upsample_sum_conv1x1).  `shared` caches the Winograd input transforms of p2 / p3 / p4, which both branches
@@ -199,9 +207,12 @@ class FPNEncoder(PackedModule):
             s4 = ops.wino_transform_gn_up2(t, st, P[gn_a + '.g'], P[gn_a + '.b'])
         else:
             s4 = ops.gn_relu_upsample(t, st, P[gn_a + '.g'], P[gn_a + '.b'], (h, w))    # 256 ch at 288^2
-        terms = [conv_stats(p2, conv_b, c_half, gn_b, share='p2'),                      # s2
-                 conv_stats(p3, conv_b, c_half, gn_b, share='p3'),                      # s3
-                 conv_stats(s4, conv_b, c_half, gn_b)]                                  # s4
+        if pre is not None:                                                             # s2, s3 from the merged GEMMs (channel slices)
+            terms = [pre[0], pre[1]]
+        else:
+            terms = [conv_stats(p2, conv_b, c_half, gn_b, share='p2'),                  # s2
+                     conv_stats(p3, conv_b, c_half, gn_b, share='p3')]                  # s3
+        terms.append(conv_stats(s4, conv_b, c_half, gn_b))                              # s4
         # (s2 + s3) + s4, each term GN + ReLU + bilinear to p2's size, and the 1x1 output layer, in one pass
         return ops.gn_relu_upsample_sum(terms, P[gn_b + '.g'], P[gn_b + '.b'], (h, w), proj=proj, keep_sum=False)
 
@@ -232,12 +243,21 @@ class FPNEncoder(PackedModule):
         p3 = self._conv3(p3, P, 'smooth2', 256)
         p2 = self._conv3(p2, P, 'smooth3', 256)
         shared = {}
+        pre_a = pre_b = None
+        if 'semantic_branch_ab.wu' in P:
+            ch = self.semantic_branch.out_channels
+            pre_a, pre_b = [], []
+            for key, src in (('p2', p2), ('p3', p3)):
+                shared[key] = ops.wino_transform(src, 1, dedicated=True)
+                t, st = ops.conv_wino(shared[key], P['semantic_branch_ab.wu'], 2 * ch, 1, shift=P['semantic_branch_ab.b'], gn_eps=self.gn11.eps)
+                pre_a.append((t[:, :ch], st[:, :ch].contiguous()))
+                pre_b.append((t[:, ch:], st[:, ch:].contiguous()))
         fea_up = self._semantic(P, p2, p3, p4, 'conv2', 'gn12', 'semantic_branch', 'gn11', shared,
-                                (P['feature_layer.w'], P['feature_layer.b'], 8, fea_up_out))
+                                (P['feature_layer.w'], P['feature_layer.b'], 8, fea_up_out), pre_a)
         seg288 = ops.conv_small(fea_up, P['output_layer_binary_seg.w'], 3, shift=P['output_layer_binary_seg.b'], pre_relu=True)
         bi_seg = ops.upsample_to_chw(seg288, (H, W))
         endp288 = self._semantic(P, p2, p3, p4, 'conv3', 'gn22', 'semantic_branch2', 'gn21', shared,
-                                 (P['output_layer_endp.w'], P['output_layer_endp.b'], 1, None))
+                                 (P['output_layer_endp.w'], P['output_layer_endp.b'], 1, None), pre_b)
         del shared
         endp = ops.upsample_to_chw(endp288, (H, W))
         return fea, fea_up, bi_seg, endp
