@@ -57,8 +57,8 @@ int lm_winograd_input_transform_f32(void* stream, const float* x, int ldx, int B
 /* V of bilinear_align_corners_x2(relu(gn(t; stats, gamma, beta))) [B][2Hi][2Wi][C] without materialising that tensor: the FPN's
  * s4 = _upsample(relu(gn(conv(p4)))) feeding one 3x3 convolution (postprojector.py:615-621).  Bit-identical to lm_gn_relu_upsample
  * followed by lm_winograd_input_transform_f32.  C = 128 or 256. */
-int lm_winograd_input_transform_gn_up2_f32(void* stream, const float* t, const float* stats, const float* gamma, const float* beta,
-                                           int B, int Hi, int Wi, int C, void* V, long V_bytes);
+int lm_winograd_input_transform_gn_up2_f32(void* stream, const float* t, int ldt, const float* stats, const float* gamma,
+                                           const float* beta, int B, int Hi, int Wi, int C, void* V, long V_bytes);
 int lm_winograd_gemm_f32(void* stream, const void* V, const float* wu, int CoutP, const float* scale, const float* shift,
                          const float* res, int ldr, float* y, int ldy, int B, int H, int W, int Cin, int Cout, int dil, int act,
                          double* gn_partial);

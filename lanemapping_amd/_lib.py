@@ -39,7 +39,7 @@ SIGNATURES = {
     'lm_conv3x3_winograd_workspace_bytes': (i64, [i32, i32, i32, i32, i32]),
     'lm_winograd_gn_chunks': (i32, [i32, i32, i32]),
     'lm_winograd_input_transform_f32': (i32, [vp, vp, i32, i32, i32, i32, i32, i32, vp, i64]),
-    'lm_winograd_input_transform_gn_up2_f32': (i32, [vp, vp, vp, vp, vp, i32, i32, i32, i32, vp, i64]),
+    'lm_winograd_input_transform_gn_up2_f32': (i32, [vp, vp, i32, vp, vp, vp, i32, i32, i32, i32, vp, i64]),
     'lm_winograd_gemm_f32': (i32, [vp, vp, vp, i32, vp, vp, vp, i32, vp, i32, i32, i32, i32, i32, i32, i32, i32, vp]),
     'lm_conv3x3_winograd_f32': (i32, [vp, vp, i32, vp, i32, vp, vp, vp, i32, vp, i32, i32, i32, i32, i32, i32, i32, i32, vp, i64]),
     'lm_conv2d_nhwc_mfma_f32_gnstats': (i32, [vp, vp, i32, vp, i32, vp, vp, i32, vp] + [i32] * 11),

@@ -112,7 +112,7 @@ __global__ __launch_bounds__(256) void wino_input_kernel(const float* __restrict
 template <int C4N>
 __global__ __launch_bounds__(256) void wino_input_gn_up2_kernel(const float* __restrict__ t, const float* __restrict__ stats,
                                                                 const float* __restrict__ gamma, const float* __restrict__ beta,
-                                                                int Hi, int Wi, WinoGeom g, float* __restrict__ V) {
+                                                                int Hi, int Wi, int ldt, WinoGeom g, float* __restrict__ V) {
     constexpr int TXB = 256 / C4N, RC = TXB + 3, C = C4N * 4;    // region: 4 source rows x (TXB + 3) source columns (scale < 1/2)
     __shared__ __attribute__((aligned(16))) float S[4 * RC * C];
     unsigned bid = blockIdx.x;
@@ -144,7 +144,7 @@ __global__ __launch_bounds__(256) void wino_input_gn_up2_kernel(const float* __r
         for (int p = tid / C4N; p < 4 * RC; p += TXB) {          // (a thread keeps its channel quad: one affine for all its pixels)
             const int ry = p / RC, rx = p % RC;
             const int sy = min(yb + ry, Hi - 1), sx = min(xb + rx, Wi - 1);
-            f32x4 v = *reinterpret_cast<const f32x4*>(t + (((long)b * Hi + sy) * Wi + sx) * C + c4);
+            f32x4 v = *reinterpret_cast<const f32x4*>(t + (((long)b * Hi + sy) * Wi + sx) * ldt + c4);
 #pragma unroll
             for (int e = 0; e < 4; ++e) v[e] = lm_gn_relu(v[e], a[e], gg[e]);
             *reinterpret_cast<f32x4*>(S + (ry * RC + rx) * C + c4) = v;
@@ -579,10 +579,12 @@ LM_API int lm_winograd_input_transform_f32(void* stream, const float* x, int ldx
 }
 
 // V of the tensor  bilinear_align_corners_x2(relu(gn(t; stats, gamma, beta)))  [B][2 Hi][2 Wi][C] that is never materialised
-// (lm_gn_relu_upsample followed by lm_winograd_input_transform_f32, bit-identical to that pair).  C = 128 or 256, dilation 1.
-LM_API int lm_winograd_input_transform_gn_up2_f32(void* stream, const float* t, const float* stats, const float* gamma, const float* beta,
-                                                  int B, int Hi, int Wi, int C, void* V, long V_bytes) {
+// (lm_gn_relu_upsample followed by lm_winograd_input_transform_f32, bit-identical to that pair).  C = 128 or 256, dilation 1;
+// ldt = floats between pixels of t (a channel slice of a wider tensor is fine).
+LM_API int lm_winograd_input_transform_gn_up2_f32(void* stream, const float* t, int ldt, const float* stats, const float* gamma,
+                                                  const float* beta, int B, int Hi, int Wi, int C, void* V, long V_bytes) {
     LM_REQUIRE(t && stats && gamma && beta && V, "wino_input_gn_up2: null pointer");
+    LM_REQUIRE(ldt >= C && ldt % 4 == 0, "wino_input_gn_up2: bad leading dimension ldt=%d", ldt);
     LM_REQUIRE((C == 128 || C == 256) && B > 0 && Hi > 1 && Wi > 1, "wino_input_gn_up2: C=%d must be 128 or 256, source at least 2x2", C);
     const int H = 2 * Hi, W = 2 * Wi;
     LM_REQUIRE(lm_conv3x3_winograd_workspace_bytes(B, H, W, C, 1) <= V_bytes, "wino_input_gn_up2: V buffer too small");
@@ -592,9 +594,9 @@ LM_API int lm_winograd_input_transform_gn_up2_f32(void* stream, const float* t, 
     const long blocks = (long)B * g.Ty * ((g.Tx + txb - 1) / txb);
     LM_REQUIRE(blocks < (1L << 31), "wino_input_gn_up2: bad grid");
     if (C == 256)
-        hipLaunchKernelGGL(wino_input_gn_up2_kernel<64>, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, t, stats, gamma, beta, Hi, Wi, g, (float*)V);
+        hipLaunchKernelGGL(wino_input_gn_up2_kernel<64>, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, t, stats, gamma, beta, Hi, Wi, ldt, g, (float*)V);
     else
-        hipLaunchKernelGGL(wino_input_gn_up2_kernel<32>, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, t, stats, gamma, beta, Hi, Wi, g, (float*)V);
+        hipLaunchKernelGGL(wino_input_gn_up2_kernel<32>, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, t, stats, gamma, beta, Hi, Wi, ldt, g, (float*)V);
     LM_LAUNCH_CHECK();
     return LM_OK;
 }

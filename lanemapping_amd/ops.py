@@ -167,9 +167,8 @@ def wino_transform(x, dil=1, dedicated=False):
 def wino_transform_gn_up2(t, stats, gamma, beta, dedicated=False):
     """Winograd input of bilinear_x2(relu(gn(t))) straight from t (the upsampled tensor is never written); == wino_transform(
     gn_relu_upsample(t, ...)) bit for bit.  C = 128 or 256."""
-    t, ld = as_nhwc(t)
+    t, ld = as_nhwc(t)                                  # may be a channel slice of a wider NHWC tensor (ld > C)
     B, cin, Hi, Wi = t.shape
-    assert ld == cin
     H, W = 2 * Hi, 2 * Wi
     need = lib().lm_conv3x3_winograd_workspace_bytes(B, H, W, cin, 1)
     if dedicated:
@@ -179,7 +178,7 @@ def wino_transform_gn_up2(t, stats, gamma, beta, dedicated=False):
         ws = _wino_ws.get(key)
         if ws is None or ws.numel() < need:
             ws = _wino_ws[key] = torch.empty(need, device=t.device, dtype=torch.uint8)
-    check(lib().lm_winograd_input_transform_gn_up2_f32(_stream(), _ptr(t), _ptr(stats), _ptr(gamma), _ptr(beta), B, Hi, Wi, cin,
+    check(lib().lm_winograd_input_transform_gn_up2_f32(_stream(), _ptr(t), ld, _ptr(stats), _ptr(gamma), _ptr(beta), B, Hi, Wi, cin,
                                                        _ptr(ws), ws.numel()))
     return WinoInput(ws, B, cin, H, W, 1)
 

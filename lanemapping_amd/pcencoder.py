@@ -148,6 +148,10 @@ class FPNEncoder(PackedModule):
                 and self.gn11.eps == self.gn21.eps):
             P['semantic_branch_ab.wu'] = ops.pack_wino(torch.cat([a.weight, b2.weight], dim=0))
             P['semantic_branch_ab.b'] = torch.cat([a.bias, b2.bias]).float().contiguous()
+            if ('conv2.wu' in P and 'conv3.wu' in P and self.conv2.out_channels == self.conv3.out_channels
+                    and self.gn12.eps == self.gn22.eps):           # likewise conv2 / conv3 on p4
+                P['conv23.wu'] = ops.pack_wino(torch.cat([self.conv2.weight, self.conv3.weight], dim=0))
+                P['conv23.b'] = torch.cat([self.conv2.bias, self.conv3.bias]).float().contiguous()
         if self.out is not None:
             P['out.w'] = ops.pack_mfma(self.out.weight)
         for name in ('feature_layer', 'output_layer_binary_seg', 'output_layer_endp'):
@@ -177,7 +181,7 @@ class FPNEncoder(PackedModule):
     def _conv3(self, x, P, name, cout):
         return self._c3(x, P, name + '.w', cout, 1, 1, shift=P[name + '.b'])
 
-    def _semantic(self, P, p2, p3, p4, conv_a, gn_a, conv_b, gn_b, shared, proj, pre=None):
+    def _semantic(self, P, p2, p3, p4, conv_a, gn_a, conv_b, gn_b, shared, proj, pre=None, pre_a4=None):
         """One of the two branches (reference :615-621 / :641-647): s2 + s3 + s4 at p2's size, followed by the branch's 1x1 output
         layer `proj` = (packed weight, bias, cout, out) - the only consumer of the sum, so the 128-channel sum is never written
         (lm_gn_relu_upsample_sum_conv1x1).  `shared` caches the Winograd input transforms of p2 / p3 / p4, which both branches
@@ -201,12 +205,12 @@ class FPNEncoder(PackedModule):
                 st = ops.gn_stats(t, eps)
             return t, st
 
-        t, st = conv_stats(p4, conv_a, p4.shape[1], gn_a, share='p4')
+        t, st = pre_a4 if pre_a4 is not None else conv_stats(p4, conv_a, p4.shape[1], gn_a, share='p4')
         if (FUSE_UP_WINO and (conv_b + '.wu') in P and (h, w) == (2 * t.shape[2], 2 * t.shape[3]) and t.shape[1] in (128, 256)):
             # s4 feeds only conv_b: its Winograd input comes straight from t, the upsampled 256-channel tensor is never written
             s4 = ops.wino_transform_gn_up2(t, st, P[gn_a + '.g'], P[gn_a + '.b'])
         else:
-            s4 = ops.gn_relu_upsample(t, st, P[gn_a + '.g'], P[gn_a + '.b'], (h, w))    # 256 ch at 288^2
+            s4 = ops.gn_relu_upsample_sum([(t, st)], P[gn_a + '.g'], P[gn_a + '.b'], (h, w))   # 256 ch at 288^2 (t may be a channel slice)
         if pre is not None:                                                             # s2, s3 from the merged GEMMs (channel slices)
             terms = [pre[0], pre[1]]
         else:
@@ -252,12 +256,18 @@ class FPNEncoder(PackedModule):
                 t, st = ops.conv_wino(shared[key], P['semantic_branch_ab.wu'], 2 * ch, 1, shift=P['semantic_branch_ab.b'], gn_eps=self.gn11.eps)
                 pre_a.append((t[:, :ch], st[:, :ch].contiguous()))
                 pre_b.append((t[:, ch:], st[:, ch:].contiguous()))
+        a4 = b4 = None
+        if 'conv23.wu' in P:
+            c4o = self.conv2.out_channels
+            shared['p4'] = ops.wino_transform(p4, 1, dedicated=True)
+            t, st = ops.conv_wino(shared['p4'], P['conv23.wu'], 2 * c4o, 1, shift=P['conv23.b'], gn_eps=self.gn12.eps)
+            a4, b4 = (t[:, :c4o], st[:, :c4o].contiguous()), (t[:, c4o:], st[:, c4o:].contiguous())
         fea_up = self._semantic(P, p2, p3, p4, 'conv2', 'gn12', 'semantic_branch', 'gn11', shared,
-                                (P['feature_layer.w'], P['feature_layer.b'], 8, fea_up_out), pre_a)
+                                (P['feature_layer.w'], P['feature_layer.b'], 8, fea_up_out), pre_a, a4)
         seg288 = ops.conv_small(fea_up, P['output_layer_binary_seg.w'], 3, shift=P['output_layer_binary_seg.b'], pre_relu=True)
         bi_seg = ops.upsample_to_chw(seg288, (H, W))
         endp288 = self._semantic(P, p2, p3, p4, 'conv3', 'gn22', 'semantic_branch2', 'gn21', shared,
-                                 (P['output_layer_endp.w'], P['output_layer_endp.b'], 1, None), pre_b)
+                                 (P['output_layer_endp.w'], P['output_layer_endp.b'], 1, None), pre_b, b4)
         del shared
         endp = ops.upsample_to_chw(endp288, (H, W))
         return fea, fea_up, bi_seg, endp

@@ -805,6 +805,12 @@ def test_winograd_input_from_gn_relu_upsample(dev, B, C, Hi, Wi):
     up = ops.gn_relu_upsample(t, st, gamma, beta, (H, W))
     v_ref = ops.wino_transform(up, 1, dedicated=True)
     v_fused = ops.wino_transform_gn_up2(t, st, gamma, beta, dedicated=True)
+    wide = torch.zeros(B, C + 64, Hi, Wi, device=dev).permute(0, 2, 3, 1).contiguous().permute(0, 3, 1, 2)   # t as a channel slice
+    wide[:, 32:32 + C] = t
+    v_slice = ops.wino_transform_gn_up2(wide[:, 32:32 + C], st, gamma, beta, dedicated=True)
+    assert torch.equal(v_slice.buf, v_fused.buf) or torch.equal(
+        v_slice.buf.view(torch.float32).view(16, B, -1, C)[:, :, :((2 * Hi + 1) // 2) * ((2 * Wi + 1) // 2)],
+        v_fused.buf.view(torch.float32).view(16, B, -1, C)[:, :, :((2 * Hi + 1) // 2) * ((2 * Wi + 1) // 2)])
     Ty, Tx = (H + 1) // 2, (W + 1) // 2
     timg = Ty * Tx
     tpad = (timg + 127) // 128 * 128
