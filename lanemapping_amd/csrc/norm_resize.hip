@@ -285,6 +285,10 @@ __global__ __launch_bounds__(256) void upsample_nhwc_kernel(const float* __restr
 }
 
 // NHWC (few channels) -> planar [B,C,Ho,Wo]
+__device__ __forceinline__ float upsample_blend(float v00, float v01, float v10, float v11, float wy0, float wy1, float wx0, float wx1) {
+    return lm_bilerp(v00, v01, v10, v11, wy0, wy1, wx0, wx1);      // fixed-order blend (common.h): scalar and vector kernels agree bit for bit
+}
+
 __global__ __launch_bounds__(256) void upsample_to_chw_kernel(const float* __restrict__ x, int ldx, float* __restrict__ y,
                                                               int Hi, int Wi, int Ho, int Wo, int C, long total) {
     const long i = (long)blockIdx.x * 256 + threadIdx.x;
@@ -302,7 +306,38 @@ __global__ __launch_bounds__(256) void upsample_to_chw_kernel(const float* __res
     const float* xb = x + (long)b * Hi * Wi * ldx + c;
     const float v00 = xb[((long)y0 * Wi + x0) * ldx], v01 = xb[((long)y0 * Wi + x1) * ldx];
     const float v10 = xb[((long)y1 * Wi + x0) * ldx], v11 = xb[((long)y1 * Wi + x1) * ldx];
-    y[i] = wy0 * (wx0 * v00 + wx1 * v01) + wy1 * (wx0 * v10 + wx1 * v11);
+    y[i] = upsample_blend(v00, v01, v10, v11, wy0, wy1, wx0, wx1);
+}
+
+// four horizontally adjacent outputs per thread (Wo % 4 == 0): one row decode and one y-axis interpolation per 16-byte store, 32-bit
+// index math.  Same blend as the scalar kernel (both written as the plain expression in this file).
+__global__ __launch_bounds__(256) void upsample_to_chw4_kernel(const float* __restrict__ x, int ldx, float* __restrict__ y,
+                                                               int Hi, int Wi, int Ho, int Wo, int C, unsigned total4) {
+    const unsigned i = blockIdx.x * 256u + threadIdx.x;
+    if (i >= total4) return;
+    const unsigned wq = (unsigned)Wo / 4;
+    const int ox0 = (int)(i % wq) * 4;
+    unsigned t = i / wq;
+    const int oy = (int)(t % (unsigned)Ho);
+    t /= (unsigned)Ho;
+    const int c = (int)(t % (unsigned)C);
+    const int b = (int)(t / (unsigned)C);
+    int y0, y1;
+    float wy0, wy1;
+    bilin_axis(oy, Hi, Ho, y0, y1, wy0, wy1);
+    const float* xb = x + (long)b * Hi * Wi * ldx + c;
+    const float* r0 = xb + (long)y0 * Wi * ldx;
+    const float* r1 = xb + (long)y1 * Wi * ldx;
+    f32x4 o;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        int x0, x1;
+        float wx0, wx1;
+        bilin_axis(ox0 + k, Wi, Wo, x0, x1, wx0, wx1);
+        const float v00 = r0[(long)x0 * ldx], v01 = r0[(long)x1 * ldx], v10 = r1[(long)x0 * ldx], v11 = r1[(long)x1 * ldx];
+        o[k] = upsample_blend(v00, v01, v10, v11, wy0, wy1, wx0, wx1);
+    }
+    *reinterpret_cast<f32x4*>(y + (long)i * 4) = o;
 }
 
 // ----------------------------------------------------------------------------- LayerNorm: one wave per row
@@ -443,6 +478,12 @@ LM_API int lm_upsample_bilinear_to_chw(void* stream, const float* x, int ldx, fl
                                        int Ho, int Wo, int C) {
     LM_REQUIRE(x && y && C >= 1, "upsample_to_chw: bad args");
     const long total = (long)B * C * Ho * Wo;
+    if (Wo % 4 == 0 && total / 4 < (1L << 31) && ((uintptr_t)y & 15) == 0) {
+        hipLaunchKernelGGL(upsample_to_chw4_kernel, dim3(lm_cdiv(total / 4, 256)), dim3(256), 0, (hipStream_t)stream,
+                           x, ldx, y, Hi, Wi, Ho, Wo, C, (unsigned)(total / 4));
+        LM_LAUNCH_CHECK();
+        return LM_OK;
+    }
     hipLaunchKernelGGL(upsample_to_chw_kernel, dim3(lm_cdiv(total, 256)), dim3(256), 0, (hipStream_t)stream,
                        x, ldx, y, Hi, Wi, Ho, Wo, C, total);
     LM_LAUNCH_CHECK();

@@ -127,8 +127,9 @@ def test_gn_relu_upsample(dev):
     _close(y, ref, 1e-5, 'gn+relu+up')
     y = ops.gn_relu_upsample(xd, st, gamma.to(dev), beta.to(dev), (40, 56), out=y, accumulate=True)
     _close(y, 2 * ref, 1e-5, 'accumulate')
-    up = ops.upsample_to_chw(xd[:, :3], (80, 112))
-    _close(up, F.interpolate(x[:, :3], size=(80, 112), mode='bilinear', align_corners=True), 1e-5, 'to_chw')
+    for size in ((80, 112), (81, 113), (37, 4)):              # 16-byte vector path (Wo % 4 == 0) and the scalar one
+        up = ops.upsample_to_chw(xd[:, :3], size)
+        _close(up, F.interpolate(x[:, :3], size=size, mode='bilinear', align_corners=True), 1e-5, f'to_chw {size}')
 
 
 def test_gn_relu_upsample_sum(dev):
