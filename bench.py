@@ -260,6 +260,13 @@ def main():
         roof_steps = 2
         roof_scope = (f'{roof_steps} instrumented single-stream steps right after the timed region (in the timed region the batch is '
                       f'split over {nstream} streams whose kernels overlap, so per-launch durations are not additive)')
+        # one untimed single-stream step first: whole-batch tensors have shapes the 4-stream steps never allocated, and a
+        # hipMalloc inside an event bracket (it synchronises the device) would be charged to that launch
+        for f in pipe.submit(tiles):
+            f.result()
+        for f in pipe.flush():
+            f.result()
+        torch.cuda.synchronize()
         prof['on'] = True
         if args.workload == 'fused':
             rast['pairs'] = []          # in the timed region the raster shares the GPU with the other streams' kernels
