@@ -1,14 +1,14 @@
 #!/usr/bin/env python3
 """Throughput bench of the lane-mapping hot path on MI355X (contract: see DESIGN.md §Measurement).
 
-    python bench.py [--gpus N --steps K --warmup W]
+    python bench.py [--gpus N --steps K --warmup W]          (N > 1 without torchrun: spawns the N ranks itself)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
-A step = one batch of 8 pre-rasterised synthetic WHU-Lane-shaped BEV tiles per GPU (BASELINE.json
-configs[1]: configs/Proj_polyline_fpn_vit_vertex_2.py, batch 8), already resident in HBM, taken all
-the way to lane polylines: FPN -> ViT -> column-proposal head -> decode (GPU), endpoint clustering +
-polyline assembly (host C++ threads, overlapped), plus one all-gather of the fixed-shape polyline
-blocks when N > 1.  Rank 0 prints ONE JSON line.
+Default workload = BASELINE.json's headline, configs[2]: on-GPU LAS -> BEV raster of 16 x 4,194,304 points resident in HBM +
+configs/Proj_polyline_fpn_vit_vertex_2.py at batch 16, all the way to lane polylines: raster -> FPN -> ViT -> column-proposal
+head -> decode (GPU), endpoint clustering + polyline assembly (host C++ threads, overlapped), plus one all-gather of the
+fixed-shape polyline blocks when N > 1.  `--workload tiles` = configs[1] (pre-rasterised, batch 8), `rowref` = configs[3]
+(RowRef head, batch 8), `lidar` = configs[4] (sparse-conv encoder).  Rank 0 prints ONE JSON line.
 """
 import argparse
 import json
@@ -23,7 +23,10 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 MFMA_F32_PEAK_TFLOPS = 157.3      # /opt/skills/guides/MI355X_MICROARCH.md: dense fp32 MFMA peak
+HBM_PEAK_GBS = 8000.0             # same guide: HBM3E 8 TB/s
 BATCH = 8
+N_PTS = 4194304                   # points per tile of the fused workload
+PMC_FILE = os.path.join(ROOT, 'profiles', 'pmc_traffic.json')     # counter bytes per step, collected offline (tools/pmc_traffic.sh)
 
 
 def usable_cores():
@@ -40,8 +43,8 @@ def usable_cores():
 
 
 def cpu_baseline(budget_s=25.0, max_threads=64):
-    """Oracle ("port" of the reference's CPU path: torch-CPU fp32 net + NumPy decode/post-proc) timed on this
-    host's cores on a bounded sample of the same workload (about `budget_s` seconds of CPU work)."""
+    """Oracle ("port" of the reference's CPU path: torch-CPU fp32 net + NumPy decode/post-proc) timed on this host's cores on a
+    bounded sample of the same workload: batch 1 for about half of `budget_s`, then ONE batch of 8 (SURVEY §8d asks for both)."""
     sys.path.insert(0, os.path.join(ROOT, 'tests', 'golden'))
     from lanemapping_amd import synth
     from lanemapping_amd.boundary import build_net_from_config
@@ -52,24 +55,48 @@ def cpu_baseline(budget_s=25.0, max_threads=64):
     synth.fill_module_(net, 2021)
     sd = {k: v for k, v in net.state_dict().items()}
 
-    def one(seed):
-        x = torch.from_numpy(synth.bev_batch([seed], 1152))
+    def run(seeds):
+        x = torch.from_numpy(synth.bev_batch(seeds, 1152))
         t = time.perf_counter()
         with torch.no_grad():
             raw = net_ref.detector_forward(sd, x)
         d = decode_ref.decode_column_proposals({k: v.numpy() for k, v in raw.items()})
-        postproc_ref.assemble_tile(d['prop_conf'][0, :, 1].numpy(), d['prop_v_ext'][0].numpy(), d['cls_offset'][0].numpy(),
-                                   d['bi_seg'][0].numpy(), d['endp'][0].numpy())
+        for b in range(len(seeds)):
+            postproc_ref.assemble_tile(d['prop_conf'][b, :, 1].numpy(), d['prop_v_ext'][b].numpy(), d['cls_offset'][b].numpy(),
+                                       d['bi_seg'][b].numpy(), d['endp'][b].numpy())
         return time.perf_counter() - t
 
-    warm = one(2021)                            # warm-up tile (also sizes the sample)
-    n = int(max(1, min(8, budget_s // max(warm, 1e-3))))
-    times = [one(2022 + i) for i in range(n)] if warm < budget_s else [warm]
+    warm = run([2021])                          # warm-up tile (also sizes the sample)
+    n = int(max(1, min(8, (budget_s * 0.5) // max(warm, 1e-3))))
+    times = [run([2022 + i]) for i in range(n)] if warm < budget_s else [warm]
     dt = sum(times)
-    return {'value': len(times) / dt, 'unit': 'tiles/s', 'cores': cores, 'kind': 'port',
-            'sample': f'{len(times)} synthetic 1152x1152 tiles, batch 1, oracle net_ref+decode_ref+postproc_ref (tile '
-                      f'generation excluded), torch {torch.get_num_threads()} threads of {os.cpu_count()} logical CPUs, '
-                      f'after 1 warm-up tile ({warm:.1f} s)'}
+    out = {'value': len(times) / dt, 'unit': 'tiles/s', 'cores': cores, 'kind': 'port',
+           'sample': f'{len(times)} synthetic 1152x1152 tiles, batch 1, oracle net_ref+decode_ref+postproc_ref (tile '
+                     f'generation excluded), torch {torch.get_num_threads()} threads of {os.cpu_count()} logical CPUs, '
+                     f'after 1 warm-up tile ({warm:.1f} s)'}
+    if warm * 8 < budget_s * 1.5:               # one batch of 8 when it fits the budget (about 8 x the batch-1 tile time)
+        t8 = run([2030 + i for i in range(8)])
+        out['batch8'] = {'value': 8 / t8, 'unit': 'tiles/s', 'sample': 'one batch of 8 tiles through the same chain'}
+    return out
+
+
+def self_launch(args):
+    """`python bench.py --gpus N` without a launcher: start the N ranks as child processes (one per GPU) BEFORE this process
+    touches the GPU, relay rank 0's JSON line through the inherited stdout and exit with the worst child's code."""
+    import socket
+    import subprocess
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    port = s.getsockname()[1]
+    s.close()
+    procs = []
+    for r in range(args.gpus):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(args.gpus), LOCAL_WORLD_SIZE=str(args.gpus),
+                   MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
+        procs.append(subprocess.Popen([sys.executable, os.path.join(ROOT, 'bench.py')] + sys.argv[1:], env=env,
+                                      stdout=None if r == 0 else subprocess.DEVNULL))
+    codes = [p.wait() for p in procs]
+    sys.exit(max(abs(c) for c in codes))
 
 
 def main():
@@ -80,21 +107,30 @@ def main():
     ap.add_argument('--cpu-budget-s', type=float, default=25.0)
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--host-threads', type=int, default=8)
-    ap.add_argument('--workload', choices=['tiles', 'fused', 'lidar'], default='tiles',
-                    help="tiles = BASELINE configs[1] (pre-rasterised, batch 8); fused = configs[2] (on-GPU LAS->BEV raster + net, "
-                         "batch 16); lidar = configs[4] (sparse-conv LiDAR encoder path, batch 8 point clouds, parity unpinned)")
+    ap.add_argument('--workload', choices=['fused', 'tiles', 'rowref', 'lidar'], default='fused',
+                    help="fused = BASELINE configs[2], the headline (on-GPU LAS->BEV raster + config 2, batch 16); tiles = configs[1] "
+                         "(pre-rasterised, batch 8); rowref = configs[3] (Proj28_GFC-T3_RowRef head, pre-rasterised, batch 8); lidar = "
+                         "configs[4] (sparse-conv LiDAR encoder path, batch 8 point clouds, parity unpinned)")
     ap.add_argument('--streams', type=int, default=None,
-                    help='split every batch over this many HIP streams (fills launch tails); default 4, 1 for --workload lidar '
-                         '(its active-set bookkeeping needs host round trips, which serialise sub-batches)')
+                    help='split every batch over this many HIP streams (fills launch tails); default 4, 1 for lidar / rowref '
+                         '(their data-dependent bookkeeping needs host round trips, which serialise sub-batches)')
     ap.add_argument('--conv-detail', action='store_true', help='per-shape table of the MFMA launches on stderr')
-    ap.add_argument('--no-roofline-events', action='store_true', help='skip the per-launch HIP events')
+    ap.add_argument('--no-stream-check', action='store_true', help='skip the bitwise multi-stream == single-stream check')
     args = ap.parse_args()
 
+    if args.gpus < 1:
+        raise SystemExit('--gpus must be >= 1')
+    if 'WORLD_SIZE' not in os.environ and args.gpus > 1:
+        ndev = torch.cuda.device_count()        # (counting devices does not initialise the GPU)
+        if ndev < args.gpus and 'LANEMAP_BENCH_DEVICE' not in os.environ:
+            raise SystemExit(f'--gpus {args.gpus} but only {ndev} GPU(s) are visible')
+        self_launch(args)                       # never returns
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
-    if world != args.gpus and world > 1:
-        raise SystemExit(f'--gpus {args.gpus} but WORLD_SIZE={world}')
+    if world != args.gpus:
+        raise SystemExit(f'--gpus {args.gpus} but WORLD_SIZE={world}: launch with `python bench.py --gpus N` (spawns the ranks itself) '
+                         f'or `python -m torch.distributed.run --nproc-per-node N bench.py --gpus N`')
     import torch.distributed as dist
     # test hooks (tests/test_gpu_parity.py exercises the N>1 code path on a 1-GPU box): every rank on one device, gloo backend
     dev_index = int(os.environ.get('LANEMAP_BENCH_DEVICE', local_rank))
@@ -114,17 +150,17 @@ def main():
     from lanemapping_amd.boundary import build_net_from_config
     from lanemapping_amd.pipeline import TilePipeline
     lib()                                                    # raises if the HIP library is missing
-    net = build_net_from_config('Proj_polyline_lidarconv_vit_vertex_2' if args.workload == 'lidar' else 'Proj_polyline_fpn_vit_vertex_2',
-                                device='cpu')
+    cfg_name = {'lidar': 'Proj_polyline_lidarconv_vit_vertex_2', 'rowref': 'Proj28_GFC-T3_RowRef_82_73_laser'}.get(
+        args.workload, 'Proj_polyline_fpn_vit_vertex_2')
+    net = build_net_from_config(cfg_name, device='cpu')
     synth.fill_module_(net, 2021)
     net = net.to(dev)
     # weak scaling: every rank owns its own BATCH tiles per step (seeds differ per rank)
     batch = 16 if args.workload == 'fused' else BATCH
-    N_PTS = 4194304
     if args.workload == 'lidar':    # the config-3 cloud in the ego frame, cropped by the voxeliser, resident in HBM
         clouds = [torch.from_numpy(synth.lidar_points(2021 + rank * 4 + i, N_PTS)).to(dev) for i in range(4)]
         tiles = [clouds[i % 4] for i in range(batch)]
-    elif args.workload == 'tiles':
+    elif args.workload in ('tiles', 'rowref'):
         tiles = torch.from_numpy(synth.bev_batch([2021 + rank * batch + i for i in range(batch)], 1152)).to(dev)
     else:       # 4,194,304 LAS-shaped points per tile, resident in HBM (4 distinct clouds, repeated)
         clouds = [torch.from_numpy(synth.las_points(2021 + rank * 4 + i, N_PTS)) for i in range(4)]
@@ -133,15 +169,16 @@ def main():
         rpar = [ops.make_raster_params(local_min_ele=-0.5, ele_reso=0.02)] * batch
         tiles = torch.empty((batch, 3, 1152, 1152), device=dev)
     pipe = TilePipeline(net, host_threads=args.host_threads)
-    nstream = max(1, args.streams if args.streams is not None else (1 if args.workload == 'lidar' else 4))
+    nstream = max(1, args.streams if args.streams is not None else (1 if args.workload in ('lidar', 'rowref') else 4))
     nstream = min(nstream, batch)
     extra_streams = [torch.cuda.Stream(device=dev) for _ in range(nstream - 1)]
     extra_pipes = [TilePipeline(net, host_threads=args.host_threads) for _ in range(nstream - 1)]
     rast = {'pairs': [], 'on': False}
     bounds = [round(i * batch / nstream) for i in range(nstream + 1)]      # every tile of the batch goes to exactly one stream
 
-    # ---- roofline instrumentation: HIP events (on the launch stream) around every MFMA conv/GEMM launch ----
-    prof = {'on': False, 'pairs': [], 'flops': 0.0, 'executed': 0.0, 'launches': 0}
+    # ---- roofline instrumentation: HIP events (on the launch stream = torch's current stream) around every MFMA conv/GEMM launch
+    # and every Winograd input transform ----
+    prof = {'on': False, 'pairs': [], 'launches': 0}
 
     def hook(kind, flops, launch, executed=None):
         # flops: algorithmic (direct-convolution) count; executed: what the matrix cores really do (Winograd launches: 16/36)
@@ -150,9 +187,7 @@ def main():
             a.record()
             launch()
             b.record()
-            prof['pairs'].append((a, b, kind, flops))
-            prof['flops'] += flops
-            prof['executed'] += flops if executed is None else executed
+            prof['pairs'].append((a, b, kind, flops, flops if executed is None else executed))
             prof['launches'] += 1
         else:
             launch()
@@ -225,10 +260,17 @@ def main():
         gather(res)
         return res
 
+    def single_stream(src):
+        """One whole batch on the main stream through the first pipeline -> per-tile results in tile order."""
+        for f in pipe.submit(src):
+            f.result()
+        return [f.result() for f in pipe.flush()]
+
     # set-up, not measurement: one priming batch loads every kernel's code object, packs the weights into their kernel
     # layouts (PackedModule) and grows the allocator / pinned-buffer pools, so that even `--warmup 0` times steady state
     step()
     drain()
+    torch.cuda.synchronize()
     state['i'] = 0
     for _ in range(args.warmup):
         step()
@@ -253,6 +295,20 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
 
+    # ---- the product path the clock just timed splits each batch over `nstream` streams / pipelines: its outputs for the last step
+    # must equal a single-stream run on the same tiles BITWISE (a cross-stream race on workspaces or packed weights would show here)
+    last_buf = tile_bufs[(state['i'] - 1) & 1] if args.steps > 0 else tiles
+    stream_check = 'skipped'
+    if nstream > 1 and not args.no_stream_check and last:
+        ref = single_stream(last_buf)
+        if len(ref) != len(last):
+            raise SystemExit(f'stream check: {len(last)} results from the {nstream}-stream step, {len(ref)} from the single-stream run')
+        for t_, ((la, ea), (lb, eb)) in enumerate(zip(last, ref)):
+            if not (np.array_equal(np.asarray(la), np.asarray(lb)) and np.array_equal(np.asarray(ea), np.asarray(eb))):
+                raise SystemExit(f'stream check FAILED: tile {t_} of the last timed step differs between the {nstream}-stream product path '
+                                 f'and a single-stream run (lanes equal: {np.array_equal(np.asarray(la), np.asarray(lb))})')
+        stream_check = f'lanes and endpoints of the last timed step ({len(last)} tiles, {nstream} streams) bitwise equal to a single-stream run'
+
     roof_steps = args.steps
     roof_scope = 'HIP events around every launch inside the timed region (single stream)'
     if nstream > 1:
@@ -262,10 +318,7 @@ def main():
                       f'split over {nstream} streams whose kernels overlap, so per-launch durations are not additive)')
         # one untimed single-stream step first: whole-batch tensors have shapes the 4-stream steps never allocated, and a
         # hipMalloc inside an event bracket (it synchronises the device) would be charged to that launch
-        for f in pipe.submit(tiles):
-            f.result()
-        for f in pipe.flush():
-            f.result()
+        single_stream(tiles if args.workload != 'fused' else last_buf)
         torch.cuda.synchronize()
         prof['on'] = True
         if args.workload == 'fused':
@@ -283,58 +336,90 @@ def main():
             f.result()
         torch.cuda.synchronize()
         prof['on'] = False
-    conv_ms = sum(p[0].elapsed_time(p[1]) for p in prof['pairs'])
+
+    # ---- aggregate per kernel class.  kind strings: 'wino_gemm ...', 'wino_input ...', 'conv ...', 'gemm ...', 'spconv ...'
+    def kclass(kind):
+        k = kind.split(' ', 1)[0]
+        return {'wino_gemm': 'wino_gemm_kernel', 'wino_implicit': 'wino_implicit_kernel', 'wino_input': 'wino_input_kernel'}.get(k, 'conv_mfma_kernel')
+    cls = {}
+    per_kind = {}
+    for a, b, kind, fl, ex in prof['pairs']:
+        ms = a.elapsed_time(b)
+        e = cls.setdefault(kclass(kind), [0, 0.0, 0.0, 0.0])
+        e[0] += 1; e[1] += ms; e[2] += fl; e[3] += ex
+        e = per_kind.setdefault(kind, [0, 0.0, 0.0, 0.0])
+        e[0] += 1; e[1] += ms; e[2] += fl; e[3] += ex
     if args.conv_detail and rank == 0:
-        agg = {}
-        for a, b, kind, fl in prof['pairs']:
-            e = agg.setdefault(kind, [0, 0.0, 0.0])
-            e[0] += 1
-            e[1] += a.elapsed_time(b)
-            e[2] += fl
-        for kind, (n, ms, fl) in sorted(agg.items(), key=lambda kv: -kv[1][1]):
-            print(f'# {kind:44s} x{n // roof_steps:3d}/step {ms / roof_steps:8.3f} ms/step {fl / ms / 1e9:7.1f} TFLOP/s (algorithmic)', file=sys.stderr)
-    achieved = prof['flops'] / (conv_ms * 1e-3) / 1e12 if conv_ms > 0 else 0.0            # algorithmic (direct-convolution) FLOP/s
-    executed = prof['executed'] / (conv_ms * 1e-3) / 1e12 if conv_ms > 0 else 0.0         # what the matrix cores really issue
+        for kind, (n, ms, fl, ex) in sorted(per_kind.items(), key=lambda kv: -kv[1][1]):
+            print(f'# {kind:52s} x{n // max(roof_steps, 1):3d}/step {ms / roof_steps:8.3f} ms/step {ex / max(ms, 1e-9) / 1e9:7.1f} TFLOP/s executed '
+                  f'({fl / max(ms, 1e-9) / 1e9:7.1f} direct-equivalent)', file=sys.stderr)
+    conv_ms = sum(e[1] for e in cls.values())
+    alg = sum(e[2] for e in cls.values())
+    exe = sum(e[3] for e in cls.values())
+    executed_tflops = exe / (conv_ms * 1e-3) / 1e12 if conv_ms > 0 else 0.0           # what the matrix cores really issue
+    alg_tflops = alg / (conv_ms * 1e-3) / 1e12 if conv_ms > 0 else 0.0                # direct-convolution equivalent
+    rs = max(roof_steps, 1)
+    per_class = {k: {'launches_per_step': e[0] / rs, 'ms_per_step': e[1] / rs, 'avg_launch_ms': e[1] / max(e[0], 1),
+                     'executed_gflop_per_step': e[3] / rs / 1e9,
+                     'executed_tflops': e[3] / (e[1] * 1e-3) / 1e12 if e[1] > 0 else 0.0,
+                     'frac': e[3] / (e[1] * 1e-3) / 1e12 / MFMA_F32_PEAK_TFLOPS if e[1] > 0 else 0.0}
+                 for k, e in cls.items()}
+    dominant = max(per_class, key=lambda k: per_class[k]['ms_per_step']) if per_class else None
+    # HBM bytes of the same kernels from the PMC counters (collected offline in their own rocprofv3 --pmc passes, FETCH_SIZE x 2 per the
+    # gfx950 note of MI355X_MICROARCH.md + WRITE_SIZE; tools/pmc_traffic.sh writes the file, profiles/ holds the raw summaries)
+    pmc = {}
+    try:
+        with open(PMC_FILE) as f:
+            pmc = json.load(f).get(args.workload, {})
+    except (OSError, ValueError):
+        pass
+    mfma_traffic = pmc.get('mfma_bytes_per_step')
     n_lines = int(np.mean([(np.count_nonzero(l[:, :, 0] > 0, axis=1) >= 2).sum() for l, _ in last])) if last else 0
+    what = {'tiles': 'pre-rasterised tile', 'fused': 'LAS points', 'lidar': 'LiDAR point cloud', 'rowref': 'pre-rasterised tile'}[args.workload]
+    workload = {
+        'tiles': 'configs/Proj_polyline_fpn_vit_vertex_2.py inference, batch=8 per GPU, pre-rasterised synthetic 1152x1152 BEV tiles '
+                 'resident in HBM, seeded random weights',
+        'rowref': 'configs/Proj28_GFC-T3_RowRef_82_73_laser.py inference (RowSharNotReducRef head), batch=8 per GPU, pre-rasterised '
+                  'synthetic 1152x1152 BEV tiles resident in HBM, seeded random weights',
+        'lidar': 'configs/Proj_polyline_lidarconv_vit_vertex_2.py inference (sparse-conv LiDAR encoder, parity unpinned), batch=8 '
+                 'point clouds of 4,194,304 points per GPU resident in HBM, seeded random weights',
+        'fused': 'on-GPU LAS->BEV raster (4,194,304 points/tile resident in HBM) + configs/Proj_polyline_fpn_vit_vertex_2.py, '
+                 'batch=16 per GPU, seeded random weights'}[args.workload]
     result = {
-        'metric': 'BEV tiles/sec end-to-end (%s -> polylines)' % {'tiles': 'pre-rasterised tile', 'fused': 'LAS points', 'lidar': 'LiDAR point cloud'}[args.workload],
+        'metric': f'BEV tiles/sec end-to-end ({what} -> polylines)',
         'value': world * batch * args.steps / dt,
         'unit': 'tiles/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
         'ms_per_step': dt / args.steps * 1e3, 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
         'dtype': 'f32', 'data': 'synthetic',
-        'config': {'workload': ('configs/Proj_polyline_fpn_vit_vertex_2.py inference, batch=8 per GPU, pre-rasterised '
-                                'synthetic 1152x1152 BEV tiles resident in HBM, seeded random weights') if args.workload == 'tiles'
-                   else ('configs/Proj_polyline_lidarconv_vit_vertex_2.py inference (sparse-conv LiDAR encoder, parity unpinned), batch=8 '
-                         'point clouds of 4,194,304 points per GPU resident in HBM, seeded random weights') if args.workload == 'lidar'
-                   else ('on-GPU LAS->BEV raster (4,194,304 points/tile resident in HBM) + configs/Proj_polyline_fpn_vit_vertex_2.py, '
-                         'batch=16 per GPU, seeded random weights'),
+        'config': {'workload': workload,
                    'tiles_per_step_per_gpu': batch, 'lines_per_tile': n_lines, 'host_threads': args.host_threads, 'streams': nstream,
+                   'stream_check': stream_check,
                    'host_postproc_ms_per_tile': 1e3 * sum(p_.host_seconds for p_ in [pipe] + extra_pipes) /
                    max(1, sum(p_.host_tiles for p_ in [pipe] + extra_pipes))},
-        'roofline': {'bound': 'mfma', 'kernel': 'conv_mfma_kernel + wino_gemm_kernel (all FPN/ViT/head implicit-GEMM launches)' if args.workload != 'lidar'
-                     else 'conv_mfma_kernel (rulebook sparse convolutions + dense tail/ViT/head GEMMs)',
-                     'achieved': achieved, 'peak': MFMA_F32_PEAK_TFLOPS, 'unit': 'TFLOP/s',
-                     'frac': achieved / MFMA_F32_PEAK_TFLOPS, 'traffic': None,
-                     'scope': roof_scope, 'launches_per_step': prof['launches'] / max(roof_steps, 1),
-                     'gflop_per_step': prof['flops'] / max(roof_steps, 1) / 1e9,
-                     'executed_gflop_per_step': prof['executed'] / max(roof_steps, 1) / 1e9, 'executed_tflops': executed,
-                     'executed_frac': executed / MFMA_F32_PEAK_TFLOPS,
-                     'note': 'achieved = ALGORITHMIC (direct-convolution, SURVEY 8d) FLOPs / time of the launches, so frac can exceed 1: '
-                             'the 3x3 layers with >= 128 input channels run through Winograd F(2x2,3x3), which executes 16/36 of those '
-                             'multiplies.  executed_tflops = FLOPs the matrix cores really issue / the same time (which also '
-                             'contains the HBM-bound Winograd input transform) = the utilisation view',
-                     'kernel_ms_per_step': conv_ms / max(roof_steps, 1)},
+        'roofline': {'bound': 'mfma',
+                     'kernel': 'every MFMA convolution / GEMM launch of a step (' + ', '.join(sorted(per_class)) + ')',
+                     # EXECUTED view: FLOPs the matrix cores really issue (Winograd F(2x2,3x3) launches: 16/36 of the direct count)
+                     # / summed HIP-event time of those launches (the HBM-bound Winograd input transforms included)
+                     'achieved': executed_tflops, 'peak': MFMA_F32_PEAK_TFLOPS, 'unit': 'TFLOP/s',
+                     'frac': executed_tflops / MFMA_F32_PEAK_TFLOPS,
+                     'traffic': mfma_traffic, 'traffic_source': pmc.get('source'),
+                     'algorithmic_equiv_tflops': alg_tflops,
+                     'scope': roof_scope, 'launches_per_step': prof['launches'] / rs,
+                     'executed_gflop_per_step': exe / rs / 1e9, 'algorithmic_gflop_per_step': alg / rs / 1e9,
+                     'kernel_ms_per_step': conv_ms / rs,
+                     'dominant_kernel': dominant, 'per_kernel': per_class,
+                     'note': 'achieved / frac = executed MFMA FLOPs / launch time / fp32 MFMA peak (always <= 1). algorithmic_equiv_tflops = '
+                             'direct-convolution FLOPs (SURVEY 8d: 2 per MAC of the 3x3 sums) / the same time: it exceeds the executed figure '
+                             'because Winograd does 16 multiplies where the direct sum does 36'},
     }
     if args.workload == 'fused' and rast['pairs']:
         rms = sum(a.elapsed_time(b) for a, b in rast['pairs']) / len(rast['pairs'])
-        alg = (16.0 * N_PTS + 3 * 1152 * 1152 * 4) * batch
+        algb = (16.0 * N_PTS + 3 * 1152 * 1152 * 4) * batch
         result['raster_roofline'] = {'bound': 'hbm', 'kernel': 'raster_partition_kernel + raster_band_kernel',
-                                     'achieved': alg / (rms * 1e-3) / 1e9, 'peak': 8000.0, 'unit': 'GB/s',
-                                     'frac': alg / (rms * 1e-3) / 1e9 / 8000.0,
-                                     # PMC FETCH_SIZE (x2, gfx950 correction) + WRITE_SIZE of both kernels, measured offline on this
-                                     # workload (profiles/r1_raster_pmc.txt): 120.7 MB per tile = 1.45 x the algorithmic bytes
-                                     'traffic': 120.7e6 * batch, 'ms_per_step': rms,
-                                     'scope': roof_scope}
+                                     'achieved': algb / (rms * 1e-3) / 1e9, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
+                                     'frac': algb / (rms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                                     'traffic': pmc.get('raster_bytes_per_step'), 'traffic_source': pmc.get('source'),
+                                     'algorithmic_bytes_per_step': algb, 'ms_per_step': rms, 'scope': roof_scope}
     if rank == 0:
         if world == 1 and not args.no_cpu_baseline:
             result['cpu_baseline'] = cpu_baseline(args.cpu_budget_s)

@@ -175,6 +175,9 @@ __global__ __launch_bounds__(256) void topk_pass_kernel(TopkParams p) {
             pick_bin(hist + lv * NB, need, bin);
             sel[lv] = bin;
         }
+        // LEVEL 3: `need` = how many keys EQUAL to the threshold T are still wanted, hist[2][bin] = how many exist.  If more exist
+        // than are wanted, the ties are ranked by index in topk_ties_kernel (lowest flat index first) and this pass skips them
+        if (LEVEL == 3) sel[3] = (hist[2 * NB + bin] == need) ? 1u : 0u;
     }
     __syncthreads();
     unsigned prefix = 0;     // key bits fixed by previous levels
@@ -192,7 +195,7 @@ __global__ __launch_bounds__(256) void topk_pass_kernel(TopkParams p) {
         } else if (LEVEL == 2) {
             if ((key >> 10) == (prefix >> 10)) atomicAdd(&lh[key & 1023u], 1u);
         } else {
-            if (key >= prefix) {   // prefix == exact threshold key T
+            if (key > prefix || (key == prefix && sel[3])) {   // prefix == exact threshold key T; at most K candidates in total
                 const unsigned slot = atomicAdd(p.cand_cnt + b, 1u);
                 if (slot < CAP) p.cand[(long)b * CAP + slot] = ((unsigned long long)key << 32) | (unsigned)(0xFFFFFFFFu - (unsigned)i);
             }
@@ -203,6 +206,60 @@ __global__ __launch_bounds__(256) void topk_pass_kernel(TopkParams p) {
         for (int i = threadIdx.x; i < NB; i += 256)
             if (lh[i]) atomicAdd(&hist[LEVEL * NB + i], lh[i]);
     }
+}
+
+// Tie-safe compaction (the reference's argsort, polyline_fpn_vit_vertex_2.py:655-660, never fails on tied scores; the build's rule is
+// "ties -> lower flat index"): when MORE pixels carry exactly the threshold key T than are still wanted (flat or
+// saturated endpoint maps), the wanted ones are the lowest-indexed.  One workgroup per tile scans the crop in index order, ranks the
+// tied pixels with a block-wide prefix sum and stops as soon as enough are taken.  Exits at once in the common all-ties-wanted case.
+__global__ __launch_bounds__(1024) void topk_ties_kernel(TopkParams p) {
+    __shared__ unsigned sh[4];
+    __shared__ unsigned wave_tot[16];
+    const int b = blockIdx.x;
+    const unsigned* hist = p.hist + (long)b * 3 * NB;
+    if (threadIdx.x == 0) {
+        unsigned need = (unsigned)p.K, bin = 0, key = 0;
+        pick_bin(hist, need, bin);
+        key = bin << 20;
+        pick_bin(hist + NB, need, bin);
+        key |= bin << 10;
+        pick_bin(hist + 2 * NB, need, bin);
+        key |= bin;
+        sh[0] = key;
+        sh[1] = need;
+        sh[2] = hist[2 * NB + bin];
+        sh[3] = p.cand_cnt[b];                                  // candidates with key > T (pass 3 is complete)
+    }
+    __syncthreads();
+    const unsigned T = sh[0], need = sh[1], base = sh[3];
+    if (sh[2] == need || need == 0) return;
+    const int Wc = p.W - 2 * p.clip;
+    const long n = (long)(p.H - 2 * p.clip) * Wc;
+    const float* lp = p.logit + (long)b * p.H * p.W;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    unsigned taken = 0;
+    for (long i0 = 0; i0 < n && taken < need; i0 += 1024) {
+        const long i = i0 + threadIdx.x;
+        bool tie = false;
+        if (i < n) {
+            const int y = (int)(i / Wc), x = (int)(i - (long)y * Wc);
+            tie = score_key(lp[(long)(y + p.clip) * p.W + x + p.clip]) == T;
+        }
+        const unsigned long long m = __ballot(tie);
+        const unsigned before = (unsigned)__popcll(m & ((1ull << lane) - 1ull));
+        if (lane == 0) wave_tot[wave] = (unsigned)__popcll(m);
+        __syncthreads();
+        unsigned off = 0, tot = 0;
+        for (int w = 0; w < 16; ++w) {
+            if (w < wave) off += wave_tot[w];
+            tot += wave_tot[w];
+        }
+        const unsigned rank = taken + off + before;
+        if (tie && rank < need) p.cand[(long)b * CAP + base + rank] = ((unsigned long long)T << 32) | (unsigned)(0xFFFFFFFFu - (unsigned)i);
+        taken += tot;
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) p.cand_cnt[b] = base + need;
 }
 
 // one workgroup per tile: bitonic sort (descending) of CAP 64-bit composites in LDS, emit top K
@@ -235,7 +292,7 @@ __global__ __launch_bounds__(1024) void topk_sort_kernel(TopkParams p, int* __re
         out_idx[(long)b * p.K + i] = ok ? (int)(0xFFFFFFFFu - (unsigned)(e & 0xFFFFFFFFu)) : -1;
         out_score[(long)b * p.K + i] = ok ? __uint_as_float((unsigned)(e >> 32)) : 0.f;
     }
-    if (threadIdx.x == 0) out_status[b] = (cnt > (unsigned)CAP) ? 1 : 0;   // 1 = too many tied scores
+    if (threadIdx.x == 0) out_status[b] = (cnt > (unsigned)CAP) ? 1 : 0;   // cannot happen since the tie-safe compaction (<= K candidates); kept as a guard
 }
 
 }  // namespace
@@ -291,6 +348,7 @@ LM_API int lm_endp_topk(void* stream, const float* endp_logit, void* workspace, 
     hipLaunchKernelGGL(topk_pass_kernel<1>, grid, dim3(256), 0, s, p);
     hipLaunchKernelGGL(topk_pass_kernel<2>, grid, dim3(256), 0, s, p);
     hipLaunchKernelGGL(topk_pass_kernel<3>, grid, dim3(256), 0, s, p);
+    hipLaunchKernelGGL(topk_ties_kernel, dim3(B), dim3(1024), 0, s, p);
     LM_LAUNCH_CHECK();
     hipLaunchKernelGGL(topk_sort_kernel, dim3(B), dim3(1024), 0, s, p, out_idx, out_score, out_status);
     LM_LAUNCH_CHECK();

@@ -136,9 +136,11 @@ __global__ __launch_bounds__(256) void rowref_decode_kernel(const float* __restr
                 bv = p[w];
                 col = w;
             }
-        cmap[(((long)b * (L + 1) + c) * H + h) * W + col] = 1;
-        cmap[(((long)b * (L + 1) + L) * H + h) * W + col] = 1;
-        conf[((long)b * H + h) * W + col] = 1;
+        if (cmap) {
+            cmap[(((long)b * (L + 1) + c) * H + h) * W + col] = 1;
+            cmap[(((long)b * (L + 1) + L) * H + h) * W + col] = 1;
+        }
+        if (conf) conf[((long)b * H + h) * W + col] = 1;
     }
     col_idx[i] = col;
 }
@@ -179,10 +181,11 @@ LM_API int lm_rowref_scatter(void* stream, const float* x_nhwc8, const float* to
 
 LM_API int lm_rowref_decode(void* stream, const float* ext2, const float* cls2, unsigned char* conf, unsigned char* cls_map,
                             int* col_idx, int B, int H, int W, int L) {
-    LM_REQUIRE(ext2 && cls2 && conf && cls_map && col_idx, "rowref_decode: null pointer");
+    // conf / cls_map (the reference's dense one-hot maps, :334-363) are optional: the tile pipeline only needs col_idx
+    LM_REQUIRE(ext2 && cls2 && col_idx, "rowref_decode: null pointer");
     hipStream_t s = (hipStream_t)stream;
-    LM_HIP(hipMemsetAsync(conf, 0, (size_t)B * H * W, s));
-    LM_HIP(hipMemsetAsync(cls_map, 0, (size_t)B * (L + 1) * H * W, s));
+    if (conf) LM_HIP(hipMemsetAsync(conf, 0, (size_t)B * H * W, s));
+    if (cls_map) LM_HIP(hipMemsetAsync(cls_map, 0, (size_t)B * (L + 1) * H * W, s));
     const long total = (long)B * L * H;
     hipLaunchKernelGGL(rowref_decode_kernel, dim3(lm_cdiv(total, 256)), dim3(256), 0, s, ext2, cls2, conf, cls_map, col_idx, H, W, L, total);
     LM_LAUNCH_CHECK();

@@ -26,6 +26,10 @@ def _ptr(t):
         return None
     if not t.is_cuda:
         raise LanemapHipError('lanemapping_amd ops need tensors on an MI355X (HIP) device; no CPU fallback exists')
+    if t.device.index != torch._C._cuda_getDevice():
+        # the library launches on the current HIP device and _stream() is that device's current stream
+        raise LanemapHipError(f'tensor on cuda:{t.device.index} but the current device is cuda:{torch._C._cuda_getDevice()}: '
+                              'call torch.cuda.set_device() (one process drives one GPU)')
     return C.c_void_p(t.data_ptr())
 
 
@@ -149,18 +153,29 @@ class WinoInput:
         self.buf, self.B, self.cin, self.H, self.W, self.dil = buf, B, cin, H, W, dil
 
 
+def _hooked(kind, flops, launch, executed=None):
+    if _conv_hook is not None:
+        _conv_hook(kind, flops, launch, executed)
+    else:
+        launch()
+
+
+def _wino_buf(need, device, dedicated):
+    if dedicated:
+        return torch.empty(need, device=device, dtype=torch.uint8)
+    key = (device, _stream().value)
+    ws = _wino_ws.get(key)
+    if ws is None or ws.numel() < need:
+        ws = _wino_ws[key] = torch.empty(need, device=device, dtype=torch.uint8)
+    return ws
+
+
 def wino_transform(x, dil=1, dedicated=False):
     x, ldx = as_nhwc(x)
     B, cin, H, W = x.shape
-    need = lib().lm_conv3x3_winograd_workspace_bytes(B, H, W, cin, dil)
-    if dedicated:
-        ws = torch.empty(need, device=x.device, dtype=torch.uint8)
-    else:
-        key = (x.device, _stream().value)
-        ws = _wino_ws.get(key)
-        if ws is None or ws.numel() < need:
-            ws = _wino_ws[key] = torch.empty(need, device=x.device, dtype=torch.uint8)
-    check(lib().lm_winograd_input_transform_f32(_stream(), _ptr(x), ldx, B, H, W, cin, dil, _ptr(ws), ws.numel()))
+    ws = _wino_buf(lib().lm_conv3x3_winograd_workspace_bytes(B, H, W, cin, dil), x.device, dedicated)
+    _hooked(f'wino_input {cin} d{dil} @{H}x{W} B{B}', 0.0,
+            lambda: check(lib().lm_winograd_input_transform_f32(_stream(), _ptr(x), ldx, B, H, W, cin, dil, _ptr(ws), ws.numel())))
     return WinoInput(ws, B, cin, H, W, dil)
 
 
@@ -170,54 +185,37 @@ def wino_transform_gn_up2(t, stats, gamma, beta, dedicated=False):
     t, ld = as_nhwc(t)                                  # may be a channel slice of a wider NHWC tensor (ld > C)
     B, cin, Hi, Wi = t.shape
     H, W = 2 * Hi, 2 * Wi
-    need = lib().lm_conv3x3_winograd_workspace_bytes(B, H, W, cin, 1)
-    if dedicated:
-        ws = torch.empty(need, device=t.device, dtype=torch.uint8)
-    else:
-        key = (t.device, _stream().value)
-        ws = _wino_ws.get(key)
-        if ws is None or ws.numel() < need:
-            ws = _wino_ws[key] = torch.empty(need, device=t.device, dtype=torch.uint8)
-    check(lib().lm_winograd_input_transform_gn_up2_f32(_stream(), _ptr(t), ld, _ptr(stats), _ptr(gamma), _ptr(beta), B, Hi, Wi, cin,
-                                                       _ptr(ws), ws.numel()))
+    ws = _wino_buf(lib().lm_conv3x3_winograd_workspace_bytes(B, H, W, cin, 1), t.device, dedicated)
+    _hooked(f'wino_input {cin} (gn+relu+up2 fused) @{H}x{W} B{B}', 0.0,
+            lambda: check(lib().lm_winograd_input_transform_gn_up2_f32(_stream(), _ptr(t), ld, _ptr(stats), _ptr(gamma), _ptr(beta),
+                                                                       B, Hi, Wi, cin, _ptr(ws), ws.numel())))
     return WinoInput(ws, B, cin, H, W, 1)
 
 
 def conv_wino(x, wu, cout, dil=1, scale=None, shift=None, res=None, act=ACT_NONE, out=None, gn_eps=None):
     """3x3 / stride 1 / pad = dil convolution via Winograd F(2x2,3x3).  x: an NHWC-stored tensor or a WinoInput (shared
     transform).  With gn_eps the GroupNorm(C,C) statistics of the output come out of the GEMM epilogue: returns (y, stats)."""
-    v = x if isinstance(x, WinoInput) else None
-    hook = _conv_hook
-
-    def run():
-        vi = v if v is not None else wino_transform(x, dil)
-        B, cin, H, W = vi.B, vi.cin, vi.H, vi.W
-        y = out if out is not None else new_act(B, cout, H, W, vi.buf.device)
-        y_, ldy = as_nhwc(y)
-        assert y_.data_ptr() == y.data_ptr(), 'conv_wino: `out` must already be NHWC-stored'
-        r, ldr = (None, 0) if res is None else as_nhwc(res)
-        part = None
-        if gn_eps is not None:
-            nchunk = lib().lm_winograd_gn_chunks(H, W, vi.dil)
-            part = torch.zeros((B, nchunk, cout, 2), device=vi.buf.device, dtype=torch.float64)   # padding chunks stay 0
-        check(lib().lm_winograd_gemm_f32(_stream(), _ptr(vi.buf), _ptr(wu), wu.shape[1], _ptr(scale), _ptr(shift), _ptr(r), ldr,
-                                         _ptr(y), ldy, B, H, W, cin, cout, vi.dil, act, _ptr(part)))
-        if gn_eps is None:
-            return y
-        stats = torch.empty((B, cout, 2), device=vi.buf.device, dtype=torch.float32)
-        check(lib().lm_gn_finalize(_stream(), _ptr(part), _ptr(stats), B, H * W, cout, part.shape[1], gn_eps))
-        return y, stats
-
-    if hook is None:
-        return run()
-    src = v if v is not None else x
-    B, cin = (src.B, src.cin) if v is not None else (src.shape[0], src.shape[1])
-    H, W = (src.H, src.W) if v is not None else src.shape[2:]
-    tiles = lib().lm_conv3x3_winograd_workspace_bytes(B, H, W, cin, dil) // (64 * cin)
-    box = {}
-    hook(f'wino {cin}->{cout} k3x3 d{dil} @{H}x{W} B{B}' + (' (shared V)' if v is not None else ''), 2.0 * B * H * W * cout * cin * 9,
-         lambda: box.setdefault('r', run()), 2.0 * 16 * tiles * cin * cout)
-    return box['r']
+    vi = x if isinstance(x, WinoInput) else wino_transform(x, dil)
+    B, cin, H, W = vi.B, vi.cin, vi.H, vi.W
+    y = out if out is not None else new_act(B, cout, H, W, vi.buf.device)
+    y_, ldy = as_nhwc(y)
+    assert y_.data_ptr() == y.data_ptr(), 'conv_wino: `out` must already be NHWC-stored'
+    r, ldr = (None, 0) if res is None else as_nhwc(res)
+    part = None
+    if gn_eps is not None:
+        nchunk = lib().lm_winograd_gn_chunks(H, W, vi.dil)
+        # every chunk the finalize pass reads is written by the GEMM (chunks made of padding rows only are stored as zeros)
+        part = torch.empty((B, nchunk, cout, 2), device=vi.buf.device, dtype=torch.float64)
+    tiles = lib().lm_conv3x3_winograd_workspace_bytes(B, H, W, cin, vi.dil) // (64 * cin)
+    _hooked(f'wino_gemm {cin}->{cout} k3x3 d{vi.dil} @{H}x{W} B{B}', 2.0 * B * H * W * cout * cin * 9,
+            lambda: check(lib().lm_winograd_gemm_f32(_stream(), _ptr(vi.buf), _ptr(wu), wu.shape[1], _ptr(scale), _ptr(shift), _ptr(r), ldr,
+                                                     _ptr(y), ldy, B, H, W, cin, cout, vi.dil, act, _ptr(part))),
+            2.0 * 16 * tiles * cin * cout)
+    if gn_eps is None:
+        return y
+    stats = torch.empty((B, cout, 2), device=vi.buf.device, dtype=torch.float32)
+    check(lib().lm_gn_finalize(_stream(), _ptr(part), _ptr(stats), B, H * W, cout, part.shape[1], gn_eps))
+    return y, stats
 
 
 def conv_mfma_gnstats(x, wp, cout, kh, kw, stride, pad, dil, shift, eps=1e-5):

@@ -25,6 +25,18 @@ class PackedModule(nn.Module):
         cache = self.__dict__.get('_packed_cache')
         if cache is None or cache[0] != key:
             with torch.no_grad():
-                cache = (key, self._pack())
+                P = self._pack()
+            # the packing kernels run on the CALLER's stream; another stream that picks the cached dict up must not read the
+            # packed weights before they are written: it waits for this event (dropped once it has completed)
+            ev = None
+            if torch.cuda.is_available() and any(isinstance(v, torch.Tensor) and v.is_cuda for v in P.values()):
+                ev = torch.cuda.Event()
+                ev.record()
+            cache = [key, P, ev, torch.cuda.current_stream().cuda_stream if ev is not None else None]
             self.__dict__['_packed_cache'] = cache
+        elif cache[2] is not None:
+            if cache[2].query():
+                cache[2] = None
+            elif torch.cuda.current_stream().cuda_stream != cache[3]:
+                torch.cuda.current_stream().wait_event(cache[2])
         return cache[1]

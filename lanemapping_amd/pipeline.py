@@ -19,9 +19,9 @@ class TilePipeline:
     def __init__(self, net, host_threads=8):
         self.net = net
         self.cfg = net.cfg
-        if net.cfg.heads.type != 'ColumnProposal2':
-            raise NotImplementedError(f"TilePipeline drives the ColumnProposal2 decode / polyline tail; for heads.type="
-                                      f"{net.cfg.heads.type!r} call the net directly (Detector1stage.forward returns its lane_maps)")
+        self.rowref = net.cfg.heads.type == 'RowSharNotReducRef'
+        if net.cfg.heads.type not in ('ColumnProposal2', 'RowSharNotReducRef'):
+            raise NotImplementedError(f'TilePipeline has no decode / polyline tail for heads.type={net.cfg.heads.type!r}')
         self.pool = ThreadPoolExecutor(max_workers=host_threads)
         self._pending = None
         self.host_seconds = 0.0      # accumulated wall time of the per-tile host tasks (all threads) and their count
@@ -32,27 +32,43 @@ class TilePipeline:
         # a [B,3,H,W] tile tensor (FPN path), a list of [N_i,4] point tensors (sparse-conv LiDAR path, config 5) or a batch dict
         batch = proj if isinstance(proj, dict) else ({'points': list(proj)} if isinstance(proj, (list, tuple)) else {'proj': proj})
         raw = self.net.forward_raw(batch)
-        prop_conf, v_ext, cls_conf, cls_idx, cls_offset = ops.decode_proposals(
-            raw['proposal_conf'], raw['ext2'], raw['cls2'], raw['offset2'], cfg.exist_thre, heads.prop_width, heads.prop_half_buff)
-        orient = ops.decode_orient(raw['orient'])
-        sem, biseg, rows = ops.decode_semantic(raw['semantic_seg'], cfg.coor_thre)
-        idx, score, status = ops.endp_topk(raw['endp_est'], K=decode.TOPK, clip=decode.CLIP)
-        dev = {'prop_conf': prop_conf, 'v_ext': v_ext, 'cls_offset': cls_offset, 'rows': rows, 'idx': idx, 'status': status}
+        if self.rowref:
+            # config 4 (reference row_shared_not_reduc_ref.py:334-393, :487-516): argmax columns on the device, per-lane tracing on the host
+            dev = {'col': heads.decode_columns(raw)}
+            keep = (raw, dev)
+            crop = 0
+        else:
+            prop_conf, v_ext, cls_conf, cls_idx, cls_offset = ops.decode_proposals(
+                raw['proposal_conf'], raw['ext2'], raw['cls2'], raw['offset2'], cfg.exist_thre, heads.prop_width, heads.prop_half_buff)
+            orient = ops.decode_orient(raw['orient'])
+            sem, biseg, rows = ops.decode_semantic(raw['semantic_seg'], cfg.coor_thre)
+            idx, score, status = ops.endp_topk(raw['endp_est'], K=decode.TOPK, clip=decode.CLIP)
+            dev = {'prop_conf': prop_conf, 'v_ext': v_ext, 'cls_offset': cls_offset, 'rows': rows, 'idx': idx, 'status': status}
+            keep = (raw, sem, biseg, orient, cls_conf, cls_idx, dev)      # keep device buffers alive until the copies land
+            crop = raw['endp_est'].shape[-1]
         host = {k: torch.empty(v.shape, dtype=v.dtype, pin_memory=True) for k, v in dev.items()}
         for k in dev:
             host[k].copy_(dev[k], non_blocking=True)
         ev = torch.cuda.Event()
         ev.record()
-        keep = (raw, sem, biseg, orient, cls_conf, cls_idx, dev)      # keep device buffers alive until the copies land
-        return host, ev, keep, raw['endp_est'].shape[-1]
+        return host, ev, keep, crop
 
     def _tile_task(self, host, b, crop_w):
         t0 = time.perf_counter()
-        pts, _ = hostpost.cluster_endpoints(host['idx'][b].numpy(), crop_w=crop_w, clip=decode.CLIP,
-                                            k0=self.net.heads.num_cls * 2 * 10, k_max=500)
-        lanes, kept = hostpost.assemble_polylines(host['prop_conf'][b].numpy(), host['v_ext'][b].numpy(),
-                                                  host['cls_offset'][b].numpy(), host['rows'][b].numpy(), pts,
-                                                  self.cfg.proposal_obj_thre)
+        if self.rowref:
+            heads = self.net.heads
+            cols = heads.lines_from_columns(host['col'][b].numpy(), heads.row_size)       # [L,144] column px (<= 0: none)
+            lanes = np.full((72, 144, 2), -1.0)                 # the [72,144,2] block the JSON writer / all-gather use
+            lanes[:, :, 1] = 0.0
+            lanes[:cols.shape[0], :, 0] = cols
+            lanes[:cols.shape[0], :, 1] = (cols > 0).astype(np.float64)
+            kept = np.zeros((0, 2), dtype=np.int32)
+        else:
+            pts, _ = hostpost.cluster_endpoints(host['idx'][b].numpy(), crop_w=crop_w, clip=decode.CLIP,
+                                                k0=self.net.heads.num_cls * 2 * 10, k_max=500)
+            lanes, kept = hostpost.assemble_polylines(host['prop_conf'][b].numpy(), host['v_ext'][b].numpy(),
+                                                      host['cls_offset'][b].numpy(), host['rows'][b].numpy(), pts,
+                                                      self.cfg.proposal_obj_thre)
         self.host_seconds += time.perf_counter() - t0      # (benign race between pool threads: statistics only)
         self.host_tiles += 1
         return lanes, kept
@@ -60,9 +76,9 @@ class TilePipeline:
     def _finish(self, pending):
         host, ev, keep, W = pending
         ev.synchronize()
-        if int(host['status'].max()) != 0:
-            raise LanemapHipError('endpoint top-K candidate overflow (too many tied scores)')
-        B = host['idx'].shape[0]
+        if not self.rowref and int(host['status'].max()) != 0:
+            raise LanemapHipError('endpoint top-K candidate overflow')   # guard only: the compaction is tie-safe (<= K candidates)
+        B = next(iter(host.values())).shape[0]
         return [self.pool.submit(self._tile_task, host, b, W - 2 * decode.CLIP) for b in range(B)]
 
     def submit(self, proj):

