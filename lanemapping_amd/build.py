@@ -12,6 +12,9 @@ SOURCES = ['errors.cpp', 'conv_mfma.hip', 'conv_wino.hip', 'conv_direct.hip', 'n
 
 # integer-output kernels whose fp32 index math must match the C oracle bit for bit
 EXACT_FP = {'raster.hip', 'lidar.hip', 'backproject.cpp'}
+# per-source extra flags.  conv_wino.hip: the SLP vectoriser packs the Winograd transform's adds into v_pk_add_f32 plus a dozen
+# v_mov shuffles per group; packed f32 VALU beside MFMAs costs issue slots (MI355X_MICROARCH.md, filler price list)
+EXTRA_FLAGS = {'conv_wino.hip': ['-fno-slp-vectorize']}
 
 
 def _stale():
@@ -35,6 +38,8 @@ def build(force=False, verbose=True):
                '-x', 'hip', '-c', os.path.join(CSRC, src), '-o', obj]
         if src in EXACT_FP:
             cmd.insert(4, '-ffp-contract=off')
+        for fl in EXTRA_FLAGS.get(src, []):
+            cmd.insert(4, fl)
         procs.append((src, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)))
         objs.append(obj)
     for src, p in procs:

@@ -551,6 +551,450 @@ WinoGeom geom(int B, int H, int W, int dil) {
     return g;
 }
 
+
+// =====================================================================================================================================
+// Implicit-transform Winograd: no V tensor.  One workgroup = 64 tiles x 64 output channels, 4 waves (one per SIMD) of 32 x 32.
+// The loop order is (input-channel slab) outer, xi inner: all SIXTEEN transformed products M[xi] of the wave tile live in registers
+// (16 accumulators x 16 = 256 AGPRs, hence one wave per SIMD), so a 32-channel slab of the RAW input patch of the 64 tiles is staged
+// in LDS once (global_load_lds gather straight from the NHWC tensor, zero block for padding) and is re-read 16 times from there: the
+// A fragment of xi = (i, j) is (d[ra][ca] +- d[rb][ca]) +- (d[ra][cb] +- d[rb][cb]), four ds_read_b128 and three vector adds in the
+// order the materialising kernel (transform_store) uses, so V - and therefore M[xi], accumulated over the same K order - has the
+// same bits.  The fold with A^T . A happens once at the end, in ascending xi like the streaming kernel: y is bit-identical.
+// B (U = G g G^T, repacked per wave fragment: [xi][slab][32-channel tile][kk][lane][4]) goes global -> registers one xi ahead.
+// Raw patch layout in LDS: cell (r, q) = patch row r (0..3), column slot q; the 64 tiles of a workgroup are consecutive in the
+// linear (phase, ty, tx) order, i.e. up to INSEG runs of horizontally adjacent tiles; inside a run neighbouring tiles share two
+// columns (slot of tile tl, patch column c: q = 2 tl + 2 run + c).  A cell is 32 floats = 8 chunks of 16 bytes; cell q sits at
+// position pi(q) (bits 0 and 1 swapped) with its chunks XOR-swizzled by (q >> 2) & 7: the 16 lanes of a ds_read_b128 group (tiles
+// tl..tl+15 at a fixed patch column) then cover all 64 banks.
+constexpr int IBM = 64, IBN = 64, INSEG = 4;
+constexpr int INCOL = 2 * IBM + 2 * INSEG;       // 136 column slots
+constexpr int ICELLS = 4 * INCOL;                // 544 cells per slab
+constexpr int IROW = INCOL * 32;                 // floats per patch row
+constexpr int IBUF = ICELLS * 32;                // floats per slab buffer (69,632 B)
+constexpr int ILPW = ICELLS * 8 / 64 / 4;        // global_load_lds instructions per wave and slab (17)
+static_assert(ICELLS * 8 % 256 == 0, "whole wave loads");
+
+__device__ __attribute__((aligned(16))) float g_wino_zeros[1024 + 32];   // zero source for padding cells, any channel slab (Cin <= 1024)
+
+struct WinoImpParams {
+    const float* x; const float* U; const float* scale; const float* shift; const float* res; float* y; const float* zeros;
+    int ldx, ldr, ldy, C, Cout, NT, act;      // NT = CoutP / 32 channel tiles in U
+    double* gn_part;
+    WinoGeom g;
+};
+
+__device__ __forceinline__ int swap01(int q) { return (q & ~3) | ((q & 1) << 1) | ((q >> 1) & 1); }
+
+// B fragment loads bypass the compiler's wait-count bookkeeping (it would drain the in-flight global_load_lds queue at every use):
+// explicit s_waitcnt vmcnt(N) below, tied to the destination registers through "+v" operands.
+__device__ __forceinline__ void bload4(f32x4 (&b)[4], unsigned voff, const float* sbase) {
+    asm volatile("global_load_dwordx4 %0, %4, %5\n\t"
+                 "global_load_dwordx4 %1, %4, %5 offset:1024\n\t"
+                 "global_load_dwordx4 %2, %4, %5 offset:2048\n\t"
+                 "global_load_dwordx4 %3, %4, %5 offset:3072"
+                 : "=&v"(b[0]), "=&v"(b[1]), "=&v"(b[2]), "=&v"(b[3]) : "v"(voff), "s"(sbase) : "memory");
+}
+template <int N>
+__device__ __forceinline__ void bwait(f32x4 (&b)[4]) {
+    asm volatile("s_waitcnt vmcnt(%4)" : "+v"(b[0]), "+v"(b[1]), "+v"(b[2]), "+v"(b[3]) : "n"(N) : "memory");
+}
+
+template <int I> struct WinoRow;      // B^T row i: d[RA] (+|-) d[RB]
+template <> struct WinoRow<0> { static constexpr int RA = 0, RB = 2; static constexpr bool SUB = true; };
+template <> struct WinoRow<1> { static constexpr int RA = 1, RB = 2; static constexpr bool SUB = false; };
+template <> struct WinoRow<2> { static constexpr int RA = 2, RB = 1; static constexpr bool SUB = true; };
+template <> struct WinoRow<3> { static constexpr int RA = 1, RB = 3; static constexpr bool SUB = true; };
+
+template <bool SUB>
+__device__ __forceinline__ f32x4 pm(const f32x4 a, const f32x4 b) {
+    f32x4 r;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) r[e] = SUB ? a[e] - b[e] : a[e] + b[e];
+    return r;
+}
+
+// raw patch values of the A fragment of (xi, kk): d[0] = (ra, ca), d[1] = (rb, ca), d[2] = (ra, cb), d[3] = (rb, cb)
+template <int XI, int KK>
+__device__ __forceinline__ void wino_a_load(f32x4 (&d)[4], const float* abuf, const int (&aoff)[4][4]) {
+    typedef WinoRow<(XI >> 2)> R;
+    typedef WinoRow<(XI & 3)> Cc;
+    d[0] = *reinterpret_cast<const f32x4*>(abuf + R::RA * IROW + aoff[Cc::RA][KK]);
+    d[1] = *reinterpret_cast<const f32x4*>(abuf + R::RB * IROW + aoff[Cc::RA][KK]);
+    d[2] = *reinterpret_cast<const f32x4*>(abuf + R::RA * IROW + aoff[Cc::RB][KK]);
+    d[3] = *reinterpret_cast<const f32x4*>(abuf + R::RB * IROW + aoff[Cc::RB][KK]);
+}
+// element t of the transformed fragment: rows first, then columns (the order of transform_store, i.e. the bits of V)
+template <int XI>
+__device__ __forceinline__ float wino_a_elem(const f32x4 (&d)[4], int t) {
+    typedef WinoRow<(XI >> 2)> R;
+    typedef WinoRow<(XI & 3)> Cc;
+    const float r0 = R::SUB ? d[0][t] - d[1][t] : d[0][t] + d[1][t];
+    const float r1 = R::SUB ? d[2][t] - d[3][t] : d[2][t] + d[3][t];
+    return Cc::SUB ? r0 - r1 : r0 + r1;
+}
+
+// One group = 4 MFMAs of (XI, KK) on the raw values in `cur`, with the LDS reads of the NEXT group (NXI, NKK) into `nxt` pinned
+// behind the first MFMA (sched_barrier(0) on both sides): the compiler waits with lgkmcnt(0) at the first use of LDS data whenever
+// LDS-DMA is in flight, so the only reads outstanding at a wait must be the ones it needs - issued ~250 cycles earlier.
+template <int XI, int NXI, int NKK, bool LOAD>
+__device__ __forceinline__ void wino_group(f32x16& acc, const f32x4 (&cur)[4], f32x4 (&nxt)[4], const f32x4 b, const float* abuf,
+                                           const int (&aoff)[4][4], f32x16& acc_alt) {
+#ifdef LM_IABL_NOXF
+#define LM_AEL(t) cur[0][t]
+#else
+#define LM_AEL(t) wino_a_elem<XI>(cur, t)
+#endif
+    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(LM_AEL(0), b[0], acc, 0, 0, 0);
+    __builtin_amdgcn_sched_barrier(0);
+#ifndef LM_IABL_NOLDS
+    if (LOAD) wino_a_load<NXI, NKK>(nxt, abuf, aoff);
+#else
+#pragma unroll
+    for (int e = 0; e < 4; ++e) nxt[e] = cur[e];
+#endif
+    __builtin_amdgcn_sched_barrier(0);
+#ifdef LM_IABL_2CHAIN                       // timing ablation: alternate two accumulators (wrong results)
+    acc_alt = __builtin_amdgcn_mfma_f32_32x32x2f32(LM_AEL(1), b[1], acc_alt, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(LM_AEL(2), b[2], acc, 0, 0, 0);
+    acc_alt = __builtin_amdgcn_mfma_f32_32x32x2f32(LM_AEL(3), b[3], acc_alt, 0, 0, 0);
+#else
+#pragma unroll
+    for (int t = 1; t < 4; ++t) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(LM_AEL(t), b[t], acc, 0, 0, 0);
+#endif
+    __builtin_amdgcn_sched_barrier(0);
+#undef LM_AEL
+}
+
+// One xi step of a slab.  All VMEM traffic of a wave shares ONE in-order counter (vmcnt): waiting for this step's B fragments also
+// waits for every patch load (global_load_lds) issued before them, and those come from HBM (~2 us under load) while B comes from
+// L2.  So (1) B runs BD = 3 steps (~1.3 us of matrix work) ahead in a ring of 4 register sets, (2) the next slab's ILPW patch
+// loads are issued in the FIRST six steps (G = 3,3,3,3,3,2), leaving ten steps for the last of them to land before the end-of-slab
+// wait, which (3) leaves the three youngest B sets in flight (vmcnt(12)).  NWAIT = loads allowed to stay outstanding when B of
+// this step is needed = 4 * BD + the patch loads issued during the last BD + 1 steps.
+// da holds the raw values of group (XI, 0) on entry and of (XI + 1, 0) on exit.
+constexpr int BD = 3;
+template <int XI, int G, int NWAIT>
+__device__ __forceinline__ void wino_imp_step(f32x16& acc, f32x16& acc_alt, f32x4 (&bq)[4][4], unsigned bvoff, const float* bpre_base,
+                                              const float* abuf, const int (&aoff)[4][4], f32x4 (&da)[4], f32x4 (&db)[4],
+                                              const float* const (&gsrc)[ILPW], long goff, float* nbuf, int wave, int& gnext) {
+    typedef __attribute__((address_space(1))) const void gptr_t;
+    typedef __attribute__((address_space(3))) void lptr_t;
+#ifndef LM_IABL_NOB                       // (timing ablations: tools/build_variant.sh)
+    bload4(bq[(XI + BD) & 3], bvoff, bpre_base);
+#endif
+#ifndef LM_IABL_NOGLDS
+#pragma unroll
+    for (int g = 0; g < G; ++g) {
+        const int s_ = gnext + g;
+        __builtin_amdgcn_global_load_lds((gptr_t*)(gsrc[s_] + goff), (lptr_t*)(nbuf + (s_ * 4 + wave) * 256), 16, 0, 0);
+    }
+#endif
+    gnext += G;
+    f32x4 (&bcur)[4] = bq[XI & 3];
+#if !defined(LM_IABL_NOB) && !defined(LM_IABL_NOGLDS)
+    bwait<NWAIT>(bcur);
+#else
+    bwait<0>(bcur);
+#endif
+    constexpr int NX = XI < 15 ? XI + 1 : 0;
+    wino_group<XI, XI, 1, true>(acc, da, db, bcur[0], abuf, aoff, acc_alt);
+    wino_group<XI, XI, 2, true>(acc, db, da, bcur[1], abuf, aoff, acc_alt);
+    wino_group<XI, XI, 3, true>(acc, da, db, bcur[2], abuf, aoff, acc_alt);
+    wino_group<XI, NX, 0, (XI < 15)>(acc, db, da, bcur[3], abuf, aoff, acc_alt);
+}
+
+__global__ __launch_bounds__(256) void wino_implicit_kernel(WinoImpParams p) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];      // [2][IBUF]
+    typedef __attribute__((address_space(1))) const void gptr_t;
+    typedef __attribute__((address_space(3))) void lptr_t;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm0 = (wave >> 1) * 32, wn0 = (wave & 1) * 32;
+    const int n_tiles = (p.Cout + IBN - 1) / IBN;
+    // XCD-aware order (workgroups are dealt round-robin to the 8 XCDs): every XCD owns a contiguous range of M blocks and walks it
+    // once per N tile, N tile OUTER - at any time the 32 CUs of an XCD stream the SAME 64-channel slice of U (1 MB for 256 -> 256:
+    // L2 resident; with the N tiles mixed the whole 4 MB U thrashes the 4 MB L2 and every B fragment load pays the fabric latency,
+    // which one wave per SIMD cannot hide); the raw patches are prefetched a whole slab ahead and do not care.
+    unsigned mblk, ntile;
+    {
+        const unsigned bid = blockIdx.x, mb = gridDim.x / (unsigned)n_tiles, mbx = mb / 8, full = mbx * 8 * (unsigned)n_tiles;
+        if (bid < full) {
+            const unsigned xcd = bid % 8, idx = bid / 8;
+            ntile = idx / mbx;
+            mblk = xcd * mbx + idx % mbx;
+        } else {
+            const unsigned r = bid - full;
+            mblk = 8 * mbx + r / (unsigned)n_tiles;
+            ntile = r % (unsigned)n_tiles;
+        }
+    }
+    const long m0 = (long)mblk * IBM;
+    const int n0 = (int)ntile * IBN;
+    const WinoGeom& g = p.g;
+    const int bi = (int)(m0 / g.Tpad);
+    const int t0 = (int)(m0 - (long)bi * g.Tpad);
+    // runs of horizontally adjacent tiles (wave-uniform): first local tile, length, (phase, ty, tx) of the first tile
+    int ts[INSEG + 1], sn[INSEG], stx[INSEG], sty[INSEG], sph[INSEG];
+    {
+        int at = 0, t = t0;
+#pragma unroll
+        for (int s_ = 0; s_ < INSEG; ++s_) {
+            ts[s_] = at;
+            const int tx = t % g.Tx, rest = t / g.Tx;
+            stx[s_] = tx;
+            sty[s_] = rest % g.Ty;
+            sph[s_] = rest / g.Ty;
+            const int n = at < IBM ? min(IBM - at, g.Tx - tx) : 0;
+            sn[s_] = n;
+            at += n;
+            t += n;
+        }
+        ts[INSEG] = at;            // == IBM (the launcher guarantees <= INSEG runs)
+    }
+    // --- per-lane sources of this wave's ILPW patch loads (one pointer each; the channel slab is a uniform offset)
+    const float* gsrc[ILPW];
+#pragma unroll
+    for (int s_ = 0; s_ < ILPW; ++s_) {
+        const int pos = (s_ * 4 + wave) * 8 + (lane >> 3);             // LDS cell position
+        const int r = pos / INCOL;
+        const int q = swap01(pos - r * INCOL);
+        const int ch = (lane & 7) ^ ((q >> 2) & 7);                    // slot p holds chunk p ^ key
+        int sg = 0;
+#pragma unroll
+        for (int k = 1; k < INSEG; ++k) sg += (sn[k] > 0 && q >= 2 * ts[k] + 2 * k) ? 1 : 0;
+        int n = sn[0], tx0 = stx[0], ty = sty[0], ph = sph[0], q0 = 0;
+#pragma unroll
+        for (int k = 1; k < INSEG; ++k)
+            if (sg == k) {
+                n = sn[k]; tx0 = stx[k]; ty = sty[k]; ph = sph[k]; q0 = 2 * ts[k] + 2 * k;
+            }
+        const int lc = q - q0;
+        const int py = 2 * ty - 1 + r, px = 2 * tx0 - 1 + lc;
+        const int pa = ph / g.dil, pb = ph - pa * g.dil;
+        const int yy = py * g.dil + pa, xx = px * g.dil + pb;
+        const bool ok = lc < 2 * n + 2 && ph < g.dil * g.dil && py >= 0 && px >= 0 && yy < g.H && xx < g.W;
+        gsrc[s_] = ok ? p.x + (((long)bi * g.H + yy) * g.W + xx) * p.ldx + ch * 4 : p.zeros + ch * 4;
+    }
+    // --- per-lane LDS offsets (floats, inside a patch row) of the A fragment reads: [patch column c][kk]
+    const int frow = lane & 31, fhalf = lane >> 5;
+    int aoff[4][4];
+    {
+        const int tl = wm0 + frow;
+        int sg = 0;
+#pragma unroll
+        for (int k = 1; k < INSEG; ++k) sg += (sn[k] > 0 && tl >= ts[k]) ? 1 : 0;
+        const int cb = 2 * tl + 2 * sg;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            const int q = cb + c, key = (q >> 2) & 7;
+#pragma unroll
+            for (int kk = 0; kk < 4; ++kk) aoff[c][kk] = (swap01(q) * 8 + ((2 * kk + fhalf) ^ key)) * 4;
+        }
+    }
+    const int cslabs = p.C / 32;
+    const unsigned bvoff = (unsigned)lane * 16u;
+    const long bstep = (long)p.NT * 1024;                              // floats between consecutive slabs of one xi
+    const float* const bbase = p.U + (long)((n0 + wn0) >> 5) * 1024;   // this wave's 32-channel tile
+
+    f32x16 acc[16];
+#pragma unroll
+    for (int k = 0; k < 16; ++k)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[k][r] = 0.f;
+    f32x4 bq[4][4];
+    const long bxi = (long)cslabs * bstep;                             // floats between consecutive xi
+    // prologue: slab 0 of the patch, B of steps 0 .. BD-1 of slab 0
+#pragma unroll
+    for (int s_ = 0; s_ < ILPW; ++s_)
+        __builtin_amdgcn_global_load_lds((gptr_t*)gsrc[s_], (lptr_t*)(smem + (s_ * 4 + wave) * 256), 16, 0, 0);
+    bload4(bq[0], bvoff, bbase);
+    bload4(bq[1], bvoff, bbase + bxi);
+    bload4(bq[2], bvoff, bbase + 2 * bxi);
+    bwait<0>(bq[0]);
+    bwait<0>(bq[1]);
+    bwait<0>(bq[2]);
+    __builtin_amdgcn_s_barrier();
+
+    for (int cs = 0; cs < cslabs; ++cs) {
+        const float* abuf = smem + (cs & 1) * IBUF;
+        float* nbuf = smem + ((cs & 1) ^ 1) * IBUF;
+        const bool more = cs + 1 < cslabs;
+        // the last slab has nothing to prefetch: its loads re-read slab 0 of the zero block / tensor into the idle buffer (harmless)
+        const long goff = more ? (long)(cs + 1) * 32 : 0;
+        const float* const bs = bbase + (long)cs * bstep;                                   // (xi 0, this slab)
+        const float* const bs_next = bbase + (long)(more ? cs + 1 : 0) * bstep;             // (xi 0, next slab)
+        int gnext = 0;
+        f32x4 da[4], db[4];
+        wino_a_load<0, 0>(da, abuf, aoff);
+        // B prefetched by step XI belongs to step XI + BD: same slab while XI + BD < 16, else step XI + BD - 16 of the next slab
+#define LM_WSTEP(XI, G, NW) \
+        wino_imp_step<XI, G, NW>(acc[XI], acc[(XI) ^ 8], bq, bvoff, (XI) + BD < 16 ? bs + (long)((XI) + BD) * bxi : bs_next + (long)((XI) + BD - 16) * bxi, \
+                                 abuf, aoff, da, db, gsrc, goff, nbuf, wave, gnext)
+        LM_WSTEP(0, 3, 15);
+        LM_WSTEP(1, 3, 18);
+        LM_WSTEP(2, 3, 21);
+        LM_WSTEP(3, 3, 24);
+        LM_WSTEP(4, 3, 24);
+        LM_WSTEP(5, 2, 23);
+        LM_WSTEP(6, 0, 20);
+        LM_WSTEP(7, 0, 17);
+        LM_WSTEP(8, 0, 14);
+        LM_WSTEP(9, 0, 12);
+        LM_WSTEP(10, 0, 12);
+        LM_WSTEP(11, 0, 12);
+        LM_WSTEP(12, 0, 12);
+        LM_WSTEP(13, 0, 12);
+        LM_WSTEP(14, 0, 12);
+        LM_WSTEP(15, 0, 12);
+#undef LM_WSTEP
+        static_assert(3 * 5 + 2 == ILPW, "patch loads per wave and slab");
+        bwait<12>(bq[0]);                      // every patch load of the next slab has landed (only the 3 youngest B sets are in flight)
+        __builtin_amdgcn_s_barrier();
+    }
+    // The last slab's B prefetches (re-reads of valid addresses, never used) are still in flight: they must land before the compiler
+    // hands their destination registers to the epilogue - a late return would overwrite whatever lives there by then (pointers).
+    bwait<0>(bq[0]);
+    bwait<0>(bq[1]);
+    bwait<0>(bq[2]);
+
+#ifdef LM_IABL_NOEPI
+    {   // timing ablation: no fold / transposes / stores; one value per thread keeps the accumulators live
+        float sum = 0.f;
+#pragma unroll
+        for (int k = 0; k < 16; ++k)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) sum += acc[k][r];
+        p.y[(long)blockIdx.x * 256 + tid] = sum;
+        return;
+    }
+#endif
+    // --- epilogue: fold the 16 products into the 2x2 outputs (ascending xi, exact +-1 coefficients), one output position at a time;
+    // the wave tile is transposed through LDS (wave-private staging) so that stores are 16-byte channel vectors
+    constexpr int ELD = 32 + 4;
+    float* stage = smem + wave * (32 * ELD);
+    constexpr int LPR = 8, RPI = 8, NP = 4;
+    const int c4 = (lane & 7) * 4;
+    const int n = n0 + wn0 + c4;
+    f32x4 sc = {1.f, 1.f, 1.f, 1.f}, sh = {0.f, 0.f, 0.f, 0.f};
+    if (n < p.Cout) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+            if (n + e < p.Cout) {
+                if (p.scale) sc[e] = p.scale[n + e];
+                if (p.shift) sh[e] = p.shift[n + e];
+            }
+    }
+    const bool vec = (n + 3 < p.Cout) && ((p.ldy & 3) == 0) && (!p.res || (p.ldr & 3) == 0);
+    f32x4 gs = {0.f, 0.f, 0.f, 0.f}, gq = {0.f, 0.f, 0.f, 0.f};
+    int pix0[NP];
+    unsigned vmask = 0;
+    {
+        int t = t0 + wm0 + lane / LPR;
+        int tx = t % g.Tx, q = t / g.Tx;
+        int ty = q % g.Ty, ph = q / g.Ty;
+        int pa = ph / g.dil, pb = ph % g.dil;
+#pragma unroll
+        for (int pass = 0; pass < NP; ++pass) {
+            const int oy = 2 * ty * g.dil + pa, ox = 2 * tx * g.dil + pb;
+            pix0[pass] = (bi * g.H + oy) * g.W + ox;
+            if (t < g.Timg && oy < g.H && ox < g.W)
+                vmask |= (1u | (oy + g.dil < g.H ? 2u : 0u) | (ox + g.dil < g.W ? 4u : 0u)) << (3 * pass);
+            t += RPI;
+            tx += RPI;
+            while (tx >= g.Tx) {
+                tx -= g.Tx;
+                if (++ty >= g.Ty) {
+                    ty = 0;
+                    ++ph;
+                    pa = ph / g.dil;
+                    pb = ph % g.dil;
+                }
+            }
+        }
+    }
+    const int step_a = g.dil * g.W, step_b = g.dil;
+    __syncthreads();                                   // every wave is done with the patch buffers
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b) {
+            f32x16 o;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) o[r] = 0.f;
+#pragma unroll
+            for (int xi = 0; xi < 16; ++xi) {
+                const int wi = xi >> 2, wj = xi & 3;
+                const float ca = a == 0 ? (wi < 3 ? 1.f : 0.f) : (wi == 0 ? 0.f : (wi == 1 ? 1.f : -1.f));
+                const float cb = b == 0 ? (wj < 3 ? 1.f : 0.f) : (wj == 0 ? 0.f : (wj == 1 ? 1.f : -1.f));
+                const float c = ca * cb;
+                if (c == 0.f) continue;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) o[r] = fmaf(acc[xi][r], c, o[r]);
+            }
+            __builtin_amdgcn_wave_barrier();
+#pragma unroll
+            for (int r = 0; r < 16; ++r) stage[((r & 3) + 8 * (r >> 2) + 4 * fhalf) * ELD + frow] = o[r];
+            __builtin_amdgcn_wave_barrier();
+            if (n >= p.Cout) continue;
+#pragma unroll
+            for (int pass = 0; pass < NP; ++pass) {
+                const int row = pass * RPI + lane / LPR;
+                const unsigned vm = vmask >> (3 * pass);
+                if (!(vm & 1u) || (a && !(vm & 2u)) || (b && !(vm & 4u))) continue;
+                const long pix = pix0[pass] + a * step_a + b * step_b;
+                f32x4 v = *reinterpret_cast<const f32x4*>(stage + row * ELD + c4);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] = p.scale ? v[e] * sc[e] + sh[e] : v[e] + sh[e];
+                if (p.gn_part) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        gs[e] += v[e];
+                        gq[e] = fmaf(v[e], v[e], gq[e]);
+                    }
+                }
+                if (vec) {
+                    if (p.res) {
+                        const f32x4 rr = *reinterpret_cast<const f32x4*>(p.res + pix * p.ldr + n);
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) v[e] += rr[e];
+                    }
+                    if (p.act == LM_ACT_RELU) {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
+                    }
+                    *reinterpret_cast<f32x4*>(p.y + pix * p.ldy + n) = v;
+                } else {
+                    for (int e = 0; e < 4 && n + e < p.Cout; ++e) {
+                        float u = v[e];
+                        if (p.res) u += p.res[pix * p.ldr + n + e];
+                        if (p.act == LM_ACT_RELU) u = fmaxf(u, 0.f);
+                        p.y[pix * p.ldy + n + e] = u;
+                    }
+                }
+            }
+        }
+    if (p.gn_part && n < p.Cout) {   // fixed-order reduction over the 8 lanes that share a channel quad, then one writer lane
+#pragma unroll
+        for (int o = LPR; o < 64; o <<= 1)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                gs[e] += __shfl_xor(gs[e], o);
+                gq[e] += __shfl_xor(gq[e], o);
+            }
+        if (lane < LPR) {
+            const long chunk = (t0 + wm0) / 32;                     // 32-tile chunk of this wave tile inside image bi
+            double* o = p.gn_part + (((long)bi * (g.Tpad / 32) + chunk) * p.Cout + n) * 2;
+            for (int e = 0; e < 4 && n + e < p.Cout; ++e) {
+                o[2 * e] = (double)gs[e];
+                o[2 * e + 1] = (double)gq[e];
+            }
+        }
+    }
+}
+
+// runs of adjacent tiles a 64-tile block can touch: floor((IBM - 2) / Tx) + 2
+bool wino_implicit_ok(const WinoGeom& g) { return (IBM - 2) / g.Tx + 2 <= INSEG; }
+
 }  // namespace
 
 LM_API long lm_conv3x3_winograd_workspace_bytes(int B, int H, int W, int Cin, int dil) {
@@ -649,4 +1093,48 @@ LM_API int lm_conv3x3_winograd_f32(void* stream, const float* x, int ldx, const 
                                    int Cout, int dil, int act, void* workspace, long workspace_bytes) {
     if (int e = lm_winograd_input_transform_f32(stream, x, ldx, B, H, W, Cin, dil, workspace, workspace_bytes)) return e;
     return lm_winograd_gemm_f32(stream, workspace, wu, CoutP, scale, shift, res, ldr, y, ldy, B, H, W, Cin, Cout, dil, act, nullptr);
+}
+
+// 1 if lm_conv3x3_winograd_implicit_f32 covers the shape (wide enough tile rows: at most INSEG runs of adjacent tiles per block)
+LM_API int lm_winograd_implicit_supported(int H, int W, int Cin, int dil) {
+    if (dil < 1 || H < 1 || W < 1 || Cin < 32 || Cin % 32 != 0 || Cin > 1024) return 0;
+    return wino_implicit_ok(geom(1, H, W, dil)) ? 1 : 0;
+}
+
+// Same result as lm_conv3x3_winograd_f32 without the transformed-input tensor (wino_implicit_kernel): x NHWC (ldx floats between
+// pixels), wu_frag = U = G g G^T repacked per wave fragment, [16][Cin/32][CoutP/32][4][64][4] floats:
+//   wu_frag[xi][cs][nt][kk][lane][e] = U[xi][nt*32 + (lane & 31)][cs*32 + kk*8 + (lane >> 5)*4 + e]     (ops.pack_wino_fragments)
+LM_API int lm_conv3x3_winograd_implicit_f32(void* stream, const float* x, int ldx, const float* wu_frag, int CoutP, const float* scale,
+                                            const float* shift, const float* res, int ldr, float* y, int ldy, int B, int H, int W,
+                                            int Cin, int Cout, int dil, int act, double* gn_partial) {
+    LM_REQUIRE(x && wu_frag && y, "conv_wino_implicit: null pointer");
+    LM_REQUIRE(lm_winograd_implicit_supported(H, W, Cin, dil) && B > 0, "conv_wino_implicit: unsupported shape (H=%d W=%d Cin=%d dil=%d)", H, W, Cin, dil);
+    LM_REQUIRE(CoutP >= Cout && CoutP % 128 == 0, "conv_wino_implicit: CoutP=%d must be Cout=%d rounded up to 128", CoutP, Cout);
+    LM_REQUIRE(ldx >= Cin && ldx % 4 == 0 && ldy >= Cout, "conv_wino_implicit: bad leading dimension");
+    LM_REQUIRE(act == LM_ACT_NONE || act == LM_ACT_RELU, "conv_wino_implicit: activation %d not supported", act);
+    LM_REQUIRE(!gn_partial || (res == nullptr && act == LM_ACT_NONE && Cout % 4 == 0), "conv_wino_implicit(gn stats): no residual / activation");
+    WinoImpParams p;
+    p.g = geom(B, H, W, dil);
+    LM_REQUIRE((long)B * H * W * ldx < (1L << 40) && (long)B * H * W < (1L << 31) && p.g.T < (1L << 31), "conv_wino_implicit: tensor too large");
+    p.x = x; p.U = wu_frag; p.scale = scale; p.shift = shift; p.res = res; p.y = y;
+    p.ldx = ldx; p.ldr = ldr; p.ldy = ldy; p.C = Cin; p.Cout = Cout; p.NT = CoutP / 32; p.act = act;
+    p.gn_part = gn_partial;
+    static const float* zeros = nullptr;
+    if (!zeros) {
+        void* sym = nullptr;
+        LM_HIP(hipGetSymbolAddress(&sym, HIP_SYMBOL(g_wino_zeros)));
+        zeros = (const float*)sym;
+    }
+    p.zeros = zeros;
+    const size_t lds = (size_t)2 * IBUF * sizeof(float);
+    static bool attr_set = false;
+    if (!attr_set) {
+        LM_HIP(hipFuncSetAttribute((const void*)wino_implicit_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        attr_set = true;
+    }
+    const long blocks = (p.g.T / IBM) * ((Cout + IBN - 1) / IBN);
+    LM_REQUIRE(blocks > 0 && blocks < (1L << 31) && p.g.T % IBM == 0, "conv_wino_implicit: bad grid %ld", blocks);
+    hipLaunchKernelGGL(wino_implicit_kernel, dim3((unsigned)blocks), dim3(256), lds, (hipStream_t)stream, p);
+    LM_LAUNCH_CHECK();
+    return LM_OK;
 }

@@ -85,6 +85,15 @@ def pack_wino(w):
     return p.contiguous()
 
 
+def pack_wino_fragments(wu):
+    """pack_wino output U [16, CoutP, Cin] -> the per-wave-fragment order of lm_conv3x3_winograd_implicit_f32:
+    [16][Cin/32][CoutP/32][kk 4][lane 64][4] with lane = fhalf * 32 + row, k = cs*32 + kk*8 + fhalf*4 + e."""
+    xi, cop, ci = wu.shape
+    assert xi == 16 and cop % 32 == 0 and ci % 32 == 0
+    t = wu.reshape(16, cop // 32, 32, ci // 32, 4, 2, 4)                 # xi, nt, row, cs, kk, fhalf, e
+    return t.permute(0, 3, 1, 4, 5, 2, 6).contiguous().reshape(16, ci // 32, cop // 32, 4, 64, 4)
+
+
 def pack_small(w):
     """[Cout<=16,Cin,KH,KW] -> [KH*KW, Cin, 16]."""
     co, ci, kh, kw = w.shape
@@ -214,6 +223,35 @@ def conv_wino(x, wu, cout, dil=1, scale=None, shift=None, res=None, act=ACT_NONE
     if gn_eps is None:
         return y
     stats = torch.empty((B, cout, 2), device=vi.buf.device, dtype=torch.float32)
+    check(lib().lm_gn_finalize(_stream(), _ptr(part), _ptr(stats), B, H * W, cout, part.shape[1], gn_eps))
+    return y, stats
+
+
+def wino_implicit_supported(H, W, cin, dil=1):
+    return bool(lib().lm_winograd_implicit_supported(int(H), int(W), int(cin), int(dil)))
+
+
+def conv_wino_implicit(x, wf, cout, dil=1, scale=None, shift=None, res=None, act=ACT_NONE, out=None, gn_eps=None):
+    """3x3 / stride 1 / pad = dil convolution via Winograd F(2x2,3x3) WITHOUT the transformed-input tensor (implicit transform in the
+    GEMM's A path).  wf = pack_wino_fragments(pack_wino(w)).  Same bits as conv_wino; with gn_eps returns (y, stats)."""
+    x, ldx = as_nhwc(x)
+    B, cin, H, W = x.shape
+    cop = wf.shape[2] * 32
+    y = out if out is not None else new_act(B, cout, H, W, x.device)
+    y_, ldy = as_nhwc(y)
+    assert y_.data_ptr() == y.data_ptr(), 'conv_wino_implicit: `out` must already be NHWC-stored'
+    r, ldr = (None, 0) if res is None else as_nhwc(res)
+    part = None
+    if gn_eps is not None:
+        part = torch.empty((B, lib().lm_winograd_gn_chunks(H, W, dil), cout, 2), device=x.device, dtype=torch.float64)
+    tiles = lib().lm_conv3x3_winograd_workspace_bytes(B, H, W, cin, dil) // (64 * cin)
+    _hooked(f'wino_implicit {cin}->{cout} k3x3 d{dil} @{H}x{W} B{B}', 2.0 * B * H * W * cout * cin * 9,
+            lambda: check(lib().lm_conv3x3_winograd_implicit_f32(_stream(), _ptr(x), ldx, _ptr(wf), cop, _ptr(scale), _ptr(shift), _ptr(r), ldr,
+                                                                 _ptr(y), ldy, B, H, W, cin, cout, dil, act, _ptr(part))),
+            2.0 * 16 * tiles * cin * cout)
+    if gn_eps is None:
+        return y
+    stats = torch.empty((B, cout, 2), device=x.device, dtype=torch.float32)
     check(lib().lm_gn_finalize(_stream(), _ptr(part), _ptr(stats), B, H * W, cout, part.shape[1], gn_eps))
     return y, stats
 

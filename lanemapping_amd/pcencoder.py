@@ -28,6 +28,10 @@ USE_WINOGRAD = os.environ.get('LANEMAP_WINOGRAD', '1') != '0'
 WINO_MIN_CIN = int(os.environ.get('LANEMAP_WINO_MIN_CIN', '128'))
 MERGE_BRANCH_CONVS = os.environ.get('LANEMAP_MERGE_BRANCH_CONVS', '1') != '0'   # conv_b of both semantic branches on p2 / p3 as one GEMM
 FUSE_UP_WINO = os.environ.get('LANEMAP_FUSE_UP_WINO', '1') != '0'    # s4: GN + ReLU + x2 upsample fused into the Winograd input transform
+# Winograd without the V tensor (csrc/conv_wino.hip wino_implicit_kernel, bit-identical results): for the convolutions whose input is
+# consumed by ONE Winograd GEMM (BasicBlock convs, smooth*); inputs shared by several GEMMs (p2 / p3 / p4 of the semantic branches) and the
+# fused GN+upsample producer keep the materialised transform.  LANEMAP_WINO_IMPLICIT=1 switches it on (A/B numbers: profiles/README.md)
+WINO_IMPLICIT = os.environ.get('LANEMAP_WINO_IMPLICIT', '0') != '0' 
 
 
 class _ResBlock(nn.Module):
@@ -131,6 +135,10 @@ class FPNEncoder(PackedModule):
                         P[k + '.w1u'] = ops.pack_wino(blk.conv1.weight)
                     if blk.conv2.in_channels >= WINO_MIN_CIN:
                         P[k + '.w2u'] = ops.pack_wino(blk.conv2.weight)
+                    if WINO_IMPLICIT:
+                        for q in ('.w1u', '.w2u'):
+                            if (k + q) in P:
+                                P[k + q + 'f'] = ops.pack_wino_fragments(P[k + q])
                 if blk.downsample is not None:
                     P[k + '.wd'] = ops.pack_mfma(blk.downsample[0].weight)
                     P[k + '.sd'], P[k + '.bd'] = ops.fold_bn(blk.downsample[1])
@@ -141,6 +149,8 @@ class FPNEncoder(PackedModule):
             P[name + '.b'] = m.bias.float().contiguous()
             if USE_WINOGRAD and m.kernel_size == (3, 3) and m.in_channels >= WINO_MIN_CIN:
                 P[name + '.wu'] = ops.pack_wino(m.weight)
+                if WINO_IMPLICIT and name.startswith('smooth'):
+                    P[name + '.wuf'] = ops.pack_wino_fragments(P[name + '.wu'])
         # the two branches convolve p2 and p3 with different weights: one GEMM with the output channels concatenated reads V once
         # per 4 N tiles instead of per 2 (same values per channel: an output column does not depend on its neighbours)
         a, b2 = self.semantic_branch, self.semantic_branch2
@@ -167,6 +177,8 @@ class FPNEncoder(PackedModule):
     @staticmethod
     def _c3(x, P, wkey, cout, stride, dil, **epi):
         """3x3 convolution, pad = dilation: Winograd when its transformed weights were packed, else the direct kernel."""
+        if (wkey + 'uf') in P and stride == 1 and ops.wino_implicit_supported(x.shape[2], x.shape[3], x.shape[1], dil):
+            return ops.conv_wino_implicit(x, P[wkey + 'uf'], cout, dil, **epi)
         if (wkey + 'u') in P and stride == 1:
             return ops.conv_wino(x, P[wkey + 'u'], cout, dil, **epi)
         return ops.conv_mfma(x, P[wkey], cout, 3, 3, stride, dil, dil, **epi)

@@ -968,6 +968,46 @@ def test_bench_two_ranks_code_path(dev):
     assert d['n_gpus'] == 2 and d['steps'] == 3 and d['cpu_baseline'] is None and d['value'] > 10
 
 
+@pytest.mark.parametrize('B,cin,cout,H,W,dil', [(2, 128, 128, 48, 44, 1), (1, 256, 200, 43, 61, 1), (2, 128, 64, 84, 90, 2),
+                                                (1, 160, 256, 85, 87, 2), (3, 128, 96, 42, 300, 1), (1, 256, 256, 144, 144, 2),
+                                                (2, 256, 512, 144, 144, 1), (1, 128, 128, 127, 129, 3)])
+def test_conv_winograd_implicit_bit_identical(dev, B, cin, cout, H, W, dil):
+    """lm_conv3x3_winograd_implicit_f32 (no V tensor: raw patches staged in LDS, B^T d B in the A-fragment path, 16 xi accumulators
+    in registers) produces the SAME BITS as the transform + streaming-GEMM pair on ragged sizes, dilations, channel counts that
+    are not multiples of the tiles, with BN scale/shift, residual and ReLU; its GroupNorm statistics agree with the statistics kernel."""
+    from lanemapping_amd import ops
+    assert ops.wino_implicit_supported(H, W, cin, dil)
+    g = torch.Generator().manual_seed(B * 1000 + cin + H + dil)
+    x = torch.randn((B, cin, H, W), generator=g)
+    w = torch.randn((cout, cin, 3, 3), generator=g) / (cin * 9) ** 0.5
+    scale, shift = torch.rand(cout, generator=g) + 0.5, torch.randn(cout, generator=g)
+    res = torch.randn((B, cout, H, W), generator=g)
+    xd = x.to(dev).permute(0, 2, 3, 1).contiguous().permute(0, 3, 1, 2)
+    rd = res.to(dev).permute(0, 2, 3, 1).contiguous().permute(0, 3, 1, 2)
+    wu = ops.pack_wino(w.to(dev))
+    wf = ops.pack_wino_fragments(wu)
+    sd, bd = scale.to(dev), shift.to(dev)
+    y0 = ops.conv_wino(xd, wu, cout, dil, scale=sd, shift=bd, res=rd, act=ops.ACT_RELU)
+    y1 = ops.conv_wino_implicit(xd, wf, cout, dil, scale=sd, shift=bd, res=rd, act=ops.ACT_RELU)
+    assert torch.equal(y0, y1), float((y0 - y1).abs().max())
+    want = F.relu(F.conv2d(x.double(), w.double(), None, 1, dil, dil) * scale.double().view(1, -1, 1, 1) + shift.double().view(1, -1, 1, 1)
+                  + res.double()).float()
+    _close(y1, want, 1e-4, 'implicit winograd vs fp64')
+    # a channel slice of a wider tensor as input, and a channel slice as output
+    wide = ops.new_act(B, cin + 32, H, W, dev).normal_()
+    wide[:, 16:16 + cin].copy_(xd)
+    outw = ops.new_act(B, cout + 8, H, W, dev).zero_()
+    ops.conv_wino_implicit(wide[:, 16:16 + cin], wf, cout, dil, shift=bd, out=outw[:, 4:4 + cout])
+    y2 = ops.conv_wino(xd, wu, cout, dil, shift=bd)
+    assert torch.equal(outw[:, 4:4 + cout], y2) and float(outw[:, :4].abs().max()) == 0 and float(outw[:, 4 + cout:].abs().max()) == 0
+    if cout in (64, 128, 256):                             # (channel counts the standalone statistics kernel takes)
+        y3, st = ops.conv_wino_implicit(xd, wf, cout, dil, shift=bd, gn_eps=1e-5)
+        assert torch.equal(y3, y2)
+        _close(st, ops.gn_stats(y3, 1e-5), 2e-5, 'gn stats from the implicit epilogue')
+        y4, st2 = ops.conv_wino_implicit(xd, wf, cout, dil, shift=bd, gn_eps=1e-5)
+        assert torch.equal(st, st2)                          # deterministic
+
+
 @pytest.mark.parametrize('seed', [3001, 3002])
 def test_full_tiles_other_seeds_vs_oracle(dev, net, synth_sd, seed):
     """Full 1152^2 tiles the goldens do not cover: raw outputs within 1e-4 of the tensor scale, and every integer decision

@@ -17,12 +17,20 @@ for cin, cout, dil, hw in SHAPES:
     shift = torch.randn(cout, device=dev)
     res = ops.new_act(B, cout, hw, hw, dev).normal_()
     wp, wu = ops.pack_mfma(w), ops.pack_wino(w)
+    wf = ops.pack_wino_fragments(wu)
+    imp = ops.wino_implicit_supported(hw, hw, cin, dil)
     yd = ops.conv_mfma(x, wp, cout, 3, 3, 1, dil, dil, shift=shift, res=res, act=ops.ACT_RELU)
     yw = ops.conv_wino(x, wu, cout, dil, shift=shift, res=res, act=ops.ACT_RELU)
     err = float((yd - yw).abs().max())
     out = {}
-    for name, fn in (('direct', lambda: ops.conv_mfma(x, wp, cout, 3, 3, 1, dil, dil, shift=shift, out=yd)),
-                     ('wino', lambda: ops.conv_wino(x, wu, cout, dil, shift=shift, out=yw))):
+    same = None
+    cases = [('direct', lambda: ops.conv_mfma(x, wp, cout, 3, 3, 1, dil, dil, shift=shift, out=yd)),
+             ('wino', lambda: ops.conv_wino(x, wu, cout, dil, shift=shift, out=yw))]
+    if imp:
+        yi = ops.conv_wino_implicit(x, wf, cout, dil, shift=shift, res=res, act=ops.ACT_RELU)
+        same = bool(torch.equal(yi, yw))
+        cases.append(('implicit', lambda: ops.conv_wino_implicit(x, wf, cout, dil, shift=shift, out=yi)))
+    for name, fn in cases:
         for _ in range(2):
             fn()
         torch.cuda.synchronize()
@@ -35,4 +43,6 @@ for cin, cout, dil, hw in SHAPES:
         out[name] = a.elapsed_time(b) / 10
     fl = 2.0 * B * hw * hw * cout * cin * 9
     print(f'{cin:4d}->{cout:4d} d{dil} @{hw}: max|diff| {err:.2e}  direct {out["direct"]:.3f} ms ({fl / out["direct"] / 1e9:6.1f} TF)  '
-          f'wino {out["wino"]:.3f} ms ({fl / out["wino"] / 1e9:6.1f} TF-equivalent)  x{out["direct"] / out["wino"]:.2f}')
+          f'wino {out["wino"]:.3f} ms ({fl / out["wino"] / 1e9:6.1f} TF-equivalent)  x{out["direct"] / out["wino"]:.2f}'
+          + (f'  implicit {out["implicit"]:.3f} ms ({fl / out["implicit"] / 1e9:6.1f} TF-eq, {fl * 16 / 36 / out["implicit"] / 1e9:6.1f} executed)  '
+             f'bit-identical to wino: {same}' if imp else ''))
