@@ -187,3 +187,14 @@ def las_points(seed, n=4194304, extent=57.6):
                      800.0 + 8200.0 * uniform(seed, n, 18))
     inten = np.floor(inten)
     return np.stack([x, y, z, inten], axis=1).astype(np.float32)
+
+
+def apply_gains_(module, gains):
+    """Multiply named parameters in place: gains = {state-dict key: factor}.  Used to derive better-conditioned synthetic heads
+    from the seeded weights (e.g. a regression layer whose outputs stay inside one bin) - same keys in the reference and here."""
+    import torch
+    sd = module.state_dict()
+    with torch.no_grad():
+        for k, g in gains.items():
+            sd[k].mul_(float(g))
+    return module

@@ -336,6 +336,62 @@ def g14(cfg, net):
     save('g14_metrics.npz', seeds=np.array([801, 802, 803, 804]), **keep)
 
 
+G15_GAINS = {'heads.offset2.2.weight': 0.02, 'heads.offset2.2.bias': 0.02}     # |offset2| stays inside one bin
+G15_TILES = (2021, 2023)
+
+
+def g15(cfg, net):
+    """Stability-screened end-to-end golden.  The polyline assembly is discontinuous, and on the G10 tile (seeded weights as they
+    come: |offset2| up to 30) a 1e-7 change regroups vertices, so G10 pins it stage by stage only.  Here the offset-regression
+    layer is scaled by 0.02 (vertex columns then stay inside their bin) and the tiles are SCREENED: kept only if the reference's
+    own final output - which vertices exist, their semantics, the kept endpoints - is identical for x, x + 1e-5 n and x - 1e-5 n
+    (n = seeded +-1 noise) and the columns move by < 1e-2 px.  An implementation that matches the decode within 1e-4 must then
+    reproduce the reference's polylines exactly.  (Screen run over tile seeds 2021..2023: 2022 failed, 2021 and 2023 passed.)"""
+    cfg2, net2 = ref_net(seed=2021)
+    synth.apply_gains_(net2, G15_GAINS)
+    keep = {}
+
+    cap = {}
+    orig = net2.heads.get_exist_coor_endp_dict
+
+    def spy(out):          # the post-processing mutates the decode dictionary in place: keep a copy of what the decode returned
+        d = orig(out)
+        cap['dec'] = {k: (v.detach().clone() if torch.is_tensor(v) else v) for k, v in d.items()}
+        return d
+    net2.heads.get_exist_coor_endp_dict = spy
+
+    def run(x):
+        with torch.no_grad():
+            o = _quiet(net2, {'proj': x})
+        return o
+
+    for i, ts in enumerate(G15_TILES):
+        x = torch.from_numpy(synth.bev_batch([ts], 1152))
+        noise = torch.from_numpy(((synth.uniform(synth.fnv1a64('g15noise') ^ ts, x.numel()) > 0.5).astype(np.float32) * 2 - 1).reshape(x.shape))
+        o = run(x)
+        dec = cap['dec']
+        V = o['lane_maps']['cls_offset_smooth'][0]
+        E = np.stack(np.nonzero(o['lane_maps']['endp_by_cls'][0]), axis=1)
+        for sgn in (1.0, -1.0):
+            o2 = run(x + sgn * 1e-5 * noise)
+            V2 = o2['lane_maps']['cls_offset_smooth'][0]
+            E2 = np.stack(np.nonzero(o2['lane_maps']['endp_by_cls'][0]), axis=1)
+            assert np.array_equal(V[:, :, 0] > 0, V2[:, :, 0] > 0) and np.array_equal(V[:, :, 1], V2[:, :, 1]) and np.array_equal(E, E2), \
+                f'tile {ts} is not stable under a 1e-5 input perturbation'
+            assert float(np.abs(V[:, :, 0] - V2[:, :, 0]).max()) < 1e-2
+        nl = int((np.count_nonzero(V[:, :, 0] > 0, axis=1) >= 2).sum())
+        print(f'  tile {ts}: {nl} lines, {len(E)} endpoints, max |cls_offset - proposal origin| '
+              f'{float((dec["cls_offset"][0] - (2 * torch.arange(72)[:, None] - 4)).abs().max()):.3f}')
+        keep[f'V{i}'] = V
+        keep[f'E{i}'] = E.astype(np.int32)
+        keep[f'prop_conf{i}'] = dec['prop_conf'][0].numpy()
+        keep[f'prop_v_ext{i}'] = dec['prop_v_ext'][0].numpy().astype(np.uint8)
+        keep[f'cls_offset{i}'] = dec['cls_offset'][0].numpy()
+        keep[f'endp{i}'] = np.stack(np.nonzero(dec['endp'][0].numpy()), axis=1).astype(np.int32)
+    save('g15_e2e_stable.npz', tile_seeds=np.array(G15_TILES), weight_seed=2021,
+         gain_keys=np.array(list(G15_GAINS)), gain_values=np.array(list(G15_GAINS.values())), **keep)
+
+
 def main():
     which = sys.argv[1:] or ['g2', 'g3', 'g4', 'g5', 'g6', 'g7', 'g10']
     _stable_sorts(True)

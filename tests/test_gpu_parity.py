@@ -477,7 +477,9 @@ def test_rowref_head_golden_g8(dev, golden):
 
 
 def test_rowref_detector_config4_vs_oracle(dev, synth_sd):
-    """Detector1stage with the RowRef head (BASELINE config 4) on one 1152^2 tile vs the oracle chain."""
+    """Detector1stage with the RowRef head (BASELINE config 4) on one 1152^2 tile vs the oracle chain: every (lane, row) decision -
+    row present (argmax ext2 == 0) and its column (argmax cls2) - equals the oracle's unless the ORACLE's own margin there is below
+    1e-4; the polylines always equal the oracle's line assembly run on the product's own decode outputs."""
     from lanemapping_amd.boundary import build_net_from_config
     from oracle import net_ref, rowref_ref
     net4 = build_net_from_config('Proj28_GFC-T3_RowRef_82_73_laser', device='cpu')
@@ -491,11 +493,23 @@ def test_rowref_detector_config4_vs_oracle(dev, synth_sd):
         o = net4({'proj': x.to(dev)})
         fea = net_ref.vit_forward(sd, net_ref.fpn_forward(sd, x)[0])
         ref = rowref_ref.rowref_forward(sd, fea)
-    conf, cls = rowref_ref.rowref_decode(ref)
-    bad = int((o['conf'].numpy() != conf).sum())
-    assert bad <= 4, f'{bad} conf pixels differ from the oracle'
-    if bad == 0:
-        assert np.array_equal(o['lane_maps']['cls_offset_smooth'][0], rowref_ref.rowref_pred_lines(conf[0], cls[0]))
+    col_p = net4.heads._col_idx.cpu().numpy()[0]                      # [12,144]: column or -1
+    flips = 0
+    for c in range(12):
+        e, p = ref[f'ext2_{c}'][0], ref[f'cls2_{c}'][0]               # [144,2], [144,144] probabilities
+        want = np.where(e.argmax(dim=1).numpy() == 0, p.argmax(dim=1).numpy(), -1)
+        top2 = torch.topk(p, 2, dim=1).values
+        margin = torch.minimum((e[:, 0] - e[:, 1]).abs(), top2[:, 0] - top2[:, 1]).numpy()
+        bad = np.flatnonzero(col_p[c] != want)
+        flips += bad.size
+        assert np.all(margin[bad] < 1e-4), f'lane {c}: decision differs from the oracle where its margin is {margin[bad].max():.2e}'
+    print(f'config 4: {flips} of {12 * 144} (lane, row) decisions flipped inside the oracle margin')
+    assert flips <= 8
+    conf_p, cls_p = o['conf'].numpy(), o['cls'].numpy()
+    assert np.array_equal(o['lane_maps']['cls_offset_smooth'][0], rowref_ref.rowref_pred_lines(conf_p[0], cls_p[0]))
+    if flips == 0:
+        conf, cls = rowref_ref.rowref_decode(ref)
+        assert np.array_equal(conf_p, conf) and np.array_equal(cls_p, cls)
 
 
 # ----------------------------------------------------------------------------------------------- config 5 (LiDAR encoder)
@@ -605,7 +619,7 @@ def test_detector_config5_end_to_end(dev):
         _close(raw['semantic_seg'], bi, 1e-4, 'bi_seg')
         _close(raw['endp_est'], en, 1e-4, 'endp')
         for k in ('proposal_conf', 'ext2', 'cls2', 'offset2', 'orient'):
-            _close(raw[k], ref[k], 2e-4, k)
+            print(k, 'config-5 head output error', _close(raw[k], ref[k], 1e-4, k))
         out = net5(batch)
     assert out['lane_maps']['cls_offset_smooth'][0].shape == (72, 144, 2)
 
@@ -822,6 +836,81 @@ def test_bench_self_launch_two_ranks(dev):
     assert len(lines) == 1
     d = json.loads(lines[0])
     assert d['n_gpus'] == 2 and d['config']['tiles_per_step_per_gpu'] == 8 and d['value'] > 10
+
+
+def _g15_net(dev, synth_sd, g):
+    from lanemapping_amd.boundary import build_net_from_config
+    net = build_net_from_config('Proj_polyline_fpn_vit_vertex_2', device='cpu')
+    sd = {k: v.clone() for k, v in synth_sd.items()}
+    for k, gain in zip(g['gain_keys'], g['gain_values']):
+        sd[str(k)] = sd[str(k)] * float(gain)
+    net.load_state_dict(sd, strict=True)
+    return net.to(dev), sd
+
+
+def test_end_to_end_stable_golden_g15(dev, golden, synth_sd):
+    """Golden G15: tiles SCREENED so that the reference's own final polylines are invariant under a 1e-5 input perturbation, with
+    an offset-regression layer that keeps vertex columns inside their bin (|offset2| <= 0.1).  The HIP path reproduces the reference
+    end to end: cls_offset / prop_conf within ABSOLUTE 1e-4 (north_star's bound), existence classes and endpoint pixels exactly,
+    and the final cls_offset_smooth - which vertices exist, their semantics, the kept endpoints - exactly, columns within 8e-4 px
+    (= 1e-4 in column-bin units x 8 px)."""
+    from lanemapping_amd.pipeline import TilePipeline
+    g = golden('g15_e2e_stable.npz')
+    net, _ = _g15_net(dev, synth_sd, g)
+    seeds = [int(s) for s in g['tile_seeds']]
+    x = torch.from_numpy(synth.bev_batch(seeds, 1152)).to(dev)
+    with torch.no_grad():
+        o = net({'proj': x})
+    c = net.heads._compact
+    res = TilePipeline(net).run_batch(x)
+    for i in range(len(seeds)):
+        err_off = float(np.abs(c['cls_offset'][i].cpu().numpy() - g[f'cls_offset{i}']).max())
+        err_conf = float(np.abs(c['prop_conf'][i].cpu().numpy() - g[f'prop_conf{i}']).max())
+        assert err_off <= 1e-4 and err_conf <= 1e-4, (err_off, err_conf)
+        assert np.array_equal(c['prop_v_ext'][i].cpu().numpy().astype(np.uint8), g[f'prop_v_ext{i}'])
+        assert np.array_equal(np.stack(np.nonzero(o['endp'][i].numpy()), axis=1), g[f'endp{i}'])
+        W = g[f'V{i}']
+        for V, E in ((o['lane_maps']['cls_offset_smooth'][i], np.stack(np.nonzero(o['lane_maps']['endp_by_cls'][i]), axis=1)), res[i]):
+            assert np.array_equal(V[:, :, 0] > 0, W[:, :, 0] > 0), f'tile {seeds[i]}: vertex set differs from the reference'
+            assert np.array_equal(V[:, :, 1], W[:, :, 1]), f'tile {seeds[i]}: semantics differ from the reference'
+            assert float(np.abs(V[:, :, 0] - W[:, :, 0]).max()) <= 8e-4
+            E = np.asarray(E).reshape(-1, 2)
+            assert np.array_equal(E[np.lexsort((E[:, 1], E[:, 0]))], g[f'E{i}'].reshape(-1, 2))      # same pixels (the pipeline lists them in cluster order)
+        print(f'G15 tile {seeds[i]}: cls_offset err {err_off:.2e}, prop_conf err {err_conf:.2e}, '
+              f'{int((np.count_nonzero(W[:, :, 0] > 0, axis=1) >= 2).sum())} lines identical to the reference')
+
+
+@pytest.mark.parametrize('B,picks', [(8, (2, 7)), (16, (5, 13))])
+def test_tiles_inside_full_batches_vs_oracle(dev, net, synth_sd, B, picks):
+    """BASELINE's batch sizes (8 pre-rasterised, 16 fused): two tiles INSIDE a full batch vs the oracle run on those tiles alone -
+    raw outputs within 1e-4 of the tensor scale, integer decisions equal wherever the oracle's own margin is >= 1e-4, and the
+    batch result equals the single-tile result of the product bit for bit (batch invariance at the real batch sizes)."""
+    from oracle import net_ref, decode_ref
+    seeds = [6000 + 10 * B + i for i in range(B)]
+    x = torch.from_numpy(synth.bev_batch(seeds, 1152)).to(dev)
+    cfg = net.cfg
+    with torch.no_grad():
+        raw = {k: v.clone() for k, v in net.forward_raw({'proj': x}).items()}
+        o = net({'proj': x})
+    comp = {k: (v.clone() if torch.is_tensor(v) else v) for k, v in net.heads._compact.items()}
+    for t in picks:
+        xs = torch.from_numpy(synth.bev_batch([seeds[t]], 1152))
+        with torch.no_grad():
+            ref = net_ref.detector_forward(synth_sd, xs)
+            one = net.forward_raw({'proj': xs.to(dev)})
+        for k in ('proposal_conf', 'ext2', 'cls2', 'offset2', 'orient', 'semantic_seg', 'endp_est'):
+            _close(raw[k][t:t + 1], ref[k], 1e-4, f'B{B} tile {t} {k}')
+            assert torch.equal(raw[k][t:t + 1], one[k]), f'B{B} tile {t} {k}: batch result != single-tile result'
+        d = decode_ref.decode_column_proposals({k: v.numpy() for k, v in ref.items()})
+        e = ref['ext2'].softmax(3)[0]
+        ext_margin = torch.minimum((e[..., 1] - e[..., 2]).abs(), (torch.maximum(e[..., 1], e[..., 2]) - cfg.exist_thre).abs()).flatten().numpy()
+        ct = torch.topk(ref['cls2'], 2, dim=-1).values[0]
+        cls_margin = (ct[..., 0] - ct[..., 1]).flatten().numpy()
+        for mine, want, margin, name in ((comp['prop_v_ext'][t].cpu().numpy(), d['prop_v_ext'][0].numpy(), ext_margin, 'prop_v_ext'),
+                                         (comp['cls_idx'][t].cpu().numpy(), d['cls_idx'][0].numpy(), cls_margin, 'cls_idx')):
+            bad = np.flatnonzero(np.asarray(mine).reshape(-1) != np.asarray(want).reshape(-1))
+            assert np.all(margin[bad] < 1e-4) and bad.size <= 4, f'B{B} tile {t} {name}: {bad.size} mismatches'
+        assert np.array_equal(np.stack(np.nonzero(o['endp'][t].numpy()), 1), np.stack(np.nonzero(d['endp'][0].numpy()), 1))
 
 
 # ----------------------------------------------------------------------------------------------- Winograd convolution
