@@ -91,6 +91,10 @@ int lm_gn_finalize(void* stream, const double* partial, float* stats, int B, int
  * y = act(conv(pre_relu ? relu(x) : x) * scale + shift). */
 int lm_stem_conv7x7_bn_relu(void* stream, const float* x_chw, const float* w_k64, const float* scale,
                             const float* shift, float* y_nhwc, int B, int H, int W);
+/* The stem on a u8 HWC tile [B][H][W][3] as the rasteriser / PNG reader emit it (u8 / 255 = the reference's to_tensor,
+ * datasets/laserlane_proposals.py:85-98, applied while staging): same bits as tile_ingest + the f32 stem, a quarter of the bytes. */
+int lm_stem_conv7x7_bn_relu_u8(void* stream, const unsigned char* x_hwc3, const float* w_k64, const float* scale,
+                               const float* shift, float* y_nhwc, int B, int H, int W);
 int lm_maxpool3x3s2_nhwc(void* stream, const float* x, float* y, int B, int H, int W, int C);
 int lm_conv2d_nhwc_small(void* stream, const float* x, int ldx, const float* w_tc16, const float* scale,
                          const float* shift, float* y, int ldy, int B, int H, int W, int Cin, int Cout,

@@ -19,7 +19,10 @@ constexpr int ST = 16;             // tile edge (outputs)
 constexpr int SP = 2 * ST + 5;     // input patch edge = 37
 constexpr int SPP = 40;            // padded patch row
 
-__global__ __launch_bounds__(256) void stem_kernel(const float* __restrict__ x, const float* __restrict__ w,
+// U8: the tile comes as u8 HWC (3 channels: what the rasteriser / the PNG reader produce) and u8 / 255 - the reference's to_tensor,
+// laserlane_proposals.py:85-98 - is applied while staging the patch: same bits as the f32 planar input, a quarter of the bytes.
+template <bool U8>
+__global__ __launch_bounds__(256) void stem_kernel(const void* __restrict__ xin, const float* __restrict__ w,
                                                    const float* __restrict__ scale, const float* __restrict__ shift,
                                                    float* __restrict__ y, int H, int W, int Ho, int Wo) {
     // The weights are wave-uniform: they are read with SCALAR loads (uniform index into a __restrict__ const pointer -> s_load into
@@ -35,7 +38,10 @@ __global__ __launch_bounds__(256) void stem_kernel(const float* __restrict__ x, 
         const int c = i / (SP * SP), r = (i / SP) % SP, q = i % SP;
         const int iy = iy0 + r, ix = ix0 + q;
         float v = 0.f;
-        if ((unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W) v = x[((long)(b * 3 + c) * H + iy) * W + ix];
+        if ((unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W) {
+            if (U8) v = (float)static_cast<const unsigned char*>(xin)[(((long)b * H + iy) * W + ix) * 3 + c] / 255.0f;
+            else v = static_cast<const float*>(xin)[((long)(b * 3 + c) * H + iy) * W + ix];
+        }
         in[c][r][q] = v;
     }
     __syncthreads();
@@ -156,7 +162,18 @@ LM_API int lm_stem_conv7x7_bn_relu(void* stream, const float* x_chw, const float
     LM_REQUIRE(x_chw && w_k64 && scale && shift && y_nhwc, "stem: null pointer");
     const int Ho = (H + 6 - 7) / 2 + 1, Wo = (W + 6 - 7) / 2 + 1;
     dim3 grid(lm_cdiv(Wo, ST), lm_cdiv(Ho, ST), B);
-    hipLaunchKernelGGL(stem_kernel, grid, dim3(256), 0, (hipStream_t)stream, x_chw, w_k64, scale, shift, y_nhwc, H, W, Ho, Wo);
+    hipLaunchKernelGGL(stem_kernel<false>, grid, dim3(256), 0, (hipStream_t)stream, (const void*)x_chw, w_k64, scale, shift, y_nhwc, H, W, Ho, Wo);
+    LM_LAUNCH_CHECK();
+    return LM_OK;
+}
+
+// the same stem on a u8 HWC tile [B][H][W][3] (x = u8 / 255 applied on the fly): bit-identical to lm_tile_ingest_u8 + the f32 stem
+LM_API int lm_stem_conv7x7_bn_relu_u8(void* stream, const unsigned char* x_hwc3, const float* w_k64, const float* scale,
+                                      const float* shift, float* y_nhwc, int B, int H, int W) {
+    LM_REQUIRE(x_hwc3 && w_k64 && scale && shift && y_nhwc, "stem_u8: null pointer");
+    const int Ho = (H + 6 - 7) / 2 + 1, Wo = (W + 6 - 7) / 2 + 1;
+    dim3 grid(lm_cdiv(Wo, ST), lm_cdiv(Ho, ST), B);
+    hipLaunchKernelGGL(stem_kernel<true>, grid, dim3(256), 0, (hipStream_t)stream, (const void*)x_hwc3, w_k64, scale, shift, y_nhwc, H, W, Ho, Wo);
     LM_LAUNCH_CHECK();
     return LM_OK;
 }

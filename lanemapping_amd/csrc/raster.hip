@@ -31,6 +31,7 @@
 #include "common.h"
 
 #include <cmath>
+#include <cstdlib>
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
@@ -47,10 +48,9 @@ struct LmRasterParams {      // mirrors the reference's per-tile parameter file 
 
 namespace {
 
-constexpr int BAND_ROWS = 16;
 constexpr int CHUNK = 8192;            // points per pass-1 workgroup = record capacity of one (tile, band, workgroup) slot
 constexpr int PER_THREAD = CHUNK / 256;
-constexpr int MAX_BANDS = 96;             // H <= 1520; keeps pass-1 LDS at 39.5 KB = 4 workgroups per CU
+constexpr int MAX_BANDS = 96;             // keeps pass-1 LDS at 39.5 KB = 4 workgroups per CU
 constexpr int MAX_TILES = 16;          // tiles per launch (kernel-argument block)
 constexpr int REP = 8;                 // replication of the LDS rank counters (fewer same-address collisions)
 
@@ -62,7 +62,7 @@ struct BatchArgs {
     TileXf tile[MAX_TILES];
 };
 
-__device__ __forceinline__ bool point_record(const f32x4 p, const TileXf& X, int H, int W, int& band, unsigned& rec) {
+__device__ __forceinline__ bool point_record(const f32x4 p, const TileXf& X, int H, int W, int band_rows, int& band, unsigned& rec) {
     const float dx = p[0] - X.t[0], dy = p[1] - X.t[1], dz = p[2] - X.t[2];
     const float vx = (X.m[0] * dx + X.m[1] * dy) + X.m[2] * dz;
     const float vy = (X.m[3] * dx + X.m[4] * dy) + X.m[5] * dz;
@@ -75,15 +75,16 @@ __device__ __forceinline__ bool point_record(const f32x4 p, const TileXf& X, int
     I = I < 1 ? 1 : (I > 255 ? 255 : I);
     int G = (int)floorf((vz - X.min_ele) * X.iele + 0.5f);
     G = G < 0 ? 0 : (G > 255 ? 255 : G);
-    band = row / BAND_ROWS;
-    rec = ((unsigned)((row - band * BAND_ROWS) * W + col) << 16) | (unsigned)((I << 8) | G);
+    band = row / band_rows;
+    rec = ((unsigned)((row - band * band_rows) * W + col) << 16) | (unsigned)((I << 8) | G);
     return true;
 }
 
-// records: [tile][band][blk][CHUNK] u32 (zero padded to 16 B per run), counts: [tile][band][nblk_max]
+// records: [tile][band][blk][CHUNK] u32 (zero padded to 16 B per run), counts: [tile][nblk_max][band]
 // grid: (nblk_max, tiles)
 __global__ __launch_bounds__(256) void raster_partition_kernel(const f32x4* __restrict__ pts, BatchArgs A, unsigned* __restrict__ counts,
-                                                               unsigned* __restrict__ records, int nblk_max, int H, int W, int nbands) {
+                                                               unsigned* __restrict__ records, int nblk_max, int H, int W, int nbands,
+                                                               int band_rows) {
     constexpr int CAPQ = (CHUNK + MAX_BANDS * 3 + 3) / 4;
     __shared__ unsigned hist[MAX_BANDS * REP];                 // [band][replica] count, then start offset in `sorted`
     __shared__ unsigned qstart[MAX_BANDS + 1];                 // first 16-byte quad of each band's run
@@ -102,6 +103,8 @@ __global__ __launch_bounds__(256) void raster_partition_kernel(const f32x4* __re
     const long left = X.count - first;
     const int rep = tid & (REP - 1);
     constexpr int LB = 8;                                      // loads kept in flight per thread
+    // (explicitly issuing batch k+1 before batch k is consumed - two register sets - measured slower: 290 -> 303 us per 16 tiles,
+    // 134 VGPRs; the fully unrolled loop below already lets the compiler hoist the next batch's loads)
 #pragma unroll
     for (int j0 = 0; j0 < PER_THREAD; j0 += LB) {
         f32x4 p[LB];
@@ -117,7 +120,7 @@ __global__ __launch_bounds__(256) void raster_partition_kernel(const f32x4* __re
             const long i = (long)(j0 + j) * 256 + tid;
             meta[j0 + j] = 0xFFFFFFFFu;
             int band;
-            if (i < left && point_record(p[j], X, H, W, band, rec[j0 + j])) {
+            if (i < left && point_record(p[j], X, H, W, band_rows, band, rec[j0 + j])) {
                 const unsigned slot = (unsigned)band * REP + rep;
                 meta[j0 + j] = (slot << 16) | atomicAdd(&hist[slot], 1u);
             }
@@ -156,7 +159,7 @@ __global__ __launch_bounds__(256) void raster_partition_kernel(const f32x4* __re
                     hist[b * REP + r] = run;
                     run += c;
                 }
-                counts[((long)tile * nbands + b) * nblk_max + blk] = bc[k];
+                counts[((long)tile * nblk_max + blk) * nbands + b] = bc[k];      // [tile][chunk][band]: one contiguous row per workgroup
             }
         }
         if (tid == 63) qstart[nbands] = tot0 + incl1;          // total quads (bands >= nbands contribute 0)
@@ -177,7 +180,7 @@ __global__ __launch_bounds__(256) void raster_partition_kernel(const f32x4* __re
     }
 }
 
-// grid: (bands, tiles); dynamic LDS = BAND_ROWS * W * 4 bytes; 1024 threads = 64 groups of 16 lanes, one run per group
+// grid: (bands, tiles); dynamic LDS = band_rows * W * 4 bytes; 1024 threads = 64 groups of 16 lanes, one run per group
 constexpr int BT = 1024;
 
 struct BandArgs {
@@ -192,30 +195,37 @@ __device__ __forceinline__ void apply4(unsigned* img, const u32x4 v) {
 
 __global__ __launch_bounds__(BT) void raster_band_kernel(const unsigned* __restrict__ counts, const unsigned* __restrict__ records,
                                                          BandArgs A, int nblk_max, float* __restrict__ out_chw,
-                                                         unsigned char* __restrict__ out_u8, int H, int W, int nbands) {
+                                                         unsigned char* __restrict__ out_u8, int H, int W, int nbands, int band_rows) {
     extern __shared__ __attribute__((aligned(16))) unsigned img[];
     const int band = blockIdx.x, tile = blockIdx.y;
-    const int npix = BAND_ROWS * W;
+    const int npix = band_rows * W;
     for (int i = threadIdx.x; i < npix; i += BT) img[i] = 0;
     __syncthreads();
     const int nblk = A.nblk[tile];
-    const unsigned* cnt = counts + ((long)tile * nbands + band) * nblk_max;
+    const unsigned* cnt = counts + (long)tile * nblk_max * nbands + band;          // cnt[b * nbands] = records of chunk b in this band
     const unsigned* rbase = records + ((long)tile * nbands + band) * (long)nblk_max * CHUNK;
     const int grp = threadIdx.x >> 4, gl = threadIdx.x & 15;
-    for (int b0 = grp; b0 < nblk; b0 += 128) {                 // two runs in flight per 16-lane group
-        u32x4 v[2][2];
-        unsigned nq[2];
+    // A 16-lane group owns the runs b = grp + 64 k.  Eight runs per step: first ALL their counts (one memory round trip), then ALL
+    // their first 32 quads (16 loads in flight per lane, a second round trip) - the loop used to pay two dependent round trips per
+    // pair of runs, i.e. eight per workgroup at 512 chunks per tile.
+    constexpr int RUNS = 8;
+    for (int b0 = grp; b0 < nblk; b0 += 64 * RUNS) {
+        unsigned nq[RUNS];
 #pragma unroll
-        for (int u = 0; u < 2; ++u) {
+        for (int u = 0; u < RUNS; ++u) {
             const int b = b0 + 64 * u;
-            nq[u] = b < nblk ? (cnt[b] + 3) / 4 : 0;
-            const u32x4* r4 = reinterpret_cast<const u32x4*>(rbase + (long)b * CHUNK);
+            nq[u] = b < nblk ? (cnt[(long)b * nbands] + 3) / 4 : 0;
+        }
+        u32x4 v[RUNS][2];
+#pragma unroll
+        for (int u = 0; u < RUNS; ++u) {
+            const u32x4* r4 = reinterpret_cast<const u32x4*>(rbase + (long)(b0 + 64 * u) * CHUNK);
 #pragma unroll
             for (int k = 0; k < 2; ++k)
                 v[u][k] = ((unsigned)(gl + 16 * k) < nq[u]) ? __builtin_nontemporal_load(r4 + gl + 16 * k) : u32x4{0u, 0u, 0u, 0u};
         }
 #pragma unroll
-        for (int u = 0; u < 2; ++u) {
+        for (int u = 0; u < RUNS; ++u) {
             apply4(img, v[u][0]);
             apply4(img, v[u][1]);
             if (nq[u] > 32) {                                  // long run (spatially skewed chunk): finish it here
@@ -238,12 +248,15 @@ __global__ __launch_bounds__(BT) void raster_band_kernel(const unsigned* __restr
         }
     }
     if (out_u8) {
-        unsigned char* o = out_u8 + ((long)tile * HW + pix0) * 3;
-        for (int i = threadIdx.x; i < npix; i += BT) {
-            const unsigned k = img[i];
-            o[3 * i + 0] = (unsigned char)(k >> 8);
-            o[3 * i + 1] = (unsigned char)(k & 255u);
-            o[3 * i + 2] = (unsigned char)(k >> 8);
+        // 4 pixels = 12 bytes = three dwords per thread (byte stores are an order of magnitude slower per byte); npix % 4 == 0
+        unsigned* o = reinterpret_cast<unsigned*>(out_u8 + ((long)tile * HW + pix0) * 3);
+        for (int i = threadIdx.x * 4; i < npix; i += BT * 4) {
+            const unsigned k0 = img[i], k1 = img[i + 1], k2 = img[i + 2], k3 = img[i + 3];
+            const unsigned i0 = k0 >> 8, g0 = k0 & 255u, i1 = k1 >> 8, g1 = k1 & 255u, i2 = k2 >> 8, g2 = k2 & 255u, i3 = k3 >> 8, g3 = k3 & 255u;
+            unsigned* d = o + (i / 4) * 3;                  // bytes I0 G0 I0 I1 | G1 I1 I2 G2 | I2 I3 G3 I3 (little endian)
+            d[0] = i0 | (g0 << 8) | (i0 << 16) | (i1 << 24);
+            d[1] = g1 | (i1 << 8) | (i2 << 16) | (g2 << 24);
+            d[2] = i2 | (i3 << 8) | (g3 << 16) | (i3 << 24);
         }
     }
 }
@@ -289,8 +302,32 @@ void derive(const LmRasterParams& P, long start, long count, TileXf& X) {
 
 static long nblk_of(long n) { return (n + CHUNK - 1) / CHUNK; }
 
+// Rows per band: the band kernel runs (bands x tiles) workgroups on 256 CUs x floor(160 KB / band image) slots; with 16-row bands a
+// 16-tile batch of 1152-row tiles is 1152 workgroups on 512 slots = 2.25 rounds (the third one a quarter full), with 12-row bands
+// 1536 on 512 = exactly 3 rounds of 3/4 the work each.  Picks the candidate with the least rounds x rows.  LM_RASTER_BAND_ROWS overrides.
+static int band_rows_for(int B, int H, int W) {
+    static const int forced = [] { const char* e = getenv("LM_RASTER_BAND_ROWS"); return e ? atoi(e) : 0; }();
+    if (forced > 0 && H % forced == 0 && H / forced <= MAX_BANDS && (long)forced * W <= 65536 && forced % 4 == 0) return forced;
+    int best = 0;
+    long best_cost = 0;
+    for (int r : {16, 12}) {
+        if (H % r != 0 || H / r > MAX_BANDS || (long)r * W > 65536) continue;
+        const long lds = (long)r * W * 4, per_cu = lds > 0 ? (160 * 1024) / lds : 1;
+        const long slots = 256 * (per_cu < 1 ? 1 : (per_cu > 2 ? 2 : per_cu));     // 1024-thread workgroups: at most 2 per CU
+        const long wgs = (long)(H / r) * (B < MAX_TILES ? B : MAX_TILES);
+        const long cost = ((wgs + slots - 1) / slots) * r;
+        if (!best || cost < best_cost) {
+            best = r;
+            best_cost = cost;
+        }
+    }
+    return best;
+}
+
 LM_API long lm_bev_raster_workspace_bytes(int B, long max_points_per_tile, int H, int W) {
-    const long nbands = H / BAND_ROWS, nblk = nblk_of(max_points_per_tile) > 0 ? nblk_of(max_points_per_tile) : 1;
+    const int br = band_rows_for(B, H, W);
+    if (!br) return 0;
+    const long nbands = H / br, nblk = nblk_of(max_points_per_tile) > 0 ? nblk_of(max_points_per_tile) : 1;
     const long head = (((long)B * nbands * nblk * (long)sizeof(unsigned) + 255) / 256) * 256;
     return head + (long)B * nbands * nblk * CHUNK * (long)sizeof(unsigned);
 }
@@ -300,9 +337,9 @@ LM_API int lm_bev_raster_batch(void* stream, const float* points_xyzi, const lon
                                int B, void* workspace, long workspace_bytes, float* out_chw, unsigned char* out_hwc_u8,
                                int H, int W) {
     LM_REQUIRE(tile_offsets && params && workspace && (out_chw || out_hwc_u8) && B >= 1, "bev_raster: null pointer");
-    LM_REQUIRE(H % BAND_ROWS == 0 && H / BAND_ROWS < MAX_BANDS && BAND_ROWS * W <= 65536 && W > 0,
-               "bev_raster: H=%d must be a multiple of %d (< %d bands) and 16*W <= 65536", H, BAND_ROWS, MAX_BANDS);
-    const int nbands = H / BAND_ROWS;
+    const int band_rows = band_rows_for(B, H, W);
+    LM_REQUIRE(band_rows > 0 && W > 0, "bev_raster: H=%d must be a multiple of 16 or 12 (at most %d bands) and rows*W <= 65536", H, MAX_BANDS);
+    const int nbands = H / band_rows;
     long nmax = 0;
     for (int b = 0; b < B; ++b) {
         const long n = tile_offsets[b + 1] - tile_offsets[b];
@@ -317,7 +354,7 @@ LM_API int lm_bev_raster_batch(void* stream, const float* points_xyzi, const lon
     hipStream_t s = (hipStream_t)stream;
     unsigned* counts = (unsigned*)workspace;
     unsigned* records = (unsigned*)((char*)workspace + (((long)B * nbands * nblk_max * sizeof(unsigned) + 255) / 256) * 256);
-    const size_t lds = (size_t)BAND_ROWS * W * sizeof(unsigned);
+    const size_t lds = (size_t)band_rows * W * sizeof(unsigned);
     static size_t lds_set = 0;
     if (lds > lds_set) {
         LM_HIP(hipFuncSetAttribute((const void*)raster_band_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
@@ -339,12 +376,12 @@ LM_API int lm_bev_raster_batch(void* stream, const float* points_xyzi, const lon
         unsigned* rec = records + (long)b0 * nbands * nblk_max * CHUNK;
         if (maxn > 0) {
             hipLaunchKernelGGL(raster_partition_kernel, dim3((unsigned)nblk_of(maxn), nb), dim3(256), 0, s,
-                               reinterpret_cast<const f32x4*>(points_xyzi), A, cnt, rec, nblk_max, H, W, nbands);
+                               reinterpret_cast<const f32x4*>(points_xyzi), A, cnt, rec, nblk_max, H, W, nbands, band_rows);
             LM_LAUNCH_CHECK();
         }
         hipLaunchKernelGGL(raster_band_kernel, dim3(nbands, nb), dim3(BT), lds, s, cnt, rec, BA, nblk_max,
                            out_chw ? out_chw + (long)b0 * 3 * HW : nullptr, out_hwc_u8 ? out_hwc_u8 + (long)b0 * 3 * HW : nullptr,
-                           H, W, nbands);
+                           H, W, nbands, band_rows);
         LM_LAUNCH_CHECK();
     }
     return LM_OK;

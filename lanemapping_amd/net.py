@@ -27,8 +27,8 @@ class Detector1stage(nn.Module):
         fused = hasattr(self.pcencoder, 'fpn') and self.cfg.heads.type == 'ColumnProposal2'
         col = None
         if fused:   # FPN writes fea_up straight into channels 8..15 of the head's concat buffer
-            proj = batch['proj']
-            B, _, H, W = proj.shape
+            proj = batch['proj']            # [B,3,H,W] f32 (the reference's tensor) or [B,H,W,3] uint8 (rasteriser / PNG output)
+            B, H, W = (proj.shape[0], proj.shape[1], proj.shape[2]) if proj.dtype == torch.uint8 else (proj.shape[0], proj.shape[2], proj.shape[3])
             col = ops.new_act(B, 16, H // 4, W // 4, proj.device)
             fea, fea_up, bi_seg, endp_est = self.pcencoder.fpn(proj, fea_up_out=col[:, 8:16])
         else:

@@ -310,13 +310,19 @@ def conv_small(x, w16, cout, kh=1, kw=1, stride=1, pad=0, scale=None, shift=None
     return out
 
 
-def stem(x_chw, w_k64, scale, shift):
-    """proj [B,3,H,W] planar -> relu(bn(conv7x7 s2)) [B,64,H/2,W/2] NHWC-stored."""
-    x_chw = x_chw.contiguous()
-    B, _, H, W = x_chw.shape
+def stem(x, w_k64, scale, shift):
+    """proj -> relu(bn(conv7x7 s2)) [B,64,H/2,W/2] NHWC-stored.  proj: [B,3,H,W] f32 planar (the reference's tensor) or
+    [B,H,W,3] uint8 (rasteriser / PNG reader output; u8 / 255 is applied inside the kernel: same bits)."""
+    x = x.contiguous()
+    if x.dtype == torch.uint8:
+        B, H, W, C_ = x.shape
+        assert C_ == 3, 'u8 tiles are [B,H,W,3]'
+    else:
+        B, _, H, W = x.shape
     Ho, Wo = (H - 1) // 2 + 1, (W - 1) // 2 + 1
-    out = new_act(B, 64, Ho, Wo, x_chw.device)
-    check(lib().lm_stem_conv7x7_bn_relu(_stream(), _ptr(x_chw), _ptr(w_k64), _ptr(scale), _ptr(shift), _ptr(out), B, H, W))
+    out = new_act(B, 64, Ho, Wo, x.device)
+    fn = lib().lm_stem_conv7x7_bn_relu_u8 if x.dtype == torch.uint8 else lib().lm_stem_conv7x7_bn_relu
+    check(fn(_stream(), _ptr(x), _ptr(w_k64), _ptr(scale), _ptr(shift), _ptr(out), B, H, W))
     return out
 
 
@@ -519,9 +525,10 @@ def make_raster_params(quat=(1, 0, 0, 0), trans=(0, 0, 0), bev_img_offset=(0, 0)
 _raster_ws = {}
 
 
-def bev_raster_batch(points, tile_offsets, params, H=1152, W=1152, out=None, want_u8=False):
+def bev_raster_batch(points, tile_offsets, params, H=1152, W=1152, out=None, want_u8=False, u8_only=False, out_u8=None):
     """points [sum N,4] f32 (x,y,z,raw intensity) on device, tile_offsets: B+1 ints, params: list of LmRasterParams
-    -> proj [B,3,H,W] f32 (= u8/255), optional u8 [B,H,W,3]."""
+    -> proj [B,3,H,W] f32 (= u8/255), optional u8 [B,H,W,3].  u8_only: only the u8 HWC tile is written (the stem takes it
+    directly, ops.stem) - a quarter of the output bytes."""
     assert points.dim() == 2 and points.shape[1] == 4 and points.is_contiguous() and points.dtype == torch.float32
     B = len(params)
     assert len(tile_offsets) == B + 1
@@ -533,11 +540,17 @@ def bev_raster_batch(points, tile_offsets, params, H=1152, W=1152, out=None, wan
     ws = _raster_ws.get(key)
     if ws is None or ws.numel() < need:
         ws = _raster_ws[key] = torch.empty(need, device=points.device, dtype=torch.uint8)
-    if out is None:
+    want_u8 = want_u8 or u8_only or out_u8 is not None
+    if out is None and not u8_only:
         out = torch.empty((B, 3, H, W), device=points.device, dtype=torch.float32)
-    u8 = torch.empty((B, H, W, 3), device=points.device, dtype=torch.uint8) if want_u8 else None
+    u8 = None
+    if want_u8:
+        u8 = out_u8 if out_u8 is not None else torch.empty((B, H, W, 3), device=points.device, dtype=torch.uint8)
+        assert u8.dtype == torch.uint8 and u8.is_contiguous() and tuple(u8.shape) == (B, H, W, 3)
     check(lib().lm_bev_raster_batch(_stream(), _ptr(points) if points.numel() else None, offs, par, B, _ptr(ws), ws.numel(),
-                                    _ptr(out), _ptr(u8), H, W))
+                                    None if u8_only else _ptr(out), _ptr(u8), H, W))
+    if u8_only:
+        return u8
     return (out, u8) if want_u8 else out
 
 

@@ -234,7 +234,10 @@ class FPNEncoder(PackedModule):
 
     def forward(self, x, fea_up_out=None):
         P = self.packed()
-        B, _, H, W = x.shape
+        if x.dtype == torch.uint8:          # u8 HWC tile straight from the rasteriser / PNG reader (ops.stem applies u8 / 255)
+            B, H, W, _ = x.shape
+        else:
+            B, _, H, W = x.shape
         c1 = ops.maxpool3x3s2(ops.stem(x, P['stem_w'], P['stem_s'], P['stem_b']))
         feats = []
         t = c1

@@ -77,7 +77,9 @@ class Runner:
             self._pinned[slot] = (self._pinned[slot][0], ev)
         if u8.shape[-1] < 3:                                   # greyscale tiles: replicate into the 3 input channels
             u8 = u8[..., :1].expand(-1, -1, -1, 3).contiguous()
-        return ops.tile_ingest(u8)
+        elif u8.shape[-1] > 3:                                 # RGBA: the reference keeps the first three channels (load_img)
+            u8 = u8[..., :3].contiguous()
+        return u8           # the stem kernel takes the u8 HWC tile and applies u8 / 255 itself (ops.stem; == ops.tile_ingest + f32 stem)
 
     def _load_batch(self, paths):
         return self._to_device(self._decode_batch(paths, 0), 0)

@@ -349,6 +349,28 @@ def test_tile_ingest(dev):
     assert torch.equal(out.cpu()[0], torch.from_numpy(synth.bev_tile(5, 96)))
 
 
+def test_u8_tile_path_bit_identical(dev, net):
+    """The pipeline hands BEV tiles over as u8 HWC (rasteriser / PNG reader output): lm_stem_conv7x7_bn_relu_u8 applies u8 / 255 while
+    staging, so the whole net gives the SAME BITS as the reference's f32 planar tensor (load_img: to_tensor(u8))."""
+    from lanemapping_amd import ops
+    u8 = torch.from_numpy(np.stack([synth.bev_tile_u8(s, 1152) for s in (71, 72)])).to(dev)          # [2,1152,1152,3]
+    f32 = ops.tile_ingest(u8)
+    assert torch.equal(f32.cpu(), torch.from_numpy(synth.bev_batch([71, 72], 1152)))
+    P = net.pcencoder.fpn.packed()
+    assert torch.equal(ops.stem(u8, P['stem_w'], P['stem_s'], P['stem_b']), ops.stem(f32, P['stem_w'], P['stem_s'], P['stem_b']))
+    with torch.no_grad():
+        a = net.forward_raw({'proj': u8})
+        b = net.forward_raw({'proj': f32})
+    for k in b:
+        assert torch.equal(a[k], b[k]), k
+    # rasteriser: the u8-only output equals the u8 tile of the two-output call, whose f32 tile is u8 / 255
+    pts = torch.from_numpy(synth.las_points(91, 300000)).to(dev)
+    par = [ops.make_raster_params(local_min_ele=-0.5, ele_reso=0.02)]
+    both = ops.bev_raster_batch(pts, [0, pts.shape[0]], par, want_u8=True)
+    only = ops.bev_raster_batch(pts, [0, pts.shape[0]], par, u8_only=True)
+    assert torch.equal(only, both[1]) and torch.equal(ops.tile_ingest(only), both[0])
+
+
 def test_runner_png_tiles_to_json(dev, net, tmp_path):
     """test_gpu_0.py-style entry: PNG tiles on disk -> per-tile JSON, identical to driving the pipeline directly."""
     import json

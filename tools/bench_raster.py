@@ -21,18 +21,24 @@ else:
     pts = torch.cat([torch.from_numpy(synth.las_points(2021 + (i % 4), N)) for i in range(TILES)]).to(dev)
 par = [ops.make_raster_params(local_min_ele=-0.5, ele_reso=0.02)] * TILES
 offs = [i * N for i in range(TILES + 1)]
-out = torch.empty((TILES, 3, 1152, 1152), device=dev)
+MODE = os.environ.get('RASTER_OUT', 'u8')          # u8 = u8 HWC only (what the pipeline uses: the stem takes it); f32 = planar f32 (the reference's tensor)
+if MODE == 'u8':
+    out = torch.empty((TILES, 1152, 1152, 3), device=dev, dtype=torch.uint8)
+    run = lambda: ops.bev_raster_batch(pts, offs, par, out_u8=out, u8_only=True)
+else:
+    out = torch.empty((TILES, 3, 1152, 1152), device=dev)
+    run = lambda: ops.bev_raster_batch(pts, offs, par, out=out)
 for i in range(3):
-    ops.bev_raster_batch(pts, offs, par, out=out)
+    run()
 torch.cuda.synchronize()
 a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
 a.record()
 REP = 10
 for r in range(REP):
-    ops.bev_raster_batch(pts, offs, par, out=out)
+    run()
 b.record()
 torch.cuda.synchronize()
 ms = a.elapsed_time(b) / (REP * TILES)
 alg = 16 * N + 3 * 1152 * 1152 * 4
-print(json.dumps({'points_per_tile': N, 'tiles_per_launch': TILES, 'ms_per_tile': ms, 'algorithmic_GBps': alg / ms / 1e6,
-                  'frac_of_8TBps': alg / ms / 1e6 / 8000, 'tiles_per_s': 1e3 / ms}))
+print(json.dumps({'points_per_tile': N, 'tiles_per_launch': TILES, 'output': MODE, 'band_rows': os.environ.get('LM_RASTER_BAND_ROWS', 'auto'),
+                  'ms_per_tile': ms, 'algorithmic_GBps': alg / ms / 1e6, 'frac_of_8TBps': alg / ms / 1e6 / 8000, 'tiles_per_s': 1e3 / ms}))
