@@ -191,6 +191,25 @@ int lm_trace_lines(const double* cols, int n, int R, const float* seg_rows, doub
 int lm_polyline_backproject(unsigned char* bev_hwc, int H, int W, int C, const double* img_seqs, const int* seq_lens, int L,
                             int Vmax, const double* params13, const double* las_read_offset, double* out);
 
+/* ---- evaluation: Lee-Kashyap-Chu thinning of a 2-D binary image, the skeletonisation inside the reference's semantic-line F1
+ * (baseline/utils/metric_utils.py:415-481 -> skimage.morphology.skeletonize(method='lee')).  PARITY UNPINNED (skimage absent: the
+ * published algorithm is restated, csrc/skeleton.cpp).  img [H][W] u8 (nonzero = object) is thinned in place to 0 / 1; returns the
+ * number of deleted pixels, -1 on bad arguments. */
+long lm_skeletonize_lee_2d(unsigned char* img, int H, int W);
+
+/* ---- cross-tile merge of LAS-frame polylines into map-level lines (baseline/utils/merge_lines.py) ------------------------
+ * Streaming host merger: create, one lm_merge_add_tile per tile in sorted file-name order (n polylines, points concatenated
+ * [sum lens][3] doubles, every polyline >= 2 vertices; n = 0 for a tile without usable lines), lm_merge_finish (returns the
+ * number of merged lines, *total_points their vertex count), lm_merge_result (points [total][3], lens [count]), destroy.
+ * merge_lines :166-291, merge_2_seqs :67-104, merge_2_reversed_seqs :106-132, helpers :17-65 / :157-164;
+ * lm_downsample_seq = downsample_seqs :133-153 (out holds up to n + 1 points, returns the number kept). */
+void* lm_merge_create(void);
+void lm_merge_destroy(void* merger);
+int lm_merge_add_tile(void* merger, const double* points, const int* lens, int n);
+long lm_merge_finish(void* merger, long* total_points);
+int lm_merge_result(void* merger, double* points, int* lens);
+int lm_downsample_seq(const double* seq, int n, double dist_min, double* out);
+
 /* ---- K-Lane "RowRef" head, config 4 (baseline/models/heads/row_shared_not_reduc_ref.py) ------------------------
  * softmax_rows :179-180,239-240 (in place); select :199-204; gather :207-211; scatter :227-230 (shrinking-range quirk);
  * decode :334-363.  Layouts: x [B,H,W,8] NHWC, ext [B,H,L,2], cls [B,H,L,W], tokens [T][8*H*5] in (c h w) order,

@@ -76,6 +76,13 @@ SIGNATURES = {
     'lm_raster_polylines': (i32, [vp, i32, i32, vp]),
     'lm_trace_lines': (i32, [vp, i32, i32, vp, vp]),
     'lm_polyline_backproject': (i32, [vp, i32, i32, i32, vp, vp, i32, i32, vp, vp, vp]),
+    'lm_skeletonize_lee_2d': (i64, [vp, i32, i32]),
+    'lm_merge_create': (vp, []),
+    'lm_merge_destroy': (None, [vp]),
+    'lm_merge_add_tile': (i32, [vp, vp, vp, i32]),
+    'lm_merge_finish': (i64, [vp, C.POINTER(i64)]),
+    'lm_merge_result': (i32, [vp, vp, vp]),
+    'lm_downsample_seq': (i32, [vp, i32, C.c_double, vp]),
     'lm_softmax_rows': (i32, [vp, vp, i64, i32]),
     'lm_rowref_select': (i32, [vp, vp, vp, vp, vp, i32, i32, i32, i32]),
     'lm_rowref_gather': (i32, [vp, vp, vp, vp, vp, i32, i32, i32, i32]),

@@ -164,3 +164,31 @@ def raster_params_from_file(param_path):
     q = p['las_rotation_trans_quan']
     return make_raster_params(quat=q[3:7], trans=q[0:3], bev_img_offset=p['bev_img_offset'], img_reso=p['img_reso'],
                               local_min_ele=p['local_min_ele'], ele_reso=p['ele_reso'])
+
+
+# ------------------------------------------------------------------------------------------------ label JSON (training-set annotations)
+def load_label_seq(seq_path):
+    """Annotation file of one tile (data/convert_data.py:25-52 `load_seq`): a list of areas {'seq': [[x, y, ...], ...], 'init_vertex',
+    'end_vertex', 'semantic', 'instance'} -> (seq [n, max_len, 2] zero padded, seq_lens, semantics, instances, init points, end points)."""
+    with open(seq_path) as f:
+        data = json.load(f)
+    seq_lens = [len(a['seq']) for a in data]
+    init_points = [a['init_vertex'] for a in data]
+    end_points = [a['end_vertex'] for a in data]
+    semantics = [a['semantic'] for a in data]
+    instances = [a['instance'] for a in data]
+    seq = np.zeros((len(seq_lens), max(seq_lens), 2))          # (an empty file raises ValueError in the reference as well: max of [])
+    for i, a in enumerate(data):
+        seq[i, :seq_lens[i]] = [v[0:2] for v in a['seq']]
+    return seq, seq_lens, semantics, instances, init_points, end_points
+
+
+def save_label_seq(seqs, seq_lens, seqs_semantic, seqs_instance, seqs_orient, seqs_filename):
+    """Inverse (data/convert_data.py:54-70 `save_seq`): one dictionary per line with the keys and key order of the reference,
+    json.dump without indentation through NpEncoder."""
+    lines = []
+    for i, n in enumerate(seq_lens):
+        lines.append({'semantic': seqs_semantic[i], 'instance': seqs_instance[i], 'seq_len': n, 'seq': seqs[i, :n, :],
+                      'init_vertex': seqs[i, 0, :], 'end_vertex': seqs[i, n - 1, :], 'seq_orient': seqs_orient[i, :n]})
+    with open(seqs_filename, 'w') as f:
+        json.dump(lines, f, cls=NpEncoder)

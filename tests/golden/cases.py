@@ -6,6 +6,8 @@ files only need to carry expected outputs.
 import os
 import sys
 
+import json
+
 import numpy as np
 
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -308,3 +310,18 @@ def metric_case(seed):
             epr[min(1151, r + int(24 * (u[5300 + k] - 0.5))), min(1151, c + int(24 * (u[5400 + k] - 0.5)))] = 1.0
     epr[5, 5] = 1.0
     return label, pred, egt, epr
+
+
+def label_json_text(seed):
+    """A seeded annotation file in the schema data/convert_data.py reads: 5 boundary instances of different lengths, vertices with
+    a third (ignored) component, integer semantics / instance ids."""
+    from lanemapping_amd import synth
+    u = synth.uniform(seed, 4000, 77)
+    areas = []
+    for k in range(5):
+        n = 3 + int(40 * u[k])
+        xs = 50 + 1000 * u[10 + k] + np.cumsum(8 * (u[100 + 60 * k:100 + 60 * k + n] - 0.5))
+        ys = 20 + np.arange(n) * (1100.0 / n)
+        seq = [[float(round(x, 3)), float(round(y, 3)), int(k)] for x, y in zip(xs, ys)]
+        areas.append({'seq': seq, 'init_vertex': seq[0][0:2], 'end_vertex': seq[-1][0:2], 'semantic': int(1 + (k % 2)), 'instance': int(k + 1)})
+    return json.dumps(areas)

@@ -392,6 +392,24 @@ def g15(cfg, net):
          gain_keys=np.array(list(G15_GAINS)), gain_values=np.array(list(G15_GAINS.values())), **keep)
 
 
+def g16(cfg, net):
+    """f4: label-JSON schema - load_seq / save_seq / cal_seq_orientation of the reference (data/convert_data.py:25-70, :72-) on a seeded file."""
+    import tempfile
+    _refload.install()
+    sys.path.insert(0, os.path.join(_refload.REF_ROOT, 'data'))
+    import convert_data as ref
+    with tempfile.TemporaryDirectory() as d:
+        src = os.path.join(d, 'label.json')
+        open(src, 'w').write(cases.label_json_text(1601))
+        seq, lens, sem, inst, init, end = ref.load_seq(src)
+        orient = ref.cal_seq_orientation(seq, lens)
+        out = os.path.join(d, 'out.json')
+        _quiet(ref.save_seq, seq, lens, sem, inst, orient, out)
+        text = open(out).read()
+    save('g16_label_json.npz', seed=1601, seq=seq, seq_lens=np.array(lens), semantic=np.array(sem), instance=np.array(inst),
+         init=np.array(init, dtype=np.float64), end=np.array(end, dtype=np.float64), orient=np.asarray(orient), saved_text=np.array(text))
+
+
 def main():
     which = sys.argv[1:] or ['g2', 'g3', 'g4', 'g5', 'g6', 'g7', 'g10']
     _stable_sorts(True)

@@ -594,11 +594,16 @@ def test_native_seqs_json_is_json_dump_byte_for_byte(tmp_path):
         assert open(p).read() == json.dumps(other, indent=4, cls=io_utils.NpEncoder)
 
 
-def test_merge_lines_golden_g13(golden, tmp_path):
-    """merge_lines / downsample_seqs vs the reference's own output on a 5-tile road (same-heading weave, reversed merge,
-    new lines, retirement incl. the pop-while-enumerating skip): identical arrays."""
+@pytest.mark.parametrize('impl', ['product', 'oracle'])
+def test_merge_lines_golden_g13(golden, tmp_path, impl):
+    """merge_lines / downsample_seqs - the host C++ merger of the C-ABI (lm_merge_*) and the numpy oracle - vs the reference's own
+    output on a 5-tile road (same-heading weave, reversed merge, new lines, retirement incl. the pop-while-enumerating skip):
+    identical arrays."""
     import cases
-    from lanemapping_amd import merge_lines as ml
+    if impl == 'product':
+        from lanemapping_amd import merge_lines as ml
+    else:
+        from oracle import merge_ref as ml
     g = golden('g13_merge.npz')
     merged = ml.merge_lines(cases.merge_case_files(str(tmp_path)))
     assert len(merged) == int(g['n'])
@@ -700,3 +705,51 @@ def test_rowref_lines_from_columns_matches_claim_loop():
                     taken.add(key)
                     lines[c, h] = col[c, h] / 144 * 1152. + 4
         assert np.array_equal(RowSharNotReducRef.lines_from_columns(col, 144), hostpost.trace_lines(lines))
+
+
+@pytest.mark.parametrize('seed', range(6))
+def test_merge_lines_cpp_vs_oracle_random_roads(seed):
+    """The streaming C++ merger vs the numpy oracle on seeded random roads: several parallel lanes cut into overlapping tiles,
+    some pieces reversed, lanes that end or start mid-way, jittered vertices - identical merged and down-sampled arrays."""
+    from lanemapping_amd import merge_lines as ml
+    from oracle import merge_ref
+    rng = np.random.RandomState(100 + seed)
+    n_lanes, n_tiles = rng.randint(2, 6), rng.randint(3, 8)
+    heading = rng.rand() * 2 * np.pi
+    u, v = np.array([np.cos(heading), np.sin(heading), 0.0]), np.array([-np.sin(heading), np.cos(heading), 0.0])
+    tiles = []
+    for t in range(n_tiles):
+        lines = []
+        for l in range(n_lanes):
+            if rng.rand() < 0.15:
+                continue                                     # the lane is missing in this tile
+            s0 = t * 40.0 + rng.rand() * 3
+            n = rng.randint(12, 40)
+            s = s0 + np.sort(rng.rand(n)) * 55.0             # 15 m overlap with the next tile
+            pts = 1000.0 + s[:, None] * u + (l * 3.5 + 0.03 * rng.randn(n))[:, None] * v + np.array([0, 0, 1.0]) * (5 + 0.01 * s[:, None])
+            if rng.rand() < 0.2:
+                pts = pts[::-1]
+            lines.append(pts)
+        tiles.append(lines if len(lines) >= 2 else [])      # load_lane_seq drops single-line files
+    m = ml.LineMerger()
+    for lines in tiles:
+        m.add_tile(lines)
+    got = m.finish()
+
+    class FakeLoad:                                          # the oracle reads files: feed it the same tiles
+        def __init__(self):
+            self.i = 0
+
+        def __call__(self, name):
+            lines = tiles[int(name)]
+            return lines, [len(x) for x in lines], [x[0] for x in lines], [x[-1] for x in lines]
+    orig = merge_ref._load
+    merge_ref._load = FakeLoad()
+    try:
+        want = merge_ref.merge_lines([f'{i:04d}' for i in range(n_tiles)])
+    finally:
+        merge_ref._load = orig
+    assert len(got) == len(want) and len(got) >= 1
+    for a, b in zip(got, want):
+        assert np.array_equal(a, b)
+        assert np.array_equal(ml.downsample_seqs(a), merge_ref.downsample_seqs(b))

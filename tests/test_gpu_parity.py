@@ -726,6 +726,15 @@ def test_runner_las_to_map_chain(dev, net, tmp_path):
         for i, rec in enumerate(got):
             assert np.array_equal(np.asarray(rec['seq']), want[i, :lens[i]])
     assert os.path.exists(os.path.join(out, 'out_pc_seq_json_dir', 'merged.txt')) and len(merged) >= 1
+    # the map-level merge (host C++ merger, lm_merge_*) equals the numpy oracle's merge of the same per-tile 3-D files: same arrays
+    from oracle import merge_ref
+    import glob as _glob
+    pc_files = sorted(_glob.glob(os.path.join(out, 'out_pc_seq_json_dir', '*_*.json')) or
+                      [f for f in _glob.glob(os.path.join(out, 'out_pc_seq_json_dir', '*.json')) if 'merged' not in f])
+    want = merge_ref.merge_lines(pc_files)
+    assert len(want) == len(merged)
+    for a, b in zip(merged, want):
+        assert np.array_equal(a, b)
 
 
 # ----------------------------------------------------------------------------------------------- edge cases
