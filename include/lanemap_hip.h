@@ -82,6 +82,8 @@ int lm_conv2d_nhwc_mfma_f32_gnstats(void* stream, const float* x, int ldx, const
                                     float* y, int ldy, double* gn_partial, int B, int H, int W, int Cin, int Cout,
                                     int KH, int KW, int stride, int pad_h, int pad_w, int dil);
 int lm_gn_finalize(void* stream, const double* partial, float* stats, int B, int HW, int C, int nchunk, float eps);
+/* same values, laid out per channel group: stats [split][B][C / split][2] (two branches sharing one merged convolution) */
+int lm_gn_finalize_split(void* stream, const double* partial, float* stats, int B, int HW, int C, int nchunk, float eps, int split);
 
 /* ---- thin layers ---------------------------------------------------------------------------------------------
  * stem: relu(bn1(conv1(x))) for planar x [B,3,H,W] -> NHWC [B,H/2,W/2,64]; w_k64 = [7][7][3][64]

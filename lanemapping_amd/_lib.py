@@ -46,6 +46,7 @@ SIGNATURES = {
     'lm_conv3x3_winograd_implicit_f32': (i32, [vp, vp, i32, vp, i32, vp, vp, vp, i32, vp, i32, i32, i32, i32, i32, i32, i32, i32, vp]),
     'lm_conv2d_nhwc_mfma_f32_gnstats': (i32, [vp, vp, i32, vp, i32, vp, vp, i32, vp] + [i32] * 11),
     'lm_gn_finalize': (i32, [vp, vp, vp, i32, i32, i32, i32, f32]),
+    'lm_gn_finalize_split': (i32, [vp, vp, vp, i32, i32, i32, i32, f32, i32]),
     'lm_stem_conv7x7_bn_relu': (i32, [vp, vp, vp, vp, vp, vp, i32, i32, i32]),
     'lm_stem_conv7x7_bn_relu_u8': (i32, [vp, vp, vp, vp, vp, vp, i32, i32, i32]),
     'lm_maxpool3x3s2_nhwc': (i32, [vp, vp, vp, i32, i32, i32, i32]),

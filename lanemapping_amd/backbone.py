@@ -107,6 +107,11 @@ class VitSegNet(PackedModule):
         return P
 
     def forward(self, img):
+        """Goes through the dispatcher: torch.ops.lanemap_hip.vit_backbone (torch_ops.py)."""
+        from . import torch_ops
+        return torch_ops.vit_backbone(img, torch_ops.module_handle(self))
+
+    def _forward_impl(self, img):
         P = self.packed()
         B = img.shape[0]
         N = self.grid * self.grid

@@ -56,8 +56,10 @@ __global__ __launch_bounds__(256) void gn_partial_kernel(const float* __restrict
 }
 
 // grid (ceil(C/32), B), 256 threads = 8 chunk lanes x 32 channels; fixed summation order => deterministic
+// `split` equal channel groups: stats come out as [split][B][C / split][2], so each group is a contiguous [B][C / split][2] block (the two
+// semantic branches share one merged GEMM and take one half each)
 __global__ __launch_bounds__(256) void gn_final_kernel(const double* __restrict__ part, float* __restrict__ stats, int HW, int C,
-                                                       int nchunk, float eps) {
+                                                       int nchunk, float eps, int split) {
     __shared__ double red[2][8][32];
     const int b = blockIdx.y;
     const int cl = threadIdx.x & 31, kl = threadIdx.x >> 5;
@@ -80,8 +82,10 @@ __global__ __launch_bounds__(256) void gn_final_kernel(const double* __restrict_
         const double mean = s / HW;
         double var = ss / HW - mean * mean;
         if (var < 0.0) var = 0.0;
-        stats[((long)b * C + c) * 2 + 0] = (float)mean;
-        stats[((long)b * C + c) * 2 + 1] = (float)(1.0 / sqrt(var + (double)eps));
+        const int cg = C / split, g = c / cg;
+        float* o = stats + (((long)g * gridDim.y + b) * cg + (c - g * cg)) * 2;
+        o[0] = (float)mean;
+        o[1] = (float)(1.0 / sqrt(var + (double)eps));
     }
 }
 
@@ -397,7 +401,7 @@ LM_API int lm_gn_stats(void* stream, const float* x, double* workspace, float* s
     const int nchunk = lm_cdiv(HW, GN_CHUNK);
     hipLaunchKernelGGL(gn_partial_kernel, dim3(nchunk, B), dim3(256), 0, (hipStream_t)stream, x, workspace, HW, C, nchunk);
     LM_LAUNCH_CHECK();
-    hipLaunchKernelGGL(gn_final_kernel, dim3(lm_cdiv(C, 32), B), dim3(256), 0, (hipStream_t)stream, workspace, stats, HW, C, nchunk, eps);
+    hipLaunchKernelGGL(gn_final_kernel, dim3(lm_cdiv(C, 32), B), dim3(256), 0, (hipStream_t)stream, workspace, stats, HW, C, nchunk, eps, 1);
     LM_LAUNCH_CHECK();
     return LM_OK;
 }
@@ -405,7 +409,15 @@ LM_API int lm_gn_stats(void* stream, const float* x, double* workspace, float* s
 // second pass for partials produced by lm_conv2d_nhwc_mfma_f32_gnstats ([B][nchunk][C][2] doubles)
 LM_API int lm_gn_finalize(void* stream, const double* partial, float* stats, int B, int HW, int C, int nchunk, float eps) {
     LM_REQUIRE(partial && stats && nchunk >= 1, "gn_finalize: bad args");
-    hipLaunchKernelGGL(gn_final_kernel, dim3(lm_cdiv(C, 32), B), dim3(256), 0, (hipStream_t)stream, partial, stats, HW, C, nchunk, eps);
+    hipLaunchKernelGGL(gn_final_kernel, dim3(lm_cdiv(C, 32), B), dim3(256), 0, (hipStream_t)stream, partial, stats, HW, C, nchunk, eps, 1);
+    LM_LAUNCH_CHECK();
+    return LM_OK;
+}
+
+// the same with the statistics laid out per channel group: stats [split][B][C / split][2] (C % split == 0) - same values
+LM_API int lm_gn_finalize_split(void* stream, const double* partial, float* stats, int B, int HW, int C, int nchunk, float eps, int split) {
+    LM_REQUIRE(partial && stats && nchunk >= 1 && split >= 1 && C % split == 0, "gn_finalize_split: bad args (C=%d split=%d)", C, split);
+    hipLaunchKernelGGL(gn_final_kernel, dim3(lm_cdiv(C, 32), B), dim3(256), 0, (hipStream_t)stream, partial, stats, HW, C, nchunk, eps, split);
     LM_LAUNCH_CHECK();
     return LM_OK;
 }

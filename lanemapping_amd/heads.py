@@ -115,7 +115,17 @@ class ColumnProposal2(PackedModule):
     # -------------------------------------------------------------------------------- forward
     def forward(self, x, x_up, x_endp=None, col=None):
         """x [B,8,144,144], x_up [B,8,288,288] -> raw head outputs (live sub-graph).
-        `col`: optional pre-assembled [B,16,288,288] buffer whose channels 8..15 already hold x_up."""
+        `col`: optional pre-assembled [B,16,288,288] buffer whose channels 8..15 already hold x_up.
+        Goes through the dispatcher: torch.ops.lanemap_hip.colprop_head (torch_ops.py)."""
+        from . import torch_ops
+        if col is None:
+            col = ops.new_act(x.shape[0], 16, x_up.shape[2], x_up.shape[3], x.device)
+            col[:, 8:16].copy_(x_up)
+        self.b_size = x.shape[0]
+        conf, ext2, cls2, off2, orient = torch_ops.colprop_head(x, col, torch_ops.module_handle(self))
+        return {'proposal_conf': conf, 'ext2': ext2, 'cls2': cls2, 'offset2': off2, 'orient': orient}
+
+    def _forward_impl(self, x, x_up, x_endp=None, col=None):
         cfg = self.cfg
         if cfg.column_att or cfg.column_transformer_decoder:
             raise NotImplementedError('column_att / column_transformer_decoder are off in every BASELINE config')

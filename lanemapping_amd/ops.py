@@ -201,9 +201,10 @@ def wino_transform_gn_up2(t, stats, gamma, beta, dedicated=False):
     return WinoInput(ws, B, cin, H, W, 1)
 
 
-def conv_wino(x, wu, cout, dil=1, scale=None, shift=None, res=None, act=ACT_NONE, out=None, gn_eps=None):
+def conv_wino(x, wu, cout, dil=1, scale=None, shift=None, res=None, act=ACT_NONE, out=None, gn_eps=None, gn_split=1):
     """3x3 / stride 1 / pad = dil convolution via Winograd F(2x2,3x3).  x: an NHWC-stored tensor or a WinoInput (shared
-    transform).  With gn_eps the GroupNorm(C,C) statistics of the output come out of the GEMM epilogue: returns (y, stats)."""
+    transform).  With gn_eps the GroupNorm(C,C) statistics of the output come out of the GEMM epilogue: returns (y, stats);
+    gn_split > 1: stats [gn_split, B, cout / gn_split, 2], one contiguous block per channel group."""
     vi = x if isinstance(x, WinoInput) else wino_transform(x, dil)
     B, cin, H, W = vi.B, vi.cin, vi.H, vi.W
     y = out if out is not None else new_act(B, cout, H, W, vi.buf.device)
@@ -222,6 +223,10 @@ def conv_wino(x, wu, cout, dil=1, scale=None, shift=None, res=None, act=ACT_NONE
             2.0 * 16 * tiles * cin * cout)
     if gn_eps is None:
         return y
+    if gn_split > 1:
+        stats = torch.empty((gn_split, B, cout // gn_split, 2), device=vi.buf.device, dtype=torch.float32)
+        check(lib().lm_gn_finalize_split(_stream(), _ptr(part), _ptr(stats), B, H * W, cout, part.shape[1], gn_eps, gn_split))
+        return y, stats
     stats = torch.empty((B, cout, 2), device=vi.buf.device, dtype=torch.float32)
     check(lib().lm_gn_finalize(_stream(), _ptr(part), _ptr(stats), B, H * W, cout, part.shape[1], gn_eps))
     return y, stats

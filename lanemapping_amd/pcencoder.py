@@ -233,6 +233,17 @@ class FPNEncoder(PackedModule):
         return ops.gn_relu_upsample_sum(terms, P[gn_b + '.g'], P[gn_b + '.b'], (h, w), proj=proj, keep_sum=False)
 
     def forward(self, x, fea_up_out=None):
+        """Goes through the dispatcher: torch.ops.lanemap_hip.fpn_encoder (torch_ops.py; schema + fake kernel, cuda-only kernel)."""
+        from . import torch_ops
+        if self.out is None:
+            return self._forward_impl(x, fea_up_out)
+        if fea_up_out is None:
+            B, H, W = (x.shape[0], x.shape[1], x.shape[2]) if x.dtype == torch.uint8 else (x.shape[0], x.shape[2], x.shape[3])
+            fea_up_out = ops.new_act(B, 8, (H + 3) // 4, (W + 3) // 4, x.device)
+        fea, bi_seg, endp = torch_ops.fpn_encoder(x, fea_up_out, torch_ops.module_handle(self))
+        return fea, fea_up_out, bi_seg, endp
+
+    def _forward_impl(self, x, fea_up_out=None):
         P = self.packed()
         if x.dtype == torch.uint8:          # u8 HWC tile straight from the rasteriser / PNG reader (ops.stem applies u8 / 255)
             B, H, W, _ = x.shape
@@ -268,15 +279,16 @@ class FPNEncoder(PackedModule):
             pre_a, pre_b = [], []
             for key, src in (('p2', p2), ('p3', p3)):
                 shared[key] = ops.wino_transform(src, 1, dedicated=True)
-                t, st = ops.conv_wino(shared[key], P['semantic_branch_ab.wu'], 2 * ch, 1, shift=P['semantic_branch_ab.b'], gn_eps=self.gn11.eps)
-                pre_a.append((t[:, :ch], st[:, :ch].contiguous()))
-                pre_b.append((t[:, ch:], st[:, ch:].contiguous()))
+                t, st = ops.conv_wino(shared[key], P['semantic_branch_ab.wu'], 2 * ch, 1, shift=P['semantic_branch_ab.b'], gn_eps=self.gn11.eps,
+                                      gn_split=2)                  # statistics per branch half: [2, B, ch, 2]
+                pre_a.append((t[:, :ch], st[0]))
+                pre_b.append((t[:, ch:], st[1]))
         a4 = b4 = None
         if 'conv23.wu' in P:
             c4o = self.conv2.out_channels
             shared['p4'] = ops.wino_transform(p4, 1, dedicated=True)
-            t, st = ops.conv_wino(shared['p4'], P['conv23.wu'], 2 * c4o, 1, shift=P['conv23.b'], gn_eps=self.gn12.eps)
-            a4, b4 = (t[:, :c4o], st[:, :c4o].contiguous()), (t[:, c4o:], st[:, c4o:].contiguous())
+            t, st = ops.conv_wino(shared['p4'], P['conv23.wu'], 2 * c4o, 1, shift=P['conv23.b'], gn_eps=self.gn12.eps, gn_split=2)
+            a4, b4 = (t[:, :c4o], st[0]), (t[:, c4o:], st[1])
         fea_up = self._semantic(P, p2, p3, p4, 'conv2', 'gn12', 'semantic_branch', 'gn11', shared,
                                 (P['feature_layer.w'], P['feature_layer.b'], 8, fea_up_out), pre_a, a4)
         seg288 = ops.conv_small(fea_up, P['output_layer_binary_seg.w'], 3, shift=P['output_layer_binary_seg.b'], pre_relu=True)

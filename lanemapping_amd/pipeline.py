@@ -11,7 +11,7 @@ from concurrent.futures import ThreadPoolExecutor
 import numpy as np
 import torch
 
-from . import decode, hostpost, ops
+from . import decode, hostpost, ops, torch_ops
 from ._lib import LanemapHipError
 
 
@@ -38,11 +38,12 @@ class TilePipeline:
             keep = (raw, dev)
             crop = 0
         else:
-            prop_conf, v_ext, cls_conf, cls_idx, cls_offset = ops.decode_proposals(
-                raw['proposal_conf'], raw['ext2'], raw['cls2'], raw['offset2'], cfg.exist_thre, heads.prop_width, heads.prop_half_buff)
-            orient = ops.decode_orient(raw['orient'])
-            sem, biseg, rows = ops.decode_semantic(raw['semantic_seg'], cfg.coor_thre)
-            idx, score, status = ops.endp_topk(raw['endp_est'], K=decode.TOPK, clip=decode.CLIP)
+            # decode kernels as dispatcher-visible custom ops (torch.ops.lanemap_hip.*, torch_ops.py)
+            prop_conf, v_ext, cls_conf, cls_idx, cls_offset = torch_ops.decode_proposals(
+                raw['proposal_conf'], raw['ext2'], raw['cls2'], raw['offset2'], float(cfg.exist_thre), heads.prop_width, heads.prop_half_buff)
+            orient = torch_ops.decode_orient(raw['orient'])
+            sem, biseg, rows = torch_ops.decode_semantic(raw['semantic_seg'], float(cfg.coor_thre))
+            idx, score, status = torch_ops.endp_topk(raw['endp_est'], decode.TOPK, decode.CLIP)
             dev = {'prop_conf': prop_conf, 'v_ext': v_ext, 'cls_offset': cls_offset, 'rows': rows, 'idx': idx, 'status': status}
             keep = (raw, sem, biseg, orient, cls_conf, cls_idx, dev)      # keep device buffers alive until the copies land
             crop = raw['endp_est'].shape[-1]

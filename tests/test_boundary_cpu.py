@@ -753,3 +753,38 @@ def test_merge_lines_cpp_vs_oracle_random_roads(seed):
     for a, b in zip(got, want):
         assert np.array_equal(a, b)
         assert np.array_equal(ml.downsample_seqs(a), merge_ref.downsample_seqs(b))
+
+
+def test_torch_ops_registered_with_schema_and_fake_kernels():
+    """Every hot-path op is a dispatcher-visible torch custom op (torch.ops.lanemap_hip.*) with a schema and a fake kernel that
+    infers output shapes / strides without touching a device; device kernels are registered for cuda only - CPU tensors are refused
+    by the dispatcher, there is no fallback implementation."""
+    from torch._subclasses.fake_tensor import FakeTensorMode
+    from lanemapping_amd import torch_ops
+    for name in torch_ops.OP_NAMES:
+        op = getattr(torch.ops.lanemap_hip, name)
+        assert op.default._schema is not None
+    assert 'Tensor(a1!) fea_up_out' in str(torch.ops.lanemap_hip.fpn_encoder.default._schema)
+    with FakeTensorMode():
+        x = torch.empty((2, 16, 16, 64), device='cuda').permute(0, 3, 1, 2)
+        y = torch.ops.lanemap_hip.conv2d_mfma(x, torch.empty((9, 128, 64), device='cuda'), 96, 3, 3, 2, 1, 1, None, None, None, 1)
+        assert tuple(y.shape) == (2, 96, 8, 8) and y.stride(1) == 1
+        y = torch.ops.lanemap_hip.conv3x3_winograd(x, torch.empty((16, 128, 64), device='cuda'), 128, 2, None, None, None, 0)
+        assert tuple(y.shape) == (2, 128, 16, 16)
+        s = torch.ops.lanemap_hip.stem_conv7x7(torch.empty((3, 64, 48, 3), device='cuda', dtype=torch.uint8), torch.empty((7, 7, 3, 64), device='cuda'),
+                                               torch.empty(64, device='cuda'), torch.empty(64, device='cuda'))
+        assert tuple(s.shape) == (3, 64, 32, 24)
+        t = torch.ops.lanemap_hip.bev_raster(torch.empty((100, 4), device='cuda'), [0, 40, 100], torch.zeros((2, 15)), 96, 80)
+        assert tuple(t.shape) == (2, 96, 80, 3) and t.dtype == torch.uint8
+        pc, ve, cc, ci, co = torch.ops.lanemap_hip.decode_proposals(torch.empty((1, 72, 2), device='cuda'), torch.empty((1, 72, 144, 3), device='cuda'),
+                                                                    torch.empty((1, 72, 144, 10), device='cuda'), torch.empty((1, 72, 144, 10), device='cuda'),
+                                                                    0.2, 2, 4)
+        assert co.dtype == torch.float64 and ci.dtype == torch.int32 and tuple(cc.shape) == (1, 72, 144, 10)
+        a = torch.ops.lanemap_hip.attention(torch.empty((648, 3072), device='cuda'), 2, 324, 16, 64, 0.125)
+        assert tuple(a.shape) == (648, 1024)
+    with pytest.raises((NotImplementedError, RuntimeError)):          # no CPU kernel: the dispatcher refuses
+        torch.ops.lanemap_hip.tile_ingest(torch.zeros((1, 8, 8, 3), dtype=torch.uint8))
+    # the two host ops run here: host C++ of the same library
+    lanes, kept = torch.ops.lanemap_hip.polyline_assemble(torch.zeros((72, 2)), torch.zeros((72, 144)), torch.zeros((72, 144), dtype=torch.float64),
+                                                          torch.zeros((144, 1152)), torch.zeros((0, 2), dtype=torch.int32), 0.3)
+    assert tuple(lanes.shape) == (72, 144, 2) and lanes.dtype == torch.float64 and kept.shape[0] == 0

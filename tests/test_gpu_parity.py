@@ -371,6 +371,39 @@ def test_u8_tile_path_bit_identical(dev, net):
     assert torch.equal(only, both[1]) and torch.equal(ops.tile_ingest(only), both[0])
 
 
+def test_torch_custom_ops_on_device(dev, net):
+    """torch.ops.lanemap_hip.*: schema / fake-kernel consistency (torch.library.opcheck) of kernel-level ops on real tensors, and the
+    stage ops the modules go through give the same bits as calling the module implementation directly."""
+    from lanemapping_amd import ops, torch_ops
+    x = ops.new_act(2, 64, 24, 20, dev).normal_()
+    w = torch.randn(96, 64, 3, 3, device=dev)
+    wp = ops.pack_mfma(w)
+    sh = torch.randn(96, device=dev)
+    args = (x, wp, 96, 3, 3, 1, 1, 1, None, sh, None, 1)
+    torch.library.opcheck(torch.ops.lanemap_hip.conv2d_mfma.default, args, test_utils=('test_schema', 'test_faketensor'))
+    assert torch.equal(torch.ops.lanemap_hip.conv2d_mfma(*args), ops.conv_mfma(x, wp, 96, 3, 3, 1, 1, 1, shift=sh, act=1))
+    u8 = torch.randint(0, 255, (2, 64, 48, 3), device=dev, dtype=torch.uint8)
+    torch.library.opcheck(torch.ops.lanemap_hip.tile_ingest.default, (u8,), test_utils=('test_schema', 'test_faketensor'))
+    lg = torch.randn(2, 3, 64, 48, device=dev)
+    torch.library.opcheck(torch.ops.lanemap_hip.decode_semantic.default, (lg, 0.2), test_utils=('test_schema', 'test_faketensor'))
+    # stage ops == module implementations
+    tiles = torch.from_numpy(synth.bev_batch([81], 1152)).to(dev)
+    fpn = net.pcencoder.fpn
+    with torch.no_grad():
+        a = fpn(tiles)                                         # through torch.ops.lanemap_hip.fpn_encoder
+        b = fpn._forward_impl(tiles)
+        for u, v in zip(a, b):
+            assert torch.equal(u, v)
+        ya = net.backbone(a[0])
+        assert torch.equal(ya, net.backbone._forward_impl(a[0]))
+        ha = net.heads(ya, a[1], a[3])
+        hb = net.heads._forward_impl(ya, a[1], a[3])
+        for k in hb:
+            assert torch.equal(ha[k], hb[k]), k
+    with pytest.raises((NotImplementedError, RuntimeError)):
+        fpn(tiles.cpu())                                       # no CPU kernel behind the op: refused, never a fallback
+
+
 def test_runner_png_tiles_to_json(dev, net, tmp_path):
     """test_gpu_0.py-style entry: PNG tiles on disk -> per-tile JSON, identical to driving the pipeline directly."""
     import json
