@@ -66,10 +66,10 @@ int lm_conv3x3_winograd_f32(void* stream, const float* x, int ldx, const float* 
                             const float* shift, const float* res, int ldr, float* y, int ldy, int B, int H, int W, int Cin,
                             int Cout, int dil, int act, void* workspace, long workspace_bytes);
 
-/* The same convolution without the transformed-input tensor V (wino_implicit_kernel: the raw 4x4 patches of 64 tiles are staged in
- * LDS per 32-channel slab, B^T d B is applied while reading the A fragments, all 16 xi accumulate in registers): bit-identical y to
- * lm_conv3x3_winograd_f32, no workspace.  wu_frag = U repacked per wave fragment, [16][Cin/32][CoutP/32][4][64][4]:
- *   wu_frag[xi][cs][nt][kk][lane][e] = U[xi][nt*32 + (lane & 31)][cs*32 + kk*8 + (lane >> 5)*4 + e].
+/* The same convolution without the transformed-input tensor V in HBM (wino_implicit_kernel: the raw 4x4 patches of 64 tiles are staged
+ * in LDS per 16-channel slab, transformed there once per workgroup, all 16 xi accumulate in registers): bit-identical y to
+ * lm_conv3x3_winograd_f32, no workspace.  wu_frag = U repacked per wave fragment, [16][Cin/16][CoutP/32][2][64][4]:
+ *   wu_frag[xi][cs][nt][kk][lane][e] = U[xi][nt*32 + (lane & 31)][cs*16 + kk*8 + (lane >> 5)*4 + e].
  * lm_winograd_implicit_supported: 1 when the shape is covered (tile rows of >= 21 tiles, Cin % 32 == 0, Cin <= 1024). */
 int lm_winograd_implicit_supported(int H, int W, int Cin, int dil);
 int lm_conv3x3_winograd_implicit_f32(void* stream, const float* x, int ldx, const float* wu_frag, int CoutP, const float* scale,

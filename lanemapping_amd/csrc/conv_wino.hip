@@ -553,26 +553,33 @@ WinoGeom geom(int B, int H, int W, int dil) {
 
 
 // =====================================================================================================================================
-// Implicit-transform Winograd: no V tensor.  One workgroup = 64 tiles x 64 output channels, 4 waves (one per SIMD) of 32 x 32.
+// Implicit-transform Winograd: no V tensor in HBM.  One workgroup = 64 tiles x 64 output channels, 4 waves (one per SIMD) of 32 x 32.
 // The loop order is (input-channel slab) outer, xi inner: all SIXTEEN transformed products M[xi] of the wave tile live in registers
-// (16 accumulators x 16 = 256 AGPRs, hence one wave per SIMD), so a 32-channel slab of the RAW input patch of the 64 tiles is staged
-// in LDS once (global_load_lds gather straight from the NHWC tensor, zero block for padding) and is re-read 16 times from there: the
-// A fragment of xi = (i, j) is (d[ra][ca] +- d[rb][ca]) +- (d[ra][cb] +- d[rb][cb]), four ds_read_b128 and three vector adds in the
-// order the materialising kernel (transform_store) uses, so V - and therefore M[xi], accumulated over the same K order - has the
-// same bits.  The fold with A^T . A happens once at the end, in ascending xi like the streaming kernel: y is bit-identical.
-// B (U = G g G^T, repacked per wave fragment: [xi][slab][32-channel tile][kk][lane][4]) goes global -> registers one xi ahead.
+// (16 accumulators x 16 = 256 AGPRs, hence one wave per SIMD).  Per 16-channel slab:
+//   1. the RAW input patch of the 64 tiles (4 patch rows x up to 136 column slots x 16 channels, 34 KB) arrives in LDS through
+//      global_load_lds gathers straight from the NHWC tensor (zero block for padding), issued during the previous slab's MFMA phase;
+//   2. TRANSFORM phase: the 256 threads turn it into the slab's V = B^T d B for all 16 xi ONCE (thread = one tile x 4 channels: 16
+//      ds_read_b128, 32 vector adds in the order of transform_store - rows first, then columns - 16 ds_write_b128) into a 64 KB LDS
+//      buffer V[xi][tile][16 ch].  f32 MFMA executes on the SIMD's vector ALUs (it runs at the VALU rate and, measured, VALU time of
+//      the same wave ADDS to MFMA time), so the transform must not be repeated per output-channel tile or per wave: the first version
+//      of this kernel transformed in the A-fragment path (3 adds per MFMA, redundantly in both N waves) and lost 21 % to it;
+//   3. MFMA phase: for xi = 0..15: two ds_read_b128 A fragments, 8 MFMAs into accumulator xi; B (U = G g G^T, repacked per wave
+//      fragment: [xi][slab][32-channel tile][kk][lane][4]) goes global -> registers seven xi steps ahead (ring of 8 register sets).
+// V has the bits of the materialising kernel and M[xi] accumulates over the same K order; the fold with A^T . A happens once at
+// the end in ascending xi like the streaming kernel: y is bit-identical to wino_input_kernel + wino_gemm_kernel.
 // Raw patch layout in LDS: cell (r, q) = patch row r (0..3), column slot q; the 64 tiles of a workgroup are consecutive in the
 // linear (phase, ty, tx) order, i.e. up to INSEG runs of horizontally adjacent tiles; inside a run neighbouring tiles share two
-// columns (slot of tile tl, patch column c: q = 2 tl + 2 run + c).  A cell is 32 floats = 8 chunks of 16 bytes; cell q sits at
-// position pi(q) (bits 0 and 1 swapped) with its chunks XOR-swizzled by (q >> 2) & 7: the 16 lanes of a ds_read_b128 group (tiles
-// tl..tl+15 at a fixed patch column) then cover all 64 banks.
-constexpr int IBM = 64, IBN = 64, INSEG = 4;
+// columns (slot of tile tl, patch column c: q = 2 tl + 2 run + c).  A cell is 16 floats = 4 chunks of 16 bytes; cell q sits at
+// position rot(q) (low three bits rotated so that the cells of consecutive TILES differ in their low two position bits): the 16
+// lanes of a ds_read_b128 group (4 tiles x 4 channel quads) then cover all 64 banks.  V rows are XOR-swizzled by (tile >> 2) & 3.
+constexpr int IBM = 64, IBN = 64, INSEG = 4, IKS = 16;
 constexpr int INCOL = 2 * IBM + 2 * INSEG;       // 136 column slots
 constexpr int ICELLS = 4 * INCOL;                // 544 cells per slab
-constexpr int IROW = INCOL * 32;                 // floats per patch row
-constexpr int IBUF = ICELLS * 32;                // floats per slab buffer (69,632 B)
-constexpr int ILPW = ICELLS * 8 / 64 / 4;        // global_load_lds instructions per wave and slab (17)
-static_assert(ICELLS * 8 % 256 == 0, "whole wave loads");
+constexpr int IROW = INCOL * IKS;                // floats per patch row
+constexpr int ILPW = 9;                          // global_load_lds instructions per wave and slab: 4 x 9 x 16 cells >= 544
+constexpr int IRAW = ILPW * 4 * 256;             // floats of the raw buffer (36,864 B; the last 32 cells are never read)
+constexpr int IVBUF = 16 * IBM * IKS;            // floats of the V slab (65,536 B)
+static_assert(ILPW * 4 * 16 >= ICELLS && INCOL % 8 == 0, "patch loads cover the slab");
 
 __device__ __attribute__((aligned(16))) float g_wino_zeros[1024 + 32];   // zero source for padding cells, any channel slab (Cin <= 1024)
 
@@ -583,128 +590,95 @@ struct WinoImpParams {
     WinoGeom g;
 };
 
-__device__ __forceinline__ int swap01(int q) { return (q & ~3) | ((q & 1) << 1) | ((q >> 1) & 1); }
+__device__ __forceinline__ int rot3(int q) { return (q & ~7) | ((q >> 1) & 3) | ((q & 1) << 2); }          // cell -> LDS position
+__device__ __forceinline__ int unrot3(int p) { return (p & ~7) | ((p & 3) << 1) | ((p >> 2) & 1); }
 
 // B fragment loads bypass the compiler's wait-count bookkeeping (it would drain the in-flight global_load_lds queue at every use):
 // explicit s_waitcnt vmcnt(N) below, tied to the destination registers through "+v" operands.
-__device__ __forceinline__ void bload4(f32x4 (&b)[4], unsigned voff, const float* sbase) {
-    asm volatile("global_load_dwordx4 %0, %4, %5\n\t"
-                 "global_load_dwordx4 %1, %4, %5 offset:1024\n\t"
-                 "global_load_dwordx4 %2, %4, %5 offset:2048\n\t"
-                 "global_load_dwordx4 %3, %4, %5 offset:3072"
-                 : "=&v"(b[0]), "=&v"(b[1]), "=&v"(b[2]), "=&v"(b[3]) : "v"(voff), "s"(sbase) : "memory");
+__device__ __forceinline__ void bload2(f32x4 (&b)[2], unsigned voff, const float* sbase) {
+    asm volatile("global_load_dwordx4 %0, %2, %3\n\t"
+                 "global_load_dwordx4 %1, %2, %3 offset:1024"
+                 : "=&v"(b[0]), "=&v"(b[1]) : "v"(voff), "s"(sbase) : "memory");
 }
 template <int N>
-__device__ __forceinline__ void bwait(f32x4 (&b)[4]) {
-    asm volatile("s_waitcnt vmcnt(%4)" : "+v"(b[0]), "+v"(b[1]), "+v"(b[2]), "+v"(b[3]) : "n"(N) : "memory");
+__device__ __forceinline__ void bwait(f32x4 (&b)[2]) {
+    asm volatile("s_waitcnt vmcnt(%2)" : "+v"(b[0]), "+v"(b[1]) : "n"(N) : "memory");
 }
 
-template <int I> struct WinoRow;      // B^T row i: d[RA] (+|-) d[RB]
-template <> struct WinoRow<0> { static constexpr int RA = 0, RB = 2; static constexpr bool SUB = true; };
-template <> struct WinoRow<1> { static constexpr int RA = 1, RB = 2; static constexpr bool SUB = false; };
-template <> struct WinoRow<2> { static constexpr int RA = 2, RB = 1; static constexpr bool SUB = true; };
-template <> struct WinoRow<3> { static constexpr int RA = 1, RB = 3; static constexpr bool SUB = true; };
-
-template <bool SUB>
-__device__ __forceinline__ f32x4 pm(const f32x4 a, const f32x4 b) {
-    f32x4 r;
+// TRANSFORM phase, one thread = (tile tl, channel quad qd): V[xi][tl][4 qd ..] = (B^T d B)[xi] with the arithmetic of transform_store
+__device__ __forceinline__ void wino_slab_transform(const float* raw, float* V, const int (&roff)[4], int voff) {
+    f32x4 r[4][4];
 #pragma unroll
-    for (int e = 0; e < 4; ++e) r[e] = SUB ? a[e] - b[e] : a[e] + b[e];
-    return r;
-}
-
-// raw patch values of the A fragment of (xi, kk): d[0] = (ra, ca), d[1] = (rb, ca), d[2] = (ra, cb), d[3] = (rb, cb)
-template <int XI, int KK>
-__device__ __forceinline__ void wino_a_load(f32x4 (&d)[4], const float* abuf, const int (&aoff)[4][4]) {
-    typedef WinoRow<(XI >> 2)> R;
-    typedef WinoRow<(XI & 3)> Cc;
-    d[0] = *reinterpret_cast<const f32x4*>(abuf + R::RA * IROW + aoff[Cc::RA][KK]);
-    d[1] = *reinterpret_cast<const f32x4*>(abuf + R::RB * IROW + aoff[Cc::RA][KK]);
-    d[2] = *reinterpret_cast<const f32x4*>(abuf + R::RA * IROW + aoff[Cc::RB][KK]);
-    d[3] = *reinterpret_cast<const f32x4*>(abuf + R::RB * IROW + aoff[Cc::RB][KK]);
-}
-// element t of the transformed fragment: rows first, then columns (the order of transform_store, i.e. the bits of V)
-template <int XI>
-__device__ __forceinline__ float wino_a_elem(const f32x4 (&d)[4], int t) {
-    typedef WinoRow<(XI >> 2)> R;
-    typedef WinoRow<(XI & 3)> Cc;
-    const float r0 = R::SUB ? d[0][t] - d[1][t] : d[0][t] + d[1][t];
-    const float r1 = R::SUB ? d[2][t] - d[3][t] : d[2][t] + d[3][t];
-    return Cc::SUB ? r0 - r1 : r0 + r1;
-}
-
-// One group = 4 MFMAs of (XI, KK) on the raw values in `cur`, with the LDS reads of the NEXT group (NXI, NKK) into `nxt` pinned
-// behind the first MFMA (sched_barrier(0) on both sides): the compiler waits with lgkmcnt(0) at the first use of LDS data whenever
-// LDS-DMA is in flight, so the only reads outstanding at a wait must be the ones it needs - issued ~250 cycles earlier.
-template <int XI, int NXI, int NKK, bool LOAD>
-__device__ __forceinline__ void wino_group(f32x16& acc, const f32x4 (&cur)[4], f32x4 (&nxt)[4], const f32x4 b, const float* abuf,
-                                           const int (&aoff)[4][4], f32x16& acc_alt) {
-#ifdef LM_IABL_NOXF
-#define LM_AEL(t) cur[0][t]
-#else
-#define LM_AEL(t) wino_a_elem<XI>(cur, t)
-#endif
-    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(LM_AEL(0), b[0], acc, 0, 0, 0);
-    __builtin_amdgcn_sched_barrier(0);
-#ifndef LM_IABL_NOLDS
-    if (LOAD) wino_a_load<NXI, NKK>(nxt, abuf, aoff);
-#else
+    for (int c = 0; c < 4; ++c) {
+        const f32x4 d0 = *reinterpret_cast<const f32x4*>(raw + roff[c]);
+        const f32x4 d1 = *reinterpret_cast<const f32x4*>(raw + IROW + roff[c]);
+        const f32x4 d2 = *reinterpret_cast<const f32x4*>(raw + 2 * IROW + roff[c]);
+        const f32x4 d3 = *reinterpret_cast<const f32x4*>(raw + 3 * IROW + roff[c]);
+        r[0][c] = d0 - d2;
+        r[1][c] = d1 + d2;
+        r[2][c] = d2 - d1;
+        r[3][c] = d1 - d3;
+    }
 #pragma unroll
-    for (int e = 0; e < 4; ++e) nxt[e] = cur[e];
-#endif
-    __builtin_amdgcn_sched_barrier(0);
-#ifdef LM_IABL_2CHAIN                       // timing ablation: alternate two accumulators (wrong results)
-    acc_alt = __builtin_amdgcn_mfma_f32_32x32x2f32(LM_AEL(1), b[1], acc_alt, 0, 0, 0);
-    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(LM_AEL(2), b[2], acc, 0, 0, 0);
-    acc_alt = __builtin_amdgcn_mfma_f32_32x32x2f32(LM_AEL(3), b[3], acc_alt, 0, 0, 0);
-#else
-#pragma unroll
-    for (int t = 1; t < 4; ++t) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(LM_AEL(t), b[t], acc, 0, 0, 0);
-#endif
-    __builtin_amdgcn_sched_barrier(0);
-#undef LM_AEL
+    for (int i = 0; i < 4; ++i) {
+        float* o = V + (4 * i) * (IBM * IKS) + voff;
+        *reinterpret_cast<f32x4*>(o) = r[i][0] - r[i][2];
+        *reinterpret_cast<f32x4*>(o + IBM * IKS) = r[i][1] + r[i][2];
+        *reinterpret_cast<f32x4*>(o + 2 * IBM * IKS) = r[i][2] - r[i][1];
+        *reinterpret_cast<f32x4*>(o + 3 * IBM * IKS) = r[i][1] - r[i][3];
+    }
 }
 
-// One xi step of a slab.  All VMEM traffic of a wave shares ONE in-order counter (vmcnt): waiting for this step's B fragments also
-// waits for every patch load (global_load_lds) issued before them, and those come from HBM (~2 us under load) while B comes from
-// L2.  So (1) B runs BD = 3 steps (~1.3 us of matrix work) ahead in a ring of 4 register sets, (2) the next slab's ILPW patch
-// loads are issued in the FIRST six steps (G = 3,3,3,3,3,2), leaving ten steps for the last of them to land before the end-of-slab
-// wait, which (3) leaves the three youngest B sets in flight (vmcnt(12)).  NWAIT = loads allowed to stay outstanding when B of
-// this step is needed = 4 * BD + the patch loads issued during the last BD + 1 steps.
-// da holds the raw values of group (XI, 0) on entry and of (XI + 1, 0) on exit.
-constexpr int BD = 3;
+// One xi step of a slab's MFMA phase.  All VMEM traffic of a wave shares ONE in-order counter (vmcnt): waiting for this step's B
+// fragments also waits for every patch load (global_load_lds) issued before them, and those come from HBM (~2 us under load) while
+// B comes from L2.  So B runs BD = 7 steps (~1.5 us of matrix work) ahead in a ring of 8 register sets, the next slab's ILPW patch
+// loads are issued in the first five steps (G = 2,2,2,2,1), and the end-of-slab wait leaves the seven youngest B sets in flight.
+// NWAIT = loads allowed to stay outstanding when B of this step is needed = 2 * BD + the patch loads of the last BD + 1 steps.
+// a_cur holds the A fragments of this xi (read behind the previous step's first MFMA); the reads of xi + 1 are pinned behind this
+// step's first MFMA (the compiler waits with lgkmcnt(0) at the first use of LDS data whenever LDS-DMA is in flight, so the only
+// reads outstanding at a wait must be the ones it needs).
+constexpr int BD = 7;
 template <int XI, int G, int NWAIT>
-__device__ __forceinline__ void wino_imp_step(f32x16& acc, f32x16& acc_alt, f32x4 (&bq)[4][4], unsigned bvoff, const float* bpre_base,
-                                              const float* abuf, const int (&aoff)[4][4], f32x4 (&da)[4], f32x4 (&db)[4],
-                                              const float* const (&gsrc)[ILPW], long goff, float* nbuf, int wave, int& gnext) {
+__device__ __forceinline__ void wino_imp_step(f32x16& acc, f32x4 (&bq)[8][2], unsigned bvoff, const float* bpre_base, const float* V,
+                                              const int (&aoff)[2], f32x4 (&a_cur)[2], f32x4 (&a_nxt)[2],
+                                              const float* const (&gsrc)[ILPW], long goff, float* rawbuf, int wave, int& gnext) {
     typedef __attribute__((address_space(1))) const void gptr_t;
     typedef __attribute__((address_space(3))) void lptr_t;
 #ifndef LM_IABL_NOB                       // (timing ablations: tools/build_variant.sh)
-    bload4(bq[(XI + BD) & 3], bvoff, bpre_base);
+    bload2(bq[(XI + BD) & 7], bvoff, bpre_base);
 #endif
 #ifndef LM_IABL_NOGLDS
 #pragma unroll
     for (int g = 0; g < G; ++g) {
         const int s_ = gnext + g;
-        __builtin_amdgcn_global_load_lds((gptr_t*)(gsrc[s_] + goff), (lptr_t*)(nbuf + (s_ * 4 + wave) * 256), 16, 0, 0);
+        __builtin_amdgcn_global_load_lds((gptr_t*)(gsrc[s_] + goff), (lptr_t*)(rawbuf + (s_ * 4 + wave) * 256), 16, 0, 0);
     }
 #endif
     gnext += G;
-    f32x4 (&bcur)[4] = bq[XI & 3];
+    f32x4 (&bcur)[2] = bq[XI & 7];
 #if !defined(LM_IABL_NOB) && !defined(LM_IABL_NOGLDS)
     bwait<NWAIT>(bcur);
 #else
     bwait<0>(bcur);
 #endif
-    constexpr int NX = XI < 15 ? XI + 1 : 0;
-    wino_group<XI, XI, 1, true>(acc, da, db, bcur[0], abuf, aoff, acc_alt);
-    wino_group<XI, XI, 2, true>(acc, db, da, bcur[1], abuf, aoff, acc_alt);
-    wino_group<XI, XI, 3, true>(acc, da, db, bcur[2], abuf, aoff, acc_alt);
-    wino_group<XI, NX, 0, (XI < 15)>(acc, db, da, bcur[3], abuf, aoff, acc_alt);
+    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a_cur[0][0], bcur[0][0], acc, 0, 0, 0);
+    __builtin_amdgcn_sched_barrier(0);
+    if (XI < 15) {
+        a_nxt[0] = *reinterpret_cast<const f32x4*>(V + (XI + 1) * (IBM * IKS) + aoff[0]);
+        a_nxt[1] = *reinterpret_cast<const f32x4*>(V + (XI + 1) * (IBM * IKS) + aoff[1]);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int t = 1; t < 4; ++t) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a_cur[0][t], bcur[0][t], acc, 0, 0, 0);
+#pragma unroll
+    for (int t = 0; t < 4; ++t) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a_cur[1][t], bcur[1][t], acc, 0, 0, 0);
+    __builtin_amdgcn_sched_barrier(0);
 }
 
 __global__ __launch_bounds__(256) void wino_implicit_kernel(WinoImpParams p) {
-    extern __shared__ __attribute__((aligned(16))) float smem[];      // [2][IBUF]
+    extern __shared__ __attribute__((aligned(16))) float smem[];      // raw patch slab [IRAW] | V slab [IVBUF]
+    float* const rawbuf = smem;
+    float* const Vbuf = smem + IRAW;
     typedef __attribute__((address_space(1))) const void gptr_t;
     typedef __attribute__((address_space(3))) void lptr_t;
     const int tid = threadIdx.x, lane = tid & 63;
@@ -712,9 +686,7 @@ __global__ __launch_bounds__(256) void wino_implicit_kernel(WinoImpParams p) {
     const int wm0 = (wave >> 1) * 32, wn0 = (wave & 1) * 32;
     const int n_tiles = (p.Cout + IBN - 1) / IBN;
     // XCD-aware order (workgroups are dealt round-robin to the 8 XCDs): every XCD owns a contiguous range of M blocks and walks it
-    // once per N tile, N tile OUTER - at any time the 32 CUs of an XCD stream the SAME 64-channel slice of U (1 MB for 256 -> 256:
-    // L2 resident; with the N tiles mixed the whole 4 MB U thrashes the 4 MB L2 and every B fragment load pays the fabric latency,
-    // which one wave per SIMD cannot hide); the raw patches are prefetched a whole slab ahead and do not care.
+    // once per N tile, N tile OUTER - at any time the 32 CUs of an XCD stream the SAME 64-channel slice of U (L2 resident)
     unsigned mblk, ntile;
     {
         const unsigned bid = blockIdx.x, mb = gridDim.x / (unsigned)n_tiles, mbx = mb / 8, full = mbx * 8 * (unsigned)n_tiles;
@@ -755,10 +727,10 @@ __global__ __launch_bounds__(256) void wino_implicit_kernel(WinoImpParams p) {
     const float* gsrc[ILPW];
 #pragma unroll
     for (int s_ = 0; s_ < ILPW; ++s_) {
-        const int pos = (s_ * 4 + wave) * 8 + (lane >> 3);             // LDS cell position
+        const int pos = (s_ * 4 + wave) * 16 + (lane >> 2);            // LDS cell position (16 cells per wave load)
         const int r = pos / INCOL;
-        const int q = swap01(pos - r * INCOL);
-        const int ch = (lane & 7) ^ ((q >> 2) & 7);                    // slot p holds chunk p ^ key
+        const int q = unrot3(pos - r * INCOL);
+        const int ch = lane & 3;
         int sg = 0;
 #pragma unroll
         for (int k = 1; k < INSEG; ++k) sg += (sn[k] > 0 && q >= 2 * ts[k] + 2 * k) ? 1 : 0;
@@ -772,90 +744,94 @@ __global__ __launch_bounds__(256) void wino_implicit_kernel(WinoImpParams p) {
         const int py = 2 * ty - 1 + r, px = 2 * tx0 - 1 + lc;
         const int pa = ph / g.dil, pb = ph - pa * g.dil;
         const int yy = py * g.dil + pa, xx = px * g.dil + pb;
-        const bool ok = lc < 2 * n + 2 && ph < g.dil * g.dil && py >= 0 && px >= 0 && yy < g.H && xx < g.W;
+        const bool ok = r < 4 && lc < 2 * n + 2 && ph < g.dil * g.dil && py >= 0 && px >= 0 && yy < g.H && xx < g.W;
         gsrc[s_] = ok ? p.x + (((long)bi * g.H + yy) * g.W + xx) * p.ldx + ch * 4 : p.zeros + ch * 4;
     }
-    // --- per-lane LDS offsets (floats, inside a patch row) of the A fragment reads: [patch column c][kk]
-    const int frow = lane & 31, fhalf = lane >> 5;
-    int aoff[4][4];
+    // --- TRANSFORM task of this thread: tile tid / 4, channel quad tid % 4
+    int roff[4], tvoff;
     {
-        const int tl = wm0 + frow;
+        const int tl = tid >> 2, qd = tid & 3;
         int sg = 0;
 #pragma unroll
         for (int k = 1; k < INSEG; ++k) sg += (sn[k] > 0 && tl >= ts[k]) ? 1 : 0;
         const int cb = 2 * tl + 2 * sg;
 #pragma unroll
-        for (int c = 0; c < 4; ++c) {
-            const int q = cb + c, key = (q >> 2) & 7;
-#pragma unroll
-            for (int kk = 0; kk < 4; ++kk) aoff[c][kk] = (swap01(q) * 8 + ((2 * kk + fhalf) ^ key)) * 4;
-        }
+        for (int c = 0; c < 4; ++c) roff[c] = (rot3(cb + c) * 4 + qd) * 4;
+        tvoff = (tl * 4 + (qd ^ ((tl >> 2) & 3))) * 4;
     }
-    const int cslabs = p.C / 32;
+    // --- MFMA-phase A fragment offsets inside V[xi]: row = tile wm0 + frow, chunk 2 kk + fhalf
+    const int frow = lane & 31, fhalf = lane >> 5;
+    int aoff[2];
+    {
+        const int tl = wm0 + frow;
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk) aoff[kk] = (tl * 4 + ((2 * kk + fhalf) ^ ((tl >> 2) & 3))) * 4;
+    }
+    const int cslabs = p.C / IKS;
     const unsigned bvoff = (unsigned)lane * 16u;
-    const long bstep = (long)p.NT * 1024;                              // floats between consecutive slabs of one xi
-    const float* const bbase = p.U + (long)((n0 + wn0) >> 5) * 1024;   // this wave's 32-channel tile
+    const long bstep = (long)p.NT * 512;                               // floats between consecutive slabs of one xi (NT x 2 x 64 x 4)
+    const float* const bbase = p.U + (long)((n0 + wn0) >> 5) * 512;    // this wave's 32-channel tile
+    const long bxi = (long)cslabs * bstep;                             // floats between consecutive xi
 
     f32x16 acc[16];
 #pragma unroll
     for (int k = 0; k < 16; ++k)
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[k][r] = 0.f;
-    f32x4 bq[4][4];
-    const long bxi = (long)cslabs * bstep;                             // floats between consecutive xi
+    f32x4 bq[8][2];
     // prologue: slab 0 of the patch, B of steps 0 .. BD-1 of slab 0
 #pragma unroll
     for (int s_ = 0; s_ < ILPW; ++s_)
-        __builtin_amdgcn_global_load_lds((gptr_t*)gsrc[s_], (lptr_t*)(smem + (s_ * 4 + wave) * 256), 16, 0, 0);
-    bload4(bq[0], bvoff, bbase);
-    bload4(bq[1], bvoff, bbase + bxi);
-    bload4(bq[2], bvoff, bbase + 2 * bxi);
-    bwait<0>(bq[0]);
-    bwait<0>(bq[1]);
-    bwait<0>(bq[2]);
+        __builtin_amdgcn_global_load_lds((gptr_t*)gsrc[s_], (lptr_t*)(rawbuf + (s_ * 4 + wave) * 256), 16, 0, 0);
+#pragma unroll
+    for (int k = 0; k < BD; ++k) bload2(bq[k], bvoff, bbase + (long)k * bxi);
+#pragma unroll
+    for (int k = 0; k < BD; ++k) bwait<0>(bq[k]);
     __builtin_amdgcn_s_barrier();
 
     for (int cs = 0; cs < cslabs; ++cs) {
-        const float* abuf = smem + (cs & 1) * IBUF;
-        float* nbuf = smem + ((cs & 1) ^ 1) * IBUF;
+        // TRANSFORM phase: raw slab cs (complete: every wave waited for its loads before the barrier) -> V
+        wino_slab_transform(rawbuf, Vbuf, roff, tvoff);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // (a raw barrier: __syncthreads() would also drain the B ring)
+        __builtin_amdgcn_s_barrier();          // V complete; the raw buffer is free for the next slab's loads
         const bool more = cs + 1 < cslabs;
         // the last slab has nothing to prefetch: its loads re-read slab 0 of the zero block / tensor into the idle buffer (harmless)
-        const long goff = more ? (long)(cs + 1) * 32 : 0;
+        const long goff = more ? (long)(cs + 1) * IKS : 0;
         const float* const bs = bbase + (long)cs * bstep;                                   // (xi 0, this slab)
         const float* const bs_next = bbase + (long)(more ? cs + 1 : 0) * bstep;             // (xi 0, next slab)
         int gnext = 0;
-        f32x4 da[4], db[4];
-        wino_a_load<0, 0>(da, abuf, aoff);
+        f32x4 a0[2], a1[2];
+        a0[0] = *reinterpret_cast<const f32x4*>(Vbuf + aoff[0]);
+        a0[1] = *reinterpret_cast<const f32x4*>(Vbuf + aoff[1]);
         // B prefetched by step XI belongs to step XI + BD: same slab while XI + BD < 16, else step XI + BD - 16 of the next slab
-#define LM_WSTEP(XI, G, NW) \
-        wino_imp_step<XI, G, NW>(acc[XI], acc[(XI) ^ 8], bq, bvoff, (XI) + BD < 16 ? bs + (long)((XI) + BD) * bxi : bs_next + (long)((XI) + BD - 16) * bxi, \
-                                 abuf, aoff, da, db, gsrc, goff, nbuf, wave, gnext)
-        LM_WSTEP(0, 3, 15);
-        LM_WSTEP(1, 3, 18);
-        LM_WSTEP(2, 3, 21);
-        LM_WSTEP(3, 3, 24);
-        LM_WSTEP(4, 3, 24);
-        LM_WSTEP(5, 2, 23);
-        LM_WSTEP(6, 0, 20);
-        LM_WSTEP(7, 0, 17);
-        LM_WSTEP(8, 0, 14);
-        LM_WSTEP(9, 0, 12);
-        LM_WSTEP(10, 0, 12);
-        LM_WSTEP(11, 0, 12);
-        LM_WSTEP(12, 0, 12);
-        LM_WSTEP(13, 0, 12);
-        LM_WSTEP(14, 0, 12);
-        LM_WSTEP(15, 0, 12);
+#define LM_WSTEP(XI, G, NW, AC, AN) \
+        wino_imp_step<XI, G, NW>(acc[XI], bq, bvoff, (XI) + BD < 16 ? bs + (long)((XI) + BD) * bxi : bs_next + (long)((XI) + BD - 16) * bxi, \
+                                 Vbuf, aoff, AC, AN, gsrc, goff, rawbuf, wave, gnext)
+        LM_WSTEP(0, 2, 16, a0, a1);
+        LM_WSTEP(1, 2, 18, a1, a0);
+        LM_WSTEP(2, 2, 20, a0, a1);
+        LM_WSTEP(3, 2, 22, a1, a0);
+        LM_WSTEP(4, 1, 23, a0, a1);
+        LM_WSTEP(5, 0, 23, a1, a0);
+        LM_WSTEP(6, 0, 23, a0, a1);
+        LM_WSTEP(7, 0, 23, a1, a0);
+        LM_WSTEP(8, 0, 21, a0, a1);
+        LM_WSTEP(9, 0, 19, a1, a0);
+        LM_WSTEP(10, 0, 17, a0, a1);
+        LM_WSTEP(11, 0, 15, a1, a0);
+        LM_WSTEP(12, 0, 14, a0, a1);
+        LM_WSTEP(13, 0, 14, a1, a0);
+        LM_WSTEP(14, 0, 14, a0, a1);
+        LM_WSTEP(15, 0, 14, a1, a0);
 #undef LM_WSTEP
-        static_assert(3 * 5 + 2 == ILPW, "patch loads per wave and slab");
-        bwait<12>(bq[0]);                      // every patch load of the next slab has landed (only the 3 youngest B sets are in flight)
-        __builtin_amdgcn_s_barrier();
+        static_assert(2 * 4 + 1 == ILPW, "patch loads per wave and slab");
+        bwait<14>(bq[0]);                      // every patch load of the next slab has landed (only the 7 youngest B sets are in flight)
+        __builtin_amdgcn_s_barrier();          // all waves: done reading V, next raw slab complete
     }
     // The last slab's B prefetches (re-reads of valid addresses, never used) are still in flight: they must land before the compiler
     // hands their destination registers to the epilogue - a late return would overwrite whatever lives there by then (pointers).
-    bwait<0>(bq[0]);
-    bwait<0>(bq[1]);
-    bwait<0>(bq[2]);
+#pragma unroll
+    for (int k = 0; k < 8; ++k) bwait<0>(bq[k]);
 
 #ifdef LM_IABL_NOEPI
     {   // timing ablation: no fold / transposes / stores; one value per thread keeps the accumulators live
@@ -1097,13 +1073,13 @@ LM_API int lm_conv3x3_winograd_f32(void* stream, const float* x, int ldx, const 
 
 // 1 if lm_conv3x3_winograd_implicit_f32 covers the shape (wide enough tile rows: at most INSEG runs of adjacent tiles per block)
 LM_API int lm_winograd_implicit_supported(int H, int W, int Cin, int dil) {
-    if (dil < 1 || H < 1 || W < 1 || Cin < 32 || Cin % 32 != 0 || Cin > 1024) return 0;
+    if (dil < 1 || H < 1 || W < 1 || Cin < 32 || Cin % 32 != 0 || Cin > 1024) return 0;      // (Cin % 32: shares pack_wino's layout rules)
     return wino_implicit_ok(geom(1, H, W, dil)) ? 1 : 0;
 }
 
 // Same result as lm_conv3x3_winograd_f32 without the transformed-input tensor (wino_implicit_kernel): x NHWC (ldx floats between
-// pixels), wu_frag = U = G g G^T repacked per wave fragment, [16][Cin/32][CoutP/32][4][64][4] floats:
-//   wu_frag[xi][cs][nt][kk][lane][e] = U[xi][nt*32 + (lane & 31)][cs*32 + kk*8 + (lane >> 5)*4 + e]     (ops.pack_wino_fragments)
+// pixels), wu_frag = U = G g G^T repacked per wave fragment, [16][Cin/16][CoutP/32][2][64][4] floats:
+//   wu_frag[xi][cs][nt][kk][lane][e] = U[xi][nt*32 + (lane & 31)][cs*16 + kk*8 + (lane >> 5)*4 + e]     (ops.pack_wino_fragments)
 LM_API int lm_conv3x3_winograd_implicit_f32(void* stream, const float* x, int ldx, const float* wu_frag, int CoutP, const float* scale,
                                             const float* shift, const float* res, int ldr, float* y, int ldy, int B, int H, int W,
                                             int Cin, int Cout, int dil, int act, double* gn_partial) {
@@ -1126,7 +1102,7 @@ LM_API int lm_conv3x3_winograd_implicit_f32(void* stream, const float* x, int ld
         zeros = (const float*)sym;
     }
     p.zeros = zeros;
-    const size_t lds = (size_t)2 * IBUF * sizeof(float);
+    const size_t lds = (size_t)(IRAW + IVBUF) * sizeof(float);
     static bool attr_set = false;
     if (!attr_set) {
         LM_HIP(hipFuncSetAttribute((const void*)wino_implicit_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));

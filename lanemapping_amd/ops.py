@@ -87,11 +87,11 @@ def pack_wino(w):
 
 def pack_wino_fragments(wu):
     """pack_wino output U [16, CoutP, Cin] -> the per-wave-fragment order of lm_conv3x3_winograd_implicit_f32:
-    [16][Cin/32][CoutP/32][kk 4][lane 64][4] with lane = fhalf * 32 + row, k = cs*32 + kk*8 + fhalf*4 + e."""
+    [16][Cin/16][CoutP/32][kk 2][lane 64][4] with lane = fhalf * 32 + row, k = cs*16 + kk*8 + fhalf*4 + e."""
     xi, cop, ci = wu.shape
-    assert xi == 16 and cop % 32 == 0 and ci % 32 == 0
-    t = wu.reshape(16, cop // 32, 32, ci // 32, 4, 2, 4)                 # xi, nt, row, cs, kk, fhalf, e
-    return t.permute(0, 3, 1, 4, 5, 2, 6).contiguous().reshape(16, ci // 32, cop // 32, 4, 64, 4)
+    assert xi == 16 and cop % 32 == 0 and ci % 16 == 0
+    t = wu.reshape(16, cop // 32, 32, ci // 16, 2, 2, 4)                 # xi, nt, row, cs, kk, fhalf, e
+    return t.permute(0, 3, 1, 4, 5, 2, 6).contiguous().reshape(16, ci // 16, cop // 32, 2, 64, 4)
 
 
 def pack_small(w):
@@ -236,9 +236,10 @@ def wino_implicit_supported(H, W, cin, dil=1):
     return bool(lib().lm_winograd_implicit_supported(int(H), int(W), int(cin), int(dil)))
 
 
-def conv_wino_implicit(x, wf, cout, dil=1, scale=None, shift=None, res=None, act=ACT_NONE, out=None, gn_eps=None):
-    """3x3 / stride 1 / pad = dil convolution via Winograd F(2x2,3x3) WITHOUT the transformed-input tensor (implicit transform in the
-    GEMM's A path).  wf = pack_wino_fragments(pack_wino(w)).  Same bits as conv_wino; with gn_eps returns (y, stats)."""
+def conv_wino_implicit(x, wf, cout, dil=1, scale=None, shift=None, res=None, act=ACT_NONE, out=None, gn_eps=None, gn_split=1):
+    """3x3 / stride 1 / pad = dil convolution via Winograd F(2x2,3x3) WITHOUT the transformed-input tensor in HBM (the raw patches are
+    transformed in LDS, once per workgroup and 16-channel slab).  wf = pack_wino_fragments(pack_wino(w)).  Same bits as conv_wino;
+    with gn_eps returns (y, stats) (gn_split: statistics laid out per channel group, see conv_wino)."""
     x, ldx = as_nhwc(x)
     B, cin, H, W = x.shape
     cop = wf.shape[2] * 32
@@ -256,6 +257,10 @@ def conv_wino_implicit(x, wf, cout, dil=1, scale=None, shift=None, res=None, act
             2.0 * 16 * tiles * cin * cout)
     if gn_eps is None:
         return y
+    if gn_split > 1:
+        stats = torch.empty((gn_split, B, cout // gn_split, 2), device=x.device, dtype=torch.float32)
+        check(lib().lm_gn_finalize_split(_stream(), _ptr(part), _ptr(stats), B, H * W, cout, part.shape[1], gn_eps, gn_split))
+        return y, stats
     stats = torch.empty((B, cout, 2), device=x.device, dtype=torch.float32)
     check(lib().lm_gn_finalize(_stream(), _ptr(part), _ptr(stats), B, H * W, cout, part.shape[1], gn_eps))
     return y, stats

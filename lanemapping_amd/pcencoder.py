@@ -28,10 +28,12 @@ USE_WINOGRAD = os.environ.get('LANEMAP_WINOGRAD', '1') != '0'
 WINO_MIN_CIN = int(os.environ.get('LANEMAP_WINO_MIN_CIN', '128'))
 MERGE_BRANCH_CONVS = os.environ.get('LANEMAP_MERGE_BRANCH_CONVS', '1') != '0'   # conv_b of both semantic branches on p2 / p3 as one GEMM
 FUSE_UP_WINO = os.environ.get('LANEMAP_FUSE_UP_WINO', '1') != '0'    # s4: GN + ReLU + x2 upsample fused into the Winograd input transform
-# Winograd without the V tensor (csrc/conv_wino.hip wino_implicit_kernel, bit-identical results): for the convolutions whose input is
-# consumed by ONE Winograd GEMM (BasicBlock convs, smooth*); inputs shared by several GEMMs (p2 / p3 / p4 of the semantic branches) and the
-# fused GN+upsample producer keep the materialised transform.  LANEMAP_WINO_IMPLICIT=1 switches it on (A/B numbers: profiles/README.md)
-WINO_IMPLICIT = os.environ.get('LANEMAP_WINO_IMPLICIT', '0') != '0' 
+# Winograd without the V tensor in HBM (csrc/conv_wino.hip wino_implicit_kernel: the raw patches are transformed in LDS, bit-identical
+# results): every 3x3 / stride-1 convolution with >= WINO_IMPLICIT_MIN_CIN input channels whose tile rows are wide enough
+# (lm_winograd_implicit_supported), 6-25 % faster than transform + streaming GEMM per layer and without its 4x-inflated HBM round trip
+# (also pays on the 64-channel layers, where the materialising path lost to the direct kernel).  LANEMAP_WINO_IMPLICIT=0 switches back.
+WINO_IMPLICIT = os.environ.get('LANEMAP_WINO_IMPLICIT', '1') != '0'
+WINO_IMPLICIT_MIN_CIN = int(os.environ.get('LANEMAP_WINO_IMPLICIT_MIN_CIN', '64'))
 
 
 class _ResBlock(nn.Module):
@@ -131,14 +133,14 @@ class FPNEncoder(PackedModule):
                 P[k + '.w2'] = ops.pack_mfma(blk.conv2.weight)
                 P[k + '.s2'], P[k + '.b2'] = ops.fold_bn(blk.bn2)
                 if USE_WINOGRAD:
-                    if blk.stride == 1 and blk.conv1.in_channels >= WINO_MIN_CIN:
-                        P[k + '.w1u'] = ops.pack_wino(blk.conv1.weight)
-                    if blk.conv2.in_channels >= WINO_MIN_CIN:
-                        P[k + '.w2u'] = ops.pack_wino(blk.conv2.weight)
-                    if WINO_IMPLICIT:
-                        for q in ('.w1u', '.w2u'):
-                            if (k + q) in P:
-                                P[k + q + 'f'] = ops.pack_wino_fragments(P[k + q])
+                    for q, conv, ok in (('.w1u', blk.conv1, blk.stride == 1), ('.w2u', blk.conv2, True)):
+                        if not ok:
+                            continue
+                        u = None
+                        if conv.in_channels >= WINO_MIN_CIN:
+                            u = P[k + q] = ops.pack_wino(conv.weight)
+                        if WINO_IMPLICIT and conv.in_channels >= WINO_IMPLICIT_MIN_CIN and conv.in_channels % 32 == 0:
+                            P[k + q + 'f'] = ops.pack_wino_fragments(u if u is not None else ops.pack_wino(conv.weight))
                 if blk.downsample is not None:
                     P[k + '.wd'] = ops.pack_mfma(blk.downsample[0].weight)
                     P[k + '.sd'], P[k + '.bd'] = ops.fold_bn(blk.downsample[1])
@@ -149,7 +151,7 @@ class FPNEncoder(PackedModule):
             P[name + '.b'] = m.bias.float().contiguous()
             if USE_WINOGRAD and m.kernel_size == (3, 3) and m.in_channels >= WINO_MIN_CIN:
                 P[name + '.wu'] = ops.pack_wino(m.weight)
-                if WINO_IMPLICIT and name.startswith('smooth'):
+                if WINO_IMPLICIT:
                     P[name + '.wuf'] = ops.pack_wino_fragments(P[name + '.wu'])
         # the two branches convolve p2 and p3 with different weights: one GEMM with the output channels concatenated reads V once
         # per 4 N tiles instead of per 2 (same values per channel: an output column does not depend on its neighbours)
@@ -158,10 +160,14 @@ class FPNEncoder(PackedModule):
                 and self.gn11.eps == self.gn21.eps):
             P['semantic_branch_ab.wu'] = ops.pack_wino(torch.cat([a.weight, b2.weight], dim=0))
             P['semantic_branch_ab.b'] = torch.cat([a.bias, b2.bias]).float().contiguous()
+            if WINO_IMPLICIT:
+                P['semantic_branch_ab.wuf'] = ops.pack_wino_fragments(P['semantic_branch_ab.wu'])
             if ('conv2.wu' in P and 'conv3.wu' in P and self.conv2.out_channels == self.conv3.out_channels
                     and self.gn12.eps == self.gn22.eps):           # likewise conv2 / conv3 on p4
                 P['conv23.wu'] = ops.pack_wino(torch.cat([self.conv2.weight, self.conv3.weight], dim=0))
                 P['conv23.b'] = torch.cat([self.conv2.bias, self.conv3.bias]).float().contiguous()
+                if WINO_IMPLICIT:
+                    P['conv23.wuf'] = ops.pack_wino_fragments(P['conv23.wu'])
         if self.out is not None:
             P['out.w'] = ops.pack_mfma(self.out.weight)
         for name in ('feature_layer', 'output_layer_binary_seg', 'output_layer_endp'):
@@ -204,7 +210,9 @@ class FPNEncoder(PackedModule):
         def conv_stats(src, conv, cout, gn, share=None):
             # conv3x3 + bias with the GroupNorm statistics coming out of the conv epilogue
             eps = getattr(self, gn).eps
-            if (conv + '.wu') in P:                             # Winograd; p2/p3/p4 are transformed once for both branches
+            if (conv + '.wuf') in P and not isinstance(src, ops.WinoInput) and ops.wino_implicit_supported(src.shape[2], src.shape[3], src.shape[1], 1):
+                t, st = ops.conv_wino_implicit(src, P[conv + '.wuf'], cout, 1, shift=P[conv + '.b'], gn_eps=eps)     # no V tensor
+            elif (conv + '.wu') in P:                           # Winograd; p2/p3/p4 are transformed once for both branches
                 if share is not None:
                     if share not in shared:
                         shared[share] = ops.wino_transform(src, 1, dedicated=True)
@@ -218,7 +226,8 @@ class FPNEncoder(PackedModule):
             return t, st
 
         t, st = pre_a4 if pre_a4 is not None else conv_stats(p4, conv_a, p4.shape[1], gn_a, share='p4')
-        if (FUSE_UP_WINO and (conv_b + '.wu') in P and (h, w) == (2 * t.shape[2], 2 * t.shape[3]) and t.shape[1] in (128, 256)):
+        imp_b = (conv_b + '.wuf') in P and ops.wino_implicit_supported(h, w, t.shape[1], 1)
+        if (not imp_b and FUSE_UP_WINO and (conv_b + '.wu') in P and (h, w) == (2 * t.shape[2], 2 * t.shape[3]) and t.shape[1] in (128, 256)):
             # s4 feeds only conv_b: its Winograd input comes straight from t, the upsampled 256-channel tensor is never written
             s4 = ops.wino_transform_gn_up2(t, st, P[gn_a + '.g'], P[gn_a + '.b'])
         else:
@@ -278,16 +287,23 @@ class FPNEncoder(PackedModule):
             ch = self.semantic_branch.out_channels
             pre_a, pre_b = [], []
             for key, src in (('p2', p2), ('p3', p3)):
-                shared[key] = ops.wino_transform(src, 1, dedicated=True)
-                t, st = ops.conv_wino(shared[key], P['semantic_branch_ab.wu'], 2 * ch, 1, shift=P['semantic_branch_ab.b'], gn_eps=self.gn11.eps,
-                                      gn_split=2)                  # statistics per branch half: [2, B, ch, 2]
+                if 'semantic_branch_ab.wuf' in P and ops.wino_implicit_supported(src.shape[2], src.shape[3], src.shape[1], 1):
+                    t, st = ops.conv_wino_implicit(src, P['semantic_branch_ab.wuf'], 2 * ch, 1, shift=P['semantic_branch_ab.b'],
+                                                   gn_eps=self.gn11.eps, gn_split=2)
+                else:
+                    shared[key] = ops.wino_transform(src, 1, dedicated=True)
+                    t, st = ops.conv_wino(shared[key], P['semantic_branch_ab.wu'], 2 * ch, 1, shift=P['semantic_branch_ab.b'],
+                                          gn_eps=self.gn11.eps, gn_split=2)              # statistics per branch half: [2, B, ch, 2]
                 pre_a.append((t[:, :ch], st[0]))
                 pre_b.append((t[:, ch:], st[1]))
         a4 = b4 = None
         if 'conv23.wu' in P:
             c4o = self.conv2.out_channels
-            shared['p4'] = ops.wino_transform(p4, 1, dedicated=True)
-            t, st = ops.conv_wino(shared['p4'], P['conv23.wu'], 2 * c4o, 1, shift=P['conv23.b'], gn_eps=self.gn12.eps, gn_split=2)
+            if 'conv23.wuf' in P and ops.wino_implicit_supported(p4.shape[2], p4.shape[3], p4.shape[1], 1):
+                t, st = ops.conv_wino_implicit(p4, P['conv23.wuf'], 2 * c4o, 1, shift=P['conv23.b'], gn_eps=self.gn12.eps, gn_split=2)
+            else:
+                shared['p4'] = ops.wino_transform(p4, 1, dedicated=True)
+                t, st = ops.conv_wino(shared['p4'], P['conv23.wu'], 2 * c4o, 1, shift=P['conv23.b'], gn_eps=self.gn12.eps, gn_split=2)
             a4, b4 = (t[:, :c4o], st[0]), (t[:, c4o:], st[1])
         fea_up = self._semantic(P, p2, p3, p4, 'conv2', 'gn12', 'semantic_branch', 'gn11', shared,
                                 (P['feature_layer.w'], P['feature_layer.b'], 8, fea_up_out), pre_a, a4)
