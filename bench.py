@@ -23,6 +23,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 MFMA_F32_PEAK_TFLOPS = 157.3      # /opt/skills/guides/MI355X_MICROARCH.md: dense fp32 MFMA peak
+BF16_PEAK_TFLOPS = 2500.0         # same guide: dense bf16 MFMA peak (only used for the opt-in split-precision kernel)
 HBM_PEAK_GBS = 8000.0             # same guide: HBM3E 8 TB/s
 BATCH = 8
 N_PTS = 4194304                   # points per tile of the fused workload
@@ -342,7 +343,10 @@ def main():
     # ---- aggregate per kernel class.  kind strings: 'wino_gemm ...', 'wino_input ...', 'conv ...', 'gemm ...', 'spconv ...'
     def kclass(kind):
         k = kind.split(' ', 1)[0]
-        return {'wino_gemm': 'wino_gemm_kernel', 'wino_implicit': 'wino_implicit_kernel', 'wino_input': 'wino_input_kernel'}.get(k, 'conv_mfma_kernel')
+        return {'wino_gemm': 'wino_gemm_kernel', 'wino_implicit': 'wino_implicit_kernel', 'wino_input': 'wino_input_kernel',
+                'wino_bf16x3': 'wino_implicit_kernel<bf16x3>'}.get(k, 'conv_mfma_kernel')
+    # peak of the dtype a kernel class issues: exact-fp32 MFMA, or (opt-in LANEMAP_WINO_BF16X3=1) bf16 MFMA fed with 3-way split fp32 operands
+    peak_of = lambda c: BF16_PEAK_TFLOPS if 'bf16x3' in c else MFMA_F32_PEAK_TFLOPS
     cls = {}
     per_kind = {}
     for a, b, kind, fl, ex in prof['pairs']:
@@ -364,7 +368,7 @@ def main():
     per_class = {k: {'launches_per_step': e[0] / rs, 'ms_per_step': e[1] / rs, 'avg_launch_ms': e[1] / max(e[0], 1),
                      'executed_gflop_per_step': e[3] / rs / 1e9,
                      'executed_tflops': e[3] / (e[1] * 1e-3) / 1e12 if e[1] > 0 else 0.0,
-                     'frac': e[3] / (e[1] * 1e-3) / 1e12 / MFMA_F32_PEAK_TFLOPS if e[1] > 0 else 0.0}
+                     'peak': peak_of(k), 'frac': e[3] / (e[1] * 1e-3) / 1e12 / peak_of(k) if e[1] > 0 else 0.0}
                  for k, e in cls.items()}
     dominant = max(per_class, key=lambda k: per_class[k]['ms_per_step']) if per_class else None
     # HBM bytes of the same kernels from the PMC counters (collected offline in their own rocprofv3 --pmc passes, FETCH_SIZE x 2 per the
@@ -403,7 +407,8 @@ def main():
                      # EXECUTED view: FLOPs the matrix cores really issue (Winograd F(2x2,3x3) launches: 16/36 of the direct count)
                      # / summed HIP-event time of those launches (the HBM-bound Winograd input transforms included)
                      'achieved': executed_tflops, 'peak': MFMA_F32_PEAK_TFLOPS, 'unit': 'TFLOP/s',
-                     'frac': executed_tflops / MFMA_F32_PEAK_TFLOPS,
+                     # time-weighted utilisation: sum_k (executed_k / peak_k) / sum_k t_k  (== achieved / peak when every launch is fp32 MFMA)
+                     'frac': (sum(e[3] / peak_of(k) for k, e in cls.items()) / (conv_ms * 1e-3) / 1e12) if conv_ms > 0 else 0.0,
                      'traffic': mfma_traffic, 'traffic_source': pmc.get('source'),
                      'algorithmic_equiv_tflops': alg_tflops,
                      'scope': roof_scope, 'launches_per_step': prof['launches'] / rs,

@@ -605,6 +605,106 @@ __device__ __forceinline__ void bwait(f32x4 (&b)[2]) {
     asm volatile("s_waitcnt vmcnt(%2)" : "+v"(b[0]), "+v"(b[1]) : "n"(N) : "memory");
 }
 
+// ---- split-precision variant (SPLIT = true): the GEMM runs on the bf16 matrix cores with fp32 operands split into three bf16
+// pieces each, v = v1 + v2 + v3 EXACTLY (truncation split with bit masks: 8 + 8 + 8 significant bits), and six of the nine piece
+// products, v1u1 + v1u2 + v2u1 + v1u3 + v2u2 + v3u1 (smallest first), accumulated in the fp32 accumulators: relative error of a product
+// <= 2^-23, the class of an fp32 rounding (profiles/r2_split_precision_study.txt: max error vs fp64 1.2e-6 on a 256-channel layer
+// against 3.3e-6 for the fp32 Winograd, 0 decision flips outside the reference margin on the G10 tile).  Six 32x32x16 bf16 MFMAs of
+// 32 cycles replace eight 32x32x2 f32 MFMAs of 64: 2.67x less matrix time, and the bf16 matrix cores do not share the vector ALUs.
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef unsigned u32x2v __attribute__((ext_vector_type(2)));
+typedef unsigned u32x4v __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ void bload3(f32x4 (&b)[3], unsigned voff, const float* sbase) {
+    asm volatile("global_load_dwordx4 %0, %3, %4\n\t"
+                 "global_load_dwordx4 %1, %3, %4 offset:1024\n\t"
+                 "global_load_dwordx4 %2, %3, %4 offset:2048"
+                 : "=&v"(b[0]), "=&v"(b[1]), "=&v"(b[2]) : "v"(voff), "s"(sbase) : "memory");
+}
+template <int N>
+__device__ __forceinline__ void bwait3(f32x4 (&b)[3]) {
+    asm volatile("s_waitcnt vmcnt(%3)" : "+v"(b[0]), "+v"(b[1]), "+v"(b[2]) : "n"(N) : "memory");
+}
+
+// three bf16 pieces of 4 floats, packed 4 x bf16 = 8 bytes per piece (piece 0 = the leading 8 bits)
+__device__ __forceinline__ void split3_pack(const f32x4 v, u32x2v (&piece)[3]) {
+    f32x4 r = v;
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        unsigned top[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) top[e] = __float_as_uint(r[e]) & 0xFFFF0000u;      // sign, exponent, 7 mantissa bits: a bf16 value
+        piece[k][0] = (top[0] >> 16) | top[1];
+        piece[k][1] = (top[2] >> 16) | top[3];
+        if (k < 2) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) r[e] = r[e] - __uint_as_float(top[e]);           // exact
+        }
+    }
+}
+
+// TRANSFORM phase (split): V piece planes [3][xi][tile][16 ch bf16] (rows of 32 bytes, 16-byte halves XOR-swizzled by (tile >> 3) & 1)
+constexpr int IVPLANE = 16 * IBM * IKS / 2;        // floats (= 4-byte units) per bf16 plane: 32 KB
+__device__ __forceinline__ void wino_slab_transform_split(const float* raw, float* V, const int (&roff)[4], int voff8) {
+    f32x4 r[4][4];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+        const f32x4 d0 = *reinterpret_cast<const f32x4*>(raw + roff[c]);
+        const f32x4 d1 = *reinterpret_cast<const f32x4*>(raw + IROW + roff[c]);
+        const f32x4 d2 = *reinterpret_cast<const f32x4*>(raw + 2 * IROW + roff[c]);
+        const f32x4 d3 = *reinterpret_cast<const f32x4*>(raw + 3 * IROW + roff[c]);
+        r[0][c] = d0 - d2;
+        r[1][c] = d1 + d2;
+        r[2][c] = d2 - d1;
+        r[3][c] = d1 - d3;
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const f32x4 v[4] = {r[i][0] - r[i][2], r[i][1] + r[i][2], r[i][2] - r[i][1], r[i][1] - r[i][3]};
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            u32x2v pc[3];
+            split3_pack(v[j], pc);
+            float* o = V + (4 * i + j) * (IBM * IKS / 2) + voff8;        // xi rows of 8 floats-worth (32 bytes)
+#pragma unroll
+            for (int k = 0; k < 3; ++k) *reinterpret_cast<u32x2v*>(o + k * IVPLANE) = pc[k];
+        }
+    }
+}
+
+// One xi step of the split MFMA phase: three 16-byte A fragments (piece planes), three B fragments, six bf16 MFMAs
+template <int XI, int G, int NWAIT>
+__device__ __forceinline__ void wino_imp_step_split(f32x16& acc, f32x4 (&bq)[8][3], unsigned bvoff, const float* bpre_base, const float* V,
+                                                    int aoff, f32x4 (&a_cur)[3], f32x4 (&a_nxt)[3],
+                                                    const float* const (&gsrc)[ILPW], long goff, float* rawbuf, int wave, int& gnext) {
+    typedef __attribute__((address_space(1))) const void gptr_t;
+    typedef __attribute__((address_space(3))) void lptr_t;
+    bload3(bq[(XI + 7) & 7], bvoff, bpre_base);
+#pragma unroll
+    for (int g = 0; g < G; ++g) {
+        const int s_ = gnext + g;
+        __builtin_amdgcn_global_load_lds((gptr_t*)(gsrc[s_] + goff), (lptr_t*)(rawbuf + (s_ * 4 + wave) * 256), 16, 0, 0);
+    }
+    gnext += G;
+    f32x4 (&b)[3] = bq[XI & 7];
+    bwait3<NWAIT>(b);
+#define LM_BF(x) __builtin_bit_cast(bf16x8, x)
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(LM_BF(a_cur[2]), LM_BF(b[0]), acc, 0, 0, 0);       // v3 u1
+    __builtin_amdgcn_sched_barrier(0);
+    if (XI < 15) {
+#pragma unroll
+        for (int k = 0; k < 3; ++k) a_nxt[k] = *reinterpret_cast<const f32x4*>(V + k * IVPLANE + (XI + 1) * (IBM * IKS / 2) + aoff);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(LM_BF(a_cur[1]), LM_BF(b[1]), acc, 0, 0, 0);       // v2 u2
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(LM_BF(a_cur[0]), LM_BF(b[2]), acc, 0, 0, 0);       // v1 u3
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(LM_BF(a_cur[1]), LM_BF(b[0]), acc, 0, 0, 0);       // v2 u1
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(LM_BF(a_cur[0]), LM_BF(b[1]), acc, 0, 0, 0);       // v1 u2
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(LM_BF(a_cur[0]), LM_BF(b[0]), acc, 0, 0, 0);       // v1 u1
+#undef LM_BF
+    __builtin_amdgcn_sched_barrier(0);
+}
+
 // TRANSFORM phase, one thread = (tile tl, channel quad qd): V[xi][tl][4 qd ..] = (B^T d B)[xi] with the arithmetic of transform_store
 __device__ __forceinline__ void wino_slab_transform(const float* raw, float* V, const int (&roff)[4], int voff) {
     f32x4 r[4][4];
@@ -675,8 +775,9 @@ __device__ __forceinline__ void wino_imp_step(f32x16& acc, f32x4 (&bq)[8][2], un
     __builtin_amdgcn_sched_barrier(0);
 }
 
+template <bool SPLIT>
 __global__ __launch_bounds__(256) void wino_implicit_kernel(WinoImpParams p) {
-    extern __shared__ __attribute__((aligned(16))) float smem[];      // raw patch slab [IRAW] | V slab [IVBUF]
+    extern __shared__ __attribute__((aligned(16))) float smem[];      // raw patch slab [IRAW] | V slab [IVBUF] (SPLIT: three bf16 planes, 3 x 32 KB)
     float* const rawbuf = smem;
     float* const Vbuf = smem + IRAW;
     typedef __attribute__((address_space(1))) const void gptr_t;
@@ -758,6 +859,7 @@ __global__ __launch_bounds__(256) void wino_implicit_kernel(WinoImpParams p) {
 #pragma unroll
         for (int c = 0; c < 4; ++c) roff[c] = (rot3(cb + c) * 4 + qd) * 4;
         tvoff = (tl * 4 + (qd ^ ((tl >> 2) & 3))) * 4;
+        if (SPLIT) tvoff = tl * 8 + (((qd >> 1) ^ ((tl >> 3) & 1)) * 4) + (qd & 1) * 2;       // floats: row of 32 B, swizzled 16-B half, 8-B quad
     }
     // --- MFMA-phase A fragment offsets inside V[xi]: row = tile wm0 + frow, chunk 2 kk + fhalf
     const int frow = lane & 31, fhalf = lane >> 5;
@@ -766,11 +868,13 @@ __global__ __launch_bounds__(256) void wino_implicit_kernel(WinoImpParams p) {
         const int tl = wm0 + frow;
 #pragma unroll
         for (int kk = 0; kk < 2; ++kk) aoff[kk] = (tl * 4 + ((2 * kk + fhalf) ^ ((tl >> 2) & 3))) * 4;
+        if (SPLIT) aoff[0] = tl * 8 + ((fhalf ^ ((tl >> 3) & 1)) * 4);                          // 16 bytes = channels 8 fhalf .. + 7 of a piece row
     }
     const int cslabs = p.C / IKS;
     const unsigned bvoff = (unsigned)lane * 16u;
-    const long bstep = (long)p.NT * 512;                               // floats between consecutive slabs of one xi (NT x 2 x 64 x 4)
-    const float* const bbase = p.U + (long)((n0 + wn0) >> 5) * 512;    // this wave's 32-channel tile
+    constexpr int BFRAG = SPLIT ? 768 : 512;                           // floats per (xi, slab, 32-channel tile): 2 x 64 x 16 B | 3 planes x 64 x 16 B
+    const long bstep = (long)p.NT * BFRAG;                             // floats between consecutive slabs of one xi
+    const float* const bbase = p.U + (long)((n0 + wn0) >> 5) * BFRAG;  // this wave's 32-channel tile
     const long bxi = (long)cslabs * bstep;                             // floats between consecutive xi
 
     f32x16 acc[16];
@@ -778,6 +882,56 @@ __global__ __launch_bounds__(256) void wino_implicit_kernel(WinoImpParams p) {
     for (int k = 0; k < 16; ++k)
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[k][r] = 0.f;
+    if constexpr (SPLIT) {
+    f32x4 bq3[8][3];
+#pragma unroll
+    for (int s_ = 0; s_ < ILPW; ++s_)
+        __builtin_amdgcn_global_load_lds((gptr_t*)gsrc[s_], (lptr_t*)(rawbuf + (s_ * 4 + wave) * 256), 16, 0, 0);
+#pragma unroll
+    for (int k = 0; k < 7; ++k) bload3(bq3[k], bvoff, bbase + (long)k * bxi);
+#pragma unroll
+    for (int k = 0; k < 7; ++k) bwait3<0>(bq3[k]);
+    __builtin_amdgcn_s_barrier();
+    for (int cs = 0; cs < cslabs; ++cs) {
+        wino_slab_transform_split(rawbuf, Vbuf, roff, tvoff);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        const bool more = cs + 1 < cslabs;
+        const long goff = more ? (long)(cs + 1) * IKS : 0;
+        const float* const bs = bbase + (long)cs * bstep;
+        const float* const bs_next = bbase + (long)(more ? cs + 1 : 0) * bstep;
+        int gnext = 0;
+        f32x4 a0[3], a1[3];
+#pragma unroll
+        for (int k = 0; k < 3; ++k) a0[k] = *reinterpret_cast<const f32x4*>(Vbuf + k * IVPLANE + aoff[0]);
+#define LM_SSTEP(XI, G, NW, AC, AN) \
+        wino_imp_step_split<XI, G, NW>(acc[XI], bq3, bvoff, (XI) + 7 < 16 ? bs + (long)((XI) + 7) * bxi : bs_next + (long)((XI) + 7 - 16) * bxi, \
+                                       Vbuf, aoff[0], AC, AN, gsrc, goff, rawbuf, wave, gnext)
+        // NWAIT = 3 * 7 + patch loads of the last 8 steps (G = 2,2,2,2,1)
+        LM_SSTEP(0, 2, 23, a0, a1);
+        LM_SSTEP(1, 2, 25, a1, a0);
+        LM_SSTEP(2, 2, 27, a0, a1);
+        LM_SSTEP(3, 2, 29, a1, a0);
+        LM_SSTEP(4, 1, 30, a0, a1);
+        LM_SSTEP(5, 0, 30, a1, a0);
+        LM_SSTEP(6, 0, 30, a0, a1);
+        LM_SSTEP(7, 0, 30, a1, a0);
+        LM_SSTEP(8, 0, 28, a0, a1);
+        LM_SSTEP(9, 0, 26, a1, a0);
+        LM_SSTEP(10, 0, 24, a0, a1);
+        LM_SSTEP(11, 0, 22, a1, a0);
+        LM_SSTEP(12, 0, 21, a0, a1);
+        LM_SSTEP(13, 0, 21, a1, a0);
+        LM_SSTEP(14, 0, 21, a0, a1);
+        LM_SSTEP(15, 0, 21, a1, a0);
+#undef LM_SSTEP
+        bwait3<21>(bq3[0]);
+        __builtin_amdgcn_s_barrier();
+    }
+#pragma unroll
+    for (int k = 0; k < 8; ++k) bwait3<0>(bq3[k]);
+
+    } else {
     f32x4 bq[8][2];
     // prologue: slab 0 of the patch, B of steps 0 .. BD-1 of slab 0
 #pragma unroll
@@ -833,6 +987,7 @@ __global__ __launch_bounds__(256) void wino_implicit_kernel(WinoImpParams p) {
 #pragma unroll
     for (int k = 0; k < 8; ++k) bwait<0>(bq[k]);
 
+    }
 #ifdef LM_IABL_NOEPI
     {   // timing ablation: no fold / transposes / stores; one value per thread keeps the accumulators live
         float sum = 0.f;
@@ -1080,9 +1235,10 @@ LM_API int lm_winograd_implicit_supported(int H, int W, int Cin, int dil) {
 // Same result as lm_conv3x3_winograd_f32 without the transformed-input tensor (wino_implicit_kernel): x NHWC (ldx floats between
 // pixels), wu_frag = U = G g G^T repacked per wave fragment, [16][Cin/16][CoutP/32][2][64][4] floats:
 //   wu_frag[xi][cs][nt][kk][lane][e] = U[xi][nt*32 + (lane & 31)][cs*16 + kk*8 + (lane >> 5)*4 + e]     (ops.pack_wino_fragments)
-LM_API int lm_conv3x3_winograd_implicit_f32(void* stream, const float* x, int ldx, const float* wu_frag, int CoutP, const float* scale,
-                                            const float* shift, const float* res, int ldr, float* y, int ldy, int B, int H, int W,
-                                            int Cin, int Cout, int dil, int act, double* gn_partial) {
+namespace {
+int wino_implicit_launch(bool split, void* stream, const float* x, int ldx, const float* wu_frag, int CoutP, const float* scale,
+                         const float* shift, const float* res, int ldr, float* y, int ldy, int B, int H, int W,
+                         int Cin, int Cout, int dil, int act, double* gn_partial) {
     LM_REQUIRE(x && wu_frag && y, "conv_wino_implicit: null pointer");
     LM_REQUIRE(lm_winograd_implicit_supported(H, W, Cin, dil) && B > 0, "conv_wino_implicit: unsupported shape (H=%d W=%d Cin=%d dil=%d)", H, W, Cin, dil);
     LM_REQUIRE(CoutP >= Cout && CoutP % 128 == 0, "conv_wino_implicit: CoutP=%d must be Cout=%d rounded up to 128", CoutP, Cout);
@@ -1102,15 +1258,36 @@ LM_API int lm_conv3x3_winograd_implicit_f32(void* stream, const float* x, int ld
         zeros = (const float*)sym;
     }
     p.zeros = zeros;
-    const size_t lds = (size_t)(IRAW + IVBUF) * sizeof(float);
-    static bool attr_set = false;
-    if (!attr_set) {
-        LM_HIP(hipFuncSetAttribute((const void*)wino_implicit_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        attr_set = true;
+    const size_t lds = (size_t)(IRAW + (split ? 3 * IVPLANE : IVBUF)) * sizeof(float);
+    static bool attr_set[2] = {false, false};
+    if (!attr_set[split ? 1 : 0]) {
+        if (split) LM_HIP(hipFuncSetAttribute((const void*)wino_implicit_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        else LM_HIP(hipFuncSetAttribute((const void*)wino_implicit_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        attr_set[split ? 1 : 0] = true;
     }
     const long blocks = (p.g.T / IBM) * ((Cout + IBN - 1) / IBN);
     LM_REQUIRE(blocks > 0 && blocks < (1L << 31) && p.g.T % IBM == 0, "conv_wino_implicit: bad grid %ld", blocks);
-    hipLaunchKernelGGL(wino_implicit_kernel, dim3((unsigned)blocks), dim3(256), lds, (hipStream_t)stream, p);
+    if (split) hipLaunchKernelGGL(wino_implicit_kernel<true>, dim3((unsigned)blocks), dim3(256), lds, (hipStream_t)stream, p);
+    else hipLaunchKernelGGL(wino_implicit_kernel<false>, dim3((unsigned)blocks), dim3(256), lds, (hipStream_t)stream, p);
     LM_LAUNCH_CHECK();
     return LM_OK;
+}
+
+}  // namespace
+
+LM_API int lm_conv3x3_winograd_implicit_f32(void* stream, const float* x, int ldx, const float* wu_frag, int CoutP, const float* scale,
+                                            const float* shift, const float* res, int ldr, float* y, int ldy, int B, int H, int W,
+                                            int Cin, int Cout, int dil, int act, double* gn_partial) {
+    return wino_implicit_launch(false, stream, x, ldx, wu_frag, CoutP, scale, shift, res, ldr, y, ldy, B, H, W, Cin, Cout, dil, act, gn_partial);
+}
+
+// The same convolution with the GEMM on the bf16 matrix cores: every fp32 operand split exactly into three bf16 pieces, six piece
+// products per multiply, fp32 accumulation (error of the class of an fp32 rounding, NOT bit-identical to the fp32 kernels).
+// wu_frag3 = U split the same way and repacked per wave fragment, [16][Cin/16][CoutP/32][3 pieces][64 lanes][8 bf16]:
+//   piece k of U[xi][nt*32 + (lane & 31)][cs*16 + (lane >> 5)*8 + e], e = 0..7        (ops.pack_wino_fragments_bf16x3)
+LM_API int lm_conv3x3_winograd_implicit_bf16x3(void* stream, const float* x, int ldx, const void* wu_frag3, int CoutP, const float* scale,
+                                               const float* shift, const float* res, int ldr, float* y, int ldy, int B, int H, int W,
+                                               int Cin, int Cout, int dil, int act, double* gn_partial) {
+    return wino_implicit_launch(true, stream, x, ldx, (const float*)wu_frag3, CoutP, scale, shift, res, ldr, y, ldy, B, H, W, Cin, Cout, dil, act,
+                                gn_partial);
 }

@@ -94,6 +94,23 @@ def pack_wino_fragments(wu):
     return t.permute(0, 3, 1, 4, 5, 2, 6).contiguous().reshape(16, ci // 16, cop // 32, 2, 64, 4)
 
 
+def pack_wino_fragments_bf16x3(wu):
+    """pack_wino output U [16, CoutP, Cin] -> three EXACT bf16 pieces (U = u1 + u2 + u3: top 8 significant bits, then the next 8, then
+    the last 8, by truncation) in the per-wave-fragment order of lm_conv3x3_winograd_implicit_bf16x3:
+    [16][Cin/16][CoutP/32][piece 3][lane 64][8] bf16 with lane = khalf * 32 + row, k = cs*16 + khalf*8 + e."""
+    xi, cop, ci = wu.shape
+    assert xi == 16 and cop % 32 == 0 and ci % 16 == 0 and wu.dtype == torch.float32
+    pieces, r = [], wu
+    for _ in range(3):
+        top = (r.contiguous().view(torch.int32) & -65536).view(torch.float32)
+        pieces.append(top)
+        r = r - top
+    assert float(r.abs().max()) == 0.0
+    t = torch.stack(pieces).to(torch.bfloat16)                                   # exact: every piece is a bf16 value
+    t = t.reshape(3, 16, cop // 32, 32, ci // 16, 2, 8)                          # piece, xi, nt, row, cs, khalf, e
+    return t.permute(1, 4, 2, 0, 5, 3, 6).contiguous().reshape(16, ci // 16, cop // 32, 3, 64, 8)
+
+
 def pack_small(w):
     """[Cout<=16,Cin,KH,KW] -> [KH*KW, Cin, 16]."""
     co, ci, kh, kw = w.shape
@@ -237,6 +254,8 @@ def wino_implicit_supported(H, W, cin, dil=1):
 
 
 def conv_wino_implicit(x, wf, cout, dil=1, scale=None, shift=None, res=None, act=ACT_NONE, out=None, gn_eps=None, gn_split=1):
+    # wf: fp32 fragments (pack_wino_fragments: exact-fp32 MFMA, bit-identical to conv_wino) or bf16x3 fragments
+    # (pack_wino_fragments_bf16x3: six bf16 MFMAs per multiply, fp32-rounding-class error, 2.67x less matrix time)
     """3x3 / stride 1 / pad = dil convolution via Winograd F(2x2,3x3) WITHOUT the transformed-input tensor in HBM (the raw patches are
     transformed in LDS, once per workgroup and 16-channel slab).  wf = pack_wino_fragments(pack_wino(w)).  Same bits as conv_wino;
     with gn_eps returns (y, stats) (gn_split: statistics laid out per channel group, see conv_wino)."""
@@ -251,10 +270,13 @@ def conv_wino_implicit(x, wf, cout, dil=1, scale=None, shift=None, res=None, act
     if gn_eps is not None:
         part = torch.empty((B, lib().lm_winograd_gn_chunks(H, W, dil), cout, 2), device=x.device, dtype=torch.float64)
     tiles = lib().lm_conv3x3_winograd_workspace_bytes(B, H, W, cin, dil) // (64 * cin)
-    _hooked(f'wino_implicit {cin}->{cout} k3x3 d{dil} @{H}x{W} B{B}', 2.0 * B * H * W * cout * cin * 9,
-            lambda: check(lib().lm_conv3x3_winograd_implicit_f32(_stream(), _ptr(x), ldx, _ptr(wf), cop, _ptr(scale), _ptr(shift), _ptr(r), ldr,
-                                                                 _ptr(y), ldy, B, H, W, cin, cout, dil, act, _ptr(part))),
-            2.0 * 16 * tiles * cin * cout)
+    split = wf.dtype == torch.bfloat16
+    fn = lib().lm_conv3x3_winograd_implicit_bf16x3 if split else lib().lm_conv3x3_winograd_implicit_f32
+    # executed FLOPs: the Winograd-domain products; the bf16x3 kernel issues six bf16 MFMA products per fp32 product
+    _hooked(f'{"wino_bf16x3" if split else "wino_implicit"} {cin}->{cout} k3x3 d{dil} @{H}x{W} B{B}', 2.0 * B * H * W * cout * cin * 9,
+            lambda: check(fn(_stream(), _ptr(x), ldx, _ptr(wf), cop, _ptr(scale), _ptr(shift), _ptr(r), ldr,
+                             _ptr(y), ldy, B, H, W, cin, cout, dil, act, _ptr(part))),
+            2.0 * 16 * tiles * cin * cout * (6 if split else 1))
     if gn_eps is None:
         return y
     if gn_split > 1:

@@ -34,6 +34,14 @@ FUSE_UP_WINO = os.environ.get('LANEMAP_FUSE_UP_WINO', '1') != '0'    # s4: GN + 
 # (also pays on the 64-channel layers, where the materialising path lost to the direct kernel).  LANEMAP_WINO_IMPLICIT=0 switches back.
 WINO_IMPLICIT = os.environ.get('LANEMAP_WINO_IMPLICIT', '1') != '0'
 WINO_IMPLICIT_MIN_CIN = int(os.environ.get('LANEMAP_WINO_IMPLICIT_MIN_CIN', '64'))
+# Opt-in: the same kernel with its GEMM on the bf16 matrix cores through exact 3-way operand splits (6 bf16 MFMAs per fp32 product;
+# fp32-rounding-class error, profiles/r2_split_precision_study.txt).  Off by default: today it is bound by the B-fragment loads, not by the
+# matrix pipe (+8 % on the kernel), and its results are not bit-identical to the fp32 kernels.
+WINO_BF16X3 = os.environ.get('LANEMAP_WINO_BF16X3', '0') != '0'
+
+
+def _frag(wu):
+    return ops.pack_wino_fragments_bf16x3(wu) if WINO_BF16X3 else ops.pack_wino_fragments(wu)
 
 
 class _ResBlock(nn.Module):
@@ -140,7 +148,7 @@ class FPNEncoder(PackedModule):
                         if conv.in_channels >= WINO_MIN_CIN:
                             u = P[k + q] = ops.pack_wino(conv.weight)
                         if WINO_IMPLICIT and conv.in_channels >= WINO_IMPLICIT_MIN_CIN and conv.in_channels % 32 == 0:
-                            P[k + q + 'f'] = ops.pack_wino_fragments(u if u is not None else ops.pack_wino(conv.weight))
+                            P[k + q + 'f'] = _frag(u if u is not None else ops.pack_wino(conv.weight))
                 if blk.downsample is not None:
                     P[k + '.wd'] = ops.pack_mfma(blk.downsample[0].weight)
                     P[k + '.sd'], P[k + '.bd'] = ops.fold_bn(blk.downsample[1])
@@ -152,7 +160,7 @@ class FPNEncoder(PackedModule):
             if USE_WINOGRAD and m.kernel_size == (3, 3) and m.in_channels >= WINO_MIN_CIN:
                 P[name + '.wu'] = ops.pack_wino(m.weight)
                 if WINO_IMPLICIT:
-                    P[name + '.wuf'] = ops.pack_wino_fragments(P[name + '.wu'])
+                    P[name + '.wuf'] = _frag(P[name + '.wu'])
         # the two branches convolve p2 and p3 with different weights: one GEMM with the output channels concatenated reads V once
         # per 4 N tiles instead of per 2 (same values per channel: an output column does not depend on its neighbours)
         a, b2 = self.semantic_branch, self.semantic_branch2
@@ -161,13 +169,13 @@ class FPNEncoder(PackedModule):
             P['semantic_branch_ab.wu'] = ops.pack_wino(torch.cat([a.weight, b2.weight], dim=0))
             P['semantic_branch_ab.b'] = torch.cat([a.bias, b2.bias]).float().contiguous()
             if WINO_IMPLICIT:
-                P['semantic_branch_ab.wuf'] = ops.pack_wino_fragments(P['semantic_branch_ab.wu'])
+                P['semantic_branch_ab.wuf'] = _frag(P['semantic_branch_ab.wu'])
             if ('conv2.wu' in P and 'conv3.wu' in P and self.conv2.out_channels == self.conv3.out_channels
                     and self.gn12.eps == self.gn22.eps):           # likewise conv2 / conv3 on p4
                 P['conv23.wu'] = ops.pack_wino(torch.cat([self.conv2.weight, self.conv3.weight], dim=0))
                 P['conv23.b'] = torch.cat([self.conv2.bias, self.conv3.bias]).float().contiguous()
                 if WINO_IMPLICIT:
-                    P['conv23.wuf'] = ops.pack_wino_fragments(P['conv23.wu'])
+                    P['conv23.wuf'] = _frag(P['conv23.wu'])
         if self.out is not None:
             P['out.w'] = ops.pack_mfma(self.out.weight)
         for name in ('feature_layer', 'output_layer_binary_seg', 'output_layer_endp'):

@@ -1161,6 +1161,32 @@ def test_conv_winograd_implicit_bit_identical(dev, B, cin, cout, H, W, dil):
         assert torch.equal(st, st2)                          # deterministic
 
 
+@pytest.mark.parametrize('B,cin,cout,H,W,dil', [(2, 128, 128, 48, 44, 1), (1, 256, 200, 43, 61, 1), (1, 160, 256, 85, 87, 2), (2, 256, 512, 144, 144, 1)])
+def test_conv_winograd_bf16x3_vs_fp64(dev, B, cin, cout, H, W, dil):
+    """Opt-in split-precision kernel (lm_conv3x3_winograd_implicit_bf16x3: operands split exactly into three bf16 pieces, six bf16 MFMA
+    products per multiply, fp32 accumulation): within 1e-4 of the tensor scale of the fp64 convolution - the tolerance the fp32 kernels
+    are held to - and within 3e-5 of the fp32 Winograd kernel; deterministic."""
+    from lanemapping_amd import ops
+    g = torch.Generator().manual_seed(B * 1000 + cin + H + dil)
+    x = torch.randn((B, cin, H, W), generator=g)
+    w = torch.randn((cout, cin, 3, 3), generator=g) / (cin * 9) ** 0.5
+    scale, shift = torch.rand(cout, generator=g) + 0.5, torch.randn(cout, generator=g)
+    res = torch.randn((B, cout, H, W), generator=g)
+    want = F.relu(F.conv2d(x.double(), w.double(), None, 1, dil, dil) * scale.double().view(1, -1, 1, 1) + shift.double().view(1, -1, 1, 1)
+                  + res.double()).float()
+    xd = x.to(dev).permute(0, 2, 3, 1).contiguous().permute(0, 3, 1, 2)
+    rd = res.to(dev).permute(0, 2, 3, 1).contiguous().permute(0, 3, 1, 2)
+    wu = ops.pack_wino(w.to(dev))
+    w3 = ops.pack_wino_fragments_bf16x3(wu)
+    y = ops.conv_wino_implicit(xd, w3, cout, dil, scale=scale.to(dev), shift=shift.to(dev), res=rd, act=ops.ACT_RELU)
+    e64 = _close(y, want, 1e-4, 'bf16x3 vs fp64')
+    y32 = ops.conv_wino(xd, wu, cout, dil, scale=scale.to(dev), shift=shift.to(dev), res=rd, act=ops.ACT_RELU)
+    e32 = _close(y, y32, 3e-5, 'bf16x3 vs fp32 winograd')
+    e32_64 = float((y32.cpu() - want).abs().max())
+    print(f'bf16x3 {cin}->{cout}: max err vs fp64 {e64:.2e} (fp32 Winograd kernel: {e32_64:.2e}), vs fp32 kernel {e32:.2e}')
+    assert torch.equal(y, ops.conv_wino_implicit(xd, w3, cout, dil, scale=scale.to(dev), shift=shift.to(dev), res=rd, act=ops.ACT_RELU))
+
+
 @pytest.mark.parametrize('seed', [3001, 3002])
 def test_full_tiles_other_seeds_vs_oracle(dev, net, synth_sd, seed):
     """Full 1152^2 tiles the goldens do not cover: raw outputs within 1e-4 of the tensor scale, and every integer decision

@@ -18,6 +18,7 @@ for cin, cout, dil, hw in SHAPES:
     res = ops.new_act(B, cout, hw, hw, dev).normal_()
     wp, wu = ops.pack_mfma(w), ops.pack_wino(w)
     wf = ops.pack_wino_fragments(wu)
+    wf3 = ops.pack_wino_fragments_bf16x3(wu)
     imp = ops.wino_implicit_supported(hw, hw, cin, dil)
     yd = ops.conv_mfma(x, wp, cout, 3, 3, 1, dil, dil, shift=shift, res=res, act=ops.ACT_RELU)
     yw = ops.conv_wino(x, wu, cout, dil, shift=shift, res=res, act=ops.ACT_RELU)
@@ -30,6 +31,9 @@ for cin, cout, dil, hw in SHAPES:
         yi = ops.conv_wino_implicit(x, wf, cout, dil, shift=shift, res=res, act=ops.ACT_RELU)
         same = bool(torch.equal(yi, yw))
         cases.append(('implicit', lambda: ops.conv_wino_implicit(x, wf, cout, dil, shift=shift, out=yi)))
+        ys = ops.conv_wino_implicit(x, wf3, cout, dil, shift=shift, res=res, act=ops.ACT_RELU)
+        err3 = float((ys - yw).abs().max())
+        cases.append(('bf16x3', lambda: ops.conv_wino_implicit(x, wf3, cout, dil, shift=shift, out=ys)))
     for name, fn in cases:
         for _ in range(2):
             fn()
@@ -45,4 +49,4 @@ for cin, cout, dil, hw in SHAPES:
     print(f'{cin:4d}->{cout:4d} d{dil} @{hw}: max|diff| {err:.2e}  direct {out["direct"]:.3f} ms ({fl / out["direct"] / 1e9:6.1f} TF)  '
           f'wino {out["wino"]:.3f} ms ({fl / out["wino"] / 1e9:6.1f} TF-equivalent)  x{out["direct"] / out["wino"]:.2f}'
           + (f'  implicit {out["implicit"]:.3f} ms ({fl / out["implicit"] / 1e9:6.1f} TF-eq, {fl * 16 / 36 / out["implicit"] / 1e9:6.1f} executed)  '
-             f'bit-identical to wino: {same}' if imp else ''))
+             f'bit-identical to wino: {same}  |  bf16x3 {out["bf16x3"]:.3f} ms ({fl / out["bf16x3"] / 1e9:6.1f} TF-eq) max|diff| vs fp32 wino {err3:.2e}' if imp else ''))
