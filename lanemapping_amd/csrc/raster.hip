@@ -19,15 +19,16 @@
 // Kernel design (HBM-bound; points arrive in acquisition order, i.e. spatially unsorted, so a workgroup cannot
 // own a pixel region directly; one device-scope atomicMax per point (v0) ran at 0.45 TB/s):
 //   pass 1  partition: every workgroup streams 8192 points with coalesced 16-byte non-temporal loads (8 in flight per
-//           lane), turns each into a 4-byte record {pixel-in-band:16 | I:8 | G:8}, counting-sorts the records by 16-row
-//           band in LDS (rank = LDS atomic add on 8x replicated counters) and writes each band's run, padded to 16 bytes,
-//           with aligned dwordx4 stores into its own static slot [tile][band][workgroup][8192] plus a count.
-//           No global atomics, no memset, no inter-workgroup communication.
-//   pass 2  one 1024-thread workgroup per (tile, band): the band's 16 x W u32 image lives in LDS (73.7 KB); the band's
-//           runs are read 16 lanes per run and applied with LDS atomic max, then the band is written once as fp32 CHW
-//           (+ u8 HWC).
-// HBM traffic per tile = 16 N (points) + 4 N (records out) + 4 N (records in) + 3 H W 4 = 1.4x the algorithmic bytes
-// (16 N + 3 H W 4): the two-pass ceiling is ~0.79 * 8 TB/s / 1.4 = 56 % of peak.
+//           lane), turns each into a 4-byte record {pixel-in-band:16 | I:8 | G:8}, counting-sorts the records by band (16 or 12
+//           rows, band_rows_for) in LDS (rank = LDS atomic add on 8x replicated counters) and writes each band's run, padded to 16
+//           bytes, with aligned dwordx4 stores into its own static slot [tile][band][workgroup][8192] plus one contiguous row of
+//           counts [tile][workgroup][band].  No global atomics, no memset, no inter-workgroup communication.
+//   pass 2  one 1024-thread workgroup per (tile, band): the band's rows x W u32 image lives in LDS; the runs are read 8 at a time
+//           per 16-lane group (all counts, then all first quads: two memory round trips) and applied with LDS atomic max, then the
+//           band is written once as u8 HWC (4 pixels = 3 packed dwords per thread) and / or fp32 CHW.
+// HBM traffic per tile (PMC, N = 4,194,304, u8 output) = 16 N (points) + 4.2 N (records out) + 5.0 N (records + counts in) + H W 3
+// = 110 MB = 1.32x the algorithmic bytes (16 N + 3 H W 4): at the 6.3 TB/s of a pure copy that alone is 17.5 us = 0.59 of 8 TB/s,
+// the ceiling of any two-pass scheme; measured 23-25 us = 0.42-0.45 (DESIGN.md §3.2 has the counter-backed breakdown).
 #include "common.h"
 
 #include <cmath>

@@ -404,6 +404,40 @@ def test_torch_custom_ops_on_device(dev, net):
         fpn(tiles.cpu())                                       # no CPU kernel behind the op: refused, never a fallback
 
 
+@pytest.mark.parametrize('case', ['constant', 'saturated', 'plateau', 'two_levels'])
+def test_endp_topk_tied_scores(dev, case):
+    """Tie-safe top-K: flat or saturated endpoint maps put far more than 4096 pixels on the threshold score; the reference's
+    argsort never fails there, and the build's rule is "ties -> lower flat index".  lm_endp_topk returns exactly the K best under
+    (score descending, index ascending), status 0, and the pipeline clusters them instead of raising."""
+    from lanemapping_amd import ops, hostpost
+    H = W = 256
+    clip, K = 20, 512
+    g = torch.Generator().manual_seed(5)
+    if case == 'constant':
+        x = torch.full((2, 1, H, W), -1.25)
+    elif case == 'saturated':
+        x = torch.full((2, 1, H, W), 30.0)                              # sigmoid == 1.0f everywhere
+        x[1, 0, 100:140, 60:90] = -3.0
+    elif case == 'plateau':
+        x = torch.randn((2, 1, H, W), generator=g) - 4.0
+        x[:, 0, 50:150, 30:200] = 2.5                                   # 17,000 tied pixels above everything else
+    else:
+        x = torch.full((2, 1, H, W), 0.5)
+        x[0, 0, 40:44, 40:140] = 3.0                                    # 400 distinct-level pixels + ties at the lower level
+        x[1, 0, 30:60, 30:60] = 3.0                                     # 900 > K
+    idx, score, status = ops.endp_topk(x.to(dev), K=K, clip=clip)
+    assert int(status.max()) == 0
+    Hc, Wc = H - 2 * clip, W - 2 * clip
+    for b in range(2):
+        s = torch.sigmoid(x[b, 0, clip:H - clip, clip:W - clip].to(dev)).cpu().numpy().reshape(-1)      # the device's own fp32 sigmoid
+        want = np.lexsort((np.arange(s.size), -s.astype(np.float64)))[:K]
+        got = idx[b].cpu().numpy()
+        assert np.array_equal(np.sort(got), np.sort(want)), f'{case}: wrong candidate set for tile {b}'
+        assert np.array_equal(got, want), f'{case}: order (score desc, index asc)'
+        pts, k_used = hostpost.cluster_endpoints(got, crop_w=Wc, clip=clip, k0=240, k_max=500)
+        assert len(pts) >= 1 and k_used >= 240
+
+
 def test_runner_png_tiles_to_json(dev, net, tmp_path):
     """test_gpu_0.py-style entry: PNG tiles on disk -> per-tile JSON, identical to driving the pipeline directly."""
     import json
