@@ -79,7 +79,7 @@ int lm_conv3x3_winograd_implicit_f32(void* stream, const float* x, int ldx, cons
  * U) is split EXACTLY into three bf16 pieces and six of the nine piece products are accumulated in fp32 - the error class of an fp32
  * rounding (profiles/r2_split_precision_study.txt), NOT bit-identical to the fp32 kernels; 2.67x less matrix time.
  * wu_frag3: U split and repacked per wave fragment, [16][Cin/16][CoutP/32][3 pieces][64 lanes][8 bf16]:
- *   piece k of U[xi][nt*32 + (lane & 31)][cs*16 + (lane >> 5)*8 + e], e = 0..7. */
+ *   piece k of U[xi][nt*32 + (lane & 31)][cs*16 + 4*(lane >> 5) + (e & 3) + 8*(e >> 2)], e = 0..7. */
 int lm_conv3x3_winograd_implicit_bf16x3(void* stream, const float* x, int ldx, const void* wu_frag3, int CoutP, const float* scale,
                                         const float* shift, const float* res, int ldr, float* y, int ldy, int B, int H, int W,
                                         int Cin, int Cout, int dil, int act, double* gn_partial);

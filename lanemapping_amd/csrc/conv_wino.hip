@@ -580,6 +580,14 @@ constexpr int ILPW = 9;                          // global_load_lds instructions
 constexpr int IRAW = ILPW * 4 * 256;             // floats of the raw buffer (36,864 B; the last 32 cells are never read)
 constexpr int IVBUF = 16 * IBM * IKS;            // floats of the V slab (65,536 B)
 static_assert(ILPW * 4 * 16 >= ICELLS && INCOL % 8 == 0, "patch loads cover the slab");
+// WIDE geometry (Cout > 64): one workgroup = 32 tiles x 128 output channels (the four waves side by side in N) and 32-channel slabs.
+// The transform of a slab (same work per thread: one tile x 4 channels) now feeds twice the matrix work: in the 64 x 64 geometry the
+// transform phase was 1,900 of a slab's 10,700 cycles (in-kernel s_memtime phases, tools/bench_wino_imp.py on an LM_IPROF build).
+// Same LDS budget: cells of 32 channels (128 B), 72 column slots, V[xi][32 tiles][32 ch].
+constexpr int WBM = 32, WBN = 128, WKS = 32;
+constexpr int WNCOL = 2 * WBM + 2 * INSEG;       // 72 column slots
+constexpr int WROW = WNCOL * WKS;                // floats per patch row
+static_assert(4 * WNCOL * WKS == IRAW && 16 * WBM * WKS == IVBUF && WBM * WKS == IBM * IKS && WNCOL % 8 == 0, "wide geometry fills the same buffers");
 
 __device__ __attribute__((aligned(16))) float g_wino_zeros[1024 + 32];   // zero source for padding cells, any channel slab (Cin <= 1024)
 
@@ -605,8 +613,9 @@ __device__ __forceinline__ void bwait(f32x4 (&b)[2]) {
     asm volatile("s_waitcnt vmcnt(%2)" : "+v"(b[0]), "+v"(b[1]) : "n"(N) : "memory");
 }
 
-// ---- split-precision variant (SPLIT = true): the GEMM runs on the bf16 matrix cores with fp32 operands split into three bf16
-// pieces each, v = v1 + v2 + v3 EXACTLY (truncation split with bit masks: 8 + 8 + 8 significant bits), and six of the nine piece
+// ---- split-precision variant (SPLIT = true): same kernel, same fp32 V slab in LDS; the GEMM runs on the bf16 matrix cores with fp32
+// operands split into three bf16 pieces each, v = v1 + v2 + v3 EXACTLY (truncation split with bit masks: 8 + 8 + 8 significant bits;
+// A fragments in registers when they are read, U at weight-packing time), and six of the nine piece
 // products, v1u1 + v1u2 + v2u1 + v1u3 + v2u2 + v3u1 (smallest first), accumulated in the fp32 accumulators: relative error of a product
 // <= 2^-23, the class of an fp32 rounding (profiles/r2_split_precision_study.txt: max error vs fp64 1.2e-6 on a 256-channel layer
 // against 3.3e-6 for the fp32 Winograd, 0 decision flips outside the reference margin on the G10 tile).  Six 32x32x16 bf16 MFMAs of
@@ -626,86 +635,98 @@ __device__ __forceinline__ void bwait3(f32x4 (&b)[3]) {
     asm volatile("s_waitcnt vmcnt(%3)" : "+v"(b[0]), "+v"(b[1]), "+v"(b[2]) : "n"(N) : "memory");
 }
 
-// three bf16 pieces of 4 floats, packed 4 x bf16 = 8 bytes per piece (piece 0 = the leading 8 bits)
-__device__ __forceinline__ void split3_pack(const f32x4 v, u32x2v (&piece)[3]) {
-    f32x4 r = v;
+// Three bf16 pieces of the 8 fp32 values of an A fragment (a0 = channels 4g..4g+3, a1 = channels 8+4g..8+4g+3 of the slab for lane
+// half g), split by truncation in registers: v & 0xFFFF0000 is the leading bf16 piece AS a float, v - piece is exact, twice; a piece
+// pair is packed with one v_perm_b32 (the high halves of two registers).  4 VALU per value + 12 packs = 44 VALU per xi step; the bf16
+// matrix cores do not share the vector ALUs, so this runs under the six MFMAs of the step.
+__device__ __forceinline__ unsigned pack_hi(float lo, float hi) {
+    return __builtin_amdgcn_perm(__float_as_uint(hi), __float_as_uint(lo), 0x07060302u);      // {hi[31:16], lo[31:16]}
+}
+__device__ __forceinline__ void split3_frag(const f32x4 a0, const f32x4 a1, f32x4 (&piece)[3]) {
+    float r[8] = {a0[0], a0[1], a0[2], a0[3], a1[0], a1[1], a1[2], a1[3]};
 #pragma unroll
     for (int k = 0; k < 3; ++k) {
-        unsigned top[4];
+        u32x4v pk;
 #pragma unroll
-        for (int e = 0; e < 4; ++e) top[e] = __float_as_uint(r[e]) & 0xFFFF0000u;      // sign, exponent, 7 mantissa bits: a bf16 value
-        piece[k][0] = (top[0] >> 16) | top[1];
-        piece[k][1] = (top[2] >> 16) | top[3];
+        for (int e = 0; e < 4; ++e) pk[e] = pack_hi(r[2 * e], r[2 * e + 1]);
+        piece[k] = __builtin_bit_cast(f32x4, pk);
         if (k < 2) {
 #pragma unroll
-            for (int e = 0; e < 4; ++e) r[e] = r[e] - __uint_as_float(top[e]);           // exact
+            for (int e = 0; e < 8; ++e) r[e] = r[e] - __uint_as_float(__float_as_uint(r[e]) & 0xFFFF0000u);      // exact
         }
     }
 }
 
-// TRANSFORM phase (split): V piece planes [3][xi][tile][16 ch bf16] (rows of 32 bytes, 16-byte halves XOR-swizzled by (tile >> 3) & 1)
-constexpr int IVPLANE = 16 * IBM * IKS / 2;        // floats (= 4-byte units) per bf16 plane: 32 KB
-__device__ __forceinline__ void wino_slab_transform_split(const float* raw, float* V, const int (&roff)[4], int voff8) {
-    f32x4 r[4][4];
-#pragma unroll
-    for (int c = 0; c < 4; ++c) {
-        const f32x4 d0 = *reinterpret_cast<const f32x4*>(raw + roff[c]);
-        const f32x4 d1 = *reinterpret_cast<const f32x4*>(raw + IROW + roff[c]);
-        const f32x4 d2 = *reinterpret_cast<const f32x4*>(raw + 2 * IROW + roff[c]);
-        const f32x4 d3 = *reinterpret_cast<const f32x4*>(raw + 3 * IROW + roff[c]);
-        r[0][c] = d0 - d2;
-        r[1][c] = d1 + d2;
-        r[2][c] = d2 - d1;
-        r[3][c] = d1 - d3;
-    }
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const f32x4 v[4] = {r[i][0] - r[i][2], r[i][1] + r[i][2], r[i][2] - r[i][1], r[i][1] - r[i][3]};
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            u32x2v pc[3];
-            split3_pack(v[j], pc);
-            float* o = V + (4 * i + j) * (IBM * IKS / 2) + voff8;        // xi rows of 8 floats-worth (32 bytes)
-#pragma unroll
-            for (int k = 0; k < 3; ++k) *reinterpret_cast<u32x2v*>(o + k * IVPLANE) = pc[k];
-        }
-    }
-}
-
-// One xi step of the split MFMA phase: three 16-byte A fragments (piece planes), three B fragments, six bf16 MFMAs
-template <int XI, int G, int NWAIT>
-__device__ __forceinline__ void wino_imp_step_split(f32x16& acc, f32x4 (&bq)[8][3], unsigned bvoff, const float* bpre_base, const float* V,
-                                                    int aoff, f32x4 (&a_cur)[3], f32x4 (&a_nxt)[3],
-                                                    const float* const (&gsrc)[ILPW], long goff, float* rawbuf, int wave, int& gnext) {
+// One PAIR of xi steps of the split MFMA phase: the fp32 A fragments of the fp32 kernel (same V slab in LDS) split in registers, three
+// B fragments per xi (U split at pack time), six bf16 MFMAs per xi, smallest products first.  Two xi are interleaved because a
+// 32x32x16 bf16 MFMA issues every 32 cycles but its accumulator is only ready after ~64: one dependent chain ran the matrix pipe at
+// half rate (measured: 10 k cycles per slab with 3 k of MFMA work and neither B loads nor the split on the critical path).
+// B runs 6 xi (3 pair steps) ahead in the ring of 8 sets; NWAIT = 18 + the patch loads of the last 4 pair steps.
+template <int P, int G, int NWAIT>
+__device__ __forceinline__ void wino_imp_pair_split(f32x16& accx, f32x16& accy, f32x4 (&bq)[8][3], unsigned bvoff, const float* bpre_x,
+                                                    const float* bpre_y, const float* V, const int (&aoff)[2], f32x4 (&a_cur)[4],
+                                                    f32x4 (&a_nxt)[4], const float* const (&gsrc)[ILPW], long goff, float* rawbuf, int wave,
+                                                    int& gnext) {
     typedef __attribute__((address_space(1))) const void gptr_t;
     typedef __attribute__((address_space(3))) void lptr_t;
-    bload3(bq[(XI + 7) & 7], bvoff, bpre_base);
+    constexpr int XI = 2 * P;
+#ifndef LM_IABL_NOB
+    bload3(bq[(XI + 6) & 7], bvoff, bpre_x);
+    bload3(bq[(XI + 7) & 7], bvoff, bpre_y);
+#endif
+#ifndef LM_IABL_NOGLDS
 #pragma unroll
     for (int g = 0; g < G; ++g) {
         const int s_ = gnext + g;
         __builtin_amdgcn_global_load_lds((gptr_t*)(gsrc[s_] + goff), (lptr_t*)(rawbuf + (s_ * 4 + wave) * 256), 16, 0, 0);
     }
+#endif
     gnext += G;
-    f32x4 (&b)[3] = bq[XI & 7];
-    bwait3<NWAIT>(b);
+    f32x4 (&bx)[3] = bq[XI & 7];
+    f32x4 (&by)[3] = bq[(XI + 1) & 7];
+    f32x4 px[3], py[3];
+#ifdef LM_IABL_NOXF
+    px[0] = a_cur[0]; px[1] = a_cur[1]; px[2] = a_cur[0];
+    py[0] = a_cur[2]; py[1] = a_cur[3]; py[2] = a_cur[2];
+#else
+    split3_frag(a_cur[0], a_cur[1], px);
+    split3_frag(a_cur[2], a_cur[3], py);
+#endif
+#if !defined(LM_IABL_NOB) && !defined(LM_IABL_NOGLDS)
+    bwait3<NWAIT>(bx);
+    bwait3<NWAIT>(by);
+#else
+    bwait3<0>(bx);
+    bwait3<0>(by);
+#endif
 #define LM_BF(x) __builtin_bit_cast(bf16x8, x)
-    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(LM_BF(a_cur[2]), LM_BF(b[0]), acc, 0, 0, 0);       // v3 u1
+    accx = __builtin_amdgcn_mfma_f32_32x32x16_bf16(LM_BF(px[2]), LM_BF(bx[0]), accx, 0, 0, 0);       // v3 u1
+    accy = __builtin_amdgcn_mfma_f32_32x32x16_bf16(LM_BF(py[2]), LM_BF(by[0]), accy, 0, 0, 0);
     __builtin_amdgcn_sched_barrier(0);
-    if (XI < 15) {
+    if (P < 7) {
 #pragma unroll
-        for (int k = 0; k < 3; ++k) a_nxt[k] = *reinterpret_cast<const f32x4*>(V + k * IVPLANE + (XI + 1) * (IBM * IKS / 2) + aoff);
+        for (int k = 0; k < 2; ++k) {
+            a_nxt[k] = *reinterpret_cast<const f32x4*>(V + (XI + 2) * (IBM * IKS) + aoff[k]);
+            a_nxt[2 + k] = *reinterpret_cast<const f32x4*>(V + (XI + 3) * (IBM * IKS) + aoff[k]);
+        }
     }
     __builtin_amdgcn_sched_barrier(0);
-    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(LM_BF(a_cur[1]), LM_BF(b[1]), acc, 0, 0, 0);       // v2 u2
-    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(LM_BF(a_cur[0]), LM_BF(b[2]), acc, 0, 0, 0);       // v1 u3
-    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(LM_BF(a_cur[1]), LM_BF(b[0]), acc, 0, 0, 0);       // v2 u1
-    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(LM_BF(a_cur[0]), LM_BF(b[1]), acc, 0, 0, 0);       // v1 u2
-    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(LM_BF(a_cur[0]), LM_BF(b[0]), acc, 0, 0, 0);       // v1 u1
+    accx = __builtin_amdgcn_mfma_f32_32x32x16_bf16(LM_BF(px[1]), LM_BF(bx[1]), accx, 0, 0, 0);       // v2 u2
+    accy = __builtin_amdgcn_mfma_f32_32x32x16_bf16(LM_BF(py[1]), LM_BF(by[1]), accy, 0, 0, 0);
+    accx = __builtin_amdgcn_mfma_f32_32x32x16_bf16(LM_BF(px[0]), LM_BF(bx[2]), accx, 0, 0, 0);       // v1 u3
+    accy = __builtin_amdgcn_mfma_f32_32x32x16_bf16(LM_BF(py[0]), LM_BF(by[2]), accy, 0, 0, 0);
+    accx = __builtin_amdgcn_mfma_f32_32x32x16_bf16(LM_BF(px[1]), LM_BF(bx[0]), accx, 0, 0, 0);       // v2 u1
+    accy = __builtin_amdgcn_mfma_f32_32x32x16_bf16(LM_BF(py[1]), LM_BF(by[0]), accy, 0, 0, 0);
+    accx = __builtin_amdgcn_mfma_f32_32x32x16_bf16(LM_BF(px[0]), LM_BF(bx[1]), accx, 0, 0, 0);       // v1 u2
+    accy = __builtin_amdgcn_mfma_f32_32x32x16_bf16(LM_BF(py[0]), LM_BF(by[1]), accy, 0, 0, 0);
+    accx = __builtin_amdgcn_mfma_f32_32x32x16_bf16(LM_BF(px[0]), LM_BF(bx[0]), accx, 0, 0, 0);       // v1 u1
+    accy = __builtin_amdgcn_mfma_f32_32x32x16_bf16(LM_BF(py[0]), LM_BF(by[0]), accy, 0, 0, 0);
 #undef LM_BF
     __builtin_amdgcn_sched_barrier(0);
 }
 
 // TRANSFORM phase, one thread = (tile tl, channel quad qd): V[xi][tl][4 qd ..] = (B^T d B)[xi] with the arithmetic of transform_store
+template <int IROW>
 __device__ __forceinline__ void wino_slab_transform(const float* raw, float* V, const int (&roff)[4], int voff) {
     f32x4 r[4][4];
 #pragma unroll
@@ -738,14 +759,14 @@ __device__ __forceinline__ void wino_slab_transform(const float* raw, float* V, 
 // step's first MFMA (the compiler waits with lgkmcnt(0) at the first use of LDS data whenever LDS-DMA is in flight, so the only
 // reads outstanding at a wait must be the ones it needs).
 constexpr int BD = 7;
-template <int XI, int G, int NWAIT>
-__device__ __forceinline__ void wino_imp_step(f32x16& acc, f32x4 (&bq)[8][2], unsigned bvoff, const float* bpre_base, const float* V,
-                                              const int (&aoff)[2], f32x4 (&a_cur)[2], f32x4 (&a_nxt)[2],
+template <int SLOT, int G, int NWAIT, bool NEXT>
+__device__ __forceinline__ void wino_imp_step(f32x16& acc, f32x4 (&bq)[8][2], unsigned bvoff, const float* bpre_base, const float* anext0,
+                                              const float* anext1, f32x4 (&a_cur)[2], f32x4 (&a_nxt)[2],
                                               const float* const (&gsrc)[ILPW], long goff, float* rawbuf, int wave, int& gnext) {
     typedef __attribute__((address_space(1))) const void gptr_t;
     typedef __attribute__((address_space(3))) void lptr_t;
 #ifndef LM_IABL_NOB                       // (timing ablations: tools/build_variant.sh)
-    bload2(bq[(XI + BD) & 7], bvoff, bpre_base);
+    bload2(bq[(SLOT + BD) & 7], bvoff, bpre_base);
 #endif
 #ifndef LM_IABL_NOGLDS
 #pragma unroll
@@ -755,7 +776,7 @@ __device__ __forceinline__ void wino_imp_step(f32x16& acc, f32x4 (&bq)[8][2], un
     }
 #endif
     gnext += G;
-    f32x4 (&bcur)[2] = bq[XI & 7];
+    f32x4 (&bcur)[2] = bq[SLOT & 7];
 #if !defined(LM_IABL_NOB) && !defined(LM_IABL_NOGLDS)
     bwait<NWAIT>(bcur);
 #else
@@ -763,9 +784,9 @@ __device__ __forceinline__ void wino_imp_step(f32x16& acc, f32x4 (&bq)[8][2], un
 #endif
     acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a_cur[0][0], bcur[0][0], acc, 0, 0, 0);
     __builtin_amdgcn_sched_barrier(0);
-    if (XI < 15) {
-        a_nxt[0] = *reinterpret_cast<const f32x4*>(V + (XI + 1) * (IBM * IKS) + aoff[0]);
-        a_nxt[1] = *reinterpret_cast<const f32x4*>(V + (XI + 1) * (IBM * IKS) + aoff[1]);
+    if (NEXT) {
+        a_nxt[0] = *reinterpret_cast<const f32x4*>(anext0);
+        a_nxt[1] = *reinterpret_cast<const f32x4*>(anext1);
     }
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
@@ -775,17 +796,43 @@ __device__ __forceinline__ void wino_imp_step(f32x16& acc, f32x4 (&bq)[8][2], un
     __builtin_amdgcn_sched_barrier(0);
 }
 
-template <bool SPLIT>
+#ifdef LM_IPROF                             // (tools/build_variant.sh probe: per-phase shader-clock cycles summed over waves)
+__device__ unsigned long long g_iprof[12];   // prologue, transform, barrier 1, MFMA phase, end-of-slab wait, barrier 2, epilogue, waves
+#define LM_TICK(slot)                                        \
+    {                                                        \
+        const long long t_now = clock64();                   \
+        iprof[slot] += t_now - t_last;                       \
+        t_last = t_now;                                      \
+    }
+#else
+#define LM_TICK(slot)
+#endif
+#ifdef LM_IPROF_EPI                         // (finer epilogue phases: costs registers, perturbs the main loop)
+#define LM_TICKE(slot) LM_TICK(slot)
+#else
+#define LM_TICKE(slot)
+#endif
+
+// MODE 0: fp32, 64 tiles x 64 channels | 1: bf16x3 split, 64 x 64 | 2: fp32, WIDE (32 tiles x 128 channels, 32-channel slabs)
+template <int MODE>
 __global__ __launch_bounds__(256) void wino_implicit_kernel(WinoImpParams p) {
-    extern __shared__ __attribute__((aligned(16))) float smem[];      // raw patch slab [IRAW] | V slab [IVBUF] (SPLIT: three bf16 planes, 3 x 32 KB)
+    constexpr bool SPLIT = MODE == 1, WIDE = MODE == 2;
+    constexpr int BM = WIDE ? WBM : IBM, BN = WIDE ? WBN : IBN, KS = WIDE ? WKS : IKS, NCOL = WIDE ? WNCOL : INCOL;
+    constexpr int CPC = KS / 4;                 // 16-byte chunks per cell (pixel x channel slab)
+    constexpr int CPL = 64 / CPC;               // cells per global_load_lds wave instruction
+#ifdef LM_IPROF
+    long long iprof[11] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    long long t_last = clock64();
+#endif
+    extern __shared__ __attribute__((aligned(16))) float smem[];      // raw patch slab [IRAW] | V slab [IVBUF] 
     float* const rawbuf = smem;
     float* const Vbuf = smem + IRAW;
     typedef __attribute__((address_space(1))) const void gptr_t;
     typedef __attribute__((address_space(3))) void lptr_t;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wm0 = (wave >> 1) * 32, wn0 = (wave & 1) * 32;
-    const int n_tiles = (p.Cout + IBN - 1) / IBN;
+    const int wm0 = WIDE ? 0 : (wave >> 1) * 32, wn0 = WIDE ? wave * 32 : (wave & 1) * 32;
+    const int n_tiles = (p.Cout + BN - 1) / BN;
     // XCD-aware order (workgroups are dealt round-robin to the 8 XCDs): every XCD owns a contiguous range of M blocks and walks it
     // once per N tile, N tile OUTER - at any time the 32 CUs of an XCD stream the SAME 64-channel slice of U (L2 resident)
     unsigned mblk, ntile;
@@ -801,8 +848,8 @@ __global__ __launch_bounds__(256) void wino_implicit_kernel(WinoImpParams p) {
             ntile = r % (unsigned)n_tiles;
         }
     }
-    const long m0 = (long)mblk * IBM;
-    const int n0 = (int)ntile * IBN;
+    const long m0 = (long)mblk * BM;
+    const int n0 = (int)ntile * BN;
     const WinoGeom& g = p.g;
     const int bi = (int)(m0 / g.Tpad);
     const int t0 = (int)(m0 - (long)bi * g.Tpad);
@@ -817,21 +864,21 @@ __global__ __launch_bounds__(256) void wino_implicit_kernel(WinoImpParams p) {
             stx[s_] = tx;
             sty[s_] = rest % g.Ty;
             sph[s_] = rest / g.Ty;
-            const int n = at < IBM ? min(IBM - at, g.Tx - tx) : 0;
+            const int n = at < BM ? min(BM - at, g.Tx - tx) : 0;
             sn[s_] = n;
             at += n;
             t += n;
         }
-        ts[INSEG] = at;            // == IBM (the launcher guarantees <= INSEG runs)
+        ts[INSEG] = at;            // == BM (the launcher guarantees <= INSEG runs)
     }
     // --- per-lane sources of this wave's ILPW patch loads (one pointer each; the channel slab is a uniform offset)
     const float* gsrc[ILPW];
 #pragma unroll
     for (int s_ = 0; s_ < ILPW; ++s_) {
-        const int pos = (s_ * 4 + wave) * 16 + (lane >> 2);            // LDS cell position (16 cells per wave load)
-        const int r = pos / INCOL;
-        const int q = unrot3(pos - r * INCOL);
-        const int ch = lane & 3;
+        const int pos = (s_ * 4 + wave) * CPL + lane / CPC;            // LDS cell position (CPL cells per wave load)
+        const int r = pos / NCOL;
+        const int q = unrot3(pos - r * NCOL);
+        const int ch = lane % CPC;
         int sg = 0;
 #pragma unroll
         for (int k = 1; k < INSEG; ++k) sg += (sn[k] > 0 && q >= 2 * ts[k] + 2 * k) ? 1 : 0;
@@ -848,34 +895,35 @@ __global__ __launch_bounds__(256) void wino_implicit_kernel(WinoImpParams p) {
         const bool ok = r < 4 && lc < 2 * n + 2 && ph < g.dil * g.dil && py >= 0 && px >= 0 && yy < g.H && xx < g.W;
         gsrc[s_] = ok ? p.x + (((long)bi * g.H + yy) * g.W + xx) * p.ldx + ch * 4 : p.zeros + ch * 4;
     }
-    // --- TRANSFORM task of this thread: tile tid / 4, channel quad tid % 4
+    // --- TRANSFORM task of this thread: tile tid / CPC, channel quad tid % CPC.  WIDE: V rows are 8 chunks, XOR-swizzled by (tile >> 1) & 7
+    // (the 8 quads of a tile fill one 128-byte row: conflict-free stores; the 16 rows of an A-fragment read group differ in
+    // (tile & 1, (tile >> 1) & 7): all 64 banks)
     int roff[4], tvoff;
     {
-        const int tl = tid >> 2, qd = tid & 3;
+        const int tl = tid / CPC, qd = tid % CPC;
         int sg = 0;
 #pragma unroll
         for (int k = 1; k < INSEG; ++k) sg += (sn[k] > 0 && tl >= ts[k]) ? 1 : 0;
         const int cb = 2 * tl + 2 * sg;
 #pragma unroll
-        for (int c = 0; c < 4; ++c) roff[c] = (rot3(cb + c) * 4 + qd) * 4;
-        tvoff = (tl * 4 + (qd ^ ((tl >> 2) & 3))) * 4;
-        if (SPLIT) tvoff = tl * 8 + (((qd >> 1) ^ ((tl >> 3) & 1)) * 4) + (qd & 1) * 2;       // floats: row of 32 B, swizzled 16-B half, 8-B quad
+        for (int c = 0; c < 4; ++c) roff[c] = (rot3(cb + c) * CPC + qd) * 4;
+        tvoff = WIDE ? (tl * 8 + (qd ^ ((tl >> 1) & 7))) * 4 : (tl * 4 + (qd ^ ((tl >> 2) & 3))) * 4;
     }
     // --- MFMA-phase A fragment offsets inside V[xi]: row = tile wm0 + frow, chunk 2 kk + fhalf
     const int frow = lane & 31, fhalf = lane >> 5;
-    int aoff[2];
+    int aoff[WIDE ? 4 : 2];                     // WIDE: [2 kh + kk], kh = 16-channel half of the slab
     {
         const int tl = wm0 + frow;
 #pragma unroll
-        for (int kk = 0; kk < 2; ++kk) aoff[kk] = (tl * 4 + ((2 * kk + fhalf) ^ ((tl >> 2) & 3))) * 4;
-        if (SPLIT) aoff[0] = tl * 8 + ((fhalf ^ ((tl >> 3) & 1)) * 4);                          // 16 bytes = channels 8 fhalf .. + 7 of a piece row
+        for (int kk = 0; kk < (WIDE ? 4 : 2); ++kk)
+            aoff[kk] = WIDE ? (tl * 8 + ((2 * kk + fhalf) ^ ((tl >> 1) & 7))) * 4 : (tl * 4 + ((2 * kk + fhalf) ^ ((tl >> 2) & 3))) * 4;
     }
-    const int cslabs = p.C / IKS;
+    const int cslabs = p.C / KS;
     const unsigned bvoff = (unsigned)lane * 16u;
     constexpr int BFRAG = SPLIT ? 768 : 512;                           // floats per (xi, slab, 32-channel tile): 2 x 64 x 16 B | 3 planes x 64 x 16 B
-    const long bstep = (long)p.NT * BFRAG;                             // floats between consecutive slabs of one xi
+    const long bstep = (long)p.NT * BFRAG;                             // floats between consecutive 16-channel slabs of one xi
     const float* const bbase = p.U + (long)((n0 + wn0) >> 5) * BFRAG;  // this wave's 32-channel tile
-    const long bxi = (long)cslabs * bstep;                             // floats between consecutive xi
+    const long bxi = (long)(p.C / IKS) * bstep;                        // floats between consecutive xi
 
     f32x16 acc[16];
 #pragma unroll
@@ -888,50 +936,56 @@ __global__ __launch_bounds__(256) void wino_implicit_kernel(WinoImpParams p) {
     for (int s_ = 0; s_ < ILPW; ++s_)
         __builtin_amdgcn_global_load_lds((gptr_t*)gsrc[s_], (lptr_t*)(rawbuf + (s_ * 4 + wave) * 256), 16, 0, 0);
 #pragma unroll
-    for (int k = 0; k < 7; ++k) bload3(bq3[k], bvoff, bbase + (long)k * bxi);
+    for (int k = 0; k < 6; ++k) bload3(bq3[k], bvoff, bbase + (long)k * bxi);
 #pragma unroll
-    for (int k = 0; k < 7; ++k) bwait3<0>(bq3[k]);
+    for (int k = 0; k < 6; ++k) bwait3<0>(bq3[k]);
     __builtin_amdgcn_s_barrier();
+    LM_TICK(0)
     for (int cs = 0; cs < cslabs; ++cs) {
-        wino_slab_transform_split(rawbuf, Vbuf, roff, tvoff);
+#ifndef LM_IABL_NOTF
+        wino_slab_transform<NCOL * KS>(rawbuf, Vbuf, roff, tvoff);
+#endif
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        LM_TICK(1)
         __builtin_amdgcn_s_barrier();
+        LM_TICK(2)
         const bool more = cs + 1 < cslabs;
-        const long goff = more ? (long)(cs + 1) * IKS : 0;
+        const long goff = more ? (long)(cs + 1) * KS : 0;
         const float* const bs = bbase + (long)cs * bstep;
         const float* const bs_next = bbase + (long)(more ? cs + 1 : 0) * bstep;
         int gnext = 0;
-        f32x4 a0[3], a1[3];
+        f32x4 a0[4], a1[4];
 #pragma unroll
-        for (int k = 0; k < 3; ++k) a0[k] = *reinterpret_cast<const f32x4*>(Vbuf + k * IVPLANE + aoff[0]);
-#define LM_SSTEP(XI, G, NW, AC, AN) \
-        wino_imp_step_split<XI, G, NW>(acc[XI], bq3, bvoff, (XI) + 7 < 16 ? bs + (long)((XI) + 7) * bxi : bs_next + (long)((XI) + 7 - 16) * bxi, \
-                                       Vbuf, aoff[0], AC, AN, gsrc, goff, rawbuf, wave, gnext)
-        // NWAIT = 3 * 7 + patch loads of the last 8 steps (G = 2,2,2,2,1)
-        LM_SSTEP(0, 2, 23, a0, a1);
-        LM_SSTEP(1, 2, 25, a1, a0);
-        LM_SSTEP(2, 2, 27, a0, a1);
-        LM_SSTEP(3, 2, 29, a1, a0);
-        LM_SSTEP(4, 1, 30, a0, a1);
-        LM_SSTEP(5, 0, 30, a1, a0);
-        LM_SSTEP(6, 0, 30, a0, a1);
-        LM_SSTEP(7, 0, 30, a1, a0);
-        LM_SSTEP(8, 0, 28, a0, a1);
-        LM_SSTEP(9, 0, 26, a1, a0);
-        LM_SSTEP(10, 0, 24, a0, a1);
-        LM_SSTEP(11, 0, 22, a1, a0);
-        LM_SSTEP(12, 0, 21, a0, a1);
-        LM_SSTEP(13, 0, 21, a1, a0);
-        LM_SSTEP(14, 0, 21, a0, a1);
-        LM_SSTEP(15, 0, 21, a1, a0);
-#undef LM_SSTEP
-        bwait3<21>(bq3[0]);
+        for (int k = 0; k < 2; ++k) {
+            a0[k] = *reinterpret_cast<const f32x4*>(Vbuf + aoff[k]);
+            a0[2 + k] = *reinterpret_cast<const f32x4*>(Vbuf + (IBM * IKS) + aoff[k]);
+        }
+        // B prefetched by pair step P belongs to xi 2P + 6 and 2P + 7: same slab while < 16, else xi - 16 of the next slab
+#define LM_BPRE(X) ((X) < 16 ? bs + (long)(X) * bxi : bs_next + (long)((X) - 16) * bxi)
+#define LM_SPAIR(P, G, NW, AC, AN) \
+        wino_imp_pair_split<P, G, NW>(acc[2 * (P)], acc[2 * (P) + 1], bq3, bvoff, LM_BPRE(2 * (P) + 6), LM_BPRE(2 * (P) + 7), Vbuf, aoff, AC, AN, \
+                                      gsrc, goff, rawbuf, wave, gnext)
+        // NWAIT = 3 pair steps x 6 B loads + the patch loads of the last 4 pair steps (G = 4, 4, 1)
+        LM_SPAIR(0, 4, 22, a0, a1);
+        LM_SPAIR(1, 4, 26, a1, a0);
+        LM_SPAIR(2, 1, 27, a0, a1);
+        LM_SPAIR(3, 0, 27, a1, a0);
+        LM_SPAIR(4, 0, 23, a0, a1);
+        LM_SPAIR(5, 0, 19, a1, a0);
+        LM_SPAIR(6, 0, 18, a0, a1);
+        LM_SPAIR(7, 0, 18, a1, a0);
+#undef LM_SPAIR
+#undef LM_BPRE
+        LM_TICK(3)
+        bwait3<18>(bq3[0]);
+        LM_TICK(4)
         __builtin_amdgcn_s_barrier();
+        LM_TICK(5)
     }
 #pragma unroll
     for (int k = 0; k < 8; ++k) bwait3<0>(bq3[k]);
 
-    } else {
+    } else if constexpr (!WIDE) {
     f32x4 bq[8][2];
     // prologue: slab 0 of the patch, B of steps 0 .. BD-1 of slab 0
 #pragma unroll
@@ -942,15 +996,20 @@ __global__ __launch_bounds__(256) void wino_implicit_kernel(WinoImpParams p) {
 #pragma unroll
     for (int k = 0; k < BD; ++k) bwait<0>(bq[k]);
     __builtin_amdgcn_s_barrier();
+    LM_TICK(0)
 
     for (int cs = 0; cs < cslabs; ++cs) {
         // TRANSFORM phase: raw slab cs (complete: every wave waited for its loads before the barrier) -> V
-        wino_slab_transform(rawbuf, Vbuf, roff, tvoff);
+#ifndef LM_IABL_NOTF
+        wino_slab_transform<NCOL * KS>(rawbuf, Vbuf, roff, tvoff);
+#endif
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // (a raw barrier: __syncthreads() would also drain the B ring)
+        LM_TICK(1)
         __builtin_amdgcn_s_barrier();          // V complete; the raw buffer is free for the next slab's loads
+        LM_TICK(2)
         const bool more = cs + 1 < cslabs;
         // the last slab has nothing to prefetch: its loads re-read slab 0 of the zero block / tensor into the idle buffer (harmless)
-        const long goff = more ? (long)(cs + 1) * IKS : 0;
+        const long goff = more ? (long)(cs + 1) * KS : 0;
         const float* const bs = bbase + (long)cs * bstep;                                   // (xi 0, this slab)
         const float* const bs_next = bbase + (long)(more ? cs + 1 : 0) * bstep;             // (xi 0, next slab)
         int gnext = 0;
@@ -959,8 +1018,9 @@ __global__ __launch_bounds__(256) void wino_implicit_kernel(WinoImpParams p) {
         a0[1] = *reinterpret_cast<const f32x4*>(Vbuf + aoff[1]);
         // B prefetched by step XI belongs to step XI + BD: same slab while XI + BD < 16, else step XI + BD - 16 of the next slab
 #define LM_WSTEP(XI, G, NW, AC, AN) \
-        wino_imp_step<XI, G, NW>(acc[XI], bq, bvoff, (XI) + BD < 16 ? bs + (long)((XI) + BD) * bxi : bs_next + (long)((XI) + BD - 16) * bxi, \
-                                 Vbuf, aoff, AC, AN, gsrc, goff, rawbuf, wave, gnext)
+        wino_imp_step<XI, G, NW, ((XI) < 15)>(acc[XI], bq, bvoff, (XI) + BD < 16 ? bs + (long)((XI) + BD) * bxi : bs_next + (long)((XI) + BD - 16) * bxi, \
+                                              Vbuf + ((XI) + 1) * (IBM * IKS) + aoff[0], Vbuf + ((XI) + 1) * (IBM * IKS) + aoff[1], AC, AN, gsrc, goff, \
+                                              rawbuf, wave, gnext)
         LM_WSTEP(0, 2, 16, a0, a1);
         LM_WSTEP(1, 2, 18, a1, a0);
         LM_WSTEP(2, 2, 20, a0, a1);
@@ -979,11 +1039,69 @@ __global__ __launch_bounds__(256) void wino_implicit_kernel(WinoImpParams p) {
         LM_WSTEP(15, 0, 14, a1, a0);
 #undef LM_WSTEP
         static_assert(2 * 4 + 1 == ILPW, "patch loads per wave and slab");
+        LM_TICK(3)
         bwait<14>(bq[0]);                      // every patch load of the next slab has landed (only the 7 youngest B sets are in flight)
+        LM_TICK(4)
         __builtin_amdgcn_s_barrier();          // all waves: done reading V, next raw slab complete
+        LM_TICK(5)
     }
     // The last slab's B prefetches (re-reads of valid addresses, never used) are still in flight: they must land before the compiler
     // hands their destination registers to the epilogue - a late return would overwrite whatever lives there by then (pointers).
+#pragma unroll
+    for (int k = 0; k < 8; ++k) bwait<0>(bq[k]);
+
+    } else {
+    // WIDE: a slab is two 16-channel halves; step S = 2 xi + kh (16-channel half kh of xi): the same 8 MFMAs, two A fragments and two
+    // B fragments as a step of the 64 x 64 loop, 32 steps per slab.  B of step S sits at (xi, 16-channel slab 2 cs + kh) of the same
+    // packed U.  The 9 patch loads of the next slab go out one per step in steps 0..8:
+    // NWAIT(S) = 2 BD + |{0..8} intersected with {S-7..S}|.
+    f32x4 bq[8][2];
+#define LM_BADDR(cs_, S) (bbase + (long)(2 * (cs_) + ((S) & 1)) * bstep + (long)((S) >> 1) * bxi)
+#pragma unroll
+    for (int s_ = 0; s_ < ILPW; ++s_)
+        __builtin_amdgcn_global_load_lds((gptr_t*)gsrc[s_], (lptr_t*)(rawbuf + (s_ * 4 + wave) * 256), 16, 0, 0);
+#pragma unroll
+    for (int k = 0; k < BD; ++k) bload2(bq[k], bvoff, LM_BADDR(0, k));
+#pragma unroll
+    for (int k = 0; k < BD; ++k) bwait<0>(bq[k]);
+    __builtin_amdgcn_s_barrier();
+    LM_TICK(0)
+    for (int cs = 0; cs < cslabs; ++cs) {
+#ifndef LM_IABL_NOTF
+        wino_slab_transform<NCOL * KS>(rawbuf, Vbuf, roff, tvoff);
+#endif
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        LM_TICK(1)
+        __builtin_amdgcn_s_barrier();
+        LM_TICK(2)
+        const bool more = cs + 1 < cslabs;
+        const long goff = more ? (long)(cs + 1) * KS : 0;
+        const int cs_next = more ? cs + 1 : 0;
+        int gnext = 0;
+        f32x4 a0[2], a1[2];
+        a0[0] = *reinterpret_cast<const f32x4*>(Vbuf + aoff[0]);
+        a0[1] = *reinterpret_cast<const f32x4*>(Vbuf + aoff[1]);
+#define LM_WSTEP(S, NW, AC, AN) \
+        wino_imp_step<(S) & 7, ((S) < 9 ? 1 : 0), NW, ((S) < 31)>(acc[(S) >> 1], bq, bvoff, \
+            (S) + BD < 32 ? LM_BADDR(cs, (S) + BD) : LM_BADDR(cs_next, (S) + BD - 32), \
+            Vbuf + (((S) + 1) >> 1) * (WBM * WKS) + aoff[2 * (((S) + 1) & 1)], Vbuf + (((S) + 1) >> 1) * (WBM * WKS) + aoff[2 * (((S) + 1) & 1) + 1], \
+            AC, AN, gsrc, goff, rawbuf, wave, gnext)
+        LM_WSTEP(0, 15, a0, a1);  LM_WSTEP(1, 16, a1, a0);  LM_WSTEP(2, 17, a0, a1);  LM_WSTEP(3, 18, a1, a0);
+        LM_WSTEP(4, 19, a0, a1);  LM_WSTEP(5, 20, a1, a0);  LM_WSTEP(6, 21, a0, a1);  LM_WSTEP(7, 22, a1, a0);
+        LM_WSTEP(8, 22, a0, a1);  LM_WSTEP(9, 21, a1, a0);  LM_WSTEP(10, 20, a0, a1); LM_WSTEP(11, 19, a1, a0);
+        LM_WSTEP(12, 18, a0, a1); LM_WSTEP(13, 17, a1, a0); LM_WSTEP(14, 16, a0, a1); LM_WSTEP(15, 15, a1, a0);
+        LM_WSTEP(16, 14, a0, a1); LM_WSTEP(17, 14, a1, a0); LM_WSTEP(18, 14, a0, a1); LM_WSTEP(19, 14, a1, a0);
+        LM_WSTEP(20, 14, a0, a1); LM_WSTEP(21, 14, a1, a0); LM_WSTEP(22, 14, a0, a1); LM_WSTEP(23, 14, a1, a0);
+        LM_WSTEP(24, 14, a0, a1); LM_WSTEP(25, 14, a1, a0); LM_WSTEP(26, 14, a0, a1); LM_WSTEP(27, 14, a1, a0);
+        LM_WSTEP(28, 14, a0, a1); LM_WSTEP(29, 14, a1, a0); LM_WSTEP(30, 14, a0, a1); LM_WSTEP(31, 14, a1, a0);
+#undef LM_WSTEP
+        LM_TICK(3)
+        bwait<14>(bq[0]);
+        LM_TICK(4)
+        __builtin_amdgcn_s_barrier();
+        LM_TICK(5)
+    }
+#undef LM_BADDR
 #pragma unroll
     for (int k = 0; k < 8; ++k) bwait<0>(bq[k]);
 
@@ -1045,6 +1163,7 @@ __global__ __launch_bounds__(256) void wino_implicit_kernel(WinoImpParams p) {
     }
     const int step_a = g.dil * g.W, step_b = g.dil;
     __syncthreads();                                   // every wave is done with the patch buffers
+    LM_TICKE(7)                                        // (epilogue setup)
 #pragma unroll
     for (int a = 0; a < 2; ++a)
 #pragma unroll
@@ -1063,9 +1182,11 @@ __global__ __launch_bounds__(256) void wino_implicit_kernel(WinoImpParams p) {
                 for (int r = 0; r < 16; ++r) o[r] = fmaf(acc[xi][r], c, o[r]);
             }
             __builtin_amdgcn_wave_barrier();
+            LM_TICKE(8)                                // (fold)
 #pragma unroll
             for (int r = 0; r < 16; ++r) stage[((r & 3) + 8 * (r >> 2) + 4 * fhalf) * ELD + frow] = o[r];
             __builtin_amdgcn_wave_barrier();
+            LM_TICKE(9)                                // (transpose writes)
             if (n >= p.Cout) continue;
 #pragma unroll
             for (int pass = 0; pass < NP; ++pass) {
@@ -1103,6 +1224,7 @@ __global__ __launch_bounds__(256) void wino_implicit_kernel(WinoImpParams p) {
                     }
                 }
             }
+            LM_TICKE(10)                               // (stores)
         }
     if (p.gn_part && n < p.Cout) {   // fixed-order reduction over the 8 lanes that share a channel quad, then one writer lane
 #pragma unroll
@@ -1121,12 +1243,31 @@ __global__ __launch_bounds__(256) void wino_implicit_kernel(WinoImpParams p) {
             }
         }
     }
+#ifdef LM_IPROF
+    LM_TICK(6)
+    if (lane == 0) {
+#pragma unroll
+        for (int k = 0; k < 11; ++k) atomicAdd(&g_iprof[k], (unsigned long long)iprof[k]);
+        atomicAdd(&g_iprof[11], 1ull);
+    }
+#endif
 }
 
 // runs of adjacent tiles a 64-tile block can touch: floor((IBM - 2) / Tx) + 2
 bool wino_implicit_ok(const WinoGeom& g) { return (IBM - 2) / g.Tx + 2 <= INSEG; }
 
 }  // namespace
+
+#ifdef LM_IPROF
+extern "C" __attribute__((visibility("default"))) int lm_iprof_read(unsigned long long* out, int reset) {
+    if (hipMemcpyFromSymbol(out, HIP_SYMBOL(g_iprof), sizeof(g_iprof)) != hipSuccess) return 1;
+    if (reset) {
+        unsigned long long z[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+        if (hipMemcpyToSymbol(HIP_SYMBOL(g_iprof), z, sizeof(z)) != hipSuccess) return 1;
+    }
+    return 0;
+}
+#endif
 
 LM_API long lm_conv3x3_winograd_workspace_bytes(int B, int H, int W, int Cin, int dil) {
     if (dil < 1) return 0;
@@ -1236,7 +1377,7 @@ LM_API int lm_winograd_implicit_supported(int H, int W, int Cin, int dil) {
 // pixels), wu_frag = U = G g G^T repacked per wave fragment, [16][Cin/16][CoutP/32][2][64][4] floats:
 //   wu_frag[xi][cs][nt][kk][lane][e] = U[xi][nt*32 + (lane & 31)][cs*16 + kk*8 + (lane >> 5)*4 + e]     (ops.pack_wino_fragments)
 namespace {
-int wino_implicit_launch(bool split, void* stream, const float* x, int ldx, const float* wu_frag, int CoutP, const float* scale,
+int wino_implicit_launch(int mode, void* stream, const float* x, int ldx, const float* wu_frag, int CoutP, const float* scale,
                          const float* shift, const float* res, int ldr, float* y, int ldy, int B, int H, int W,
                          int Cin, int Cout, int dil, int act, double* gn_partial) {
     LM_REQUIRE(x && wu_frag && y, "conv_wino_implicit: null pointer");
@@ -1258,17 +1399,22 @@ int wino_implicit_launch(bool split, void* stream, const float* x, int ldx, cons
         zeros = (const float*)sym;
     }
     p.zeros = zeros;
-    const size_t lds = (size_t)(IRAW + (split ? 3 * IVPLANE : IVBUF)) * sizeof(float);
-    static bool attr_set[2] = {false, false};
-    if (!attr_set[split ? 1 : 0]) {
-        if (split) LM_HIP(hipFuncSetAttribute((const void*)wino_implicit_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        else LM_HIP(hipFuncSetAttribute((const void*)wino_implicit_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        attr_set[split ? 1 : 0] = true;
+    const size_t lds = (size_t)(IRAW + IVBUF) * sizeof(float);
+    // the WIDE geometry halves the transform work per matrix operation; it needs 128 real output channels per workgroup to pay
+    static const bool wide_ok = !(getenv("LANEMAP_WINO_WIDE") && atoi(getenv("LANEMAP_WINO_WIDE")) == 0);
+    if (mode == 0 && wide_ok && Cout > IBN && Cin % WKS == 0) mode = 2;
+    static bool attr_set[3] = {false, false, false};
+    const void* fn = mode == 0 ? (const void*)wino_implicit_kernel<0> : mode == 1 ? (const void*)wino_implicit_kernel<1> : (const void*)wino_implicit_kernel<2>;
+    if (!attr_set[mode]) {
+        LM_HIP(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        attr_set[mode] = true;
     }
-    const long blocks = (p.g.T / IBM) * ((Cout + IBN - 1) / IBN);
-    LM_REQUIRE(blocks > 0 && blocks < (1L << 31) && p.g.T % IBM == 0, "conv_wino_implicit: bad grid %ld", blocks);
-    if (split) hipLaunchKernelGGL(wino_implicit_kernel<true>, dim3((unsigned)blocks), dim3(256), lds, (hipStream_t)stream, p);
-    else hipLaunchKernelGGL(wino_implicit_kernel<false>, dim3((unsigned)blocks), dim3(256), lds, (hipStream_t)stream, p);
+    const int bm = mode == 2 ? WBM : IBM, bn = mode == 2 ? WBN : IBN;
+    const long blocks = (p.g.T / bm) * ((Cout + bn - 1) / bn);
+    LM_REQUIRE(blocks > 0 && blocks < (1L << 31) && p.g.T % bm == 0, "conv_wino_implicit: bad grid %ld", blocks);
+    if (mode == 0) hipLaunchKernelGGL(wino_implicit_kernel<0>, dim3((unsigned)blocks), dim3(256), lds, (hipStream_t)stream, p);
+    else if (mode == 1) hipLaunchKernelGGL(wino_implicit_kernel<1>, dim3((unsigned)blocks), dim3(256), lds, (hipStream_t)stream, p);
+    else hipLaunchKernelGGL(wino_implicit_kernel<2>, dim3((unsigned)blocks), dim3(256), lds, (hipStream_t)stream, p);
     LM_LAUNCH_CHECK();
     return LM_OK;
 }
@@ -1278,16 +1424,17 @@ int wino_implicit_launch(bool split, void* stream, const float* x, int ldx, cons
 LM_API int lm_conv3x3_winograd_implicit_f32(void* stream, const float* x, int ldx, const float* wu_frag, int CoutP, const float* scale,
                                             const float* shift, const float* res, int ldr, float* y, int ldy, int B, int H, int W,
                                             int Cin, int Cout, int dil, int act, double* gn_partial) {
-    return wino_implicit_launch(false, stream, x, ldx, wu_frag, CoutP, scale, shift, res, ldr, y, ldy, B, H, W, Cin, Cout, dil, act, gn_partial);
+    return wino_implicit_launch(0, stream, x, ldx, wu_frag, CoutP, scale, shift, res, ldr, y, ldy, B, H, W, Cin, Cout, dil, act, gn_partial);
 }
 
 // The same convolution with the GEMM on the bf16 matrix cores: every fp32 operand split exactly into three bf16 pieces, six piece
 // products per multiply, fp32 accumulation (error of the class of an fp32 rounding, NOT bit-identical to the fp32 kernels).
 // wu_frag3 = U split the same way and repacked per wave fragment, [16][Cin/16][CoutP/32][3 pieces][64 lanes][8 bf16]:
-//   piece k of U[xi][nt*32 + (lane & 31)][cs*16 + (lane >> 5)*8 + e], e = 0..7        (ops.pack_wino_fragments_bf16x3)
+//   piece k of U[xi][nt*32 + (lane & 31)][cs*16 + 4*(lane >> 5) + (e & 3) + 8*(e >> 2)], e = 0..7     (ops.pack_wino_fragments_bf16x3;
+//   the k order of a lane half = the channels of its two fp32 A fragments)
 LM_API int lm_conv3x3_winograd_implicit_bf16x3(void* stream, const float* x, int ldx, const void* wu_frag3, int CoutP, const float* scale,
                                                const float* shift, const float* res, int ldr, float* y, int ldy, int B, int H, int W,
                                                int Cin, int Cout, int dil, int act, double* gn_partial) {
-    return wino_implicit_launch(true, stream, x, ldx, (const float*)wu_frag3, CoutP, scale, shift, res, ldr, y, ldy, B, H, W, Cin, Cout, dil, act,
+    return wino_implicit_launch(1, stream, x, ldx, (const float*)wu_frag3, CoutP, scale, shift, res, ldr, y, ldy, B, H, W, Cin, Cout, dil, act,
                                 gn_partial);
 }

@@ -97,7 +97,7 @@ def pack_wino_fragments(wu):
 def pack_wino_fragments_bf16x3(wu):
     """pack_wino output U [16, CoutP, Cin] -> three EXACT bf16 pieces (U = u1 + u2 + u3: top 8 significant bits, then the next 8, then
     the last 8, by truncation) in the per-wave-fragment order of lm_conv3x3_winograd_implicit_bf16x3:
-    [16][Cin/16][CoutP/32][piece 3][lane 64][8] bf16 with lane = khalf * 32 + row, k = cs*16 + khalf*8 + e."""
+    [16][Cin/16][CoutP/32][piece 3][lane 64][8] bf16 with lane = khalf * 32 + row, channel = cs*16 + 8*(e >> 2) + 4*khalf + (e & 3)."""
     xi, cop, ci = wu.shape
     assert xi == 16 and cop % 32 == 0 and ci % 16 == 0 and wu.dtype == torch.float32
     pieces, r = [], wu
@@ -107,8 +107,10 @@ def pack_wino_fragments_bf16x3(wu):
         r = r - top
     assert float(r.abs().max()) == 0.0
     t = torch.stack(pieces).to(torch.bfloat16)                                   # exact: every piece is a bf16 value
-    t = t.reshape(3, 16, cop // 32, 32, ci // 16, 2, 8)                          # piece, xi, nt, row, cs, khalf, e
-    return t.permute(1, 4, 2, 0, 5, 3, 6).contiguous().reshape(16, ci // 16, cop // 32, 3, 64, 8)
+    # channel c of a 16-channel slab = 8 * hi + 4 * khalf + lo (hi, khalf in 0..1, lo in 0..3): lane half `khalf` holds the channels of
+    # its two fp32 A fragments, element e = 4 * hi + lo
+    t = t.reshape(3, 16, cop // 32, 32, ci // 16, 2, 2, 4)                       # piece, xi, nt, row, cs, hi, khalf, lo
+    return t.permute(1, 4, 2, 0, 6, 3, 5, 7).contiguous().reshape(16, ci // 16, cop // 32, 3, 64, 8)
 
 
 def pack_small(w):
