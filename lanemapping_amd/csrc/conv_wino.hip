@@ -797,7 +797,8 @@ __device__ __forceinline__ void wino_imp_step(f32x16& acc, f32x4 (&bq)[8][2], un
 }
 
 #ifdef LM_IPROF                             // (tools/build_variant.sh probe: per-phase shader-clock cycles summed over waves)
-__device__ unsigned long long g_iprof[12];   // prologue, transform, barrier 1, MFMA phase, end-of-slab wait, barrier 2, epilogue, waves
+constexpr int IPROF_WG = 16384;
+__device__ unsigned long long g_iprof[IPROF_WG][12];   // [workgroup % IPROF_WG][phase], wave 0 only (plain stores: same-address atomics serialise)   // prologue, transform, barrier 1, MFMA phase, end-of-slab wait, barrier 2, epilogue, waves
 #define LM_TICK(slot)                                        \
     {                                                        \
         const long long t_now = clock64();                   \
@@ -853,47 +854,60 @@ __global__ __launch_bounds__(256) void wino_implicit_kernel(WinoImpParams p) {
     const WinoGeom& g = p.g;
     const int bi = (int)(m0 / g.Tpad);
     const int t0 = (int)(m0 - (long)bi * g.Tpad);
-    // runs of horizontally adjacent tiles (wave-uniform): first local tile, length, (phase, ty, tx) of the first tile
-    int ts[INSEG + 1], sn[INSEG], stx[INSEG], sty[INSEG], sph[INSEG];
+    // runs of horizontally adjacent tiles (workgroup-uniform, scalar registers): first local tile ts, length sn, and per run the input
+    // pixel of patch cell (0, 0) (iy0, ix0: may be negative = padding), the output pixel of its first tile (oy0, ox0) and the first
+    // column slot q0.  A run past the last real tile of the image (padding rows of V) has sn = 0.
+    int ts[INSEG + 1], sn[INSEG], iy0[INSEG], ix0[INSEG], oy0[INSEG], ox0[INSEG];
     {
         int at = 0, t = t0;
+        int tx = t0 % g.Tx, rest = t0 / g.Tx;          // one decode (three divisions), then carries: a run ends at the end of a tile row
+        int ty = rest % g.Ty, ph = rest / g.Ty;
+        int pa = ph / g.dil, pb = ph - pa * g.dil;
 #pragma unroll
         for (int s_ = 0; s_ < INSEG; ++s_) {
             ts[s_] = at;
-            const int tx = t % g.Tx, rest = t / g.Tx;
-            stx[s_] = tx;
-            sty[s_] = rest % g.Ty;
-            sph[s_] = rest / g.Ty;
+            const bool real = t < g.Timg && at < BM;
             const int n = at < BM ? min(BM - at, g.Tx - tx) : 0;
-            sn[s_] = n;
+            sn[s_] = real ? n : 0;
+            iy0[s_] = (2 * ty - 1) * g.dil + pa;
+            ix0[s_] = (2 * tx - 1) * g.dil + pb;
+            oy0[s_] = 2 * ty * g.dil + pa;
+            ox0[s_] = 2 * tx * g.dil + pb;
             at += n;
             t += n;
+            tx += n;
+            if (tx >= g.Tx) {
+                tx = 0;
+                if (++ty >= g.Ty) {
+                    ty = 0;
+                    if (++pb >= g.dil) {
+                        pb = 0;
+                        ++pa;
+                    }
+                }
+            }
         }
         ts[INSEG] = at;            // == BM (the launcher guarantees <= INSEG runs)
     }
     // --- per-lane sources of this wave's ILPW patch loads (one pointer each; the channel slab is a uniform offset)
     const float* gsrc[ILPW];
+    const int img_pix0 = bi * g.H * g.W;
 #pragma unroll
     for (int s_ = 0; s_ < ILPW; ++s_) {
         const int pos = (s_ * 4 + wave) * CPL + lane / CPC;            // LDS cell position (CPL cells per wave load)
         const int r = pos / NCOL;
         const int q = unrot3(pos - r * NCOL);
         const int ch = lane % CPC;
-        int sg = 0;
-#pragma unroll
-        for (int k = 1; k < INSEG; ++k) sg += (sn[k] > 0 && q >= 2 * ts[k] + 2 * k) ? 1 : 0;
-        int n = sn[0], tx0 = stx[0], ty = sty[0], ph = sph[0], q0 = 0;
+        int n = sn[0], yb = iy0[0], xb = ix0[0], q0 = 0;
 #pragma unroll
         for (int k = 1; k < INSEG; ++k)
-            if (sg == k) {
-                n = sn[k]; tx0 = stx[k]; ty = sty[k]; ph = sph[k]; q0 = 2 * ts[k] + 2 * k;
+            if (q >= 2 * ts[k] + 2 * k) {                              // (runs are in slot order: the last match wins)
+                n = sn[k]; yb = iy0[k]; xb = ix0[k]; q0 = 2 * ts[k] + 2 * k;
             }
         const int lc = q - q0;
-        const int py = 2 * ty - 1 + r, px = 2 * tx0 - 1 + lc;
-        const int pa = ph / g.dil, pb = ph - pa * g.dil;
-        const int yy = py * g.dil + pa, xx = px * g.dil + pb;
-        const bool ok = r < 4 && lc < 2 * n + 2 && ph < g.dil * g.dil && py >= 0 && px >= 0 && yy < g.H && xx < g.W;
-        gsrc[s_] = ok ? p.x + (((long)bi * g.H + yy) * g.W + xx) * p.ldx + ch * 4 : p.zeros + ch * 4;
+        const int yy = yb + r * g.dil, xx = xb + lc * g.dil;
+        const bool ok = r < 4 && lc < 2 * n + 2 && n > 0 && (unsigned)yy < (unsigned)g.H && (unsigned)xx < (unsigned)g.W;
+        gsrc[s_] = ok ? p.x + (long)(img_pix0 + yy * g.W + xx) * p.ldx + ch * 4 : p.zeros + ch * 4;
     }
     // --- TRANSFORM task of this thread: tile tid / CPC, channel quad tid % CPC.  WIDE: V rows are 8 chunks, XOR-swizzled by (tile >> 1) & 7
     // (the 8 quads of a tile fill one 128-byte row: conflict-free stores; the 16 rows of an A-fragment read group differ in
@@ -903,7 +917,7 @@ __global__ __launch_bounds__(256) void wino_implicit_kernel(WinoImpParams p) {
         const int tl = tid / CPC, qd = tid % CPC;
         int sg = 0;
 #pragma unroll
-        for (int k = 1; k < INSEG; ++k) sg += (sn[k] > 0 && tl >= ts[k]) ? 1 : 0;
+        for (int k = 1; k < INSEG; ++k) sg += (ts[k] < BM && tl >= ts[k]) ? 1 : 0;
         const int cb = 2 * tl + 2 * sg;
 #pragma unroll
         for (int c = 0; c < 4; ++c) roff[c] = (rot3(cb + c) * CPC + qd) * 4;
@@ -930,6 +944,9 @@ __global__ __launch_bounds__(256) void wino_implicit_kernel(WinoImpParams p) {
     for (int k = 0; k < 16; ++k)
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[k][r] = 0.f;
+#if defined(LM_IPROF) && !defined(LM_IPROF_EPI)
+    LM_TICK(7)                                  // (index setup; slot 0 = the prologue's loads)
+#endif
     if constexpr (SPLIT) {
     f32x4 bq3[8][3];
 #pragma unroll
@@ -1067,6 +1084,8 @@ __global__ __launch_bounds__(256) void wino_implicit_kernel(WinoImpParams p) {
     __builtin_amdgcn_s_barrier();
     LM_TICK(0)
     for (int cs = 0; cs < cslabs; ++cs) {
+        // (storing planes 4..15 of V behind the first MFMA steps was tried: f32 MFMA issue stalls on the wave's own ds_write data
+        // transfer, the matrix phase grew by exactly the store time it was meant to hide)
 #ifndef LM_IABL_NOTF
         wino_slab_transform<NCOL * KS>(rawbuf, Vbuf, roff, tvoff);
 #endif
@@ -1086,6 +1105,8 @@ __global__ __launch_bounds__(256) void wino_implicit_kernel(WinoImpParams p) {
             (S) + BD < 32 ? LM_BADDR(cs, (S) + BD) : LM_BADDR(cs_next, (S) + BD - 32), \
             Vbuf + (((S) + 1) >> 1) * (WBM * WKS) + aoff[2 * (((S) + 1) & 1)], Vbuf + (((S) + 1) >> 1) * (WBM * WKS) + aoff[2 * (((S) + 1) & 1) + 1], \
             AC, AN, gsrc, goff, rawbuf, wave, gnext)
+        // (a separate step sequence for the last slab - no patch loads, no B beyond the slab - was tried: the branch makes the compiler
+        // copy ring registers at the join while their asm loads are still in flight.  The loop body must stay straight-line code.)
         LM_WSTEP(0, 15, a0, a1);  LM_WSTEP(1, 16, a1, a0);  LM_WSTEP(2, 17, a0, a1);  LM_WSTEP(3, 18, a1, a0);
         LM_WSTEP(4, 19, a0, a1);  LM_WSTEP(5, 20, a1, a0);  LM_WSTEP(6, 21, a0, a1);  LM_WSTEP(7, 22, a1, a0);
         LM_WSTEP(8, 22, a0, a1);  LM_WSTEP(9, 21, a1, a0);  LM_WSTEP(10, 20, a0, a1); LM_WSTEP(11, 19, a1, a0);
@@ -1136,30 +1157,20 @@ __global__ __launch_bounds__(256) void wino_implicit_kernel(WinoImpParams p) {
     const bool vec = (n + 3 < p.Cout) && ((p.ldy & 3) == 0) && (!p.res || (p.ldr & 3) == 0);
     f32x4 gs = {0.f, 0.f, 0.f, 0.f}, gq = {0.f, 0.f, 0.f, 0.f};
     int pix0[NP];
-    unsigned vmask = 0;
-    {
-        int t = t0 + wm0 + lane / LPR;
-        int tx = t % g.Tx, q = t / g.Tx;
-        int ty = q % g.Ty, ph = q / g.Ty;
-        int pa = ph / g.dil, pb = ph % g.dil;
+    unsigned vmask = 0;                                // 3 bits per row: tile exists | a = 1 inside | b = 1 inside
 #pragma unroll
-        for (int pass = 0; pass < NP; ++pass) {
-            const int oy = 2 * ty * g.dil + pa, ox = 2 * tx * g.dil + pb;
-            pix0[pass] = (bi * g.H + oy) * g.W + ox;
-            if (t < g.Timg && oy < g.H && ox < g.W)
-                vmask |= (1u | (oy + g.dil < g.H ? 2u : 0u) | (ox + g.dil < g.W ? 4u : 0u)) << (3 * pass);
-            t += RPI;
-            tx += RPI;
-            while (tx >= g.Tx) {
-                tx -= g.Tx;
-                if (++ty >= g.Ty) {
-                    ty = 0;
-                    ++ph;
-                    pa = ph / g.dil;
-                    pb = ph % g.dil;
-                }
+    for (int pass = 0; pass < NP; ++pass) {            // output pixel of the rows this lane stores, from the run table
+        const int tl = wm0 + pass * RPI + lane / LPR;
+        int n = sn[0], oy = oy0[0], oxb = ox0[0], tb = 0;
+#pragma unroll
+        for (int k = 1; k < INSEG; ++k)
+            if (tl >= ts[k]) {
+                n = sn[k]; oy = oy0[k]; oxb = ox0[k]; tb = ts[k];
             }
-        }
+        const int ox = oxb + 2 * (tl - tb) * g.dil;
+        pix0[pass] = img_pix0 + oy * g.W + ox;
+        if (n > 0 && oy < g.H && ox < g.W)
+            vmask |= (1u | (oy + g.dil < g.H ? 2u : 0u) | (ox + g.dil < g.W ? 4u : 0u)) << (3 * pass);
     }
     const int step_a = g.dil * g.W, step_b = g.dil;
     __syncthreads();                                   // every wave is done with the patch buffers
@@ -1245,10 +1256,10 @@ __global__ __launch_bounds__(256) void wino_implicit_kernel(WinoImpParams p) {
     }
 #ifdef LM_IPROF
     LM_TICK(6)
-    if (lane == 0) {
+    if (tid == 0) {
 #pragma unroll
-        for (int k = 0; k < 11; ++k) atomicAdd(&g_iprof[k], (unsigned long long)iprof[k]);
-        atomicAdd(&g_iprof[11], 1ull);
+        for (int k = 0; k < 11; ++k) g_iprof[blockIdx.x % IPROF_WG][k] = (unsigned long long)iprof[k];
+        g_iprof[blockIdx.x % IPROF_WG][11] = 1ull;
     }
 #endif
 }
@@ -1260,10 +1271,14 @@ bool wino_implicit_ok(const WinoGeom& g) { return (IBM - 2) / g.Tx + 2 <= INSEG;
 
 #ifdef LM_IPROF
 extern "C" __attribute__((visibility("default"))) int lm_iprof_read(unsigned long long* out, int reset) {
-    if (hipMemcpyFromSymbol(out, HIP_SYMBOL(g_iprof), sizeof(g_iprof)) != hipSuccess) return 1;
+    static unsigned long long host[IPROF_WG][12];
+    if (hipMemcpyFromSymbol(host, HIP_SYMBOL(g_iprof), sizeof(host)) != hipSuccess) return 1;
+    for (int k = 0; k < 12; ++k) out[k] = 0;
+    for (int w = 0; w < IPROF_WG; ++w)
+        for (int k = 0; k < 12; ++k) out[k] += host[w][k];
     if (reset) {
-        unsigned long long z[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
-        if (hipMemcpyToSymbol(HIP_SYMBOL(g_iprof), z, sizeof(z)) != hipSuccess) return 1;
+        static unsigned long long zero[IPROF_WG][12];
+        if (hipMemcpyToSymbol(HIP_SYMBOL(g_iprof), zero, sizeof(zero)) != hipSuccess) return 1;
     }
     return 0;
 }
