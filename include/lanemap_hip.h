@@ -242,6 +242,13 @@ int lm_rowref_decode(void* stream, const float* ext2, const float* cls2, unsigne
  * sparse_to_dense_nhwc = SparseConvTensor.dense().view(N, C*D, H, W) + torch.flip(dims=[2]) (:70);
  * upsample_bicubic_nhwc = F.interpolate(mode='bicubic', align_corners=False) (:72). */
 long lm_voxelize_workspace_bytes(long n_points);
+/* The two device-wide primitives under the voxeliser and the output-site compaction (csrc/prim.hip: the library's own kernels, where
+ * mmdet3d's hard_voxelize / spconv's indice generation loop or hash on the device): exclusive prefix sum of u32 (wraps; in == out
+ * allowed) and STABLE sort of (u32 key, u32 value) pairs by the low end_bit bits of the keys, in place. */
+long lm_scan_workspace_bytes(long n);
+int lm_exclusive_scan_u32(void* stream, const unsigned* in, unsigned* out, long n, void* workspace, long workspace_bytes);
+long lm_sort_pairs_workspace_bytes(long n);
+int lm_sort_pairs_u32(void* stream, unsigned* keys_io, unsigned* vals_io, long n, int end_bit, void* workspace, long workspace_bytes);
 int lm_voxelize_hard(void* stream, const float* points, long n, const float* range_lo_xyz, const float* voxel_size_xyz,
                      const int* grid_xyz, int max_points, int max_voxels, int batch_idx, const int* row_base, int cap_rows,
                      float* feats, int ldf, int* coords, int* row_end, int raster_order, void* workspace,

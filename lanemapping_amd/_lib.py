@@ -91,6 +91,10 @@ SIGNATURES = {
     'lm_rowref_scatter': (i32, [vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32]),
     'lm_rowref_decode': (i32, [vp, vp, vp, vp, vp, vp, i32, i32, i32, i32]),
     'lm_voxelize_workspace_bytes': (i64, [i64]),
+    'lm_scan_workspace_bytes': (i64, [i64]),
+    'lm_exclusive_scan_u32': (i32, [vp, vp, vp, i64, vp, i64]),
+    'lm_sort_pairs_workspace_bytes': (i64, [i64]),
+    'lm_sort_pairs_u32': (i32, [vp, vp, vp, i64, i32, vp, i64]),
     'lm_voxelize_hard': (i32, [vp, vp, i64, c_f32p, c_f32p, C.POINTER(i32), i32, i32, i32, vp, i32, vp, i32, vp, vp, i32, vp, i64]),
     'lm_sparse_grid_build': (i32, [vp, vp, i64, vp, i32, i32, i32, i32]),
     'lm_sparse_conv_outputs_workspace_bytes': (i64, [i64]),

@@ -7,7 +7,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, 'csrc')
 LIB = os.path.join(HERE, 'liblanemap_hip.so')
 SOURCES = ['errors.cpp', 'conv_mfma.hip', 'conv_wino.hip', 'conv_direct.hip', 'norm_resize.hip', 'vit.hip', 'head.hip',
-           'decode.hip', 'raster.hip', 'rowref.hip', 'lidar.hip', 'postproc.cpp', 'backproject.cpp', 'png_reader.cpp', 'lane_json.cpp', 'merge_lines.cpp', 'skeleton.cpp']
+           'decode.hip', 'raster.hip', 'rowref.hip', 'prim.hip', 'lidar.hip', 'postproc.cpp', 'backproject.cpp', 'png_reader.cpp', 'lane_json.cpp', 'merge_lines.cpp', 'skeleton.cpp']
 
 
 # integer-output kernels whose fp32 index math must match the C oracle bit for bit

@@ -18,8 +18,7 @@
 // "hashing" is a plain load and output-site compaction is one exclusive scan in raster order (deterministic row order).
 // The convolutions themselves run on the MFMA gather kernel (conv_mfma.hip, lm_conv_gather_mfma_f32).
 #include "common.h"
-
-#include <hipcub/hipcub.hpp>
+#include "prim.h"
 
 namespace {
 
@@ -262,17 +261,8 @@ __global__ __launch_bounds__(256) void bicubic_kernel(const float* __restrict__ 
 
 size_t align256(size_t v) { return (v + 255) / 256 * 256; }
 
-size_t sort_temp_bytes(long n) {
-    size_t b = 0;
-    (void)hipcub::DeviceRadixSort::SortPairs(nullptr, b, (const unsigned*)nullptr, (unsigned*)nullptr, (const unsigned*)nullptr,
-                                       (unsigned*)nullptr, (int)n, 0, 32, (hipStream_t)0);
-    return b;
-}
-size_t scan_temp_bytes(long n) {
-    size_t b = 0;
-    (void)hipcub::DeviceScan::ExclusiveSum(nullptr, b, (const unsigned*)nullptr, (unsigned*)nullptr, (int)n, (hipStream_t)0);
-    return b;
-}
+size_t sort_temp_bytes(long n) { return lm_prim_sort_temp_bytes(n); }       // (prim.hip: the library's own radix sort and scan)
+size_t scan_temp_bytes(long n) { return lm_prim_scan_temp_bytes(n); }
 
 }  // namespace
 
@@ -322,14 +312,28 @@ LM_API int lm_voxelize_hard(void* stream, const float* points, long n, const flo
     const float4* p4 = reinterpret_cast<const float4*>(points);
     hipLaunchKernelGGL(vox_keys_kernel, dim3(blocks), dim3(256), 0, s, p4, n, G, keys_in, vals_in, flags);
     LM_LAUNCH_CHECK();
-    LM_HIP(hipcub::DeviceRadixSort::SortPairs(temp, t1, keys_in, keys_out, vals_in, vals_out, (int)n, 0, 32, s));
+    // stable sort by cell: only the bits a cell index can have take part, chosen so that the all-ones INVALID_KEY still sorts last
+    const long cells = (long)grid_xyz[0] * grid_xyz[1] * grid_xyz[2];
+    int end_bit = 8;
+    while (end_bit < 32 && cells > (1L << end_bit) - 1) end_bit += 8;
+    {
+        unsigned *kr = nullptr, *vr = nullptr;
+        const int rc = lm_prim_sort_pairs_u32(s, keys_in, keys_out, vals_in, vals_out, n, end_bit, temp, t1, &kr, &vr);
+        if (rc != LM_OK) return rc;
+        keys_out = kr;
+        vals_out = vr;
+    }
     hipLaunchKernelGGL(vox_heads_kernel, dim3(blocks), dim3(256), 0, s, keys_out, vals_out, n, flags);
     LM_LAUNCH_CHECK();
-    LM_HIP(hipcub::DeviceScan::ExclusiveSum(temp, t2, flags, rank, (int)n, s));
+    {
+        const int rc = lm_prim_exclusive_scan_u32(s, flags, rank, n, temp, t2);
+        if (rc != LM_OK) return rc;
+    }
     if (raster_order) {
         hipLaunchKernelGGL(vox_kept_kernel, dim3(blocks), dim3(256), 0, s, keys_out, vals_out, rank, n, max_voxels, kept);
         LM_LAUNCH_CHECK();
-        LM_HIP(hipcub::DeviceScan::ExclusiveSum(temp, t2, kept, rrank, (int)n, s));
+        const int rc = lm_prim_exclusive_scan_u32(s, kept, rrank, n, temp, t2);
+        if (rc != LM_OK) return rc;
     }
     hipLaunchKernelGGL(vox_emit_kernel, dim3(blocks), dim3(256), 0, s, p4, keys_out, vals_out, rank, flags,
                        raster_order ? rrank : (const unsigned*)nullptr, n, G, max_points, max_voxels,
@@ -383,7 +387,10 @@ LM_API int lm_sparse_conv_outputs(void* stream, const int* in_coords, long n_in,
     LM_HIP(hipMemsetAsync(flags, 0, (size_t)cells * 4, s));
     hipLaunchKernelGGL(conv_mark_kernel, dim3(lm_cdiv(n_in, 256)), dim3(256), 0, s, in_coords, n_in, cv, go, flags);
     LM_LAUNCH_CHECK();
-    LM_HIP(hipcub::DeviceScan::ExclusiveSum(temp, tb, flags, ids, (int)cells, s));
+    {
+        const int rc = lm_prim_exclusive_scan_u32(s, (const unsigned*)flags, (unsigned*)ids, cells, temp, tb);
+        if (rc != LM_OK) return rc;
+    }
     hipLaunchKernelGGL(conv_compact_kernel, dim3(lm_cdiv(cells, 256)), dim3(256), 0, s, flags, ids, cells, go, cap_rows, out_grid,
                        out_coords, out_count);
     LM_LAUNCH_CHECK();

@@ -12,7 +12,7 @@ unpinned); ``oracle/lidar_ref.py`` restates the published behaviour
 The in-repo tail (flip, bicubic, fea_aligner, fea_conv, 1x1 heads, bilinear) is pinned against the imported reference
 (tests/golden G11).  Everything runs in liblanemap_hip.so:
 
-  hard voxelisation + per-voxel mean            -> lm_voxelize_hard (hipCUB radix sort + scan, deterministic)
+  hard voxelisation + per-voxel mean            -> lm_voxelize_hard (stable radix sort + scan of csrc/prim.hip, deterministic)
   active-site bookkeeping                       -> lm_sparse_grid_build / lm_sparse_conv_outputs / lm_sparse_rulebook
   SubMConv3d / SparseConv3d + BN1d + ReLU (+res) -> lm_conv_gather_mfma_f32 (MFMA implicit GEMM over the rulebook)
   dense() + view + flip H, bicubic x(288/75)    -> lm_sparse_to_dense_nhwc, lm_upsample_bicubic_nhwc

@@ -607,6 +607,27 @@ def tile_ingest(u8_hwc):
 _vox_ws = {}
 
 
+def exclusive_scan_u32(x, out=None):
+    """out[i] = x[0] + .. + x[i-1] over a device int32/uint32 vector (u32 arithmetic; csrc/prim.hip)."""
+    x = x.contiguous()
+    assert x.dim() == 1 and x.dtype in (torch.int32, torch.uint32)
+    out = torch.empty_like(x) if out is None else out
+    n = x.numel()
+    ws = torch.empty((lib().lm_scan_workspace_bytes(n),), device=x.device, dtype=torch.uint8)
+    check(lib().lm_exclusive_scan_u32(_stream(), _ptr(x), _ptr(out), n, _ptr(ws), ws.numel()))
+    return out
+
+
+def sort_pairs_u32_(keys, vals, end_bit=32):
+    """Stable in-place sort of (keys, vals) (device int32 vectors read as u32) by the low end_bit bits of the keys (csrc/prim.hip)."""
+    assert keys.dim() == 1 and keys.shape == vals.shape and keys.is_contiguous() and vals.is_contiguous()
+    assert keys.dtype in (torch.int32, torch.uint32) and vals.dtype in (torch.int32, torch.uint32)
+    n = keys.numel()
+    ws = torch.empty((lib().lm_sort_pairs_workspace_bytes(n),), device=keys.device, dtype=torch.uint8)
+    check(lib().lm_sort_pairs_u32(_stream(), _ptr(keys), _ptr(vals), n, int(end_bit), _ptr(ws), ws.numel()))
+    return keys, vals
+
+
 def voxelize_batch(points, range_lo, voxel_size, grid_xyz, max_points, max_voxels, ldf=16, raster_order=False):
     """Hard-voxelise a list of [N_i,4] device tensors -> (feats [V,ldf] (mean x,y,z,i; rest 0), coords [V,4] i32 (b,z,y,x),
     row_ends list).  One host sync at the end (the row count sizes every later launch).  Rows of a sample come in the

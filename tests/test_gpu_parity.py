@@ -1301,3 +1301,46 @@ def test_bench_other_workloads(dev, workload):
     assert r.returncode == 0, r.stderr[-2000:]
     d = json.loads([l for l in r.stdout.strip().split('\n') if l.startswith('{')][-1])
     assert d['value'] > 10 and 0.0 < d['roofline']['frac'] <= 1.0 and d['config']['tiles_per_step_per_gpu'] == 8
+
+
+@pytest.mark.parametrize('n', [0, 1, 63, 4096, 4097, 70001, 5_000_011, 33_554_433])
+def test_exclusive_scan_u32(dev, n):
+    """lm_exclusive_scan_u32 (the library's own three-phase scan, csrc/prim.hip) against numpy's cumsum, in place and out of place,
+    with wrap-around."""
+    from lanemapping_amd import ops
+    rng = np.random.default_rng(n + 7)
+    x = rng.integers(0, 5 if n < 10 ** 6 else 2 ** 31, size=n, dtype=np.int64).astype(np.uint32)
+    want = np.zeros(n, dtype=np.uint32)
+    if n > 1:
+        want[1:] = np.cumsum(x[:-1].astype(np.uint64)).astype(np.uint32)
+    xd = torch.from_numpy(x.view(np.int32)).to(dev)
+    got = ops.exclusive_scan_u32(xd).cpu().numpy().view(np.uint32)
+    np.testing.assert_array_equal(got, want)
+    ops.exclusive_scan_u32(xd, out=xd)
+    np.testing.assert_array_equal(xd.cpu().numpy().view(np.uint32), want)
+
+
+@pytest.mark.parametrize('n,end_bit,kind', [(0, 32, 'rand'), (1, 32, 'rand'), (64, 8, 'rand'), (4097, 32, 'rand'), (100_003, 24, 'few'),
+                                            (1_000_000, 32, 'rand'), (4_194_304, 24, 'cells'), (3_000_001, 16, 'equal')])
+def test_sort_pairs_u32_stable(dev, n, end_bit, kind):
+    """lm_sort_pairs_u32 (LSD radix sort, csrc/prim.hip) = numpy's STABLE argsort on the masked keys: duplicates keep their input
+    order (the voxeliser numbers voxels by first point and keeps the first max_points points, so stability is the contract), keys with
+    bits above end_bit set (the all-ones invalid key) still sort last."""
+    from lanemapping_amd import ops
+    rng = np.random.default_rng(n + end_bit)
+    if kind == 'rand':
+        k = rng.integers(0, 2 ** 32, size=n, dtype=np.uint64).astype(np.uint32)
+    elif kind == 'few':
+        k = rng.integers(0, 37, size=n).astype(np.uint32) * 449
+    elif kind == 'equal':
+        k = np.full(n, 12345, dtype=np.uint32)
+    else:      # voxel cells with 10 % invalid points
+        k = rng.integers(0, 600 * 600 * 21, size=n).astype(np.uint32)
+        k[rng.random(n) < 0.1] = 0xFFFFFFFF
+    v = np.arange(n, dtype=np.uint32)
+    mask = np.uint32(0xFFFFFFFF) if end_bit >= 32 else np.uint32((1 << (-(-end_bit // 8) * 8)) - 1)      # whole 8-bit digits take part
+    order = np.argsort(k & mask, kind='stable')
+    kd, vd = torch.from_numpy(k.view(np.int32)).to(dev), torch.from_numpy(v.view(np.int32)).to(dev)
+    ops.sort_pairs_u32_(kd, vd, end_bit)
+    np.testing.assert_array_equal(vd.cpu().numpy().view(np.uint32), v[order])
+    np.testing.assert_array_equal(kd.cpu().numpy().view(np.uint32), k[order])

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Reads a rocprofv3 kernel trace (p_kernel_trace.csv) of bench.py and prints, for the steady-state part, how much of the wall time
-at least one kernel / at least one MFMA-bound kernel (wino_gemm, conv_mfma) was running, and the per-class sums.
+at least one kernel / at least one MFMA-bound kernel (wino_implicit / wino_gemm, conv_mfma) was running, and the per-class sums.
 usage: timeline_overlap.py <kernel_trace.csv>"""
 import csv
 import sys
@@ -9,7 +9,7 @@ rows = []
 for r in csv.DictReader(open(sys.argv[1])):
     rows.append((int(r['Start_Timestamp']), int(r['End_Timestamp']), r['Kernel_Name']))
 rows.sort()
-g = [(s, e) for s, e, n in rows if 'wino_gemm' in n]
+g = [(s, e) for s, e, n in rows if 'wino_gemm' in n or 'wino_implicit' in n]
 g0, g1 = g[0][0], max(e for _, e in g)
 lo, hi = g0 + 0.3 * (g1 - g0), g0 + 0.9 * (g1 - g0)      # steady state: inside the span of the GEMM launches, past priming / warm-up
 rows = [(max(s, lo), min(e, hi), n) for s, e, n in rows if e > lo and s < hi]
@@ -30,7 +30,7 @@ def union(iv):
 
 
 wall = hi - lo
-cls = lambda n: 'mfma' if ('wino_gemm' in n or 'conv_mfma' in n or 'attention_mfma' in n) else ('wino_input' if 'wino_input' in n else 'other')
+cls = lambda n: 'mfma' if ('wino_gemm' in n or 'wino_implicit' in n or 'conv_mfma' in n or 'attention_mfma' in n) else ('wino_input' if 'wino_input' in n else 'other')
 allu = union([(s, e) for s, e, _ in rows])
 mf = union([(s, e) for s, e, n in rows if cls(n) == 'mfma'])
 sums = {}
