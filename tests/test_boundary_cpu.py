@@ -788,3 +788,36 @@ def test_torch_ops_registered_with_schema_and_fake_kernels():
     lanes, kept = torch.ops.lanemap_hip.polyline_assemble(torch.zeros((72, 2)), torch.zeros((72, 144)), torch.zeros((72, 144), dtype=torch.float64),
                                                           torch.zeros((144, 1152)), torch.zeros((0, 2), dtype=torch.int32), 0.3)
     assert tuple(lanes.shape) == (72, 144, 2) and lanes.dtype == torch.float64 and kept.shape[0] == 0
+
+
+def test_winograd_weight_packers_layout_and_exact_split():
+    """Host-side packers of the implicit Winograd kernels (ops.pack_wino*): U = G g G^T against a direct fp64 evaluation, the
+    per-wave-fragment order documented in include/lanemap_hip.h, and the three-way bf16 split of U being EXACT (u1 + u2 + u3 == U bit
+    for bit, every piece representable in bf16)."""
+    from lanemapping_amd import ops
+    g = torch.Generator().manual_seed(11)
+    cout, cin = 72, 48
+    w = torch.randn((cout, cin, 3, 3), generator=g)
+    wu = ops.pack_wino(w)
+    assert wu.shape == (16, 128, cin) and float(wu[:, cout:].abs().max()) == 0.0
+    G = np.array([[1, 0, 0], [.5, .5, .5], [.5, -.5, .5], [0, 0, 1]])
+    want = np.einsum('ij,ocjk,lk->iloc', G, w.double().numpy(), G).reshape(16, cout, cin)
+    np.testing.assert_allclose(wu[:, :cout].numpy(), want, rtol=0, atol=2e-7 * np.abs(want).max())
+    wf = ops.pack_wino_fragments(wu)
+    assert wf.shape == (16, cin // 16, 4, 2, 64, 4)
+    rng = np.random.default_rng(3)
+    for _ in range(200):
+        xi, cs, nt, kk, lane, e = (int(rng.integers(0, n)) for n in (16, cin // 16, 4, 2, 64, 4))
+        assert float(wf[xi, cs, nt, kk, lane, e]) == float(wu[xi, nt * 32 + (lane & 31), cs * 16 + kk * 8 + (lane >> 5) * 4 + e])
+    w3 = ops.pack_wino_fragments_bf16x3(wu)
+    assert w3.dtype == torch.bfloat16 and w3.shape == (16, cin // 16, 4, 3, 64, 8)
+    # undo the fragment order: channel = cs*16 + 8*(e >> 2) + 4*khalf + (e & 3), lane = khalf*32 + row
+    back = torch.zeros((3, 16, 128, cin), dtype=torch.float64)
+    for khalf in range(2):
+        for e in range(8):
+            ch = torch.arange(cin // 16) * 16 + 8 * (e >> 2) + 4 * khalf + (e & 3)
+            blk = w3[:, :, :, :, khalf * 32:khalf * 32 + 32, e].double()          # xi, cs, nt, piece, row
+            back[:, :, :, ch] = blk.permute(3, 0, 2, 4, 1).reshape(3, 16, 128, cin // 16)
+    total = (back[0] + back[1] + back[2]).float()                                 # three bf16 values: their fp64 sum is exact
+    assert torch.equal(total, wu), float((total - wu).abs().max())
+    assert float(back[1].abs().max()) <= float(back[0].abs().max()) * 2.0 ** -7 and float(back[2].abs().max()) <= float(back[0].abs().max()) * 2.0 ** -15
