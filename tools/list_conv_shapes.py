@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Every MFMA convolution launch of one network forward (config 2, batch argv[1] = 4): label, ms, executed TFLOP/s, sorted by time."""
+"""Every MFMA convolution launch of one network forward (config argv[2] = config 2, batch argv[1] = 4): label, ms, executed TFLOP/s, sorted by time."""
 import os
 import sys
 import collections
@@ -11,8 +11,9 @@ from lanemapping_amd import ops, synth  # noqa: E402
 from lanemapping_amd.boundary import build_net_from_config  # noqa: E402
 
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 4
+CFG = sys.argv[2] if len(sys.argv) > 2 else 'Proj_polyline_fpn_vit_vertex_2'
 dev = torch.device('cuda:0')
-net = build_net_from_config('Proj_polyline_fpn_vit_vertex_2', device='cpu')
+net = build_net_from_config(CFG, device='cpu')
 synth.fill_module_(net, 2021)
 net = net.to(dev)
 x = torch.from_numpy(synth.bev_batch([2021 + i for i in range(B)], 1152)).to(dev)
