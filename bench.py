@@ -117,6 +117,7 @@ def main():
                          '(their data-dependent bookkeeping needs host round trips, which serialise sub-batches)')
     ap.add_argument('--conv-detail', action='store_true', help='per-shape table of the MFMA launches on stderr')
     ap.add_argument('--no-stream-check', action='store_true', help='skip the bitwise multi-stream == single-stream check')
+    ap.add_argument('--graphs', action='store_true', help='replay the device part of every sub-batch as one HIP graph (TilePipeline use_graph)')
     args = ap.parse_args()
 
     if args.gpus < 1:
@@ -171,11 +172,13 @@ def main():
         # the rasteriser hands the tile over as u8 HWC (what a BEV tile IS: the reference's PNG; f32 = u8 / 255 is applied inside the
         # stem kernel, same bits) - a quarter of the bytes of the f32 planar tensor on both sides
         tiles = torch.empty((batch, 1152, 1152, 3), device=dev, dtype=torch.uint8)
-    pipe = TilePipeline(net, host_threads=args.host_threads)
+    pipe = TilePipeline(net, host_threads=args.host_threads, use_graph=args.graphs)
+    # whole-batch reference / instrumented passes launch kernel by kernel (the roofline hook brackets every launch with events)
+    pipe_eager = pipe if not args.graphs else TilePipeline(net, host_threads=args.host_threads, use_graph=False)
     nstream = max(1, args.streams if args.streams is not None else (1 if args.workload in ('lidar', 'rowref') else 4))
     nstream = min(nstream, batch)
     extra_streams = [torch.cuda.Stream(device=dev) for _ in range(nstream - 1)]
-    extra_pipes = [TilePipeline(net, host_threads=args.host_threads) for _ in range(nstream - 1)]
+    extra_pipes = [TilePipeline(net, host_threads=args.host_threads, use_graph=args.graphs) for _ in range(nstream - 1)]
     rast = {'pairs': [], 'on': False}
     bounds = [round(i * batch / nstream) for i in range(nstream + 1)]      # every tile of the batch goes to exactly one stream
 
@@ -265,9 +268,9 @@ def main():
 
     def single_stream(src):
         """One whole batch on the main stream through the first pipeline -> per-tile results in tile order."""
-        for f in pipe.submit(src):
+        for f in pipe_eager.submit(src):
             f.result()
-        return [f.result() for f in pipe.flush()]
+        return [f.result() for f in pipe_eager.flush()]
 
     # set-up, not measurement: one priming batch loads every kernel's code object, packs the weights into their kernel
     # layouts (PackedModule) and grows the allocator / pinned-buffer pools, so that even `--warmup 0` times steady state
@@ -282,7 +285,7 @@ def main():
     if world > 1:
         dist.barrier()
     rast['on'] = True
-    prof['on'] = nstream == 1      # with >1 streams kernels overlap: the roofline is measured in its own pass below
+    prof['on'] = nstream == 1 and not args.graphs      # with >1 streams kernels overlap (and a graph replay bypasses the hook): the roofline is measured in its own pass below
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
@@ -314,7 +317,7 @@ def main():
 
     roof_steps = args.steps
     roof_scope = 'HIP events around every launch inside the timed region (single stream)'
-    if nstream > 1:
+    if nstream > 1 or args.graphs:
         # per-launch durations are only meaningful when launches do not share the GPU: instrumented single-stream steps
         roof_steps = 2
         roof_scope = (f'{roof_steps} instrumented single-stream steps right after the timed region (in the timed region the batch is '
@@ -333,9 +336,9 @@ def main():
                 ops.bev_raster_batch(points, offs, rpar, out_u8=tiles, u8_only=True)
                 b.record()
                 rast['pairs'].append((a, b))
-            for f in pipe.submit(tiles):
+            for f in pipe_eager.submit(tiles):
                 f.result()
-        for f in pipe.flush():
+        for f in pipe_eager.flush():
             f.result()
         torch.cuda.synchronize()
         prof['on'] = False
@@ -398,7 +401,7 @@ def main():
         'ms_per_step': dt / args.steps * 1e3, 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
         'dtype': 'f32', 'data': 'synthetic',
         'config': {'workload': workload,
-                   'tiles_per_step_per_gpu': batch, 'lines_per_tile': n_lines, 'host_threads': args.host_threads, 'streams': nstream,
+                   'tiles_per_step_per_gpu': batch, 'lines_per_tile': n_lines, 'host_threads': args.host_threads, 'streams': nstream, 'hip_graphs': bool(args.graphs),
                    'stream_check': stream_check,
                    'host_postproc_ms_per_tile': 1e3 * sum(p_.host_seconds for p_ in [pipe] + extra_pipes) /
                    max(1, sum(p_.host_tiles for p_ in [pipe] + extra_pipes))},

@@ -159,6 +159,11 @@ __device__ void pick_bin(const unsigned* h, unsigned& need, unsigned& bin) {
     need = 0;
 }
 
+__global__ __launch_bounds__(256) void zero_u32_kernel(unsigned* __restrict__ p, long n) {
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i < n) p[i] = 0u;
+}
+
 template <int LEVEL>   // 0,1,2 = histogram passes; 3 = candidate compaction
 __global__ __launch_bounds__(256) void topk_pass_kernel(TopkParams p) {
     __shared__ unsigned lh[NB];
@@ -342,7 +347,10 @@ LM_API int lm_endp_topk(void* stream, const float* endp_logit, void* workspace, 
     p.cand_cnt = (unsigned*)(ws + (size_t)B * 3 * NB * sizeof(unsigned));
     p.cand = (unsigned long long*)(ws + (size_t)B * (3 * NB + 4) * sizeof(unsigned));
     p.H = H; p.W = W; p.clip = clip; p.K = K;
-    LM_HIP(hipMemsetAsync(workspace, 0, (size_t)B * (3 * NB + 4) * sizeof(unsigned), s));
+    // (a kernel, not hipMemsetAsync: the call sits inside HIP-graph captures of the tile pipeline, and replays of a captured memset
+    // node were observed to leave the histograms of the previous replay in place)
+    const long zero_words = (long)B * (3 * NB + 4);
+    hipLaunchKernelGGL(zero_u32_kernel, dim3(lm_cdiv(zero_words, 256)), dim3(256), 0, s, (unsigned*)workspace, zero_words);
     dim3 grid(256, B);
     hipLaunchKernelGGL(topk_pass_kernel<0>, grid, dim3(256), 0, s, p);
     hipLaunchKernelGGL(topk_pass_kernel<1>, grid, dim3(256), 0, s, p);

@@ -34,7 +34,9 @@ class PackedModule(nn.Module):
                 ev.record()
             cache = [key, P, ev, torch.cuda.current_stream().cuda_stream if ev is not None else None]
             self.__dict__['_packed_cache'] = cache
-        elif cache[2] is not None:
+        elif cache[2] is not None and not (torch.cuda.is_available() and torch.cuda.is_current_stream_capturing()):
+            # (not while a HIP graph is being captured: event queries invalidate the capture, and TilePipeline captures only after a
+            # warm-up run and a device synchronisation, i.e. with every packing kernel complete)
             if cache[2].query():
                 cache[2] = None
             elif torch.cuda.current_stream().cuda_stream != cache[3]:

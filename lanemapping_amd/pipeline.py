@@ -5,6 +5,7 @@ in C++ (ctypes releases the GIL), fanned out over a thread pool, one task per ti
 GPU work of the next batch.  Replaces the per-batch body of Runner.infer_lane_coordinate_endpoint_semantics
 (reference engine/runner.py:725-828) minus metrics / overlays.
 """
+import os
 import time
 from concurrent.futures import ThreadPoolExecutor
 
@@ -16,7 +17,12 @@ from ._lib import LanemapHipError
 
 
 class TilePipeline:
-    def __init__(self, net, host_threads=8):
+    def __init__(self, net, host_threads=8, use_graph=None):
+        """use_graph (default: env LANEMAP_GRAPHS=1): capture the device part of a batch (network + decode kernels, ~350 launches) into
+        one HIP graph per input shape and replay it - the host then spends one launch per batch instead of ~9 ms of enqueue work.
+        Same kernels, same arguments, same stream order: bit-identical outputs (test_tile_pipeline_graph_replay_bit_identical)."""
+        self.use_graph = (os.environ.get('LANEMAP_GRAPHS', '0') != '0') if use_graph is None else bool(use_graph)
+        self._graphs = {}
         self.net = net
         self.cfg = net.cfg
         self.rowref = net.cfg.heads.type == 'RowSharNotReducRef'
@@ -28,6 +34,39 @@ class TilePipeline:
         self.host_tiles = 0
 
     def _gpu_stage(self, proj):
+        if self.use_graph and torch.is_tensor(proj) and not self.rowref:      # (the RowRef head reads a mask on the host mid-forward)
+            dev, keep, crop = self._replay(proj)
+        else:
+            dev, keep, crop = self._device_part(proj)
+        host = {k: torch.empty(v.shape, dtype=v.dtype, pin_memory=True) for k, v in dev.items()}
+        for k in dev:
+            host[k].copy_(dev[k], non_blocking=True)
+        ev = torch.cuda.Event()
+        ev.record()
+        return host, ev, keep, crop
+
+    def _replay(self, proj):
+        """HIP-graph path: static input / output buffers per (shape, dtype); the first batch of a shape runs once eagerly (lazy
+        initialisation: weight packing, kernel attributes, workspaces) and is then captured on a stream of its own."""
+        key = (tuple(proj.shape), proj.dtype, proj.device)
+        ent = self._graphs.get(key)
+        if ent is None:
+            static_in = torch.empty_like(proj)
+            static_in.copy_(proj)
+            self._device_part(static_in)
+            torch.cuda.synchronize()
+            graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(graph, stream=torch.cuda.Stream(device=proj.device)):
+                out = self._device_part(static_in)
+            ent = (graph, static_in, out)
+            self._graphs[key] = ent
+        graph, static_in, out = ent
+        static_in.copy_(proj, non_blocking=True)
+        graph.replay()
+        return out
+
+    def _device_part(self, proj):
+        """Every device-side launch of a batch (no host reads, no pinned allocations: capturable): raw net outputs + decode kernels."""
         heads, cfg = self.net.heads, self.cfg
         # a [B,3,H,W] tile tensor (FPN path), a list of [N_i,4] point tensors (sparse-conv LiDAR path, config 5) or a batch dict
         batch = proj if isinstance(proj, dict) else ({'points': list(proj)} if isinstance(proj, (list, tuple)) else {'proj': proj})
@@ -47,12 +86,7 @@ class TilePipeline:
             dev = {'prop_conf': prop_conf, 'v_ext': v_ext, 'cls_offset': cls_offset, 'rows': rows, 'idx': idx, 'status': status}
             keep = (raw, sem, biseg, orient, cls_conf, cls_idx, dev)      # keep device buffers alive until the copies land
             crop = raw['endp_est'].shape[-1]
-        host = {k: torch.empty(v.shape, dtype=v.dtype, pin_memory=True) for k, v in dev.items()}
-        for k in dev:
-            host[k].copy_(dev[k], non_blocking=True)
-        ev = torch.cuda.Event()
-        ev.record()
-        return host, ev, keep, crop
+        return dev, keep, crop
 
     def _tile_task(self, host, b, crop_w):
         t0 = time.perf_counter()

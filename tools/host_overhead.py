@@ -18,7 +18,8 @@ net = net.to(dev)
 tiles = torch.from_numpy(synth.bev_batch([2021 + i for i in range(8)], 1152)).to(dev)
 NS = 4
 streams = [torch.cuda.current_stream()] + [torch.cuda.Stream(device=dev) for _ in range(NS - 1)]
-pipes = [TilePipeline(net) for _ in range(NS)]
+GRAPHS = os.environ.get('GRAPHS', '0') != '0'       # GRAPHS=1: the device part of every sub-batch replayed as one HIP graph
+pipes = [TilePipeline(net, use_graph=GRAPHS) for _ in range(NS)]
 
 
 def step():
@@ -44,4 +45,4 @@ t0 = time.perf_counter()
 enq = sum(step() for _ in range(10))
 torch.cuda.synchronize()
 tot = time.perf_counter() - t0
-print(f'step {tot / 10 * 1e3:.2f} ms, of which pure host enqueue (kernel launches, allocations, async copies) {enq / 10 * 1e3:.2f} ms')
+print(f'graphs={GRAPHS}: step {tot / 10 * 1e3:.2f} ms, of which pure host enqueue (kernel launches, allocations, async copies) {enq / 10 * 1e3:.2f} ms')
