@@ -331,6 +331,10 @@ def main():
             rast['pairs'] = []          # in the timed region the raster shares the GPU with the other streams' kernels
         for _ in range(roof_steps):
             if args.workload == 'fused':
+                # the GPU is idle at this point (the previous batch's results were waited for): an untimed launch first, so that the
+                # timed one is already queued behind it when its start event fires - the bracket then holds the two kernels'
+                # execution, not the host's argument marshalling for 16 tiles
+                ops.bev_raster_batch(points, offs, rpar, out_u8=tiles, u8_only=True)
                 a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                 a.record()
                 ops.bev_raster_batch(points, offs, rpar, out_u8=tiles, u8_only=True)
@@ -429,7 +433,8 @@ def main():
                                      'achieved': algb / (rms * 1e-3) / 1e9, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
                                      'frac': algb / (rms * 1e-3) / 1e9 / HBM_PEAK_GBS,
                                      'traffic': pmc.get('raster_bytes_per_step'), 'traffic_source': pmc.get('source'),
-                                     'algorithmic_bytes_per_step': algb, 'ms_per_step': rms, 'scope': roof_scope,
+                                     'algorithmic_bytes_per_step': algb, 'ms_per_step': rms,
+                                     'scope': roof_scope + ('; each timed raster launch is queued behind an untimed one, so the event bracket holds GPU execution only' if (nstream > 1 or args.graphs) else ''),
                                      'note': 'achieved = SURVEY 8(d) algorithmic bytes (16 B per point + the 3 x H x W f32 tile) / time; the tile is '
                                              'physically emitted as u8 HWC (its information content, 1/4 of the bytes) because its only consumer, '
                                              'the stem kernel, applies u8 / 255 itself (bit-identical); traffic = what the counters saw'}
