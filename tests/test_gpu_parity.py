@@ -1364,3 +1364,18 @@ def test_tile_pipeline_graph_replay_bit_identical(dev):
         for (la, ea), (lb, eb) in zip(want, got):
             assert np.array_equal(np.asarray(la), np.asarray(lb)) and np.array_equal(np.asarray(ea), np.asarray(eb))
     assert len(graph._graphs) == 2
+
+
+def test_bench_hip_graphs_four_streams(dev):
+    """`bench.py --graphs`: four HIP graphs (one per stream / sub-batch) replayed concurrently; the bench's own check compares the last
+    timed step bitwise with a kernel-by-kernel single-stream run (it raises SystemExit on any difference)."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, 'bench.py'), '--workload', 'tiles', '--graphs', '--steps', '3', '--warmup', '1',
+                        '--no-cpu-baseline'], capture_output=True, text=True, timeout=900, cwd=root)
+    assert r.returncode == 0, r.stderr[-2000:]
+    d = json.loads([l for l in r.stdout.strip().split('\n') if l.startswith('{')][-1])
+    assert d['value'] > 10 and d['config']['hip_graphs'] is True and d['config']['streams'] == 4
+    assert 'bitwise equal' in d['config']['stream_check'] and 0.0 < d['roofline']['frac'] <= 1.0
