@@ -759,10 +759,10 @@ __device__ __forceinline__ void wino_slab_transform(const float* raw, float* V, 
 // step's first MFMA (the compiler waits with lgkmcnt(0) at the first use of LDS data whenever LDS-DMA is in flight, so the only
 // reads outstanding at a wait must be the ones it needs).
 constexpr int BD = 7;
-template <int SLOT, int G, int NWAIT, bool NEXT>
+template <int SLOT, int G, int NWAIT, bool NEXT, int NL>
 __device__ __forceinline__ void wino_imp_step(f32x16& acc, f32x4 (&bq)[8][2], unsigned bvoff, const float* bpre_base, const float* anext0,
                                               const float* anext1, f32x4 (&a_cur)[2], f32x4 (&a_nxt)[2],
-                                              const float* const (&gsrc)[ILPW], long goff, float* rawbuf, int wave, int& gnext) {
+                                              const float* const (&gsrc)[NL], long goff, float* rawbuf, int wave, int& gnext) {
     typedef __attribute__((address_space(1))) const void gptr_t;
     typedef __attribute__((address_space(3))) void lptr_t;
 #ifndef LM_IABL_NOB                       // (timing ablations: tools/build_variant.sh)
@@ -1264,6 +1264,345 @@ __global__ __launch_bounds__(256) void wino_implicit_kernel(WinoImpParams p) {
 #endif
 }
 
+// =====================================================================================================================================
+// DUAL geometry (round 2, third version): TWO workgroups per CU.  With sixteen accumulators per wave (512 registers) a CU holds one
+// workgroup, and nothing runs under its transform phases, its prologue and its epilogue (26 % of the wide kernel's cycles, see the
+// phase table in DESIGN.md 3.1c).  Here a wave keeps EIGHT xi (128 AGPRs + <= 128 VGPRs = two waves per SIMD): a workgroup is
+// 32 tiles x 64 output channels, its four waves are (32-channel half nh) x (xi half xh); 16-channel slabs, 20 KB raw + 32 KB V of LDS.
+// While one workgroup transforms, waits at a barrier or stores its outputs, the other one's MFMAs own the SIMDs.
+// The fold needs all sixteen products: the xi < 8 waves fold their eight products (the PREFIX of the ascending-xi sum), hand the four
+// partial outputs over through LDS, and the xi >= 8 waves continue the same sum with theirs and store - the same sequence of
+// additions as everywhere else, bit-identical outputs.
+constexpr int DBM = 32, DBN = 64, DKS = 16, DLPW = 5;
+constexpr int DNCOL = 2 * DBM + 2 * INSEG;        // 72 column slots
+constexpr int DRAW = DLPW * 4 * 256;              // floats of the raw buffer (20 KB; cells 288.. are zero-source padding)
+constexpr int DVBUF = 16 * DBM * DKS;             // floats of the V slab (32 KB)
+static_assert(4 * DNCOL * DKS <= DRAW && DNCOL % 8 == 0, "dual geometry: patch loads cover the slab");
+
+// this thread's half of the slab transform: tile x channel quad x row pair ih (xi = 8 ih .. 8 ih + 7); arithmetic of wino_slab_transform
+__device__ __forceinline__ void wino_slab_transform_half(const float* raw, float* V, const int (&roff)[4], int voff, int ih) {
+    constexpr int ROWF = DNCOL * DKS;
+    f32x4 ra[4], rb[4];
+    if (ih == 0) {
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            const f32x4 d0 = *reinterpret_cast<const f32x4*>(raw + roff[c]);
+            const f32x4 d1 = *reinterpret_cast<const f32x4*>(raw + ROWF + roff[c]);
+            const f32x4 d2 = *reinterpret_cast<const f32x4*>(raw + 2 * ROWF + roff[c]);
+            ra[c] = d0 - d2;
+            rb[c] = d1 + d2;
+        }
+    } else {
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            const f32x4 d1 = *reinterpret_cast<const f32x4*>(raw + ROWF + roff[c]);
+            const f32x4 d2 = *reinterpret_cast<const f32x4*>(raw + 2 * ROWF + roff[c]);
+            const f32x4 d3 = *reinterpret_cast<const f32x4*>(raw + 3 * ROWF + roff[c]);
+            ra[c] = d2 - d1;
+            rb[c] = d1 - d3;
+        }
+    }
+    float* o = V + (8 * ih) * (DBM * DKS) + voff;
+    *reinterpret_cast<f32x4*>(o) = ra[0] - ra[2];
+    *reinterpret_cast<f32x4*>(o + DBM * DKS) = ra[1] + ra[2];
+    *reinterpret_cast<f32x4*>(o + 2 * DBM * DKS) = ra[2] - ra[1];
+    *reinterpret_cast<f32x4*>(o + 3 * DBM * DKS) = ra[1] - ra[3];
+    *reinterpret_cast<f32x4*>(o + 4 * DBM * DKS) = rb[0] - rb[2];
+    *reinterpret_cast<f32x4*>(o + 5 * DBM * DKS) = rb[1] + rb[2];
+    *reinterpret_cast<f32x4*>(o + 6 * DBM * DKS) = rb[2] - rb[1];
+    *reinterpret_cast<f32x4*>(o + 7 * DBM * DKS) = rb[1] - rb[3];
+}
+
+__device__ __forceinline__ float wino_fold_coef(int ab, int xi) {      // (A^T)[a][wi] (A^T)[b][wj], xi = 4 wi + wj
+    const int a = ab >> 1, b = ab & 1, wi = xi >> 2, wj = xi & 3;
+    const float ca = a == 0 ? (wi < 3 ? 1.f : 0.f) : (wi == 0 ? 0.f : (wi == 1 ? 1.f : -1.f));
+    const float cb = b == 0 ? (wj < 3 ? 1.f : 0.f) : (wj == 0 ? 0.f : (wj == 1 ? 1.f : -1.f));
+    return ca * cb;
+}
+
+__global__ __launch_bounds__(256, 2) void wino_dual_kernel(WinoImpParams p) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];      // raw patch slab [DRAW] | V slab [DVBUF]
+    float* const rawbuf = smem;
+    float* const Vbuf = smem + DRAW;
+    typedef __attribute__((address_space(1))) const void gptr_t;
+    typedef __attribute__((address_space(3))) void lptr_t;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int nh = wave & 1, xh = wave >> 1;            // 32-channel half, xi half (waves 0,1: xi 0..7; waves 2,3: xi 8..15)
+    const int wn0 = nh * 32;
+    const int n_tiles = (p.Cout + DBN - 1) / DBN;
+    unsigned mblk, ntile;
+    {   // XCD-aware order, N tile outer (see wino_implicit_kernel)
+        const unsigned bid = blockIdx.x, mb = gridDim.x / (unsigned)n_tiles, mbx = mb / 8, full = mbx * 8 * (unsigned)n_tiles;
+        if (bid < full) {
+            const unsigned xcd = bid % 8, idx = bid / 8;
+            ntile = idx / mbx;
+            mblk = xcd * mbx + idx % mbx;
+        } else {
+            const unsigned r = bid - full;
+            mblk = 8 * mbx + r / (unsigned)n_tiles;
+            ntile = r % (unsigned)n_tiles;
+        }
+    }
+    const long m0 = (long)mblk * DBM;
+    const int n0 = (int)ntile * DBN;
+    const WinoGeom& g = p.g;
+    const int bi = (int)(m0 / g.Tpad);
+    const int t0 = (int)(m0 - (long)bi * g.Tpad);
+    int ts[INSEG + 1], sn[INSEG], iy0[INSEG], ix0[INSEG], oy0[INSEG], ox0[INSEG];      // run table (see wino_implicit_kernel)
+    {
+        int at = 0, t = t0;
+        int tx = t0 % g.Tx, rest = t0 / g.Tx;
+        int ty = rest % g.Ty, ph = rest / g.Ty;
+        int pa = ph / g.dil, pb = ph - pa * g.dil;
+#pragma unroll
+        for (int s_ = 0; s_ < INSEG; ++s_) {
+            ts[s_] = at;
+            const bool real = t < g.Timg && at < DBM;
+            const int n = at < DBM ? min(DBM - at, g.Tx - tx) : 0;
+            sn[s_] = real ? n : 0;
+            iy0[s_] = (2 * ty - 1) * g.dil + pa;
+            ix0[s_] = (2 * tx - 1) * g.dil + pb;
+            oy0[s_] = 2 * ty * g.dil + pa;
+            ox0[s_] = 2 * tx * g.dil + pb;
+            at += n;
+            t += n;
+            tx += n;
+            if (tx >= g.Tx) {
+                tx = 0;
+                if (++ty >= g.Ty) {
+                    ty = 0;
+                    if (++pb >= g.dil) {
+                        pb = 0;
+                        ++pa;
+                    }
+                }
+            }
+        }
+        ts[INSEG] = at;
+    }
+    const float* gsrc[DLPW];
+    const int img_pix0 = bi * g.H * g.W;
+#pragma unroll
+    for (int s_ = 0; s_ < DLPW; ++s_) {
+        const int pos = (s_ * 4 + wave) * 16 + (lane >> 2);           // LDS cell position (16 cells of 64 B per wave load)
+        const int r = pos / DNCOL;
+        const int q = unrot3(pos - r * DNCOL);
+        const int ch = lane & 3;
+        int n = sn[0], yb = iy0[0], xb = ix0[0], q0 = 0;
+#pragma unroll
+        for (int k = 1; k < INSEG; ++k)
+            if (q >= 2 * ts[k] + 2 * k) {
+                n = sn[k]; yb = iy0[k]; xb = ix0[k]; q0 = 2 * ts[k] + 2 * k;
+            }
+        const int lc = q - q0;
+        const int yy = yb + r * g.dil, xx = xb + lc * g.dil;
+        const bool ok = r < 4 && lc < 2 * n + 2 && n > 0 && (unsigned)yy < (unsigned)g.H && (unsigned)xx < (unsigned)g.W;
+        gsrc[s_] = ok ? p.x + (long)(img_pix0 + yy * g.W + xx) * p.ldx + ch * 4 : p.zeros + ch * 4;
+    }
+    // transform task: tile (tid & 127) / 4, channel quad tid & 3, row pair tid / 128 (= xh: a wave transforms the xi it will multiply)
+    int roff[4], tvoff;
+    {
+        const int tl = (tid & 127) >> 2, qd = tid & 3;
+        int sg = 0;
+#pragma unroll
+        for (int k = 1; k < INSEG; ++k) sg += (ts[k] < DBM && tl >= ts[k]) ? 1 : 0;
+        const int cb = 2 * tl + 2 * sg;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) roff[c] = (rot3(cb + c) * 4 + qd) * 4;
+        tvoff = (tl * 4 + (qd ^ ((tl >> 2) & 3))) * 4;
+    }
+    const int frow = lane & 31, fhalf = lane >> 5;
+    int aoff[2];
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk) aoff[kk] = (frow * 4 + ((2 * kk + fhalf) ^ ((frow >> 2) & 3))) * 4;
+    const float* const Vx = Vbuf + (8 * xh) * (DBM * DKS);             // this wave's eight planes
+    const int cslabs = p.C / DKS;
+    const unsigned bvoff = (unsigned)lane * 16u;
+    const long bstep = (long)p.NT * 512;
+    const long bxi = (long)cslabs * bstep;
+    const float* const bbase = p.U + (long)((n0 + wn0) >> 5) * 512 + (long)(8 * xh) * bxi;
+
+    f32x16 acc[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[k][r] = 0.f;
+    f32x4 bq[8][2];
+#pragma unroll
+    for (int s_ = 0; s_ < DLPW; ++s_)
+        __builtin_amdgcn_global_load_lds((gptr_t*)gsrc[s_], (lptr_t*)(rawbuf + (s_ * 4 + wave) * 256), 16, 0, 0);
+#pragma unroll
+    for (int k = 0; k < BD; ++k) bload2(bq[k], bvoff, bbase + (long)k * bxi);
+#pragma unroll
+    for (int k = 0; k < BD; ++k) bwait<0>(bq[k]);
+    __builtin_amdgcn_s_barrier();
+    for (int cs = 0; cs < cslabs; ++cs) {
+        wino_slab_transform_half(rawbuf, Vbuf, roff, tvoff, xh);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        const bool more = cs + 1 < cslabs;
+        const long goff = more ? (long)(cs + 1) * DKS : 0;
+        const float* const bs = bbase + (long)cs * bstep;
+        const float* const bs_next = bbase + (long)(more ? cs + 1 : 0) * bstep;
+        int gnext = 0;
+        f32x4 a0[2], a1[2];
+        a0[0] = *reinterpret_cast<const f32x4*>(Vx + aoff[0]);
+        a0[1] = *reinterpret_cast<const f32x4*>(Vx + aoff[1]);
+        // eight steps (one per xi of this wave) per slab, B seven steps ahead in the ring of 8: a window of eight consecutive steps is
+        // one slab period, so the loads younger than a step's B fragments are always 14 B loads + the 5 patch loads: NWAIT = 19
+#define LM_DSTEP(K, AC, AN) \
+        wino_imp_step<K, ((K) < DLPW ? 1 : 0), 19, ((K) < 7)>(acc[K], bq, bvoff, (K) + BD < 8 ? bs + (long)((K) + BD) * bxi : bs_next + (long)((K) + BD - 8) * bxi, \
+                                                             Vx + ((K) + 1) * (DBM * DKS) + aoff[0], Vx + ((K) + 1) * (DBM * DKS) + aoff[1], AC, AN, gsrc, goff, \
+                                                             rawbuf, wave, gnext)
+        LM_DSTEP(0, a0, a1); LM_DSTEP(1, a1, a0); LM_DSTEP(2, a0, a1); LM_DSTEP(3, a1, a0);
+        LM_DSTEP(4, a0, a1); LM_DSTEP(5, a1, a0); LM_DSTEP(6, a0, a1); LM_DSTEP(7, a1, a0);
+#undef LM_DSTEP
+        bwait<6>(bq[0]);                       // the patch loads (last one in step 4) have landed: only steps 5..7's B loads are younger
+        __builtin_amdgcn_s_barrier();
+    }
+#pragma unroll
+    for (int k = 0; k < 8; ++k) bwait<0>(bq[k]);
+
+    // --- epilogue.  xi < 8 waves: prefix of the fold -> LDS; xi >= 8 waves: rest of the fold, transposes, stores.
+    float* const xchg = smem + nh * 4096;                              // [ab 4][r4 4][lane 64][4] floats per channel half
+    constexpr int ELD = 32 + 4;
+    float* const stage = smem + 8192 + nh * (32 * ELD);
+    static_assert(8192 + 2 * 32 * ELD <= DRAW + DVBUF, "dual epilogue buffers fit");
+    __syncthreads();                                   // every wave is done with the patch / V buffers
+    if (xh == 0) {
+#pragma unroll
+        for (int ab = 0; ab < 4; ++ab) {
+            f32x16 o;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) o[r] = 0.f;
+#pragma unroll
+            for (int xi = 0; xi < 8; ++xi) {
+                const float c = wino_fold_coef(ab, xi);
+                if (c == 0.f) continue;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) o[r] = fmaf(acc[xi][r], c, o[r]);
+            }
+#pragma unroll
+            for (int r4 = 0; r4 < 4; ++r4) {
+                f32x4 v = {o[4 * r4], o[4 * r4 + 1], o[4 * r4 + 2], o[4 * r4 + 3]};
+                *reinterpret_cast<f32x4*>(xchg + ((ab * 4 + r4) * 64 + lane) * 4) = v;
+            }
+        }
+    }
+    __syncthreads();
+    if (xh == 0) return;
+    constexpr int LPR = 8, RPI = 8, NP = 4;
+    const int c4 = (lane & 7) * 4;
+    const int n = n0 + wn0 + c4;
+    f32x4 sc = {1.f, 1.f, 1.f, 1.f}, sh = {0.f, 0.f, 0.f, 0.f};
+    if (n < p.Cout) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+            if (n + e < p.Cout) {
+                if (p.scale) sc[e] = p.scale[n + e];
+                if (p.shift) sh[e] = p.shift[n + e];
+            }
+    }
+    const bool vec = (n + 3 < p.Cout) && ((p.ldy & 3) == 0) && (!p.res || (p.ldr & 3) == 0);
+    f32x4 gs = {0.f, 0.f, 0.f, 0.f}, gq = {0.f, 0.f, 0.f, 0.f};
+    int pix0[NP];
+    unsigned vmask = 0;
+#pragma unroll
+    for (int pass = 0; pass < NP; ++pass) {
+        const int tl = pass * RPI + lane / LPR;
+        int nn = sn[0], oy = oy0[0], oxb = ox0[0], tb = 0;
+#pragma unroll
+        for (int k = 1; k < INSEG; ++k)
+            if (tl >= ts[k]) {
+                nn = sn[k]; oy = oy0[k]; oxb = ox0[k]; tb = ts[k];
+            }
+        const int ox = oxb + 2 * (tl - tb) * g.dil;
+        pix0[pass] = img_pix0 + oy * g.W + ox;
+        if (nn > 0 && oy < g.H && ox < g.W)
+            vmask |= (1u | (oy + g.dil < g.H ? 2u : 0u) | (ox + g.dil < g.W ? 4u : 0u)) << (3 * pass);
+    }
+    const int step_a = g.dil * g.W, step_b = g.dil;
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b) {
+            const int ab = 2 * a + b;
+            f32x16 o;
+#pragma unroll
+            for (int r4 = 0; r4 < 4; ++r4) {
+                const f32x4 v = *reinterpret_cast<const f32x4*>(xchg + ((ab * 4 + r4) * 64 + lane) * 4);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) o[4 * r4 + e] = v[e];
+            }
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                const float c = wino_fold_coef(ab, 8 + k);
+                if (c == 0.f) continue;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) o[r] = fmaf(acc[k][r], c, o[r]);
+            }
+            __builtin_amdgcn_wave_barrier();
+#pragma unroll
+            for (int r = 0; r < 16; ++r) stage[((r & 3) + 8 * (r >> 2) + 4 * fhalf) * ELD + frow] = o[r];
+            __builtin_amdgcn_wave_barrier();
+            if (n >= p.Cout) continue;
+#pragma unroll
+            for (int pass = 0; pass < NP; ++pass) {
+                const int row = pass * RPI + lane / LPR;
+                const unsigned vm = vmask >> (3 * pass);
+                if (!(vm & 1u) || (a && !(vm & 2u)) || (b && !(vm & 4u))) continue;
+                const long pix = pix0[pass] + a * step_a + b * step_b;
+                f32x4 v = *reinterpret_cast<const f32x4*>(stage + row * ELD + c4);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] = p.scale ? v[e] * sc[e] + sh[e] : v[e] + sh[e];
+                if (p.gn_part) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        gs[e] += v[e];
+                        gq[e] = fmaf(v[e], v[e], gq[e]);
+                    }
+                }
+                if (vec) {
+                    if (p.res) {
+                        const f32x4 rr = *reinterpret_cast<const f32x4*>(p.res + pix * p.ldr + n);
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) v[e] += rr[e];
+                    }
+                    if (p.act == LM_ACT_RELU) {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
+                    }
+                    *reinterpret_cast<f32x4*>(p.y + pix * p.ldy + n) = v;
+                } else {
+                    for (int e = 0; e < 4 && n + e < p.Cout; ++e) {
+                        float u = v[e];
+                        if (p.res) u += p.res[pix * p.ldr + n + e];
+                        if (p.act == LM_ACT_RELU) u = fmaxf(u, 0.f);
+                        p.y[pix * p.ldy + n + e] = u;
+                    }
+                }
+            }
+        }
+    if (p.gn_part && n < p.Cout) {
+#pragma unroll
+        for (int o = LPR; o < 64; o <<= 1)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                gs[e] += __shfl_xor(gs[e], o);
+                gq[e] += __shfl_xor(gq[e], o);
+            }
+        if (lane < LPR) {
+            const long chunk = t0 / 32;
+            double* o = p.gn_part + (((long)bi * (g.Tpad / 32) + chunk) * p.Cout + n) * 2;
+            for (int e = 0; e < 4 && n + e < p.Cout; ++e) {
+                o[2 * e] = (double)gs[e];
+                o[2 * e + 1] = (double)gq[e];
+            }
+        }
+    }
+}
+
 // runs of adjacent tiles a 64-tile block can touch: floor((IBM - 2) / Tx) + 2
 bool wino_implicit_ok(const WinoGeom& g) { return (IBM - 2) / g.Tx + 2 <= INSEG; }
 
@@ -1417,6 +1756,20 @@ int wino_implicit_launch(int mode, void* stream, const float* x, int ldx, const 
     const size_t lds = (size_t)(IRAW + IVBUF) * sizeof(float);
     // the WIDE geometry halves the transform work per matrix operation; it needs 128 real output channels per workgroup to pay
     static const bool wide_ok = !(getenv("LANEMAP_WINO_WIDE") && atoi(getenv("LANEMAP_WINO_WIDE")) == 0);
+    // DUAL geometry (two workgroups per CU): measured on B = 8 (tools/bench_wino.py, LANEMAP_WINO_DUAL=1 vs 0): 64->64@288^2 0.324 ->
+    // 0.290 ms, 128->128@144^2 0.248 -> 0.236, 128->256@144^2 0.461 -> 0.445, 256->256 d2@144^2 0.799 -> 0.793, but 256->256@288^2
+    // 3.25 -> 3.39 and 256->128@288^2 1.55 -> 1.58 (twice the transform and twice the input re-reads per matrix operation); end to
+    // end 252.7 tiles/s with it everywhere against 259.8, 260.4 with it on Cin <= 128, 260.9 on Cout <= 64.  Default: the layers the
+    // wide geometry cannot take (Cout <= 64).  LANEMAP_WINO_DUAL = 0: never, 1: every fp32 launch, 2: Cout <= 64, 3: Cin <= 128
+    static const int dual_sel = getenv("LANEMAP_WINO_DUAL") ? atoi(getenv("LANEMAP_WINO_DUAL")) : 2;
+    if (mode == 0 && (dual_sel == 1 || (dual_sel == 2 && Cout <= IBN) || (dual_sel == 3 && Cin <= 128))) {
+        const size_t dlds = (size_t)(DRAW + DVBUF) * sizeof(float);
+        const long dblocks = (p.g.T / DBM) * ((Cout + DBN - 1) / DBN);
+        LM_REQUIRE(dblocks > 0 && dblocks < (1L << 31) && p.g.T % DBM == 0, "conv_wino_implicit: bad grid %ld", dblocks);
+        hipLaunchKernelGGL(wino_dual_kernel, dim3((unsigned)dblocks), dim3(256), dlds, (hipStream_t)stream, p);
+        LM_LAUNCH_CHECK();
+        return LM_OK;
+    }
     if (mode == 0 && wide_ok && Cout > IBN && Cin % WKS == 0) mode = 2;
     static bool attr_set[3] = {false, false, false};
     const void* fn = mode == 0 ? (const void*)wino_implicit_kernel<0> : mode == 1 ? (const void*)wino_implicit_kernel<1> : (const void*)wino_implicit_kernel<2>;

@@ -1379,3 +1379,39 @@ def test_bench_hip_graphs_four_streams(dev):
     d = json.loads([l for l in r.stdout.strip().split('\n') if l.startswith('{')][-1])
     assert d['value'] > 10 and d['config']['hip_graphs'] is True and d['config']['streams'] == 4
     assert 'bitwise equal' in d['config']['stream_check'] and 0.0 < d['roofline']['frac'] <= 1.0
+
+
+@pytest.mark.parametrize('dual', ['0', '1'])
+def test_conv_winograd_geometries_bit_identical(dev, dual):
+    """The implicit Winograd kernel exists in three geometries (64 x 64, WIDE 32 x 128, DUAL 32 x 64 with the sixteen xi split over two
+    waves and the fold handed over through LDS).  The launcher picks by shape; LANEMAP_WINO_DUAL (read once per process) forces the
+    DUAL one everywhere (1) or nowhere (0): both runs must reproduce the materialising pair bit for bit with the residual / BN / ReLU
+    epilogue, and its GroupNorm statistics to fp32 summation-order accuracy."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = """
+import torch
+from lanemapping_amd import ops
+dev = torch.device('cuda:0')
+for (B, cin, cout, H, W, dil) in [(2, 128, 64, 84, 90, 2), (1, 256, 200, 43, 61, 1), (2, 64, 64, 96, 100, 1), (1, 160, 256, 85, 87, 2)]:
+    g = torch.Generator().manual_seed(cin + cout + H)
+    x = torch.randn((B, cin, H, W), generator=g).to(dev).permute(0, 2, 3, 1).contiguous().permute(0, 3, 1, 2)
+    r = torch.randn((B, cout, H, W), generator=g).to(dev).permute(0, 2, 3, 1).contiguous().permute(0, 3, 1, 2)
+    w = (torch.randn((cout, cin, 3, 3), generator=g) / (cin * 9) ** 0.5).to(dev)
+    sc, sh = (torch.rand(cout, generator=g) + 0.5).to(dev), torch.randn(cout, generator=g).to(dev)
+    wu = ops.pack_wino(w)
+    wf = ops.pack_wino_fragments(wu)
+    y0 = ops.conv_wino(x, wu, cout, dil, scale=sc, shift=sh, res=r, act=ops.ACT_RELU)
+    y1 = ops.conv_wino_implicit(x, wf, cout, dil, scale=sc, shift=sh, res=r, act=ops.ACT_RELU)
+    assert torch.equal(y0, y1), (cin, cout, float((y0 - y1).abs().max()))
+    if cout % 4 == 0 and cout in (64, 256):
+        a, sa = ops.conv_wino(x, wu, cout, dil, shift=sh, gn_eps=1e-5)
+        b, sb = ops.conv_wino_implicit(x, wf, cout, dil, shift=sh, gn_eps=1e-5)
+        # (y bit for bit; the statistics are fixed-order fp32 sums whose grouping differs between the kernels' epilogues)
+        assert torch.equal(a, b) and torch.allclose(sa, sb, rtol=2e-5, atol=1e-6), (cin, cout, 'gn', float((sa - sb).abs().max()))
+print('ok')
+"""
+    env = dict(os.environ, LANEMAP_WINO_DUAL=dual)
+    r = subprocess.run([sys.executable, '-c', code], capture_output=True, text=True, timeout=600, cwd=root, env=env)
+    assert r.returncode == 0 and r.stdout.strip().endswith('ok'), (r.stdout + r.stderr)[-2000:]
