@@ -24,7 +24,7 @@ for wl in ('fused', 'tiles'):
         f = glob.glob('$O/%s_%s/*counter_collection.csv' % (wl, c))[0]
         for r in csv.DictReader(open(f)):
             n = r['Kernel_Name']
-            k = ('wino_gemm' if 'wino_gemm' in n else 'wino_implicit' if 'wino_implicit' in n else 'wino_input' if 'wino_input' in n else
+            k = ('wino_gemm' if 'wino_gemm' in n else 'wino_implicit' if ('wino_implicit' in n or 'wino_dual' in n) else 'wino_input' if 'wino_input' in n else
                  'conv_mfma' if 'conv_mfma' in n else 'raster_partition' if 'raster_partition' in n else 'raster_band' if 'raster_band' in n else None)
             if k is None: continue
             per[k][c] += float(r['Counter_Value'])
