@@ -726,6 +726,27 @@ __device__ __forceinline__ void wino_imp_pair_split(f32x16& accx, f32x16& accy, 
 }
 
 // TRANSFORM phase, one thread = (tile tl, channel quad qd): V[xi][tl][4 qd ..] = (B^T d B)[xi] with the arithmetic of transform_store
+// Packed fp32 adds for the transform phases (no MFMA is in flight there): v_pk_add_f32 does two lanes of a sum per issue slot; the
+// compiler selects it for a + b but turns a - b (and a + (-b)) into four scalar v_sub_f32, so the subtraction is spelled out with
+// the negate modifiers.  IEEE fp32 adds either way: same bits.
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ f32x4 pk_sub4(const f32x4 a, const f32x4 b) {
+    const f32x2 alo = __builtin_shufflevector(a, a, 0, 1), ahi = __builtin_shufflevector(a, a, 2, 3);
+    const f32x2 blo = __builtin_shufflevector(b, b, 0, 1), bhi = __builtin_shufflevector(b, b, 2, 3);
+    f32x2 rlo, rhi;
+    asm("v_pk_add_f32 %0, %1, %2 neg_lo:[0,1] neg_hi:[0,1]" : "=v"(rlo) : "v"(alo), "v"(blo));
+    asm("v_pk_add_f32 %0, %1, %2 neg_lo:[0,1] neg_hi:[0,1]" : "=v"(rhi) : "v"(ahi), "v"(bhi));
+    return __builtin_shufflevector(rlo, rhi, 0, 1, 2, 3);
+}
+__device__ __forceinline__ f32x4 pk_add4(const f32x4 a, const f32x4 b) {
+    const f32x2 alo = __builtin_shufflevector(a, a, 0, 1), ahi = __builtin_shufflevector(a, a, 2, 3);
+    const f32x2 blo = __builtin_shufflevector(b, b, 0, 1), bhi = __builtin_shufflevector(b, b, 2, 3);
+    f32x2 rlo, rhi;
+    asm("v_pk_add_f32 %0, %1, %2" : "=v"(rlo) : "v"(alo), "v"(blo));
+    asm("v_pk_add_f32 %0, %1, %2" : "=v"(rhi) : "v"(ahi), "v"(bhi));
+    return __builtin_shufflevector(rlo, rhi, 0, 1, 2, 3);
+}
+
 template <int IROW>
 __device__ __forceinline__ void wino_slab_transform(const float* raw, float* V, const int (&roff)[4], int voff) {
     f32x4 r[4][4];
@@ -735,18 +756,18 @@ __device__ __forceinline__ void wino_slab_transform(const float* raw, float* V, 
         const f32x4 d1 = *reinterpret_cast<const f32x4*>(raw + IROW + roff[c]);
         const f32x4 d2 = *reinterpret_cast<const f32x4*>(raw + 2 * IROW + roff[c]);
         const f32x4 d3 = *reinterpret_cast<const f32x4*>(raw + 3 * IROW + roff[c]);
-        r[0][c] = d0 - d2;
-        r[1][c] = d1 + d2;
-        r[2][c] = d2 - d1;
-        r[3][c] = d1 - d3;
+        r[0][c] = pk_sub4(d0, d2);
+        r[1][c] = pk_add4(d1, d2);
+        r[2][c] = pk_sub4(d2, d1);
+        r[3][c] = pk_sub4(d1, d3);
     }
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
         float* o = V + (4 * i) * (IBM * IKS) + voff;
-        *reinterpret_cast<f32x4*>(o) = r[i][0] - r[i][2];
-        *reinterpret_cast<f32x4*>(o + IBM * IKS) = r[i][1] + r[i][2];
-        *reinterpret_cast<f32x4*>(o + 2 * IBM * IKS) = r[i][2] - r[i][1];
-        *reinterpret_cast<f32x4*>(o + 3 * IBM * IKS) = r[i][1] - r[i][3];
+        *reinterpret_cast<f32x4*>(o) = pk_sub4(r[i][0], r[i][2]);
+        *reinterpret_cast<f32x4*>(o + IBM * IKS) = pk_add4(r[i][1], r[i][2]);
+        *reinterpret_cast<f32x4*>(o + 2 * IBM * IKS) = pk_sub4(r[i][2], r[i][1]);
+        *reinterpret_cast<f32x4*>(o + 3 * IBM * IKS) = pk_sub4(r[i][1], r[i][3]);
     }
 }
 
@@ -1289,8 +1310,8 @@ __device__ __forceinline__ void wino_slab_transform_half(const float* raw, float
             const f32x4 d0 = *reinterpret_cast<const f32x4*>(raw + roff[c]);
             const f32x4 d1 = *reinterpret_cast<const f32x4*>(raw + ROWF + roff[c]);
             const f32x4 d2 = *reinterpret_cast<const f32x4*>(raw + 2 * ROWF + roff[c]);
-            ra[c] = d0 - d2;
-            rb[c] = d1 + d2;
+            ra[c] = pk_sub4(d0, d2);
+            rb[c] = pk_add4(d1, d2);
         }
     } else {
 #pragma unroll
@@ -1298,19 +1319,19 @@ __device__ __forceinline__ void wino_slab_transform_half(const float* raw, float
             const f32x4 d1 = *reinterpret_cast<const f32x4*>(raw + ROWF + roff[c]);
             const f32x4 d2 = *reinterpret_cast<const f32x4*>(raw + 2 * ROWF + roff[c]);
             const f32x4 d3 = *reinterpret_cast<const f32x4*>(raw + 3 * ROWF + roff[c]);
-            ra[c] = d2 - d1;
-            rb[c] = d1 - d3;
+            ra[c] = pk_sub4(d2, d1);
+            rb[c] = pk_sub4(d1, d3);
         }
     }
     float* o = V + (8 * ih) * (DBM * DKS) + voff;
-    *reinterpret_cast<f32x4*>(o) = ra[0] - ra[2];
-    *reinterpret_cast<f32x4*>(o + DBM * DKS) = ra[1] + ra[2];
-    *reinterpret_cast<f32x4*>(o + 2 * DBM * DKS) = ra[2] - ra[1];
-    *reinterpret_cast<f32x4*>(o + 3 * DBM * DKS) = ra[1] - ra[3];
-    *reinterpret_cast<f32x4*>(o + 4 * DBM * DKS) = rb[0] - rb[2];
-    *reinterpret_cast<f32x4*>(o + 5 * DBM * DKS) = rb[1] + rb[2];
-    *reinterpret_cast<f32x4*>(o + 6 * DBM * DKS) = rb[2] - rb[1];
-    *reinterpret_cast<f32x4*>(o + 7 * DBM * DKS) = rb[1] - rb[3];
+    *reinterpret_cast<f32x4*>(o) = pk_sub4(ra[0], ra[2]);
+    *reinterpret_cast<f32x4*>(o + DBM * DKS) = pk_add4(ra[1], ra[2]);
+    *reinterpret_cast<f32x4*>(o + 2 * DBM * DKS) = pk_sub4(ra[2], ra[1]);
+    *reinterpret_cast<f32x4*>(o + 3 * DBM * DKS) = pk_sub4(ra[1], ra[3]);
+    *reinterpret_cast<f32x4*>(o + 4 * DBM * DKS) = pk_sub4(rb[0], rb[2]);
+    *reinterpret_cast<f32x4*>(o + 5 * DBM * DKS) = pk_add4(rb[1], rb[2]);
+    *reinterpret_cast<f32x4*>(o + 6 * DBM * DKS) = pk_sub4(rb[2], rb[1]);
+    *reinterpret_cast<f32x4*>(o + 7 * DBM * DKS) = pk_sub4(rb[1], rb[3]);
 }
 
 __device__ __forceinline__ float wino_fold_coef(int ab, int xi) {      // (A^T)[a][wi] (A^T)[b][wj], xi = 4 wi + wj
