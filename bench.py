@@ -405,7 +405,8 @@ def main():
         'ms_per_step': dt / args.steps * 1e3, 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
         'dtype': 'f32', 'data': 'synthetic',
         'config': {'workload': workload,
-                   'tiles_per_step_per_gpu': batch, 'lines_per_tile': n_lines, 'host_threads': args.host_threads, 'streams': nstream, 'hip_graphs': bool(args.graphs),
+                   'tiles_per_step_per_gpu': batch, 'lines_per_tile': n_lines, 'host_threads': args.host_threads, 'streams': nstream, 'hip_graphs': bool(args.graphs and args.workload in ('fused', 'tiles')),      # (RowRef reads a mask on the host mid-forward, the LiDAR path sizes launches on the host: no capture)
+                  
                    'stream_check': stream_check,
                    'host_postproc_ms_per_tile': 1e3 * sum(p_.host_seconds for p_ in [pipe] + extra_pipes) /
                    max(1, sum(p_.host_tiles for p_ in [pipe] + extra_pipes))},
