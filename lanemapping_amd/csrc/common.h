@@ -15,6 +15,7 @@ enum {
 };
 
 void lm_set_error(const char* fmt, ...);
+int lm_ensure_dynamic_lds(const void* kernel, size_t bytes);   // per device and kernel, thread-safe (errors.cpp)
 
 #define LM_REQUIRE(cond, ...)            \
     do {                                 \

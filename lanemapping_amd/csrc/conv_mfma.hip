@@ -322,12 +322,7 @@ template <int BM, int BN, int WM, int WN, bool GATHER = false, int TPS = 1>
 int launch(const ConvParams& p, hipStream_t stream) {
     const size_t kloop = (size_t)2 * (BM + BN) * LDS_LD, stage = (size_t)4 * WM * (WN + 4);   // floats
     const size_t lds = (kloop > stage ? kloop : stage) * sizeof(float);
-    static bool attr_set = false;
-    if (!attr_set) {
-        LM_HIP(hipFuncSetAttribute((const void*)conv_mfma_kernel<BM, BN, WM, WN, GATHER, TPS>,
-                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        attr_set = true;
-    }
+    if (int e = lm_ensure_dynamic_lds((const void*)conv_mfma_kernel<BM, BN, WM, WN, GATHER, TPS>, lds)) return e;
     const long m_tiles = (p.M + BM - 1) / BM;
     const long blocks = m_tiles * ((p.Cout + BN - 1) / BN);
     LM_REQUIRE(blocks > 0 && blocks < (1L << 31), "conv_mfma: bad grid %ld", blocks);

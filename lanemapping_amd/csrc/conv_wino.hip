@@ -519,11 +519,7 @@ int launch_wino(const WinoParams& p, hipStream_t stream) {
     LM_REQUIRE(p.C % KB == 0, "conv_wino: Cin=%d must be a multiple of the %d-float K slab", p.C, KB);
     const size_t kloop = (size_t)NBUF * (BM + BN) * KB, stage = (size_t)(BM / WM) * (BN / WN) * WM * (WN + 4);
     const size_t lds = (kloop > stage ? kloop : stage) * sizeof(float);
-    static bool attr_set = false;
-    if (!attr_set) {
-        LM_HIP(hipFuncSetAttribute((const void*)wino_gemm_kernel<BM, BN, WM, WN, KB, NBUF>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        attr_set = true;
-    }
+    if (int e = lm_ensure_dynamic_lds((const void*)wino_gemm_kernel<BM, BN, WM, WN, KB, NBUF>, lds)) return e;
     const long blocks = ((p.g.T + BM - 1) / BM) * ((p.Cout + BN - 1) / BN);
     LM_REQUIRE(blocks > 0 && blocks < (1L << 31), "conv_wino: bad grid %ld", blocks);
     LM_REQUIRE(p.g.T % BM == 0, "conv_wino: %ld rows of V are not a multiple of the %d-row tile", p.g.T, BM);   // loads are unguarded
@@ -780,7 +776,7 @@ __device__ __forceinline__ void wino_slab_transform(const float* raw, float* V, 
 // step's first MFMA (the compiler waits with lgkmcnt(0) at the first use of LDS data whenever LDS-DMA is in flight, so the only
 // reads outstanding at a wait must be the ones it needs).
 constexpr int BD = 7;
-template <int SLOT, int G, int NWAIT, bool NEXT, int NL>
+template <int SLOT, int G, int NWAIT, bool NEXT, int NWV = 4, int NL>
 __device__ __forceinline__ void wino_imp_step(f32x16& acc, f32x4 (&bq)[8][2], unsigned bvoff, const float* bpre_base, const float* anext0,
                                               const float* anext1, f32x4 (&a_cur)[2], f32x4 (&a_nxt)[2],
                                               const float* const (&gsrc)[NL], long goff, float* rawbuf, int wave, int& gnext) {
@@ -793,7 +789,7 @@ __device__ __forceinline__ void wino_imp_step(f32x16& acc, f32x4 (&bq)[8][2], un
 #pragma unroll
     for (int g = 0; g < G; ++g) {
         const int s_ = gnext + g;
-        __builtin_amdgcn_global_load_lds((gptr_t*)(gsrc[s_] + goff), (lptr_t*)(rawbuf + (s_ * 4 + wave) * 256), 16, 0, 0);
+        __builtin_amdgcn_global_load_lds((gptr_t*)(gsrc[s_] + goff), (lptr_t*)(rawbuf + (s_ * NWV + wave) * 256), 16, 0, 0);
     }
 #endif
     gnext += G;
@@ -1624,6 +1620,432 @@ __global__ __launch_bounds__(256, 2) void wino_dual_kernel(WinoImpParams p) {
     }
 }
 
+// =====================================================================================================================================
+// OCTO geometry (round 3): the WIDE workgroup (32 tiles x 128 output channels) run by EIGHT waves = (32-channel quarter nq) x (xi
+// half xh), two waves per SIMD (waves w and w + 4 share SIMD w % 4: the same channel quarter, the two xi halves), 8 accumulators per
+// wave like the DUAL geometry - but ONE workgroup per CU, so the slab transform and the patch loads are paid once per 128 output
+// channels as in the wide kernel.  What the co-issue probes (tools/probes/coissue_probe*.hip, profiles/r3_coissue_probe.txt) measured
+// on v_mfma_f32_32x32x2_f32:
+//   - inside ONE wave a VALU instruction costs 8 cycles on top of the MFMA stream, a VMEM instruction 8-9, an LDS instruction nothing;
+//   - two waves of a SIMD that both stream MFMAs do NOT interleave: one keeps the matrix pipe until it stalls, the other waits, and
+//     the in-wave VALU / VMEM cost of either is paid in full (no s_setprio setting changes that);
+//   - a wave that issues NO MFMAs runs its VALU work at ~1.6 instructions per MFMA period and its LDS / VMEM work freely beside a
+//     streaming partner, at no cost to the partner.
+// So the two waves of a SIMD take turns.  Time is cut into slots, one 16-channel half-slab h each.  A wave's M phase is 64 MFMAs fed
+// from registers (all eight B fragment pairs of the slot) and LDS (A fragments): nothing but MFMAs and ds_reads.  Its X phase does
+// everything else for its next M phase - the 16 B-fragment loads, its patch loads of half-slab h + 2, its share of the transform of
+// half-slab h + 1 - while the partner wave is in ITS M phase:
+//     xi <  8 waves ("A"):   M(h) ; X ; barrier                 xi >= 8 waves ("B"):   M(h) ; barrier ; X
+// i.e. inside slot h the B wave runs X first (under A's MFMAs) and the A wave last (under B's).  Both roles execute the same
+// straight-line loop body; they differ in where the barrier sits and in the half-slab indices inside X.
+// LDS: raw[2] (24 KB each: 18 wave-loads of real cells + padding) and V[2] (32 KB each, [xi][tile][16 ch]) = 112 KB.
+// Same V bits, same per-accumulator channel order (ascending h), same fold order (prefix by the A waves, handed over through LDS,
+// continued by the B waves) => bit-identical to the other geometries; the B waves' epilogue is the wide kernel's (same GroupNorm
+// partial-sum grouping: one 32-tile x 32-channel wave tile).
+constexpr int OBM = 32, OBN = 128, OKS = 16, OLPW = 3;
+constexpr int ONCOL = 2 * OBM + 2 * INSEG;        // 72 column slots
+constexpr int ORAWH = OLPW * 8 * 256;             // floats of one raw half-slab buffer (24 KB; cells 288.. are zero-source padding)
+constexpr int OVH = 16 * OBM * OKS;               // floats of one V half-slab buffer (32 KB)
+static_assert(4 * ONCOL * OKS <= ORAWH && ONCOL % 8 == 0, "octo geometry: patch loads cover the half-slab");
+
+// this wave's share of a half-slab transform: 16 tiles x 4 channel quads, ONE row i of B^T d (xi = 4 i .. 4 i + 3).  Row i of B^T d
+// is P + sgn Q for two patch rows (P, Q) - fmaf(Q, +-1, P) is the IEEE sum / difference - and the column pass is wino_slab_transform's.
+__device__ __forceinline__ void wino_octo_transform(const float* raw, float* V, const int (&roff)[4], int poff, int qoff, float sgn) {
+    f32x4 r[4];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+        const f32x4 dp = *reinterpret_cast<const f32x4*>(raw + poff + roff[c]);
+        const f32x4 dq = *reinterpret_cast<const f32x4*>(raw + qoff + roff[c]);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) r[c][e] = __builtin_fmaf(dq[e], sgn, dp[e]);
+    }
+    *reinterpret_cast<f32x4*>(V) = pk_sub4(r[0], r[2]);
+    *reinterpret_cast<f32x4*>(V + OBM * OKS) = pk_add4(r[1], r[2]);
+    *reinterpret_cast<f32x4*>(V + 2 * OBM * OKS) = pk_sub4(r[2], r[1]);
+    *reinterpret_cast<f32x4*>(V + 3 * OBM * OKS) = pk_sub4(r[1], r[3]);
+}
+
+// One step (one xi of this wave) of an M phase: 8 MFMAs on B fragments that are already in registers; the A fragments of the next
+// step are read behind the first MFMA.
+template <bool NEXT>
+__device__ __forceinline__ void wino_octo_step(f32x16& acc, const f32x4 (&b)[2], const float* anext0, const float* anext1,
+                                               const f32x4 (&a_cur)[2], f32x4 (&a_nxt)[2]) {
+    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a_cur[0][0], b[0][0], acc, 0, 0, 0);
+    __builtin_amdgcn_sched_barrier(0);
+    if constexpr (NEXT) {
+        a_nxt[0] = *reinterpret_cast<const f32x4*>(anext0);
+        a_nxt[1] = *reinterpret_cast<const f32x4*>(anext1);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int t = 1; t < 4; ++t) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a_cur[0][t], b[0][t], acc, 0, 0, 0);
+#pragma unroll
+    for (int t = 0; t < 4; ++t) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a_cur[1][t], b[1][t], acc, 0, 0, 0);
+    __builtin_amdgcn_sched_barrier(0);
+}
+
+__global__ __launch_bounds__(512) void wino_octo_kernel(WinoImpParams p) {
+#ifdef LM_IPROF                              // phases of wave 0 (role A) in slots 0..4, of wave 4 (role B) in 5..9: set-up + prologue, M, T, barriers, epilogue
+    long long iprof[11] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    long long t_last = clock64();
+#endif
+    extern __shared__ __attribute__((aligned(16))) float smem[];      // raw[2][ORAWH] | V[2][OVH]
+    float* const raw0 = smem;
+    float* const V0 = smem + 2 * ORAWH;
+    typedef __attribute__((address_space(1))) const void gptr_t;
+    typedef __attribute__((address_space(3))) void lptr_t;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int nq = wave & 3, xh = wave >> 2;            // 32-channel quarter, xi half (waves 0..3: xi 0..7 = role A; 4..7: xi 8..15 = role B)
+    const int wn0 = nq * 32;
+    const int n_tiles = (p.Cout + OBN - 1) / OBN;
+    unsigned mblk, ntile;
+    {   // XCD-aware order, N tile outer (see wino_implicit_kernel)
+        const unsigned bid = blockIdx.x, mb = gridDim.x / (unsigned)n_tiles, mbx = mb / 8, full = mbx * 8 * (unsigned)n_tiles;
+        if (bid < full) {
+            const unsigned xcd = bid % 8, idx = bid / 8;
+            ntile = idx / mbx;
+            mblk = xcd * mbx + idx % mbx;
+        } else {
+            const unsigned r = bid - full;
+            mblk = 8 * mbx + r / (unsigned)n_tiles;
+            ntile = r % (unsigned)n_tiles;
+        }
+    }
+    const long m0 = (long)mblk * OBM;
+    const int n0 = (int)ntile * OBN;
+    const WinoGeom& g = p.g;
+    const int bi = (int)(m0 / g.Tpad);
+    const int t0 = (int)(m0 - (long)bi * g.Tpad);
+    int ts[INSEG + 1], sn[INSEG], iy0[INSEG], ix0[INSEG], oy0[INSEG], ox0[INSEG];      // run table (see wino_implicit_kernel)
+    {
+        int at = 0, t = t0;
+        int tx = t0 % g.Tx, rest = t0 / g.Tx;
+        int ty = rest % g.Ty, ph = rest / g.Ty;
+        int pa = ph / g.dil, pb = ph - pa * g.dil;
+#pragma unroll
+        for (int s_ = 0; s_ < INSEG; ++s_) {
+            ts[s_] = at;
+            const bool real = t < g.Timg && at < OBM;
+            const int n = at < OBM ? min(OBM - at, g.Tx - tx) : 0;
+            sn[s_] = real ? n : 0;
+            iy0[s_] = (2 * ty - 1) * g.dil + pa;
+            ix0[s_] = (2 * tx - 1) * g.dil + pb;
+            oy0[s_] = 2 * ty * g.dil + pa;
+            ox0[s_] = 2 * tx * g.dil + pb;
+            at += n;
+            t += n;
+            tx += n;
+            if (tx >= g.Tx) {
+                tx = 0;
+                if (++ty >= g.Ty) {
+                    ty = 0;
+                    if (++pb >= g.dil) {
+                        pb = 0;
+                        ++pa;
+                    }
+                }
+            }
+        }
+        ts[INSEG] = at;
+    }
+    // per-lane sources of this wave's OLPW patch loads per half-slab: wave-load L = s_ * 8 + wave covers 16 cells of 64 B
+    const float* gsrc[OLPW];
+    const int img_pix0 = bi * g.H * g.W;
+#pragma unroll
+    for (int s_ = 0; s_ < OLPW; ++s_) {
+        const int pos = (s_ * 8 + wave) * 16 + (lane >> 2);
+        const int r = pos / ONCOL;
+        const int q = unrot3(pos - r * ONCOL);
+        const int ch = lane & 3;
+        int n = sn[0], yb = iy0[0], xb = ix0[0], q0 = 0;
+#pragma unroll
+        for (int k = 1; k < INSEG; ++k)
+            if (q >= 2 * ts[k] + 2 * k) {
+                n = sn[k]; yb = iy0[k]; xb = ix0[k]; q0 = 2 * ts[k] + 2 * k;
+            }
+        const int lc = q - q0;
+        const int yy = yb + r * g.dil, xx = xb + lc * g.dil;
+        const bool ok = r < 4 && lc < 2 * n + 2 && n > 0 && (unsigned)yy < (unsigned)g.H && (unsigned)xx < (unsigned)g.W;
+        gsrc[s_] = ok ? p.x + (long)(img_pix0 + yy * g.W + xx) * p.ldx + ch * 4 : p.zeros + ch * 4;
+    }
+    // transform share of this wave: row i = 2 xh + (nq & 1) of B^T d, tiles 16 (nq >> 1) .. + 15 (lane >> 2), channel quad lane & 3
+    int roff[4], tvoff, tpoff, tqoff;
+    float tsgn;
+    {
+        const int ti = 2 * xh + (nq & 1);
+        const int tl = 16 * (nq >> 1) + (lane >> 2), qd = lane & 3;
+        int sg = 0;
+#pragma unroll
+        for (int k = 1; k < INSEG; ++k) sg += (ts[k] < OBM && tl >= ts[k]) ? 1 : 0;
+        const int cb = 2 * tl + 2 * sg;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) roff[c] = (rot3(cb + c) * 4 + qd) * 4;
+        tvoff = (4 * ti) * (OBM * OKS) + (tl * 4 + (qd ^ ((tl >> 2) & 3))) * 4;
+        constexpr int ROWF = ONCOL * OKS;
+        // row 0: d0 - d2 | 1: d1 + d2 | 2: d2 - d1 | 3: d1 - d3
+        tpoff = (ti == 0 ? 0 : ti == 2 ? 2 : 1) * ROWF;
+        tqoff = (ti == 0 ? 2 : ti == 1 ? 2 : ti == 2 ? 1 : 3) * ROWF;
+        tsgn = ti == 1 ? 1.f : -1.f;
+    }
+    const int frow = lane & 31, fhalf = lane >> 5;
+    int aoff[2];
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk) aoff[kk] = (8 * xh) * (OBM * OKS) + (frow * 4 + ((2 * kk + fhalf) ^ ((frow >> 2) & 3))) * 4;
+    const int H = p.C / OKS;                           // half-slabs (slots)
+    const unsigned bvoff = (unsigned)lane * 16u;
+    const long bstep = (long)p.NT * 512;
+    const long bxi = (long)H * bstep;
+    const float* const bbase = p.U + (long)((n0 + wn0) >> 5) * 512 + (long)(8 * xh) * bxi;
+
+    f32x16 acc[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[k][r] = 0.f;
+    f32x4 bq[8][2];
+    // prologue: raw half-slabs 0 and 1, the B fragments of slot 0, V of half-slab 0
+#pragma unroll
+    for (int s_ = 0; s_ < OLPW; ++s_)
+        __builtin_amdgcn_global_load_lds((gptr_t*)gsrc[s_], (lptr_t*)(raw0 + (s_ * 8 + wave) * 256), 16, 0, 0);
+#pragma unroll
+    for (int s_ = 0; s_ < OLPW; ++s_)
+        __builtin_amdgcn_global_load_lds((gptr_t*)(gsrc[s_] + OKS), (lptr_t*)(raw0 + ORAWH + (s_ * 8 + wave) * 256), 16, 0, 0);
+#pragma unroll
+    for (int k = 0; k < 8; ++k) bload2(bq[k], bvoff, bbase + (long)k * bxi);
+#pragma unroll
+    for (int k = 0; k < 8; ++k) bwait<0>(bq[k]);
+    __builtin_amdgcn_s_barrier();
+    wino_octo_transform(raw0, V0 + tvoff, roff, tpoff, tqoff, tsgn);                      // T(0): every wave its share
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    if (xh) {                                                                             // role B runs its X one half-slot ahead: patch loads of
+#pragma unroll                                                                            // half-slab 2 (raw(0) is spent), its share of T(1)
+        for (int s_ = 0; s_ < OLPW; ++s_)
+            __builtin_amdgcn_global_load_lds((gptr_t*)(gsrc[s_] + (H > 2 ? 2 * OKS : 0)), (lptr_t*)(raw0 + (s_ * 8 + wave) * 256), 16, 0, 0);
+        wino_octo_transform(raw0 + ORAWH, V0 + OVH + tvoff, roff, tpoff, tqoff, tsgn);
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    }
+    LM_TICK(0)
+    for (int h = 0; h < H; ++h) {
+        // ---- M(h): 64 MFMAs, B fragments from the ring (complete), A fragments from V[h & 1]
+        const float* const Vx = V0 + (h & 1) * OVH;
+        f32x4 a0[2], a1[2];
+        a0[0] = *reinterpret_cast<const f32x4*>(Vx + aoff[0]);
+        a0[1] = *reinterpret_cast<const f32x4*>(Vx + aoff[1]);
+#define LM_OSTEP(K, AC, AN) \
+        wino_octo_step<((K) < 7)>(acc[K], bq[K], Vx + ((K) + 1) * (OBM * OKS) + aoff[0], Vx + ((K) + 1) * (OBM * OKS) + aoff[1], AC, AN)
+        LM_OSTEP(0, a0, a1); LM_OSTEP(1, a1, a0); LM_OSTEP(2, a0, a1); LM_OSTEP(3, a1, a0);
+        LM_OSTEP(4, a0, a1); LM_OSTEP(5, a1, a0); LM_OSTEP(6, a0, a1); LM_OSTEP(7, a1, a0);
+#undef LM_OSTEP
+        LM_TICK(1)
+#ifndef LM_OABL_NOBAR
+        if (xh) __builtin_amdgcn_s_barrier();  // role B: slot h ends here
+#endif
+        LM_TICK(3)
+        // ---- X: everything this wave's NEXT M phase needs, issued while the partner wave multiplies.  Role A (second half of slot h):
+        // B fragments of slot h + 1, patch loads of half-slab h + 2, share of T(h + 1).  Role B (first half of slot h + 1): B fragments
+        // of slot h + 1, patch loads of half-slab h + 3, share of T(h + 2).  Past the last half-slab the loads re-read valid addresses
+        // and the transform works on stale data in buffers nobody reads any more.
+        {
+            const int hb = h + 1 < H ? h + 1 : 0;
+            const float* const bs = bbase + (long)hb * bstep;
+#ifndef LM_IABL_NOB
+#pragma unroll
+            for (int k = 0; k < 8; ++k) bload2(bq[k], bvoff, bs + (long)k * bxi);
+#endif
+            const int hl = h + 2 + xh, ht = h + 1 + xh;
+            const long goff = hl < H ? (long)hl * OKS : 0;
+            float* const rawld = raw0 + (hl & 1) * ORAWH;
+#ifndef LM_IABL_NOGLDS
+#pragma unroll
+            for (int s_ = 0; s_ < OLPW; ++s_)
+                __builtin_amdgcn_global_load_lds((gptr_t*)(gsrc[s_] + goff), (lptr_t*)(rawld + (s_ * 8 + wave) * 256), 16, 0, 0);
+#endif
+#ifndef LM_OABL_NOT
+            wino_octo_transform(raw0 + (ht & 1) * ORAWH, V0 + (ht & 1) * OVH + tvoff, roff, tpoff, tqoff, tsgn);
+#endif
+#pragma unroll
+            for (int k = 0; k < 8; ++k) bwait<0>(bq[k]);
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        }
+        LM_TICK(2)
+#ifndef LM_OABL_NOBAR
+        if (!xh) __builtin_amdgcn_s_barrier(); // role A: slot h ends here
+#endif
+        LM_TICK(3)
+    }
+
+    // (the lane index is re-derived here: kept live across the slot loop it cost the 257th register, i.e. a scratch spill)
+    const int elane = (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
+    const int efrow = elane & 31, efhalf = elane >> 5;
+    // --- epilogue.  A waves: prefix of the fold -> LDS; B waves: rest of the fold, transposes, stores (the wide kernel's epilogue).
+    float* const xchg = smem + nq * 4096;                              // [ab 4][r4 4][elane 64][4] floats per channel quarter
+    constexpr int ELD = 32 + 4;
+    float* const stage = smem + 4 * 4096 + nq * (32 * ELD);
+    static_assert(4 * 4096 + 4 * 32 * ELD <= 2 * ORAWH + 2 * OVH, "octo epilogue buffers fit");
+#ifdef LM_OABL_NOEPI
+    {   // timing ablation: no fold / hand-over / transposes / stores; one value per thread keeps the accumulators live
+        float sum = 0.f;
+#pragma unroll
+        for (int k = 0; k < 8; ++k)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) sum += acc[k][r];
+        p.y[(long)blockIdx.x * 512 + tid] = sum;
+        return;
+    }
+#endif
+    __syncthreads();                                   // every wave is done with the patch / V buffers
+    if (xh == 0) {
+#pragma unroll
+        for (int ab = 0; ab < 4; ++ab) {
+            f32x16 o;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) o[r] = 0.f;
+#pragma unroll
+            for (int xi = 0; xi < 8; ++xi) {
+                const float c = wino_fold_coef(ab, xi);
+                if (c == 0.f) continue;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) o[r] = fmaf(acc[xi][r], c, o[r]);
+            }
+#pragma unroll
+            for (int r4 = 0; r4 < 4; ++r4) {
+                f32x4 v = {o[4 * r4], o[4 * r4 + 1], o[4 * r4 + 2], o[4 * r4 + 3]};
+                *reinterpret_cast<f32x4*>(xchg + ((ab * 4 + r4) * 64 + elane) * 4) = v;
+            }
+        }
+    }
+    __syncthreads();
+#ifdef LM_IPROF
+    if (xh == 0) {
+        LM_TICK(4)
+        if (tid == 0) {
+#pragma unroll
+            for (int k = 0; k < 5; ++k) g_iprof[blockIdx.x % IPROF_WG][k] = (unsigned long long)iprof[k];
+            g_iprof[blockIdx.x % IPROF_WG][11] = 1ull;
+        }
+    }
+#endif
+    if (xh == 0) return;
+    constexpr int LPR = 8, RPI = 8, NP = 4;
+    const int c4 = (elane & 7) * 4;
+    const int n = n0 + wn0 + c4;
+    f32x4 sc = {1.f, 1.f, 1.f, 1.f}, sh = {0.f, 0.f, 0.f, 0.f};
+    if (n < p.Cout) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+            if (n + e < p.Cout) {
+                if (p.scale) sc[e] = p.scale[n + e];
+                if (p.shift) sh[e] = p.shift[n + e];
+            }
+    }
+    const bool vec = (n + 3 < p.Cout) && ((p.ldy & 3) == 0) && (!p.res || (p.ldr & 3) == 0);
+    f32x4 gs = {0.f, 0.f, 0.f, 0.f}, gq = {0.f, 0.f, 0.f, 0.f};
+    int pix0[NP];
+    unsigned vmask = 0;
+#pragma unroll
+    for (int pass = 0; pass < NP; ++pass) {
+        const int tl = pass * RPI + elane / LPR;
+        int nn = sn[0], oy = oy0[0], oxb = ox0[0], tb = 0;
+#pragma unroll
+        for (int k = 1; k < INSEG; ++k)
+            if (tl >= ts[k]) {
+                nn = sn[k]; oy = oy0[k]; oxb = ox0[k]; tb = ts[k];
+            }
+        const int ox = oxb + 2 * (tl - tb) * g.dil;
+        pix0[pass] = img_pix0 + oy * g.W + ox;
+        if (nn > 0 && oy < g.H && ox < g.W)
+            vmask |= (1u | (oy + g.dil < g.H ? 2u : 0u) | (ox + g.dil < g.W ? 4u : 0u)) << (3 * pass);
+    }
+    const int step_a = g.dil * g.W, step_b = g.dil;
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b) {
+            const int ab = 2 * a + b;
+            f32x16 o;
+#pragma unroll
+            for (int r4 = 0; r4 < 4; ++r4) {
+                const f32x4 v = *reinterpret_cast<const f32x4*>(xchg + ((ab * 4 + r4) * 64 + elane) * 4);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) o[4 * r4 + e] = v[e];
+            }
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                const float c = wino_fold_coef(ab, 8 + k);
+                if (c == 0.f) continue;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) o[r] = fmaf(acc[k][r], c, o[r]);
+            }
+            __builtin_amdgcn_wave_barrier();
+#pragma unroll
+            for (int r = 0; r < 16; ++r) stage[((r & 3) + 8 * (r >> 2) + 4 * efhalf) * ELD + efrow] = o[r];
+            __builtin_amdgcn_wave_barrier();
+            if (n >= p.Cout) continue;
+#pragma unroll
+            for (int pass = 0; pass < NP; ++pass) {
+                const int row = pass * RPI + elane / LPR;
+                const unsigned vm = vmask >> (3 * pass);
+                if (!(vm & 1u) || (a && !(vm & 2u)) || (b && !(vm & 4u))) continue;
+                const long pix = pix0[pass] + a * step_a + b * step_b;
+                f32x4 v = *reinterpret_cast<const f32x4*>(stage + row * ELD + c4);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] = p.scale ? v[e] * sc[e] + sh[e] : v[e] + sh[e];
+                if (p.gn_part) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        gs[e] += v[e];
+                        gq[e] = fmaf(v[e], v[e], gq[e]);
+                    }
+                }
+                if (vec) {
+                    if (p.res) {
+                        const f32x4 rr = *reinterpret_cast<const f32x4*>(p.res + pix * p.ldr + n);
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) v[e] += rr[e];
+                    }
+                    if (p.act == LM_ACT_RELU) {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
+                    }
+                    *reinterpret_cast<f32x4*>(p.y + pix * p.ldy + n) = v;
+                } else {
+                    for (int e = 0; e < 4 && n + e < p.Cout; ++e) {
+                        float u = v[e];
+                        if (p.res) u += p.res[pix * p.ldr + n + e];
+                        if (p.act == LM_ACT_RELU) u = fmaxf(u, 0.f);
+                        p.y[pix * p.ldy + n + e] = u;
+                    }
+                }
+            }
+        }
+    if (p.gn_part && n < p.Cout) {
+#pragma unroll
+        for (int o = LPR; o < 64; o <<= 1)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                gs[e] += __shfl_xor(gs[e], o);
+                gq[e] += __shfl_xor(gq[e], o);
+            }
+        if (elane < LPR) {
+            const long chunk = t0 / 32;
+            double* o = p.gn_part + (((long)bi * (g.Tpad / 32) + chunk) * p.Cout + n) * 2;
+            for (int e = 0; e < 4 && n + e < p.Cout; ++e) {
+                o[2 * e] = (double)gs[e];
+                o[2 * e + 1] = (double)gq[e];
+            }
+        }
+    }
+#ifdef LM_IPROF
+    LM_TICK(4)
+    if (tid == 256) {
+#pragma unroll
+        for (int k = 0; k < 5; ++k) g_iprof[blockIdx.x % IPROF_WG][5 + k] = (unsigned long long)iprof[k];
+    }
+#endif
+}
+
 // runs of adjacent tiles a 64-tile block can touch: floor((IBM - 2) / Tx) + 2
 bool wino_implicit_ok(const WinoGeom& g) { return (IBM - 2) / g.Tx + 2 <= INSEG; }
 
@@ -1787,17 +2209,26 @@ int wino_implicit_launch(int mode, void* stream, const float* x, int ldx, const 
         const size_t dlds = (size_t)(DRAW + DVBUF) * sizeof(float);
         const long dblocks = (p.g.T / DBM) * ((Cout + DBN - 1) / DBN);
         LM_REQUIRE(dblocks > 0 && dblocks < (1L << 31) && p.g.T % DBM == 0, "conv_wino_implicit: bad grid %ld", dblocks);
+        if (int e = lm_ensure_dynamic_lds((const void*)wino_dual_kernel, dlds)) return e;      // (52 KB: below the default limit, set anyway)
         hipLaunchKernelGGL(wino_dual_kernel, dim3((unsigned)dblocks), dim3(256), dlds, (hipStream_t)stream, p);
         LM_LAUNCH_CHECK();
         return LM_OK;
     }
-    if (mode == 0 && wide_ok && Cout > IBN && Cin % WKS == 0) mode = 2;
-    static bool attr_set[3] = {false, false, false};
-    const void* fn = mode == 0 ? (const void*)wino_implicit_kernel<0> : mode == 1 ? (const void*)wino_implicit_kernel<1> : (const void*)wino_implicit_kernel<2>;
-    if (!attr_set[mode]) {
-        LM_HIP(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        attr_set[mode] = true;
+    // OCTO geometry (round 3): the wide workgroup run by eight waves, two per SIMD half a phase apart (wino_octo_kernel).
+    // LANEMAP_WINO_OCTO = 1: wherever the wide kernel would run; default 0 (measured: no faster than the wide kernel)
+    static const bool octo_ok = getenv("LANEMAP_WINO_OCTO") && atoi(getenv("LANEMAP_WINO_OCTO")) != 0;
+    if (mode == 0 && octo_ok && wide_ok && Cout > IBN && Cin % WKS == 0) {
+        const size_t olds = (size_t)(2 * ORAWH + 2 * OVH) * sizeof(float);
+        const long oblocks = (p.g.T / OBM) * ((Cout + OBN - 1) / OBN);
+        LM_REQUIRE(oblocks > 0 && oblocks < (1L << 31) && p.g.T % OBM == 0, "conv_wino_implicit: bad grid %ld", oblocks);
+        if (int e = lm_ensure_dynamic_lds((const void*)wino_octo_kernel, olds)) return e;
+        hipLaunchKernelGGL(wino_octo_kernel, dim3((unsigned)oblocks), dim3(512), olds, (hipStream_t)stream, p);
+        LM_LAUNCH_CHECK();
+        return LM_OK;
     }
+    if (mode == 0 && wide_ok && Cout > IBN && Cin % WKS == 0) mode = 2;
+    const void* fn = mode == 0 ? (const void*)wino_implicit_kernel<0> : mode == 1 ? (const void*)wino_implicit_kernel<1> : (const void*)wino_implicit_kernel<2>;
+    if (int e = lm_ensure_dynamic_lds(fn, lds)) return e;
     const int bm = mode == 2 ? WBM : IBM, bn = mode == 2 ? WBN : IBN;
     const long blocks = (p.g.T / bm) * ((Cout + bn - 1) / bn);
     LM_REQUIRE(blocks > 0 && blocks < (1L << 31) && p.g.T % bm == 0, "conv_wino_implicit: bad grid %ld", blocks);

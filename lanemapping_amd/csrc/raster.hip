@@ -356,11 +356,7 @@ LM_API int lm_bev_raster_batch(void* stream, const float* points_xyzi, const lon
     unsigned* counts = (unsigned*)workspace;
     unsigned* records = (unsigned*)((char*)workspace + (((long)B * nbands * nblk_max * sizeof(unsigned) + 255) / 256) * 256);
     const size_t lds = (size_t)band_rows * W * sizeof(unsigned);
-    static size_t lds_set = 0;
-    if (lds > lds_set) {
-        LM_HIP(hipFuncSetAttribute((const void*)raster_band_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        lds_set = lds;
-    }
+    if (int e = lm_ensure_dynamic_lds((const void*)raster_band_kernel, lds)) return e;
     const long HW = (long)H * W;
     for (int b0 = 0; b0 < B; b0 += MAX_TILES) {
         const int nb = (B - b0) < MAX_TILES ? (B - b0) : MAX_TILES;

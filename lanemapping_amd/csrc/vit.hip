@@ -204,11 +204,7 @@ LM_API int lm_attention_f32(void* stream, const float* qkv, float* out, int B, i
     LM_REQUIRE(dim_head == DH, "attention: dim_head=%d must be %d", dim_head, DH);
     if (N > NPAD - 32 && N <= NPAD) {       // the ViT block (324 tokens): matrix cores
         const size_t lds_m = (size_t)NPAD * KP * sizeof(float);
-        static bool set_m = false;
-        if (!set_m) {
-            LM_HIP(hipFuncSetAttribute((const void*)attention_mfma_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_m));
-            set_m = true;
-        }
+        if (int e = lm_ensure_dynamic_lds((const void*)attention_mfma_kernel, lds_m)) return e;
         hipLaunchKernelGGL(attention_mfma_kernel, dim3(lm_cdiv(lm_cdiv(N, 32), 4), heads, B), dim3(256), lds_m, (hipStream_t)stream, qkv, out,
                            N, heads, scale);
         LM_LAUNCH_CHECK();
@@ -216,11 +212,7 @@ LM_API int lm_attention_f32(void* stream, const float* qkv, float* out, int B, i
     }
     const size_t lds = ((size_t)N * KLD + (size_t)QC * (N + 4) + QC * DH) * sizeof(float);
     LM_REQUIRE(lds <= 160 * 1024, "attention: N=%d does not fit LDS", N);
-    static size_t lds_set = 0;
-    if (lds > lds_set) {
-        LM_HIP(hipFuncSetAttribute((const void*)attention_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        lds_set = lds;
-    }
+    if (int e = lm_ensure_dynamic_lds((const void*)attention_kernel, lds)) return e;
     hipLaunchKernelGGL(attention_kernel, dim3(lm_cdiv(N, QC), heads, B), dim3(256), lds, (hipStream_t)stream, qkv, out, N, heads, scale);
     LM_LAUNCH_CHECK();
     return LM_OK;
