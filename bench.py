@@ -30,6 +30,20 @@ N_PTS = 4194304                   # points per tile of the fused workload (SURVE
 PMC_FILE = os.path.join(ROOT, 'profiles', 'pmc_traffic.json')     # counter bytes per step, collected offline (tools/pmc_traffic.sh)
 
 
+def csrc_sha16():
+    """Stamp of the kernel sources (lanemapping_amd/csrc): tools/pmc_traffic.sh stores it with the counter bytes it collects, bench.py
+    compares - `traffic_stale` says the committed counters were measured on other kernels than the ones that just ran."""
+    import hashlib
+    d = os.path.join(ROOT, 'lanemapping_amd', 'csrc')
+    h = hashlib.sha256()
+    for name in sorted(os.listdir(d)):
+        if name.endswith(('.hip', '.cpp', '.h')):
+            h.update(name.encode())
+            with open(os.path.join(d, name), 'rb') as f:
+                h.update(f.read())
+    return h.hexdigest()[:16]
+
+
 def usable_cores():
     """Cores this process may actually use: affinity mask, capped by the cgroup CPU quota if there is one."""
     n = len(os.sched_getaffinity(0)) if hasattr(os, 'sched_getaffinity') else (os.cpu_count() or 1)
@@ -107,7 +121,12 @@ def main():
     ap.add_argument('--warmup', type=int, default=3)
     ap.add_argument('--cpu-budget-s', type=float, default=25.0)
     ap.add_argument('--no-cpu-baseline', action='store_true')
-    ap.add_argument('--host-threads', type=int, default=8)
+    ap.add_argument('--host-threads', type=int, default=None, help='post-processing pool threads per pipeline (default 8; max(1, K - 1) under --host-cores K)')
+    ap.add_argument('--host-cores', type=int, default=None,
+                    help='per-rank host budget: pin this process (rank r) to K of the cores it may use, cores [r*K, (r+1)*K), BEFORE any GPU call - '
+                         'the 1-GPU proxy for an 8-rank node where every rank only has usable_cores/8.  K <= 4 switches HIP graphs on (one '
+                         'launch per sub-batch instead of ~350) unless --no-graphs')
+    ap.add_argument('--no-graphs', action='store_true', help='never switch HIP graphs on automatically')
     ap.add_argument('--workload', choices=['fused', 'tiles', 'rowref', 'lidar'], default='fused',
                     help="fused = BASELINE configs[2], the headline (on-GPU LAS->BEV raster + config 2, batch 16); tiles = configs[1] "
                          "(pre-rasterised, batch 8); rowref = configs[3] (Proj28_GFC-T3_RowRef head, pre-rasterised, batch 8); lidar = "
@@ -133,6 +152,21 @@ def main():
     if world != args.gpus:
         raise SystemExit(f'--gpus {args.gpus} but WORLD_SIZE={world}: launch with `python bench.py --gpus N` (spawns the ranks itself) '
                          f'or `python -m torch.distributed.run --nproc-per-node N bench.py --gpus N`')
+    # ---- per-rank host budget (nothing has touched the GPU yet: no HIP call, no torch.cuda.is_available)
+    cores_avail = usable_cores()
+    if args.host_cores is not None:
+        if args.host_cores < 1:
+            raise SystemExit('--host-cores must be >= 1')
+        allowed = sorted(os.sched_getaffinity(0))
+        k = min(args.host_cores, len(allowed))
+        mine = allowed[(local_rank * k) % len(allowed):][:k] or allowed[:k]
+        os.sched_setaffinity(0, set(mine))
+        torch.set_num_threads(max(1, k))
+        if k <= 4 and not args.no_graphs and args.workload in ('fused', 'tiles'):
+            args.graphs = True
+    host_cores_per_rank = len(os.sched_getaffinity(0)) if args.host_cores is not None else min(cores_avail, len(os.sched_getaffinity(0)))
+    if args.host_threads is None:
+        args.host_threads = 8 if args.host_cores is None else max(1, host_cores_per_rank - 1)
     import torch.distributed as dist
     # test hooks (tests/test_gpu_parity.py exercises the N>1 code path on a 1-GPU box): every rank on one device, gloo backend
     dev_index = int(os.environ.get('LANEMAP_BENCH_DEVICE', local_rank))
@@ -249,12 +283,12 @@ def main():
     inflight = []
 
     def gather(res):
-        """One all-gather of the fixed-shape polyline blocks per batch, on its own stream: neither the staging copy nor the
+        """ONE all-gather of the fixed-shape per-tile byte blocks per batch, on its own stream: neither the staging copy nor the
         collective queues behind (or in front of) the compute streams, and the host does not wait for them."""
         if world > 1 and res:
             with torch.cuda.stream(comm):
-                blocks = shard.pack_tile_results([r[0] for r in res], [r[1] for r in res], batch, dev, pinned=True)
-                inflight.append((blocks, shard.all_gather_results(*blocks)))
+                block = shard.pack_tile_results([r[0] for r in res], [r[1] for r in res], batch, dev, pinned=True)
+                inflight.append((block, shard.all_gather_results(block), res))     # ONE collective per batch
             del inflight[:-4]
 
     def drain():
@@ -300,6 +334,45 @@ def main():
         t = torch.tensor([dt], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
+
+    # ---- N > 1: what the last all-gather delivered.  Every rank holds the rank-major concatenation: all world x batch slots must be valid
+    # tiles, this rank's slice must be the block it sent bit for bit and must unpack to the results of its last batch; the verdict
+    # of all ranks is combined so that rank 0's line speaks for the job
+    gather_check = 'n/a (1 rank)'
+    if world > 1:
+        ok = 0
+        if inflight:
+            comm.synchronize()
+            block, gathered, res_l = inflight[-1]
+            slots = shard.unpack_gathered(gathered, include_padding=True)
+            mine = slots[rank * batch:(rank + 1) * batch]
+            ok = int(tuple(gathered.shape) == (world * batch, shard.TILE_BYTES) and all(s_ is not None for s_ in slots)
+                     and torch.equal(gathered[rank * batch:(rank + 1) * batch], block) and len(res_l) == batch
+                     and all(np.array_equal(m[0], np.asarray(r_[0], dtype=np.float64)) and
+                             np.array_equal(m[1], np.asarray(r_[1], dtype=np.int32).reshape(-1, 2)) for m, r_ in zip(mine, res_l)))
+        t = torch.tensor([ok], device=dev, dtype=torch.int32)
+        dist.all_reduce(t, op=dist.ReduceOp.MIN)
+        if int(t.item()) != 1:
+            raise SystemExit(f'gather check FAILED on rank {rank}: the all-gathered block does not hold world x batch valid tiles equal to the per-rank results')
+        gather_check = (f'last all-gather: {world * batch} valid tiles in one [{world * batch}, {shard.TILE_BYTES}] byte block; on every rank its own slice '
+                        f'is bitwise the block it sent and unpacks to the lanes / endpoints of its last batch')
+
+    # ---- fused workload: the rasteriser's tiles of the last timed step against the scalar C oracle (oracle/raster_ref.c) - the first
+    # and the last tile of the 16-tile launch (a wrong record slot at a high chunk index, or in the last BatchArgs entry, shows here).
+    # Checker leg, outside the clock.
+    raster_check = 'n/a'
+    if args.workload == 'fused' and args.steps > 0 and not args.no_stream_check:
+        from oracle import raster_ref
+        lb = tile_bufs[(state['i'] - 1) & 1]
+        rp = raster_ref.params(local_min_ele=-0.5, ele_reso=0.02)
+        for t_ in (0, batch - 1):
+            want = raster_ref.raster(clouds[t_ % 4].numpy(), rp, 1152, 1152)
+            got = lb[t_].cpu().numpy()
+            if not np.array_equal(got, want):
+                raise SystemExit(f'raster check FAILED: tile {t_} of the last timed step differs from oracle/raster_ref.c in '
+                                 f'{int((got != want).any(axis=2).sum())} pixels')
+        raster_check = (f'tiles 0 and {batch - 1} of the last timed {batch} x {N_PTS}-point launch equal oracle/raster_ref.c bit for bit '
+                        f'(u8 HWC, {1152 * 1152} pixels each)')
 
     # ---- the product path the clock just timed splits each batch over `nstream` streams / pipelines: its outputs for the last step
     # must equal a single-stream run on the same tiles BITWISE (a cross-stream race on workspaces or packed weights would show here)
@@ -387,6 +460,7 @@ def main():
     except (OSError, ValueError):
         pass
     mfma_traffic = pmc.get('mfma_bytes_per_step')
+    traffic_stale = pmc.get('csrc_sha16') != csrc_sha16()      # the counters were collected on other kernel sources than the ones that ran
     n_lines = int(np.mean([(np.count_nonzero(l[:, :, 0] > 0, axis=1) >= 2).sum() for l, _ in last])) if last else 0
     what = {'tiles': 'pre-rasterised tile', 'fused': 'LAS points', 'lidar': 'LiDAR point cloud', 'rowref': 'pre-rasterised tile'}[args.workload]
     workload = {
@@ -407,7 +481,8 @@ def main():
         'config': {'workload': workload,
                    'tiles_per_step_per_gpu': batch, 'lines_per_tile': n_lines, 'host_threads': args.host_threads, 'streams': nstream, 'hip_graphs': bool(args.graphs and args.workload in ('fused', 'tiles')),      # (RowRef reads a mask on the host mid-forward, the LiDAR path sizes launches on the host: no capture)
                   
-                   'stream_check': stream_check,
+                   'stream_check': stream_check, 'gather_check': gather_check, 'raster_check': raster_check,
+                   'host_cores_per_rank': host_cores_per_rank, 'host_cores_pinned': args.host_cores is not None,
                    'host_postproc_ms_per_tile': 1e3 * sum(p_.host_seconds for p_ in [pipe] + extra_pipes) /
                    max(1, sum(p_.host_tiles for p_ in [pipe] + extra_pipes))},
         'roofline': {'bound': 'mfma',
@@ -417,7 +492,7 @@ def main():
                      'achieved': executed_tflops, 'peak': MFMA_F32_PEAK_TFLOPS, 'unit': 'TFLOP/s',
                      # time-weighted utilisation: sum_k (executed_k / peak_k) / sum_k t_k  (== achieved / peak when every launch is fp32 MFMA)
                      'frac': (sum(e[3] / peak_of(k) for k, e in cls.items()) / (conv_ms * 1e-3) / 1e12) if conv_ms > 0 else 0.0,
-                     'traffic': mfma_traffic, 'traffic_source': pmc.get('source'),
+                     'traffic': mfma_traffic, 'traffic_source': pmc.get('source'), 'traffic_stale': traffic_stale,
                      'algorithmic_equiv_tflops': alg_tflops,
                      'scope': roof_scope, 'launches_per_step': prof['launches'] / rs,
                      'executed_gflop_per_step': exe / rs / 1e9, 'algorithmic_gflop_per_step': alg / rs / 1e9,
@@ -430,20 +505,22 @@ def main():
     if args.workload == 'fused' and rast['pairs']:
         rms = sum(a.elapsed_time(b) for a, b in rast['pairs']) / len(rast['pairs'])
         algb = (16.0 * N_PTS + 3 * 1152 * 1152 * 4) * batch
+        movedb = (16.0 * N_PTS + 3 * 1152 * 1152) * batch          # what this design has to move: the tile leaves as u8
         result['raster_roofline'] = {'bound': 'hbm', 'kernel': 'raster_partition_kernel + raster_band_kernel',
                                      'achieved': algb / (rms * 1e-3) / 1e9, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
                                      'frac': algb / (rms * 1e-3) / 1e9 / HBM_PEAK_GBS,
-                                     'traffic': pmc.get('raster_bytes_per_step'), 'traffic_source': pmc.get('source'),
+                                     'frac_moved': movedb / (rms * 1e-3) / 1e9 / HBM_PEAK_GBS, 'moved_bytes_per_step': movedb,
+                                     'traffic': pmc.get('raster_bytes_per_step'), 'traffic_source': pmc.get('source'), 'traffic_stale': traffic_stale,
                                      'algorithmic_bytes_per_step': algb, 'ms_per_step': rms,
                                      'scope': roof_scope + ('; each timed raster launch is queued behind an untimed one, so the event bracket holds GPU execution only' if (nstream > 1 or args.graphs) else ''),
                                      'note': 'achieved = SURVEY 8(d) algorithmic bytes (16 B per point + the 3 x H x W f32 tile) / time; the tile is '
                                              'physically emitted as u8 HWC (its information content, 1/4 of the bytes) because its only consumer, '
-                                             'the stem kernel, applies u8 / 255 itself (bit-identical); traffic = what the counters saw'}
+                                             'the stem kernel, applies u8 / 255 itself (bit-identical); frac_moved = the honest numerator of this '
+                                             'design (16 B per point + the 3 x H x W u8 tile) / time / peak; traffic = what the counters saw'}
     if rank == 0:
-        if world == 1 and not args.no_cpu_baseline:
-            result['cpu_baseline'] = cpu_baseline(args.cpu_budget_s)
-        else:
-            result['cpu_baseline'] = None
+        # the CPU path timed on this node's own host cores in the same run, next to the 1 / 2 / 4 / 8-GPU numbers (north_star); at N > 1
+        # the other ranks are parked in the barrier below meanwhile, so the oracle has the host to itself
+        result['cpu_baseline'] = None if args.no_cpu_baseline else cpu_baseline(args.cpu_budget_s)
         print(json.dumps(result), flush=True)
     if world > 1:
         dist.barrier()

@@ -776,7 +776,7 @@ __device__ __forceinline__ void wino_slab_transform(const float* raw, float* V, 
 // step's first MFMA (the compiler waits with lgkmcnt(0) at the first use of LDS data whenever LDS-DMA is in flight, so the only
 // reads outstanding at a wait must be the ones it needs).
 constexpr int BD = 7;
-template <int SLOT, int G, int NWAIT, bool NEXT, int NWV = 4, int NL>
+template <int SLOT, int G, int NWAIT, bool NEXT, int NL>
 __device__ __forceinline__ void wino_imp_step(f32x16& acc, f32x4 (&bq)[8][2], unsigned bvoff, const float* bpre_base, const float* anext0,
                                               const float* anext1, f32x4 (&a_cur)[2], f32x4 (&a_nxt)[2],
                                               const float* const (&gsrc)[NL], long goff, float* rawbuf, int wave, int& gnext) {
@@ -789,7 +789,7 @@ __device__ __forceinline__ void wino_imp_step(f32x16& acc, f32x4 (&bq)[8][2], un
 #pragma unroll
     for (int g = 0; g < G; ++g) {
         const int s_ = gnext + g;
-        __builtin_amdgcn_global_load_lds((gptr_t*)(gsrc[s_] + goff), (lptr_t*)(rawbuf + (s_ * NWV + wave) * 256), 16, 0, 0);
+        __builtin_amdgcn_global_load_lds((gptr_t*)(gsrc[s_] + goff), (lptr_t*)(rawbuf + (s_ * 4 + wave) * 256), 16, 0, 0);
     }
 #endif
     gnext += G;
@@ -1621,84 +1621,145 @@ __global__ __launch_bounds__(256, 2) void wino_dual_kernel(WinoImpParams p) {
 }
 
 // =====================================================================================================================================
-// OCTO geometry (round 3): the WIDE workgroup (32 tiles x 128 output channels) run by EIGHT waves = (32-channel quarter nq) x (xi
-// half xh), two waves per SIMD (waves w and w + 4 share SIMD w % 4: the same channel quarter, the two xi halves), 8 accumulators per
-// wave like the DUAL geometry - but ONE workgroup per CU, so the slab transform and the patch loads are paid once per 128 output
-// channels as in the wide kernel.  What the co-issue probes (tools/probes/coissue_probe*.hip, profiles/r3_coissue_probe.txt) measured
-// on v_mfma_f32_32x32x2_f32:
-//   - inside ONE wave a VALU instruction costs 8 cycles on top of the MFMA stream, a VMEM instruction 8-9, an LDS instruction nothing;
-//   - two waves of a SIMD that both stream MFMAs do NOT interleave: one keeps the matrix pipe until it stalls, the other waits, and
-//     the in-wave VALU / VMEM cost of either is paid in full (no s_setprio setting changes that);
-//   - a wave that issues NO MFMAs runs its VALU work at ~1.6 instructions per MFMA period and its LDS / VMEM work freely beside a
-//     streaming partner, at no cost to the partner.
-// So the two waves of a SIMD take turns.  Time is cut into slots, one 16-channel half-slab h each.  A wave's M phase is 64 MFMAs fed
-// from registers (all eight B fragment pairs of the slot) and LDS (A fragments): nothing but MFMAs and ds_reads.  Its X phase does
-// everything else for its next M phase - the 16 B-fragment loads, its patch loads of half-slab h + 2, its share of the transform of
-// half-slab h + 1 - while the partner wave is in ITS M phase:
-//     xi <  8 waves ("A"):   M(h) ; X ; barrier                 xi >= 8 waves ("B"):   M(h) ; barrier ; X
-// i.e. inside slot h the B wave runs X first (under A's MFMAs) and the A wave last (under B's).  Both roles execute the same
-// straight-line loop body; they differ in where the barrier sits and in the half-slab indices inside X.
-// LDS: raw[2] (24 KB each: 18 wave-loads of real cells + padding) and V[2] (32 KB each, [xi][tile][16 ch]) = 112 KB.
-// Same V bits, same per-accumulator channel order (ascending h), same fold order (prefix by the A waves, handed over through LDS,
-// continued by the B waves) => bit-identical to the other geometries; the B waves' epilogue is the wide kernel's (same GroupNorm
-// partial-sum grouping: one 32-tile x 32-channel wave tile).
-constexpr int OBM = 32, OBN = 128, OKS = 16, OLPW = 3;
-constexpr int ONCOL = 2 * OBM + 2 * INSEG;        // 72 column slots
-constexpr int ORAWH = OLPW * 8 * 256;             // floats of one raw half-slab buffer (24 KB; cells 288.. are zero-source padding)
-constexpr int OVH = 16 * OBM * OKS;               // floats of one V half-slab buffer (32 KB)
-static_assert(4 * ONCOL * OKS <= ORAWH && ONCOL % 8 == 0, "octo geometry: patch loads cover the half-slab");
+// PIPE geometry (round 3): the WIDE workgroup (32 tiles x 128 output channels, four waves side by side in N, sixteen xi per wave) with
+// the slab transform taken OUT of its own phase and spread over the MFMA steps.  Measured with tools/probes/coissue_probe*.hip
+// (profiles/r3_coissue_probe.txt) on v_mfma_f32_32x32x2_f32, one wave per SIMD: an LDS instruction behind an MFMA costs nothing (up
+// to one per MFMA; four ds_write_b128 in a row do cost), a VALU instruction 8 cycles, a VMEM instruction 8-9 - and a second wave on
+// the SIMD does not change any of that (two MFMA-streaming waves do not interleave, the f32 MFMA holds the SIMD's VALU issue for its
+// 64 cycles).  The wide kernel's transform phase is 2.0 k cycles per 32-channel slab, most of it the 64 KB of ds_write_b128 traffic
+// (13 cycles of data transfer per wave instruction) and LDS round trips with nothing to overlap; as single instructions between MFMAs
+// only its 64 packed adds remain visible.
+// Time is cut into slots of one 16-channel half-slab h: 16 steps (one per xi) of 8 MFMAs on V[h & 1], and between them the pieces of
+// this thread's share of the transform of half-slab h + 1 (raw[(h + 1) & 1] -> V[(h + 1) & 1]: 12 ds_read_b128, 16 packed FMAs / adds
+// x 2, 8 ds_write_b128) and the five patch loads of half-slab h + 2.  One barrier per slot.  Per accumulator the channels still
+// arrive in ascending order (half-slab h = channels 16 h ..), V has the bits of the materialising kernel: bit-identical outputs.
+// LDS: raw[2] x 20 KB + V[2] x 32 KB = 104 KB; layouts of the DUAL geometry (16-float cells, rot3 columns, V rows XOR-swizzled).
+constexpr int PBM = 32, PBN = 128, PKS = 16, PLPW = 5;
+constexpr int PNCOL = 2 * PBM + 2 * INSEG;        // 72 column slots
+constexpr int PRAWH = PLPW * 4 * 256;             // floats of one raw half-slab buffer (20 KB; cells 288.. are zero-source padding)
+constexpr int PVH = 16 * PBM * PKS;               // floats of one V half-slab buffer (32 KB)
+static_assert(4 * PNCOL * PKS <= PRAWH && PNCOL % 8 == 0, "pipe geometry: patch loads cover the half-slab");
 
-// this wave's share of a half-slab transform: 16 tiles x 4 channel quads, ONE row i of B^T d (xi = 4 i .. 4 i + 3).  Row i of B^T d
-// is P + sgn Q for two patch rows (P, Q) - fmaf(Q, +-1, P) is the IEEE sum / difference - and the column pass is wino_slab_transform's.
-__device__ __forceinline__ void wino_octo_transform(const float* raw, float* V, const int (&roff)[4], int poff, int qoff, float sgn) {
-    f32x4 r[4];
-#pragma unroll
-    for (int c = 0; c < 4; ++c) {
-        const f32x4 dp = *reinterpret_cast<const f32x4*>(raw + poff + roff[c]);
-        const f32x4 dq = *reinterpret_cast<const f32x4*>(raw + qoff + roff[c]);
-#pragma unroll
-        for (int e = 0; e < 4; ++e) r[c][e] = __builtin_fmaf(dq[e], sgn, dp[e]);
-    }
-    *reinterpret_cast<f32x4*>(V) = pk_sub4(r[0], r[2]);
-    *reinterpret_cast<f32x4*>(V + OBM * OKS) = pk_add4(r[1], r[2]);
-    *reinterpret_cast<f32x4*>(V + 2 * OBM * OKS) = pk_sub4(r[2], r[1]);
-    *reinterpret_cast<f32x4*>(V + 3 * OBM * OKS) = pk_sub4(r[1], r[3]);
+typedef float f32x2v __attribute__((ext_vector_type(2)));
+// r = p + s q on four lanes of a channel quad, s = +-1 (IEEE sum / difference through the FMA unit: the product is exact)
+__device__ __forceinline__ f32x4 pk_fma4(const f32x4 q, const f32x2v s, const f32x4 p) {
+    const f32x2v qlo = __builtin_shufflevector(q, q, 0, 1), qhi = __builtin_shufflevector(q, q, 2, 3);
+    const f32x2v plo = __builtin_shufflevector(p, p, 0, 1), phi = __builtin_shufflevector(p, p, 2, 3);
+    f32x2v rlo, rhi;
+    asm("v_pk_fma_f32 %0, %1, %2, %3" : "=v"(rlo) : "v"(qlo), "v"(s), "v"(plo));
+    asm("v_pk_fma_f32 %0, %1, %2, %3" : "=v"(rhi) : "v"(qhi), "v"(s), "v"(phi));
+    return __builtin_shufflevector(rlo, rhi, 0, 1, 2, 3);
 }
 
-// One step (one xi of this wave) of an M phase: 8 MFMAs on B fragments that are already in registers; the A fragments of the next
-// step are read behind the first MFMA.
-template <bool NEXT>
-__device__ __forceinline__ void wino_octo_step(f32x16& acc, const f32x4 (&b)[2], const float* anext0, const float* anext1,
-                                               const f32x4 (&a_cur)[2], f32x4 (&a_nxt)[2]) {
-    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a_cur[0][0], b[0][0], acc, 0, 0, 0);
+// This thread's share of a half-slab transform = (tile, channel quad, row pair ih): rows 2 ih and 2 ih + 1 of B^T d for its four
+// patch columns, then the column pass -> planes xi = 8 ih .. 8 ih + 7.  Row pair 0: ra = d0 - d2, rb = d1 + d2; row pair 1: ra = d2 - d1,
+// rb = d1 - d3: three patch rows each, the per-wave row offsets and the sign of rb's second operand spell that out (wino_pipe_kernel).
+// PIECE 0..3: read column c; 4..7: row pass of column c - 4; 8..15: compute output plane PIECE - 8; 16..23: store plane PIECE - 16.
+struct PipeXf {
+    f32x4 d[2][3];         // two columns in flight (the reads of column c + 1 are issued before the row pass of column c): patch rows o0, o1, o2
+    f32x4 ra[4], rb[4];
+    f32x4 o;               // the output plane computed in the previous step, stored in this one
+};
+template <int PIECE>
+__device__ __forceinline__ void wino_pipe_xf(PipeXf& t, const float* raw, float* V, const int (&roff)[4], int o0, int o1, int o2,
+                                             f32x2v sb) {
+    const f32x2v neg = {-1.f, -1.f};
+    if constexpr (PIECE < 4) {
+#ifndef LM_PABL_NOXLDS
+        t.d[PIECE & 1][0] = *reinterpret_cast<const f32x4*>(raw + o0 + roff[PIECE]);
+        t.d[PIECE & 1][1] = *reinterpret_cast<const f32x4*>(raw + o1 + roff[PIECE]);
+        t.d[PIECE & 1][2] = *reinterpret_cast<const f32x4*>(raw + o2 + roff[PIECE]);
+#endif
+    } else if constexpr (PIECE < 8) {
+        // row pair 0: (o0, o1, o2) = rows (0, 2, 1): ra = d0 - d2, rb = d1 + d2 = d[2] + (+1) d[1]
+        // row pair 1: (o0, o1, o2) = rows (2, 1, 3): ra = d2 - d1, rb = d1 - d3 = d[1] + (-1) d[2]  -> the operands of rb swap with ih (o1 / o2 below)
+        const f32x4 (&d)[3] = t.d[PIECE & 1];
+#ifdef LM_PABL_NOXVALU
+        t.ra[PIECE - 4] = d[0];
+        t.rb[PIECE - 4] = d[2];
+#else
+        t.ra[PIECE - 4] = pk_fma4(d[1], neg, d[0]);
+        t.rb[PIECE - 4] = pk_fma4(d[2], sb, d[1]);
+#endif
+    } else if constexpr (PIECE < 16) {
+        constexpr int k = PIECE - 8, j = k & 3;
+        const f32x4 (&r)[4] = k < 4 ? t.ra : t.rb;
+#ifdef LM_PABL_NOXVALU
+        t.o = r[j];
+#else
+        t.o = j == 0 ? pk_sub4(r[0], r[2]) : j == 1 ? pk_add4(r[1], r[2]) : j == 2 ? pk_sub4(r[2], r[1]) : pk_sub4(r[1], r[3]);
+#endif
+    } else {               // PIECE 16..23: store output plane PIECE - 16 (computed one step earlier: the store must not wait for this step's VALU work)
+#ifndef LM_PABL_NOXLDS
+        *reinterpret_cast<f32x4*>(V + (PIECE - 16) * (PBM * PKS)) = t.o;
+#else
+        asm volatile("" :: "v"(t.o));
+#endif
+    }
+}
+
+// One step (xi = K) of a slot: 8 MFMAs; B ring of 8 register sets, BD = 7 steps ahead; the slot's PLPW patch loads go out in steps
+// 0 .. PLPW-1; NWAIT = 14 B loads + the patch loads of the last eight steps.  XW / XR / XV = transform pieces issued behind the
+// first MFMA (-1: none), in this order: XW the ds_write of the plane computed a step ago, the A-fragment reads of the next step, XR
+// the ds_reads of the next patch column, XV the VALU piece on data read a step ago - LAST, because VALU work of this wave only starts
+// when the MFMA before it has left the pipe, and every LDS instruction behind it would wait as well (measured: store right behind
+// its adds 906 cycles per slot, adds and LDS traffic separately 175 + 225).
+template <int K, int NWAIT, int XW, int XR, int XV>
+__device__ __forceinline__ void wino_pipe_step(f32x16& acc, f32x4 (&bq)[8][2], unsigned bvoff, const float* bpre, const float* anext0,
+                                               const float* anext1, f32x4 (&a_cur)[2], f32x4 (&a_nxt)[2], const float* const (&gsrc)[PLPW],
+                                               long goff, float* rawld, int wave, PipeXf& xf, const float* xraw, float* xV,
+                                               const int (&roff)[4], int o0, int o1, int o2, f32x2v sb) {
+    typedef __attribute__((address_space(1))) const void gptr_t;
+    typedef __attribute__((address_space(3))) void lptr_t;
+#ifndef LM_IABL_NOB
+    bload2(bq[(K + BD) & 7], bvoff, bpre);
+#endif
+#ifndef LM_IABL_NOGLDS
+    if constexpr (K < PLPW)
+        __builtin_amdgcn_global_load_lds((gptr_t*)(gsrc[K] + goff), (lptr_t*)(rawld + (K * 4 + wave) * 256), 16, 0, 0);
+#endif
+    f32x4 (&bcur)[2] = bq[K & 7];
+#if !defined(LM_IABL_NOB) && !defined(LM_IABL_NOGLDS)
+    bwait<NWAIT>(bcur);
+#else
+    bwait<0>(bcur);
+#endif
+    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a_cur[0][0], bcur[0][0], acc, 0, 0, 0);
     __builtin_amdgcn_sched_barrier(0);
-    if constexpr (NEXT) {
+#ifndef LM_PABL_NOT
+    if constexpr (XW >= 16) wino_pipe_xf<XW>(xf, xraw, xV, roff, o0, o1, o2, sb);
+#endif
+    if constexpr (K < 15) {
         a_nxt[0] = *reinterpret_cast<const f32x4*>(anext0);
         a_nxt[1] = *reinterpret_cast<const f32x4*>(anext1);
     }
+#ifndef LM_PABL_NOT
+    if constexpr (XR >= 0 && XR < 4) wino_pipe_xf<XR>(xf, xraw, xV, roff, o0, o1, o2, sb);
+    __builtin_amdgcn_sched_barrier(0);
+    if constexpr (XV >= 4 && XV < 16) wino_pipe_xf<XV>(xf, xraw, xV, roff, o0, o1, o2, sb);
+#endif
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-    for (int t = 1; t < 4; ++t) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a_cur[0][t], b[0][t], acc, 0, 0, 0);
+    for (int t = 1; t < 4; ++t) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a_cur[0][t], bcur[0][t], acc, 0, 0, 0);
 #pragma unroll
-    for (int t = 0; t < 4; ++t) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a_cur[1][t], b[1][t], acc, 0, 0, 0);
+    for (int t = 0; t < 4; ++t) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a_cur[1][t], bcur[1][t], acc, 0, 0, 0);
     __builtin_amdgcn_sched_barrier(0);
 }
 
-__global__ __launch_bounds__(512) void wino_octo_kernel(WinoImpParams p) {
-#ifdef LM_IPROF                              // phases of wave 0 (role A) in slots 0..4, of wave 4 (role B) in 5..9: set-up + prologue, M, T, barriers, epilogue
+__global__ __launch_bounds__(256) void wino_pipe_kernel(WinoImpParams p) {
+#ifdef LM_IPROF
     long long iprof[11] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
     long long t_last = clock64();
 #endif
-    extern __shared__ __attribute__((aligned(16))) float smem[];      // raw[2][ORAWH] | V[2][OVH]
+    extern __shared__ __attribute__((aligned(16))) float smem[];      // raw[2][PRAWH] | V[2][PVH]
     float* const raw0 = smem;
-    float* const V0 = smem + 2 * ORAWH;
+    float* const V0 = smem + 2 * PRAWH;
     typedef __attribute__((address_space(1))) const void gptr_t;
     typedef __attribute__((address_space(3))) void lptr_t;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int nq = wave & 3, xh = wave >> 2;            // 32-channel quarter, xi half (waves 0..3: xi 0..7 = role A; 4..7: xi 8..15 = role B)
-    const int wn0 = nq * 32;
-    const int n_tiles = (p.Cout + OBN - 1) / OBN;
+    const int wn0 = wave * 32;
+    const int n_tiles = (p.Cout + PBN - 1) / PBN;
     unsigned mblk, ntile;
     {   // XCD-aware order, N tile outer (see wino_implicit_kernel)
         const unsigned bid = blockIdx.x, mb = gridDim.x / (unsigned)n_tiles, mbx = mb / 8, full = mbx * 8 * (unsigned)n_tiles;
@@ -1712,8 +1773,8 @@ __global__ __launch_bounds__(512) void wino_octo_kernel(WinoImpParams p) {
             ntile = r % (unsigned)n_tiles;
         }
     }
-    const long m0 = (long)mblk * OBM;
-    const int n0 = (int)ntile * OBN;
+    const long m0 = (long)mblk * PBM;
+    const int n0 = (int)ntile * PBN;
     const WinoGeom& g = p.g;
     const int bi = (int)(m0 / g.Tpad);
     const int t0 = (int)(m0 - (long)bi * g.Tpad);
@@ -1726,8 +1787,8 @@ __global__ __launch_bounds__(512) void wino_octo_kernel(WinoImpParams p) {
 #pragma unroll
         for (int s_ = 0; s_ < INSEG; ++s_) {
             ts[s_] = at;
-            const bool real = t < g.Timg && at < OBM;
-            const int n = at < OBM ? min(OBM - at, g.Tx - tx) : 0;
+            const bool real = t < g.Timg && at < PBM;
+            const int n = at < PBM ? min(PBM - at, g.Tx - tx) : 0;
             sn[s_] = real ? n : 0;
             iy0[s_] = (2 * ty - 1) * g.dil + pa;
             ix0[s_] = (2 * tx - 1) * g.dil + pb;
@@ -1749,14 +1810,13 @@ __global__ __launch_bounds__(512) void wino_octo_kernel(WinoImpParams p) {
         }
         ts[INSEG] = at;
     }
-    // per-lane sources of this wave's OLPW patch loads per half-slab: wave-load L = s_ * 8 + wave covers 16 cells of 64 B
-    const float* gsrc[OLPW];
+    const float* gsrc[PLPW];
     const int img_pix0 = bi * g.H * g.W;
 #pragma unroll
-    for (int s_ = 0; s_ < OLPW; ++s_) {
-        const int pos = (s_ * 8 + wave) * 16 + (lane >> 2);
-        const int r = pos / ONCOL;
-        const int q = unrot3(pos - r * ONCOL);
+    for (int s_ = 0; s_ < PLPW; ++s_) {
+        const int pos = (s_ * 4 + wave) * 16 + (lane >> 2);           // LDS cell position (16 cells of 64 B per wave load)
+        const int r = pos / PNCOL;
+        const int q = unrot3(pos - r * PNCOL);
         const int ch = lane & 3;
         int n = sn[0], yb = iy0[0], xb = ix0[0], q0 = 0;
 #pragma unroll
@@ -1769,167 +1829,114 @@ __global__ __launch_bounds__(512) void wino_octo_kernel(WinoImpParams p) {
         const bool ok = r < 4 && lc < 2 * n + 2 && n > 0 && (unsigned)yy < (unsigned)g.H && (unsigned)xx < (unsigned)g.W;
         gsrc[s_] = ok ? p.x + (long)(img_pix0 + yy * g.W + xx) * p.ldx + ch * 4 : p.zeros + ch * 4;
     }
-    // transform share of this wave: row i = 2 xh + (nq & 1) of B^T d, tiles 16 (nq >> 1) .. + 15 (lane >> 2), channel quad lane & 3
-    int roff[4], tvoff, tpoff, tqoff;
-    float tsgn;
+    // transform share: tile (tid & 127) >> 2, channel quad tid & 3, row pair ih = wave >> 1 (uniform per wave: the row offsets and the
+    // sign below are scalars)
+    int roff[4], tvoff, xo0, xo1, xo2;
+    f32x2v xsb;
     {
-        const int ti = 2 * xh + (nq & 1);
-        const int tl = 16 * (nq >> 1) + (lane >> 2), qd = lane & 3;
+        const int ih = wave >> 1;
+        const int tl = (tid & 127) >> 2, qd = tid & 3;
         int sg = 0;
 #pragma unroll
-        for (int k = 1; k < INSEG; ++k) sg += (ts[k] < OBM && tl >= ts[k]) ? 1 : 0;
+        for (int k = 1; k < INSEG; ++k) sg += (ts[k] < PBM && tl >= ts[k]) ? 1 : 0;
         const int cb = 2 * tl + 2 * sg;
 #pragma unroll
         for (int c = 0; c < 4; ++c) roff[c] = (rot3(cb + c) * 4 + qd) * 4;
-        tvoff = (4 * ti) * (OBM * OKS) + (tl * 4 + (qd ^ ((tl >> 2) & 3))) * 4;
-        constexpr int ROWF = ONCOL * OKS;
-        // row 0: d0 - d2 | 1: d1 + d2 | 2: d2 - d1 | 3: d1 - d3
-        tpoff = (ti == 0 ? 0 : ti == 2 ? 2 : 1) * ROWF;
-        tqoff = (ti == 0 ? 2 : ti == 1 ? 2 : ti == 2 ? 1 : 3) * ROWF;
-        tsgn = ti == 1 ? 1.f : -1.f;
+        tvoff = (8 * ih) * (PBM * PKS) + (tl * 4 + (qd ^ ((tl >> 2) & 3))) * 4;
+        constexpr int ROWF = PNCOL * PKS;
+        // ih = 0: d[] = rows (0, 2, 1): ra = d[0] - d[1] = d0 - d2, rb = d[1] + d[2]... see wino_pipe_xf: ra = d[0] - d[1], rb = d[1] + sb d[2]
+        //         rb = d1 + d2 is commutative: rows (0, 2, 1) give d[1] + d[2] = d2 + d1 - NOT the same bits as d1 + d2?  They are: IEEE
+        //         addition is commutative.  ih = 1: d[] = rows (2, 1, 3): ra = d2 - d1, rb = d1 - d3.
+        xo0 = (ih == 0 ? 0 : 2) * ROWF;
+        xo1 = (ih == 0 ? 2 : 1) * ROWF;
+        xo2 = (ih == 0 ? 1 : 3) * ROWF;
+        const float sbv = ih == 0 ? 1.f : -1.f;
+        xsb = f32x2v{sbv, sbv};
     }
     const int frow = lane & 31, fhalf = lane >> 5;
     int aoff[2];
 #pragma unroll
-    for (int kk = 0; kk < 2; ++kk) aoff[kk] = (8 * xh) * (OBM * OKS) + (frow * 4 + ((2 * kk + fhalf) ^ ((frow >> 2) & 3))) * 4;
-    const int H = p.C / OKS;                           // half-slabs (slots)
+    for (int kk = 0; kk < 2; ++kk) aoff[kk] = (frow * 4 + ((2 * kk + fhalf) ^ ((frow >> 2) & 3))) * 4;
+    const int H = p.C / PKS;                           // half-slabs (slots)
     const unsigned bvoff = (unsigned)lane * 16u;
     const long bstep = (long)p.NT * 512;
     const long bxi = (long)H * bstep;
-    const float* const bbase = p.U + (long)((n0 + wn0) >> 5) * 512 + (long)(8 * xh) * bxi;
+    const float* const bbase = p.U + (long)((n0 + wn0) >> 5) * 512;
 
-    f32x16 acc[8];
+    f32x16 acc[16];
 #pragma unroll
-    for (int k = 0; k < 8; ++k)
+    for (int k = 0; k < 16; ++k)
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[k][r] = 0.f;
+    LM_TICK(7)
     f32x4 bq[8][2];
-    // prologue: raw half-slabs 0 and 1, the B fragments of slot 0, V of half-slab 0
+    PipeXf xf;
+    // prologue: raw half-slabs 0 and 1, B of steps 0 .. BD-1 of slot 0, V of half-slab 0
 #pragma unroll
-    for (int s_ = 0; s_ < OLPW; ++s_)
-        __builtin_amdgcn_global_load_lds((gptr_t*)gsrc[s_], (lptr_t*)(raw0 + (s_ * 8 + wave) * 256), 16, 0, 0);
+    for (int s_ = 0; s_ < PLPW; ++s_)
+        __builtin_amdgcn_global_load_lds((gptr_t*)gsrc[s_], (lptr_t*)(raw0 + (s_ * 4 + wave) * 256), 16, 0, 0);
 #pragma unroll
-    for (int s_ = 0; s_ < OLPW; ++s_)
-        __builtin_amdgcn_global_load_lds((gptr_t*)(gsrc[s_] + OKS), (lptr_t*)(raw0 + ORAWH + (s_ * 8 + wave) * 256), 16, 0, 0);
+    for (int s_ = 0; s_ < PLPW; ++s_)
+        __builtin_amdgcn_global_load_lds((gptr_t*)(gsrc[s_] + PKS), (lptr_t*)(raw0 + PRAWH + (s_ * 4 + wave) * 256), 16, 0, 0);
 #pragma unroll
-    for (int k = 0; k < 8; ++k) bload2(bq[k], bvoff, bbase + (long)k * bxi);
+    for (int k = 0; k < BD; ++k) bload2(bq[k], bvoff, bbase + (long)k * bxi);
+#pragma unroll
+    for (int k = 0; k < BD; ++k) bwait<0>(bq[k]);
+    __builtin_amdgcn_s_barrier();
+    LM_TICK(0)
+#define LM_PXF(P) wino_pipe_xf<P>(xf, raw0, V0 + tvoff, roff, xo0, xo1, xo2, xsb)
+    LM_PXF(0); LM_PXF(4); LM_PXF(1); LM_PXF(5); LM_PXF(2); LM_PXF(6); LM_PXF(3); LM_PXF(7);
+    LM_PXF(8); LM_PXF(16); LM_PXF(9); LM_PXF(17); LM_PXF(10); LM_PXF(18); LM_PXF(11); LM_PXF(19);
+    LM_PXF(12); LM_PXF(20); LM_PXF(13); LM_PXF(21); LM_PXF(14); LM_PXF(22); LM_PXF(15); LM_PXF(23);
+#undef LM_PXF
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    LM_TICK(1)
+    __builtin_amdgcn_s_barrier();
+    LM_TICK(2)
+    // one slot, PAR = h & 1 a compile-time constant (every LDS address of the slot is then a register + immediate): H is even
+#define LM_PSTEP(PAR, K, NW, XW, XR, XV, AC, AN) \
+        wino_pipe_step<K, NW, XW, XR, XV>(acc[K], bq, bvoff, (K) + BD < 16 ? bs + (long)((K) + BD) * bxi : bs_next + (long)((K) + BD - 16) * bxi, \
+                                          V0 + (PAR) * PVH + ((K) + 1) * (PBM * PKS) + aoff[0], V0 + (PAR) * PVH + ((K) + 1) * (PBM * PKS) + aoff[1], AC, AN, \
+                                          gsrc, goff, raw0 + (PAR) * PRAWH, wave, xf, raw0 + ((PAR) ^ 1) * PRAWH, V0 + ((PAR) ^ 1) * PVH + tvoff, roff, xo0, xo1, xo2, xsb)
+    // NWAIT(K) = 2 BD + |{K-7 .. K} (mod 16) intersected with the patch-load steps {0 .. 4}|.  Transform pieces: column c read in step
+    // c, its row pass in step c + 1 (pieces 4..7), output plane k computed in step 5 + k (8..15) and stored in step 6 + k (16..23)
+#define LM_PSLOT(PAR, HH)                                                                                                        \
+    {                                                                                                                            \
+        const int hh = (HH);                                                                                                     \
+        const long goff = hh + 2 < H ? (long)(hh + 2) * PKS : 0;            /* (nothing left to fetch: harmless re-read) */       \
+        const float* const bs = bbase + (long)hh * bstep;                                                                        \
+        const float* const bs_next = bbase + (long)(hh + 1 < H ? hh + 1 : 0) * bstep;                                            \
+        f32x4 a0[2], a1[2];                                                                                                      \
+        a0[0] = *reinterpret_cast<const f32x4*>(V0 + (PAR) * PVH + aoff[0]);                                                     \
+        a0[1] = *reinterpret_cast<const f32x4*>(V0 + (PAR) * PVH + aoff[1]);                                                     \
+        LM_PSTEP(PAR, 0, 15, -1, 0, -1, a0, a1);  LM_PSTEP(PAR, 1, 16, -1, 1, 4, a1, a0);   LM_PSTEP(PAR, 2, 17, -1, 2, 5, a0, a1);   \
+        LM_PSTEP(PAR, 3, 18, -1, 3, 6, a1, a0);   LM_PSTEP(PAR, 4, 19, -1, -1, 7, a0, a1);  LM_PSTEP(PAR, 5, 19, -1, -1, 8, a1, a0);  \
+        LM_PSTEP(PAR, 6, 19, 16, -1, 9, a0, a1);  LM_PSTEP(PAR, 7, 19, 17, -1, 10, a1, a0); LM_PSTEP(PAR, 8, 18, 18, -1, 11, a0, a1); \
+        LM_PSTEP(PAR, 9, 17, 19, -1, 12, a1, a0); LM_PSTEP(PAR, 10, 16, 20, -1, 13, a0, a1); LM_PSTEP(PAR, 11, 15, 21, -1, 14, a1, a0); \
+        LM_PSTEP(PAR, 12, 14, 22, -1, 15, a0, a1); LM_PSTEP(PAR, 13, 14, 23, -1, -1, a1, a0); LM_PSTEP(PAR, 14, 14, -1, -1, -1, a0, a1); \
+        LM_PSTEP(PAR, 15, 14, -1, -1, -1, a1, a0);                                                                               \
+        LM_TICK(3)                                                                                                               \
+        bwait<14>(bq[0]);                      /* this wave's patch loads (steps 0 .. 4) have landed */                          \
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                                                       \
+        LM_TICK(4)                                                                                                               \
+        __builtin_amdgcn_s_barrier();          /* V(h + 1) complete, V(h) and raw(h + 1) free, raw(h + 2) landed */              \
+        LM_TICK(5)                                                                                                               \
+    }
+    static_assert(PLPW == 5 && BD == 7, "NWAIT table above");
+    for (int h = 0; h < H; h += 2) {
+        LM_PSLOT(0, h)
+        LM_PSLOT(1, h + 1)
+    }
+#undef LM_PSLOT
+#undef LM_PSTEP
 #pragma unroll
     for (int k = 0; k < 8; ++k) bwait<0>(bq[k]);
-    __builtin_amdgcn_s_barrier();
-    wino_octo_transform(raw0, V0 + tvoff, roff, tpoff, tqoff, tsgn);                      // T(0): every wave its share
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();
-    if (xh) {                                                                             // role B runs its X one half-slot ahead: patch loads of
-#pragma unroll                                                                            // half-slab 2 (raw(0) is spent), its share of T(1)
-        for (int s_ = 0; s_ < OLPW; ++s_)
-            __builtin_amdgcn_global_load_lds((gptr_t*)(gsrc[s_] + (H > 2 ? 2 * OKS : 0)), (lptr_t*)(raw0 + (s_ * 8 + wave) * 256), 16, 0, 0);
-        wino_octo_transform(raw0 + ORAWH, V0 + OVH + tvoff, roff, tpoff, tqoff, tsgn);
-        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-    }
-    LM_TICK(0)
-    for (int h = 0; h < H; ++h) {
-        // ---- M(h): 64 MFMAs, B fragments from the ring (complete), A fragments from V[h & 1]
-        const float* const Vx = V0 + (h & 1) * OVH;
-        f32x4 a0[2], a1[2];
-        a0[0] = *reinterpret_cast<const f32x4*>(Vx + aoff[0]);
-        a0[1] = *reinterpret_cast<const f32x4*>(Vx + aoff[1]);
-#define LM_OSTEP(K, AC, AN) \
-        wino_octo_step<((K) < 7)>(acc[K], bq[K], Vx + ((K) + 1) * (OBM * OKS) + aoff[0], Vx + ((K) + 1) * (OBM * OKS) + aoff[1], AC, AN)
-        LM_OSTEP(0, a0, a1); LM_OSTEP(1, a1, a0); LM_OSTEP(2, a0, a1); LM_OSTEP(3, a1, a0);
-        LM_OSTEP(4, a0, a1); LM_OSTEP(5, a1, a0); LM_OSTEP(6, a0, a1); LM_OSTEP(7, a1, a0);
-#undef LM_OSTEP
-        LM_TICK(1)
-#ifndef LM_OABL_NOBAR
-        if (xh) __builtin_amdgcn_s_barrier();  // role B: slot h ends here
-#endif
-        LM_TICK(3)
-        // ---- X: everything this wave's NEXT M phase needs, issued while the partner wave multiplies.  Role A (second half of slot h):
-        // B fragments of slot h + 1, patch loads of half-slab h + 2, share of T(h + 1).  Role B (first half of slot h + 1): B fragments
-        // of slot h + 1, patch loads of half-slab h + 3, share of T(h + 2).  Past the last half-slab the loads re-read valid addresses
-        // and the transform works on stale data in buffers nobody reads any more.
-        {
-            const int hb = h + 1 < H ? h + 1 : 0;
-            const float* const bs = bbase + (long)hb * bstep;
-#ifndef LM_IABL_NOB
-#pragma unroll
-            for (int k = 0; k < 8; ++k) bload2(bq[k], bvoff, bs + (long)k * bxi);
-#endif
-            const int hl = h + 2 + xh, ht = h + 1 + xh;
-            const long goff = hl < H ? (long)hl * OKS : 0;
-            float* const rawld = raw0 + (hl & 1) * ORAWH;
-#ifndef LM_IABL_NOGLDS
-#pragma unroll
-            for (int s_ = 0; s_ < OLPW; ++s_)
-                __builtin_amdgcn_global_load_lds((gptr_t*)(gsrc[s_] + goff), (lptr_t*)(rawld + (s_ * 8 + wave) * 256), 16, 0, 0);
-#endif
-#ifndef LM_OABL_NOT
-            wino_octo_transform(raw0 + (ht & 1) * ORAWH, V0 + (ht & 1) * OVH + tvoff, roff, tpoff, tqoff, tsgn);
-#endif
-#pragma unroll
-            for (int k = 0; k < 8; ++k) bwait<0>(bq[k]);
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        }
-        LM_TICK(2)
-#ifndef LM_OABL_NOBAR
-        if (!xh) __builtin_amdgcn_s_barrier(); // role A: slot h ends here
-#endif
-        LM_TICK(3)
-    }
 
-    // (the lane index is re-derived here: kept live across the slot loop it cost the 257th register, i.e. a scratch spill)
-    const int elane = (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
-    const int efrow = elane & 31, efhalf = elane >> 5;
-    // --- epilogue.  A waves: prefix of the fold -> LDS; B waves: rest of the fold, transposes, stores (the wide kernel's epilogue).
-    float* const xchg = smem + nq * 4096;                              // [ab 4][r4 4][elane 64][4] floats per channel quarter
+    // --- epilogue: the wide kernel's (fold in ascending xi, wave-private LDS transposes, 16-byte stores)
     constexpr int ELD = 32 + 4;
-    float* const stage = smem + 4 * 4096 + nq * (32 * ELD);
-    static_assert(4 * 4096 + 4 * 32 * ELD <= 2 * ORAWH + 2 * OVH, "octo epilogue buffers fit");
-#ifdef LM_OABL_NOEPI
-    {   // timing ablation: no fold / hand-over / transposes / stores; one value per thread keeps the accumulators live
-        float sum = 0.f;
-#pragma unroll
-        for (int k = 0; k < 8; ++k)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) sum += acc[k][r];
-        p.y[(long)blockIdx.x * 512 + tid] = sum;
-        return;
-    }
-#endif
-    __syncthreads();                                   // every wave is done with the patch / V buffers
-    if (xh == 0) {
-#pragma unroll
-        for (int ab = 0; ab < 4; ++ab) {
-            f32x16 o;
-#pragma unroll
-            for (int r = 0; r < 16; ++r) o[r] = 0.f;
-#pragma unroll
-            for (int xi = 0; xi < 8; ++xi) {
-                const float c = wino_fold_coef(ab, xi);
-                if (c == 0.f) continue;
-#pragma unroll
-                for (int r = 0; r < 16; ++r) o[r] = fmaf(acc[xi][r], c, o[r]);
-            }
-#pragma unroll
-            for (int r4 = 0; r4 < 4; ++r4) {
-                f32x4 v = {o[4 * r4], o[4 * r4 + 1], o[4 * r4 + 2], o[4 * r4 + 3]};
-                *reinterpret_cast<f32x4*>(xchg + ((ab * 4 + r4) * 64 + elane) * 4) = v;
-            }
-        }
-    }
-    __syncthreads();
-#ifdef LM_IPROF
-    if (xh == 0) {
-        LM_TICK(4)
-        if (tid == 0) {
-#pragma unroll
-            for (int k = 0; k < 5; ++k) g_iprof[blockIdx.x % IPROF_WG][k] = (unsigned long long)iprof[k];
-            g_iprof[blockIdx.x % IPROF_WG][11] = 1ull;
-        }
-    }
-#endif
-    if (xh == 0) return;
+    float* stage = smem + wave * (32 * ELD);
     constexpr int LPR = 8, RPI = 8, NP = 4;
-    const int c4 = (elane & 7) * 4;
+    const int c4 = (lane & 7) * 4;
     const int n = n0 + wn0 + c4;
     f32x4 sc = {1.f, 1.f, 1.f, 1.f}, sh = {0.f, 0.f, 0.f, 0.f};
     if (n < p.Cout) {
@@ -1943,10 +1950,10 @@ __global__ __launch_bounds__(512) void wino_octo_kernel(WinoImpParams p) {
     const bool vec = (n + 3 < p.Cout) && ((p.ldy & 3) == 0) && (!p.res || (p.ldr & 3) == 0);
     f32x4 gs = {0.f, 0.f, 0.f, 0.f}, gq = {0.f, 0.f, 0.f, 0.f};
     int pix0[NP];
-    unsigned vmask = 0;
+    unsigned vmask = 0;                                // 3 bits per row: tile exists | a = 1 inside | b = 1 inside
 #pragma unroll
     for (int pass = 0; pass < NP; ++pass) {
-        const int tl = pass * RPI + elane / LPR;
+        const int tl = pass * RPI + lane / LPR;
         int nn = sn[0], oy = oy0[0], oxb = ox0[0], tb = 0;
 #pragma unroll
         for (int k = 1; k < INSEG; ++k)
@@ -1959,33 +1966,29 @@ __global__ __launch_bounds__(512) void wino_octo_kernel(WinoImpParams p) {
             vmask |= (1u | (oy + g.dil < g.H ? 2u : 0u) | (ox + g.dil < g.W ? 4u : 0u)) << (3 * pass);
     }
     const int step_a = g.dil * g.W, step_b = g.dil;
+    __syncthreads();                                   // every wave is done with the patch / V buffers
 #pragma unroll
     for (int a = 0; a < 2; ++a)
 #pragma unroll
         for (int b = 0; b < 2; ++b) {
-            const int ab = 2 * a + b;
             f32x16 o;
 #pragma unroll
-            for (int r4 = 0; r4 < 4; ++r4) {
-                const f32x4 v = *reinterpret_cast<const f32x4*>(xchg + ((ab * 4 + r4) * 64 + elane) * 4);
+            for (int r = 0; r < 16; ++r) o[r] = 0.f;
 #pragma unroll
-                for (int e = 0; e < 4; ++e) o[4 * r4 + e] = v[e];
-            }
-#pragma unroll
-            for (int k = 0; k < 8; ++k) {
-                const float c = wino_fold_coef(ab, 8 + k);
+            for (int xi = 0; xi < 16; ++xi) {
+                const float c = wino_fold_coef(2 * a + b, xi);
                 if (c == 0.f) continue;
 #pragma unroll
-                for (int r = 0; r < 16; ++r) o[r] = fmaf(acc[k][r], c, o[r]);
+                for (int r = 0; r < 16; ++r) o[r] = fmaf(acc[xi][r], c, o[r]);
             }
             __builtin_amdgcn_wave_barrier();
 #pragma unroll
-            for (int r = 0; r < 16; ++r) stage[((r & 3) + 8 * (r >> 2) + 4 * efhalf) * ELD + efrow] = o[r];
+            for (int r = 0; r < 16; ++r) stage[((r & 3) + 8 * (r >> 2) + 4 * fhalf) * ELD + frow] = o[r];
             __builtin_amdgcn_wave_barrier();
             if (n >= p.Cout) continue;
 #pragma unroll
             for (int pass = 0; pass < NP; ++pass) {
-                const int row = pass * RPI + elane / LPR;
+                const int row = pass * RPI + lane / LPR;
                 const unsigned vm = vmask >> (3 * pass);
                 if (!(vm & 1u) || (a && !(vm & 2u)) || (b && !(vm & 4u))) continue;
                 const long pix = pix0[pass] + a * step_a + b * step_b;
@@ -2020,7 +2023,7 @@ __global__ __launch_bounds__(512) void wino_octo_kernel(WinoImpParams p) {
                 }
             }
         }
-    if (p.gn_part && n < p.Cout) {
+    if (p.gn_part && n < p.Cout) {   // fixed-order reduction over the 8 lanes that share a channel quad, then one writer lane
 #pragma unroll
         for (int o = LPR; o < 64; o <<= 1)
 #pragma unroll
@@ -2028,7 +2031,7 @@ __global__ __launch_bounds__(512) void wino_octo_kernel(WinoImpParams p) {
                 gs[e] += __shfl_xor(gs[e], o);
                 gq[e] += __shfl_xor(gq[e], o);
             }
-        if (elane < LPR) {
+        if (lane < LPR) {
             const long chunk = t0 / 32;
             double* o = p.gn_part + (((long)bi * (g.Tpad / 32) + chunk) * p.Cout + n) * 2;
             for (int e = 0; e < 4 && n + e < p.Cout; ++e) {
@@ -2038,10 +2041,11 @@ __global__ __launch_bounds__(512) void wino_octo_kernel(WinoImpParams p) {
         }
     }
 #ifdef LM_IPROF
-    LM_TICK(4)
-    if (tid == 256) {
+    LM_TICK(6)
+    if (tid == 0) {
 #pragma unroll
-        for (int k = 0; k < 5; ++k) g_iprof[blockIdx.x % IPROF_WG][5 + k] = (unsigned long long)iprof[k];
+        for (int k = 0; k < 11; ++k) g_iprof[blockIdx.x % IPROF_WG][k] = (unsigned long long)iprof[k];
+        g_iprof[blockIdx.x % IPROF_WG][11] = 1ull;
     }
 #endif
 }
@@ -2214,15 +2218,15 @@ int wino_implicit_launch(int mode, void* stream, const float* x, int ldx, const 
         LM_LAUNCH_CHECK();
         return LM_OK;
     }
-    // OCTO geometry (round 3): the wide workgroup run by eight waves, two per SIMD half a phase apart (wino_octo_kernel).
-    // LANEMAP_WINO_OCTO = 1: wherever the wide kernel would run; default 0 (measured: no faster than the wide kernel)
-    static const bool octo_ok = getenv("LANEMAP_WINO_OCTO") && atoi(getenv("LANEMAP_WINO_OCTO")) != 0;
-    if (mode == 0 && octo_ok && wide_ok && Cout > IBN && Cin % WKS == 0) {
-        const size_t olds = (size_t)(2 * ORAWH + 2 * OVH) * sizeof(float);
-        const long oblocks = (p.g.T / OBM) * ((Cout + OBN - 1) / OBN);
-        LM_REQUIRE(oblocks > 0 && oblocks < (1L << 31) && p.g.T % OBM == 0, "conv_wino_implicit: bad grid %ld", oblocks);
-        if (int e = lm_ensure_dynamic_lds((const void*)wino_octo_kernel, olds)) return e;
-        hipLaunchKernelGGL(wino_octo_kernel, dim3((unsigned)oblocks), dim3(512), olds, (hipStream_t)stream, p);
+    // PIPE geometry (round 3): the wide workgroup with the slab transform spread over the MFMA steps (wino_pipe_kernel).
+    // LANEMAP_WINO_PIPE = 0: the round-2 wide kernel instead
+    static const bool pipe_ok = !(getenv("LANEMAP_WINO_PIPE") && atoi(getenv("LANEMAP_WINO_PIPE")) == 0);
+    if (mode == 0 && pipe_ok && wide_ok && Cout > IBN && Cin % WKS == 0) {
+        const size_t plds = (size_t)(2 * PRAWH + 2 * PVH) * sizeof(float);
+        const long pblocks = (p.g.T / PBM) * ((Cout + PBN - 1) / PBN);
+        LM_REQUIRE(pblocks > 0 && pblocks < (1L << 31) && p.g.T % PBM == 0, "conv_wino_implicit: bad grid %ld", pblocks);
+        if (int e = lm_ensure_dynamic_lds((const void*)wino_pipe_kernel, plds)) return e;
+        hipLaunchKernelGGL(wino_pipe_kernel, dim3((unsigned)pblocks), dim3(256), plds, (hipStream_t)stream, p);
         LM_LAUNCH_CHECK();
         return LM_OK;
     }

@@ -122,8 +122,8 @@ class Runner:
         for f in pipe.flush():
             lanes_all.append(f.result()[0]); endp_all.append(f.result()[1])
         if world > 1:
-            blocks = shard.pack_tile_results(lanes_all, endp_all, per, self.device)
-            gathered = shard.unpack_gathered(*shard.all_gather_results(*blocks))
+            block = shard.pack_tile_results(lanes_all, endp_all, per, self.device)
+            gathered = shard.unpack_gathered(shard.all_gather_results(block))         # ONE collective for the whole job
             names = paths
         else:
             gathered = list(zip(lanes_all, endp_all))

@@ -1,6 +1,12 @@
 """Multi-GPU data parallelism over BEV tiles: one process per GPU, static contiguous
-block shard of the sorted tile list, no data-path collective; the per-tile results (fixed-shape polyline
-blocks: [72,144,2] f64 + [64,2] i32 + [2] i32 = 166.4 KB per tile) are combined with ONE all-gather (RCCL over xGMI on GPUs, gloo on CPU in tests).
+block shard of the sorted tile list, no data-path collective; the per-tile results are combined with ONE all-gather per batch
+(RCCL over xGMI on GPUs, gloo on CPU in tests) of ONE fixed-shape byte block per tile:
+
+    [ lanes 72 x 144 x 2 f64 | endpoints MAX_ENDP x 2 i32 | valid flag, endpoint count (i32 x 2) ]  = TILE_BYTES = 169,992 B
+
+(round 2 issued three collectives - lanes, endpoints, counts - per batch).  MAX_ENDP = 512 covers every tile: the endpoint
+candidates of a tile are the clusters of its top-K endpoint pixels (decode.TOPK = 512), so more than 512 cannot exist and no rank can
+fail alone in front of the collective.
 
 The reference has no equivalent on its inference path (nn.DataParallel, runner.py:103-104); its own pattern for
 gathering variable-length per-rank results is the two-round pickle all-gather of utils/dist_utils.py:112-152,
@@ -10,7 +16,10 @@ import numpy as np
 import torch
 import torch.distributed as dist
 
-MAX_ENDP = 64   # endpoint slots per tile in the gathered block
+MAX_ENDP = 512                                  # endpoint slots per tile (>= decode.TOPK candidates: cannot overflow)
+LANES_BYTES = 72 * 144 * 2 * 8
+ENDP_BYTES = MAX_ENDP * 2 * 4
+TILE_BYTES = LANES_BYTES + ENDP_BYTES + 8       # 169,992 (a multiple of 8: every tile's f64 block stays aligned)
 
 
 def shard_range(n_tiles, rank, world):
@@ -23,51 +32,59 @@ def shard_range(n_tiles, rank, world):
 
 
 def pack_tile_results(lanes_list, endp_list, per, device, pinned=False):
-    """lanes [72,144,2] f64 per tile, endpoints [k,2] -> fixed-shape f64 / i32 blocks padded to `per` tiles (f64: the column
-    coordinates are float64 in the reference and in the single-rank path, so rank 0 writes byte-identical files either way).
-    pinned: stage in page-locked memory and copy asynchronously on the current stream (the caller keeps the returned
-    tensors alive until that stream has run the copies), so the host never waits for the compute queued before it."""
+    """lanes [72,144,2] f64 per tile, endpoints [k,2] -> ONE uint8 block [per, TILE_BYTES] (f64 lanes: the column coordinates are
+    float64 in the reference and in the single-rank path, so rank 0 writes byte-identical files either way); slots beyond the list
+    are padding tiles (valid flag 0).
+    pinned: stage in page-locked memory and copy asynchronously on the current stream (the returned tensor keeps its pinned source
+    alive), so the host never waits for the compute queued before it."""
     T = len(lanes_list)
+    if T > per:
+        raise ValueError(f'{T} tiles do not fit {per} slots')
     pin = bool(pinned) and torch.device(device).type == 'cuda'
-    lanes = torch.full((per, 72, 144, 2), -1.0, dtype=torch.float64, pin_memory=pin)
-    lanes[..., 1] = 0.0
-    endp = torch.full((per, MAX_ENDP, 2), -1, dtype=torch.int32, pin_memory=pin)
-    count = torch.zeros((per, 2), dtype=torch.int32, pin_memory=pin)           # [valid tile flag, n endpoints]
+    block = torch.zeros((per, TILE_BYTES), dtype=torch.uint8, pin_memory=pin)
+    raw = block.numpy()
+    lanes = raw[:, :LANES_BYTES].view(np.float64).reshape(per, 72, 144, 2)
+    endp = raw[:, LANES_BYTES:LANES_BYTES + ENDP_BYTES].view(np.int32).reshape(per, MAX_ENDP, 2)
+    count = raw[:, LANES_BYTES + ENDP_BYTES:].view(np.int32).reshape(per, 2)          # [valid tile flag, n endpoints]
+    lanes[..., 0] = -1.0
+    endp[...] = -1
     for t in range(T):
-        lanes[t] = torch.from_numpy(np.asarray(lanes_list[t], dtype=np.float64))
+        lanes[t] = np.asarray(lanes_list[t], dtype=np.float64)
         e = np.asarray(endp_list[t], dtype=np.int32).reshape(-1, 2)
-        if len(e) > MAX_ENDP:
+        if len(e) > MAX_ENDP:       # (unreachable through the pipeline: <= decode.TOPK candidates per tile)
             raise ValueError(f'tile {t}: {len(e)} endpoints exceed the {MAX_ENDP} slots of the gathered block')
-        endp[t, :len(e)] = torch.from_numpy(e)
+        endp[t, :len(e)] = e
         count[t, 0] = 1
         count[t, 1] = len(e)
     if pin:
-        host = (lanes, endp, count)
-        dev = tuple(t.to(device, non_blocking=True) for t in host)
-        for d, h in zip(dev, host):
-            d._host_staging = h          # keep the pinned source alive as long as the device copy
+        dev = block.to(device, non_blocking=True)
+        dev._host_staging = block            # keep the pinned source alive as long as the device copy
         return dev
-    return lanes.to(device), endp.to(device), count.to(device)
+    return block.to(device)
 
 
-def all_gather_results(lanes, endp, count):
-    """Returns the rank-major concatenation on every rank ([world*per, ...])."""
+def all_gather_results(block):
+    """ONE collective: returns the rank-major concatenation on every rank ([world * per, TILE_BYTES])."""
     if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
-        return lanes, endp, count
+        return block
     world = dist.get_world_size()
-    outs = []
-    for t in (lanes, endp, count):
-        out = torch.empty((world * t.shape[0],) + tuple(t.shape[1:]), dtype=t.dtype, device=t.device)
-        dist.all_gather_into_tensor(out, t.contiguous())
-        outs.append(out)
-    return tuple(outs)
+    out = torch.empty((world * block.shape[0], block.shape[1]), dtype=block.dtype, device=block.device)
+    dist.all_gather_into_tensor(out, block.contiguous())
+    return out
 
 
-def unpack_gathered(lanes, endp, count):
-    """-> list of (lanes [72,144,2] f64, endpoints [k,2]) for the valid tiles, in global tile order."""
+def unpack_gathered(block, include_padding=False):
+    """-> list of (lanes [72,144,2] f64, endpoints [k,2] i32) for the valid tiles, in global tile order (include_padding: None for
+    the padding slots instead of skipping them, so that positions stay rank-major)."""
+    raw = block.cpu().numpy()
+    n = raw.shape[0]
+    lanes = raw[:, :LANES_BYTES].view(np.float64).reshape(n, 72, 144, 2)
+    endp = raw[:, LANES_BYTES:LANES_BYTES + ENDP_BYTES].view(np.int32).reshape(n, MAX_ENDP, 2)
+    count = raw[:, LANES_BYTES + ENDP_BYTES:].view(np.int32).reshape(n, 2)
     res = []
-    lanes, endp, count = lanes.cpu().numpy(), endp.cpu().numpy(), count.cpu().numpy()
-    for t in range(lanes.shape[0]):
+    for t in range(n):
         if count[t, 0]:
             res.append((lanes[t], endp[t, :count[t, 1]]))
+        elif include_padding:
+            res.append(None)
     return res

@@ -1,5 +1,5 @@
-"""CPU, world_size 2 over gloo: the N>1 path of the bench (static tile shard + one all-gather of the
-fixed-shape polyline blocks)."""
+"""CPU, world_size 2 over gloo: the N>1 path of the bench (static tile shard + ONE all-gather of one fixed-shape byte
+block per tile: lanes f64 | endpoints i32 | flags)."""
 import os
 import socket
 
@@ -33,8 +33,21 @@ def _worker(rank, world, port, n_tiles, q):
         l[t % 72, :, 1] = 1 + t % 2
         lanes.append(l)
         endp.append(np.array([[t, t + 1]] * (t % 3)))
-    blocks = shard.pack_tile_results(lanes, endp, per, torch.device('cpu'))
-    out = shard.unpack_gathered(*shard.all_gather_results(*blocks))
+    block = shard.pack_tile_results(lanes, endp, per, torch.device('cpu'))
+    assert block.dtype == torch.uint8 and tuple(block.shape) == (per, shard.TILE_BYTES)
+    calls = []
+    real = dist.all_gather_into_tensor
+    dist.all_gather_into_tensor = lambda *a, **k: (calls.append(1), real(*a, **k))[1]
+    gathered = shard.all_gather_results(block)
+    dist.all_gather_into_tensor = real
+    assert len(calls) == 1, 'one collective per batch'
+    out = shard.unpack_gathered(gathered)
+    slots = shard.unpack_gathered(gathered, include_padding=True)
+    assert len(slots) == world * per and [s is None for s in slots] == [t >= n_tiles for t in range(world * per)]
+    # the rank's own slice of the gathered block is what it sent, bit for bit
+    assert torch.equal(gathered[rank * per:(rank + 1) * per], block)
+    for (l, e), l0, e0 in zip(out[lo:hi], lanes, endp):
+        assert np.array_equal(l, l0) and np.array_equal(e, np.asarray(e0, dtype=np.int32).reshape(-1, 2))
     q.put((rank, [(float(l[:, :, 0].max()), len(e)) for l, e in out]))
     dist.barrier()
     dist.destroy_process_group()
@@ -60,7 +73,14 @@ def test_all_gather_world2_gloo():
 
 
 def test_pack_refuses_to_drop_endpoints():
+    """The block has room for every candidate a tile can have (the clusters of its top-K endpoint pixels), so no rank can fail alone
+    in front of the collective; a caller that hands over more is refused loudly instead of being truncated."""
     import pytest
+    from lanemapping_amd import decode
+    assert shard.MAX_ENDP >= decode.TOPK and shard.TILE_BYTES % 8 == 0
     lanes = [np.full((72, 144, 2), -1.0)]
+    ok = shard.pack_tile_results(lanes, [np.arange(2 * decode.TOPK, dtype=np.int32).reshape(-1, 2)], 2, torch.device('cpu'))
+    (l, e), pad = shard.unpack_gathered(ok, include_padding=True)
+    assert pad is None and np.array_equal(l, lanes[0]) and np.array_equal(e, np.arange(2 * decode.TOPK).reshape(-1, 2))
     with pytest.raises(ValueError):
         shard.pack_tile_results(lanes, [np.zeros((shard.MAX_ENDP + 1, 2), dtype=np.int32)], 1, torch.device('cpu'))

@@ -4,7 +4,7 @@
 # reports half of a wide streaming read), units of 1 KiB per count as rocprofv3 reports them for these derived counters.
 # Writes profiles/pmc_traffic.json (read by bench.py) + the per-kernel table under profiles/.   usage: tools/pmc_traffic.sh [tag]
 R=${GRAFT_REPO_ROOT:?run through gpurun (GRAFT_REPO_ROOT is the repo copy on the GPU box)}
-TAG=${1:-r2}
+TAG=${1:-r3}
 O=$R/gpurun_out/pmc_traffic
 mkdir -p $O
 cd /tmp && export TMPDIR=/tmp
@@ -14,7 +14,9 @@ for wl in fused tiles; do
   done
 done
 python3 - <<PY
-import csv, glob, json, collections
+import csv, glob, json, collections, sys
+sys.path.insert(0, '$R')
+from bench import csrc_sha16          # stamp of the kernel sources these counters belong to (bench.py prints traffic_stale when it differs)
 out = {}
 table = []
 for wl in ('fused', 'tiles'):
@@ -24,7 +26,7 @@ for wl in ('fused', 'tiles'):
         f = glob.glob('$O/%s_%s/*counter_collection.csv' % (wl, c))[0]
         for r in csv.DictReader(open(f)):
             n = r['Kernel_Name']
-            k = ('wino_gemm' if 'wino_gemm' in n else 'wino_implicit' if ('wino_implicit' in n or 'wino_dual' in n) else 'wino_input' if 'wino_input' in n else
+            k = ('wino_gemm' if 'wino_gemm' in n else 'wino_implicit' if ('wino_implicit' in n or 'wino_dual' in n or 'wino_pipe' in n) else 'wino_input' if 'wino_input' in n else
                  'conv_mfma' if 'conv_mfma' in n else 'raster_partition' if 'raster_partition' in n else 'raster_band' if 'raster_band' in n else None)
             if k is None: continue
             per[k][c] += float(r['Counter_Value'])
@@ -36,7 +38,7 @@ for wl in ('fused', 'tiles'):
         return (2.0 * per[k]['FETCH_SIZE'] + per[k]['WRITE_SIZE']) * KB / steps
     mfma = sum(bytes_of(k) for k in ('wino_gemm', 'wino_implicit', 'wino_input', 'conv_mfma') if k in per)
     rast = sum(bytes_of(k) for k in ('raster_partition', 'raster_band') if k in per)
-    out[wl] = {'mfma_bytes_per_step': mfma, 'raster_bytes_per_step': rast if rast else None,
+    out[wl] = {'mfma_bytes_per_step': mfma, 'raster_bytes_per_step': rast if rast else None, 'csrc_sha16': csrc_sha16(),
                'source': 'profiles/${TAG}_pmc_traffic.txt (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes on bench.py --workload %s --streams 1; FETCH x 2 + WRITE, KiB units)' % wl}
     for k in per:
         table.append('%-6s %-18s launches/step %6.1f  fetch(x2) %10.1f MB/step  write %10.1f MB/step' % (wl, k, launches[k] / steps, 2 * per[k]['FETCH_SIZE'] * KB / steps / 1e6, per[k]['WRITE_SIZE'] * KB / steps / 1e6))

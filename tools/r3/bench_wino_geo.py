@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
-"""Implicit Winograd kernel alone on the FPN's big shapes (LANEMAP_WINO_OCTO picks the geometry, LANEMAP_HIP_LIB a variant build).
-On an LM_IPROF build it prints the octo kernel's phase cycles: wave 0 (role A) and wave 4 (role B)."""
+"""Implicit Winograd kernel alone on the FPN's big shapes (env switches pick the geometry, LANEMAP_HIP_LIB a variant build); on an
+LM_IPROF build the phase cycles of wave 0 per workgroup."""
 import ctypes
 import os
 import sys
@@ -9,7 +9,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspa
 from lanemapping_amd import ops
 dev = torch.device('cuda:0')
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 8
-SHAPES = [(256, 256, 1, 288), (256, 128, 1, 288), (256, 256, 2, 144), (128, 128, 1, 144), (128, 256, 1, 144)][:int(os.environ.get('NSHAPES', '5'))]
+SHAPES = [(256, 256, 1, 288), (256, 128, 1, 288), (256, 256, 2, 144), (128, 128, 1, 144), (128, 256, 1, 144), (256, 512, 1, 144)][:int(os.environ.get('NSHAPES', '6'))]
 out = []
 for cin, cout, dil, hw in SHAPES:
     x = ops.new_act(B, cin, hw, hw, dev).normal_()
@@ -37,14 +37,8 @@ for cin, cout, dil, hw in SHAPES:
     if has_prof:
         ops.lib().lm_iprof_read(buf, 1)
         nw = max(buf[11], 1)
-        names = ['setup+prologue', 'M', 'T', 'barriers', 'epilogue']
-        print(f'  iprof {cin}->{cout} d{dil} @{hw}: A: ' + ' '.join(f'{n}={buf[i] / nw:.0f}' for i, n in enumerate(names)) + f' total={sum(buf[:5]) / nw:.0f}'
-              + ' | B: ' + ' '.join(f'{n}={buf[5 + i] / nw:.0f}' for i, n in enumerate(names)) + f' total={sum(buf[5:10]) / nw:.0f}')
-    if has_prof and hasattr(ops.lib(), 'lm_oprof_read'):
-        ob = (ctypes.c_ulonglong * 20)()
-        ops.lib().lm_oprof_read(ob)
-        nslot = nw * (cin // 16)          # (plain stores per workgroup: the last launch; never reset - only the first, largest shape is clean)
-        print('     per-slot step cycles  wave0: ' + ' '.join(f'{ob[i] / nslot:.0f}' for i in range(9)) + '   wave4: ' + ' '.join(f'{ob[10 + i] / nslot:.0f}' for i in range(9)))
+        names = ['prologue', 'transform', 'barrier1', 'mfma', 'slabwait', 'barrier2', 'epilogue', 'setup']
+        print(f'  iprof {cin}->{cout} d{dil} @{hw}: ' + ' '.join(f'{n}={buf[i] / nw:.0f}' for i, n in enumerate(names)) + f' total={sum(buf[:11]) / nw:.0f} cycles/workgroup')
     tiles = ops.lib().lm_conv3x3_winograd_workspace_bytes(B, hw, hw, cin, dil) // (64 * cin)
     out.append(f'{cin}->{cout} d{dil}@{hw} {ms:.3f} ms {2.0 * 16 * tiles * cin * cout / ms / 1e9:5.1f} TF')
-print(os.path.basename(os.environ.get('LANEMAP_HIP_LIB', 'product')), 'octo' if os.environ.get('LANEMAP_WINO_OCTO', '1') != '0' else 'wide', ' | '.join(out))
+print(os.path.basename(os.environ.get('LANEMAP_HIP_LIB', 'product')), {k[13:]: v for k, v in os.environ.items() if k.startswith('LANEMAP_WINO')}, ' | '.join(out))
