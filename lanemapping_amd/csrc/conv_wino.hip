@@ -530,19 +530,13 @@ int launch_wino(const WinoParams& p, hipStream_t stream) {
     return LM_OK;
 }
 
-int wino_force() {   // LM_WINO_TILE: tile-variant experiments only
-    static const int force = [] { const char* e = getenv("LM_WINO_TILE"); return e ? atoi(e) : 0; }();
-    return force;
-}
-
 WinoGeom geom(int B, int H, int W, int dil) {
     WinoGeom g;
     g.B = B; g.H = H; g.W = W; g.dil = dil;
     g.Ty = ((H + dil - 1) / dil + 1) / 2;
     g.Tx = ((W + dil - 1) / dil + 1) / 2;
     g.Timg = dil * dil * g.Ty * g.Tx;
-    const int unit = wino_force() == 8 ? 384 : 128;      // rows per workgroup (192-row variant: lcm with the 128 of the others)
-    g.Tpad = (g.Timg + unit - 1) / unit * unit;
+    g.Tpad = (g.Timg + 127) / 128 * 128;                 // 128 rows of V per workgroup of the GEMM: a workgroup never straddles two images
     g.T = (long)B * g.Tpad;
     return g;
 }
@@ -576,15 +570,6 @@ constexpr int ILPW = 9;                          // global_load_lds instructions
 constexpr int IRAW = ILPW * 4 * 256;             // floats of the raw buffer (36,864 B; the last 32 cells are never read)
 constexpr int IVBUF = 16 * IBM * IKS;            // floats of the V slab (65,536 B)
 static_assert(ILPW * 4 * 16 >= ICELLS && INCOL % 8 == 0, "patch loads cover the slab");
-// WIDE geometry (Cout > 64): one workgroup = 32 tiles x 128 output channels (the four waves side by side in N) and 32-channel slabs.
-// The transform of a slab (same work per thread: one tile x 4 channels) now feeds twice the matrix work: in the 64 x 64 geometry the
-// transform phase was 1,900 of a slab's 10,700 cycles (in-kernel s_memtime phases, tools/bench_wino_imp.py on an LM_IPROF build).
-// Same LDS budget: cells of 32 channels (128 B), 72 column slots, V[xi][32 tiles][32 ch].
-constexpr int WBM = 32, WBN = 128, WKS = 32;
-constexpr int WNCOL = 2 * WBM + 2 * INSEG;       // 72 column slots
-constexpr int WROW = WNCOL * WKS;                // floats per patch row
-static_assert(4 * WNCOL * WKS == IRAW && 16 * WBM * WKS == IVBUF && WBM * WKS == IBM * IKS && WNCOL % 8 == 0, "wide geometry fills the same buffers");
-
 __device__ __attribute__((aligned(16))) float g_wino_zeros[1024 + 32];   // zero source for padding cells, any channel slab (Cin <= 1024)
 
 struct WinoImpParams {
@@ -831,11 +816,10 @@ __device__ unsigned long long g_iprof[IPROF_WG][12];   // [workgroup % IPROF_WG]
 #define LM_TICKE(slot)
 #endif
 
-// MODE 0: fp32, 64 tiles x 64 channels | 1: bf16x3 split, 64 x 64 | 2: fp32, WIDE (32 tiles x 128 channels, 32-channel slabs)
-template <int MODE>
-__global__ __launch_bounds__(256) void wino_implicit_kernel(WinoImpParams p) {
-    constexpr bool SPLIT = MODE == 1, WIDE = MODE == 2;
-    constexpr int BM = WIDE ? WBM : IBM, BN = WIDE ? WBN : IBN, KS = WIDE ? WKS : IKS, NCOL = WIDE ? WNCOL : INCOL;
+// The 64 tiles x 64 channels geometry described at the top of this section, with the split-precision GEMM (the fp32 variants of this
+// kernel - 64 x 64 and the WIDE 32 x 128 one of round 2 - were superseded by wino_dual_kernel / wino_pipe_kernel and removed).
+__global__ __launch_bounds__(256) void wino_split_kernel(WinoImpParams p) {
+    constexpr int BM = IBM, BN = IBN, KS = IKS, NCOL = INCOL;
     constexpr int CPC = KS / 4;                 // 16-byte chunks per cell (pixel x channel slab)
     constexpr int CPL = 64 / CPC;               // cells per global_load_lds wave instruction
 #ifdef LM_IPROF
@@ -849,7 +833,7 @@ __global__ __launch_bounds__(256) void wino_implicit_kernel(WinoImpParams p) {
     typedef __attribute__((address_space(3))) void lptr_t;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wm0 = WIDE ? 0 : (wave >> 1) * 32, wn0 = WIDE ? wave * 32 : (wave & 1) * 32;
+    const int wm0 = (wave >> 1) * 32, wn0 = (wave & 1) * 32;
     const int n_tiles = (p.Cout + BN - 1) / BN;
     // XCD-aware order (workgroups are dealt round-robin to the 8 XCDs): every XCD owns a contiguous range of M blocks and walks it
     // once per N tile, N tile OUTER - at any time the 32 CUs of an XCD stream the SAME 64-channel slice of U (L2 resident)
@@ -926,7 +910,7 @@ __global__ __launch_bounds__(256) void wino_implicit_kernel(WinoImpParams p) {
         const bool ok = r < 4 && lc < 2 * n + 2 && n > 0 && (unsigned)yy < (unsigned)g.H && (unsigned)xx < (unsigned)g.W;
         gsrc[s_] = ok ? p.x + (long)(img_pix0 + yy * g.W + xx) * p.ldx + ch * 4 : p.zeros + ch * 4;
     }
-    // --- TRANSFORM task of this thread: tile tid / CPC, channel quad tid % CPC.  WIDE: V rows are 8 chunks, XOR-swizzled by (tile >> 1) & 7
+    // --- TRANSFORM task of this thread: tile tid / CPC, channel quad tid % CPC
     // (the 8 quads of a tile fill one 128-byte row: conflict-free stores; the 16 rows of an A-fragment read group differ in
     // (tile & 1, (tile >> 1) & 7): all 64 banks)
     int roff[4], tvoff;
@@ -938,20 +922,19 @@ __global__ __launch_bounds__(256) void wino_implicit_kernel(WinoImpParams p) {
         const int cb = 2 * tl + 2 * sg;
 #pragma unroll
         for (int c = 0; c < 4; ++c) roff[c] = (rot3(cb + c) * CPC + qd) * 4;
-        tvoff = WIDE ? (tl * 8 + (qd ^ ((tl >> 1) & 7))) * 4 : (tl * 4 + (qd ^ ((tl >> 2) & 3))) * 4;
+        tvoff = (tl * 4 + (qd ^ ((tl >> 2) & 3))) * 4;
     }
     // --- MFMA-phase A fragment offsets inside V[xi]: row = tile wm0 + frow, chunk 2 kk + fhalf
     const int frow = lane & 31, fhalf = lane >> 5;
-    int aoff[WIDE ? 4 : 2];                     // WIDE: [2 kh + kk], kh = 16-channel half of the slab
+    int aoff[2];
     {
         const int tl = wm0 + frow;
 #pragma unroll
-        for (int kk = 0; kk < (WIDE ? 4 : 2); ++kk)
-            aoff[kk] = WIDE ? (tl * 8 + ((2 * kk + fhalf) ^ ((tl >> 1) & 7))) * 4 : (tl * 4 + ((2 * kk + fhalf) ^ ((tl >> 2) & 3))) * 4;
+        for (int kk = 0; kk < 2; ++kk) aoff[kk] = (tl * 4 + ((2 * kk + fhalf) ^ ((tl >> 2) & 3))) * 4;
     }
     const int cslabs = p.C / KS;
     const unsigned bvoff = (unsigned)lane * 16u;
-    constexpr int BFRAG = SPLIT ? 768 : 512;                           // floats per (xi, slab, 32-channel tile): 2 x 64 x 16 B | 3 planes x 64 x 16 B
+    constexpr int BFRAG = 768;                                         // floats per (xi, slab, 32-channel tile): 3 planes x 64 x 16 B
     const long bstep = (long)p.NT * BFRAG;                             // floats between consecutive 16-channel slabs of one xi
     const float* const bbase = p.U + (long)((n0 + wn0) >> 5) * BFRAG;  // this wave's 32-channel tile
     const long bxi = (long)(p.C / IKS) * bstep;                        // floats between consecutive xi
@@ -964,7 +947,7 @@ __global__ __launch_bounds__(256) void wino_implicit_kernel(WinoImpParams p) {
 #if defined(LM_IPROF) && !defined(LM_IPROF_EPI)
     LM_TICK(7)                                  // (index setup; slot 0 = the prologue's loads)
 #endif
-    if constexpr (SPLIT) {
+    {
     f32x4 bq3[8][3];
 #pragma unroll
     for (int s_ = 0; s_ < ILPW; ++s_)
@@ -1018,130 +1001,6 @@ __global__ __launch_bounds__(256) void wino_implicit_kernel(WinoImpParams p) {
     }
 #pragma unroll
     for (int k = 0; k < 8; ++k) bwait3<0>(bq3[k]);
-
-    } else if constexpr (!WIDE) {
-    f32x4 bq[8][2];
-    // prologue: slab 0 of the patch, B of steps 0 .. BD-1 of slab 0
-#pragma unroll
-    for (int s_ = 0; s_ < ILPW; ++s_)
-        __builtin_amdgcn_global_load_lds((gptr_t*)gsrc[s_], (lptr_t*)(rawbuf + (s_ * 4 + wave) * 256), 16, 0, 0);
-#pragma unroll
-    for (int k = 0; k < BD; ++k) bload2(bq[k], bvoff, bbase + (long)k * bxi);
-#pragma unroll
-    for (int k = 0; k < BD; ++k) bwait<0>(bq[k]);
-    __builtin_amdgcn_s_barrier();
-    LM_TICK(0)
-
-    for (int cs = 0; cs < cslabs; ++cs) {
-        // TRANSFORM phase: raw slab cs (complete: every wave waited for its loads before the barrier) -> V
-#ifndef LM_IABL_NOTF
-        wino_slab_transform<NCOL * KS>(rawbuf, Vbuf, roff, tvoff);
-#endif
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // (a raw barrier: __syncthreads() would also drain the B ring)
-        LM_TICK(1)
-        __builtin_amdgcn_s_barrier();          // V complete; the raw buffer is free for the next slab's loads
-        LM_TICK(2)
-        const bool more = cs + 1 < cslabs;
-        // the last slab has nothing to prefetch: its loads re-read slab 0 of the zero block / tensor into the idle buffer (harmless)
-        const long goff = more ? (long)(cs + 1) * KS : 0;
-        const float* const bs = bbase + (long)cs * bstep;                                   // (xi 0, this slab)
-        const float* const bs_next = bbase + (long)(more ? cs + 1 : 0) * bstep;             // (xi 0, next slab)
-        int gnext = 0;
-        f32x4 a0[2], a1[2];
-        a0[0] = *reinterpret_cast<const f32x4*>(Vbuf + aoff[0]);
-        a0[1] = *reinterpret_cast<const f32x4*>(Vbuf + aoff[1]);
-        // B prefetched by step XI belongs to step XI + BD: same slab while XI + BD < 16, else step XI + BD - 16 of the next slab
-#define LM_WSTEP(XI, G, NW, AC, AN) \
-        wino_imp_step<XI, G, NW, ((XI) < 15)>(acc[XI], bq, bvoff, (XI) + BD < 16 ? bs + (long)((XI) + BD) * bxi : bs_next + (long)((XI) + BD - 16) * bxi, \
-                                              Vbuf + ((XI) + 1) * (IBM * IKS) + aoff[0], Vbuf + ((XI) + 1) * (IBM * IKS) + aoff[1], AC, AN, gsrc, goff, \
-                                              rawbuf, wave, gnext)
-        LM_WSTEP(0, 2, 16, a0, a1);
-        LM_WSTEP(1, 2, 18, a1, a0);
-        LM_WSTEP(2, 2, 20, a0, a1);
-        LM_WSTEP(3, 2, 22, a1, a0);
-        LM_WSTEP(4, 1, 23, a0, a1);
-        LM_WSTEP(5, 0, 23, a1, a0);
-        LM_WSTEP(6, 0, 23, a0, a1);
-        LM_WSTEP(7, 0, 23, a1, a0);
-        LM_WSTEP(8, 0, 21, a0, a1);
-        LM_WSTEP(9, 0, 19, a1, a0);
-        LM_WSTEP(10, 0, 17, a0, a1);
-        LM_WSTEP(11, 0, 15, a1, a0);
-        LM_WSTEP(12, 0, 14, a0, a1);
-        LM_WSTEP(13, 0, 14, a1, a0);
-        LM_WSTEP(14, 0, 14, a0, a1);
-        LM_WSTEP(15, 0, 14, a1, a0);
-#undef LM_WSTEP
-        static_assert(2 * 4 + 1 == ILPW, "patch loads per wave and slab");
-        LM_TICK(3)
-        bwait<14>(bq[0]);                      // every patch load of the next slab has landed (only the 7 youngest B sets are in flight)
-        LM_TICK(4)
-        __builtin_amdgcn_s_barrier();          // all waves: done reading V, next raw slab complete
-        LM_TICK(5)
-    }
-    // The last slab's B prefetches (re-reads of valid addresses, never used) are still in flight: they must land before the compiler
-    // hands their destination registers to the epilogue - a late return would overwrite whatever lives there by then (pointers).
-#pragma unroll
-    for (int k = 0; k < 8; ++k) bwait<0>(bq[k]);
-
-    } else {
-    // WIDE: a slab is two 16-channel halves; step S = 2 xi + kh (16-channel half kh of xi): the same 8 MFMAs, two A fragments and two
-    // B fragments as a step of the 64 x 64 loop, 32 steps per slab.  B of step S sits at (xi, 16-channel slab 2 cs + kh) of the same
-    // packed U.  The 9 patch loads of the next slab go out one per step in steps 0..8:
-    // NWAIT(S) = 2 BD + |{0..8} intersected with {S-7..S}|.
-    f32x4 bq[8][2];
-#define LM_BADDR(cs_, S) (bbase + (long)(2 * (cs_) + ((S) & 1)) * bstep + (long)((S) >> 1) * bxi)
-#pragma unroll
-    for (int s_ = 0; s_ < ILPW; ++s_)
-        __builtin_amdgcn_global_load_lds((gptr_t*)gsrc[s_], (lptr_t*)(rawbuf + (s_ * 4 + wave) * 256), 16, 0, 0);
-#pragma unroll
-    for (int k = 0; k < BD; ++k) bload2(bq[k], bvoff, LM_BADDR(0, k));
-#pragma unroll
-    for (int k = 0; k < BD; ++k) bwait<0>(bq[k]);
-    __builtin_amdgcn_s_barrier();
-    LM_TICK(0)
-    for (int cs = 0; cs < cslabs; ++cs) {
-        // (storing planes 4..15 of V behind the first MFMA steps was tried: f32 MFMA issue stalls on the wave's own ds_write data
-        // transfer, the matrix phase grew by exactly the store time it was meant to hide)
-#ifndef LM_IABL_NOTF
-        wino_slab_transform<NCOL * KS>(rawbuf, Vbuf, roff, tvoff);
-#endif
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        LM_TICK(1)
-        __builtin_amdgcn_s_barrier();
-        LM_TICK(2)
-        const bool more = cs + 1 < cslabs;
-        const long goff = more ? (long)(cs + 1) * KS : 0;
-        const int cs_next = more ? cs + 1 : 0;
-        int gnext = 0;
-        f32x4 a0[2], a1[2];
-        a0[0] = *reinterpret_cast<const f32x4*>(Vbuf + aoff[0]);
-        a0[1] = *reinterpret_cast<const f32x4*>(Vbuf + aoff[1]);
-#define LM_WSTEP(S, NW, AC, AN) \
-        wino_imp_step<(S) & 7, ((S) < 9 ? 1 : 0), NW, ((S) < 31)>(acc[(S) >> 1], bq, bvoff, \
-            (S) + BD < 32 ? LM_BADDR(cs, (S) + BD) : LM_BADDR(cs_next, (S) + BD - 32), \
-            Vbuf + (((S) + 1) >> 1) * (WBM * WKS) + aoff[2 * (((S) + 1) & 1)], Vbuf + (((S) + 1) >> 1) * (WBM * WKS) + aoff[2 * (((S) + 1) & 1) + 1], \
-            AC, AN, gsrc, goff, rawbuf, wave, gnext)
-        // (a separate step sequence for the last slab - no patch loads, no B beyond the slab - was tried: the branch makes the compiler
-        // copy ring registers at the join while their asm loads are still in flight.  The loop body must stay straight-line code.)
-        LM_WSTEP(0, 15, a0, a1);  LM_WSTEP(1, 16, a1, a0);  LM_WSTEP(2, 17, a0, a1);  LM_WSTEP(3, 18, a1, a0);
-        LM_WSTEP(4, 19, a0, a1);  LM_WSTEP(5, 20, a1, a0);  LM_WSTEP(6, 21, a0, a1);  LM_WSTEP(7, 22, a1, a0);
-        LM_WSTEP(8, 22, a0, a1);  LM_WSTEP(9, 21, a1, a0);  LM_WSTEP(10, 20, a0, a1); LM_WSTEP(11, 19, a1, a0);
-        LM_WSTEP(12, 18, a0, a1); LM_WSTEP(13, 17, a1, a0); LM_WSTEP(14, 16, a0, a1); LM_WSTEP(15, 15, a1, a0);
-        LM_WSTEP(16, 14, a0, a1); LM_WSTEP(17, 14, a1, a0); LM_WSTEP(18, 14, a0, a1); LM_WSTEP(19, 14, a1, a0);
-        LM_WSTEP(20, 14, a0, a1); LM_WSTEP(21, 14, a1, a0); LM_WSTEP(22, 14, a0, a1); LM_WSTEP(23, 14, a1, a0);
-        LM_WSTEP(24, 14, a0, a1); LM_WSTEP(25, 14, a1, a0); LM_WSTEP(26, 14, a0, a1); LM_WSTEP(27, 14, a1, a0);
-        LM_WSTEP(28, 14, a0, a1); LM_WSTEP(29, 14, a1, a0); LM_WSTEP(30, 14, a0, a1); LM_WSTEP(31, 14, a1, a0);
-#undef LM_WSTEP
-        LM_TICK(3)
-        bwait<14>(bq[0]);
-        LM_TICK(4)
-        __builtin_amdgcn_s_barrier();
-        LM_TICK(5)
-    }
-#undef LM_BADDR
-#pragma unroll
-    for (int k = 0; k < 8; ++k) bwait<0>(bq[k]);
 
     }
 #ifdef LM_IABL_NOEPI
@@ -2144,19 +2003,8 @@ LM_API int lm_winograd_gemm_f32(void* stream, const void* V, const float* wu, in
     }
     p.zero = zero;
     hipStream_t s = (hipStream_t)stream;
-    const int force = wino_force();
-    if (force == 8) return launch_wino<192, 64, 96, 32>(p, s);         // 4 waves of 96x32: three accumulator tiles (chains) per wave
-    if (force == 9) return launch_wino<128, 64, 32, 64, 32, 3>(p, s);   // loads two slabs ahead (72 KB LDS, still 2 workgroups/CU)
-    if (force == 11) return launch_wino<128, 64, 32, 32>(p, s);    // 8 waves of 32x32: half the loads per wave, 4 waves per SIMD if <= 128 registers
-    if (force == 10) return launch_wino<64, 64, 32, 32>(p, s);     // 4 waves of 32x32: ~120 registers, 4 workgroups/CU
-    if (force == 1 && !gn_partial) return launch_wino<128, 128, 64, 64>(p, s);
-    if (force == 3 && !gn_partial) return launch_wino<64, 128, 32, 64>(p, s);
-    if (force == 4) return launch_wino<256, 64, 32, 64>(p, s);
-    if (force == 5) return launch_wino<128, 128, 64, 32>(p, s);
-    if (force == 6 && Cin % 64 == 0) return launch_wino<128, 128, 64, 32, 64>(p, s);   // 8 waves, 64-float K slabs, 128 KB LDS
-    if (force == 7 && Cin % 64 == 0) return launch_wino<128, 64, 32, 64, 64>(p, s);    // 4 waves, 64-float K slabs, 96 KB LDS
-    // 128 x 64 tiles: 4 output + 1 temporary accumulator sets = 246 registers -> two workgroups per CU.  The 128 x 128 tile
-    // (471 registers, one workgroup per CU) measured 1.32x over the direct kernel on 256->256@288^2, this one 1.52x.
+    // 128 x 64 tiles: 4 output + 1 temporary accumulator sets = 246 registers -> two workgroups per CU (the tile / slab / buffering
+    // variants that were measured against it in round 1 are listed in profiles/README.md; their code is gone)
     return launch_wino<128, 64, 32, 64>(p, s);
 }
 
@@ -2200,16 +2048,23 @@ int wino_implicit_launch(int mode, void* stream, const float* x, int ldx, const 
         zeros = (const float*)sym;
     }
     p.zeros = zeros;
-    const size_t lds = (size_t)(IRAW + IVBUF) * sizeof(float);
-    // the WIDE geometry halves the transform work per matrix operation; it needs 128 real output channels per workgroup to pay
-    static const bool wide_ok = !(getenv("LANEMAP_WINO_WIDE") && atoi(getenv("LANEMAP_WINO_WIDE")) == 0);
-    // DUAL geometry (two workgroups per CU): measured on B = 8 (tools/bench_wino.py, LANEMAP_WINO_DUAL=1 vs 0): 64->64@288^2 0.324 ->
-    // 0.290 ms, 128->128@144^2 0.248 -> 0.236, 128->256@144^2 0.461 -> 0.445, 256->256 d2@144^2 0.799 -> 0.793, but 256->256@288^2
-    // 3.25 -> 3.39 and 256->128@288^2 1.55 -> 1.58 (twice the transform and twice the input re-reads per matrix operation); end to
-    // end 252.7 tiles/s with it everywhere against 259.8, 260.4 with it on Cin <= 128, 260.9 on Cout <= 64.  Default: the layers the
-    // wide geometry cannot take (Cout <= 64).  LANEMAP_WINO_DUAL = 0: never, 1: every fp32 launch, 2: Cout <= 64, 3: Cin <= 128
-    static const int dual_sel = getenv("LANEMAP_WINO_DUAL") ? atoi(getenv("LANEMAP_WINO_DUAL")) : 2;
-    if (mode == 0 && (dual_sel == 1 || (dual_sel == 2 && Cout <= IBN) || (dual_sel == 3 && Cin <= 128))) {
+    if (mode == 1) {        // split-precision study kernel (64 tiles x 64 channels)
+        const size_t lds = (size_t)(IRAW + IVBUF) * sizeof(float);
+        const long blocks = (p.g.T / IBM) * ((Cout + IBN - 1) / IBN);
+        LM_REQUIRE(blocks > 0 && blocks < (1L << 31) && p.g.T % IBM == 0, "conv_wino_implicit: bad grid %ld", blocks);
+        if (int e = lm_ensure_dynamic_lds((const void*)wino_split_kernel, lds)) return e;
+        hipLaunchKernelGGL(wino_split_kernel, dim3((unsigned)blocks), dim3(256), lds, (hipStream_t)stream, p);
+        LM_LAUNCH_CHECK();
+        return LM_OK;
+    }
+    // fp32, two geometries (bit-identical to each other and to the materialising pair):
+    //   Cout <= 64: DUAL (32 tiles x 64 channels, 8 xi per wave, two workgroups per CU) - what the per-workgroup fixed costs of the
+    //               thin layers want (64->64@288^2 B = 8: 0.324 ms with a 64 x 64 sixteen-xi tile, 0.290 with this one);
+    //   Cout  > 64: PIPE (32 tiles x 128 channels, 16 xi per wave, the slab transform spread over the MFMA steps) - half the transform
+    //               work and half the input re-reads per matrix operation (256->256@288^2: DUAL 3.39 ms, round-2 WIDE 3.25, PIPE 3.18).
+    // LANEMAP_WINO_DUAL=1 forces DUAL everywhere (test_conv_winograd_geometries_bit_identical).
+    static const bool dual_all = getenv("LANEMAP_WINO_DUAL") && atoi(getenv("LANEMAP_WINO_DUAL")) == 1;
+    if (dual_all || Cout <= DBN) {
         const size_t dlds = (size_t)(DRAW + DVBUF) * sizeof(float);
         const long dblocks = (p.g.T / DBM) * ((Cout + DBN - 1) / DBN);
         LM_REQUIRE(dblocks > 0 && dblocks < (1L << 31) && p.g.T % DBM == 0, "conv_wino_implicit: bad grid %ld", dblocks);
@@ -2218,27 +2073,11 @@ int wino_implicit_launch(int mode, void* stream, const float* x, int ldx, const 
         LM_LAUNCH_CHECK();
         return LM_OK;
     }
-    // PIPE geometry (round 3): the wide workgroup with the slab transform spread over the MFMA steps (wino_pipe_kernel).
-    // LANEMAP_WINO_PIPE = 0: the round-2 wide kernel instead
-    static const bool pipe_ok = !(getenv("LANEMAP_WINO_PIPE") && atoi(getenv("LANEMAP_WINO_PIPE")) == 0);
-    if (mode == 0 && pipe_ok && wide_ok && Cout > IBN && Cin % WKS == 0) {
-        const size_t plds = (size_t)(2 * PRAWH + 2 * PVH) * sizeof(float);
-        const long pblocks = (p.g.T / PBM) * ((Cout + PBN - 1) / PBN);
-        LM_REQUIRE(pblocks > 0 && pblocks < (1L << 31) && p.g.T % PBM == 0, "conv_wino_implicit: bad grid %ld", pblocks);
-        if (int e = lm_ensure_dynamic_lds((const void*)wino_pipe_kernel, plds)) return e;
-        hipLaunchKernelGGL(wino_pipe_kernel, dim3((unsigned)pblocks), dim3(256), plds, (hipStream_t)stream, p);
-        LM_LAUNCH_CHECK();
-        return LM_OK;
-    }
-    if (mode == 0 && wide_ok && Cout > IBN && Cin % WKS == 0) mode = 2;
-    const void* fn = mode == 0 ? (const void*)wino_implicit_kernel<0> : mode == 1 ? (const void*)wino_implicit_kernel<1> : (const void*)wino_implicit_kernel<2>;
-    if (int e = lm_ensure_dynamic_lds(fn, lds)) return e;
-    const int bm = mode == 2 ? WBM : IBM, bn = mode == 2 ? WBN : IBN;
-    const long blocks = (p.g.T / bm) * ((Cout + bn - 1) / bn);
-    LM_REQUIRE(blocks > 0 && blocks < (1L << 31) && p.g.T % bm == 0, "conv_wino_implicit: bad grid %ld", blocks);
-    if (mode == 0) hipLaunchKernelGGL(wino_implicit_kernel<0>, dim3((unsigned)blocks), dim3(256), lds, (hipStream_t)stream, p);
-    else if (mode == 1) hipLaunchKernelGGL(wino_implicit_kernel<1>, dim3((unsigned)blocks), dim3(256), lds, (hipStream_t)stream, p);
-    else hipLaunchKernelGGL(wino_implicit_kernel<2>, dim3((unsigned)blocks), dim3(256), lds, (hipStream_t)stream, p);
+    const size_t plds = (size_t)(2 * PRAWH + 2 * PVH) * sizeof(float);
+    const long pblocks = (p.g.T / PBM) * ((Cout + PBN - 1) / PBN);
+    LM_REQUIRE(pblocks > 0 && pblocks < (1L << 31) && p.g.T % PBM == 0 && Cin % (2 * PKS) == 0, "conv_wino_implicit: bad grid %ld", pblocks);
+    if (int e = lm_ensure_dynamic_lds((const void*)wino_pipe_kernel, plds)) return e;
+    hipLaunchKernelGGL(wino_pipe_kernel, dim3((unsigned)pblocks), dim3(256), plds, (hipStream_t)stream, p);
     LM_LAUNCH_CHECK();
     return LM_OK;
 }

@@ -351,11 +351,16 @@ LM_API int lm_endp_topk(void* stream, const float* endp_logit, void* workspace, 
     // node were observed to leave the histograms of the previous replay in place)
     const long zero_words = (long)B * (3 * NB + 4);
     hipLaunchKernelGGL(zero_u32_kernel, dim3(lm_cdiv(zero_words, 256)), dim3(256), 0, s, (unsigned*)workspace, zero_words);
+    LM_LAUNCH_CHECK();
     dim3 grid(256, B);
     hipLaunchKernelGGL(topk_pass_kernel<0>, grid, dim3(256), 0, s, p);
+    LM_LAUNCH_CHECK();
     hipLaunchKernelGGL(topk_pass_kernel<1>, grid, dim3(256), 0, s, p);
+    LM_LAUNCH_CHECK();
     hipLaunchKernelGGL(topk_pass_kernel<2>, grid, dim3(256), 0, s, p);
+    LM_LAUNCH_CHECK();
     hipLaunchKernelGGL(topk_pass_kernel<3>, grid, dim3(256), 0, s, p);
+    LM_LAUNCH_CHECK();
     hipLaunchKernelGGL(topk_ties_kernel, dim3(B), dim3(1024), 0, s, p);
     LM_LAUNCH_CHECK();
     hipLaunchKernelGGL(topk_sort_kernel, dim3(B), dim3(1024), 0, s, p, out_idx, out_score, out_status);

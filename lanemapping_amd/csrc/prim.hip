@@ -107,7 +107,7 @@ __global__ __launch_bounds__(256) void scan_tile_kernel(const unsigned* __restri
 size_t align256(size_t v) { return (v + 255) / 256 * 256; }
 
 // ---------------------------------------------------------------------------------------------------------------- radix sort
-__global__ __launch_bounds__(256) void sort_hist_kernel(const unsigned* __restrict__ keys, long n, int shift, unsigned nblocks,
+__global__ __launch_bounds__(256) void sort_hist_kernel(const unsigned* __restrict__ keys, long n, int shift, unsigned mask, unsigned nblocks,
                                                         unsigned* __restrict__ hist) {
     __shared__ unsigned h[256];
     h[threadIdx.x] = 0;
@@ -116,14 +116,14 @@ __global__ __launch_bounds__(256) void sort_hist_kernel(const unsigned* __restri
 #pragma unroll
     for (int k = 0; k < IPT; ++k) {
         const long i = base + k * 256 + threadIdx.x;
-        if (i < n) atomicAdd(&h[(keys[i] >> shift) & 255u], 1u);
+        if (i < n) atomicAdd(&h[(keys[i] >> shift) & mask], 1u);
     }
     __syncthreads();
     hist[(size_t)threadIdx.x * nblocks + blockIdx.x] = h[threadIdx.x];
 }
 
 __global__ __launch_bounds__(256) void sort_scatter_kernel(const unsigned* __restrict__ keys, const unsigned* __restrict__ vals, long n,
-                                                           int shift, unsigned nblocks, const unsigned* __restrict__ hist_scan,
+                                                           int shift, unsigned mask, unsigned nblocks, const unsigned* __restrict__ hist_scan,
                                                            unsigned* __restrict__ keys_out, unsigned* __restrict__ vals_out) {
     __shared__ unsigned cnt[4][256];          // per wave: elements of each digit seen so far (ends as the wave's digit counts)
     __shared__ unsigned dstart[256];          // first slot of a digit in the tile's digit-ordered staging
@@ -143,7 +143,7 @@ __global__ __launch_bounds__(256) void sort_scatter_kernel(const unsigned* __res
         const bool ok = i < n;
         key[c] = ok ? keys[i] : 0u;
         val[c] = ok ? vals[i] : 0u;
-        const unsigned d = (key[c] >> shift) & 255u;
+        const unsigned d = (key[c] >> shift) & mask;
         unsigned long long peers = __ballot(ok);
 #pragma unroll
         for (int b = 0; b < 8; ++b) {
@@ -174,7 +174,7 @@ __global__ __launch_bounds__(256) void sort_scatter_kernel(const unsigned* __res
     for (int c = 0; c < IPT; ++c) {
         const long i = base + c * 64 + lane;
         if (i < n) {
-            const unsigned d = (key[c] >> shift) & 255u;
+            const unsigned d = (key[c] >> shift) & mask;
             const unsigned pos = dstart[d] + cnt[w][d] + rank[c];
             stage_k[pos] = key[c];
             stage_v[pos] = val[c];
@@ -183,7 +183,7 @@ __global__ __launch_bounds__(256) void sort_scatter_kernel(const unsigned* __res
     __syncthreads();
     for (unsigned j = tid; j < all; j += 256) {
         const unsigned k = stage_k[j];
-        const unsigned d = (k >> shift) & 255u;
+        const unsigned d = (k >> shift) & mask;
         const size_t o = (size_t)gbase[d] + (j - dstart[d]);
         keys_out[o] = k;
         vals_out[o] = stage_v[j];
@@ -237,11 +237,13 @@ int lm_prim_sort_pairs_u32(hipStream_t s, unsigned* keys, unsigned* keys_alt, un
     const size_t hbytes = align256((size_t)nb * 256 * 4);
     unsigned *ki = keys, *ko = keys_alt, *vi = vals, *vo = vals_alt;
     for (int shift = 0; shift < end_bit; shift += 8) {
-        hipLaunchKernelGGL(sort_hist_kernel, dim3(nb), dim3(256), 0, s, ki, n, shift, nb, hist);
+        // the last pass only looks at the bits below end_bit: keys may carry payload above it ([begin, end) semantics of the contract)
+        const unsigned mask = (1u << (end_bit - shift < 8 ? end_bit - shift : 8)) - 1u;
+        hipLaunchKernelGGL(sort_hist_kernel, dim3(nb), dim3(256), 0, s, ki, n, shift, mask, nb, hist);
         LM_LAUNCH_CHECK();
         const int rc = lm_prim_exclusive_scan_u32(s, hist, hist, (long)nb * 256, (char*)temp + hbytes, temp_bytes - hbytes);
         if (rc != LM_OK) return rc;
-        hipLaunchKernelGGL(sort_scatter_kernel, dim3(nb), dim3(256), 0, s, ki, vi, n, shift, nb, hist, ko, vo);
+        hipLaunchKernelGGL(sort_scatter_kernel, dim3(nb), dim3(256), 0, s, ki, vi, n, shift, mask, nb, hist, ko, vo);
         LM_LAUNCH_CHECK();
         unsigned* t = ki; ki = ko; ko = t;
         t = vi; vi = vo; vo = t;

@@ -20,8 +20,13 @@ class PackedModule(nn.Module):
             self.__dict__['_packed_slots'] = slots
         return slots
 
+    def param_key(self):
+        """Identity + version of every parameter / buffer below this module: what the packed cache - and a captured HIP graph, which
+        bakes the packed pointers in - is valid for."""
+        return tuple((t.data_ptr(), t._version) for d, n in self._slots() for t in (d[n],) if t is not None)
+
     def packed(self):
-        key = tuple((t.data_ptr(), t._version) for d, n in self._slots() for t in (d[n],) if t is not None)
+        key = self.param_key()
         cache = self.__dict__.get('_packed_cache')
         if cache is None or cache[0] != key:
             with torch.no_grad():

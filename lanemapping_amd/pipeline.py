@@ -5,6 +5,7 @@ in C++ (ctypes releases the GIL), fanned out over a thread pool, one task per ti
 GPU work of the next batch.  Replaces the per-batch body of Runner.infer_lane_coordinate_endpoint_semantics
 (reference engine/runner.py:725-828) minus metrics / overlays.
 """
+import collections
 import os
 import time
 from concurrent.futures import ThreadPoolExecutor
@@ -22,7 +23,7 @@ class TilePipeline:
         one HIP graph per input shape and replay it - the host then spends one launch per batch instead of ~9 ms of enqueue work.
         Same kernels, same arguments, same stream order: bit-identical outputs (test_tile_pipeline_graph_replay_bit_identical)."""
         self.use_graph = (os.environ.get('LANEMAP_GRAPHS', '0') != '0') if use_graph is None else bool(use_graph)
-        self._graphs = {}
+        self._graphs = collections.OrderedDict()      # (shape, dtype, device) -> (graph, static input, outputs, weight key); LRU, MAX_GRAPHS entries
         self.net = net
         self.cfg = net.cfg
         self.rowref = net.cfg.heads.type == 'RowSharNotReducRef'
@@ -45,11 +46,31 @@ class TilePipeline:
         ev.record()
         return host, ev, keep, crop
 
+    MAX_GRAPHS = 4          # captured graphs kept per pipeline (each one pins a private activation pool: ~1 GB per tile of its batch)
+
+    def _weights_key(self):
+        """What a captured graph is valid for: the parameter identities / versions of every module that packs weights.  A graph bakes
+        the packed-weight and workspace pointers in and never re-runs PackedModule.packed(), so load_ckpt / load_state_dict / .to() /
+        an in-place edit must force a recapture (the eager path repacks through the same key)."""
+        from .packing import PackedModule
+        mods = self.__dict__.get('_packed_mods')
+        if mods is None:
+            mods = self.__dict__['_packed_mods'] = [m for m in self.net.modules() if isinstance(m, PackedModule)]
+        return tuple(m.param_key() for m in mods)
+
+    def clear_graphs(self):
+        """Drop every captured graph (and the activation pools they pin)."""
+        self._graphs.clear()
+
     def _replay(self, proj):
         """HIP-graph path: static input / output buffers per (shape, dtype); the first batch of a shape runs once eagerly (lazy
         initialisation: weight packing, kernel attributes, workspaces) and is then captured on a stream of its own."""
         key = (tuple(proj.shape), proj.dtype, proj.device)
+        wkey = self._weights_key()
         ent = self._graphs.get(key)
+        if ent is not None and ent[3] != wkey:        # the weights changed under the graph: recapture
+            del self._graphs[key]
+            ent = None
         if ent is None:
             static_in = torch.empty_like(proj)
             static_in.copy_(proj)
@@ -58,9 +79,12 @@ class TilePipeline:
             graph = torch.cuda.CUDAGraph()
             with torch.cuda.graph(graph, stream=torch.cuda.Stream(device=proj.device)):
                 out = self._device_part(static_in)
-            ent = (graph, static_in, out)
+            ent = (graph, static_in, out, wkey)
             self._graphs[key] = ent
-        graph, static_in, out = ent
+            while len(self._graphs) > self.MAX_GRAPHS:
+                self._graphs.popitem(last=False)
+        self._graphs.move_to_end(key)
+        graph, static_in, out, _ = ent
         static_in.copy_(proj, non_blocking=True)
         graph.replay()
         return out

@@ -927,13 +927,18 @@ def test_bench_self_launch_two_ranks(dev):
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     env = {k: v for k, v in os.environ.items() if k not in ('WORLD_SIZE', 'RANK', 'LOCAL_RANK')}
     env.update(LANEMAP_BENCH_DEVICE='0', LANEMAP_BENCH_BACKEND='gloo')
-    r = subprocess.run([sys.executable, os.path.join(root, 'bench.py'), '--gpus', '2', '--workload', 'tiles', '--steps', '2', '--warmup', '1'],
-                       capture_output=True, text=True, timeout=900, cwd=root, env=env)
+    r = subprocess.run([sys.executable, os.path.join(root, 'bench.py'), '--gpus', '2', '--workload', 'tiles', '--steps', '2', '--warmup', '1',
+                        '--cpu-budget-s', '6'], capture_output=True, text=True, timeout=900, cwd=root, env=env)
     assert r.returncode == 0, (r.stdout + r.stderr)[-3000:]
     lines = [l for l in r.stdout.strip().split('\n') if l.startswith('{')]
     assert len(lines) == 1
     d = json.loads(lines[0])
     assert d['n_gpus'] == 2 and d['config']['tiles_per_step_per_gpu'] == 8 and d['value'] > 10
+    # the bench validated the CONTENT of its last all-gather on every rank (it exits non-zero otherwise): 2 x 8 valid tiles in ONE
+    # byte block, each rank's slice bitwise the block it sent and equal to the lanes / endpoints of its last batch
+    assert d['config']['gather_check'].startswith('last all-gather: 16 valid tiles in one [16, 169992] byte block'), d['config']['gather_check']
+    # ... and the CPU path is timed on this host next to the N > 1 number too
+    assert d['cpu_baseline'] is not None and d['cpu_baseline']['value'] > 0 and d['cpu_baseline']['cores'] >= 1
 
 
 def _g15_net(dev, synth_sd, g):
@@ -1321,11 +1326,13 @@ def test_exclusive_scan_u32(dev, n):
 
 
 @pytest.mark.parametrize('n,end_bit,kind', [(0, 32, 'rand'), (1, 32, 'rand'), (64, 8, 'rand'), (4097, 32, 'rand'), (100_003, 24, 'few'),
-                                            (1_000_000, 32, 'rand'), (4_194_304, 24, 'cells'), (3_000_001, 16, 'equal')])
+                                            (1_000_000, 32, 'rand'), (4_194_304, 24, 'cells'), (3_000_001, 16, 'equal'),
+                                            (200_001, 13, 'rand'), (70_000, 3, 'rand'), (500_000, 23, 'cells')])
 def test_sort_pairs_u32_stable(dev, n, end_bit, kind):
     """lm_sort_pairs_u32 (LSD radix sort, csrc/prim.hip) = numpy's STABLE argsort on the masked keys: duplicates keep their input
-    order (the voxeliser numbers voxels by first point and keeps the first max_points points, so stability is the contract), keys with
-    bits above end_bit set (the all-ones invalid key) still sort last."""
+    order (the voxeliser numbers voxels by first point and keeps the first max_points points, so stability is the contract).  Exactly
+    the low end_bit bits take part - also when end_bit is not a multiple of the 8-bit digit - so keys may carry payload above them, and
+    the all-ones invalid key still sorts last."""
     from lanemapping_amd import ops
     rng = np.random.default_rng(n + end_bit)
     if kind == 'rand':
@@ -1338,7 +1345,7 @@ def test_sort_pairs_u32_stable(dev, n, end_bit, kind):
         k = rng.integers(0, 600 * 600 * 21, size=n).astype(np.uint32)
         k[rng.random(n) < 0.1] = 0xFFFFFFFF
     v = np.arange(n, dtype=np.uint32)
-    mask = np.uint32(0xFFFFFFFF) if end_bit >= 32 else np.uint32((1 << (-(-end_bit // 8) * 8)) - 1)      # whole 8-bit digits take part
+    mask = np.uint32(0xFFFFFFFF) if end_bit >= 32 else np.uint32((1 << end_bit) - 1)
     order = np.argsort(k & mask, kind='stable')
     kd, vd = torch.from_numpy(k.view(np.int32)).to(dev), torch.from_numpy(v.view(np.int32)).to(dev)
     ops.sort_pairs_u32_(kd, vd, end_bit)
@@ -1364,6 +1371,19 @@ def test_tile_pipeline_graph_replay_bit_identical(dev):
         for (la, ea), (lb, eb) in zip(want, got):
             assert np.array_equal(np.asarray(la), np.asarray(lb)) and np.array_equal(np.asarray(ea), np.asarray(eb))
     assert len(graph._graphs) == 2
+    # a graph bakes the packed-weight pointers in: new weights (load_ckpt / load_state_dict / in-place edits) must force a recapture,
+    # never a silent replay of the old ones
+    synth.fill_module_(net, 77)
+    x = torch.from_numpy(synth.bev_batch([2021, 2022], 1152)).to(dev)
+    want, got = eager.run_batch(x), graph.run_batch(x)
+    for (la, ea), (lb, eb) in zip(want, got):
+        assert np.array_equal(np.asarray(la), np.asarray(lb)) and np.array_equal(np.asarray(ea), np.asarray(eb))
+    # the cache is bounded (every graph pins a private activation pool)
+    for n in (1, 3, 4):
+        graph.run_batch(torch.from_numpy(synth.bev_batch([5 + i for i in range(n)], 1152)).to(dev))
+    assert len(graph._graphs) <= TilePipeline.MAX_GRAPHS
+    graph.clear_graphs()
+    assert len(graph._graphs) == 0
 
 
 def test_bench_hip_graphs_four_streams(dev):
@@ -1381,10 +1401,11 @@ def test_bench_hip_graphs_four_streams(dev):
     assert 'bitwise equal' in d['config']['stream_check'] and 0.0 < d['roofline']['frac'] <= 1.0
 
 
-@pytest.mark.parametrize('dual', ['0', '1'])
+@pytest.mark.parametrize('dual', ['2', '1'])
 def test_conv_winograd_geometries_bit_identical(dev, dual):
-    """The implicit Winograd kernel exists in three geometries (64 x 64, WIDE 32 x 128, DUAL 32 x 64 with the sixteen xi split over two
-    waves and the fold handed over through LDS).  The launcher picks by shape; LANEMAP_WINO_DUAL (read once per process) forces the
+    """The fp32 implicit Winograd kernel exists in two geometries: PIPE (32 tiles x 128 channels, sixteen xi per wave, the slab transform
+    spread over the MFMA steps; Cout > 64) and DUAL (32 x 64, the sixteen xi split over two waves and the fold handed over through LDS;
+    Cout <= 64).  The launcher picks by shape (LANEMAP_WINO_DUAL = 2, the default); LANEMAP_WINO_DUAL = 1 (read once per process) forces the
     DUAL one everywhere (1) or nowhere (0): both runs must reproduce the materialising pair bit for bit with the residual / BN / ReLU
     epilogue, and its GroupNorm statistics to fp32 summation-order accuracy."""
     import subprocess
@@ -1415,3 +1436,110 @@ print('ok')
     env = dict(os.environ, LANEMAP_WINO_DUAL=dual)
     r = subprocess.run([sys.executable, '-c', code], capture_output=True, text=True, timeout=600, cwd=root, env=env)
     assert r.returncode == 0 and r.stdout.strip().endswith('ok'), (r.stdout + r.stderr)[-2000:]
+
+
+# ----------------------------------------------------------------------------------------------- round 3: parity at the bench's own sizes
+def test_raster_headline_launch_vs_oracle(dev):
+    """The rasteriser at the HEADLINE shape - one u8_only launch of 16 tiles x 4,194,304 points (512 partition chunks per tile, a full
+    16-entry argument block) - against oracle/raster_ref.c on the first and the last tile of the launch: a wrong record slot at a chunk
+    index >= 128, or in tile 15's argument entry, would pass every smaller test.  Tiles differ (4 distinct clouds, different
+    elevation windows per tile), so a tile written into the wrong slot shows as well."""
+    from lanemapping_amd import ops
+    from oracle import raster_ref
+    n, batch = 4194304, 16
+    clouds = [synth.las_points(500 + i, n) for i in range(4)]
+    points = torch.cat([torch.from_numpy(clouds[i % 4]) for i in range(batch)]).to(dev)
+    offs = [i * n for i in range(batch + 1)]
+    kws = [dict(local_min_ele=-0.5 - 0.01 * t, ele_reso=0.02) for t in range(batch)]
+    out = torch.empty((batch, 1152, 1152, 3), device=dev, dtype=torch.uint8)
+    ops.bev_raster_batch(points, offs, [ops.make_raster_params(**kw) for kw in kws], out_u8=out, u8_only=True)
+    for t in (0, 15, 6):
+        want = raster_ref.raster(clouds[t % 4], raster_ref.params(**kws[t]), 1152, 1152)
+        assert np.array_equal(out[t].cpu().numpy(), want), f'tile {t} of the 16 x 4,194,304-point launch differs from the C oracle'
+    # the same launch again into the same buffer: deterministic
+    first = out.clone()
+    ops.bev_raster_batch(points, offs, [ops.make_raster_params(**kw) for kw in kws], out_u8=out, u8_only=True)
+    assert torch.equal(first, out)
+
+
+def test_rowref_config4_tiles_inside_batch8_vs_oracle(dev):
+    """Config 4 at the bench batch (B = 8): two tiles INSIDE the batch against the oracle chain run on those tiles alone, margin-aware
+    like test_rowref_detector_config4_vs_oracle; the polylines always equal the oracle's line assembly on the product's own decode
+    outputs, and the in-batch result equals the product's own single-tile result bit for bit."""
+    from lanemapping_amd.boundary import build_net_from_config
+    from oracle import net_ref, rowref_ref
+    net4 = build_net_from_config('Proj28_GFC-T3_RowRef_82_73_laser', device='cpu')
+    synth.fill_module_(net4, 2021)
+    sd = {k: v.clone() for k, v in net4.state_dict().items()}
+    for c in range(12):
+        sd[f'heads.emb_{c}'] = getattr(net4.heads, f'emb_{c}').clone()
+    net4 = net4.to(dev)
+    seeds = [3100 + i for i in range(8)]
+    x = torch.from_numpy(synth.bev_batch(seeds, 1152))
+    with torch.no_grad():
+        o = net4({'proj': x.to(dev)})
+    col_b = net4.heads._col_idx.cpu().numpy()                         # [8,12,144]
+    conf_b, cls_b = o['conf'].numpy(), o['cls'].numpy()
+    lanes_b = [np.array(l) for l in o['lane_maps']['cls_offset_smooth']]
+    total_flips = 0
+    for t in (2, 7):
+        with torch.no_grad():
+            fea = net_ref.vit_forward(sd, net_ref.fpn_forward(sd, x[t:t + 1])[0])
+            ref = rowref_ref.rowref_forward(sd, fea)
+            o1 = net4({'proj': x[t:t + 1].to(dev)})
+        assert np.array_equal(net4.heads._col_idx.cpu().numpy()[0], col_b[t]), 'in-batch tile differs from the single-tile run'
+        assert np.array_equal(np.array(o1['lane_maps']['cls_offset_smooth'][0]), lanes_b[t])
+        for c in range(12):
+            e, p = ref[f'ext2_{c}'][0], ref[f'cls2_{c}'][0]
+            want = np.where(e.argmax(dim=1).numpy() == 0, p.argmax(dim=1).numpy(), -1)
+            top2 = torch.topk(p, 2, dim=1).values
+            margin = torch.minimum((e[:, 0] - e[:, 1]).abs(), top2[:, 0] - top2[:, 1]).numpy()
+            bad = np.flatnonzero(col_b[t][c] != want)
+            total_flips += bad.size
+            assert np.all(margin[bad] < 1e-4), f'tile {t} lane {c}: decision differs from the oracle where its margin is {margin[bad].max():.2e}'
+        assert np.array_equal(lanes_b[t], rowref_ref.rowref_pred_lines(conf_b[t], cls_b[t]))
+    print(f'config 4, B = 8: {total_flips} decisions flipped inside the oracle margin on 2 tiles')
+    assert total_flips <= 16
+
+
+def test_detector_config5_headline_points_vs_oracle(dev):
+    """Config 5 at the bench's point count (4,194,304 points per cloud; the older test uses 1 M): raw head outputs vs the restated
+    oracle chain (third-party arithmetic: parity stays unpinned)."""
+    from lanemapping_amd.boundary import build_net_from_config
+    from oracle import lidar_ref, net_ref
+    net5 = build_net_from_config('Proj_polyline_lidarconv_vit_vertex_2', device='cpu')
+    synth.fill_module_(net5, 2021)
+    sd = {k: v.clone() for k, v in net5.state_dict().items()}
+    net5 = net5.to(dev)
+    pts = [synth.lidar_points(62, 4194304)]
+    pc = dict(net5.cfg.pcencoder)
+    pc['gt_downsample_ratio'] = 8
+    sd_pc = {k[len('pcencoder.'):]: v for k, v in sd.items() if k.startswith('pcencoder.')}
+    with torch.no_grad():
+        fea, fea_up, bi, en = lidar_ref.lidar_encoder_ref(pts, sd_pc, pc)
+        ref = net_ref.head_forward(sd, net_ref.vit_forward(sd, fea), fea_up)
+        raw = net5.forward_raw({'points': [torch.from_numpy(p).to(dev) for p in pts]})
+        _close(raw['semantic_seg'], bi, 1e-4, 'bi_seg')
+        _close(raw['endp_est'], en, 1e-4, 'endp')
+        for k in ('proposal_conf', 'ext2', 'cls2', 'offset2', 'orient'):
+            print(k, 'config-5 (4.19 M points) head output error', _close(raw[k], ref[k], 1e-4, k))
+
+
+@pytest.mark.parametrize('switch', ['LANEMAP_WINO_IMPLICIT=0', 'LANEMAP_WINOGRAD=0', 'LANEMAP_GRAPHS=1', 'LANEMAP_WINO_BF16X3=1',
+                                    'LANEMAP_WINO_DUAL=1', 'LANEMAP_WINO_IMPLICIT=0 LANEMAP_FUSE_UP_WINO=0',
+                                    'LANEMAP_MERGE_BRANCH_CONVS=0'])
+def test_goldens_under_every_advertised_switch(switch):
+    """README's runtime switches are read once per process, so each non-default setting gets its own interpreter: the end-to-end
+    goldens (G10: one full tile against the reference's outputs, margin-aware; G15: two stability-screened tiles whose final
+    polylines must equal the reference's) run under it.  A switch that is not tested here does not exist."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ)
+    for kv in switch.split():
+        k, v = kv.split('=')
+        env[k] = v
+    r = subprocess.run([sys.executable, '-m', 'pytest', os.path.join(root, 'tests', 'test_gpu_parity.py'), '-x', '-q', '-m', 'gpu', '-k',
+                        'test_end_to_end_golden_g10 or test_end_to_end_stable_golden_g15 or test_tile_pipeline_graph_replay'],
+                       capture_output=True, text=True, timeout=1500, cwd=root, env=env)
+    assert r.returncode == 0 and ' passed' in r.stdout, (r.stdout + r.stderr)[-3000:]
