@@ -109,7 +109,7 @@ class VitSegNet(PackedModule):
     def forward(self, img):
         """Goes through the dispatcher: torch.ops.lanemap_hip.vit_backbone (torch_ops.py)."""
         from . import torch_ops
-        return torch_ops.vit_backbone(img, torch_ops.module_handle(self))
+        return torch_ops.vit_backbone(img, torch_ops.stage_weights(self), torch_ops.stage_name(self))
 
     def _forward_impl(self, img):
         P = self.packed()

@@ -122,7 +122,7 @@ class ColumnProposal2(PackedModule):
             col = ops.new_act(x.shape[0], 16, x_up.shape[2], x_up.shape[3], x.device)
             col[:, 8:16].copy_(x_up)
         self.b_size = x.shape[0]
-        conf, ext2, cls2, off2, orient = torch_ops.colprop_head(x, col, torch_ops.module_handle(self))
+        conf, ext2, cls2, off2, orient = torch_ops.colprop_head(x, col, torch_ops.stage_weights(self), torch_ops.stage_name(self))
         return {'proposal_conf': conf, 'ext2': ext2, 'cls2': cls2, 'offset2': off2, 'orient': orient}
 
     def _forward_impl(self, x, x_up, x_endp=None, col=None):

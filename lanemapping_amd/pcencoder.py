@@ -257,7 +257,7 @@ class FPNEncoder(PackedModule):
         if fea_up_out is None:
             B, H, W = (x.shape[0], x.shape[1], x.shape[2]) if x.dtype == torch.uint8 else (x.shape[0], x.shape[2], x.shape[3])
             fea_up_out = ops.new_act(B, 8, (H + 3) // 4, (W + 3) // 4, x.device)
-        fea, bi_seg, endp = torch_ops.fpn_encoder(x, fea_up_out, torch_ops.module_handle(self))
+        fea, bi_seg, endp = torch_ops.fpn_encoder(x, fea_up_out, torch_ops.stage_weights(self), torch_ops.stage_name(self))
         return fea, fea_up_out, bi_seg, endp
 
     def _forward_impl(self, x, fea_up_out=None):

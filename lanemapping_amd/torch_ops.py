@@ -9,13 +9,17 @@ liblanemap_hip.so, registered for the ``cuda`` (HIP) device only - calling an op
 same library and are registered for ``cpu`` because that is where their inputs live.
 
 Two levels:
-  * stage ops - what the modules' ``forward`` go through: ``bev_raster``, ``fpn_encoder``, ``vit_backbone``, ``colprop_head``,
-    ``colprop_decode`` (+ ``endp_cluster``, ``polyline_assemble`` on the host).  A stage op names its module by an integer
-    handle (``module_handle``): the structure (which layers, strides, dilations) and the packed weights live in the module.
+  * stage ops - what the modules' ``forward`` go through: ``bev_raster``, ``fpn_encoder``, ``vit_backbone``, ``colprop_head``
+    (+ ``endp_cluster``, ``polyline_assemble`` on the host).  A stage op takes the stage's WEIGHTS as a ``Tensor[]`` operand (every
+    parameter and buffer of the module, in ``state_dict`` order - the tracer / ``torch.export`` see them as inputs of the op, and the
+    op computes from the tensors it is handed) and the stage's STRUCTURE (which layers, strides, dilations) as a string: the name
+    under which the module registered itself (``stage_name``: class name + a process-wide counter, never recycled).  Round 2 passed
+    ``id(module)``: a process-local integer that could alias a recycled id and hid the weights from the graph.
   * kernel ops - one per device kernel family (``conv2d_mfma``, ``conv3x3_winograd``, ``stem_conv7x7``, ``gn_relu_upsample``,
     ``layernorm_rows``, ``attention``, ``linear_mfma``, ``decode_proposals``, ``decode_semantic``, ``endp_topk``, ``tile_ingest``, ...).
 Activations are logically NCHW, stored channels-last (ops.new_act); fake kernels return the same strides.
 """
+import itertools
 import weakref
 from typing import List, Optional, Tuple
 
@@ -25,20 +29,57 @@ from torch import Tensor
 
 from . import ops as _ops
 
-_MODULES = weakref.WeakValueDictionary()
+_STAGES = weakref.WeakValueDictionary()      # stage name -> live module (the structure; the weights travel as op operands)
+_STAGE_COUNTER = itertools.count()
 
 
-def module_handle(module):
-    """Integer name of a live module for the stage ops (valid while the module is alive, in this process)."""
-    h = id(module)
-    _MODULES[h] = module
-    return h
+def stage_name(module):
+    """Name of a stage module for the stage ops: '<ClassName>#<n>', n from a process-wide counter (unique for the life of the process,
+    unlike id(); two processes that build the same net in the same order agree on it)."""
+    n = module.__dict__.get('_lanemap_stage_name')
+    if n is None:
+        n = module.__dict__['_lanemap_stage_name'] = f'{type(module).__name__}#{next(_STAGE_COUNTER)}'
+    _STAGES[n] = module
+    return n
 
 
-def _module(handle):
-    m = _MODULES.get(int(handle))
+def stage_weights(module):
+    """Every parameter and buffer of the module, in state_dict order (cached slot list of PackedModule: no module walk per call)."""
+    return [d[n] for d, n in module._slots() if d[n] is not None]
+
+
+class _with_weights:
+    """Run a stage with the weights the op was handed.  Fast path: they ARE the module's own tensors.  Otherwise (a functional caller,
+    an exported graph replayed with other weights) they are swapped in for the duration of the call; the packed-weight cache is keyed
+    by tensor identity + version, so it repacks by itself."""
+
+    def __init__(self, spec, weights):
+        m = _STAGES.get(spec)
+        if m is None:
+            raise RuntimeError(f'lanemap_hip: no live stage module registered as {spec!r}')
+        slots = [(d, n) for d, n in m._slots() if d[n] is not None]
+        if len(slots) != len(weights):
+            raise RuntimeError(f'lanemap_hip: stage {spec} has {len(slots)} weight tensors, the op was handed {len(weights)}')
+        self.m, self.swap = m, [(d, n, d[n], w) for (d, n), w in zip(slots, weights) if d[n] is not w]
+        for d, n, own, w in self.swap:
+            if own.shape != w.shape or own.dtype != w.dtype:
+                raise RuntimeError(f'lanemap_hip: stage {spec}: weight {n} is {tuple(w.shape)} {w.dtype}, expected {tuple(own.shape)} {own.dtype}')
+
+    def __enter__(self):
+        for d, n, own, w in self.swap:
+            d[n] = w if not isinstance(own, torch.nn.Parameter) or isinstance(w, torch.nn.Parameter) else torch.nn.Parameter(w, requires_grad=False)
+        return self.m
+
+    def __exit__(self, *exc):
+        for d, n, own, w in self.swap:
+            d[n] = own
+        return False
+
+
+def _stage(spec):
+    m = _STAGES.get(spec)
     if m is None:
-        raise RuntimeError(f'lanemap_hip: no live module behind handle {handle}')
+        raise RuntimeError(f'lanemap_hip: no live stage module registered as {spec!r}')
     return m
 
 
@@ -210,16 +251,18 @@ def raster_params_tensor(params):
     return torch.tensor(rows, dtype=torch.float32)
 
 
-def _fpn_encoder(proj: Tensor, fea_up_out: Tensor, module: int) -> Tuple[Tensor, Tensor, Tensor]:
+def _fpn_encoder(proj: Tensor, fea_up_out: Tensor, weights: List[Tensor], stage: str) -> Tuple[Tensor, Tensor, Tensor]:
     """FPN encoder stage (pcencoder.FPNEncoder): proj [B,3,H,W] f32 or [B,H,W,3] u8 -> (fea [B,64,H/8,W/8], bi_seg [B,3,H,W],
-    endp [B,1,H,W]); fea_up [B,8,H/4,W/4] is written into `fea_up_out` (a channel slice of the head's concat buffer is fine)."""
-    fea, _, bi_seg, endp = _module(module)._forward_impl(proj, fea_up_out)
+    endp [B,1,H,W]); fea_up [B,8,H/4,W/4] is written into `fea_up_out` (a channel slice of the head's concat buffer is fine).
+    weights = stage_weights(module), stage = stage_name(module)."""
+    with _with_weights(stage, weights) as m:
+        fea, _, bi_seg, endp = m._forward_impl(proj, fea_up_out)
     return fea, bi_seg, endp
 
 
-def _fpn_encoder_fake(proj, fea_up_out, module):
+def _fpn_encoder_fake(proj, fea_up_out, weights, stage):
     B, H, W = (proj.shape[0], proj.shape[1], proj.shape[2]) if proj.dtype == torch.uint8 else (proj.shape[0], proj.shape[2], proj.shape[3])
-    m = _module(module)
+    m = _stage(stage)
     cf = m.out.out_channels if m.out is not None else 256
     return (_fake_act(proj, B, cf, H // 8, W // 8), proj.new_empty((B, 3, H, W), dtype=torch.float32),
             proj.new_empty((B, 1, H, W), dtype=torch.float32))
@@ -228,12 +271,13 @@ def _fpn_encoder_fake(proj, fea_up_out, module):
 fpn_encoder = _define('fpn_encoder', _fpn_encoder, _fpn_encoder_fake, mutates=('fea_up_out',))
 
 
-def _vit_backbone(fea: Tensor, module: int) -> Tensor:
-    return _module(module)._forward_impl(fea)
+def _vit_backbone(fea: Tensor, weights: List[Tensor], stage: str) -> Tensor:
+    with _with_weights(stage, weights) as m:
+        return m._forward_impl(fea)
 
 
-def _vit_backbone_fake(fea, module):
-    m = _module(module)
+def _vit_backbone_fake(fea, weights, stage):
+    m = _stage(stage)
     c = m.shared_mlp.out_channels if m.is_with_shared_mlp else m.out_c
     return _fake_act(fea, fea.shape[0], c, m.grid * m.patch, m.grid * m.patch)
 
@@ -241,15 +285,16 @@ def _vit_backbone_fake(fea, module):
 vit_backbone = _define('vit_backbone', _vit_backbone, _vit_backbone_fake)
 
 
-def _colprop_head(x: Tensor, col: Tensor, module: int) -> Tuple[Tensor, Tensor, Tensor, Tensor, Tensor]:
+def _colprop_head(x: Tensor, col: Tensor, weights: List[Tensor], stage: str) -> Tuple[Tensor, Tensor, Tensor, Tensor, Tensor]:
     """Column-proposal head stage (heads.ColumnProposal2): x [B,8,144,144], col [B,16,288,288] whose channels 8..15 hold fea_up
     (channels 0..7 are filled here) -> (proposal_conf, ext2, cls2, offset2, orient logits)."""
-    o = _module(module)._forward_impl(x, None, None, col=col)
+    with _with_weights(stage, weights) as m:
+        o = m._forward_impl(x, None, None, col=col)
     return o['proposal_conf'], o['ext2'], o['cls2'], o['offset2'], o['orient']
 
 
-def _colprop_head_fake(x, col, module):
-    m = _module(module)
+def _colprop_head_fake(x, col, weights, stage):
+    m = _stage(stage)
     B, R, P = x.shape[0], x.shape[2], m.num_prop
     return (x.new_empty((B, P, 2)), x.new_empty((B, P, R, 3)), x.new_empty((B, P, R, 10)), x.new_empty((B, P, R, 10)),
             _fake_act(x, B, m.num_orients, x.shape[2], x.shape[3]))

@@ -788,6 +788,46 @@ def test_torch_ops_registered_with_schema_and_fake_kernels():
     lanes, kept = torch.ops.lanemap_hip.polyline_assemble(torch.zeros((72, 2)), torch.zeros((72, 144)), torch.zeros((72, 144), dtype=torch.float64),
                                                           torch.zeros((144, 1152)), torch.zeros((0, 2), dtype=torch.int32), 0.3)
     assert tuple(lanes.shape) == (72, 144, 2) and lanes.dtype == torch.float64 and kept.shape[0] == 0
+    # torch.library.opcheck (schema vs behaviour, fake kernel vs real outputs, dispatcher registrations) on the ops that can run here
+    args = (torch.zeros((72, 2)), torch.zeros((72, 144)), torch.zeros((72, 144), dtype=torch.float64), torch.zeros((144, 1152)),
+            torch.zeros((0, 2), dtype=torch.int32), 0.3)
+    torch.library.opcheck(torch.ops.lanemap_hip.polyline_assemble.default, args, test_utils=('test_schema', 'test_faketensor'))
+    idx = (torch.arange(512, dtype=torch.int32) * 2503) % (1136 * 1136)          # 512 valid flat indices of the cropped map
+    torch.library.opcheck(torch.ops.lanemap_hip.endp_cluster.default, (idx, 1136, 8, 60, 500), test_utils=('test_schema', 'test_faketensor'))
+
+
+def test_stage_ops_take_weights_and_a_stage_name():
+    """The stage ops (what the modules' forward go through) take the stage's weights as a Tensor[] operand and its structure as a
+    registered name - not id(module): the name comes from a process-wide counter (never recycled), the weights are visible to a
+    tracer, and the fake kernels infer the output shapes from them without a device."""
+    from torch._subclasses.fake_tensor import FakeTensorMode
+    from lanemapping_amd import torch_ops
+    from lanemapping_amd.boundary import build_net_from_config
+    for name in ('fpn_encoder', 'vit_backbone', 'colprop_head'):
+        sch = str(getattr(torch.ops.lanemap_hip, name).default._schema)
+        assert 'Tensor[] weights' in sch and 'str stage' in sch and 'int module' not in sch, sch
+    net = build_net_from_config('Proj_polyline_fpn_vit_vertex_2', device='cpu')
+    enc = net.pcencoder.fpn           # (the stage module: FPNEncoder inside the PostProjector2 wrapper)
+    n1, n2 = torch_ops.stage_name(enc), torch_ops.stage_name(net.backbone)
+    assert n1 != n2 and n1 == torch_ops.stage_name(enc) and n1.split('#')[0] == type(enc).__name__
+    w = torch_ops.stage_weights(enc)
+    sd = enc.state_dict(keep_vars=True)
+    assert len(w) == len(sd) and all(a is b for a, b in zip(w, sd.values()))          # every parameter and buffer, state_dict order
+    with FakeTensorMode(allow_non_fake_inputs=True):
+        x = torch.empty((2, 1152, 1152, 3), device='cuda', dtype=torch.uint8)
+        up = torch.empty((2, 288, 288, 8), device='cuda').permute(0, 3, 1, 2)
+        fea, bi, en = torch.ops.lanemap_hip.fpn_encoder(x, up, w, n1)
+        assert tuple(fea.shape) == (2, 64, 144, 144) and tuple(bi.shape) == (2, 3, 1152, 1152) and tuple(en.shape) == (2, 1, 1152, 1152)
+        y = torch.ops.lanemap_hip.vit_backbone(fea, torch_ops.stage_weights(net.backbone), n2)
+        assert tuple(y.shape) == (2, 8, 144, 144)
+    # a dead module's name is refused, never silently re-bound (id() could alias a recycled object)
+    del net, enc
+    import gc
+    gc.collect()
+    with pytest.raises(RuntimeError):
+        with FakeTensorMode(allow_non_fake_inputs=True):
+            torch.ops.lanemap_hip.fpn_encoder(torch.empty((1, 1152, 1152, 3), device='cuda', dtype=torch.uint8),
+                                              torch.empty((1, 8, 288, 288), device='cuda'), w, n1)
 
 
 def test_winograd_weight_packers_layout_and_exact_split():

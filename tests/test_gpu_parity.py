@@ -1151,13 +1151,16 @@ def test_bench_two_ranks_code_path(dev):
     s.close()
     env = dict(os.environ, LANEMAP_BENCH_DEVICE='0', LANEMAP_BENCH_BACKEND='gloo')
     r = subprocess.run([sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2', '--master-addr', '127.0.0.1',
-                        '--master-port', str(port), os.path.join(root, 'bench.py'), '--gpus', '2', '--steps', '3', '--warmup', '1'],
+                        '--master-port', str(port), os.path.join(root, 'bench.py'), '--gpus', '2', '--steps', '3', '--warmup', '1', '--cpu-budget-s', '6'],
                        capture_output=True, text=True, timeout=900, cwd=root, env=env)
     assert r.returncode == 0, (r.stdout + r.stderr)[-3000:]
     lines = [l for l in r.stdout.strip().split('\n') if l.startswith('{')]
     assert len(lines) == 1                                           # rank 0 only
     d = json.loads(lines[0])
-    assert d['n_gpus'] == 2 and d['steps'] == 3 and d['cpu_baseline'] is None and d['value'] > 10
+    # (N > 1 lines carry the CPU baseline too: north_star wants it timed on the node's own host cores in the same run)
+    assert d['n_gpus'] == 2 and d['steps'] == 3 and d['cpu_baseline'] is not None and d['cpu_baseline']['value'] > 0 and d['value'] > 10
+    assert d['config']['gather_check'].startswith('last all-gather: 32 valid tiles in one [32, 169992] byte block')
+    assert d['config']['raster_check'].startswith('tiles 0 and 15 of the last timed 16 x 4194304-point launch equal oracle/raster_ref.c')
 
 
 @pytest.mark.parametrize('B,cin,cout,H,W,dil', [(2, 128, 128, 48, 44, 1), (1, 256, 200, 43, 61, 1), (2, 128, 64, 84, 90, 2),
@@ -1543,3 +1546,38 @@ def test_goldens_under_every_advertised_switch(switch):
                         'test_end_to_end_golden_g10 or test_end_to_end_stable_golden_g15 or test_tile_pipeline_graph_replay'],
                        capture_output=True, text=True, timeout=1500, cwd=root, env=env)
     assert r.returncode == 0 and ' passed' in r.stdout, (r.stdout + r.stderr)[-3000:]
+
+
+def test_stage_ops_opcheck_and_functional_weights(dev, net):
+    """The stage ops as the dispatcher sees them: torch.library.opcheck (schema incl. the declared mutation of fea_up_out / col, fake
+    kernel vs real outputs) on all three, and the weights are REAL operands - handed other tensors than the module's own, the op
+    computes with those (and the module's own weights are back in place afterwards)."""
+    import copy
+    from lanemapping_amd import ops, torch_ops
+    enc, vit, head = net.pcencoder.fpn, net.backbone, net.heads
+    x = torch.from_numpy(synth.bev_batch([2021], 1152)).to(dev)
+    we, ne = torch_ops.stage_weights(enc), torch_ops.stage_name(enc)
+    wv, nv = torch_ops.stage_weights(vit), torch_ops.stage_name(vit)
+    wh, nh = torch_ops.stage_weights(head), torch_ops.stage_name(head)
+    utils = ('test_schema', 'test_faketensor')
+    with torch.no_grad():
+        up = ops.new_act(1, 8, 288, 288, dev)
+        torch.library.opcheck(torch.ops.lanemap_hip.fpn_encoder.default, (x, up, we, ne), test_utils=utils)
+        fea, bi, en = torch.ops.lanemap_hip.fpn_encoder(x, up, we, ne)
+        torch.library.opcheck(torch.ops.lanemap_hip.vit_backbone.default, (fea, wv, nv), test_utils=utils)
+        y = torch.ops.lanemap_hip.vit_backbone(fea, wv, nv)
+        col = ops.new_act(1, 16, 288, 288, dev)
+        col[:, 8:] = up
+        torch.library.opcheck(torch.ops.lanemap_hip.colprop_head.default, (y, col, wh, nh), test_utils=utils)
+        # functional use: other weights through the same op == a module that owns those weights
+        w2 = [t.detach().clone() for t in wv]
+        for t in w2:
+            if t.dtype == torch.float32 and t.dim() >= 2:
+                t.mul_(0.75)
+        y2 = torch.ops.lanemap_hip.vit_backbone(fea, w2, nv)
+        vit2 = copy.deepcopy(vit)
+        for (d, n), t in zip([(d, n) for d, n in vit2._slots() if d[n] is not None], w2):
+            d[n].data.copy_(t)
+        assert torch.equal(y2, vit2(fea)) and not torch.equal(y2, y)
+        assert torch.equal(torch.ops.lanemap_hip.vit_backbone(fea, wv, nv), y), "the module's own weights are back in place"
+        assert all(a is b for a, b in zip(torch_ops.stage_weights(vit), wv))
