@@ -132,8 +132,8 @@ def main():
                          "(pre-rasterised, batch 8); rowref = configs[3] (Proj28_GFC-T3_RowRef head, pre-rasterised, batch 8); lidar = "
                          "configs[4] (sparse-conv LiDAR encoder path, batch 8 point clouds, parity unpinned)")
     ap.add_argument('--streams', type=int, default=None,
-                    help='split every batch over this many HIP streams (fills launch tails); default 4, 1 for lidar / rowref '
-                         '(their data-dependent bookkeeping needs host round trips, which serialise sub-batches)')
+                    help='split every batch over this many HIP streams (fills launch tails); default 4, 1 for lidar '
+                         '(its data-dependent launch sizes need host round trips, which serialise sub-batches)')
     ap.add_argument('--conv-detail', action='store_true', help='per-shape table of the MFMA launches on stderr')
     ap.add_argument('--no-stream-check', action='store_true', help='skip the bitwise multi-stream == single-stream check')
     ap.add_argument('--graphs', action='store_true', help='replay the device part of every sub-batch as one HIP graph (TilePipeline use_graph)')
@@ -162,7 +162,7 @@ def main():
         mine = allowed[(local_rank * k) % len(allowed):][:k] or allowed[:k]
         os.sched_setaffinity(0, set(mine))
         torch.set_num_threads(max(1, k))
-        if k <= 4 and not args.no_graphs and args.workload in ('fused', 'tiles'):
+        if k <= 4 and not args.no_graphs and args.workload in ('fused', 'tiles', 'rowref'):
             args.graphs = True
     host_cores_per_rank = len(os.sched_getaffinity(0)) if args.host_cores is not None else min(cores_avail, len(os.sched_getaffinity(0)))
     if args.host_threads is None:
@@ -209,7 +209,7 @@ def main():
     pipe = TilePipeline(net, host_threads=args.host_threads, use_graph=args.graphs)
     # whole-batch reference / instrumented passes launch kernel by kernel (the roofline hook brackets every launch with events)
     pipe_eager = pipe if not args.graphs else TilePipeline(net, host_threads=args.host_threads, use_graph=False)
-    nstream = max(1, args.streams if args.streams is not None else (1 if args.workload in ('lidar', 'rowref') else 4))
+    nstream = max(1, args.streams if args.streams is not None else (1 if args.workload == 'lidar' else 4))
     nstream = min(nstream, batch)
     extra_streams = [torch.cuda.Stream(device=dev) for _ in range(nstream - 1)]
     extra_pipes = [TilePipeline(net, host_threads=args.host_threads, use_graph=args.graphs) for _ in range(nstream - 1)]
@@ -479,7 +479,7 @@ def main():
         'ms_per_step': dt / args.steps * 1e3, 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
         'dtype': 'f32', 'data': 'synthetic',
         'config': {'workload': workload,
-                   'tiles_per_step_per_gpu': batch, 'lines_per_tile': n_lines, 'host_threads': args.host_threads, 'streams': nstream, 'hip_graphs': bool(args.graphs and args.workload in ('fused', 'tiles')),      # (RowRef reads a mask on the host mid-forward, the LiDAR path sizes launches on the host: no capture)
+                   'tiles_per_step_per_gpu': batch, 'lines_per_tile': n_lines, 'host_threads': args.host_threads, 'streams': nstream, 'hip_graphs': bool(args.graphs and args.workload in ('fused', 'tiles', 'rowref')),      # (the LiDAR path sizes launches on the host: no capture)
                   
                    'stream_check': stream_check, 'gather_check': gather_check, 'raster_check': raster_check,
                    'host_cores_per_rank': host_cores_per_rank, 'host_cores_pinned': args.host_cores is not None,

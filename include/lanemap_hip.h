@@ -139,6 +139,9 @@ int lm_unpatchify(void* stream, const float* tokens, float* y_nhwc, int B, int G
 
 /* ---- attention core: softmax(q k^T * scale) v per (batch, head); qkv = [B*N][3*heads*64] (vitsegnet.py:58-68) */
 int lm_attention_f32(void* stream, const float* qkv, float* out, int B, int N, int heads, int dim_head, float scale);
+/* the same with a key mask, valid [B][N] ints (N <= 64): per batch element only the flagged tokens are keys, compacted in token order
+ * (row_shared_not_reduc_ref.py:199-215: the transformer runs over the data-dependent subset of the lane tokens) */
+int lm_attention_masked_f32(void* stream, const float* qkv, float* out, const int* valid, int B, int N, int heads, int dim_head, float scale);
 
 /* ---- column-proposal head (heads/polyline_fpn_vit_vertex_2.py:390-421) ----------------------------------------
  * tokens: tok[(b,p,h), c*10+w] = avg_pool8(up(seg window p))[h,w] * row_fea_pad[b,c,h,2p+w]   (:392-405)
@@ -222,13 +225,14 @@ int lm_downsample_seq(const double* seq, int n, double dist_min, double* out);
 
 /* ---- K-Lane "RowRef" head, config 4 (baseline/models/heads/row_shared_not_reduc_ref.py) ------------------------
  * softmax_rows :179-180,239-240 (in place); select :199-204; gather :207-211; scatter :227-230 (shrinking-range quirk);
- * decode :334-363.  Layouts: x [B,H,W,8] NHWC, ext [B,H,L,2], cls [B,H,L,W], tokens [T][8*H*5] in (c h w) order,
- * sel [T][2] = (b, lane), bstart [B+1] token ranges. */
+ * decode :334-363.  Layouts: x [B,H,W,8] NHWC, ext [B,H,L,2], cls [B,H,L,W], tokens on the fixed grid t = b * L + lane,
+ * [B*L][8*H*5] in (c h w) order; valid [B][L] = the reference's lane selection (mean existence > thr_ext), computed on the device. */
 int lm_softmax_rows(void* stream, float* x, long rows, int cols);
-int lm_rowref_select(void* stream, const float* ext, const float* cls, float* mean_out, int* corr, int B, int H, int W, int L);
-int lm_rowref_gather(void* stream, const float* x_nhwc8, const int* corr, const int* sel, float* tok, int T, int H, int W, int L);
-int lm_rowref_scatter(void* stream, const float* x_nhwc8, const float* tok, const int* corr, const int* sel,
-                      const int* bstart, float* y_nhwc8, int B, int H, int W, int L);
+int lm_rowref_select(void* stream, const float* ext, const float* cls, float* mean_out, int* valid, float thr_ext, int* corr,
+                     int B, int H, int W, int L);
+int lm_rowref_gather(void* stream, const float* x_nhwc8, const int* corr, float* tok, int B, int H, int W, int L);
+int lm_rowref_scatter(void* stream, const float* x_nhwc8, const float* tok, const int* corr, const int* valid,
+                      float* y_nhwc8, int B, int H, int W, int L);
 int lm_rowref_decode(void* stream, const float* ext2, const float* cls2, unsigned char* conf, unsigned char* cls_map,
                      int* col_idx, int B, int H, int W, int L);
 

@@ -62,6 +62,7 @@ SIGNATURES = {
     'lm_layernorm_rows': (i32, [vp, vp, vp, vp, vp, i64, i32, f32]),
     'lm_unpatchify': (i32, [vp, vp, vp, i32, i32, i32, i32]),
     'lm_attention_f32': (i32, [vp, vp, vp, i32, i32, i32, i32, f32]),
+    'lm_attention_masked_f32': (i32, [vp, vp, vp, vp, i32, i32, i32, i32, f32]),
     'lm_head_tokens': (i32, [vp, vp, vp, vp, f32, i32, i32, i32, i32, i32, i32]),
     'lm_head_stage2': (i32, [vp, vp, i32, i32, vp, vp, vp, vp, vp, i64]),
     'lm_head_proposal_conf': (i32, [vp, vp, vp, vp, vp, i32, i32]),
@@ -86,9 +87,9 @@ SIGNATURES = {
     'lm_merge_result': (i32, [vp, vp, vp]),
     'lm_downsample_seq': (i32, [vp, i32, C.c_double, vp]),
     'lm_softmax_rows': (i32, [vp, vp, i64, i32]),
-    'lm_rowref_select': (i32, [vp, vp, vp, vp, vp, i32, i32, i32, i32]),
-    'lm_rowref_gather': (i32, [vp, vp, vp, vp, vp, i32, i32, i32, i32]),
-    'lm_rowref_scatter': (i32, [vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32]),
+    'lm_rowref_select': (i32, [vp, vp, vp, vp, vp, f32, vp, i32, i32, i32, i32]),
+    'lm_rowref_gather': (i32, [vp, vp, vp, vp, i32, i32, i32, i32]),
+    'lm_rowref_scatter': (i32, [vp, vp, vp, vp, vp, vp, i32, i32, i32, i32]),
     'lm_rowref_decode': (i32, [vp, vp, vp, vp, vp, vp, i32, i32, i32, i32]),
     'lm_voxelize_workspace_bytes': (i64, [i64]),
     'lm_scan_workspace_bytes': (i64, [i64]),

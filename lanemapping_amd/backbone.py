@@ -43,13 +43,14 @@ class _Transformer(nn.Module):
                                                     _PreNorm(dim, _FeedForward(dim, mlp_dim))]) for _ in range(depth)])
 
 
-def transformer_forward(layers, P, prefix, t, B, N):
-    """t [B*N, dim] -> [B*N, dim]; pre-norm blocks `x = attn(x) + x; x = ff(x) + x` (vitsegnet.py:79-83)."""
+def transformer_forward(layers, P, prefix, t, B, N, valid=None):
+    """t [B*N, dim] -> [B*N, dim]; pre-norm blocks `x = attn(x) + x; x = ff(x) + x` (vitsegnet.py:79-83).  valid: key mask of the
+    attention core (ops.attention); everything else is row-wise, rows of unflagged tokens are computed and ignored by the caller."""
     for l, (attn, ff) in enumerate(layers):
         k = f'{prefix}{l}'
         y = ops.layernorm(t, P[k + '.ln1.g'], P[k + '.ln1.b'], attn.norm.eps)
         qkv = ops.linear_mfma(y, P[k + '.qkv'], attn.fn.to_qkv.out_features)
-        o = ops.attention(qkv, B, N, attn.fn.heads, attn.fn.dim_head, attn.fn.scale)
+        o = ops.attention(qkv, B, N, attn.fn.heads, attn.fn.dim_head, attn.fn.scale, valid=valid)
         t = ops.linear_mfma(o, P[k + '.proj'], t.shape[1], shift=P[k + '.proj.b'], res=t)
         y = ops.layernorm(t, P[k + '.ln2.g'], P[k + '.ln2.b'], ff.norm.eps)
         y = ops.linear_mfma(y, P[k + '.fc1'], ff.fn.net[0].out_features, shift=P[k + '.fc1.b'], act=ops.ACT_GELU)

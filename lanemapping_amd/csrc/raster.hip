@@ -49,8 +49,18 @@ struct LmRasterParams {      // mirrors the reference's per-tile parameter file 
 
 namespace {
 
-constexpr int CHUNK = 8192;            // points per pass-1 workgroup = record capacity of one (tile, band, workgroup) slot
-constexpr int PER_THREAD = CHUNK / 256;
+#ifndef LM_RASTER_NT
+#define LM_RASTER_NT 256
+#endif
+#ifndef LM_RASTER_BQ
+#define LM_RASTER_BQ 2
+#endif
+constexpr int NT = LM_RASTER_NT;       // threads per pass-1 workgroup
+constexpr int PER_THREAD = 32;
+constexpr int CHUNK = NT * PER_THREAD; // points per pass-1 workgroup = record capacity of one (tile, band, workgroup) slot
+constexpr int PART_CAPQ = (NT * 32 + 96 * 3 + 3) / 4;       // quads of the sorted buffer: every band's run is padded to 16 bytes
+constexpr size_t PART_LDS = (size_t)PART_CAPQ * 16 + ((PART_CAPQ + 15) / 16) * 16;
+constexpr int BQ = LM_RASTER_BQ;       // quads per lane of a 16-lane group fetched with a run's first round trip (pass 2)
 constexpr int MAX_BANDS = 96;             // keeps pass-1 LDS at 39.5 KB = 4 workgroups per CU
 constexpr int MAX_TILES = 16;          // tiles per launch (kernel-argument block)
 constexpr int REP = 8;                 // replication of the LDS rank counters (fewer same-address collisions)
@@ -83,20 +93,21 @@ __device__ __forceinline__ bool point_record(const f32x4 p, const TileXf& X, int
 
 // records: [tile][band][blk][CHUNK] u32 (zero padded to 16 B per run), counts: [tile][nblk_max][band]
 // grid: (nblk_max, tiles)
-__global__ __launch_bounds__(256) void raster_partition_kernel(const f32x4* __restrict__ pts, BatchArgs A, unsigned* __restrict__ counts,
+__global__ __launch_bounds__(NT) void raster_partition_kernel(const f32x4* __restrict__ pts, BatchArgs A, unsigned* __restrict__ counts,
                                                                unsigned* __restrict__ records, int nblk_max, int H, int W, int nbands,
                                                                int band_rows) {
-    constexpr int CAPQ = (CHUNK + MAX_BANDS * 3 + 3) / 4;
+    constexpr int CAPQ = PART_CAPQ;
     __shared__ unsigned hist[MAX_BANDS * REP];                 // [band][replica] count, then start offset in `sorted`
     __shared__ unsigned qstart[MAX_BANDS + 1];                 // first 16-byte quad of each band's run
-    __shared__ __attribute__((aligned(16))) unsigned sorted[CAPQ * 4];
-    __shared__ unsigned char qband[CAPQ];
+    extern __shared__ __attribute__((aligned(16))) unsigned part_lds[];      // sorted[CAPQ * 4] | qband[CAPQ] (dynamic: > 64 KB from 512 threads on)
+    unsigned* const sorted = part_lds;
+    unsigned char* const qband = reinterpret_cast<unsigned char*>(part_lds + CAPQ * 4);
     const int tile = blockIdx.y, blk = blockIdx.x, tid = threadIdx.x;
     const TileXf& X = A.tile[tile];
     const long first = (long)blk * CHUNK;
     if (first >= X.count) return;                              // pass 2 never looks at slots beyond the tile's last chunk
-    for (int i = tid; i < MAX_BANDS * REP; i += 256) hist[i] = 0;
-    for (int i = tid; i < CAPQ * 4; i += 256) sorted[i] = 0;   // padding records must be 0
+    for (int i = tid; i < MAX_BANDS * REP; i += NT) hist[i] = 0;
+    for (int i = tid; i < CAPQ * 4; i += NT) sorted[i] = 0;   // padding records must be 0
     __syncthreads();
     unsigned rec[PER_THREAD];
     unsigned meta[PER_THREAD];                                 // slot << 16 | rank, 0xFFFFFFFF = dropped
@@ -111,14 +122,14 @@ __global__ __launch_bounds__(256) void raster_partition_kernel(const f32x4* __re
         f32x4 p[LB];
 #pragma unroll
         for (int j = 0; j < LB; ++j) {
-            const long i = (long)(j0 + j) * 256 + tid;
+            const long i = (long)(j0 + j) * NT + tid;
             // unconditional (index clamped into the chunk): a predicated load made the compiler wait for each load before
             // issuing the next one, i.e. 1 load in flight per lane instead of 8; the tail lanes are masked below
             p[j] = __builtin_nontemporal_load(base + (i < left ? i : left - 1));
         }
 #pragma unroll
         for (int j = 0; j < LB; ++j) {
-            const long i = (long)(j0 + j) * 256 + tid;
+            const long i = (long)(j0 + j) * NT + tid;
             meta[j0 + j] = 0xFFFFFFFFu;
             int band;
             if (i < left && point_record(p[j], X, H, W, band_rows, band, rec[j0 + j])) {
@@ -169,12 +180,12 @@ __global__ __launch_bounds__(256) void raster_partition_kernel(const f32x4* __re
 #pragma unroll
     for (int j = 0; j < PER_THREAD; ++j)
         if (meta[j] != 0xFFFFFFFFu) sorted[hist[meta[j] >> 16] + (meta[j] & 0xFFFFu)] = rec[j];
-    for (int b = tid; b < nbands; b += 256)
+    for (int b = tid; b < nbands; b += NT)
         for (unsigned q = qstart[b]; q < qstart[b + 1]; ++q) qband[q] = (unsigned char)b;
     __syncthreads();
     const unsigned totq = qstart[nbands];
     const u32x4* s4 = reinterpret_cast<const u32x4*>(sorted);
-    for (unsigned q = tid; q < totq; q += 256) {
+    for (unsigned q = tid; q < totq; q += NT) {
         const unsigned b = qband[q];
         u32x4* dst = reinterpret_cast<u32x4*>(records + (((long)tile * nbands + b) * nblk_max + blk) * CHUNK) + (q - qstart[b]);
         *dst = s4[q];
@@ -217,21 +228,21 @@ __global__ __launch_bounds__(BT) void raster_band_kernel(const unsigned* __restr
             const int b = b0 + 64 * u;
             nq[u] = b < nblk ? (cnt[(long)b * nbands] + 3) / 4 : 0;
         }
-        u32x4 v[RUNS][2];
+        u32x4 v[RUNS][BQ];
 #pragma unroll
         for (int u = 0; u < RUNS; ++u) {
             const u32x4* r4 = reinterpret_cast<const u32x4*>(rbase + (long)(b0 + 64 * u) * CHUNK);
 #pragma unroll
-            for (int k = 0; k < 2; ++k)
+            for (int k = 0; k < BQ; ++k)
                 v[u][k] = ((unsigned)(gl + 16 * k) < nq[u]) ? __builtin_nontemporal_load(r4 + gl + 16 * k) : u32x4{0u, 0u, 0u, 0u};
         }
 #pragma unroll
         for (int u = 0; u < RUNS; ++u) {
-            apply4(img, v[u][0]);
-            apply4(img, v[u][1]);
-            if (nq[u] > 32) {                                  // long run (spatially skewed chunk): finish it here
+#pragma unroll
+            for (int k = 0; k < BQ; ++k) apply4(img, v[u][k]);
+            if (nq[u] > 16 * BQ) {                             // long run (spatially skewed chunk): finish it here
                 const u32x4* r4 = reinterpret_cast<const u32x4*>(rbase + (long)(b0 + 64 * u) * CHUNK);
-                for (unsigned q = 32 + gl; q < nq[u]; q += 16) apply4(img, r4[q]);
+                for (unsigned q = 16 * BQ + gl; q < nq[u]; q += 16) apply4(img, r4[q]);
             }
         }
     }
@@ -372,7 +383,8 @@ LM_API int lm_bev_raster_batch(void* stream, const float* points_xyzi, const lon
         unsigned* cnt = counts + (long)b0 * nbands * nblk_max;
         unsigned* rec = records + (long)b0 * nbands * nblk_max * CHUNK;
         if (maxn > 0) {
-            hipLaunchKernelGGL(raster_partition_kernel, dim3((unsigned)nblk_of(maxn), nb), dim3(256), 0, s,
+            if (int e = lm_ensure_dynamic_lds((const void*)raster_partition_kernel, PART_LDS)) return e;
+            hipLaunchKernelGGL(raster_partition_kernel, dim3((unsigned)nblk_of(maxn), nb), dim3(NT), PART_LDS, s,
                                reinterpret_cast<const f32x4*>(points_xyzi), A, cnt, rec, nblk_max, H, W, nbands, band_rows);
             LM_LAUNCH_CHECK();
         }

@@ -2,10 +2,15 @@
 // The Conv1d/BN1d stacks, the token Linear layers and the lane-token transformer run on lm_conv2d_nhwc_mfma_f32 /
 // lm_layernorm_rows / lm_attention_f32; this file holds what is specific to the head:
 //   lm_softmax_rows    softmax(dim=2) of the ext / cls logits                                   (:179-180, :239-240)
-//   lm_rowref_select   per (b, lane): mean_h ext[b,h,lane,0] and argmax_w cls[b,h,lane,:]        (:199-204)
+//   lm_rowref_select   per (b, lane): mean_h ext[b,h,lane,0], the lane-selection flag mean > thr_ext, argmax_w cls[b,h,lane,:]  (:199-204)
 //   lm_rowref_gather   5-column window around the arg-max column of every row -> token input     (:207-211)
 //   lm_rowref_scatter  write the refined windows back, later lanes over earlier ones, lane i only on rows
 //                      0 .. 142-i: the reference's leaked/shrinking loop variable (:227-230)
+// Round 3: the data-dependent lane set no longer goes through the host.  The reference compacts the selected (b, lane) pairs into a
+// token list (:199-204); here the tokens live on the FIXED grid t = b * L + lane, `valid[b][lane]` says which of them exist, gather /
+// token MLP / transformer / expansion run on all B * L rows (a few wasted rows of tiny GEMMs), the attention core compacts the valid
+// keys of a tile in lane order (lm_attention_masked_f32: same arithmetic as on the compacted list) and the scatter derives a lane's
+// rank among the selected lanes of its tile - what the shrinking-range quirk is indexed by - from the flags.
 //   lm_rowref_decode   row exists iff argmax(ext2)==0, column = argmax(cls2) -> conf / cls maps   (:334-363)
 // Layouts: feature x [B,H,W,8] NHWC; ext [B,H,L,2]; cls [B,H,L,W]; tokens [T, 8*H*5] in (c h w) order.
 #include "common.h"
@@ -35,7 +40,8 @@ __global__ __launch_bounds__(256) void softmax_rows_kernel(float* __restrict__ x
 
 // grid (L, B), 256 threads
 __global__ __launch_bounds__(256) void rowref_select_kernel(const float* __restrict__ ext, const float* __restrict__ cls,
-                                                            float* __restrict__ mean_out, int* __restrict__ corr, int H, int W, int L) {
+                                                            float* __restrict__ mean_out, int* __restrict__ valid, float thr,
+                                                            int* __restrict__ corr, int H, int W, int L) {
     __shared__ float red[256];
     const int c = blockIdx.x, b = blockIdx.y, tid = threadIdx.x;
     float s = 0.f;
@@ -57,19 +63,22 @@ __global__ __launch_bounds__(256) void rowref_select_kernel(const float* __restr
         if (tid < k) red[tid] += red[tid + k];
         __syncthreads();
     }
-    if (tid == 0) mean_out[b * L + c] = red[0] / (float)H;
+    if (tid == 0) {
+        const float m = red[0] / (float)H;
+        mean_out[b * L + c] = m;
+        valid[b * L + c] = m > thr ? 1 : 0;                    // (:199-200: exist_mean > thr_ext, fp32 like the reference's tensor compare)
+    }
 }
 
-// sel: [T][2] = (b, lane).  tok[t][(cf*H + h)*5 + j] = x_pad[b, cf, h, corr + j]
+// token t = b * L + lane (fixed grid).  tok[t][(cf*H + h)*5 + j] = x_pad[b, cf, h, corr + j]
 __global__ __launch_bounds__(256) void rowref_gather_kernel(const float* __restrict__ x, const int* __restrict__ corr,
-                                                            const int* __restrict__ sel, float* __restrict__ tok, int H, int W, int L,
-                                                            long total) {
-    const long i = (long)blockIdx.x * 256 + threadIdx.x;   // over T*H*KW
+                                                            float* __restrict__ tok, int H, int W, int L, long total) {
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;   // over B*L*H*KW
     if (i >= total) return;
     const int j = (int)(i % KW);
     const int h = (int)((i / KW) % H);
     const int t = (int)(i / ((long)KW * H));
-    const int b = sel[2 * t], c = sel[2 * t + 1];
+    const int b = t / L, c = t - b * L;
     const int w = corr[((long)b * L + c) * H + h] + j - KW / 2;
     float* o = tok + (long)t * (CF * H * KW) + (long)h * KW + j;
     if ((unsigned)w < (unsigned)W) {
@@ -82,12 +91,11 @@ __global__ __launch_bounds__(256) void rowref_gather_kernel(const float* __restr
     }
 }
 
-// bstart: [B+1] token range of each batch element (tokens ordered by (b, lane)).  Lane number i (0-based within b)
-// is written on rows h < H-1-i only; among covering lanes the last one wins.
+// Selected lane number n (0-based among the selected lanes of its tile, lane order) is written on rows h < H-1-n only; among covering
+// lanes the last one wins.  No lane of the tile selected: y = x.
 __global__ __launch_bounds__(256) void rowref_scatter_kernel(const float* __restrict__ x, const float* __restrict__ tok,
-                                                             const int* __restrict__ corr, const int* __restrict__ sel,
-                                                             const int* __restrict__ bstart, float* __restrict__ y, int H, int W, int L,
-                                                             long total) {
+                                                             const int* __restrict__ corr, const int* __restrict__ valid,
+                                                             float* __restrict__ y, int H, int W, int L, long total) {
     const long i = (long)blockIdx.x * 256 + threadIdx.x;   // over B*H*W
     if (i >= total) return;
     const int w = (int)(i % W);
@@ -96,12 +104,15 @@ __global__ __launch_bounds__(256) void rowref_scatter_kernel(const float* __rest
     const float* src = x + i * CF;
     long tsel = -1;
     int jsel = 0;
-    for (int t = bstart[b + 1] - 1; t >= bstart[b]; --t) {
-        const int n = t - bstart[b];
+    int n = 0;
+    for (int c = 0; c < L; ++c) n += valid[b * L + c] ? 1 : 0;
+    for (int c = L - 1; c >= 0; --c) {                      // from the last selected lane down: the first hit is the winner
+        if (!valid[b * L + c]) continue;
+        --n;                                                // rank of lane c among the selected lanes of the tile
         if (h >= H - 1 - n) continue;
-        const int j = w - corr[((long)b * L + sel[2 * t + 1]) * H + h] + KW / 2;
+        const int j = w - corr[((long)b * L + c) * H + h] + KW / 2;
         if ((unsigned)j < (unsigned)KW) {
-            tsel = t;
+            tsel = (long)b * L + c;
             jsel = j;
             break;
         }
@@ -154,27 +165,28 @@ LM_API int lm_softmax_rows(void* stream, float* x, long rows, int cols) {
     return LM_OK;
 }
 
-LM_API int lm_rowref_select(void* stream, const float* ext, const float* cls, float* mean_out, int* corr, int B, int H, int W, int L) {
-    LM_REQUIRE(ext && cls && mean_out && corr, "rowref_select: null pointer");
-    hipLaunchKernelGGL(rowref_select_kernel, dim3(L, B), dim3(256), 0, (hipStream_t)stream, ext, cls, mean_out, corr, H, W, L);
+LM_API int lm_rowref_select(void* stream, const float* ext, const float* cls, float* mean_out, int* valid, float thr_ext, int* corr,
+                            int B, int H, int W, int L) {
+    LM_REQUIRE(ext && cls && mean_out && valid && corr, "rowref_select: null pointer");
+    hipLaunchKernelGGL(rowref_select_kernel, dim3(L, B), dim3(256), 0, (hipStream_t)stream, ext, cls, mean_out, valid, thr_ext, corr, H, W, L);
     LM_LAUNCH_CHECK();
     return LM_OK;
 }
 
-LM_API int lm_rowref_gather(void* stream, const float* x_nhwc8, const int* corr, const int* sel, float* tok, int T, int H, int W, int L) {
-    LM_REQUIRE(x_nhwc8 && corr && sel && tok && T >= 1, "rowref_gather: bad args");
-    const long total = (long)T * H * KW;
-    hipLaunchKernelGGL(rowref_gather_kernel, dim3(lm_cdiv(total, 256)), dim3(256), 0, (hipStream_t)stream, x_nhwc8, corr, sel, tok, H, W, L, total);
+LM_API int lm_rowref_gather(void* stream, const float* x_nhwc8, const int* corr, float* tok, int B, int H, int W, int L) {
+    LM_REQUIRE(x_nhwc8 && corr && tok && B >= 1 && L >= 1, "rowref_gather: bad args");
+    const long total = (long)B * L * H * KW;
+    hipLaunchKernelGGL(rowref_gather_kernel, dim3(lm_cdiv(total, 256)), dim3(256), 0, (hipStream_t)stream, x_nhwc8, corr, tok, H, W, L, total);
     LM_LAUNCH_CHECK();
     return LM_OK;
 }
 
-LM_API int lm_rowref_scatter(void* stream, const float* x_nhwc8, const float* tok, const int* corr, const int* sel,
-                             const int* bstart, float* y_nhwc8, int B, int H, int W, int L) {
-    LM_REQUIRE(x_nhwc8 && tok && corr && sel && bstart && y_nhwc8, "rowref_scatter: null pointer");
+LM_API int lm_rowref_scatter(void* stream, const float* x_nhwc8, const float* tok, const int* corr, const int* valid,
+                             float* y_nhwc8, int B, int H, int W, int L) {
+    LM_REQUIRE(x_nhwc8 && tok && corr && valid && y_nhwc8, "rowref_scatter: null pointer");
     const long total = (long)B * H * W;
-    hipLaunchKernelGGL(rowref_scatter_kernel, dim3(lm_cdiv(total, 256)), dim3(256), 0, (hipStream_t)stream, x_nhwc8, tok, corr, sel,
-                       bstart, y_nhwc8, H, W, L, total);
+    hipLaunchKernelGGL(rowref_scatter_kernel, dim3(lm_cdiv(total, 256)), dim3(256), 0, (hipStream_t)stream, x_nhwc8, tok, corr, valid,
+                       y_nhwc8, H, W, L, total);
     LM_LAUNCH_CHECK();
     return LM_OK;
 }

@@ -17,26 +17,51 @@ constexpr int DH = 64;
 constexpr int QC = 36;      // query rows per workgroup
 constexpr int KLD = DH + 1; // padded K/V row (floats): conflict-free column access
 
-__global__ __launch_bounds__(256) void attention_kernel(const float* __restrict__ qkv, float* __restrict__ out, int N,
-                                                        int heads, float scale) {
+// valid (optional, [B][NT] ints, NT <= 64 tokens per batch element): only the tokens with a non-zero flag take part as KEYS, in token
+// order - the scores, the softmax and P V are computed on the compacted key list exactly as if the call had been made on the valid
+// tokens alone (the RowRef head's lane tokens live on a fixed grid, their subset is data dependent).  Query rows are computed for
+// every token; rows of a batch element without any valid token are written as zeros.
+__global__ __launch_bounds__(256) void attention_kernel(const float* __restrict__ qkv, float* __restrict__ out, int NT,
+                                                        int heads, float scale, const int* __restrict__ valid) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
+    __shared__ int kidx[64];
+    __shared__ int kcount;
+    const int tid = threadIdx.x;
+    const int q0 = blockIdx.x * QC, h = blockIdx.y, b = blockIdx.z;
+    const int inner = heads * DH;
+    const long row0 = (long)b * NT;
+    const int ld = 3 * inner;
+    int N = NT;                        // keys
+    if (valid) {
+        if (tid < 64) {                // one wave: ballot compaction in token order
+            const bool v = tid < NT && valid[(long)b * NT + tid] != 0;
+            const unsigned long long m = __ballot(v);
+            if (v) kidx[__popcll(m & ((1ull << tid) - 1ull))] = tid;
+            if (tid == 0) kcount = (int)__popcll(m);
+        }
+        __syncthreads();
+        N = kcount;
+        if (N == 0) {
+            for (int i = tid; i < QC * DH; i += 256) {
+                const int n = q0 + (i >> 6);
+                if (n < NT) out[(row0 + n) * inner + h * DH + (i & 63)] = 0.f;
+            }
+            return;
+        }
+    }
     const int SLD = N + 4;
     float* KV = smem;                  // [N][KLD]
     float* S = KV + N * KLD;           // [QC][SLD]
     float* Q = S + QC * SLD;           // [QC][DH]
-    const int tid = threadIdx.x;
-    const int q0 = blockIdx.x * QC, h = blockIdx.y, b = blockIdx.z;
-    const int inner = heads * DH;
-    const long row0 = (long)b * N;
-    const int ld = 3 * inner;
+#define LM_KROW(n) (valid ? kidx[n] : (n))
 
     for (int i = tid; i < N * DH; i += 256) {
         const int n = i >> 6, d = i & 63;
-        KV[n * KLD + d] = qkv[(row0 + n) * ld + inner + h * DH + d];
+        KV[n * KLD + d] = qkv[(row0 + LM_KROW(n)) * ld + inner + h * DH + d];
     }
     for (int i = tid; i < QC * DH; i += 256) {
         const int n = i >> 6, d = i & 63;
-        Q[i] = (q0 + n < N) ? qkv[(row0 + q0 + n) * ld + h * DH + d] : 0.f;
+        Q[i] = (q0 + n < NT) ? qkv[(row0 + q0 + n) * ld + h * DH + d] : 0.f;
     }
     __syncthreads();
     // scores
@@ -53,8 +78,9 @@ __global__ __launch_bounds__(256) void attention_kernel(const float* __restrict_
     // V replaces K while the softmax runs on S
     for (int i = tid; i < N * DH; i += 256) {
         const int n = i >> 6, d = i & 63;
-        KV[n * KLD + d] = qkv[(row0 + n) * ld + 2 * inner + h * DH + d];
+        KV[n * KLD + d] = qkv[(row0 + LM_KROW(n)) * ld + 2 * inner + h * DH + d];
     }
+#undef LM_KROW
     const int wave = tid >> 6, lane = tid & 63;
     for (int i = wave; i < QC; i += 4) {
         float* sr = S + i * SLD;
@@ -85,7 +111,7 @@ __global__ __launch_bounds__(256) void attention_kernel(const float* __restrict_
 #pragma unroll
     for (int r = 0; r < QC / 4; ++r) {
         const int i = q0 + wave + 4 * r;
-        if (i < N) out[(row0 + i) * inner + h * DH + d] = acc[r];
+        if (i < NT) out[(row0 + i) * inner + h * DH + d] = acc[r];
     }
 }
 
@@ -213,7 +239,21 @@ LM_API int lm_attention_f32(void* stream, const float* qkv, float* out, int B, i
     const size_t lds = ((size_t)N * KLD + (size_t)QC * (N + 4) + QC * DH) * sizeof(float);
     LM_REQUIRE(lds <= 160 * 1024, "attention: N=%d does not fit LDS", N);
     if (int e = lm_ensure_dynamic_lds((const void*)attention_kernel, lds)) return e;
-    hipLaunchKernelGGL(attention_kernel, dim3(lm_cdiv(N, QC), heads, B), dim3(256), lds, (hipStream_t)stream, qkv, out, N, heads, scale);
+    hipLaunchKernelGGL(attention_kernel, dim3(lm_cdiv(N, QC), heads, B), dim3(256), lds, (hipStream_t)stream, qkv, out, N, heads, scale,
+                       (const int*)nullptr);
+    LM_LAUNCH_CHECK();
+    return LM_OK;
+}
+
+// The same attention with a key mask: valid [B][N] ints (device), N <= 64.  Per batch element only the tokens with a non-zero flag are
+// keys (compacted in token order: the arithmetic of a call on the valid tokens alone); every token gets an output row.
+LM_API int lm_attention_masked_f32(void* stream, const float* qkv, float* out, const int* valid, int B, int N, int heads, int dim_head,
+                                   float scale) {
+    LM_REQUIRE(qkv && out && valid, "attention_masked: null pointer");
+    LM_REQUIRE(dim_head == DH && N >= 1 && N <= 64, "attention_masked: dim_head=%d must be %d, N=%d at most 64", dim_head, DH, N);
+    const size_t lds = ((size_t)N * KLD + (size_t)QC * (N + 4) + QC * DH) * sizeof(float);
+    if (int e = lm_ensure_dynamic_lds((const void*)attention_kernel, lds)) return e;
+    hipLaunchKernelGGL(attention_kernel, dim3(lm_cdiv(N, QC), heads, B), dim3(256), lds, (hipStream_t)stream, qkv, out, N, heads, scale, valid);
     LM_LAUNCH_CHECK();
     return LM_OK;
 }

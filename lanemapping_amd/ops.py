@@ -461,10 +461,16 @@ def unpatchify(tokens, B, G, P, C_):
     return out
 
 
-def attention(qkv, B, N, heads, dim_head, scale):
+def attention(qkv, B, N, heads, dim_head, scale, valid=None):
+    """valid (optional, [B, N] int32 on the device, N <= 64): per batch element only the flagged tokens are keys (compacted in token
+    order: the arithmetic of a call on those tokens alone); every token still gets an output row."""
     assert qkv.is_contiguous()
     out = torch.empty((B * N, heads * dim_head), device=qkv.device, dtype=torch.float32)
-    check(lib().lm_attention_f32(_stream(), _ptr(qkv), _ptr(out), B, N, heads, dim_head, float(scale)))
+    if valid is None:
+        check(lib().lm_attention_f32(_stream(), _ptr(qkv), _ptr(out), B, N, heads, dim_head, float(scale)))
+    else:
+        assert valid.dtype == torch.int32 and valid.is_contiguous() and tuple(valid.shape) == (B, N)
+        check(lib().lm_attention_masked_f32(_stream(), _ptr(qkv), _ptr(out), _ptr(valid), B, N, heads, dim_head, float(scale)))
     return out
 
 

@@ -35,7 +35,7 @@ class TilePipeline:
         self.host_tiles = 0
 
     def _gpu_stage(self, proj):
-        if self.use_graph and torch.is_tensor(proj) and not self.rowref:      # (the RowRef head reads a mask on the host mid-forward)
+        if self.use_graph and torch.is_tensor(proj):      # (a tile tensor: the LiDAR path sizes its launches on the host and cannot be captured)
             dev, keep, crop = self._replay(proj)
         else:
             dev, keep, crop = self._device_part(proj)

@@ -28,6 +28,16 @@ def _stack(cin, hidden, cout):
     return nn.Sequential(nn.Conv1d(cin, hidden, 1), nn.BatchNorm1d(hidden), nn.Conv1d(hidden, cout, 1), nn.Identity())
 
 
+class _Last(dict):
+    """Tensors of the last forward; 'selected' (the [B, L] boolean lane-selection mask the reference computes on the host) is only
+    materialised when somebody asks for it - the forward itself never reads it back."""
+
+    def __missing__(self, key):
+        if key == 'selected':
+            return self['valid'].cpu().numpy() != 0
+        raise KeyError(key)
+
+
 @HEADS.register_module
 class RowSharNotReducRef(PackedModule):
     def __init__(self, dim_feat=8, row_size=144, dim_shared=512, lambda_cls=1., thr_ext=0.3, off_grid=2, dim_token=1024,
@@ -118,39 +128,28 @@ class RowSharNotReducRef(PackedModule):
         self.b_size = B
         dev = x.device
         ext1, cls1 = self._stage(P, 's1', 'ext', 'cls', x)
+        # lane selection (:199-204) stays on the device: tokens live on the fixed grid t = b * L + lane, `valid` flags the selected ones
+        # (round 2 read the mask on the host here, which serialised the streams and ruled out graph capture)
         mean = torch.empty((B, L), device=dev, dtype=torch.float32)
+        valid = torch.empty((B, L), device=dev, dtype=torch.int32)
         corr = torch.empty((B, L, H), device=dev, dtype=torch.int32)
-        check(lib().lm_rowref_select(ops._stream(), ops._ptr(ext1), ops._ptr(cls1), ops._ptr(mean), ops._ptr(corr), B, H, W, L))
-        sel_mask = (mean.cpu() > self.thr_ext).numpy()                     # data-dependent lane set (:199-200)
-        sel = np.ascontiguousarray(np.argwhere(sel_mask), dtype=np.int32)     # [T,2] rows sorted by (b, lane), C order
-        x2 = x
-        if len(sel):
-            T = len(sel)
-            bstart = np.zeros(B + 1, dtype=np.int32)
-            bstart[1:] = np.cumsum(sel_mask.sum(1))
-            sel_d = torch.from_numpy(sel).to(dev)
-            bstart_d = torch.from_numpy(bstart).to(dev)
-            tok = torch.empty((T, C * H * 5), device=dev, dtype=torch.float32)
-            check(lib().lm_rowref_gather(ops._stream(), ops._ptr(x), ops._ptr(corr), ops._ptr(sel_d), ops._ptr(tok), T, H, W, L))
-            emb = P['emb'][sel_d[:, 1].long()]
-            t = ops.linear_mfma(tok, P['tok.w'], self.dim_token, shift=P['tok.b'], res=emb)
-            parts = []
-            layers = self.tr_lane_correlator[0].layers
-            for b in range(B):                                             # attention only among the lanes of one tile
-                if bstart[b + 1] > bstart[b]:
-                    parts.append(transformer_forward(layers, P, 'T', t[bstart[b]:bstart[b + 1]], 1, int(bstart[b + 1] - bstart[b])))
-            t = torch.cat(parts, dim=0) if len(parts) > 1 else parts[0]
-            t = ops.layernorm(t.contiguous(), P['ln.g'], P['ln.b'], self.tr_lane_correlator[1].eps)
-            t = ops.linear_mfma(t, P['exp.w'], C * H * 5, shift=P['exp.b'])
-            x2 = ops.new_act(B, C, H, W, dev)
-            check(lib().lm_rowref_scatter(ops._stream(), ops._ptr(x), ops._ptr(t), ops._ptr(corr), ops._ptr(sel_d),
-                                          ops._ptr(bstart_d), ops._ptr(x2), B, H, W, L))
+        check(lib().lm_rowref_select(ops._stream(), ops._ptr(ext1), ops._ptr(cls1), ops._ptr(mean), ops._ptr(valid), float(self.thr_ext),
+                                     ops._ptr(corr), B, H, W, L))
+        tok = torch.empty((B * L, C * H * 5), device=dev, dtype=torch.float32)
+        check(lib().lm_rowref_gather(ops._stream(), ops._ptr(x), ops._ptr(corr), ops._ptr(tok), B, H, W, L))
+        t = ops.linear_mfma(tok, P['tok.w'], self.dim_token, shift=P['tok.b'], res=P['emb'], res_rows=L)      # + lane embedding (row t: lane t % L)
+        # attention only among the selected lanes of one tile: keys = the flagged tokens of the tile, in lane order
+        t = transformer_forward(self.tr_lane_correlator[0].layers, P, 'T', t, B, L, valid=valid)
+        t = ops.layernorm(t.contiguous(), P['ln.g'], P['ln.b'], self.tr_lane_correlator[1].eps)
+        t = ops.linear_mfma(t, P['exp.w'], C * H * 5, shift=P['exp.b'])
+        x2 = ops.new_act(B, C, H, W, dev)
+        check(lib().lm_rowref_scatter(ops._stream(), ops._ptr(x), ops._ptr(t), ops._ptr(corr), ops._ptr(valid), ops._ptr(x2), B, H, W, L))
         ext2, cls2 = self._stage(P, 's2', 'ext2', 'cls2', x2)
         out = {}
         for c in range(L):
             out[f'ext_{c}'], out[f'cls_{c}'] = ext1[:, :, c, :], cls1[:, :, c, :]
             out[f'ext2_{c}'], out[f'cls2_{c}'] = ext2[:, :, c, :], cls2[:, :, c, :]
-        self._last = {'ext2': ext2, 'cls2': cls2, 'refined': x2, 'selected': sel_mask}
+        self._last = _Last({'ext2': ext2, 'cls2': cls2, 'refined': x2, 'valid': valid})
         return out
 
     # ------------------------------------------------------------------------------------------ decode / lines
