@@ -107,13 +107,18 @@ __global__ __launch_bounds__(256) void gn_relu_upsample_kernel(const float* __re
     float wy0, wy1, wx0, wx1;
     bilin_axis(oy, Hi, Ho, y0, y1, wy0, wy1);
     bilin_axis(ox, Wi, Wo, x0, x1, wx0, wx1);
-    f32x4 a, g;   // per-channel affine of the normalisation: v*a + g
+    f32x4 a, g;   // per-channel affine of the normalisation: v*a + g  (statistics / gamma / beta as 16-byte loads)
+    {
+        const f32x4* st = reinterpret_cast<const f32x4*>(stats + ((long)b * C + c) * 2);
+        const f32x4 s0 = st[0], s1 = st[1], gm = *reinterpret_cast<const f32x4*>(gamma + c), bt = *reinterpret_cast<const f32x4*>(beta + c);
+        const float mean[4] = {s0[0], s0[2], s1[0], s1[2]}, rstd[4] = {s0[1], s0[3], s1[1], s1[3]};
 #pragma unroll
-    for (int e = 0; e < 4; ++e) {
-        float ae, ge;
-        lm_gn_affine(stats[((long)b * C + c + e) * 2], stats[((long)b * C + c + e) * 2 + 1], gamma[c + e], beta[c + e], ae, ge);
-        a[e] = ae;
-        g[e] = ge;
+        for (int e = 0; e < 4; ++e) {
+            float ae, ge;
+            lm_gn_affine(mean[e], rstd[e], gm[e], bt[e], ae, ge);
+            a[e] = ae;
+            g[e] = ge;
+        }
     }
     const float* xb = x + (long)b * Hi * Wi * C + c;
     auto tap = [&](int yy, int xx) {
@@ -159,28 +164,26 @@ struct Proj1x1 {
     int cout, ldy1;
 };
 
+// grid (ceil(Wo * C/4 / 256), Ho, B): the output row and the image come from the block index (the flat index used to be decoded with
+// three 32-bit divisions per thread - ~120 instructions in front of six loads: the kernel ran at 2.5 TB/s, VALU bound), the column
+// with one division by C/4 (a shift for the power-of-two channel counts of the FPN).
 __global__ __launch_bounds__(256) void gn_relu_upsample_sum_kernel(GnSum P, const float* __restrict__ gamma, const float* __restrict__ beta,
-                                                                   float* __restrict__ y, int Ho, int Wo, int C, unsigned total4, Proj1x1 Q) {
+                                                                   float* __restrict__ y, int Ho, int Wo, int C, int c4shift, Proj1x1 Q) {
     __shared__ __attribute__((aligned(16))) float wl[256 * 8];   // projection weights [C][8] (cout padded with zeros)
     if (Q.w) {
         for (int k = threadIdx.x; k < C * 8; k += 256) wl[k] = (k & 7) < Q.cout ? Q.w[(k >> 3) * 16 + (k & 7)] : 0.f;
         __syncthreads();
     }
-    const unsigned i = blockIdx.x * 256u + threadIdx.x;
-    if (i >= total4) return;                                  // (total4 is a multiple of C/4: the lanes of a pixel leave together)
     const unsigned c4n = (unsigned)C / 4;
-    const int c = (int)(i % c4n) * 4;
-    unsigned t = i / c4n;
-    const int ox = (int)(t % (unsigned)Wo);
-    t /= (unsigned)Wo;
-    const int oy = (int)(t % (unsigned)Ho);
-    const int b = (int)(t / (unsigned)Ho);
-    f32x4 gm, bt;
-#pragma unroll
-    for (int e = 0; e < 4; ++e) {
-        gm[e] = gamma[c + e];
-        bt[e] = beta[c + e];
-    }
+    const unsigned j = blockIdx.x * 256u + threadIdx.x;       // (column, channel quad) inside the output row
+    if (j >= (unsigned)Wo * c4n) return;                      // (a multiple of C/4: the lanes of a pixel leave together)
+    const int ox = c4shift >= 0 ? (int)(j >> c4shift) : (int)(j / c4n);
+    const int c = (int)(j - (unsigned)ox * c4n) * 4;
+    const int oy = (int)blockIdx.y, b = (int)blockIdx.z;
+    const unsigned i = ((unsigned)(b * Ho + oy) * (unsigned)Wo) * c4n + j;      // flat output quad
+    // (gamma / beta / statistics of the thread's 4 channels as 16-byte loads: 8 load instructions per pixel quad instead of 32 scalar
+    // ones - the kernel was bound by the issue of its small loads, not by its 6 taps)
+    const f32x4 gm = *reinterpret_cast<const f32x4*>(gamma + c), bt = *reinterpret_cast<const f32x4*>(beta + c);
     f32x4 acc = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int k = 0; k < 3; ++k) {
@@ -191,12 +194,17 @@ __global__ __launch_bounds__(256) void gn_relu_upsample_sum_kernel(GnSum P, cons
         bilin_axis(oy, T.Hi, Ho, y0, y1, wy0, wy1);
         bilin_axis(ox, T.Wi, Wo, x0, x1, wx0, wx1);
         f32x4 a, g;
+        {
+            const f32x4* st = reinterpret_cast<const f32x4*>(T.stats + ((long)b * C + c) * 2);      // (mean, rstd) x 4 channels
+            const f32x4 s0 = st[0], s1 = st[1];
+            const float mean[4] = {s0[0], s0[2], s1[0], s1[2]}, rstd[4] = {s0[1], s0[3], s1[1], s1[3]};
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            float ae, ge;
-            lm_gn_affine(T.stats[((long)b * C + c + e) * 2], T.stats[((long)b * C + c + e) * 2 + 1], gm[e], bt[e], ae, ge);
-            a[e] = ae;
-            g[e] = ge;
+            for (int e = 0; e < 4; ++e) {
+                float ae, ge;
+                lm_gn_affine(mean[e], rstd[e], gm[e], bt[e], ae, ge);
+                a[e] = ae;
+                g[e] = ge;
+            }
         }
         const float* xb = T.x + (long)b * T.Hi * T.Wi * T.ld + c;
         auto tap = [&](int yy, int xx) {
@@ -248,9 +256,9 @@ __global__ __launch_bounds__(256) void gn_relu_upsample_sum_kernel(GnSum P, cons
             }
         }
         for (unsigned o = 8; o < c4n; o <<= 1) part[0] += __shfl_xor(part[0], (int)o);
-        const unsigned li = i % c4n;
+        const unsigned li = (unsigned)c >> 2;
         const int n = 4 * (int)(li & 1) + 2 * (int)((li >> 1) & 1) + (int)((li >> 2) & 1);
-        if (li < 8 && n < Q.cout) Q.y1[(long)(i / c4n) * Q.ldy1 + n] = part[0] + (Q.bias ? Q.bias[n] : 0.f);
+        if (li < 8 && n < Q.cout) Q.y1[(long)((b * Ho + oy) * Wo + ox) * Q.ldy1 + n] = part[0] + (Q.bias ? Q.bias[n] : 0.f);
     }
 }
 
@@ -451,8 +459,14 @@ int launch_gn_sum(void* stream, int n, const float* const* x, const float* const
         LM_REQUIRE(ld >= C && ld % 4 == 0, "gn_relu_upsample_sum: bad leading dimension %d of term %d", ld, q);
         P.t[k] = GnTerm{x[q], stats[q], Hi[q], Wi[q], ld};
     }
-    hipLaunchKernelGGL(gn_relu_upsample_sum_kernel, dim3((unsigned)lm_cdiv(total4, 256)), dim3(256), 0, (hipStream_t)stream, P, gamma, beta,
-                       y, Ho, Wo, C, (unsigned)total4, Q);
+    const int c4n = C / 4;
+    LM_REQUIRE(256 % c4n == 0 || !Q.w, "gn_relu_upsample_sum: the fused 1x1 projection needs C/4 = %d to divide 256", c4n);
+    LM_REQUIRE(Ho <= 65535 && B <= 65535, "gn_relu_upsample_sum: grid too large");
+    int c4shift = -1;
+    for (int sft = 0; sft < 16; ++sft)
+        if ((1 << sft) == c4n) c4shift = sft;
+    hipLaunchKernelGGL(gn_relu_upsample_sum_kernel, dim3((unsigned)lm_cdiv((long)Wo * c4n, 256), (unsigned)Ho, (unsigned)B), dim3(256), 0,
+                       (hipStream_t)stream, P, gamma, beta, y, Ho, Wo, C, c4shift, Q);
     LM_LAUNCH_CHECK();
     return LM_OK;
 }

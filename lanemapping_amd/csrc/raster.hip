@@ -18,10 +18,10 @@
 //
 // Kernel design (HBM-bound; points arrive in acquisition order, i.e. spatially unsorted, so a workgroup cannot
 // own a pixel region directly; one device-scope atomicMax per point (v0) ran at 0.45 TB/s):
-//   pass 1  partition: every workgroup streams 8192 points with coalesced 16-byte non-temporal loads (8 in flight per
+//   pass 1  partition: every workgroup streams 16,384 points with coalesced 16-byte non-temporal loads (8 in flight per
 //           lane), turns each into a 4-byte record {pixel-in-band:16 | I:8 | G:8}, counting-sorts the records by band (16 or 12
 //           rows, band_rows_for) in LDS (rank = LDS atomic add on 8x replicated counters) and writes each band's run, padded to 16
-//           bytes, with aligned dwordx4 stores into its own static slot [tile][band][workgroup][8192] plus one contiguous row of
+//           bytes, with aligned dwordx4 stores into its own static slot [tile][band][workgroup][16384] plus one contiguous row of
 //           counts [tile][workgroup][band].  No global atomics, no memset, no inter-workgroup communication.
 //   pass 2  one 1024-thread workgroup per (tile, band): the band's rows x W u32 image lives in LDS; the runs are read 8 at a time
 //           per 16-lane group (all counts, then all first quads: two memory round trips) and applied with LDS atomic max, then the
@@ -49,11 +49,15 @@ struct LmRasterParams {      // mirrors the reference's per-tile parameter file 
 
 namespace {
 
+// Pass-1 workgroup size (x 32 points per thread = the chunk) and pass-2 prefetch depth: 512 threads / 16,384-point chunks (twice as
+// long record runs, half the count rows; 71 KB of LDS = two workgroups per CU) with 3 quads per lane measured 24.3 us per tile against
+// 25.4-25.7 for 256 / 2 on the same box; 1024 threads (one workgroup per CU: its load, sort and write-out phases no longer overlap
+// with another workgroup's) 41 us.
 #ifndef LM_RASTER_NT
-#define LM_RASTER_NT 256
+#define LM_RASTER_NT 512
 #endif
 #ifndef LM_RASTER_BQ
-#define LM_RASTER_BQ 2
+#define LM_RASTER_BQ 3
 #endif
 constexpr int NT = LM_RASTER_NT;       // threads per pass-1 workgroup
 constexpr int PER_THREAD = 32;
@@ -61,7 +65,7 @@ constexpr int CHUNK = NT * PER_THREAD; // points per pass-1 workgroup = record c
 constexpr int PART_CAPQ = (NT * 32 + 96 * 3 + 3) / 4;       // quads of the sorted buffer: every band's run is padded to 16 bytes
 constexpr size_t PART_LDS = (size_t)PART_CAPQ * 16 + ((PART_CAPQ + 15) / 16) * 16;
 constexpr int BQ = LM_RASTER_BQ;       // quads per lane of a 16-lane group fetched with a run's first round trip (pass 2)
-constexpr int MAX_BANDS = 96;             // keeps pass-1 LDS at 39.5 KB = 4 workgroups per CU
+constexpr int MAX_BANDS = 96;             // (12-row bands of a 1152-row tile)
 constexpr int MAX_TILES = 16;          // tiles per launch (kernel-argument block)
 constexpr int REP = 8;                 // replication of the LDS rank counters (fewer same-address collisions)
 
@@ -369,6 +373,8 @@ LM_API int lm_bev_raster_batch(void* stream, const float* points_xyzi, const lon
     const size_t lds = (size_t)band_rows * W * sizeof(unsigned);
     if (int e = lm_ensure_dynamic_lds((const void*)raster_band_kernel, lds)) return e;
     const long HW = (long)H * W;
+    // (launching the two passes per group of 8 / 4 / 2 tiles, so that a group's records - 17.7 MB per tile - could stay inside the 256 MB
+    // Infinity Cache between them, measured 25.3 / 27.1 / 27.4 us per tile against 23.8 for all 16 at once: the launch tails cost more)
     for (int b0 = 0; b0 < B; b0 += MAX_TILES) {
         const int nb = (B - b0) < MAX_TILES ? (B - b0) : MAX_TILES;
         BatchArgs A;
