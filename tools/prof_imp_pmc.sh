@@ -16,7 +16,7 @@ for f in sorted(glob.glob('$O/pass*/*counter_collection.csv')):
     agg = collections.defaultdict(lambda: collections.defaultdict(float)); n = collections.Counter()
     for r in csv.DictReader(open(f)):
         k = r['Kernel_Name'][:60]
-        if 'implicit' not in k and 'wino_dual' not in k: continue
+        if 'implicit' not in k and 'wino_dual' not in k and 'wino_pipe' not in k and 'wino_split' not in k: continue
         key = (k, r['Grid_Size'])
         agg[key][r['Counter_Name']] += float(r['Counter_Value'])
     for key, d in agg.items():

@@ -1,6 +1,6 @@
 #!/bin/bash
 # Re-measure the committed evidence: bench lines (headline = fused, tiles, rowref), raster micro-bench, rocprofv3 kernel stats of the
-# default command and of --streams 1 -> gpurun_out/refresh (copy what is to be judged into profiles/ as r2_*)
+# default command and of --streams 1 -> gpurun_out/refresh (copy what is to be judged into profiles/ as r3_*)
 R=${GRAFT_REPO_ROOT:?run through gpurun (GRAFT_REPO_ROOT is the repo copy on the GPU box)}
 O=$R/gpurun_out/refresh
 mkdir -p $O
@@ -9,6 +9,8 @@ python bench.py --steps 10 --warmup 3 2>/dev/null | tail -1 > $O/bench_config3_f
 python bench.py --workload tiles --steps 10 --warmup 3 --no-cpu-baseline 2>/dev/null | tail -1 > $O/bench_config2.json
 python bench.py --workload rowref --steps 5 --warmup 2 --no-cpu-baseline 2>/dev/null | tail -1 > $O/bench_config4_rowref.json
 python tools/bench_raster.py 2>/dev/null | tail -1 > $O/raster.json
+python tools/bench_lidar.py 8 > $O/lidar_config5.txt 2>/dev/null
+python bench.py --workload lidar --steps 5 --warmup 2 --no-cpu-baseline 2>/dev/null | tail -1 > $O/bench_config5_lidar.json
 cd /tmp && export TMPDIR=/tmp
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_default -o p -- python3 $R/bench.py --steps 4 --warmup 1 --no-cpu-baseline > /dev/null 2>> $R/gpurun_out/prof_stderr.log
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_s1 -o p -- python3 $R/bench.py --steps 4 --warmup 1 --no-cpu-baseline --streams 1 > /dev/null 2>> $R/gpurun_out/prof_stderr.log
