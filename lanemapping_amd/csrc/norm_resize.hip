@@ -164,9 +164,14 @@ struct Proj1x1 {
     int cout, ldy1;
 };
 
-// grid (ceil(Wo * C/4 / 256), Ho, B): the output row and the image come from the block index (the flat index used to be decoded with
-// three 32-bit divisions per thread - ~120 instructions in front of six loads: the kernel ran at 2.5 TB/s, VALU bound), the column
-// with one division by C/4 (a shift for the power-of-two channel counts of the FPN).
+// grid (ceil(Wo * C/4 / 256), Ho, B): the output row and the image come from the block index, the column with one division by C/4 (a
+// shift for the power-of-two channel counts of the FPN).
+// N terms, SAME = bit k set when term k has the output's size (one tap, returned as it is).  Both are TEMPLATE parameters: with run-time
+// term counts / sizes every term sat behind a branch, its loads could not be hoisted above the previous term's arithmetic, and a thread
+// paid up to three serial memory round trips - the counters showed 73 % of the wave cycles parked at s_waitcnt with 8 waves per SIMD
+// (tools/prof_gn_pmc.sh).  Now the statistics and every tap of every term are loaded first (up to 6 + 6 16-byte loads in flight per
+// lane), then the arithmetic runs in the old order: same bits.
+template <int N, int SAME>
 __global__ __launch_bounds__(256) void gn_relu_upsample_sum_kernel(GnSum P, const float* __restrict__ gamma, const float* __restrict__ beta,
                                                                    float* __restrict__ y, int Ho, int Wo, int C, int c4shift, Proj1x1 Q) {
     __shared__ __attribute__((aligned(16))) float wl[256 * 8];   // projection weights [C][8] (cout padded with zeros)
@@ -181,45 +186,54 @@ __global__ __launch_bounds__(256) void gn_relu_upsample_sum_kernel(GnSum P, cons
     const int c = (int)(j - (unsigned)ox * c4n) * 4;
     const int oy = (int)blockIdx.y, b = (int)blockIdx.z;
     const unsigned i = ((unsigned)(b * Ho + oy) * (unsigned)Wo) * c4n + j;      // flat output quad
-    // (gamma / beta / statistics of the thread's 4 channels as 16-byte loads: 8 load instructions per pixel quad instead of 32 scalar
-    // ones - the kernel was bound by the issue of its small loads, not by its 6 taps)
+    // ---- phase 1: every load of the thread
     const f32x4 gm = *reinterpret_cast<const f32x4*>(gamma + c), bt = *reinterpret_cast<const f32x4*>(beta + c);
+    f32x4 st0[N], st1[N], tap[N][4];
+    float wy0[N], wy1[N], wx0[N], wx1[N];
+#pragma unroll
+    for (int k = 0; k < N; ++k) {
+        const GnTerm& T = P.t[k];
+        const f32x4* st = reinterpret_cast<const f32x4*>(T.stats + ((long)b * C + c) * 2);      // (mean, rstd) x 4 channels
+        st0[k] = st[0];
+        st1[k] = st[1];
+        const float* xb = T.x + (long)b * T.Hi * T.Wi * T.ld + c;
+        if ((SAME >> k) & 1) {
+            tap[k][0] = *reinterpret_cast<const f32x4*>(xb + ((long)oy * T.Wi + ox) * T.ld);
+        } else {
+            int y0, y1, x0, x1;
+            bilin_axis(oy, T.Hi, Ho, y0, y1, wy0[k], wy1[k]);
+            bilin_axis(ox, T.Wi, Wo, x0, x1, wx0[k], wx1[k]);
+            tap[k][0] = *reinterpret_cast<const f32x4*>(xb + ((long)y0 * T.Wi + x0) * T.ld);
+            tap[k][1] = *reinterpret_cast<const f32x4*>(xb + ((long)y0 * T.Wi + x1) * T.ld);
+            tap[k][2] = *reinterpret_cast<const f32x4*>(xb + ((long)y1 * T.Wi + x0) * T.ld);
+            tap[k][3] = *reinterpret_cast<const f32x4*>(xb + ((long)y1 * T.Wi + x1) * T.ld);
+        }
+    }
+    // ---- phase 2: arithmetic, term by term
     f32x4 acc = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-    for (int k = 0; k < 3; ++k) {
-        if (k >= P.n) break;
-        const GnTerm& T = P.t[k];
-        int y0, y1, x0, x1;
-        float wy0, wy1, wx0, wx1;
-        bilin_axis(oy, T.Hi, Ho, y0, y1, wy0, wy1);
-        bilin_axis(ox, T.Wi, Wo, x0, x1, wx0, wx1);
+    for (int k = 0; k < N; ++k) {
         f32x4 a, g;
-        {
-            const f32x4* st = reinterpret_cast<const f32x4*>(T.stats + ((long)b * C + c) * 2);      // (mean, rstd) x 4 channels
-            const f32x4 s0 = st[0], s1 = st[1];
-            const float mean[4] = {s0[0], s0[2], s1[0], s1[2]}, rstd[4] = {s0[1], s0[3], s1[1], s1[3]};
+        const float mean[4] = {st0[k][0], st0[k][2], st1[k][0], st1[k][2]}, rstd[4] = {st0[k][1], st0[k][3], st1[k][1], st1[k][3]};
 #pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                float ae, ge;
-                lm_gn_affine(mean[e], rstd[e], gm[e], bt[e], ae, ge);
-                a[e] = ae;
-                g[e] = ge;
-            }
+        for (int e = 0; e < 4; ++e) {
+            float ae, ge;
+            lm_gn_affine(mean[e], rstd[e], gm[e], bt[e], ae, ge);
+            a[e] = ae;
+            g[e] = ge;
         }
-        const float* xb = T.x + (long)b * T.Hi * T.Wi * T.ld + c;
-        auto tap = [&](int yy, int xx) {
-            f32x4 v = *reinterpret_cast<const f32x4*>(xb + ((long)yy * T.Wi + xx) * T.ld);
-#pragma unroll
-            for (int e = 0; e < 4; ++e) v[e] = lm_gn_relu(v[e], a[e], g[e]);
-            return v;
-        };
         f32x4 o;
-        if (T.Hi == Ho && T.Wi == Wo) {     // same size: the blend has weights (1, 0) and returns the tap itself, bit for bit
-            o = tap(oy, ox);
-        } else {
-            const f32x4 v00 = tap(y0, x0), v01 = tap(y0, x1), v10 = tap(y1, x0), v11 = tap(y1, x1);
+        if ((SAME >> k) & 1) {              // same size: the blend has weights (1, 0) and returns the tap itself, bit for bit
 #pragma unroll
-            for (int e = 0; e < 4; ++e) o[e] = lm_bilerp(v00[e], v01[e], v10[e], v11[e], wy0, wy1, wx0, wx1);
+            for (int e = 0; e < 4; ++e) o[e] = lm_gn_relu(tap[k][0][e], a[e], g[e]);
+        } else {
+            f32x4 v[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[q][e] = lm_gn_relu(tap[k][q][e], a[e], g[e]);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) o[e] = lm_bilerp(v[0][e], v[1][e], v[2][e], v[3][e], wy0[k], wy1[k], wx0[k], wx1[k]);
         }
         if (k == 0) {
             acc = o;
@@ -250,9 +264,9 @@ __global__ __launch_bounds__(256) void gn_relu_upsample_sum_kernel(GnSum P, cons
         for (int half = 4, mask = 1; half >= 1; half >>= 1, mask <<= 1) {
             const bool upper = (lane & mask) != 0;
 #pragma unroll
-            for (int j = 0; j < half; ++j) {
-                const float send = upper ? part[j] : part[j + half], keep = upper ? part[j + half] : part[j];
-                part[j] = keep + __shfl_xor(send, mask);
+            for (int jj = 0; jj < half; ++jj) {
+                const float send = upper ? part[jj] : part[jj + half], keep = upper ? part[jj + half] : part[jj];
+                part[jj] = keep + __shfl_xor(send, mask);
             }
         }
         for (unsigned o = 8; o < c4n; o <<= 1) part[0] += __shfl_xor(part[0], (int)o);
@@ -465,8 +479,21 @@ int launch_gn_sum(void* stream, int n, const float* const* x, const float* const
     int c4shift = -1;
     for (int sft = 0; sft < 16; ++sft)
         if ((1 << sft) == c4n) c4shift = sft;
-    hipLaunchKernelGGL(gn_relu_upsample_sum_kernel, dim3((unsigned)lm_cdiv((long)Wo * c4n, 256), (unsigned)Ho, (unsigned)B), dim3(256), 0,
-                       (hipStream_t)stream, P, gamma, beta, y, Ho, Wo, C, c4shift, Q);
+    int same = 0;
+    for (int k = 0; k < n; ++k)
+        if (Hi[k] == Ho && Wi[k] == Wo) same |= 1 << k;
+    const dim3 grid((unsigned)lm_cdiv((long)Wo * c4n, 256), (unsigned)Ho, (unsigned)B);
+#define LM_GNS(NN, SS)                                                                                                           \
+    case (NN) * 8 + (SS):                                                                                                        \
+        hipLaunchKernelGGL((gn_relu_upsample_sum_kernel<NN, SS>), grid, dim3(256), 0, (hipStream_t)stream, P, gamma, beta, y, Ho, Wo, C, \
+                           c4shift, Q);                                                                                         \
+        break;
+    switch (n * 8 + same) {
+        LM_GNS(1, 0) LM_GNS(1, 1)
+        LM_GNS(2, 0) LM_GNS(2, 1) LM_GNS(2, 2) LM_GNS(2, 3)
+        LM_GNS(3, 0) LM_GNS(3, 1) LM_GNS(3, 2) LM_GNS(3, 3) LM_GNS(3, 4) LM_GNS(3, 5) LM_GNS(3, 6) LM_GNS(3, 7)
+    }
+#undef LM_GNS
     LM_LAUNCH_CHECK();
     return LM_OK;
 }
