@@ -1404,6 +1404,17 @@ __global__ __launch_bounds__(256, 2) void wino_dual_kernel(WinoImpParams p) {
 #pragma unroll
         for (int b = 0; b < 2; ++b) {
             const int ab = 2 * a + b;
+            // (residual loads of this output position before its fold: see wino_pipe_kernel)
+            f32x4 rpre[NP];
+            if (vec && p.res && n < p.Cout) {
+#pragma unroll
+                for (int pass = 0; pass < NP; ++pass) {
+                    const unsigned vm = vmask >> (3 * pass);
+                    const bool ok = (vm & 1u) && (!a || (vm & 2u)) && (!b || (vm & 4u));
+                    const long pix = pix0[pass] + a * step_a + b * step_b;
+                    rpre[pass] = ok ? *reinterpret_cast<const f32x4*>(p.res + pix * p.ldr + n) : f32x4{0.f, 0.f, 0.f, 0.f};
+                }
+            }
             f32x16 o;
 #pragma unroll
             for (int r4 = 0; r4 < 4; ++r4) {
@@ -1441,7 +1452,7 @@ __global__ __launch_bounds__(256, 2) void wino_dual_kernel(WinoImpParams p) {
                 }
                 if (vec) {
                     if (p.res) {
-                        const f32x4 rr = *reinterpret_cast<const f32x4*>(p.res + pix * p.ldr + n);
+                        const f32x4 rr = rpre[pass];
 #pragma unroll
                         for (int e = 0; e < 4; ++e) v[e] += rr[e];
                     }
@@ -1830,6 +1841,19 @@ __global__ __launch_bounds__(256) void wino_pipe_kernel(WinoImpParams p) {
     for (int a = 0; a < 2; ++a)
 #pragma unroll
         for (int b = 0; b < 2; ++b) {
+            // residual (BasicBlock identity): the four 16-byte loads of this output position go out BEFORE its fold (~1.3 k cycles of VALU
+            // work) - in the pass loop each of them was a memory round trip of its own in front of a store (-3 % on the residual layers;
+            // all sixteen up front spill)
+            f32x4 rpre[NP];
+            if (vec && p.res && n < p.Cout) {
+#pragma unroll
+                for (int pass = 0; pass < NP; ++pass) {
+                    const unsigned vm = vmask >> (3 * pass);
+                    const bool ok = (vm & 1u) && (!a || (vm & 2u)) && (!b || (vm & 4u));
+                    const long pix = pix0[pass] + a * step_a + b * step_b;
+                    rpre[pass] = ok ? *reinterpret_cast<const f32x4*>(p.res + pix * p.ldr + n) : f32x4{0.f, 0.f, 0.f, 0.f};
+                }
+            }
             f32x16 o;
 #pragma unroll
             for (int r = 0; r < 16; ++r) o[r] = 0.f;
@@ -1863,7 +1887,7 @@ __global__ __launch_bounds__(256) void wino_pipe_kernel(WinoImpParams p) {
                 }
                 if (vec) {
                     if (p.res) {
-                        const f32x4 rr = *reinterpret_cast<const f32x4*>(p.res + pix * p.ldr + n);
+                        const f32x4 rr = rpre[pass];
 #pragma unroll
                         for (int e = 0; e < 4; ++e) v[e] += rr[e];
                     }
