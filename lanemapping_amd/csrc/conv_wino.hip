@@ -1750,8 +1750,9 @@ __global__ __launch_bounds__(256) void wino_pipe_kernel(WinoImpParams p) {
         __builtin_amdgcn_global_load_lds((gptr_t*)(gsrc[s_] + PKS), (lptr_t*)(raw0 + PRAWH + (s_ * 4 + wave) * 256), 16, 0, 0);
 #pragma unroll
     for (int k = 0; k < BD; ++k) bload2(bq[k], bvoff, bbase + (long)k * bxi);
-#pragma unroll
-    for (int k = 0; k < BD; ++k) bwait<0>(bq[k]);
+    // only raw half-slab 0 has to be there for T(0): its PLPW loads are the oldest of the 2 PLPW + 2 BD in flight.  Raw half-slab 1 is
+    // waited for behind T(0) (slot 0 reads it), the B fragments by the steps that use them.
+    bwait<PLPW + 2 * BD>(bq[0]);
     __builtin_amdgcn_s_barrier();
     LM_TICK(0)
 #define LM_PXF(P) wino_pipe_xf<P>(xf, raw0, V0 + tvoff, roff, xo0, xo1, xo2, xsb)
@@ -1759,6 +1760,7 @@ __global__ __launch_bounds__(256) void wino_pipe_kernel(WinoImpParams p) {
     LM_PXF(8); LM_PXF(16); LM_PXF(9); LM_PXF(17); LM_PXF(10); LM_PXF(18); LM_PXF(11); LM_PXF(19);
     LM_PXF(12); LM_PXF(20); LM_PXF(13); LM_PXF(21); LM_PXF(14); LM_PXF(22); LM_PXF(15); LM_PXF(23);
 #undef LM_PXF
+    bwait<2 * BD>(bq[0]);                      // raw half-slab 1 has landed (this wave's part; the barrier below collects all parts)
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     LM_TICK(1)
     __builtin_amdgcn_s_barrier();
