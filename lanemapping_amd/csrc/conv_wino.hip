@@ -1804,127 +1804,7 @@ __global__ __launch_bounds__(256) void wino_pipe_kernel(WinoImpParams p) {
 #pragma unroll
     for (int k = 0; k < 8; ++k) bwait<0>(bq[k]);
 
-    // --- epilogue: the wide kernel's (fold in ascending xi, wave-private LDS transposes, 16-byte stores)
-    constexpr int ELD = 32 + 4;
-    float* stage = smem + wave * (32 * ELD);
-    constexpr int LPR = 8, RPI = 8, NP = 4;
-    const int c4 = (lane & 7) * 4;
-    const int n = n0 + wn0 + c4;
-    f32x4 sc = {1.f, 1.f, 1.f, 1.f}, sh = {0.f, 0.f, 0.f, 0.f};
-    if (n < p.Cout) {
-#pragma unroll
-        for (int e = 0; e < 4; ++e)
-            if (n + e < p.Cout) {
-                if (p.scale) sc[e] = p.scale[n + e];
-                if (p.shift) sh[e] = p.shift[n + e];
-            }
-    }
-    const bool vec = (n + 3 < p.Cout) && ((p.ldy & 3) == 0) && (!p.res || (p.ldr & 3) == 0);
-    f32x4 gs = {0.f, 0.f, 0.f, 0.f}, gq = {0.f, 0.f, 0.f, 0.f};
-    int pix0[NP];
-    unsigned vmask = 0;                                // 3 bits per row: tile exists | a = 1 inside | b = 1 inside
-#pragma unroll
-    for (int pass = 0; pass < NP; ++pass) {
-        const int tl = pass * RPI + lane / LPR;
-        int nn = sn[0], oy = oy0[0], oxb = ox0[0], tb = 0;
-#pragma unroll
-        for (int k = 1; k < INSEG; ++k)
-            if (tl >= ts[k]) {
-                nn = sn[k]; oy = oy0[k]; oxb = ox0[k]; tb = ts[k];
-            }
-        const int ox = oxb + 2 * (tl - tb) * g.dil;
-        pix0[pass] = img_pix0 + oy * g.W + ox;
-        if (nn > 0 && oy < g.H && ox < g.W)
-            vmask |= (1u | (oy + g.dil < g.H ? 2u : 0u) | (ox + g.dil < g.W ? 4u : 0u)) << (3 * pass);
-    }
-    const int step_a = g.dil * g.W, step_b = g.dil;
-    __syncthreads();                                   // every wave is done with the patch / V buffers
-#pragma unroll
-    for (int a = 0; a < 2; ++a)
-#pragma unroll
-        for (int b = 0; b < 2; ++b) {
-            // residual (BasicBlock identity): the four 16-byte loads of this output position go out BEFORE its fold (~1.3 k cycles of VALU
-            // work) - in the pass loop each of them was a memory round trip of its own in front of a store (-3 % on the residual layers;
-            // all sixteen up front spill)
-            f32x4 rpre[NP];
-            if (vec && p.res && n < p.Cout) {
-#pragma unroll
-                for (int pass = 0; pass < NP; ++pass) {
-                    const unsigned vm = vmask >> (3 * pass);
-                    const bool ok = (vm & 1u) && (!a || (vm & 2u)) && (!b || (vm & 4u));
-                    const long pix = pix0[pass] + a * step_a + b * step_b;
-                    rpre[pass] = ok ? *reinterpret_cast<const f32x4*>(p.res + pix * p.ldr + n) : f32x4{0.f, 0.f, 0.f, 0.f};
-                }
-            }
-            f32x16 o;
-#pragma unroll
-            for (int r = 0; r < 16; ++r) o[r] = 0.f;
-#pragma unroll
-            for (int xi = 0; xi < 16; ++xi) {
-                const float c = wino_fold_coef(2 * a + b, xi);
-                if (c == 0.f) continue;
-#pragma unroll
-                for (int r = 0; r < 16; ++r) o[r] = fmaf(acc[xi][r], c, o[r]);
-            }
-            __builtin_amdgcn_wave_barrier();
-#pragma unroll
-            for (int r = 0; r < 16; ++r) stage[((r & 3) + 8 * (r >> 2) + 4 * fhalf) * ELD + frow] = o[r];
-            __builtin_amdgcn_wave_barrier();
-            if (n >= p.Cout) continue;
-#pragma unroll
-            for (int pass = 0; pass < NP; ++pass) {
-                const int row = pass * RPI + lane / LPR;
-                const unsigned vm = vmask >> (3 * pass);
-                if (!(vm & 1u) || (a && !(vm & 2u)) || (b && !(vm & 4u))) continue;
-                const long pix = pix0[pass] + a * step_a + b * step_b;
-                f32x4 v = *reinterpret_cast<const f32x4*>(stage + row * ELD + c4);
-#pragma unroll
-                for (int e = 0; e < 4; ++e) v[e] = p.scale ? v[e] * sc[e] + sh[e] : v[e] + sh[e];
-                if (p.gn_part) {
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        gs[e] += v[e];
-                        gq[e] = fmaf(v[e], v[e], gq[e]);
-                    }
-                }
-                if (vec) {
-                    if (p.res) {
-                        const f32x4 rr = rpre[pass];
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) v[e] += rr[e];
-                    }
-                    if (p.act == LM_ACT_RELU) {
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
-                    }
-                    *reinterpret_cast<f32x4*>(p.y + pix * p.ldy + n) = v;
-                } else {
-                    for (int e = 0; e < 4 && n + e < p.Cout; ++e) {
-                        float u = v[e];
-                        if (p.res) u += p.res[pix * p.ldr + n + e];
-                        if (p.act == LM_ACT_RELU) u = fmaxf(u, 0.f);
-                        p.y[pix * p.ldy + n + e] = u;
-                    }
-                }
-            }
-        }
-    if (p.gn_part && n < p.Cout) {   // fixed-order reduction over the 8 lanes that share a channel quad, then one writer lane
-#pragma unroll
-        for (int o = LPR; o < 64; o <<= 1)
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                gs[e] += __shfl_xor(gs[e], o);
-                gq[e] += __shfl_xor(gq[e], o);
-            }
-        if (lane < LPR) {
-            const long chunk = t0 / 32;
-            double* o = p.gn_part + (((long)bi * (g.Tpad / 32) + chunk) * p.Cout + n) * 2;
-            for (int e = 0; e < 4 && n + e < p.Cout; ++e) {
-                o[2 * e] = (double)gs[e];
-                o[2 * e + 1] = (double)gq[e];
-            }
-        }
-    }
+#include "wino_pipe_epilogue.h"
 #ifdef LM_IPROF
     LM_TICK(6)
     if (tid == 0) {
@@ -1933,6 +1813,271 @@ __global__ __launch_bounds__(256) void wino_pipe_kernel(WinoImpParams p) {
         g_iprof[blockIdx.x % IPROF_WG][11] = 1ull;
     }
 #endif
+}
+
+// =====================================================================================================================================
+// PIPE geometry, split-precision GEMM (opt-in, LANEMAP_WINO_BF16X3=1; replaces the 64 x 64 split kernel of round 2).  Same workgroup,
+// same slots as wino_pipe_kernel, but the products run on the bf16 matrix cores: every fp32 operand is split EXACTLY into three bf16
+// pieces (v = v1 + v2 + v3 by truncation, 8 + 8 + 8 significant bits; U at weight-packing time) and six of the nine piece products are
+// accumulated in fp32, smallest first (error of a product <= 2^-23: the class of an fp32 rounding - profiles/r2_split_precision_study.txt).
+// What round 2's version lost its 2.67x less matrix time to - splitting every A fragment in registers, per wave and per N tile (44 VALU
+// per xi) - is gone: V is split ONCE, by the transform, and stored in LDS as bf16 pieces in the MFMA's own operand order:
+//   Vp[buffer][xi][piece][tile][16 channels as 2 chunks of 8 bf16]  (chunk g = channels 4g..4g+3 and 8+4g..8+4g+3: the k order of lane half g,
+//   which is also the order pack_wino_fragments_bf16x3 gives the U pieces), 3 KB per xi, 48 KB per half-slab buffer;
+// an A piece is one conflict-free ds_read_b128 per lane.  Six 32x32x16 bf16 MFMAs (32 cycles each) per xi and half-slab replace eight
+// f32 MFMAs (64 cycles); two xi are interleaved (a dependent bf16 MFMA chain issues at half rate).  The B pieces (3 KB per wave and xi)
+// come global -> registers six xi ahead in a ring of 8 sets: 192 KB per slot and CU = 62 B/clk at full matrix speed against the 64 the
+// vector memory path delivers - this kernel is bound by its B traffic, not by the matrix pipe.
+// Results are NOT bit-identical to the fp32 kernels (different products, same order of magnitude of error); `dtype` of a run with it is
+// bf16x3 and its roofline the bf16 peak.
+constexpr int SVH = 16 * 3 * PBM * 8;             // floats of one V half-slab buffer of bf16 pieces: 16 xi x 3 pieces x 32 tiles x 32 B = 48 KB
+
+// three bf16 pieces of four fp32 values, each piece packed as 4 bf16 = 2 dwords (channel c in the low half of dword c / 2)
+__device__ __forceinline__ void split3_quad(const f32x4 v, u32x2v (&piece)[3]) {
+    float r[4] = {v[0], v[1], v[2], v[3]};
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        piece[k][0] = pack_hi(r[0], r[1]);
+        piece[k][1] = pack_hi(r[2], r[3]);
+        if (k < 2) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) r[e] = r[e] - __uint_as_float(__float_as_uint(r[e]) & 0xFFFF0000u);      // exact
+        }
+    }
+}
+
+// This thread's share of a half-slab transform (see wino_pipe_xf: (tile, channel quad, row pair)), with the split: eight planes x three
+// pieces x 8 bytes.  vbyte = byte offset of (tile, quad) inside a piece plane.
+__device__ __forceinline__ void wino_split_transform(const float* raw, float* Vp, const int (&roff)[4], int o0, int o1, int o2, f32x2v sb,
+                                                     int plane0, int vbyte) {
+    const f32x2v neg = {-1.f, -1.f};
+    f32x4 ra[4], rb[4];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+        const f32x4 d0 = *reinterpret_cast<const f32x4*>(raw + o0 + roff[c]);
+        const f32x4 d1 = *reinterpret_cast<const f32x4*>(raw + o1 + roff[c]);
+        const f32x4 d2 = *reinterpret_cast<const f32x4*>(raw + o2 + roff[c]);
+        ra[c] = pk_fma4(d1, neg, d0);
+        rb[c] = pk_fma4(d2, sb, d1);
+    }
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        const f32x4 (&r)[4] = k < 4 ? ra : rb;
+        const int j = k & 3;
+        const f32x4 v = j == 0 ? pk_sub4(r[0], r[2]) : j == 1 ? pk_add4(r[1], r[2]) : j == 2 ? pk_sub4(r[2], r[1]) : pk_sub4(r[1], r[3]);
+        u32x2v pc[3];
+        split3_quad(v, pc);
+        char* base = reinterpret_cast<char*>(Vp) + (plane0 + k) * 3072 + vbyte;
+#pragma unroll
+        for (int q = 0; q < 3; ++q) *reinterpret_cast<u32x2v*>(base + q * 1024) = pc[q];
+    }
+}
+
+// One PAIR of xi steps (xi = 2P, 2P + 1) of a slot: 12 bf16 MFMAs; the B pieces of xi 2P + 6 / 2P + 7 are requested, the slot's PLPW
+// patch loads go out in pair steps 0 .. PLPW-1, the A pieces of the next pair are read behind the first two MFMAs.
+template <int P, int NWAIT>
+__device__ __forceinline__ void wino_split_pair(f32x16& accx, f32x16& accy, f32x4 (&bq)[8][3], unsigned bvoff, const float* bpre_x,
+                                                const float* bpre_y, const float* Vp, int aoff, f32x4 (&a_cur)[6], f32x4 (&a_nxt)[6],
+                                                const float* const (&gsrc)[PLPW], long goff, float* rawld, int wave) {
+    typedef __attribute__((address_space(1))) const void gptr_t;
+    typedef __attribute__((address_space(3))) void lptr_t;
+    constexpr int XI = 2 * P;
+    bload3(bq[(XI + 6) & 7], bvoff, bpre_x);
+    bload3(bq[(XI + 7) & 7], bvoff, bpre_y);
+    if constexpr (P < PLPW)
+        __builtin_amdgcn_global_load_lds((gptr_t*)(gsrc[P] + goff), (lptr_t*)(rawld + (P * 4 + wave) * 256), 16, 0, 0);
+    f32x4 (&bx)[3] = bq[XI & 7];
+    f32x4 (&by)[3] = bq[(XI + 1) & 7];
+    bwait3<NWAIT>(bx);
+    bwait3<NWAIT>(by);
+#define LM_BF(x) __builtin_bit_cast(bf16x8, x)
+    accx = __builtin_amdgcn_mfma_f32_32x32x16_bf16(LM_BF(a_cur[2]), LM_BF(bx[0]), accx, 0, 0, 0);       // v3 u1
+    accy = __builtin_amdgcn_mfma_f32_32x32x16_bf16(LM_BF(a_cur[5]), LM_BF(by[0]), accy, 0, 0, 0);
+    __builtin_amdgcn_sched_barrier(0);
+    if constexpr (P < 7) {
+#pragma unroll
+        for (int q = 0; q < 3; ++q) {
+            a_nxt[q] = *reinterpret_cast<const f32x4*>(Vp + (XI + 2) * 768 + q * 256 + aoff);
+            a_nxt[3 + q] = *reinterpret_cast<const f32x4*>(Vp + (XI + 3) * 768 + q * 256 + aoff);
+        }
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    accx = __builtin_amdgcn_mfma_f32_32x32x16_bf16(LM_BF(a_cur[1]), LM_BF(bx[1]), accx, 0, 0, 0);       // v2 u2
+    accy = __builtin_amdgcn_mfma_f32_32x32x16_bf16(LM_BF(a_cur[4]), LM_BF(by[1]), accy, 0, 0, 0);
+    accx = __builtin_amdgcn_mfma_f32_32x32x16_bf16(LM_BF(a_cur[0]), LM_BF(bx[2]), accx, 0, 0, 0);       // v1 u3
+    accy = __builtin_amdgcn_mfma_f32_32x32x16_bf16(LM_BF(a_cur[3]), LM_BF(by[2]), accy, 0, 0, 0);
+    accx = __builtin_amdgcn_mfma_f32_32x32x16_bf16(LM_BF(a_cur[1]), LM_BF(bx[0]), accx, 0, 0, 0);       // v2 u1
+    accy = __builtin_amdgcn_mfma_f32_32x32x16_bf16(LM_BF(a_cur[4]), LM_BF(by[0]), accy, 0, 0, 0);
+    accx = __builtin_amdgcn_mfma_f32_32x32x16_bf16(LM_BF(a_cur[0]), LM_BF(bx[1]), accx, 0, 0, 0);       // v1 u2
+    accy = __builtin_amdgcn_mfma_f32_32x32x16_bf16(LM_BF(a_cur[3]), LM_BF(by[1]), accy, 0, 0, 0);
+    accx = __builtin_amdgcn_mfma_f32_32x32x16_bf16(LM_BF(a_cur[0]), LM_BF(bx[0]), accx, 0, 0, 0);       // v1 u1
+    accy = __builtin_amdgcn_mfma_f32_32x32x16_bf16(LM_BF(a_cur[3]), LM_BF(by[0]), accy, 0, 0, 0);
+#undef LM_BF
+    __builtin_amdgcn_sched_barrier(0);
+}
+
+__global__ __launch_bounds__(256) void wino_pipe_split_kernel(WinoImpParams p) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];      // raw[2][PRAWH] | Vp[2][SVH]
+    float* const raw0 = smem;
+    float* const V0 = smem + 2 * PRAWH;
+    typedef __attribute__((address_space(1))) const void gptr_t;
+    typedef __attribute__((address_space(3))) void lptr_t;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wn0 = wave * 32;
+    const int n_tiles = (p.Cout + PBN - 1) / PBN;
+    unsigned mblk, ntile;
+    {   // XCD-aware order, N tile outer (see wino_pipe_kernel)
+        const unsigned bid = blockIdx.x, mb = gridDim.x / (unsigned)n_tiles, mbx = mb / 8, full = mbx * 8 * (unsigned)n_tiles;
+        if (bid < full) {
+            const unsigned xcd = bid % 8, idx = bid / 8;
+            ntile = idx / mbx;
+            mblk = xcd * mbx + idx % mbx;
+        } else {
+            const unsigned r = bid - full;
+            mblk = 8 * mbx + r / (unsigned)n_tiles;
+            ntile = r % (unsigned)n_tiles;
+        }
+    }
+    const long m0 = (long)mblk * PBM;
+    const int n0 = (int)ntile * PBN;
+    const WinoGeom& g = p.g;
+    const int bi = (int)(m0 / g.Tpad);
+    const int t0 = (int)(m0 - (long)bi * g.Tpad);
+    int ts[INSEG + 1], sn[INSEG], iy0[INSEG], ix0[INSEG], oy0[INSEG], ox0[INSEG];      // run table (see wino_implicit_kernel)
+    {
+        int at = 0, t = t0;
+        int tx = t0 % g.Tx, rest = t0 / g.Tx;
+        int ty = rest % g.Ty, ph = rest / g.Ty;
+        int pa = ph / g.dil, pb = ph - pa * g.dil;
+#pragma unroll
+        for (int s_ = 0; s_ < INSEG; ++s_) {
+            ts[s_] = at;
+            const bool real = t < g.Timg && at < PBM;
+            const int n = at < PBM ? min(PBM - at, g.Tx - tx) : 0;
+            sn[s_] = real ? n : 0;
+            iy0[s_] = (2 * ty - 1) * g.dil + pa;
+            ix0[s_] = (2 * tx - 1) * g.dil + pb;
+            oy0[s_] = 2 * ty * g.dil + pa;
+            ox0[s_] = 2 * tx * g.dil + pb;
+            at += n;
+            t += n;
+            tx += n;
+            if (tx >= g.Tx) {
+                tx = 0;
+                if (++ty >= g.Ty) {
+                    ty = 0;
+                    if (++pb >= g.dil) {
+                        pb = 0;
+                        ++pa;
+                    }
+                }
+            }
+        }
+        ts[INSEG] = at;
+    }
+    const float* gsrc[PLPW];
+    const int img_pix0 = bi * g.H * g.W;
+#pragma unroll
+    for (int s_ = 0; s_ < PLPW; ++s_) {
+        const int pos = (s_ * 4 + wave) * 16 + (lane >> 2);           // LDS cell position (16 cells of 64 B per wave load)
+        const int r = pos / PNCOL;
+        const int q = unrot3(pos - r * PNCOL);
+        const int ch = lane & 3;
+        int n = sn[0], yb = iy0[0], xb = ix0[0], q0 = 0;
+#pragma unroll
+        for (int k = 1; k < INSEG; ++k)
+            if (q >= 2 * ts[k] + 2 * k) {
+                n = sn[k]; yb = iy0[k]; xb = ix0[k]; q0 = 2 * ts[k] + 2 * k;
+            }
+        const int lc = q - q0;
+        const int yy = yb + r * g.dil, xx = xb + lc * g.dil;
+        const bool ok = r < 4 && lc < 2 * n + 2 && n > 0 && (unsigned)yy < (unsigned)g.H && (unsigned)xx < (unsigned)g.W;
+        gsrc[s_] = ok ? p.x + (long)(img_pix0 + yy * g.W + xx) * p.ldx + ch * 4 : p.zeros + ch * 4;
+    }
+    // transform share: tile (tid & 127) >> 2, channel quad tid & 3, row pair ih = wave >> 1
+    int roff[4], xo0, xo1, xo2, tplane0, tvbyte;
+    f32x2v xsb;
+    {
+        const int ih = wave >> 1;
+        const int tl = (tid & 127) >> 2, qd = tid & 3;
+        int sg = 0;
+#pragma unroll
+        for (int k = 1; k < INSEG; ++k) sg += (ts[k] < PBM && tl >= ts[k]) ? 1 : 0;
+        const int cb = 2 * tl + 2 * sg;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) roff[c] = (rot3(cb + c) * 4 + qd) * 4;
+        tplane0 = 8 * ih;
+        tvbyte = tl * 32 + (qd & 1) * 16 + (qd >> 1) * 8;          // chunk (qd & 1) = lane half, second 8 bytes for channels 8..15
+        constexpr int ROWF = PNCOL * PKS;
+        xo0 = (ih == 0 ? 0 : 2) * ROWF;
+        xo1 = (ih == 0 ? 2 : 1) * ROWF;
+        xo2 = (ih == 0 ? 1 : 3) * ROWF;
+        const float sbv = ih == 0 ? 1.f : -1.f;
+        xsb = f32x2v{sbv, sbv};
+    }
+    const int frow = lane & 31, fhalf = lane >> 5;
+    const int aoff = frow * 8 + fhalf * 4;             // floats inside a piece plane: tile row of 32 B, chunk = lane half
+    const int H = p.C / PKS;                           // half-slabs (slots)
+    const unsigned bvoff = (unsigned)lane * 16u;
+    const long bstep = (long)p.NT * 768;               // floats between consecutive 16-channel slabs of one xi (3 pieces x 64 lanes x 16 B)
+    const long bxi = (long)H * bstep;
+    const float* const bbase = p.U + (long)((n0 + wn0) >> 5) * 768;
+
+    f32x16 acc[16];
+#pragma unroll
+    for (int k = 0; k < 16; ++k)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[k][r] = 0.f;
+    f32x4 bq3[8][3];
+    // prologue: raw half-slabs 0 and 1, B of xi 0 .. 5 of slot 0, Vp of half-slab 0
+#pragma unroll
+    for (int s_ = 0; s_ < PLPW; ++s_)
+        __builtin_amdgcn_global_load_lds((gptr_t*)gsrc[s_], (lptr_t*)(raw0 + (s_ * 4 + wave) * 256), 16, 0, 0);
+#pragma unroll
+    for (int s_ = 0; s_ < PLPW; ++s_)
+        __builtin_amdgcn_global_load_lds((gptr_t*)(gsrc[s_] + PKS), (lptr_t*)(raw0 + PRAWH + (s_ * 4 + wave) * 256), 16, 0, 0);
+#pragma unroll
+    for (int k = 0; k < 6; ++k) bload3(bq3[k], bvoff, bbase + (long)k * bxi);
+#pragma unroll
+    for (int k = 0; k < 6; ++k) bwait3<0>(bq3[k]);
+    __builtin_amdgcn_s_barrier();
+    wino_split_transform(raw0, V0, roff, xo0, xo1, xo2, xsb, tplane0, tvbyte);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    for (int h = 0; h < H; ++h) {
+        const int par = h & 1;
+        // transform + split of half-slab h + 1 (past the last one: stale data into a buffer nobody reads)
+        wino_split_transform(raw0 + (par ^ 1) * PRAWH, V0 + (par ^ 1) * SVH, roff, xo0, xo1, xo2, xsb, tplane0, tvbyte);
+        float* const rawld = raw0 + par * PRAWH;                                           // raw(h + 2) replaces raw(h)
+        const float* const Vp = V0 + par * SVH;
+        const long goff = h + 2 < H ? (long)(h + 2) * PKS : 0;
+        const float* const bs = bbase + (long)h * bstep;
+        const float* const bs_next = bbase + (long)(h + 1 < H ? h + 1 : 0) * bstep;
+        f32x4 a0[6], a1[6];
+#pragma unroll
+        for (int q = 0; q < 3; ++q) {
+            a0[q] = *reinterpret_cast<const f32x4*>(Vp + q * 256 + aoff);
+            a0[3 + q] = *reinterpret_cast<const f32x4*>(Vp + 768 + q * 256 + aoff);
+        }
+#define LM_BPRE(X) ((X) < 16 ? bs + (long)(X) * bxi : bs_next + (long)((X) - 16) * bxi)
+#define LM_SPAIR(P, NW, AC, AN) \
+        wino_split_pair<P, NW>(acc[2 * (P)], acc[2 * (P) + 1], bq3, bvoff, LM_BPRE(2 * (P) + 6), LM_BPRE(2 * (P) + 7), Vp, aoff, AC, AN, gsrc, goff, \
+                               rawld, wave)
+        // NWAIT = 3 pair steps x 6 B loads + the patch loads of the last four pair steps (pair steps 0 .. 4 issue one each)
+        LM_SPAIR(0, 19, a0, a1); LM_SPAIR(1, 20, a1, a0); LM_SPAIR(2, 21, a0, a1); LM_SPAIR(3, 22, a1, a0);
+        LM_SPAIR(4, 22, a0, a1); LM_SPAIR(5, 21, a1, a0); LM_SPAIR(6, 20, a0, a1); LM_SPAIR(7, 19, a1, a0);
+#undef LM_SPAIR
+#undef LM_BPRE
+        static_assert(PLPW == 5, "NWAIT table above");
+        bwait3<18>(bq3[0]);                    // this wave's patch loads (pair steps 0 .. 4) have landed: only the B loads of pair steps 5 .. 7 are younger
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();          // Vp(h + 1) complete, Vp(h) and raw(h + 1) free, raw(h + 2) landed
+    }
+#pragma unroll
+    for (int k = 0; k < 8; ++k) bwait3<0>(bq3[k]);
+
+#include "wino_pipe_epilogue.h"
 }
 
 // runs of adjacent tiles a 64-tile block can touch: floor((IBM - 2) / Tx) + 2
@@ -2074,12 +2219,12 @@ int wino_implicit_launch(int mode, void* stream, const float* x, int ldx, const 
         zeros = (const float*)sym;
     }
     p.zeros = zeros;
-    if (mode == 1) {        // split-precision study kernel (64 tiles x 64 channels)
-        const size_t lds = (size_t)(IRAW + IVBUF) * sizeof(float);
-        const long blocks = (p.g.T / IBM) * ((Cout + IBN - 1) / IBN);
-        LM_REQUIRE(blocks > 0 && blocks < (1L << 31) && p.g.T % IBM == 0, "conv_wino_implicit: bad grid %ld", blocks);
-        if (int e = lm_ensure_dynamic_lds((const void*)wino_split_kernel, lds)) return e;
-        hipLaunchKernelGGL(wino_split_kernel, dim3((unsigned)blocks), dim3(256), lds, (hipStream_t)stream, p);
+    if (mode == 1) {        // split-precision GEMM, PIPE geometry (wino_pipe_split_kernel)
+        const size_t slds = (size_t)(2 * PRAWH + 2 * SVH) * sizeof(float);
+        const long sblocks = (p.g.T / PBM) * ((Cout + PBN - 1) / PBN);
+        LM_REQUIRE(sblocks > 0 && sblocks < (1L << 31) && p.g.T % PBM == 0, "conv_wino_implicit: bad grid %ld", sblocks);
+        if (int e = lm_ensure_dynamic_lds((const void*)wino_pipe_split_kernel, slds)) return e;
+        hipLaunchKernelGGL(wino_pipe_split_kernel, dim3((unsigned)sblocks), dim3(256), slds, (hipStream_t)stream, p);
         LM_LAUNCH_CHECK();
         return LM_OK;
     }
