@@ -1847,30 +1847,55 @@ __device__ __forceinline__ void split3_quad(const f32x4 v, u32x2v (&piece)[3]) {
 }
 
 // This thread's share of a half-slab transform (see wino_pipe_xf: (tile, channel quad, row pair)), with the split: eight planes x three
-// pieces x 8 bytes.  vbyte = byte offset of (tile, quad) inside a piece plane.
-__device__ __forceinline__ void wino_split_transform(const float* raw, float* Vp, const int (&roff)[4], int o0, int o1, int o2, f32x2v sb,
-                                                     int plane0, int vbyte) {
-    const f32x2v neg = {-1.f, -1.f};
+// pieces x 8 bytes, in pieces that ride behind the MFMAs of the pair steps.  Plain (unpacked) fp32 VALU on purpose: up to four single-rate
+// VALU instructions per bf16 MFMA issue for free in the same wave, a v_pk_*_f32 costs ~10 cycles of matrix time each
+// (tools/probes/split_probe.hip).  vbyte = byte offset of (tile, quad) inside a piece plane.
+struct SplitRows {
     f32x4 ra[4], rb[4];
+};
+
+__device__ __forceinline__ void wino_split_rows(const float* raw, const int (&roff)[4], int o0, int o1, int o2, float sb, SplitRows& t) {
 #pragma unroll
     for (int c = 0; c < 4; ++c) {
         const f32x4 d0 = *reinterpret_cast<const f32x4*>(raw + o0 + roff[c]);
         const f32x4 d1 = *reinterpret_cast<const f32x4*>(raw + o1 + roff[c]);
         const f32x4 d2 = *reinterpret_cast<const f32x4*>(raw + o2 + roff[c]);
-        ra[c] = pk_fma4(d1, neg, d0);
-        rb[c] = pk_fma4(d2, sb, d1);
-    }
 #pragma unroll
-    for (int k = 0; k < 8; ++k) {
-        const f32x4 (&r)[4] = k < 4 ? ra : rb;
-        const int j = k & 3;
-        const f32x4 v = j == 0 ? pk_sub4(r[0], r[2]) : j == 1 ? pk_add4(r[1], r[2]) : j == 2 ? pk_sub4(r[2], r[1]) : pk_sub4(r[1], r[3]);
-        u32x2v pc[3];
-        split3_quad(v, pc);
-        char* base = reinterpret_cast<char*>(Vp) + (plane0 + k) * 3072 + vbyte;
-#pragma unroll
-        for (int q = 0; q < 3; ++q) *reinterpret_cast<u32x2v*>(base + q * 1024) = pc[q];
+        for (int e = 0; e < 4; ++e) {
+            t.ra[c][e] = d0[e] - d1[e];
+            t.rb[c][e] = fmaf(d2[e], sb, d1[e]);
+        }
     }
+}
+
+template <int K>
+__device__ __forceinline__ void wino_split_plane(const SplitRows& t, float* Vp, int plane0, int vbyte) {
+    const f32x4 (&r)[4] = K < 4 ? t.ra : t.rb;
+    constexpr int j = K & 3;
+    float v[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) v[e] = j == 0 ? r[0][e] - r[2][e] : j == 1 ? r[1][e] + r[2][e] : j == 2 ? r[2][e] - r[1][e] : r[1][e] - r[3][e];
+    char* base = reinterpret_cast<char*>(Vp) + (plane0 + K) * 3072 + vbyte;
+#pragma unroll
+    for (int q = 0; q < 3; ++q) {
+        u32x2v pc;
+        pc[0] = pack_hi(v[0], v[1]);
+        pc[1] = pack_hi(v[2], v[3]);
+        *reinterpret_cast<u32x2v*>(base + q * 1024) = pc;
+        if (q < 2) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = v[e] - __uint_as_float(__float_as_uint(v[e]) & 0xFFFF0000u);      // exact
+        }
+    }
+}
+
+__device__ __forceinline__ void wino_split_transform(const float* raw, float* Vp, const int (&roff)[4], int o0, int o1, int o2, float sb,
+                                                     int plane0, int vbyte) {
+    SplitRows t;
+    wino_split_rows(raw, roff, o0, o1, o2, sb, t);
+    wino_split_plane<0>(t, Vp, plane0, vbyte); wino_split_plane<1>(t, Vp, plane0, vbyte); wino_split_plane<2>(t, Vp, plane0, vbyte);
+    wino_split_plane<3>(t, Vp, plane0, vbyte); wino_split_plane<4>(t, Vp, plane0, vbyte); wino_split_plane<5>(t, Vp, plane0, vbyte);
+    wino_split_plane<6>(t, Vp, plane0, vbyte); wino_split_plane<7>(t, Vp, plane0, vbyte);
 }
 
 // One PAIR of xi steps (xi = 2P, 2P + 1) of a slot: 12 bf16 MFMAs; the B pieces of xi 2P + 6 / 2P + 7 are requested, the slot's PLPW
@@ -1878,18 +1903,27 @@ __device__ __forceinline__ void wino_split_transform(const float* raw, float* Vp
 template <int P, int NWAIT>
 __device__ __forceinline__ void wino_split_pair(f32x16& accx, f32x16& accy, f32x4 (&bq)[8][3], unsigned bvoff, const float* bpre_x,
                                                 const float* bpre_y, const float* Vp, int aoff, f32x4 (&a_cur)[6], f32x4 (&a_nxt)[6],
-                                                const float* const (&gsrc)[PLPW], long goff, float* rawld, int wave) {
+                                                const float* const (&gsrc)[PLPW], long goff, float* rawld, int wave, SplitRows& xt,
+                                                const float* xraw, float* xVp, const int (&roff)[4], int xo0, int xo1, int xo2, float xsb,
+                                                int xplane0, int xvbyte) {
     typedef __attribute__((address_space(1))) const void gptr_t;
     typedef __attribute__((address_space(3))) void lptr_t;
     constexpr int XI = 2 * P;
+#ifndef LM_SABL_NOB
     bload3(bq[(XI + 6) & 7], bvoff, bpre_x);
     bload3(bq[(XI + 7) & 7], bvoff, bpre_y);
+#endif
     if constexpr (P < PLPW)
         __builtin_amdgcn_global_load_lds((gptr_t*)(gsrc[P] + goff), (lptr_t*)(rawld + (P * 4 + wave) * 256), 16, 0, 0);
     f32x4 (&bx)[3] = bq[XI & 7];
     f32x4 (&by)[3] = bq[(XI + 1) & 7];
+#ifndef LM_SABL_NOB
     bwait3<NWAIT>(bx);
     bwait3<NWAIT>(by);
+#else
+    bwait3<0>(bx);
+    bwait3<0>(by);
+#endif
 #define LM_BF(x) __builtin_bit_cast(bf16x8, x)
     accx = __builtin_amdgcn_mfma_f32_32x32x16_bf16(LM_BF(a_cur[2]), LM_BF(bx[0]), accx, 0, 0, 0);       // v3 u1
     accy = __builtin_amdgcn_mfma_f32_32x32x16_bf16(LM_BF(a_cur[5]), LM_BF(by[0]), accy, 0, 0, 0);
@@ -1902,6 +1936,12 @@ __device__ __forceinline__ void wino_split_pair(f32x16& accx, f32x16& accy, f32x
         }
     }
     __builtin_amdgcn_sched_barrier(0);
+    // the transform piece of this pair step (half-slab h + 1): the row pass in step 0, plane P in every step; the scheduler may spread
+    // it over the remaining ten MFMAs (groups: 1 MFMA, then up to 4 VALU / 1 LDS)
+#ifndef LM_SABL_NOT
+    if constexpr (P == 0) wino_split_rows(xraw, roff, xo0, xo1, xo2, xsb, xt);
+    wino_split_plane<P>(xt, xVp, xplane0, xvbyte);
+#endif
     accx = __builtin_amdgcn_mfma_f32_32x32x16_bf16(LM_BF(a_cur[1]), LM_BF(bx[1]), accx, 0, 0, 0);       // v2 u2
     accy = __builtin_amdgcn_mfma_f32_32x32x16_bf16(LM_BF(a_cur[4]), LM_BF(by[1]), accy, 0, 0, 0);
     accx = __builtin_amdgcn_mfma_f32_32x32x16_bf16(LM_BF(a_cur[0]), LM_BF(bx[2]), accx, 0, 0, 0);       // v1 u3
@@ -1913,6 +1953,12 @@ __device__ __forceinline__ void wino_split_pair(f32x16& accx, f32x16& accy, f32x
     accx = __builtin_amdgcn_mfma_f32_32x32x16_bf16(LM_BF(a_cur[0]), LM_BF(bx[0]), accx, 0, 0, 0);       // v1 u1
     accy = __builtin_amdgcn_mfma_f32_32x32x16_bf16(LM_BF(a_cur[3]), LM_BF(by[0]), accy, 0, 0, 0);
 #undef LM_BF
+#pragma unroll
+    for (int k = 0; k < 10; ++k) {
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);      // one MFMA
+        __builtin_amdgcn_sched_group_barrier(0x002, P == 0 ? 7 : 4, 0);      // VALU
+        __builtin_amdgcn_sched_group_barrier(0x300, P == 0 ? 2 : 1, 0);      // DS read / write
+    }
     __builtin_amdgcn_sched_barrier(0);
 }
 
@@ -1997,7 +2043,7 @@ __global__ __launch_bounds__(256) void wino_pipe_split_kernel(WinoImpParams p) {
     }
     // transform share: tile (tid & 127) >> 2, channel quad tid & 3, row pair ih = wave >> 1
     int roff[4], xo0, xo1, xo2, tplane0, tvbyte;
-    f32x2v xsb;
+    float xsb;
     {
         const int ih = wave >> 1;
         const int tl = (tid & 127) >> 2, qd = tid & 3;
@@ -2014,7 +2060,7 @@ __global__ __launch_bounds__(256) void wino_pipe_split_kernel(WinoImpParams p) {
         xo1 = (ih == 0 ? 2 : 1) * ROWF;
         xo2 = (ih == 0 ? 1 : 3) * ROWF;
         const float sbv = ih == 0 ? 1.f : -1.f;
-        xsb = f32x2v{sbv, sbv};
+        xsb = sbv;
     }
     const int frow = lane & 31, fhalf = lane >> 5;
     const int aoff = frow * 8 + fhalf * 4;             // floats inside a piece plane: tile row of 32 B, chunk = lane half
@@ -2045,10 +2091,12 @@ __global__ __launch_bounds__(256) void wino_pipe_split_kernel(WinoImpParams p) {
     wino_split_transform(raw0, V0, roff, xo0, xo1, xo2, xsb, tplane0, tvbyte);
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
+    SplitRows xt;
     for (int h = 0; h < H; ++h) {
         const int par = h & 1;
-        // transform + split of half-slab h + 1 (past the last one: stale data into a buffer nobody reads)
-        wino_split_transform(raw0 + (par ^ 1) * PRAWH, V0 + (par ^ 1) * SVH, roff, xo0, xo1, xo2, xsb, tplane0, tvbyte);
+        // the transform + split of half-slab h + 1 rides in the pair steps (past the last one: stale data into a buffer nobody reads)
+        const float* const xraw = raw0 + (par ^ 1) * PRAWH;
+        float* const xVp = V0 + (par ^ 1) * SVH;
         float* const rawld = raw0 + par * PRAWH;                                           // raw(h + 2) replaces raw(h)
         const float* const Vp = V0 + par * SVH;
         const long goff = h + 2 < H ? (long)(h + 2) * PKS : 0;
@@ -2063,7 +2111,7 @@ __global__ __launch_bounds__(256) void wino_pipe_split_kernel(WinoImpParams p) {
 #define LM_BPRE(X) ((X) < 16 ? bs + (long)(X) * bxi : bs_next + (long)((X) - 16) * bxi)
 #define LM_SPAIR(P, NW, AC, AN) \
         wino_split_pair<P, NW>(acc[2 * (P)], acc[2 * (P) + 1], bq3, bvoff, LM_BPRE(2 * (P) + 6), LM_BPRE(2 * (P) + 7), Vp, aoff, AC, AN, gsrc, goff, \
-                               rawld, wave)
+                               rawld, wave, xt, xraw, xVp, roff, xo0, xo1, xo2, xsb, tplane0, tvbyte)
         // NWAIT = 3 pair steps x 6 B loads + the patch loads of the last four pair steps (pair steps 0 .. 4 issue one each)
         LM_SPAIR(0, 19, a0, a1); LM_SPAIR(1, 20, a1, a0); LM_SPAIR(2, 21, a0, a1); LM_SPAIR(3, 22, a1, a0);
         LM_SPAIR(4, 22, a0, a1); LM_SPAIR(5, 21, a1, a0); LM_SPAIR(6, 20, a0, a1); LM_SPAIR(7, 19, a1, a0);
