@@ -2128,6 +2128,291 @@ __global__ __launch_bounds__(256) void wino_pipe_split_kernel(WinoImpParams p) {
 #include "wino_pipe_epilogue.h"
 }
 
+// =====================================================================================================================================
+// ROWS geometry of the split-precision GEMM: 64 tiles x 64 channels per workgroup, wave w owns the four Winograd products of ROW w of the
+// 4 x 4 transform (xi = 4w .. 4w + 3) for the whole block - 4 xi x 2 tile halves x 2 channel halves = 16 accumulator blocks.
+// Why: wino_pipe_split_kernel pulls 192 KB of B pieces per slot and CU = 62 B/clk at full matrix speed; the vector memory path sustains
+// ~40 of its 64 B/clk with every CU pulling, so that kernel runs at the speed of its B traffic (2.43 ms on 256->256@288^2 B = 8, matrix
+// time 0.95).  Here every B fragment is loaded by exactly ONE wave and used for both tile halves (32 B/clk), and the transform of a xi row
+// needs nothing from the other waves: V[w][j] comes from two patch rows (row pass), a column pass and the split, all in the registers of
+// the lane that feeds it to the MFMA (lane (r, g) = tile r, channels 4g..4g+3 and 8+4g..8+4g+3) - no V in LDS, no barrier but the one that
+// publishes the patch buffer of the slot after next.  The 480 VALU instructions per slot and wave ride behind the 96 MFMAs (four to five
+// plain fp32 VALU per bf16 MFMA issue for free - tools/probes/split_probe.hip).  Patch layout in LDS: 32 planes (row, channel quad,
+// column parity) of 68 16-byte entries, so the 32 lanes of a tile half read consecutive entries (conflict-free ds_read_b128).
+// The 2 x 2 outputs need all four rows: the epilogue folds a wave's four xi (column pass), exchanges the row terms through LDS and the
+// wave that owns a (tile half, channel half) block sums them in ascending row order and stores (wino_rows_epilogue.h).
+constexpr int RBM = 64, RBN = 64, RKS = 16, RLPW = 9;
+constexpr int RPL = RBM + INSEG;                  // 16-byte entries of one patch plane (the columns of one parity)
+constexpr int RRAWH = RLPW * 4 * 256;             // floats of one patch buffer (36 KB)
+constexpr int RELD = 32 + 4;
+constexpr int RXCH = 16 * 32 * RELD;              // floats of the epilogue's exchange area (72 KB)
+static_assert(8 * RPL * 4 <= RLPW * 4 * 64, "rows geometry: patch loads cover the planes");
+
+struct RowsR {
+    float v[4][8];                                // row-pass result of one tile: [patch column][channel of the lane's 8]
+};
+
+// row pass of ROW w for one tile half: r[c] = d[first row][c] + sgn * d[second row][c], 16 ds_read_b128 (two-way bank conflicts: the
+// swizzle of the quad position covers half of the 16-lane groups' 64-byte stride)
+__device__ __forceinline__ void wino_rows_rowpass(const float* raw, const int (&b1)[2], const int (&b2)[2], float sgn, RowsR& r) {
+#pragma unroll
+    for (int c = 0; c < 4; ++c)
+#pragma unroll
+        for (int qs = 0; qs < 2; ++qs) {
+            const int off = (c & 1) * (RPL * 16) + qs * 8;
+            const f32x4 d1 = *reinterpret_cast<const f32x4*>(raw + b1[c >> 1] + off);
+            const f32x4 d2 = *reinterpret_cast<const f32x4*>(raw + b2[c >> 1] + off);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) r.v[c][qs * 4 + e] = fmaf(d2[e], sgn, d1[e]);
+        }
+}
+
+// column pass J of the row + split into the three A pieces (52 VALU)
+template <int J>
+__device__ __forceinline__ void wino_rows_make_a(const RowsR& r, f32x4 (&a)[3]) {
+    f32x4 lo, hi;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        lo[e] = J == 0 ? r.v[0][e] - r.v[2][e] : J == 1 ? r.v[1][e] + r.v[2][e] : J == 2 ? r.v[2][e] - r.v[1][e] : r.v[1][e] - r.v[3][e];
+        hi[e] = J == 0 ? r.v[0][4 + e] - r.v[2][4 + e] : J == 1 ? r.v[1][4 + e] + r.v[2][4 + e] : J == 2 ? r.v[2][4 + e] - r.v[1][4 + e]
+                                                                                                   : r.v[1][4 + e] - r.v[3][4 + e];
+    }
+    split3_frag(lo, hi, a);
+}
+
+// the twelve MFMAs of (xi, tile half): both channel halves, six piece products each, smallest first
+__device__ __forceinline__ void wino_rows_mfma12(f32x16& acc0, f32x16& acc1, const f32x4 (&a)[3], const f32x4 (&b0)[3], const f32x4 (&b1)[3]) {
+#define LM_BF(x) __builtin_bit_cast(bf16x8, x)
+    acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(LM_BF(a[2]), LM_BF(b0[0]), acc0, 0, 0, 0);       // v3 u1
+    acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(LM_BF(a[2]), LM_BF(b1[0]), acc1, 0, 0, 0);
+    acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(LM_BF(a[1]), LM_BF(b0[1]), acc0, 0, 0, 0);       // v2 u2
+    acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(LM_BF(a[1]), LM_BF(b1[1]), acc1, 0, 0, 0);
+    acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(LM_BF(a[0]), LM_BF(b0[2]), acc0, 0, 0, 0);       // v1 u3
+    acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(LM_BF(a[0]), LM_BF(b1[2]), acc1, 0, 0, 0);
+    acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(LM_BF(a[1]), LM_BF(b0[0]), acc0, 0, 0, 0);       // v2 u1
+    acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(LM_BF(a[1]), LM_BF(b1[0]), acc1, 0, 0, 0);
+    acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(LM_BF(a[0]), LM_BF(b0[1]), acc0, 0, 0, 0);       // v1 u2
+    acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(LM_BF(a[0]), LM_BF(b1[1]), acc1, 0, 0, 0);
+    acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(LM_BF(a[0]), LM_BF(b0[0]), acc0, 0, 0, 0);       // v1 u1
+    acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(LM_BF(a[0]), LM_BF(b1[0]), acc1, 0, 0, 0);
+#undef LM_BF
+}
+
+__global__ __launch_bounds__(256) void wino_rows_split_kernel(WinoImpParams p) {
+#ifdef LM_IPROF
+    long long iprof[11] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    long long t_last = clock64();
+#endif
+    extern __shared__ __attribute__((aligned(16))) float smem[];      // patches[3][RRAWH]; the epilogue's exchange area afterwards
+    float* const raw0 = smem;
+    typedef __attribute__((address_space(1))) const void gptr_t;
+    typedef __attribute__((address_space(3))) void lptr_t;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int n_tiles = (p.Cout + RBN - 1) / RBN;
+    unsigned mblk, ntile;
+    {   // XCD-aware order, N tile outer (see wino_pipe_kernel)
+        const unsigned bid = blockIdx.x, mb = gridDim.x / (unsigned)n_tiles, mbx = mb / 8, full = mbx * 8 * (unsigned)n_tiles;
+        if (bid < full) {
+            const unsigned xcd = bid % 8, idx = bid / 8;
+            ntile = idx / mbx;
+            mblk = xcd * mbx + idx % mbx;
+        } else {
+            const unsigned r = bid - full;
+            mblk = 8 * mbx + r / (unsigned)n_tiles;
+            ntile = r % (unsigned)n_tiles;
+        }
+    }
+    const long m0 = (long)mblk * RBM;
+    const int n0 = (int)ntile * RBN;
+    const WinoGeom& g = p.g;
+    const int bi = (int)(m0 / g.Tpad);
+    const int t0 = (int)(m0 - (long)bi * g.Tpad);
+    int ts[INSEG + 1], sn[INSEG], iy0[INSEG], ix0[INSEG], oy0[INSEG], ox0[INSEG];      // run table (see wino_implicit_kernel)
+    {
+        int at = 0, t = t0;
+        int tx = t0 % g.Tx, rest = t0 / g.Tx;
+        int ty = rest % g.Ty, ph = rest / g.Ty;
+        int pa = ph / g.dil, pb = ph - pa * g.dil;
+#pragma unroll
+        for (int s_ = 0; s_ < INSEG; ++s_) {
+            ts[s_] = at;
+            const bool real = t < g.Timg && at < RBM;
+            const int n = at < RBM ? min(RBM - at, g.Tx - tx) : 0;
+            sn[s_] = real ? n : 0;
+            iy0[s_] = (2 * ty - 1) * g.dil + pa;
+            ix0[s_] = (2 * tx - 1) * g.dil + pb;
+            oy0[s_] = 2 * ty * g.dil + pa;
+            ox0[s_] = 2 * tx * g.dil + pb;
+            at += n;
+            t += n;
+            tx += n;
+            if (tx >= g.Tx) {
+                tx = 0;
+                if (++ty >= g.Ty) {
+                    ty = 0;
+                    if (++pb >= g.dil) {
+                        pb = 0;
+                        ++pa;
+                    }
+                }
+            }
+        }
+        ts[INSEG] = at;
+    }
+    // patch loads: LDS 16-byte unit (load * 4 + wave) * 64 + lane = entry * 4 + position, entry = plane * RPL + idx, plane = row * 2 + column
+    // parity; the four lanes of an entry fetch the 64 contiguous bytes of one pixel's slab, quad q at position q ^ ((idx >> 2) & 1)
+    const float* gsrc[RLPW];
+    const int img_pix0 = bi * g.H * g.W;
+#pragma unroll
+    for (int s_ = 0; s_ < RLPW; ++s_) {
+        const int ent4 = (s_ * 4 + wave) * 64 + lane;
+        const int ent = ent4 >> 2;
+        const int plane = ent / RPL, idx = ent - plane * RPL;
+        const int r = plane >> 1, ch = (ent4 & 3) ^ ((idx >> 2) & 1);
+        const int q = 2 * idx + (plane & 1);
+        int n = sn[0], yb = iy0[0], xb = ix0[0], q0 = 0;
+#pragma unroll
+        for (int k = 1; k < INSEG; ++k)
+            if (q >= 2 * ts[k] + 2 * k) {
+                n = sn[k]; yb = iy0[k]; xb = ix0[k]; q0 = 2 * ts[k] + 2 * k;
+            }
+        const int lc = q - q0;
+        const int yy = yb + r * g.dil, xx = xb + lc * g.dil;
+        const bool ok = plane < 8 && lc < 2 * n + 2 && n > 0 && (unsigned)yy < (unsigned)g.H && (unsigned)xx < (unsigned)g.W;
+        gsrc[s_] = ok ? p.x + (long)(img_pix0 + yy * g.W + xx) * p.ldx + ch * 4 : p.zeros + ch * 4;
+    }
+    // row-pass reads of this lane: tile ms * 32 + (lane & 31), quads g and g + 2 (g = lane >> 5); rows of ROW w: first + sgn * second
+    const int frow = lane & 31, fhalf = lane >> 5;
+    const int row1 = wave == 0 ? 0 : wave == 2 ? 2 : 1;
+    const int row2 = wave == 2 ? 1 : wave == 3 ? 3 : 2;
+    const float rsgn = wave == 1 ? 1.f : -1.f;
+    int rb1[2][2], rb2[2][2];                          // [tile half][patch column pair]
+#pragma unroll
+    for (int ms = 0; ms < 2; ++ms) {
+        const int tl = ms * 32 + frow;
+        int sg = 0;
+#pragma unroll
+        for (int k = 1; k < INSEG; ++k) sg += (ts[k] < RBM && tl >= ts[k]) ? 1 : 0;
+#pragma unroll
+        for (int cp = 0; cp < 2; ++cp) {
+            const int idx = tl + sg + cp;                               // entry idx = (2 tl + 2 sg + c) / 2, c = 2 cp + parity
+            const int e0 = idx * 16 + (fhalf ^ ((idx >> 2) & 1)) * 4;
+            rb1[ms][cp] = row1 * 2 * (RPL * 16) + e0;
+            rb2[ms][cp] = row2 * 2 * (RPL * 16) + e0;
+        }
+    }
+    const int H = p.C / RKS;                           // slots (16 input channels each)
+    const unsigned bvoff = (unsigned)lane * 16u;
+    const long bstep = (long)p.NT * 768;               // floats between consecutive 16-channel slabs of one xi (3 pieces x 64 lanes x 16 B)
+    const long bxi = (long)H * bstep;
+    const float* const bbase = p.U + (long)(n0 >> 5) * 768 + (long)(4 * wave) * bxi;      // xi = 4 * wave, channel half 0 (half 1: + 768)
+
+    f32x16 acc[16];                                    // [j][tile half][channel half]
+#pragma unroll
+    for (int k = 0; k < 16; ++k)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[k][r] = 0.f;
+    f32x4 bq[4][2][3];                                 // B ring: xi step j in set j & 3, requested three steps ahead
+    // prologue: patches of slots 0 .. 2 (three buffers in rotation), B of steps 0 .. 2, row pass of slot 0, A(0, tile half 0)
+#pragma unroll
+    for (int s_ = 0; s_ < RLPW; ++s_)
+        __builtin_amdgcn_global_load_lds((gptr_t*)gsrc[s_], (lptr_t*)(raw0 + (s_ * 4 + wave) * 256), 16, 0, 0);
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        bload3(bq[k][0], bvoff, bbase + (long)k * bxi);
+        bload3(bq[k][1], bvoff, bbase + (long)k * bxi + 768);
+    }
+#pragma unroll
+    for (int s_ = 0; s_ < RLPW; ++s_)
+        __builtin_amdgcn_global_load_lds((gptr_t*)(gsrc[s_] + RKS), (lptr_t*)(raw0 + RRAWH + (s_ * 4 + wave) * 256), 16, 0, 0);
+    {
+        const long g2 = H > 2 ? 2 * RKS : 0;
+#pragma unroll
+        for (int s_ = 0; s_ < RLPW; ++s_)
+            __builtin_amdgcn_global_load_lds((gptr_t*)(gsrc[s_] + g2), (lptr_t*)(raw0 + 2 * RRAWH + (s_ * 4 + wave) * 256), 16, 0, 0);
+    }
+    asm volatile("s_waitcnt vmcnt(36)" ::: "memory");      // the patches of slot 0 (18 B loads and 18 patch loads are younger)
+    __builtin_amdgcn_s_barrier();
+    RowsR rr[2];
+    f32x4 a0[3], a1[3];
+    wino_rows_rowpass(raw0, rb1[0], rb2[0], rsgn, rr[0]);
+    wino_rows_rowpass(raw0, rb1[1], rb2[1], rsgn, rr[1]);
+    wino_rows_make_a<0>(rr[0], a0);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();              // every wave has read the patches of slot 0: the loads of slot 3 may replace them
+    LM_TICK(0)
+    int bcur = 0, bnxt = RRAWH;                // float offsets of the buffers of slot h (refilled with slot h + 3) and of slot h + 1
+    for (int h = 0; h < H; ++h) {
+        float* const rawld = raw0 + bcur;                                                  // patches of slot h + 3 replace those of slot h
+        const float* const rawnx = raw0 + bnxt;                                            // patches of slot h + 1 (row pass in step 3)
+        const long goff = h + 3 < H ? (long)(h + 3) * RKS : 0;                             // (nothing left to fetch: harmless re-read)
+        const float* const bs = bbase + (long)h * bstep;
+        const float* const bs_next = bbase + (long)(h + 1 < H ? h + 1 : 0) * bstep;
+#define LM_BPRE(X) ((X) < 4 ? bs + (long)(X) * bxi : bs_next + (long)((X) - 4) * bxi)
+#define LM_GROUPS(NV, ND)                                                        \
+        _Pragma("unroll") for (int k_ = 0; k_ < 12; ++k_) {                      \
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                   \
+            if (ND) __builtin_amdgcn_sched_group_barrier(0x100, ND, 0);          \
+            __builtin_amdgcn_sched_group_barrier(0x002, NV, 0);                  \
+        }
+        // step J: patch loads P0 .. P1-1 of the slot, B of step J + 3; then (J, tile half 0) with A(J, 1) made behind it, (J, 1) with
+        // A(J + 1, 0).  NW = loads younger than B(J) after this step's requests: the patch loads of three steps + 18.
+#define LM_RSTEP(J, P0, P1, NW, MAKE0, GRP0, MAKE1, GRP1)                                                                                        \
+        {                                                                                                                             \
+            _Pragma("unroll") for (int s_ = P0; s_ < P1; ++s_)                                                                        \
+                __builtin_amdgcn_global_load_lds((gptr_t*)(gsrc[s_] + goff), (lptr_t*)(rawld + (s_ * 4 + wave) * 256), 16, 0, 0);    \
+            bload3(bq[((J) + 3) & 3][0], bvoff, LM_BPRE((J) + 3));                                                                    \
+            bload3(bq[((J) + 3) & 3][1], bvoff, LM_BPRE((J) + 3) + 768);                                                              \
+            bwait3<NW>(bq[(J) & 3][0]);                                                                                               \
+            bwait3<NW>(bq[(J) & 3][1]);                                                                                               \
+            LM_TICK((J) == 0 ? 1 : 3)                                                                                                 \
+            __builtin_amdgcn_sched_barrier(0);                                                                                        \
+            MAKE0                                                                                                                     \
+            wino_rows_mfma12(acc[4 * (J)], acc[4 * (J) + 1], a0, bq[(J) & 3][0], bq[(J) & 3][1]);                                     \
+            GRP0                                                                                                                      \
+            __builtin_amdgcn_sched_barrier(0);                                                                                        \
+            MAKE1                                                                                                                     \
+            wino_rows_mfma12(acc[4 * (J) + 2], acc[4 * (J) + 3], a1, bq[(J) & 3][0], bq[(J) & 3][1]);                                 \
+            GRP1                                                                                                                      \
+            __builtin_amdgcn_sched_barrier(0);                                                                                        \
+            LM_TICK((J) == 3 ? 2 : 4)                                                                                                 \
+        }
+        static_assert(RLPW == 9, "NW table: patch loads per step 3, 3, 3, 0");
+        LM_RSTEP(0, 0, 3, 24, wino_rows_make_a<0>(rr[1], a1);, LM_GROUPS(5, 0), wino_rows_make_a<1>(rr[0], a0);, LM_GROUPS(5, 0))
+        LM_RSTEP(1, 3, 6, 24, wino_rows_make_a<1>(rr[1], a1);, LM_GROUPS(5, 0), wino_rows_make_a<2>(rr[0], a0);, LM_GROUPS(5, 0))
+        LM_RSTEP(2, 6, 9, 27, wino_rows_make_a<2>(rr[1], a1);, LM_GROUPS(5, 0), wino_rows_make_a<3>(rr[0], a0);, LM_GROUPS(5, 0))
+        // step 3: the row pass of slot h + 1 follows the last use of each tile half's row data
+        LM_RSTEP(3, 9, 9, 24,
+                 wino_rows_rowpass(rawnx, rb1[0], rb2[0], rsgn, rr[0]); wino_rows_make_a<3>(rr[1], a1);, LM_GROUPS(7, 2),
+                 wino_rows_rowpass(rawnx, rb1[1], rb2[1], rsgn, rr[1]); wino_rows_make_a<0>(rr[0], a0);, LM_GROUPS(7, 2))
+#undef LM_RSTEP
+#undef LM_GROUPS
+#undef LM_BPRE
+        asm volatile("s_waitcnt vmcnt(33)" ::: "memory");     // this wave's patch loads of the PREVIOUS slot have landed (33 loads per slot)
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();          // patches of slot h + 2 visible, every wave is done reading those of slot h + 1
+        LM_TICK(5)
+        bcur = bnxt;
+        bnxt = bnxt == 2 * RRAWH ? 0 : bnxt + RRAWH;
+    }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        bwait3<0>(bq[k][0]);
+        bwait3<0>(bq[k][1]);
+    }
+
+#include "wino_rows_epilogue.h"
+#ifdef LM_IPROF
+    LM_TICK(6)
+    if (tid == 0) {
+#pragma unroll
+        for (int k = 0; k < 11; ++k) g_iprof[blockIdx.x % IPROF_WG][k] = (unsigned long long)iprof[k];
+        g_iprof[blockIdx.x % IPROF_WG][11] = 1ull;
+    }
+#endif
+}
+
 // runs of adjacent tiles a 64-tile block can touch: floor((IBM - 2) / Tx) + 2
 bool wino_implicit_ok(const WinoGeom& g) { return (IBM - 2) / g.Tx + 2 <= INSEG; }
 
@@ -2267,6 +2552,16 @@ int wino_implicit_launch(int mode, void* stream, const float* x, int ldx, const 
         zeros = (const float*)sym;
     }
     p.zeros = zeros;
+    static const bool split_pipe = getenv("LANEMAP_SPLIT_PIPE") && atoi(getenv("LANEMAP_SPLIT_PIPE")) == 1;
+    if (mode == 1 && !split_pipe) {        // split-precision GEMM, ROWS geometry (wino_rows_split_kernel)
+        const size_t rlds = (size_t)(3 * RRAWH > 2 * RXCH ? 3 * RRAWH : 2 * RXCH) * sizeof(float);
+        const long rblocks = (p.g.T / RBM) * ((Cout + RBN - 1) / RBN);
+        LM_REQUIRE(rblocks > 0 && rblocks < (1L << 31) && p.g.T % RBM == 0, "conv_wino_implicit: bad grid %ld", rblocks);
+        if (int e = lm_ensure_dynamic_lds((const void*)wino_rows_split_kernel, rlds)) return e;
+        hipLaunchKernelGGL(wino_rows_split_kernel, dim3((unsigned)rblocks), dim3(256), rlds, (hipStream_t)stream, p);
+        LM_LAUNCH_CHECK();
+        return LM_OK;
+    }
     if (mode == 1) {        // split-precision GEMM, PIPE geometry (wino_pipe_split_kernel)
         const size_t slds = (size_t)(2 * PRAWH + 2 * SVH) * sizeof(float);
         const long sblocks = (p.g.T / PBM) * ((Cout + PBN - 1) / PBN);

@@ -17,10 +17,15 @@ for cin, cout, dil, hw in [(256, 256, 1, 288), (256, 128, 1, 288), (256, 256, 2,
     y = ops.conv_wino_implicit(x, wf3, cout, dil)
     err = float((y - y32).abs().max())
     res = {}
+    import ctypes
+    has_prof = hasattr(ops.lib(), 'lm_iprof_read')
     for name, f in (('fp32', wf), ('bf16x3', wf3)):
         for _ in range(2):
             ops.conv_wino_implicit(x, f, cout, dil, out=y)
         torch.cuda.synchronize()
+        if has_prof:
+            buf = (ctypes.c_ulonglong * 12)()
+            ops.lib().lm_iprof_read(buf, 1)
         a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         a.record()
         for _ in range(10):
@@ -28,5 +33,9 @@ for cin, cout, dil, hw in [(256, 256, 1, 288), (256, 128, 1, 288), (256, 256, 2,
         b.record()
         torch.cuda.synchronize()
         res[name] = a.elapsed_time(b) / 10
+        if has_prof and name == 'bf16x3':
+            ops.lib().lm_iprof_read(buf, 1)
+            nw = max(buf[11], 1)
+            print(f'  iprof {cin}->{cout}@{hw}: ' + ' '.join(f'{k}={buf[k] / nw:.0f}' for k in range(8)) + f' total={sum(buf[:11]) / nw:.0f}')
     out.append(f'{cin}->{cout} d{dil}@{hw} fp32 {res["fp32"]:.3f} split {res["bf16x3"]:.3f} ms (x{res["fp32"] / res["bf16x3"]:.2f}) err {err:.1e}')
 print(os.path.basename(os.environ.get('LANEMAP_HIP_LIB', 'product')), ' | '.join(out))
