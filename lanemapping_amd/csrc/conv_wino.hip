@@ -562,19 +562,13 @@ WinoGeom geom(int B, int H, int W, int dil) {
 // columns (slot of tile tl, patch column c: q = 2 tl + 2 run + c).  A cell is 16 floats = 4 chunks of 16 bytes; cell q sits at
 // position rot(q) (low three bits rotated so that the cells of consecutive TILES differ in their low two position bits): the 16
 // lanes of a ds_read_b128 group (4 tiles x 4 channel quads) then cover all 64 banks.  V rows are XOR-swizzled by (tile >> 2) & 3.
-constexpr int IBM = 64, IBN = 64, INSEG = 4, IKS = 16;
-constexpr int INCOL = 2 * IBM + 2 * INSEG;       // 136 column slots
-constexpr int ICELLS = 4 * INCOL;                // 544 cells per slab
-constexpr int IROW = INCOL * IKS;                // floats per patch row
-constexpr int ILPW = 9;                          // global_load_lds instructions per wave and slab: 4 x 9 x 16 cells >= 544
-constexpr int IRAW = ILPW * 4 * 256;             // floats of the raw buffer (36,864 B; the last 32 cells are never read)
-constexpr int IVBUF = 16 * IBM * IKS;            // floats of the V slab (65,536 B)
-static_assert(ILPW * 4 * 16 >= ICELLS && INCOL % 8 == 0, "patch loads cover the slab");
+constexpr int IBM = 64, INSEG = 4;               // the largest tile block of the geometries below and the runs of adjacent tiles it can touch
 __device__ __attribute__((aligned(16))) float g_wino_zeros[1024 + 32];   // zero source for padding cells, any channel slab (Cin <= 1024)
 
 struct WinoImpParams {
     const float* x; const float* U; const float* scale; const float* shift; const float* res; float* y; const float* zeros;
     int ldx, ldr, ldy, C, Cout, NT, act;      // NT = CoutP / 32 channel tiles in U
+    int n_inner;                               // (ROWS) workgroup order: N tile inner
     double* gn_part;
     WinoGeom g;
 };
@@ -602,7 +596,6 @@ __device__ __forceinline__ void bwait(f32x4 (&b)[2]) {
 // against 3.3e-6 for the fp32 Winograd, 0 decision flips outside the reference margin on the G10 tile).  Six 32x32x16 bf16 MFMAs of
 // 32 cycles replace eight 32x32x2 f32 MFMAs of 64: 2.67x less matrix time, and the bf16 matrix cores do not share the vector ALUs.
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
-typedef unsigned u32x2v __attribute__((ext_vector_type(2)));
 typedef unsigned u32x4v __attribute__((ext_vector_type(4)));
 
 __device__ __forceinline__ void bload3(f32x4 (&b)[3], unsigned voff, const float* sbase) {
@@ -638,74 +631,6 @@ __device__ __forceinline__ void split3_frag(const f32x4 a0, const f32x4 a1, f32x
     }
 }
 
-// One PAIR of xi steps of the split MFMA phase: the fp32 A fragments of the fp32 kernel (same V slab in LDS) split in registers, three
-// B fragments per xi (U split at pack time), six bf16 MFMAs per xi, smallest products first.  Two xi are interleaved because a
-// 32x32x16 bf16 MFMA issues every 32 cycles but its accumulator is only ready after ~64: one dependent chain ran the matrix pipe at
-// half rate (measured: 10 k cycles per slab with 3 k of MFMA work and neither B loads nor the split on the critical path).
-// B runs 6 xi (3 pair steps) ahead in the ring of 8 sets; NWAIT = 18 + the patch loads of the last 4 pair steps.
-template <int P, int G, int NWAIT>
-__device__ __forceinline__ void wino_imp_pair_split(f32x16& accx, f32x16& accy, f32x4 (&bq)[8][3], unsigned bvoff, const float* bpre_x,
-                                                    const float* bpre_y, const float* V, const int (&aoff)[2], f32x4 (&a_cur)[4],
-                                                    f32x4 (&a_nxt)[4], const float* const (&gsrc)[ILPW], long goff, float* rawbuf, int wave,
-                                                    int& gnext) {
-    typedef __attribute__((address_space(1))) const void gptr_t;
-    typedef __attribute__((address_space(3))) void lptr_t;
-    constexpr int XI = 2 * P;
-#ifndef LM_IABL_NOB
-    bload3(bq[(XI + 6) & 7], bvoff, bpre_x);
-    bload3(bq[(XI + 7) & 7], bvoff, bpre_y);
-#endif
-#ifndef LM_IABL_NOGLDS
-#pragma unroll
-    for (int g = 0; g < G; ++g) {
-        const int s_ = gnext + g;
-        __builtin_amdgcn_global_load_lds((gptr_t*)(gsrc[s_] + goff), (lptr_t*)(rawbuf + (s_ * 4 + wave) * 256), 16, 0, 0);
-    }
-#endif
-    gnext += G;
-    f32x4 (&bx)[3] = bq[XI & 7];
-    f32x4 (&by)[3] = bq[(XI + 1) & 7];
-    f32x4 px[3], py[3];
-#ifdef LM_IABL_NOXF
-    px[0] = a_cur[0]; px[1] = a_cur[1]; px[2] = a_cur[0];
-    py[0] = a_cur[2]; py[1] = a_cur[3]; py[2] = a_cur[2];
-#else
-    split3_frag(a_cur[0], a_cur[1], px);
-    split3_frag(a_cur[2], a_cur[3], py);
-#endif
-#if !defined(LM_IABL_NOB) && !defined(LM_IABL_NOGLDS)
-    bwait3<NWAIT>(bx);
-    bwait3<NWAIT>(by);
-#else
-    bwait3<0>(bx);
-    bwait3<0>(by);
-#endif
-#define LM_BF(x) __builtin_bit_cast(bf16x8, x)
-    accx = __builtin_amdgcn_mfma_f32_32x32x16_bf16(LM_BF(px[2]), LM_BF(bx[0]), accx, 0, 0, 0);       // v3 u1
-    accy = __builtin_amdgcn_mfma_f32_32x32x16_bf16(LM_BF(py[2]), LM_BF(by[0]), accy, 0, 0, 0);
-    __builtin_amdgcn_sched_barrier(0);
-    if (P < 7) {
-#pragma unroll
-        for (int k = 0; k < 2; ++k) {
-            a_nxt[k] = *reinterpret_cast<const f32x4*>(V + (XI + 2) * (IBM * IKS) + aoff[k]);
-            a_nxt[2 + k] = *reinterpret_cast<const f32x4*>(V + (XI + 3) * (IBM * IKS) + aoff[k]);
-        }
-    }
-    __builtin_amdgcn_sched_barrier(0);
-    accx = __builtin_amdgcn_mfma_f32_32x32x16_bf16(LM_BF(px[1]), LM_BF(bx[1]), accx, 0, 0, 0);       // v2 u2
-    accy = __builtin_amdgcn_mfma_f32_32x32x16_bf16(LM_BF(py[1]), LM_BF(by[1]), accy, 0, 0, 0);
-    accx = __builtin_amdgcn_mfma_f32_32x32x16_bf16(LM_BF(px[0]), LM_BF(bx[2]), accx, 0, 0, 0);       // v1 u3
-    accy = __builtin_amdgcn_mfma_f32_32x32x16_bf16(LM_BF(py[0]), LM_BF(by[2]), accy, 0, 0, 0);
-    accx = __builtin_amdgcn_mfma_f32_32x32x16_bf16(LM_BF(px[1]), LM_BF(bx[0]), accx, 0, 0, 0);       // v2 u1
-    accy = __builtin_amdgcn_mfma_f32_32x32x16_bf16(LM_BF(py[1]), LM_BF(by[0]), accy, 0, 0, 0);
-    accx = __builtin_amdgcn_mfma_f32_32x32x16_bf16(LM_BF(px[0]), LM_BF(bx[1]), accx, 0, 0, 0);       // v1 u2
-    accy = __builtin_amdgcn_mfma_f32_32x32x16_bf16(LM_BF(py[0]), LM_BF(by[1]), accy, 0, 0, 0);
-    accx = __builtin_amdgcn_mfma_f32_32x32x16_bf16(LM_BF(px[0]), LM_BF(bx[0]), accx, 0, 0, 0);       // v1 u1
-    accy = __builtin_amdgcn_mfma_f32_32x32x16_bf16(LM_BF(py[0]), LM_BF(by[0]), accy, 0, 0, 0);
-#undef LM_BF
-    __builtin_amdgcn_sched_barrier(0);
-}
-
 // TRANSFORM phase, one thread = (tile tl, channel quad qd): V[xi][tl][4 qd ..] = (B^T d B)[xi] with the arithmetic of transform_store
 // Packed fp32 adds for the transform phases (no MFMA is in flight there): v_pk_add_f32 does two lanes of a sum per issue slot; the
 // compiler selects it for a + b but turns a - b (and a + (-b)) into four scalar v_sub_f32, so the subtraction is spelled out with
@@ -728,29 +653,6 @@ __device__ __forceinline__ f32x4 pk_add4(const f32x4 a, const f32x4 b) {
     return __builtin_shufflevector(rlo, rhi, 0, 1, 2, 3);
 }
 
-template <int IROW>
-__device__ __forceinline__ void wino_slab_transform(const float* raw, float* V, const int (&roff)[4], int voff) {
-    f32x4 r[4][4];
-#pragma unroll
-    for (int c = 0; c < 4; ++c) {
-        const f32x4 d0 = *reinterpret_cast<const f32x4*>(raw + roff[c]);
-        const f32x4 d1 = *reinterpret_cast<const f32x4*>(raw + IROW + roff[c]);
-        const f32x4 d2 = *reinterpret_cast<const f32x4*>(raw + 2 * IROW + roff[c]);
-        const f32x4 d3 = *reinterpret_cast<const f32x4*>(raw + 3 * IROW + roff[c]);
-        r[0][c] = pk_sub4(d0, d2);
-        r[1][c] = pk_add4(d1, d2);
-        r[2][c] = pk_sub4(d2, d1);
-        r[3][c] = pk_sub4(d1, d3);
-    }
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        float* o = V + (4 * i) * (IBM * IKS) + voff;
-        *reinterpret_cast<f32x4*>(o) = pk_sub4(r[i][0], r[i][2]);
-        *reinterpret_cast<f32x4*>(o + IBM * IKS) = pk_add4(r[i][1], r[i][2]);
-        *reinterpret_cast<f32x4*>(o + 2 * IBM * IKS) = pk_sub4(r[i][2], r[i][1]);
-        *reinterpret_cast<f32x4*>(o + 3 * IBM * IKS) = pk_sub4(r[i][1], r[i][3]);
-    }
-}
 
 // One xi step of a slab's MFMA phase.  All VMEM traffic of a wave shares ONE in-order counter (vmcnt): waiting for this step's B
 // fragments also waits for every patch load (global_load_lds) issued before them, and those come from HBM (~2 us under load) while
@@ -815,330 +717,6 @@ __device__ unsigned long long g_iprof[IPROF_WG][12];   // [workgroup % IPROF_WG]
 #else
 #define LM_TICKE(slot)
 #endif
-
-// The 64 tiles x 64 channels geometry described at the top of this section, with the split-precision GEMM (the fp32 variants of this
-// kernel - 64 x 64 and the WIDE 32 x 128 one of round 2 - were superseded by wino_dual_kernel / wino_pipe_kernel and removed).
-__global__ __launch_bounds__(256) void wino_split_kernel(WinoImpParams p) {
-    constexpr int BM = IBM, BN = IBN, KS = IKS, NCOL = INCOL;
-    constexpr int CPC = KS / 4;                 // 16-byte chunks per cell (pixel x channel slab)
-    constexpr int CPL = 64 / CPC;               // cells per global_load_lds wave instruction
-#ifdef LM_IPROF
-    long long iprof[11] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
-    long long t_last = clock64();
-#endif
-    extern __shared__ __attribute__((aligned(16))) float smem[];      // raw patch slab [IRAW] | V slab [IVBUF] 
-    float* const rawbuf = smem;
-    float* const Vbuf = smem + IRAW;
-    typedef __attribute__((address_space(1))) const void gptr_t;
-    typedef __attribute__((address_space(3))) void lptr_t;
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wm0 = (wave >> 1) * 32, wn0 = (wave & 1) * 32;
-    const int n_tiles = (p.Cout + BN - 1) / BN;
-    // XCD-aware order (workgroups are dealt round-robin to the 8 XCDs): every XCD owns a contiguous range of M blocks and walks it
-    // once per N tile, N tile OUTER - at any time the 32 CUs of an XCD stream the SAME 64-channel slice of U (L2 resident)
-    unsigned mblk, ntile;
-    {
-        const unsigned bid = blockIdx.x, mb = gridDim.x / (unsigned)n_tiles, mbx = mb / 8, full = mbx * 8 * (unsigned)n_tiles;
-        if (bid < full) {
-            const unsigned xcd = bid % 8, idx = bid / 8;
-            ntile = idx / mbx;
-            mblk = xcd * mbx + idx % mbx;
-        } else {
-            const unsigned r = bid - full;
-            mblk = 8 * mbx + r / (unsigned)n_tiles;
-            ntile = r % (unsigned)n_tiles;
-        }
-    }
-    const long m0 = (long)mblk * BM;
-    const int n0 = (int)ntile * BN;
-    const WinoGeom& g = p.g;
-    const int bi = (int)(m0 / g.Tpad);
-    const int t0 = (int)(m0 - (long)bi * g.Tpad);
-    // runs of horizontally adjacent tiles (workgroup-uniform, scalar registers): first local tile ts, length sn, and per run the input
-    // pixel of patch cell (0, 0) (iy0, ix0: may be negative = padding), the output pixel of its first tile (oy0, ox0) and the first
-    // column slot q0.  A run past the last real tile of the image (padding rows of V) has sn = 0.
-    int ts[INSEG + 1], sn[INSEG], iy0[INSEG], ix0[INSEG], oy0[INSEG], ox0[INSEG];
-    {
-        int at = 0, t = t0;
-        int tx = t0 % g.Tx, rest = t0 / g.Tx;          // one decode (three divisions), then carries: a run ends at the end of a tile row
-        int ty = rest % g.Ty, ph = rest / g.Ty;
-        int pa = ph / g.dil, pb = ph - pa * g.dil;
-#pragma unroll
-        for (int s_ = 0; s_ < INSEG; ++s_) {
-            ts[s_] = at;
-            const bool real = t < g.Timg && at < BM;
-            const int n = at < BM ? min(BM - at, g.Tx - tx) : 0;
-            sn[s_] = real ? n : 0;
-            iy0[s_] = (2 * ty - 1) * g.dil + pa;
-            ix0[s_] = (2 * tx - 1) * g.dil + pb;
-            oy0[s_] = 2 * ty * g.dil + pa;
-            ox0[s_] = 2 * tx * g.dil + pb;
-            at += n;
-            t += n;
-            tx += n;
-            if (tx >= g.Tx) {
-                tx = 0;
-                if (++ty >= g.Ty) {
-                    ty = 0;
-                    if (++pb >= g.dil) {
-                        pb = 0;
-                        ++pa;
-                    }
-                }
-            }
-        }
-        ts[INSEG] = at;            // == BM (the launcher guarantees <= INSEG runs)
-    }
-    // --- per-lane sources of this wave's ILPW patch loads (one pointer each; the channel slab is a uniform offset)
-    const float* gsrc[ILPW];
-    const int img_pix0 = bi * g.H * g.W;
-#pragma unroll
-    for (int s_ = 0; s_ < ILPW; ++s_) {
-        const int pos = (s_ * 4 + wave) * CPL + lane / CPC;            // LDS cell position (CPL cells per wave load)
-        const int r = pos / NCOL;
-        const int q = unrot3(pos - r * NCOL);
-        const int ch = lane % CPC;
-        int n = sn[0], yb = iy0[0], xb = ix0[0], q0 = 0;
-#pragma unroll
-        for (int k = 1; k < INSEG; ++k)
-            if (q >= 2 * ts[k] + 2 * k) {                              // (runs are in slot order: the last match wins)
-                n = sn[k]; yb = iy0[k]; xb = ix0[k]; q0 = 2 * ts[k] + 2 * k;
-            }
-        const int lc = q - q0;
-        const int yy = yb + r * g.dil, xx = xb + lc * g.dil;
-        const bool ok = r < 4 && lc < 2 * n + 2 && n > 0 && (unsigned)yy < (unsigned)g.H && (unsigned)xx < (unsigned)g.W;
-        gsrc[s_] = ok ? p.x + (long)(img_pix0 + yy * g.W + xx) * p.ldx + ch * 4 : p.zeros + ch * 4;
-    }
-    // --- TRANSFORM task of this thread: tile tid / CPC, channel quad tid % CPC
-    // (the 8 quads of a tile fill one 128-byte row: conflict-free stores; the 16 rows of an A-fragment read group differ in
-    // (tile & 1, (tile >> 1) & 7): all 64 banks)
-    int roff[4], tvoff;
-    {
-        const int tl = tid / CPC, qd = tid % CPC;
-        int sg = 0;
-#pragma unroll
-        for (int k = 1; k < INSEG; ++k) sg += (ts[k] < BM && tl >= ts[k]) ? 1 : 0;
-        const int cb = 2 * tl + 2 * sg;
-#pragma unroll
-        for (int c = 0; c < 4; ++c) roff[c] = (rot3(cb + c) * CPC + qd) * 4;
-        tvoff = (tl * 4 + (qd ^ ((tl >> 2) & 3))) * 4;
-    }
-    // --- MFMA-phase A fragment offsets inside V[xi]: row = tile wm0 + frow, chunk 2 kk + fhalf
-    const int frow = lane & 31, fhalf = lane >> 5;
-    int aoff[2];
-    {
-        const int tl = wm0 + frow;
-#pragma unroll
-        for (int kk = 0; kk < 2; ++kk) aoff[kk] = (tl * 4 + ((2 * kk + fhalf) ^ ((tl >> 2) & 3))) * 4;
-    }
-    const int cslabs = p.C / KS;
-    const unsigned bvoff = (unsigned)lane * 16u;
-    constexpr int BFRAG = 768;                                         // floats per (xi, slab, 32-channel tile): 3 planes x 64 x 16 B
-    const long bstep = (long)p.NT * BFRAG;                             // floats between consecutive 16-channel slabs of one xi
-    const float* const bbase = p.U + (long)((n0 + wn0) >> 5) * BFRAG;  // this wave's 32-channel tile
-    const long bxi = (long)(p.C / IKS) * bstep;                        // floats between consecutive xi
-
-    f32x16 acc[16];
-#pragma unroll
-    for (int k = 0; k < 16; ++k)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) acc[k][r] = 0.f;
-#if defined(LM_IPROF) && !defined(LM_IPROF_EPI)
-    LM_TICK(7)                                  // (index setup; slot 0 = the prologue's loads)
-#endif
-    {
-    f32x4 bq3[8][3];
-#pragma unroll
-    for (int s_ = 0; s_ < ILPW; ++s_)
-        __builtin_amdgcn_global_load_lds((gptr_t*)gsrc[s_], (lptr_t*)(rawbuf + (s_ * 4 + wave) * 256), 16, 0, 0);
-#pragma unroll
-    for (int k = 0; k < 6; ++k) bload3(bq3[k], bvoff, bbase + (long)k * bxi);
-#pragma unroll
-    for (int k = 0; k < 6; ++k) bwait3<0>(bq3[k]);
-    __builtin_amdgcn_s_barrier();
-    LM_TICK(0)
-    for (int cs = 0; cs < cslabs; ++cs) {
-#ifndef LM_IABL_NOTF
-        wino_slab_transform<NCOL * KS>(rawbuf, Vbuf, roff, tvoff);
-#endif
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        LM_TICK(1)
-        __builtin_amdgcn_s_barrier();
-        LM_TICK(2)
-        const bool more = cs + 1 < cslabs;
-        const long goff = more ? (long)(cs + 1) * KS : 0;
-        const float* const bs = bbase + (long)cs * bstep;
-        const float* const bs_next = bbase + (long)(more ? cs + 1 : 0) * bstep;
-        int gnext = 0;
-        f32x4 a0[4], a1[4];
-#pragma unroll
-        for (int k = 0; k < 2; ++k) {
-            a0[k] = *reinterpret_cast<const f32x4*>(Vbuf + aoff[k]);
-            a0[2 + k] = *reinterpret_cast<const f32x4*>(Vbuf + (IBM * IKS) + aoff[k]);
-        }
-        // B prefetched by pair step P belongs to xi 2P + 6 and 2P + 7: same slab while < 16, else xi - 16 of the next slab
-#define LM_BPRE(X) ((X) < 16 ? bs + (long)(X) * bxi : bs_next + (long)((X) - 16) * bxi)
-#define LM_SPAIR(P, G, NW, AC, AN) \
-        wino_imp_pair_split<P, G, NW>(acc[2 * (P)], acc[2 * (P) + 1], bq3, bvoff, LM_BPRE(2 * (P) + 6), LM_BPRE(2 * (P) + 7), Vbuf, aoff, AC, AN, \
-                                      gsrc, goff, rawbuf, wave, gnext)
-        // NWAIT = 3 pair steps x 6 B loads + the patch loads of the last 4 pair steps (G = 4, 4, 1)
-        LM_SPAIR(0, 4, 22, a0, a1);
-        LM_SPAIR(1, 4, 26, a1, a0);
-        LM_SPAIR(2, 1, 27, a0, a1);
-        LM_SPAIR(3, 0, 27, a1, a0);
-        LM_SPAIR(4, 0, 23, a0, a1);
-        LM_SPAIR(5, 0, 19, a1, a0);
-        LM_SPAIR(6, 0, 18, a0, a1);
-        LM_SPAIR(7, 0, 18, a1, a0);
-#undef LM_SPAIR
-#undef LM_BPRE
-        LM_TICK(3)
-        bwait3<18>(bq3[0]);
-        LM_TICK(4)
-        __builtin_amdgcn_s_barrier();
-        LM_TICK(5)
-    }
-#pragma unroll
-    for (int k = 0; k < 8; ++k) bwait3<0>(bq3[k]);
-
-    }
-#ifdef LM_IABL_NOEPI
-    {   // timing ablation: no fold / transposes / stores; one value per thread keeps the accumulators live
-        float sum = 0.f;
-#pragma unroll
-        for (int k = 0; k < 16; ++k)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) sum += acc[k][r];
-        p.y[(long)blockIdx.x * 256 + tid] = sum;
-        return;
-    }
-#endif
-    // --- epilogue: fold the 16 products into the 2x2 outputs (ascending xi, exact +-1 coefficients), one output position at a time;
-    // the wave tile is transposed through LDS (wave-private staging) so that stores are 16-byte channel vectors
-    constexpr int ELD = 32 + 4;
-    float* stage = smem + wave * (32 * ELD);
-    constexpr int LPR = 8, RPI = 8, NP = 4;
-    const int c4 = (lane & 7) * 4;
-    const int n = n0 + wn0 + c4;
-    f32x4 sc = {1.f, 1.f, 1.f, 1.f}, sh = {0.f, 0.f, 0.f, 0.f};
-    if (n < p.Cout) {
-#pragma unroll
-        for (int e = 0; e < 4; ++e)
-            if (n + e < p.Cout) {
-                if (p.scale) sc[e] = p.scale[n + e];
-                if (p.shift) sh[e] = p.shift[n + e];
-            }
-    }
-    const bool vec = (n + 3 < p.Cout) && ((p.ldy & 3) == 0) && (!p.res || (p.ldr & 3) == 0);
-    f32x4 gs = {0.f, 0.f, 0.f, 0.f}, gq = {0.f, 0.f, 0.f, 0.f};
-    int pix0[NP];
-    unsigned vmask = 0;                                // 3 bits per row: tile exists | a = 1 inside | b = 1 inside
-#pragma unroll
-    for (int pass = 0; pass < NP; ++pass) {            // output pixel of the rows this lane stores, from the run table
-        const int tl = wm0 + pass * RPI + lane / LPR;
-        int n = sn[0], oy = oy0[0], oxb = ox0[0], tb = 0;
-#pragma unroll
-        for (int k = 1; k < INSEG; ++k)
-            if (tl >= ts[k]) {
-                n = sn[k]; oy = oy0[k]; oxb = ox0[k]; tb = ts[k];
-            }
-        const int ox = oxb + 2 * (tl - tb) * g.dil;
-        pix0[pass] = img_pix0 + oy * g.W + ox;
-        if (n > 0 && oy < g.H && ox < g.W)
-            vmask |= (1u | (oy + g.dil < g.H ? 2u : 0u) | (ox + g.dil < g.W ? 4u : 0u)) << (3 * pass);
-    }
-    const int step_a = g.dil * g.W, step_b = g.dil;
-    __syncthreads();                                   // every wave is done with the patch buffers
-    LM_TICKE(7)                                        // (epilogue setup)
-#pragma unroll
-    for (int a = 0; a < 2; ++a)
-#pragma unroll
-        for (int b = 0; b < 2; ++b) {
-            f32x16 o;
-#pragma unroll
-            for (int r = 0; r < 16; ++r) o[r] = 0.f;
-#pragma unroll
-            for (int xi = 0; xi < 16; ++xi) {
-                const int wi = xi >> 2, wj = xi & 3;
-                const float ca = a == 0 ? (wi < 3 ? 1.f : 0.f) : (wi == 0 ? 0.f : (wi == 1 ? 1.f : -1.f));
-                const float cb = b == 0 ? (wj < 3 ? 1.f : 0.f) : (wj == 0 ? 0.f : (wj == 1 ? 1.f : -1.f));
-                const float c = ca * cb;
-                if (c == 0.f) continue;
-#pragma unroll
-                for (int r = 0; r < 16; ++r) o[r] = fmaf(acc[xi][r], c, o[r]);
-            }
-            __builtin_amdgcn_wave_barrier();
-            LM_TICKE(8)                                // (fold)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) stage[((r & 3) + 8 * (r >> 2) + 4 * fhalf) * ELD + frow] = o[r];
-            __builtin_amdgcn_wave_barrier();
-            LM_TICKE(9)                                // (transpose writes)
-            if (n >= p.Cout) continue;
-#pragma unroll
-            for (int pass = 0; pass < NP; ++pass) {
-                const int row = pass * RPI + lane / LPR;
-                const unsigned vm = vmask >> (3 * pass);
-                if (!(vm & 1u) || (a && !(vm & 2u)) || (b && !(vm & 4u))) continue;
-                const long pix = pix0[pass] + a * step_a + b * step_b;
-                f32x4 v = *reinterpret_cast<const f32x4*>(stage + row * ELD + c4);
-#pragma unroll
-                for (int e = 0; e < 4; ++e) v[e] = p.scale ? v[e] * sc[e] + sh[e] : v[e] + sh[e];
-                if (p.gn_part) {
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        gs[e] += v[e];
-                        gq[e] = fmaf(v[e], v[e], gq[e]);
-                    }
-                }
-                if (vec) {
-                    if (p.res) {
-                        const f32x4 rr = *reinterpret_cast<const f32x4*>(p.res + pix * p.ldr + n);
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) v[e] += rr[e];
-                    }
-                    if (p.act == LM_ACT_RELU) {
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
-                    }
-                    *reinterpret_cast<f32x4*>(p.y + pix * p.ldy + n) = v;
-                } else {
-                    for (int e = 0; e < 4 && n + e < p.Cout; ++e) {
-                        float u = v[e];
-                        if (p.res) u += p.res[pix * p.ldr + n + e];
-                        if (p.act == LM_ACT_RELU) u = fmaxf(u, 0.f);
-                        p.y[pix * p.ldy + n + e] = u;
-                    }
-                }
-            }
-            LM_TICKE(10)                               // (stores)
-        }
-    if (p.gn_part && n < p.Cout) {   // fixed-order reduction over the 8 lanes that share a channel quad, then one writer lane
-#pragma unroll
-        for (int o = LPR; o < 64; o <<= 1)
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                gs[e] += __shfl_xor(gs[e], o);
-                gq[e] += __shfl_xor(gq[e], o);
-            }
-        if (lane < LPR) {
-            const long chunk = (t0 + wm0) / 32;                     // 32-tile chunk of this wave tile inside image bi
-            double* o = p.gn_part + (((long)bi * (g.Tpad / 32) + chunk) * p.Cout + n) * 2;
-            for (int e = 0; e < 4 && n + e < p.Cout; ++e) {
-                o[2 * e] = (double)gs[e];
-                o[2 * e + 1] = (double)gq[e];
-            }
-        }
-    }
-#ifdef LM_IPROF
-    LM_TICK(6)
-    if (tid == 0) {
-#pragma unroll
-        for (int k = 0; k < 11; ++k) g_iprof[blockIdx.x % IPROF_WG][k] = (unsigned long long)iprof[k];
-        g_iprof[blockIdx.x % IPROF_WG][11] = 1ull;
-    }
-#endif
-}
 
 // =====================================================================================================================================
 // DUAL geometry (round 2, third version): TWO workgroups per CU.  With sixteen accumulators per wave (512 registers) a CU holds one
@@ -1816,319 +1394,6 @@ __global__ __launch_bounds__(256) void wino_pipe_kernel(WinoImpParams p) {
 }
 
 // =====================================================================================================================================
-// PIPE geometry, split-precision GEMM (opt-in, LANEMAP_WINO_BF16X3=1; replaces the 64 x 64 split kernel of round 2).  Same workgroup,
-// same slots as wino_pipe_kernel, but the products run on the bf16 matrix cores: every fp32 operand is split EXACTLY into three bf16
-// pieces (v = v1 + v2 + v3 by truncation, 8 + 8 + 8 significant bits; U at weight-packing time) and six of the nine piece products are
-// accumulated in fp32, smallest first (error of a product <= 2^-23: the class of an fp32 rounding - profiles/r2_split_precision_study.txt).
-// What round 2's version lost its 2.67x less matrix time to - splitting every A fragment in registers, per wave and per N tile (44 VALU
-// per xi) - is gone: V is split ONCE, by the transform, and stored in LDS as bf16 pieces in the MFMA's own operand order:
-//   Vp[buffer][xi][piece][tile][16 channels as 2 chunks of 8 bf16]  (chunk g = channels 4g..4g+3 and 8+4g..8+4g+3: the k order of lane half g,
-//   which is also the order pack_wino_fragments_bf16x3 gives the U pieces), 3 KB per xi, 48 KB per half-slab buffer;
-// an A piece is one conflict-free ds_read_b128 per lane.  Six 32x32x16 bf16 MFMAs (32 cycles each) per xi and half-slab replace eight
-// f32 MFMAs (64 cycles); two xi are interleaved (a dependent bf16 MFMA chain issues at half rate).  The B pieces (3 KB per wave and xi)
-// come global -> registers six xi ahead in a ring of 8 sets: 192 KB per slot and CU = 62 B/clk at full matrix speed against the 64 the
-// vector memory path delivers - this kernel is bound by its B traffic, not by the matrix pipe.
-// Results are NOT bit-identical to the fp32 kernels (different products, same order of magnitude of error); `dtype` of a run with it is
-// bf16x3 and its roofline the bf16 peak.
-constexpr int SVH = 16 * 3 * PBM * 8;             // floats of one V half-slab buffer of bf16 pieces: 16 xi x 3 pieces x 32 tiles x 32 B = 48 KB
-
-// three bf16 pieces of four fp32 values, each piece packed as 4 bf16 = 2 dwords (channel c in the low half of dword c / 2)
-__device__ __forceinline__ void split3_quad(const f32x4 v, u32x2v (&piece)[3]) {
-    float r[4] = {v[0], v[1], v[2], v[3]};
-#pragma unroll
-    for (int k = 0; k < 3; ++k) {
-        piece[k][0] = pack_hi(r[0], r[1]);
-        piece[k][1] = pack_hi(r[2], r[3]);
-        if (k < 2) {
-#pragma unroll
-            for (int e = 0; e < 4; ++e) r[e] = r[e] - __uint_as_float(__float_as_uint(r[e]) & 0xFFFF0000u);      // exact
-        }
-    }
-}
-
-// This thread's share of a half-slab transform (see wino_pipe_xf: (tile, channel quad, row pair)), with the split: eight planes x three
-// pieces x 8 bytes, in pieces that ride behind the MFMAs of the pair steps.  Plain (unpacked) fp32 VALU on purpose: up to four single-rate
-// VALU instructions per bf16 MFMA issue for free in the same wave, a v_pk_*_f32 costs ~10 cycles of matrix time each
-// (tools/probes/split_probe.hip).  vbyte = byte offset of (tile, quad) inside a piece plane.
-struct SplitRows {
-    f32x4 ra[4], rb[4];
-};
-
-__device__ __forceinline__ void wino_split_rows(const float* raw, const int (&roff)[4], int o0, int o1, int o2, float sb, SplitRows& t) {
-#pragma unroll
-    for (int c = 0; c < 4; ++c) {
-        const f32x4 d0 = *reinterpret_cast<const f32x4*>(raw + o0 + roff[c]);
-        const f32x4 d1 = *reinterpret_cast<const f32x4*>(raw + o1 + roff[c]);
-        const f32x4 d2 = *reinterpret_cast<const f32x4*>(raw + o2 + roff[c]);
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            t.ra[c][e] = d0[e] - d1[e];
-            t.rb[c][e] = fmaf(d2[e], sb, d1[e]);
-        }
-    }
-}
-
-template <int K>
-__device__ __forceinline__ void wino_split_plane(const SplitRows& t, float* Vp, int plane0, int vbyte) {
-    const f32x4 (&r)[4] = K < 4 ? t.ra : t.rb;
-    constexpr int j = K & 3;
-    float v[4];
-#pragma unroll
-    for (int e = 0; e < 4; ++e) v[e] = j == 0 ? r[0][e] - r[2][e] : j == 1 ? r[1][e] + r[2][e] : j == 2 ? r[2][e] - r[1][e] : r[1][e] - r[3][e];
-    char* base = reinterpret_cast<char*>(Vp) + (plane0 + K) * 3072 + vbyte;
-#pragma unroll
-    for (int q = 0; q < 3; ++q) {
-        u32x2v pc;
-        pc[0] = pack_hi(v[0], v[1]);
-        pc[1] = pack_hi(v[2], v[3]);
-        *reinterpret_cast<u32x2v*>(base + q * 1024) = pc;
-        if (q < 2) {
-#pragma unroll
-            for (int e = 0; e < 4; ++e) v[e] = v[e] - __uint_as_float(__float_as_uint(v[e]) & 0xFFFF0000u);      // exact
-        }
-    }
-}
-
-__device__ __forceinline__ void wino_split_transform(const float* raw, float* Vp, const int (&roff)[4], int o0, int o1, int o2, float sb,
-                                                     int plane0, int vbyte) {
-    SplitRows t;
-    wino_split_rows(raw, roff, o0, o1, o2, sb, t);
-    wino_split_plane<0>(t, Vp, plane0, vbyte); wino_split_plane<1>(t, Vp, plane0, vbyte); wino_split_plane<2>(t, Vp, plane0, vbyte);
-    wino_split_plane<3>(t, Vp, plane0, vbyte); wino_split_plane<4>(t, Vp, plane0, vbyte); wino_split_plane<5>(t, Vp, plane0, vbyte);
-    wino_split_plane<6>(t, Vp, plane0, vbyte); wino_split_plane<7>(t, Vp, plane0, vbyte);
-}
-
-// One PAIR of xi steps (xi = 2P, 2P + 1) of a slot: 12 bf16 MFMAs; the B pieces of xi 2P + 6 / 2P + 7 are requested, the slot's PLPW
-// patch loads go out in pair steps 0 .. PLPW-1, the A pieces of the next pair are read behind the first two MFMAs.
-template <int P, int NWAIT>
-__device__ __forceinline__ void wino_split_pair(f32x16& accx, f32x16& accy, f32x4 (&bq)[8][3], unsigned bvoff, const float* bpre_x,
-                                                const float* bpre_y, const float* Vp, int aoff, f32x4 (&a_cur)[6], f32x4 (&a_nxt)[6],
-                                                const float* const (&gsrc)[PLPW], long goff, float* rawld, int wave, SplitRows& xt,
-                                                const float* xraw, float* xVp, const int (&roff)[4], int xo0, int xo1, int xo2, float xsb,
-                                                int xplane0, int xvbyte) {
-    typedef __attribute__((address_space(1))) const void gptr_t;
-    typedef __attribute__((address_space(3))) void lptr_t;
-    constexpr int XI = 2 * P;
-#ifndef LM_SABL_NOB
-    bload3(bq[(XI + 6) & 7], bvoff, bpre_x);
-    bload3(bq[(XI + 7) & 7], bvoff, bpre_y);
-#endif
-    if constexpr (P < PLPW)
-        __builtin_amdgcn_global_load_lds((gptr_t*)(gsrc[P] + goff), (lptr_t*)(rawld + (P * 4 + wave) * 256), 16, 0, 0);
-    f32x4 (&bx)[3] = bq[XI & 7];
-    f32x4 (&by)[3] = bq[(XI + 1) & 7];
-#ifndef LM_SABL_NOB
-    bwait3<NWAIT>(bx);
-    bwait3<NWAIT>(by);
-#else
-    bwait3<0>(bx);
-    bwait3<0>(by);
-#endif
-#define LM_BF(x) __builtin_bit_cast(bf16x8, x)
-    accx = __builtin_amdgcn_mfma_f32_32x32x16_bf16(LM_BF(a_cur[2]), LM_BF(bx[0]), accx, 0, 0, 0);       // v3 u1
-    accy = __builtin_amdgcn_mfma_f32_32x32x16_bf16(LM_BF(a_cur[5]), LM_BF(by[0]), accy, 0, 0, 0);
-    __builtin_amdgcn_sched_barrier(0);
-    if constexpr (P < 7) {
-#pragma unroll
-        for (int q = 0; q < 3; ++q) {
-            a_nxt[q] = *reinterpret_cast<const f32x4*>(Vp + (XI + 2) * 768 + q * 256 + aoff);
-            a_nxt[3 + q] = *reinterpret_cast<const f32x4*>(Vp + (XI + 3) * 768 + q * 256 + aoff);
-        }
-    }
-    __builtin_amdgcn_sched_barrier(0);
-    // the transform piece of this pair step (half-slab h + 1): the row pass in step 0, plane P in every step; the scheduler may spread
-    // it over the remaining ten MFMAs (groups: 1 MFMA, then up to 4 VALU / 1 LDS)
-#ifndef LM_SABL_NOT
-    if constexpr (P == 0) wino_split_rows(xraw, roff, xo0, xo1, xo2, xsb, xt);
-    wino_split_plane<P>(xt, xVp, xplane0, xvbyte);
-#endif
-    accx = __builtin_amdgcn_mfma_f32_32x32x16_bf16(LM_BF(a_cur[1]), LM_BF(bx[1]), accx, 0, 0, 0);       // v2 u2
-    accy = __builtin_amdgcn_mfma_f32_32x32x16_bf16(LM_BF(a_cur[4]), LM_BF(by[1]), accy, 0, 0, 0);
-    accx = __builtin_amdgcn_mfma_f32_32x32x16_bf16(LM_BF(a_cur[0]), LM_BF(bx[2]), accx, 0, 0, 0);       // v1 u3
-    accy = __builtin_amdgcn_mfma_f32_32x32x16_bf16(LM_BF(a_cur[3]), LM_BF(by[2]), accy, 0, 0, 0);
-    accx = __builtin_amdgcn_mfma_f32_32x32x16_bf16(LM_BF(a_cur[1]), LM_BF(bx[0]), accx, 0, 0, 0);       // v2 u1
-    accy = __builtin_amdgcn_mfma_f32_32x32x16_bf16(LM_BF(a_cur[4]), LM_BF(by[0]), accy, 0, 0, 0);
-    accx = __builtin_amdgcn_mfma_f32_32x32x16_bf16(LM_BF(a_cur[0]), LM_BF(bx[1]), accx, 0, 0, 0);       // v1 u2
-    accy = __builtin_amdgcn_mfma_f32_32x32x16_bf16(LM_BF(a_cur[3]), LM_BF(by[1]), accy, 0, 0, 0);
-    accx = __builtin_amdgcn_mfma_f32_32x32x16_bf16(LM_BF(a_cur[0]), LM_BF(bx[0]), accx, 0, 0, 0);       // v1 u1
-    accy = __builtin_amdgcn_mfma_f32_32x32x16_bf16(LM_BF(a_cur[3]), LM_BF(by[0]), accy, 0, 0, 0);
-#undef LM_BF
-#pragma unroll
-    for (int k = 0; k < 10; ++k) {
-        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);      // one MFMA
-        __builtin_amdgcn_sched_group_barrier(0x002, P == 0 ? 7 : 4, 0);      // VALU
-        __builtin_amdgcn_sched_group_barrier(0x300, P == 0 ? 2 : 1, 0);      // DS read / write
-    }
-    __builtin_amdgcn_sched_barrier(0);
-}
-
-__global__ __launch_bounds__(256) void wino_pipe_split_kernel(WinoImpParams p) {
-    extern __shared__ __attribute__((aligned(16))) float smem[];      // raw[2][PRAWH] | Vp[2][SVH]
-    float* const raw0 = smem;
-    float* const V0 = smem + 2 * PRAWH;
-    typedef __attribute__((address_space(1))) const void gptr_t;
-    typedef __attribute__((address_space(3))) void lptr_t;
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wn0 = wave * 32;
-    const int n_tiles = (p.Cout + PBN - 1) / PBN;
-    unsigned mblk, ntile;
-    {   // XCD-aware order, N tile outer (see wino_pipe_kernel)
-        const unsigned bid = blockIdx.x, mb = gridDim.x / (unsigned)n_tiles, mbx = mb / 8, full = mbx * 8 * (unsigned)n_tiles;
-        if (bid < full) {
-            const unsigned xcd = bid % 8, idx = bid / 8;
-            ntile = idx / mbx;
-            mblk = xcd * mbx + idx % mbx;
-        } else {
-            const unsigned r = bid - full;
-            mblk = 8 * mbx + r / (unsigned)n_tiles;
-            ntile = r % (unsigned)n_tiles;
-        }
-    }
-    const long m0 = (long)mblk * PBM;
-    const int n0 = (int)ntile * PBN;
-    const WinoGeom& g = p.g;
-    const int bi = (int)(m0 / g.Tpad);
-    const int t0 = (int)(m0 - (long)bi * g.Tpad);
-    int ts[INSEG + 1], sn[INSEG], iy0[INSEG], ix0[INSEG], oy0[INSEG], ox0[INSEG];      // run table (see wino_implicit_kernel)
-    {
-        int at = 0, t = t0;
-        int tx = t0 % g.Tx, rest = t0 / g.Tx;
-        int ty = rest % g.Ty, ph = rest / g.Ty;
-        int pa = ph / g.dil, pb = ph - pa * g.dil;
-#pragma unroll
-        for (int s_ = 0; s_ < INSEG; ++s_) {
-            ts[s_] = at;
-            const bool real = t < g.Timg && at < PBM;
-            const int n = at < PBM ? min(PBM - at, g.Tx - tx) : 0;
-            sn[s_] = real ? n : 0;
-            iy0[s_] = (2 * ty - 1) * g.dil + pa;
-            ix0[s_] = (2 * tx - 1) * g.dil + pb;
-            oy0[s_] = 2 * ty * g.dil + pa;
-            ox0[s_] = 2 * tx * g.dil + pb;
-            at += n;
-            t += n;
-            tx += n;
-            if (tx >= g.Tx) {
-                tx = 0;
-                if (++ty >= g.Ty) {
-                    ty = 0;
-                    if (++pb >= g.dil) {
-                        pb = 0;
-                        ++pa;
-                    }
-                }
-            }
-        }
-        ts[INSEG] = at;
-    }
-    const float* gsrc[PLPW];
-    const int img_pix0 = bi * g.H * g.W;
-#pragma unroll
-    for (int s_ = 0; s_ < PLPW; ++s_) {
-        const int pos = (s_ * 4 + wave) * 16 + (lane >> 2);           // LDS cell position (16 cells of 64 B per wave load)
-        const int r = pos / PNCOL;
-        const int q = unrot3(pos - r * PNCOL);
-        const int ch = lane & 3;
-        int n = sn[0], yb = iy0[0], xb = ix0[0], q0 = 0;
-#pragma unroll
-        for (int k = 1; k < INSEG; ++k)
-            if (q >= 2 * ts[k] + 2 * k) {
-                n = sn[k]; yb = iy0[k]; xb = ix0[k]; q0 = 2 * ts[k] + 2 * k;
-            }
-        const int lc = q - q0;
-        const int yy = yb + r * g.dil, xx = xb + lc * g.dil;
-        const bool ok = r < 4 && lc < 2 * n + 2 && n > 0 && (unsigned)yy < (unsigned)g.H && (unsigned)xx < (unsigned)g.W;
-        gsrc[s_] = ok ? p.x + (long)(img_pix0 + yy * g.W + xx) * p.ldx + ch * 4 : p.zeros + ch * 4;
-    }
-    // transform share: tile (tid & 127) >> 2, channel quad tid & 3, row pair ih = wave >> 1
-    int roff[4], xo0, xo1, xo2, tplane0, tvbyte;
-    float xsb;
-    {
-        const int ih = wave >> 1;
-        const int tl = (tid & 127) >> 2, qd = tid & 3;
-        int sg = 0;
-#pragma unroll
-        for (int k = 1; k < INSEG; ++k) sg += (ts[k] < PBM && tl >= ts[k]) ? 1 : 0;
-        const int cb = 2 * tl + 2 * sg;
-#pragma unroll
-        for (int c = 0; c < 4; ++c) roff[c] = (rot3(cb + c) * 4 + qd) * 4;
-        tplane0 = 8 * ih;
-        tvbyte = tl * 32 + (qd & 1) * 16 + (qd >> 1) * 8;          // chunk (qd & 1) = lane half, second 8 bytes for channels 8..15
-        constexpr int ROWF = PNCOL * PKS;
-        xo0 = (ih == 0 ? 0 : 2) * ROWF;
-        xo1 = (ih == 0 ? 2 : 1) * ROWF;
-        xo2 = (ih == 0 ? 1 : 3) * ROWF;
-        const float sbv = ih == 0 ? 1.f : -1.f;
-        xsb = sbv;
-    }
-    const int frow = lane & 31, fhalf = lane >> 5;
-    const int aoff = frow * 8 + fhalf * 4;             // floats inside a piece plane: tile row of 32 B, chunk = lane half
-    const int H = p.C / PKS;                           // half-slabs (slots)
-    const unsigned bvoff = (unsigned)lane * 16u;
-    const long bstep = (long)p.NT * 768;               // floats between consecutive 16-channel slabs of one xi (3 pieces x 64 lanes x 16 B)
-    const long bxi = (long)H * bstep;
-    const float* const bbase = p.U + (long)((n0 + wn0) >> 5) * 768;
-
-    f32x16 acc[16];
-#pragma unroll
-    for (int k = 0; k < 16; ++k)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) acc[k][r] = 0.f;
-    f32x4 bq3[8][3];
-    // prologue: raw half-slabs 0 and 1, B of xi 0 .. 5 of slot 0, Vp of half-slab 0
-#pragma unroll
-    for (int s_ = 0; s_ < PLPW; ++s_)
-        __builtin_amdgcn_global_load_lds((gptr_t*)gsrc[s_], (lptr_t*)(raw0 + (s_ * 4 + wave) * 256), 16, 0, 0);
-#pragma unroll
-    for (int s_ = 0; s_ < PLPW; ++s_)
-        __builtin_amdgcn_global_load_lds((gptr_t*)(gsrc[s_] + PKS), (lptr_t*)(raw0 + PRAWH + (s_ * 4 + wave) * 256), 16, 0, 0);
-#pragma unroll
-    for (int k = 0; k < 6; ++k) bload3(bq3[k], bvoff, bbase + (long)k * bxi);
-#pragma unroll
-    for (int k = 0; k < 6; ++k) bwait3<0>(bq3[k]);
-    __builtin_amdgcn_s_barrier();
-    wino_split_transform(raw0, V0, roff, xo0, xo1, xo2, xsb, tplane0, tvbyte);
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();
-    SplitRows xt;
-    for (int h = 0; h < H; ++h) {
-        const int par = h & 1;
-        // the transform + split of half-slab h + 1 rides in the pair steps (past the last one: stale data into a buffer nobody reads)
-        const float* const xraw = raw0 + (par ^ 1) * PRAWH;
-        float* const xVp = V0 + (par ^ 1) * SVH;
-        float* const rawld = raw0 + par * PRAWH;                                           // raw(h + 2) replaces raw(h)
-        const float* const Vp = V0 + par * SVH;
-        const long goff = h + 2 < H ? (long)(h + 2) * PKS : 0;
-        const float* const bs = bbase + (long)h * bstep;
-        const float* const bs_next = bbase + (long)(h + 1 < H ? h + 1 : 0) * bstep;
-        f32x4 a0[6], a1[6];
-#pragma unroll
-        for (int q = 0; q < 3; ++q) {
-            a0[q] = *reinterpret_cast<const f32x4*>(Vp + q * 256 + aoff);
-            a0[3 + q] = *reinterpret_cast<const f32x4*>(Vp + 768 + q * 256 + aoff);
-        }
-#define LM_BPRE(X) ((X) < 16 ? bs + (long)(X) * bxi : bs_next + (long)((X) - 16) * bxi)
-#define LM_SPAIR(P, NW, AC, AN) \
-        wino_split_pair<P, NW>(acc[2 * (P)], acc[2 * (P) + 1], bq3, bvoff, LM_BPRE(2 * (P) + 6), LM_BPRE(2 * (P) + 7), Vp, aoff, AC, AN, gsrc, goff, \
-                               rawld, wave, xt, xraw, xVp, roff, xo0, xo1, xo2, xsb, tplane0, tvbyte)
-        // NWAIT = 3 pair steps x 6 B loads + the patch loads of the last four pair steps (pair steps 0 .. 4 issue one each)
-        LM_SPAIR(0, 19, a0, a1); LM_SPAIR(1, 20, a1, a0); LM_SPAIR(2, 21, a0, a1); LM_SPAIR(3, 22, a1, a0);
-        LM_SPAIR(4, 22, a0, a1); LM_SPAIR(5, 21, a1, a0); LM_SPAIR(6, 20, a0, a1); LM_SPAIR(7, 19, a1, a0);
-#undef LM_SPAIR
-#undef LM_BPRE
-        static_assert(PLPW == 5, "NWAIT table above");
-        bwait3<18>(bq3[0]);                    // this wave's patch loads (pair steps 0 .. 4) have landed: only the B loads of pair steps 5 .. 7 are younger
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();          // Vp(h + 1) complete, Vp(h) and raw(h + 1) free, raw(h + 2) landed
-    }
-#pragma unroll
-    for (int k = 0; k < 8; ++k) bwait3<0>(bq3[k]);
-
-#include "wino_pipe_epilogue.h"
-}
-
-// =====================================================================================================================================
 // ROWS geometry of the split-precision GEMM: 64 tiles x 64 channels per workgroup, wave w owns the four Winograd products of ROW w of the
 // 4 x 4 transform (xi = 4w .. 4w + 3) for the whole block - 4 xi x 2 tile halves x 2 channel halves = 16 accumulator blocks.
 // Why: wino_pipe_split_kernel pulls 192 KB of B pieces per slot and CU = 62 B/clk at full matrix speed; the vector memory path sustains
@@ -2167,7 +1432,7 @@ __device__ __forceinline__ void wino_rows_rowpass(const float* raw, const int (&
         }
 }
 
-// column pass J of the row + split into the three A pieces (52 VALU)
+// column pass J of the row + split into the three A pieces (52 VALU) - the prologue's version
 template <int J>
 __device__ __forceinline__ void wino_rows_make_a(const RowsR& r, f32x4 (&a)[3]) {
     f32x4 lo, hi;
@@ -2180,22 +1445,118 @@ __device__ __forceinline__ void wino_rows_make_a(const RowsR& r, f32x4 (&a)[3]) 
     split3_frag(lo, hi, a);
 }
 
-// the twelve MFMAs of (xi, tile half): both channel halves, six piece products each, smallest first
-__device__ __forceinline__ void wino_rows_mfma12(f32x16& acc0, f32x16& acc1, const f32x4 (&a)[3], const f32x4 (&b0)[3], const f32x4 (&b1)[3]) {
-#define LM_BF(x) __builtin_bit_cast(bf16x8, x)
-    acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(LM_BF(a[2]), LM_BF(b0[0]), acc0, 0, 0, 0);       // v3 u1
-    acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(LM_BF(a[2]), LM_BF(b1[0]), acc1, 0, 0, 0);
-    acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(LM_BF(a[1]), LM_BF(b0[1]), acc0, 0, 0, 0);       // v2 u2
-    acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(LM_BF(a[1]), LM_BF(b1[1]), acc1, 0, 0, 0);
-    acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(LM_BF(a[0]), LM_BF(b0[2]), acc0, 0, 0, 0);       // v1 u3
-    acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(LM_BF(a[0]), LM_BF(b1[2]), acc1, 0, 0, 0);
-    acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(LM_BF(a[1]), LM_BF(b0[0]), acc0, 0, 0, 0);       // v2 u1
-    acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(LM_BF(a[1]), LM_BF(b1[0]), acc1, 0, 0, 0);
-    acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(LM_BF(a[0]), LM_BF(b0[1]), acc0, 0, 0, 0);       // v1 u2
-    acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(LM_BF(a[0]), LM_BF(b1[1]), acc1, 0, 0, 0);
-    acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(LM_BF(a[0]), LM_BF(b0[0]), acc0, 0, 0, 0);       // v1 u1
-    acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(LM_BF(a[0]), LM_BF(b1[0]), acc1, 0, 0, 0);
-#undef LM_BF
+// The same work cut into the twelve pieces that ride behind the twelve MFMAs of a sub-step: piece K makes part K % 3 of dword K / 3
+// (values 2d, 2d + 1 of the lane's eight) - column pass + leading piece (5 VALU), second piece (5), third piece (3).
+struct RowsSplitSt {
+    float x, y;
+};
+__device__ __forceinline__ float wino_low16(float v) { return v - __uint_as_float(__float_as_uint(v) & 0xFFFF0000u); }      // exact
+template <int J, int K>
+__device__ __forceinline__ void wino_rows_chunk(const RowsR& r, f32x4 (&a)[3], RowsSplitSt& st) {
+    constexpr int d = K / 3, part = K % 3, e0 = 2 * d, e1 = 2 * d + 1;
+    if constexpr (part == 0) {
+        const float v0 = J == 0 ? r.v[0][e0] - r.v[2][e0] : J == 1 ? r.v[1][e0] + r.v[2][e0] : J == 2 ? r.v[2][e0] - r.v[1][e0] : r.v[1][e0] - r.v[3][e0];
+        const float v1 = J == 0 ? r.v[0][e1] - r.v[2][e1] : J == 1 ? r.v[1][e1] + r.v[2][e1] : J == 2 ? r.v[2][e1] - r.v[1][e1] : r.v[1][e1] - r.v[3][e1];
+        a[0][d] = __uint_as_float(pack_hi(v0, v1));
+        st.x = wino_low16(v0);
+        st.y = v1;
+    } else if constexpr (part == 1) {
+        const float r1 = wino_low16(st.y);
+        a[1][d] = __uint_as_float(pack_hi(st.x, r1));
+        st.x = wino_low16(st.x);
+        st.y = r1;
+    } else {
+        a[2][d] = __uint_as_float(pack_hi(st.x, wino_low16(st.y)));
+    }
+}
+
+// One patch column of the row pass (r[C] = d[first row][C] + sgn * d[second row][C], 8 channels), spread over a sub-step: the four
+// ds_read_b128 behind MFMAs 0 and 1, the eight fma behind MFMAs 5, 8 and 11 (where the split piece is the short one).
+struct RowsColT {
+    f32x4 d1[2], d2[2];
+};
+template <int K, int C>
+__device__ __forceinline__ void wino_rows_col(const float* raw, int b1, int b2, float sgn, RowsR& r, RowsColT& t) {
+    constexpr int off = (C & 1) * (RPL * 16);
+    if constexpr (K == 0) {
+        t.d1[0] = *reinterpret_cast<const f32x4*>(raw + b1 + off);
+        t.d2[0] = *reinterpret_cast<const f32x4*>(raw + b2 + off);
+    } else if constexpr (K == 1) {
+        t.d1[1] = *reinterpret_cast<const f32x4*>(raw + b1 + off + 8);
+        t.d2[1] = *reinterpret_cast<const f32x4*>(raw + b2 + off + 8);
+    } else if constexpr (K == 5) {
+#pragma unroll
+        for (int e = 0; e < 3; ++e) r.v[C][e] = fmaf(t.d2[0][e], sgn, t.d1[0][e]);
+    } else if constexpr (K == 8) {
+        r.v[C][3] = fmaf(t.d2[0][3], sgn, t.d1[0][3]);
+        r.v[C][4] = fmaf(t.d2[1][0], sgn, t.d1[1][0]);
+        r.v[C][5] = fmaf(t.d2[1][1], sgn, t.d1[1][1]);
+    } else if constexpr (K == 11) {
+        r.v[C][6] = fmaf(t.d2[1][2], sgn, t.d1[1][2]);
+        r.v[C][7] = fmaf(t.d2[1][3], sgn, t.d1[1][3]);
+    }
+}
+
+template <int OFF>
+__device__ __forceinline__ void bload1(f32x4& b, unsigned voff, const float* sbase) {
+    asm volatile("global_load_dwordx4 %0, %1, %2 offset:%3" : "=&v"(b) : "v"(voff), "s"(sbase), "n"(OFF) : "memory");
+}
+template <int N>
+__device__ __forceinline__ void bwait6(f32x4 (&b)[2][3]) {
+    asm volatile("s_waitcnt vmcnt(%6)" : "+v"(b[0][0]), "+v"(b[0][1]), "+v"(b[0][2]), "+v"(b[1][0]), "+v"(b[1][1]), "+v"(b[1][2]) : "n"(N) : "memory");
+}
+
+// MFMA K of a sub-step: piece product K / 2 (smallest first: v3 u1, v2 u2, v1 u3, v2 u1, v1 u2, v1 u1), channel half K % 2
+template <int K>
+__device__ __forceinline__ void wino_rows_mfma(f32x16& acc0, f32x16& acc1, const f32x4 (&a)[3], const f32x4 (&b)[2][3]) {
+    constexpr int PP = K >> 1, NS = K & 1;
+    constexpr int AI = PP == 0 ? 2 : (PP == 1 || PP == 3) ? 1 : 0;
+    constexpr int BI = (PP == 0 || PP == 3 || PP == 5) ? 0 : (PP == 1 || PP == 4) ? 1 : 2;
+    if constexpr (NS == 0)
+        acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a[AI]), __builtin_bit_cast(bf16x8, b[0][BI]), acc0, 0, 0, 0);
+    else
+        acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a[AI]), __builtin_bit_cast(bf16x8, b[1][BI]), acc1, 0, 0, 0);
+}
+
+// Sub-step (J, MS): the twelve MFMAs of (xi 4w + J, tile half MS) and, one piece behind each: the A pieces of the NEXT sub-step
+// ((J, 1) after (J, 0); (J + 1, 0) of this or the next slot after (J, 1)), one patch column of the row pass, and at most one vector
+// memory instruction (a run of them holds the wave's issue for 16+ cycles each - the MFMA pipe drains): the six B loads of step J + 3
+// behind the even MFMAs of (J, 0), three patch loads behind MFMAs 1, 5, 9 of (J, 1), J < 3.
+// Row-pass columns: (0, ms) column 0, (2, ms) column 2, (3, ms) column 1 of the NEXT slot's patches, (1, ms) column 3 of THIS slot's -
+// each right after the last column pass that read the old value (J = 0 reads columns 0 2, J = 1: 1 2, J = 2: 2 1, J = 3: 1 3).
+template <int J, int MS, int K>
+__device__ __forceinline__ void wino_rows_gap(f32x16 (&acc)[16], f32x4 (&bq)[4][2][3], const f32x4 (&acur)[3], f32x4 (&anxt)[3], RowsR (&rr)[2],
+                                              RowsSplitSt& st, RowsColT& ct, const float* rawcol, int b1, int b2, float rsgn, unsigned bvoff,
+                                              const float* bnext, const float* const (&gsrc)[RLPW], long goff, float* rawld, int wave) {
+    typedef __attribute__((address_space(1))) const void gptr_t;
+    typedef __attribute__((address_space(3))) void lptr_t;
+    constexpr int JN = MS == 0 ? J : (J + 1) & 3;
+    constexpr int C = J == 0 ? 0 : J == 1 ? 3 : J == 2 ? 2 : 1;
+    wino_rows_mfma<K>(acc[4 * J + 2 * MS], acc[4 * J + 2 * MS + 1], acur, bq[J & 3]);
+    wino_rows_chunk<JN, K>(rr[MS ^ 1], anxt, st);
+    wino_rows_col<K, C>(rawcol, b1, b2, rsgn, rr[MS], ct);
+    if constexpr (MS == 0 && (K & 1) == 0) {
+        constexpr int li = K / 2, ns = li / 3, piece = li % 3;
+        bload1<piece * 1024>(bq[(J + 3) & 3][ns][piece], bvoff, bnext + ns * 768);
+    }
+    if constexpr (MS == 1 && J < 3 && (K == 1 || K == 5 || K == 9)) {
+        constexpr int s_ = 3 * J + (K - 1) / 4;
+        __builtin_amdgcn_global_load_lds((gptr_t*)(gsrc[s_] + goff), (lptr_t*)(rawld + (s_ * 4 + wave) * 256), 16, 0, 0);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+}
+
+template <int J, int MS>
+__device__ __forceinline__ void wino_rows_substep(f32x16 (&acc)[16], f32x4 (&bq)[4][2][3], const f32x4 (&acur)[3], f32x4 (&anxt)[3], RowsR (&rr)[2],
+                                                  const float* rawcol, const int (&rb1)[2][2], const int (&rb2)[2][2], float rsgn, unsigned bvoff,
+                                                  const float* bnext, const float* const (&gsrc)[RLPW], long goff, float* rawld, int wave) {
+    constexpr int C = J == 0 ? 0 : J == 1 ? 3 : J == 2 ? 2 : 1;
+    const int b1 = rb1[MS][C >> 1], b2 = rb2[MS][C >> 1];
+    RowsSplitSt st;
+    RowsColT ct;
+#define LM_G(K) wino_rows_gap<J, MS, K>(acc, bq, acur, anxt, rr, st, ct, rawcol, b1, b2, rsgn, bvoff, bnext, gsrc, goff, rawld, wave);
+    LM_G(0) LM_G(1) LM_G(2) LM_G(3) LM_G(4) LM_G(5) LM_G(6) LM_G(7) LM_G(8) LM_G(9) LM_G(10) LM_G(11)
+#undef LM_G
 }
 
 __global__ __launch_bounds__(256) void wino_rows_split_kernel(WinoImpParams p) {
@@ -2203,7 +1564,7 @@ __global__ __launch_bounds__(256) void wino_rows_split_kernel(WinoImpParams p) {
     long long iprof[11] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
     long long t_last = clock64();
 #endif
-    extern __shared__ __attribute__((aligned(16))) float smem[];      // patches[3][RRAWH]; the epilogue's exchange area afterwards
+    extern __shared__ __attribute__((aligned(16))) float smem[];      // patches[4][RRAWH]; the epilogue's exchange area afterwards
     float* const raw0 = smem;
     typedef __attribute__((address_space(1))) const void gptr_t;
     typedef __attribute__((address_space(3))) void lptr_t;
@@ -2215,8 +1576,13 @@ __global__ __launch_bounds__(256) void wino_rows_split_kernel(WinoImpParams p) {
         const unsigned bid = blockIdx.x, mb = gridDim.x / (unsigned)n_tiles, mbx = mb / 8, full = mbx * 8 * (unsigned)n_tiles;
         if (bid < full) {
             const unsigned xcd = bid % 8, idx = bid / 8;
-            ntile = idx / mbx;
-            mblk = xcd * mbx + idx % mbx;
+            if (p.n_inner) {        // the N tiles of a tile block back to back on one XCD: its patches are fetched from HBM once
+                ntile = idx % (unsigned)n_tiles;
+                mblk = xcd * mbx + idx / (unsigned)n_tiles;
+            } else {                // N tile outer: one N tile's B pieces stay in the XCD's L2
+                ntile = idx / mbx;
+                mblk = xcd * mbx + idx % mbx;
+            }
         } else {
             const unsigned r = bid - full;
             mblk = 8 * mbx + r / (unsigned)n_tiles;
@@ -2314,7 +1680,8 @@ __global__ __launch_bounds__(256) void wino_rows_split_kernel(WinoImpParams p) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[k][r] = 0.f;
     f32x4 bq[4][2][3];                                 // B ring: xi step j in set j & 3, requested three steps ahead
-    // prologue: patches of slots 0 .. 2 (three buffers in rotation), B of steps 0 .. 2, row pass of slot 0, A(0, tile half 0)
+    LM_TICK(7)
+    // prologue: patches of slots 0 .. 2 (four buffers in rotation), B of steps 0 .. 2; columns 0 .. 2 of slot 0's row pass, A(0, half 0)
 #pragma unroll
     for (int s_ = 0; s_ < RLPW; ++s_)
         __builtin_amdgcn_global_load_lds((gptr_t*)gsrc[s_], (lptr_t*)(raw0 + (s_ * 4 + wave) * 256), 16, 0, 0);
@@ -2334,67 +1701,42 @@ __global__ __launch_bounds__(256) void wino_rows_split_kernel(WinoImpParams p) {
     }
     asm volatile("s_waitcnt vmcnt(36)" ::: "memory");      // the patches of slot 0 (18 B loads and 18 patch loads are younger)
     __builtin_amdgcn_s_barrier();
+    LM_TICK(8)
     RowsR rr[2];
     f32x4 a0[3], a1[3];
-    wino_rows_rowpass(raw0, rb1[0], rb2[0], rsgn, rr[0]);
+    wino_rows_rowpass(raw0, rb1[0], rb2[0], rsgn, rr[0]);  // (column 3 is made again in step 1 of slot 0)
     wino_rows_rowpass(raw0, rb1[1], rb2[1], rsgn, rr[1]);
     wino_rows_make_a<0>(rr[0], a0);
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();              // every wave has read the patches of slot 0: the loads of slot 3 may replace them
+    asm volatile("s_waitcnt vmcnt(9)" ::: "memory");       // the patches of slot 1: column passes read them from step 0 on
+    __builtin_amdgcn_s_barrier();
     LM_TICK(0)
-    int bcur = 0, bnxt = RRAWH;                // float offsets of the buffers of slot h (refilled with slot h + 3) and of slot h + 1
     for (int h = 0; h < H; ++h) {
-        float* const rawld = raw0 + bcur;                                                  // patches of slot h + 3 replace those of slot h
-        const float* const rawnx = raw0 + bnxt;                                            // patches of slot h + 1 (row pass in step 3)
+        const float* const rawC = raw0 + (h & 3) * RRAWH;                                  // patches of this slot (column 3 in step 1)
+        const float* const rawN = raw0 + ((h + 1) & 3) * RRAWH;                            // patches of slot h + 1 (columns 0, 2, 1)
+        float* const rawld = raw0 + ((h + 3) & 3) * RRAWH;                                 // patches of slot h + 3 replace those of slot h - 1
         const long goff = h + 3 < H ? (long)(h + 3) * RKS : 0;                             // (nothing left to fetch: harmless re-read)
         const float* const bs = bbase + (long)h * bstep;
         const float* const bs_next = bbase + (long)(h + 1 < H ? h + 1 : 0) * bstep;
 #define LM_BPRE(X) ((X) < 4 ? bs + (long)(X) * bxi : bs_next + (long)((X) - 4) * bxi)
-#define LM_GROUPS(NV, ND)                                                        \
-        _Pragma("unroll") for (int k_ = 0; k_ < 12; ++k_) {                      \
-            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                   \
-            if (ND) __builtin_amdgcn_sched_group_barrier(0x100, ND, 0);          \
-            __builtin_amdgcn_sched_group_barrier(0x002, NV, 0);                  \
-        }
-        // step J: patch loads P0 .. P1-1 of the slot, B of step J + 3; then (J, tile half 0) with A(J, 1) made behind it, (J, 1) with
-        // A(J + 1, 0).  NW = loads younger than B(J) after this step's requests: the patch loads of three steps + 18.
-#define LM_RSTEP(J, P0, P1, NW, MAKE0, GRP0, MAKE1, GRP1)                                                                                        \
-        {                                                                                                                             \
-            _Pragma("unroll") for (int s_ = P0; s_ < P1; ++s_)                                                                        \
-                __builtin_amdgcn_global_load_lds((gptr_t*)(gsrc[s_] + goff), (lptr_t*)(rawld + (s_ * 4 + wave) * 256), 16, 0, 0);    \
-            bload3(bq[((J) + 3) & 3][0], bvoff, LM_BPRE((J) + 3));                                                                    \
-            bload3(bq[((J) + 3) & 3][1], bvoff, LM_BPRE((J) + 3) + 768);                                                              \
-            bwait3<NW>(bq[(J) & 3][0]);                                                                                               \
-            bwait3<NW>(bq[(J) & 3][1]);                                                                                               \
-            LM_TICK((J) == 0 ? 1 : 3)                                                                                                 \
-            __builtin_amdgcn_sched_barrier(0);                                                                                        \
-            MAKE0                                                                                                                     \
-            wino_rows_mfma12(acc[4 * (J)], acc[4 * (J) + 1], a0, bq[(J) & 3][0], bq[(J) & 3][1]);                                     \
-            GRP0                                                                                                                      \
-            __builtin_amdgcn_sched_barrier(0);                                                                                        \
-            MAKE1                                                                                                                     \
-            wino_rows_mfma12(acc[4 * (J) + 2], acc[4 * (J) + 3], a1, bq[(J) & 3][0], bq[(J) & 3][1]);                                 \
-            GRP1                                                                                                                      \
-            __builtin_amdgcn_sched_barrier(0);                                                                                        \
-            LM_TICK((J) == 3 ? 2 : 4)                                                                                                 \
-        }
+        // NW = loads younger than B(J) when step J starts: 12 B loads and the patch loads of the three steps before (3, 3, 3, 0 per step)
+#define LM_RSTEP(J, NW, RAWCOL)                                                                                                        \
+        bwait6<NW>(bq[(J) & 3]);                                                                                                      \
+        LM_TICK((J) == 0 ? 1 : 3)                                                                                                     \
+        __builtin_amdgcn_sched_barrier(0);                                                                                            \
+        wino_rows_substep<J, 0>(acc, bq, a0, a1, rr, RAWCOL, rb1, rb2, rsgn, bvoff, LM_BPRE((J) + 3), gsrc, goff, rawld, wave);       \
+        wino_rows_substep<J, 1>(acc, bq, a1, a0, rr, RAWCOL, rb1, rb2, rsgn, bvoff, LM_BPRE((J) + 3), gsrc, goff, rawld, wave);       \
+        LM_TICK((J) == 3 ? 2 : 4)
         static_assert(RLPW == 9, "NW table: patch loads per step 3, 3, 3, 0");
-        LM_RSTEP(0, 0, 3, 24, wino_rows_make_a<0>(rr[1], a1);, LM_GROUPS(5, 0), wino_rows_make_a<1>(rr[0], a0);, LM_GROUPS(5, 0))
-        LM_RSTEP(1, 3, 6, 24, wino_rows_make_a<1>(rr[1], a1);, LM_GROUPS(5, 0), wino_rows_make_a<2>(rr[0], a0);, LM_GROUPS(5, 0))
-        LM_RSTEP(2, 6, 9, 27, wino_rows_make_a<2>(rr[1], a1);, LM_GROUPS(5, 0), wino_rows_make_a<3>(rr[0], a0);, LM_GROUPS(5, 0))
-        // step 3: the row pass of slot h + 1 follows the last use of each tile half's row data
-        LM_RSTEP(3, 9, 9, 24,
-                 wino_rows_rowpass(rawnx, rb1[0], rb2[0], rsgn, rr[0]); wino_rows_make_a<3>(rr[1], a1);, LM_GROUPS(7, 2),
-                 wino_rows_rowpass(rawnx, rb1[1], rb2[1], rsgn, rr[1]); wino_rows_make_a<0>(rr[0], a0);, LM_GROUPS(7, 2))
+        LM_RSTEP(0, 18, rawN)
+        LM_RSTEP(1, 18, rawC)
+        LM_RSTEP(2, 18, rawN)
+        LM_RSTEP(3, 21, rawN)
 #undef LM_RSTEP
-#undef LM_GROUPS
 #undef LM_BPRE
         asm volatile("s_waitcnt vmcnt(33)" ::: "memory");     // this wave's patch loads of the PREVIOUS slot have landed (33 loads per slot)
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();          // patches of slot h + 2 visible, every wave is done reading those of slot h + 1
+        __builtin_amdgcn_s_barrier();          // patches of slot h + 2 visible; every wave is done with those of slot h
         LM_TICK(5)
-        bcur = bnxt;
-        bnxt = bnxt == 2 * RRAWH ? 0 : bnxt + RRAWH;
     }
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
@@ -2552,22 +1894,16 @@ int wino_implicit_launch(int mode, void* stream, const float* x, int ldx, const 
         zeros = (const float*)sym;
     }
     p.zeros = zeros;
-    static const bool split_pipe = getenv("LANEMAP_SPLIT_PIPE") && atoi(getenv("LANEMAP_SPLIT_PIPE")) == 1;
-    if (mode == 1 && !split_pipe) {        // split-precision GEMM, ROWS geometry (wino_rows_split_kernel)
-        const size_t rlds = (size_t)(3 * RRAWH > 2 * RXCH ? 3 * RRAWH : 2 * RXCH) * sizeof(float);
+    p.n_inner = 0;
+    if (mode == 1) {        // split-precision GEMM, ROWS geometry (wino_rows_split_kernel)
+        const size_t rlds = (size_t)(4 * RRAWH > 2 * RXCH ? 4 * RRAWH : 2 * RXCH) * sizeof(float);
         const long rblocks = (p.g.T / RBM) * ((Cout + RBN - 1) / RBN);
+        // an input larger than the 256 MB Infinity Cache is re-read from HBM once per N tile in the N-outer order (256->256@288^2 B = 8:
+        // 680 MB x 4): N inner there (2.33 -> 2.21 ms); smaller inputs keep N outer (256->256 d2@144^2: 0.581 vs 0.591 ms)
+        p.n_inner = (long)B * H * W * Cin * 4 > (256L << 20) ? 1 : 0;
         LM_REQUIRE(rblocks > 0 && rblocks < (1L << 31) && p.g.T % RBM == 0, "conv_wino_implicit: bad grid %ld", rblocks);
         if (int e = lm_ensure_dynamic_lds((const void*)wino_rows_split_kernel, rlds)) return e;
         hipLaunchKernelGGL(wino_rows_split_kernel, dim3((unsigned)rblocks), dim3(256), rlds, (hipStream_t)stream, p);
-        LM_LAUNCH_CHECK();
-        return LM_OK;
-    }
-    if (mode == 1) {        // split-precision GEMM, PIPE geometry (wino_pipe_split_kernel)
-        const size_t slds = (size_t)(2 * PRAWH + 2 * SVH) * sizeof(float);
-        const long sblocks = (p.g.T / PBM) * ((Cout + PBN - 1) / PBN);
-        LM_REQUIRE(sblocks > 0 && sblocks < (1L << 31) && p.g.T % PBM == 0, "conv_wino_implicit: bad grid %ld", sblocks);
-        if (int e = lm_ensure_dynamic_lds((const void*)wino_pipe_split_kernel, slds)) return e;
-        hipLaunchKernelGGL(wino_pipe_split_kernel, dim3((unsigned)sblocks), dim3(256), slds, (hipStream_t)stream, p);
         LM_LAUNCH_CHECK();
         return LM_OK;
     }

@@ -52,8 +52,10 @@
                 st[((r & 3) + 8 * (r >> 2) + 4 * fhalf) * RELD + frow] = o;
             }
         }
+    LM_TICK(9)
     const float* const rd = xch + wave * (32 * RELD) + (lane / LPR) * RELD + c4;      // + (b * 4 + row w) * 4 blocks, + pass * RPI rows
     __syncthreads();
+    LM_TICK(10)
     if (n < p.Cout) {
 #pragma unroll
         for (int a = 0; a < 2; ++a)

@@ -36,6 +36,6 @@ for cin, cout, dil, hw in [(256, 256, 1, 288), (256, 128, 1, 288), (256, 256, 2,
         if has_prof and name == 'bf16x3':
             ops.lib().lm_iprof_read(buf, 1)
             nw = max(buf[11], 1)
-            print(f'  iprof {cin}->{cout}@{hw}: ' + ' '.join(f'{k}={buf[k] / nw:.0f}' for k in range(8)) + f' total={sum(buf[:11]) / nw:.0f}')
+            print(f'  iprof {cin}->{cout}@{hw}: ' + ' '.join(f'{k}={buf[k] / nw:.0f}' for k in range(11)) + f' total={sum(buf[:11]) / nw:.0f}')
     out.append(f'{cin}->{cout} d{dil}@{hw} fp32 {res["fp32"]:.3f} split {res["bf16x3"]:.3f} ms (x{res["fp32"] / res["bf16x3"]:.2f}) err {err:.1e}')
 print(os.path.basename(os.environ.get('LANEMAP_HIP_LIB', 'product')), ' | '.join(out))
