@@ -892,6 +892,13 @@ def test_bench_default_command(dev):
     rr = d['raster_roofline']
     assert rr['bound'] == 'hbm' and 0.1 < rr['frac'] < 1.0
     assert {'value', 'unit', 'cores', 'kind', 'sample'} <= set(d['cpu_baseline']) and d['cpu_baseline']['value'] > 0
+    # the declared second line: the same workload with the split-precision Winograd GEMMs, priced against the bf16 peak; never the headline
+    assert d['dtype'] == 'f32'
+    sl = d['second_line']
+    assert 'error' not in sl, sl
+    assert sl['dtype'] == 'bf16x3' and sl['steps'] == 2 and sl['unit'] == d['unit'] and sl['value'] > 10
+    assert 'bf16x3' in sl['roofline']['dominant_kernel'] and sl['roofline']['peak'] > 1000 and 0.0 < sl['roofline']['frac'] <= 1.0
+    assert sl['winograd_ms_per_step'] < rf['winograd_ms_per_step']
 
 
 def test_multi_stream_pipeline_bitwise_equals_single_stream(dev, net):
