@@ -1675,10 +1675,6 @@ __global__ __launch_bounds__(256) void wino_rows_split_kernel(WinoImpParams p) {
     const float* const bbase = p.U + (long)(n0 >> 5) * 768 + (long)(4 * wave) * bxi;      // xi = 4 * wave, channel half 0 (half 1: + 768)
 
     f32x16 acc[16];                                    // [j][tile half][channel half]
-#pragma unroll
-    for (int k = 0; k < 16; ++k)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) acc[k][r] = 0.f;
     f32x4 bq[4][2][3];                                 // B ring: xi step j in set j & 3, requested three steps ahead
     LM_TICK(7)
     // prologue: patches of slots 0 .. 2 (four buffers in rotation), B of steps 0 .. 2; columns 0 .. 2 of slot 0's row pass, A(0, half 0)
@@ -1698,6 +1694,14 @@ __global__ __launch_bounds__(256) void wino_rows_split_kernel(WinoImpParams p) {
 #pragma unroll
         for (int s_ = 0; s_ < RLPW; ++s_)
             __builtin_amdgcn_global_load_lds((gptr_t*)(gsrc[s_] + g2), (lptr_t*)(raw0 + 2 * RRAWH + (s_ * 4 + wave) * 256), 16, 0, 0);
+    }
+    // the 256 accumulator writes go out HERE, under the cold loads (the compiler sinks them to the loop's doorstep otherwise: 2.7 k cycles
+    // in front of the first MFMA of every workgroup)
+#pragma unroll
+    for (int k = 0; k < 16; ++k) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[k][r] = 0.f;
+        asm volatile("" : "+a"(acc[k]));
     }
     asm volatile("s_waitcnt vmcnt(36)" ::: "memory");      // the patches of slot 0 (18 B loads and 18 patch loads are younger)
     __builtin_amdgcn_s_barrier();
