@@ -72,21 +72,25 @@
                         rpre[pass] = ok ? *reinterpret_cast<const f32x4*>(p.res + pix * p.ldr + n) : f32x4{0.f, 0.f, 0.f, 0.f};
                     }
                 }
+                // the twelve reads of the position first, unconditionally (a row without a tile reads finite stale data that is never stored)
+                f32x4 vv[NP];
+#pragma unroll
+                for (int pass = 0; pass < NP; ++pass) {
+                    const float* const src = rd + pass * (RPI * RELD) + (b * 4 + a) * (4 * 32 * RELD);      // rows a, a + 1, a + 2
+                    const f32x4 v0 = *reinterpret_cast<const f32x4*>(src);
+                    const f32x4 v1 = *reinterpret_cast<const f32x4*>(src + 4 * 32 * RELD);
+                    const f32x4 v2 = *reinterpret_cast<const f32x4*>(src + 8 * 32 * RELD);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) vv[pass][e] = a == 0 ? (v0[e] + v1[e]) + v2[e] : (v0[e] - v1[e]) - v2[e];
+                }
 #pragma unroll
                 for (int pass = 0; pass < NP; ++pass) {
                     const unsigned vm = vmask >> (3 * pass);
                     if (!(vm & 1u) || (a && !(vm & 2u)) || (b && !(vm & 4u))) continue;
                     const long pix = pix0[pass] + a * step_a + b * step_b;
-                    const float* const src = rd + pass * (RPI * RELD) + (b * 4 + a) * (4 * 32 * RELD);      // rows a, a + 1, a + 2
-                    const f32x4 v0 = *reinterpret_cast<const f32x4*>(src);
-                    const f32x4 v1 = *reinterpret_cast<const f32x4*>(src + 4 * 32 * RELD);
-                    const f32x4 v2 = *reinterpret_cast<const f32x4*>(src + 8 * 32 * RELD);
-                    f32x4 v;
+                    f32x4 v = vv[pass];
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        v[e] = a == 0 ? (v0[e] + v1[e]) + v2[e] : (v0[e] - v1[e]) - v2[e];
-                        v[e] = p.scale ? v[e] * sc[e] + sh[e] : v[e] + sh[e];
-                    }
+                    for (int e = 0; e < 4; ++e) v[e] = p.scale ? v[e] * sc[e] + sh[e] : v[e] + sh[e];
                     if (p.gn_part) {
 #pragma unroll
                         for (int e = 0; e < 4; ++e) {
