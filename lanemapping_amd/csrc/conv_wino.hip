@@ -1471,29 +1471,30 @@ __device__ __forceinline__ void wino_rows_chunk(const RowsR& r, f32x4 (&a)[3], R
 }
 
 // One patch column of the row pass (r[C] = d[first row][C] + sgn * d[second row][C], 8 channels), spread over a sub-step: the four
-// ds_read_b128 behind MFMAs 0 and 1, the eight fma behind MFMAs 5, 8 and 11 (where the split piece is the short one).
+// ds_read_b128 behind MFMAs 2 and 5 (short split pieces), the eight fma behind MFMAs 8 .. 11 - with the loads in the first half of the
+// sub-step every MFMA has at most six instructions behind it.
 struct RowsColT {
     f32x4 d1[2], d2[2];
 };
 template <int K, int C>
 __device__ __forceinline__ void wino_rows_col(const float* raw, int b1, int b2, float sgn, RowsR& r, RowsColT& t) {
     constexpr int off = (C & 1) * (RPL * 16);
-    if constexpr (K == 0) {
+    if constexpr (K == 2) {
         t.d1[0] = *reinterpret_cast<const f32x4*>(raw + b1 + off);
         t.d2[0] = *reinterpret_cast<const f32x4*>(raw + b2 + off);
-    } else if constexpr (K == 1) {
+    } else if constexpr (K == 5) {
         t.d1[1] = *reinterpret_cast<const f32x4*>(raw + b1 + off + 8);
         t.d2[1] = *reinterpret_cast<const f32x4*>(raw + b2 + off + 8);
-    } else if constexpr (K == 5) {
+    } else if constexpr (K == 8) {
 #pragma unroll
         for (int e = 0; e < 3; ++e) r.v[C][e] = fmaf(t.d2[0][e], sgn, t.d1[0][e]);
-    } else if constexpr (K == 8) {
+    } else if constexpr (K == 9) {
         r.v[C][3] = fmaf(t.d2[0][3], sgn, t.d1[0][3]);
+    } else if constexpr (K == 10) {
         r.v[C][4] = fmaf(t.d2[1][0], sgn, t.d1[1][0]);
-        r.v[C][5] = fmaf(t.d2[1][1], sgn, t.d1[1][1]);
     } else if constexpr (K == 11) {
-        r.v[C][6] = fmaf(t.d2[1][2], sgn, t.d1[1][2]);
-        r.v[C][7] = fmaf(t.d2[1][3], sgn, t.d1[1][3]);
+#pragma unroll
+        for (int e = 1; e < 4; ++e) r.v[C][4 + e] = fmaf(t.d2[1][e], sgn, t.d1[1][e]);
     }
 }
 
@@ -1521,7 +1522,7 @@ __device__ __forceinline__ void wino_rows_mfma(f32x16& acc0, f32x16& acc1, const
 // Sub-step (J, MS): the twelve MFMAs of (xi 4w + J, tile half MS) and, one piece behind each: the A pieces of the NEXT sub-step
 // ((J, 1) after (J, 0); (J + 1, 0) of this or the next slot after (J, 1)), one patch column of the row pass, and at most one vector
 // memory instruction (a run of them holds the wave's issue for 16+ cycles each - the MFMA pipe drains): the six B loads of step J + 3
-// behind the even MFMAs of (J, 0), three patch loads behind MFMAs 1, 5, 9 of (J, 1), J < 3.
+// behind MFMAs 0 .. 5 of (J, 0), three patch loads behind MFMAs 0, 3, 6 of (J, 1), J < 3.
 // Row-pass columns: (0, ms) column 0, (2, ms) column 2, (3, ms) column 1 of the NEXT slot's patches, (1, ms) column 3 of THIS slot's -
 // each right after the last column pass that read the old value (J = 0 reads columns 0 2, J = 1: 1 2, J = 2: 2 1, J = 3: 1 3).
 template <int J, int MS, int K>
@@ -1535,12 +1536,12 @@ __device__ __forceinline__ void wino_rows_gap(f32x16 (&acc)[16], f32x4 (&bq)[4][
     wino_rows_mfma<K>(acc[4 * J + 2 * MS], acc[4 * J + 2 * MS + 1], acur, bq[J & 3]);
     wino_rows_chunk<JN, K>(rr[MS ^ 1], anxt, st);
     wino_rows_col<K, C>(rawcol, b1, b2, rsgn, rr[MS], ct);
-    if constexpr (MS == 0 && (K & 1) == 0) {
-        constexpr int li = K / 2, ns = li / 3, piece = li % 3;
+    if constexpr (MS == 0 && K < 6) {
+        constexpr int ns = K / 3, piece = K % 3;
         bload1<piece * 1024>(bq[(J + 3) & 3][ns][piece], bvoff, bnext + ns * 768);
     }
-    if constexpr (MS == 1 && J < 3 && (K == 1 || K == 5 || K == 9)) {
-        constexpr int s_ = 3 * J + (K - 1) / 4;
+    if constexpr (MS == 1 && J < 3 && (K == 0 || K == 3 || K == 6)) {
+        constexpr int s_ = 3 * J + K / 3;
         __builtin_amdgcn_global_load_lds((gptr_t*)(gsrc[s_] + goff), (lptr_t*)(rawld + (s_ * 4 + wave) * 256), 16, 0, 0);
     }
     __builtin_amdgcn_sched_barrier(0);
