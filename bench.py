@@ -121,7 +121,7 @@ def second_line(args):
     tests/test_gpu_parity.py test_goldens_under_every_advertised_switch), so it never replaces `value`: exact fp32 stays the headline.
     Run in a child process after the headline has been timed - the switch is read when the weights are packed."""
     import subprocess
-    cmd = [sys.executable, os.path.abspath(__file__), '--steps', str(args.steps), '--warmup', str(args.warmup), '--workload', args.workload,
+    cmd = [sys.executable, os.path.join(ROOT, 'bench.py'), '--steps', str(args.steps), '--warmup', str(args.warmup), '--workload', args.workload,
            '--no-cpu-baseline', '--no-second-line']
     if args.streams is not None:
         cmd += ['--streams', str(args.streams)]

@@ -543,7 +543,10 @@ WinoGeom geom(int B, int H, int W, int dil) {
 
 
 // =====================================================================================================================================
-// Implicit-transform Winograd: no V tensor in HBM.  One workgroup = 64 tiles x 64 output channels, 4 waves (one per SIMD) of 32 x 32.
+// Implicit-transform Winograd: no V tensor in HBM.  Three kernels share the scheme described here (it is the round-2 kernel's, a
+// 64 tiles x 64 channels workgroup of four 32 x 32 waves, whose code is gone): wino_dual_kernel (fp32, 32 x 64, Cout <= 64),
+// wino_pipe_kernel (fp32, 32 x 128, the transform spread over the MFMA steps) and wino_rows_split_kernel (bf16 x 3, 64 x 64, one
+// transform row per wave, transform in registers) - their own headers say what differs.
 // The loop order is (input-channel slab) outer, xi inner: all SIXTEEN transformed products M[xi] of the wave tile live in registers
 // (16 accumulators x 16 = 256 AGPRs, hence one wave per SIMD).  Per 16-channel slab:
 //   1. the RAW input patch of the 64 tiles (4 patch rows x up to 136 column slots x 16 channels, 34 KB) arrives in LDS through
@@ -1396,21 +1399,24 @@ __global__ __launch_bounds__(256) void wino_pipe_kernel(WinoImpParams p) {
 // =====================================================================================================================================
 // ROWS geometry of the split-precision GEMM: 64 tiles x 64 channels per workgroup, wave w owns the four Winograd products of ROW w of the
 // 4 x 4 transform (xi = 4w .. 4w + 3) for the whole block - 4 xi x 2 tile halves x 2 channel halves = 16 accumulator blocks.
-// Why: wino_pipe_split_kernel pulls 192 KB of B pieces per slot and CU = 62 B/clk at full matrix speed; the vector memory path sustains
-// ~40 of its 64 B/clk with every CU pulling, so that kernel runs at the speed of its B traffic (2.43 ms on 256->256@288^2 B = 8, matrix
-// time 0.95).  Here every B fragment is loaded by exactly ONE wave and used for both tile halves (32 B/clk), and the transform of a xi row
+// Why: the same GEMM in the PIPE geometry (32 x 128, V pieces in LDS; measured and removed) pulled 192 KB of B pieces per slot and CU
+// = 62 B/clk at full matrix speed; the vector memory path sustains ~35-40 of its 64 B/clk with every CU pulling, so it ran at the speed
+// of its B traffic (2.43 ms on 256->256@288^2 B = 8, matrix time 0.95; this kernel: 2.13, the fp32 PIPE kernel: 2.97).
+// Here every B fragment is loaded by exactly ONE wave and used for both tile halves (32 B/clk), and the transform of a xi row
 // needs nothing from the other waves: V[w][j] comes from two patch rows (row pass), a column pass and the split, all in the registers of
 // the lane that feeds it to the MFMA (lane (r, g) = tile r, channels 4g..4g+3 and 8+4g..8+4g+3) - no V in LDS, no barrier but the one that
 // publishes the patch buffer of the slot after next.  The 480 VALU instructions per slot and wave ride behind the 96 MFMAs (four to five
-// plain fp32 VALU per bf16 MFMA issue for free - tools/probes/split_probe.hip).  Patch layout in LDS: 32 planes (row, channel quad,
-// column parity) of 68 16-byte entries, so the 32 lanes of a tile half read consecutive entries (conflict-free ds_read_b128).
+// plain fp32 VALU per bf16 MFMA issue for free - tools/probes/split_probe.hip).  Patch layout in LDS: 8 planes (patch row, column
+// parity) of 68 entries of 64 bytes (one pixel's 16-channel slab, fetched by four adjacent lanes of a global_load_lds; quad q at
+// position q ^ ((entry >> 2) & 1)): the 32 lanes of a tile half read consecutive entries, two-way bank conflicts at most.  Four
+// patch buffers in rotation (slot h fills the buffer of slot h + 3; the end-of-slot wait is for the loads of ONE SLOT AGO).
 // The 2 x 2 outputs need all four rows: the epilogue folds a wave's four xi (column pass), exchanges the row terms through LDS and the
-// wave that owns a (tile half, channel half) block sums them in ascending row order and stores (wino_rows_epilogue.h).
+// wave that owns a (tile half, channel half) block combines them in ascending row order and stores (wino_rows_epilogue.h).  DESIGN 3.1e.
 constexpr int RBM = 64, RBN = 64, RKS = 16, RLPW = 9;
-constexpr int RPL = RBM + INSEG;                  // 16-byte entries of one patch plane (the columns of one parity)
+constexpr int RPL = RBM + INSEG;                  // 64-byte entries of one patch plane (the columns of one parity)
 constexpr int RRAWH = RLPW * 4 * 256;             // floats of one patch buffer (36 KB)
 constexpr int RELD = 32 + 4;
-constexpr int RXCH = 16 * 32 * RELD;              // floats of the epilogue's exchange area (72 KB)
+constexpr int RXCH = 16 * 32 * RELD;              // floats of ONE output column's terms in the epilogue's exchange area (72 KB; two columns)
 static_assert(8 * RPL * 4 <= RLPW * 4 * 64, "rows geometry: patch loads cover the planes");
 
 struct RowsR {

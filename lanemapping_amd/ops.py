@@ -257,7 +257,7 @@ def wino_implicit_supported(H, W, cin, dil=1):
 
 def conv_wino_implicit(x, wf, cout, dil=1, scale=None, shift=None, res=None, act=ACT_NONE, out=None, gn_eps=None, gn_split=1):
     # wf: fp32 fragments (pack_wino_fragments: exact-fp32 MFMA, bit-identical to conv_wino) or bf16x3 fragments
-    # (pack_wino_fragments_bf16x3: six bf16 MFMAs per multiply, fp32-rounding-class error, 2.67x less matrix time)
+    # (pack_wino_fragments_bf16x3: six bf16 MFMAs per multiply, fp32-rounding-class error, not bit-identical; wino_rows_split_kernel)
     """3x3 / stride 1 / pad = dil convolution via Winograd F(2x2,3x3) WITHOUT the transformed-input tensor in HBM (the raw patches are
     transformed in LDS, once per workgroup and 16-channel slab).  wf = pack_wino_fragments(pack_wino(w)).  Same bits as conv_wino;
     with gn_eps returns (y, stats) (gn_split: statistics laid out per channel group, see conv_wino)."""

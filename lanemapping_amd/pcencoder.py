@@ -34,9 +34,9 @@ FUSE_UP_WINO = os.environ.get('LANEMAP_FUSE_UP_WINO', '1') != '0'    # s4: GN + 
 # (also pays on the 64-channel layers, where the materialising path lost to the direct kernel).  LANEMAP_WINO_IMPLICIT=0 switches back.
 WINO_IMPLICIT = os.environ.get('LANEMAP_WINO_IMPLICIT', '1') != '0'
 WINO_IMPLICIT_MIN_CIN = int(os.environ.get('LANEMAP_WINO_IMPLICIT_MIN_CIN', '64'))
-# Opt-in: the same kernel with its GEMM on the bf16 matrix cores through exact 3-way operand splits (6 bf16 MFMAs per fp32 product;
-# fp32-rounding-class error, profiles/r2_split_precision_study.txt).  Off by default: bound by the B-fragment loads and the split's VALU
-# work, not by the matrix pipe - no faster than the wide fp32 kernel - and not bit-identical to the fp32 kernels.
+# Opt-in: the same convolutions with their GEMM on the bf16 matrix cores through exact 3-way operand splits (6 bf16 MFMAs per fp32
+# product; fp32-rounding-class error, profiles/r2_split_precision_study.txt; csrc/conv_wino.hip wino_rows_split_kernel).
+# Off by default because its results are not bit-identical to the fp32 kernels; 1.2-1.4x faster per layer, bench.py's second line.
 WINO_BF16X3 = os.environ.get('LANEMAP_WINO_BF16X3', '0') != '0'
 
 
