@@ -1236,6 +1236,49 @@ def test_conv_winograd_bf16x3_vs_fp64(dev, B, cin, cout, H, W, dil):
     assert torch.equal(y, ops.conv_wino_implicit(xd, w3, cout, dil, scale=scale.to(dev), shift=shift.to(dev), res=rd, act=ops.ACT_RELU))
 
 
+def test_conv_winograd_bf16x3_paths(dev):
+    """The other paths of wino_rows_split_kernel, against the fp32 implicit kernel (3e-5 of the tensor scale, the tolerance of
+    test_conv_winograd_bf16x3_vs_fp64): the N-inner workgroup order (inputs beyond the 256 MB Infinity Cache), the GroupNorm partial
+    sums of its epilogue, channel slices of wider tensors as input and output, the 4-slot case Cin = 64, an odd channel count."""
+    from lanemapping_amd import ops
+    g = torch.Generator().manual_seed(77)
+
+    def pair(B, cin, cout, H, W, dil):
+        x = ops.new_act(B, cin, H, W, dev).normal_()
+        w = (torch.randn((cout, cin, 3, 3), generator=g) / (cin * 9) ** 0.5).to(dev)
+        wu = ops.pack_wino(w)
+        return x, wu, ops.pack_wino_fragments(wu), ops.pack_wino_fragments_bf16x3(wu)
+
+    # (a) 4 x 288 x 288 x 256 floats = 340 MB: N tile inner; residual + ReLU + BN
+    x, wu, wf, w3 = pair(4, 256, 256, 288, 288, 1)
+    sc, sh = (torch.rand(256, generator=g) + 0.5).to(dev), torch.randn(256, generator=g).to(dev)
+    res = ops.new_act(4, 256, 288, 288, dev).normal_()
+    y32 = ops.conv_wino_implicit(x, wf, 256, 1, scale=sc, shift=sh, res=res, act=ops.ACT_RELU)
+    y3 = ops.conv_wino_implicit(x, w3, 256, 1, scale=sc, shift=sh, res=res, act=ops.ACT_RELU)
+    _close(y3, y32, 3e-5, 'bf16x3 N-inner vs fp32')
+    del x, res, y32, y3
+    # (b) GroupNorm partial sums from the epilogue, (c) slices, (d) Cin = 64
+    for (B, cin, cout, H, W, dil) in [(2, 128, 128, 144, 144, 1), (1, 64, 64, 96, 100, 1), (1, 256, 256, 144, 144, 2)]:
+        x, wu, wf, w3 = pair(B, cin, cout, H, W, dil)
+        sh = torch.randn(cout, generator=g).to(dev)
+        y32 = ops.conv_wino_implicit(x, wf, cout, dil, shift=sh)
+        y3, st = ops.conv_wino_implicit(x, w3, cout, dil, shift=sh, gn_eps=1e-5)
+        _close(y3, y32, 3e-5, 'bf16x3 vs fp32')
+        _close(st, ops.gn_stats(y3, 1e-5), 2e-5, 'gn stats from the split kernel\'s epilogue')
+        y4, st2 = ops.conv_wino_implicit(x, w3, cout, dil, shift=sh, gn_eps=1e-5)
+        assert torch.equal(y3, y4) and torch.equal(st, st2)                      # deterministic
+        wide = ops.new_act(B, cin + 32, H, W, dev).normal_()
+        wide[:, 16:16 + cin].copy_(x)
+        outw = ops.new_act(B, cout + 8, H, W, dev).zero_()
+        ops.conv_wino_implicit(wide[:, 16:16 + cin], w3, cout, dil, shift=sh, out=outw[:, 4:4 + cout])
+        assert torch.equal(outw[:, 4:4 + cout], y3) and float(outw[:, :4].abs().max()) == 0 and float(outw[:, 4 + cout:].abs().max()) == 0
+    # (e) a channel count that is no multiple of 4 or 64: the element-wise tail of the epilogue
+    x, wu, wf, w3 = pair(1, 64, 70, 50, 46, 1)
+    res = ops.new_act(1, 70, 50, 46, dev).normal_()
+    _close(ops.conv_wino_implicit(x, w3, 70, 1, res=res, act=ops.ACT_RELU), ops.conv_wino_implicit(x, wf, 70, 1, res=res, act=ops.ACT_RELU), 3e-5,
+           'bf16x3 odd channel count')
+
+
 @pytest.mark.parametrize('seed', [3001, 3002])
 def test_full_tiles_other_seeds_vs_oracle(dev, net, synth_sd, seed):
     """Full 1152^2 tiles the goldens do not cover: raw outputs within 1e-4 of the tensor scale, and every integer decision
