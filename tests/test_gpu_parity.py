@@ -887,12 +887,16 @@ def test_bench_default_command(dev):
     rf = d['roofline']
     assert {'bound', 'achieved', 'peak', 'unit', 'frac', 'traffic', 'algorithmic_equiv_tflops', 'per_kernel'} <= set(rf)
     assert 0.0 < rf['frac'] <= 1.0 and abs(rf['frac'] - rf['achieved'] / rf['peak']) < 1e-9
-    assert rf['algorithmic_equiv_tflops'] >= rf['achieved']
+    split_run = os.environ.get('LANEMAP_WINO_BF16X3', '0') != '0'       # the suite itself run under the switch: that process IS the split line
+    assert split_run or rf['algorithmic_equiv_tflops'] >= rf['achieved']
     assert all(0.0 <= v['frac'] <= 1.0 for v in rf['per_kernel'].values())
     rr = d['raster_roofline']
     assert rr['bound'] == 'hbm' and 0.1 < rr['frac'] < 1.0
     assert {'value', 'unit', 'cores', 'kind', 'sample'} <= set(d['cpu_baseline']) and d['cpu_baseline']['value'] > 0
     # the declared second line: the same workload with the split-precision Winograd GEMMs, priced against the bf16 peak; never the headline
+    if split_run:
+        assert d['dtype'] == 'bf16x3' and 'second_line' not in d and rf['peak'] > 1000
+        return
     assert d['dtype'] == 'f32'
     sl = d['second_line']
     assert 'error' not in sl, sl
@@ -1355,7 +1359,7 @@ def test_bench_other_workloads(dev, workload):
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     r = subprocess.run([sys.executable, os.path.join(root, 'bench.py'), '--workload', workload, '--steps', '2', '--warmup', '1',
-                        '--no-cpu-baseline'], capture_output=True, text=True, timeout=900, cwd=root)
+                        '--no-cpu-baseline', '--no-second-line'], capture_output=True, text=True, timeout=900, cwd=root)
     assert r.returncode == 0, r.stderr[-2000:]
     d = json.loads([l for l in r.stdout.strip().split('\n') if l.startswith('{')][-1])
     assert d['value'] > 10 and 0.0 < d['roofline']['frac'] <= 1.0 and d['config']['tiles_per_step_per_gpu'] == 8
@@ -1447,7 +1451,7 @@ def test_bench_hip_graphs_four_streams(dev):
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     r = subprocess.run([sys.executable, os.path.join(root, 'bench.py'), '--workload', 'tiles', '--graphs', '--steps', '3', '--warmup', '1',
-                        '--no-cpu-baseline'], capture_output=True, text=True, timeout=900, cwd=root)
+                        '--no-cpu-baseline', '--no-second-line'], capture_output=True, text=True, timeout=900, cwd=root)
     assert r.returncode == 0, r.stderr[-2000:]
     d = json.loads([l for l in r.stdout.strip().split('\n') if l.startswith('{')][-1])
     assert d['value'] > 10 and d['config']['hip_graphs'] is True and d['config']['streams'] == 4
