@@ -499,7 +499,8 @@ def main():
     except (OSError, ValueError):
         pass
     mfma_traffic = pmc.get('mfma_bytes_per_step')
-    traffic_stale = pmc.get('csrc_sha16') != csrc_sha16()      # the counters were collected on other kernel sources than the ones that ran
+    # the counters were collected on other kernel sources than the ones that ran (None: no counters were collected for this workload)
+    traffic_stale = (pmc.get('csrc_sha16') != csrc_sha16()) if pmc else None
     n_lines = int(np.mean([(np.count_nonzero(l[:, :, 0] > 0, axis=1) >= 2).sum() for l, _ in last])) if last else 0
     what = {'tiles': 'pre-rasterised tile', 'fused': 'LAS points', 'lidar': 'LiDAR point cloud', 'rowref': 'pre-rasterised tile'}[args.workload]
     workload = {
