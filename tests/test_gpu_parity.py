@@ -1214,7 +1214,8 @@ def test_conv_winograd_implicit_bit_identical(dev, B, cin, cout, H, W, dil):
         assert torch.equal(st, st2)                          # deterministic
 
 
-@pytest.mark.parametrize('B,cin,cout,H,W,dil', [(2, 128, 128, 48, 44, 1), (1, 256, 200, 43, 61, 1), (1, 160, 256, 85, 87, 2), (2, 256, 512, 144, 144, 1)])
+@pytest.mark.parametrize('B,cin,cout,H,W,dil', [(2, 128, 128, 48, 44, 1), (1, 256, 200, 43, 61, 1), (1, 160, 256, 85, 87, 2), (2, 256, 512, 144, 144, 1),
+                                                (1, 32, 64, 100, 96, 1), (2, 96, 32, 60, 90, 1)])      # (two slots; six slots, one N tile half empty)
 def test_conv_winograd_bf16x3_vs_fp64(dev, B, cin, cout, H, W, dil):
     """Opt-in split-precision kernel (lm_conv3x3_winograd_implicit_bf16x3: operands split exactly into three bf16 pieces, six bf16 MFMA
     products per multiply, fp32 accumulation): within 1e-4 of the tensor scale of the fp64 convolution - the tolerance the fp32 kernels
