@@ -193,6 +193,15 @@ def main():
                          f'or `python -m torch.distributed.run --nproc-per-node N bench.py --gpus N`')
     # ---- per-rank host budget (nothing has touched the GPU yet: no HIP call, no torch.cuda.is_available)
     cores_avail = usable_cores()
+    affinity0 = set(os.sched_getaffinity(0)) if hasattr(os, 'sched_getaffinity') else None     # (restored for the cpu_baseline leg)
+    host_cores_auto = False
+    if world > 1 and args.host_cores is None:
+        # several ranks on one node share its host cores: without a budget every rank would start 8 post-processing threads (72 threads
+        # on the 16 usable cores of an 8-GPU box).  Each rank takes its slice, exactly as `--host-cores K` does on one GPU.
+        local_world = int(os.environ.get('LOCAL_WORLD_SIZE', world))
+        k_auto = max(1, cores_avail // max(1, local_world))
+        if k_auto <= 8:
+            args.host_cores, host_cores_auto = k_auto, True
     if args.host_cores is not None:
         if args.host_cores < 1:
             raise SystemExit('--host-cores must be >= 1')
@@ -523,6 +532,7 @@ def main():
                   
                    'stream_check': stream_check, 'gather_check': gather_check, 'raster_check': raster_check,
                    'host_cores_per_rank': host_cores_per_rank, 'host_cores_pinned': args.host_cores is not None,
+                   'host_cores_auto': host_cores_auto,       # N > 1 without --host-cores: usable cores / ranks on the node
                    'host_postproc_ms_per_tile': 1e3 * sum(p_.host_seconds for p_ in [pipe] + extra_pipes) /
                    max(1, sum(p_.host_tiles for p_ in [pipe] + extra_pipes))},
         'roofline': {'bound': 'mfma',
@@ -572,6 +582,8 @@ def main():
     if rank == 0:
         # the CPU path timed on this node's own host cores in the same run, next to the 1 / 2 / 4 / 8-GPU numbers (north_star); at N > 1
         # the other ranks are parked in the barrier below meanwhile, so the oracle has the host to itself
+        if not args.no_cpu_baseline and affinity0 is not None and args.host_cores is not None:
+            os.sched_setaffinity(0, affinity0)          # the CPU path gets the node's cores back, not this rank's slice
         result['cpu_baseline'] = None if args.no_cpu_baseline else cpu_baseline(args.cpu_budget_s)
         print(json.dumps(result), flush=True)
     if world > 1:

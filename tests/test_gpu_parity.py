@@ -1171,6 +1171,9 @@ def test_bench_two_ranks_code_path(dev):
     # (N > 1 lines carry the CPU baseline too: north_star wants it timed on the node's own host cores in the same run)
     assert d['n_gpus'] == 2 and d['steps'] == 3 and d['cpu_baseline'] is not None and d['cpu_baseline']['value'] > 0 and d['value'] > 10
     assert d['config']['gather_check'].startswith('last all-gather: 32 valid tiles in one [32, 169992] byte block')
+    # several ranks on a node split its host cores (no --host-cores given): each took its slice; the CPU baseline ran on all of them
+    assert d['config']['host_cores_auto'] is True and d['config']['host_cores_pinned'] is True
+    assert d['config']['host_cores_per_rank'] <= 8 and d['cpu_baseline']['cores'] >= d['config']['host_cores_per_rank']
     assert d['config']['raster_check'].startswith('tiles 0 and 15 of the last timed 16 x 4194304-point launch equal oracle/raster_ref.c')
 
 
