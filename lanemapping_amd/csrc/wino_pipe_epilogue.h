@@ -1,4 +1,5 @@
-// Epilogue shared by wino_pipe_kernel and wino_pipe_split_kernel (conv_wino.hip), #included INSIDE the kernel bodies: it uses their local
+// Epilogue of wino_pipe_kernel (conv_wino.hip), #included INSIDE the kernel body (a file of its own since a split-precision kernel of the
+// same geometry shared it in round 3; that kernel was superseded by wino_rows_split_kernel): it uses the kernel's local
 // names (acc[16] accumulators, smem, wave, lane, frow, fhalf, n0, wn0, p, g, ts / sn / oy0 / ox0 run table, img_pix0, bi, t0).
 // Fold of the 16 Winograd products into the 2x2 outputs in ascending xi (exact +-1 coefficients), wave-private LDS transposes, BN scale /
 // shift, residual (its loads issued before the fold of each output position), ReLU, 16-byte stores, optional GroupNorm partial sums.
