@@ -114,6 +114,25 @@ def self_launch(args):
     sys.exit(max(abs(c) for c in codes))
 
 
+def host_budget(world, local_world, local_rank, cores_avail, allowed, host_cores, no_graphs, workload):
+    """Per-rank host budget, decided before anything touches the GPU.  `--host-cores K` (the 1-GPU proxy of a rank on a shared node) or,
+    when several ranks were launched without it, this rank's slice of the node: usable cores / ranks on the node, if that is <= 8
+    (8 ranks x 8 pool threads on the 16 usable cores of a box otherwise).  -> {'k': cores, 'cores': the CPU ids to pin to (None = leave
+    the affinity alone), 'graphs': switch HIP graphs on (k <= 4: one launch per sub-batch instead of ~350), 'auto': decided here}"""
+    auto = False
+    if world > 1 and host_cores is None:
+        k_auto = max(1, cores_avail // max(1, local_world))
+        if k_auto <= 8:
+            host_cores, auto = k_auto, True
+    if host_cores is None:
+        return {'k': None, 'cores': None, 'graphs': False, 'auto': False}
+    if host_cores < 1:
+        raise SystemExit('--host-cores must be >= 1')
+    k = min(host_cores, len(allowed))
+    mine = allowed[(local_rank * k) % len(allowed):][:k] or allowed[:k]
+    return {'k': k, 'cores': mine, 'graphs': k <= 4 and not no_graphs and workload in ('fused', 'tiles', 'rowref'), 'auto': auto}
+
+
 def second_line(args):
     """The declared SECOND measurement (route b): the same workload, same steps, with the Winograd GEMMs on the bf16
     matrix cores through exact three-way operand splits (LANEMAP_WINO_BF16X3=1, csrc/conv_wino.hip wino_rows_split_kernel).  Its outputs
@@ -194,23 +213,14 @@ def main():
     # ---- per-rank host budget (nothing has touched the GPU yet: no HIP call, no torch.cuda.is_available)
     cores_avail = usable_cores()
     affinity0 = set(os.sched_getaffinity(0)) if hasattr(os, 'sched_getaffinity') else None     # (restored for the cpu_baseline leg)
-    host_cores_auto = False
-    if world > 1 and args.host_cores is None:
-        # several ranks on one node share its host cores: without a budget every rank would start 8 post-processing threads (72 threads
-        # on the 16 usable cores of an 8-GPU box).  Each rank takes its slice, exactly as `--host-cores K` does on one GPU.
-        local_world = int(os.environ.get('LOCAL_WORLD_SIZE', world))
-        k_auto = max(1, cores_avail // max(1, local_world))
-        if k_auto <= 8:
-            args.host_cores, host_cores_auto = k_auto, True
-    if args.host_cores is not None:
-        if args.host_cores < 1:
-            raise SystemExit('--host-cores must be >= 1')
-        allowed = sorted(os.sched_getaffinity(0))
-        k = min(args.host_cores, len(allowed))
-        mine = allowed[(local_rank * k) % len(allowed):][:k] or allowed[:k]
-        os.sched_setaffinity(0, set(mine))
-        torch.set_num_threads(max(1, k))
-        if k <= 4 and not args.no_graphs and args.workload in ('fused', 'tiles', 'rowref'):
+    hb = host_budget(world, int(os.environ.get('LOCAL_WORLD_SIZE', world)), local_rank, cores_avail, sorted(os.sched_getaffinity(0)),
+                     args.host_cores, args.no_graphs, args.workload)
+    host_cores_auto = hb['auto']
+    if hb['cores'] is not None:
+        args.host_cores = hb['k']
+        os.sched_setaffinity(0, set(hb['cores']))
+        torch.set_num_threads(max(1, hb['k']))
+        if hb['graphs']:
             args.graphs = True
     host_cores_per_rank = len(os.sched_getaffinity(0)) if args.host_cores is not None else min(cores_avail, len(os.sched_getaffinity(0)))
     if args.host_threads is None:

@@ -861,3 +861,29 @@ def test_winograd_weight_packers_layout_and_exact_split():
     total = (back[0] + back[1] + back[2]).float()                                 # three bf16 values: their fp64 sum is exact
     assert torch.equal(total, wu), float((total - wu).abs().max())
     assert float(back[1].abs().max()) <= float(back[0].abs().max()) * 2.0 ** -7 and float(back[2].abs().max()) <= float(back[0].abs().max()) * 2.0 ** -15
+
+
+def test_bench_host_budget_per_rank():
+    """bench.py's per-rank host budget (pure function, decided before the GPU is touched): an 8-rank launch on a box with 16 usable cores
+    gives every rank its own 2 cores, a 1-thread pool and HIP graphs; 2 ranks get 8 each without graphs; a roomy node is left alone;
+    `--host-cores` wins over the automatic choice; one rank never pins itself."""
+    import importlib.util
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location('bench_mod', os.path.join(root, 'bench.py'))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    allowed = list(range(256))
+    seen = set()
+    for r in range(8):
+        hb = bench.host_budget(8, 8, r, 16, allowed, None, False, 'fused')
+        assert hb['auto'] and hb['k'] == 2 and hb['graphs'] and len(hb['cores']) == 2 and not (seen & set(hb['cores']))
+        seen |= set(hb['cores'])
+    hb = bench.host_budget(2, 2, 1, 16, allowed, None, False, 'fused')
+    assert hb['auto'] and hb['k'] == 8 and not hb['graphs'] and hb['cores'] == list(range(8, 16))
+    assert bench.host_budget(8, 8, 3, 128, allowed, None, False, 'fused') == {'k': None, 'cores': None, 'graphs': False, 'auto': False}
+    hb = bench.host_budget(8, 8, 3, 128, allowed, 4, False, 'tiles')
+    assert not hb['auto'] and hb['k'] == 4 and hb['graphs'] and hb['cores'] == [12, 13, 14, 15]
+    assert not bench.host_budget(8, 8, 0, 16, allowed, None, True, 'fused')['graphs']            # --no-graphs
+    assert not bench.host_budget(8, 8, 0, 16, allowed, None, False, 'lidar')['graphs']           # the LiDAR path is not captured
+    assert bench.host_budget(1, 1, 0, 16, allowed, None, False, 'fused')['cores'] is None
+    assert bench.host_budget(1, 1, 0, 16, [0, 1, 2], 8, False, 'fused')['k'] == 3                # never more than the mask allows
