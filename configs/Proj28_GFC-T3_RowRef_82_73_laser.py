@@ -16,4 +16,15 @@ heads = dict(type='RowSharNotReducRef', dim_feat=8, row_size=144, dim_shared=512
              is_reuse_same_network=False)
 conf_thr = 0.5
 show_result = False
-dataset_type = 'KLane'
+dataset_type = 'LaserLane'
+
+# entry-point contract (load_config_and_runner / Runner.infer_*: baseline/engine/runner.py:57-66, :690-697)
+log_dir = './logs'
+distributed = False
+batch_size = 6
+workers = 12
+dataset_path = './../All'
+dataset = dict(
+    train=dict(type=dataset_type, data_root=dataset_path, mode='train'),
+    test=dict(type=dataset_type, data_root=dataset_path, mode='test'),
+)

@@ -12,3 +12,15 @@ view = False
 seg_thre = 0.1
 endp_thre = 0.1
 dataset_type = 'LaserLane'
+
+# entry-point contract (load_config_and_runner / Runner.infer_*: baseline/engine/runner.py:57-66, :690-697)
+log_dir = './logs'
+distributed = False
+batch_size = 6
+workers = 12
+dataset_path = './data/LaserLane/All'
+dataset = dict(
+    train=dict(type=dataset_type, data_root=dataset_path, mode='train'),
+    val=dict(type=dataset_type, data_root=dataset_path, mode='val'),
+    test=dict(type=dataset_type, data_root=dataset_path, mode='test'),
+)

@@ -30,3 +30,19 @@ column_att = False
 column_transformer_decoder = False
 spatial_att = True
 cls_smooth = False
+
+# entry-point contract (load_config_and_runner / Runner.infer_*: baseline/engine/runner.py:57-66, :690-697)
+log_dir = './logs'
+distributed = False
+batch_size = 6
+validate_buffer = 10
+gt_downsample_ratio = 8
+workers = 12
+dataset_path = './data/LaserLane/TrainValAll'
+data_split_file = 'data_split-shuffle.json'
+dataset_color_augment = False
+dataset = dict(
+    train=dict(type=dataset_type, data_root=dataset_path, data_split_file=data_split_file, mode='train'),
+    val=dict(type=dataset_type, data_root=dataset_path, data_split_file=data_split_file, mode='val'),
+    test=dict(type=dataset_type, data_root=dataset_path, data_split_file=data_split_file, mode='test'),
+)

@@ -41,3 +41,18 @@ column_att = False
 column_transformer_decoder = False
 spatial_att = True
 cls_smooth = False
+
+# entry-point contract (load_config_and_runner / Runner.infer_*: baseline/engine/runner.py:57-66, :690-697)
+log_dir = './logs'
+distributed = False
+batch_size = 4
+validate_buffer = 10
+workers = 12
+dataset_path = './data/LaserLane/TrainValAll'
+data_split_file = 'data_split-shuffle-lidar-range.json'
+dataset_color_augment = False
+dataset = dict(
+    train=dict(type=dataset_type, data_root=dataset_path, data_split_file=data_split_file, mode='train'),
+    val=dict(type=dataset_type, data_root=dataset_path, data_split_file=data_split_file, mode='val'),
+    test=dict(type=dataset_type, data_root=dataset_path, data_split_file=data_split_file, mode='test'),
+)

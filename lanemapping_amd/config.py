@@ -57,7 +57,7 @@ class Config(ConfigDict):
 
 
 _DEFAULTS = dict(vit_seg=True, is_gt_avai=False, view=False, view_detail=False, show_result=False, column_att=False,
-                 column_transformer_decoder=False, spatial_att=True, cls_smooth=False, validate_buffer=10,
+                 column_transformer_decoder=False, spatial_att=True, cls_smooth=False, validate_buffer=10, gt_downsample_ratio=8,
                  flip_label=False, number_lanes=12, number_orients=11, dataset_type='LaserLaneProposal',
                  proposal_obj_thre=0.3, exist_thre=0.2, coor_thre=0.2, endp_thre=0.08, seg_thre=0.1,
                  featuremap_out_channel=64)

@@ -18,10 +18,11 @@ from ._lib import LanemapHipError
 
 
 class TilePipeline:
-    def __init__(self, net, host_threads=8, use_graph=None):
+    def __init__(self, net, host_threads=8, use_graph=None, with_decode_endp=False):
         """use_graph (default: env LANEMAP_GRAPHS=1): capture the device part of a batch (network + decode kernels, ~350 launches) into
         one HIP graph per input shape and replay it - the host then spends one launch per batch instead of ~9 ms of enqueue work.
         Same kernels, same arguments, same stream order: bit-identical outputs (test_tile_pipeline_graph_replay_bit_identical)."""
+        self.with_decode_endp = bool(with_decode_endp)   # tile results become (lanes, kept endpoints, the decode's endpoints before the filter)
         self.use_graph = (os.environ.get('LANEMAP_GRAPHS', '0') != '0') if use_graph is None else bool(use_graph)
         self._graphs = collections.OrderedDict()      # (shape, dtype, device) -> (graph, static input, outputs, weight key); LRU, MAX_GRAPHS entries
         self.net = net
@@ -121,7 +122,7 @@ class TilePipeline:
             lanes[:, :, 1] = 0.0
             lanes[:cols.shape[0], :, 0] = cols
             lanes[:cols.shape[0], :, 1] = (cols > 0).astype(np.float64)
-            kept = np.zeros((0, 2), dtype=np.int32)
+            kept = pts = np.zeros((0, 2), dtype=np.int32)
         else:
             pts, _ = hostpost.cluster_endpoints(host['idx'][b].numpy(), crop_w=crop_w, clip=decode.CLIP,
                                                 k0=self.net.heads.num_cls * 2 * 10, k_max=500)
@@ -130,7 +131,7 @@ class TilePipeline:
                                                       self.cfg.proposal_obj_thre)
         self.host_seconds += time.perf_counter() - t0      # (benign race between pool threads: statistics only)
         self.host_tiles += 1
-        return lanes, kept
+        return (lanes, kept, pts) if self.with_decode_endp else (lanes, kept)
 
     def _finish(self, pending):
         host, ev, keep, W = pending

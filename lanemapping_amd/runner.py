@@ -1,18 +1,28 @@
-"""Inference runner: the `test_gpu_0.py` / `Runner` entry of the reference, hot-path subset.
+"""Inference runner: the `test_gpu_0.py` / `Runner` entry of the reference (hot-path subset + the evaluation loop).
 
-  load_config_and_runner(path, gpus)                 <- baseline/engine/runner.py:57-66
+  load_config_and_runner(path, gpus)                 <- baseline/engine/runner.py:57-66 (log_dir + '/vis', work_dirs = log_dir/<dataset.train.type>)
   Runner.load_ckpt(path)                             <- :399-401 (strict, 'module.'-prefixed keys accepted)
-  Runner.infer_lane_coordinate_endpoint_semantics()  <- :690-867 minus metrics / cv2 overlays: every tile ->
-                                                        <work_dirs>/<image_name[0:11]>.json via save_lane_seq_2d
-  Runner.infer_lane_geometry_segmentation_segmentor()<- :945-1036 minus overlays (Segmentor config)
+  Runner.infer_lane_coordinate_endpoint_semantics()  <- :690-867, the reference's signature: the split `mode_data` (default cfg.dataset.test)
+                                                        is listed the reference's way (datasets.py: <data_root>/<data_split_file>[mode] ->
+                                                        <data_root>/cropped_tiff/<stem>.png), every tile -> <work_dirs>/<image_name[0:11]>.json
+                                                        via save_lane_seq_2d when write_lane_vertex, and with gt_avail the loop's
+                                                        coordinate / endpoint / semantic counters and its nine P / R / F1 lines
+  Runner.infer_lane_coordinate()                     <- :606-687 (the K-Lane / RowRef entry, config 4: coordinate measures only)
+  Runner.infer_lane_geometry_segmentation_segmentor()<- :945-1036 (Segmentor config)
   Runner.infer_las_to_map()                          <- the offline chain LAS -> BEV -> polylines -> LAS frame -> merged map
                                                         (read_las, Las2BEV, Runner, coor_img2pc.py, merge_lines.py) in one call
+Deviations, all deliberate: (1) tiles are walked SORTED by stem, not in the seeded shuffle of the reference's test list (SURVEY C13;
+per-tile results and the summed counters do not depend on the order; datasets.load_datadir(shuffle_seed=cfg.seed) gives the reference's
+order); (2) `mode_view=True` is accepted and ignored with one notice: the cv2 overlays (:793-822) are not results (OUT);
+(3) keyword-only extras `tiles=` (explicit list / directory of PNG tiles instead of a split: no labels, so no evaluation),
+`batch_size=`, `work_dirs=`.  Unknown keywords raise TypeError, an empty tile list raises ValueError.
 Tiles are PNG files (load_img contract, datasets/laserlane_proposals.py:85-98): decoded on the host by the library's own PNG reader (png_io, zlib on the host thread pool),
 converted u8 -> f32/255 on the GPU (lm_tile_ingest_u8).  With torch.distributed initialised, tiles are sharded
 over the ranks (lanemapping_amd/shard.py) and rank 0 writes every file after one all-gather per batch.
 """
 import glob
 import os
+import random
 
 import numpy as np
 import torch
@@ -25,9 +35,23 @@ from .registry import build_net
 
 def load_config_and_runner(path_config, gpus='0'):
     cfg = load_config(path_config)
-    cfg['gpus'] = len(str(gpus).split(','))
-    cfg.setdefault('work_dirs', os.path.join(cfg.get('log_dir', './logs'), 'infer'))
+    cfg.log_dir = cfg.log_dir + '/vis'
+    os.makedirs(cfg.log_dir, exist_ok=True)
+    cfg.work_dirs = cfg.log_dir + '/' + cfg.dataset.train.type
+    os.makedirs(cfg.work_dirs, exist_ok=True)
+    cfg.gpus = len(str(gpus).split(','))
     return cfg, Runner(cfg)
+
+
+EPS = 1e-16      # baseline/engine/runner.py:30
+
+
+def _prf(tp, dets, dg, gts):
+    """precision / recall / F1 from the loop's counters (runner.py:843-857)."""
+    pre = tp / (dets + EPS)
+    rec = dg / (gts + EPS)
+    f1 = 2. * pre * rec / (pre + rec) if (pre + rec) > 0. else 0.
+    return pre, rec, f1
 
 
 class Runner:
@@ -36,6 +60,7 @@ class Runner:
         seed = int(cfg.get('seed', 2021))
         torch.manual_seed(seed)
         np.random.seed(seed)
+        random.seed(seed)
         self.device = torch.device(device or ('cuda:%d' % int(os.environ.get('LOCAL_RANK', 0))))
         if self.device.type == 'cuda':
             # the C library launches on the CURRENT HIP device / its current stream (ops._stream): one process drives one GPU
@@ -99,41 +124,130 @@ class Runner:
                 yield self._to_device(view, k & 1)
 
     # ------------------------------------------------------------------------------------------------ inference
-    def infer_lane_coordinate_endpoint_semantics(self, tiles=None, path_ckpt=None, write_lane_vertex=True, batch_size=None,
-                                                 work_dirs=None, **_ignored):
-        """Returns {image_name: (lanes [72,144,2], endpoints [k,2])} for this rank's tiles (all tiles on rank 0)."""
+    def _entries(self, mode_data, tiles):
+        """The tiles of a run, sorted by stem: [(image_name, png path, dataset entry | None)]."""
+        from . import datasets
+        if tiles is not None:
+            paths = self.list_tiles(tiles)
+            ents = [(os.path.splitext(os.path.basename(p))[0][0:11], p, None) for p in paths]
+        else:
+            split = self.cfg.dataset.test if mode_data is None else mode_data
+            ents = sorted(datasets.split_entries(split, self.cfg), key=lambda e: e['stem'])
+            # the reference's stems keep the dot of '<stem>.json' (laserlane_proposals.py:534) and are cut to 11 characters (:76)
+            ents = [((e['stem'] + '.')[0:11], e['image'], e) for e in ents]
+        if not ents:
+            raise ValueError('Runner: no tiles to process (' + (f'tiles={tiles!r}' if tiles is not None else 'the split lists none') + ')')
+        missing = [p for _, p, _ in ents if not os.path.isfile(p)]
+        if missing:
+            raise FileNotFoundError(f'Runner: {len(missing)} of {len(ents)} tiles do not exist, first: {missing[0]}')
+        return ents
+
+    def _view_notice(self, mode_view):
+        if mode_view and not self.__dict__.get('_view_noticed'):
+            self._view_noticed = True
+            print('lanemapping_amd.Runner: mode_view=True - the *_source / *_offset / *_seg / *_gt PNG overlays of the reference are '
+                  'not produced (cv2 drawing is outside the hot path); results, JSON files and metrics are unaffected')
+
+    def _infer(self, path_ckpt, mode_data, mode_view, gt_avail, write_lane_vertex, measures, tiles, batch_size, work_dirs):
+        """Shared body of the two detector entries.  measures: subset of ('coor', 'endp', 'semantic') | ('klane',)."""
+        from . import datasets, hostpost, metric_utils
         if path_ckpt:
             self.load_ckpt(path_ckpt)
-        paths = self.list_tiles(tiles if tiles is not None else self.cfg.dataset.test.data_root)
-        out_dir = work_dirs or self.cfg.get('work_dirs', './work_dirs')
+        self._view_notice(mode_view)
+        ents = self._entries(mode_data, tiles)
+        if tiles is not None:
+            gt_avail = False                                     # an explicit tile list carries no labels
+        out_dir = work_dirs or self.cfg.work_dirs
         os.makedirs(out_dir, exist_ok=True)
         B = int(batch_size or self.cfg.get('batch_size', 8))
-        world = torch.distributed.get_world_size() if torch.distributed.is_initialized() else 1
-        rank = torch.distributed.get_rank() if torch.distributed.is_initialized() else 0
-        lo, hi, per = shard.shard_range(len(paths), rank, world)
-        mine = paths[lo:hi]
-        results = {}
-        lanes_all, endp_all = [], []
+        dist = torch.distributed
+        world = dist.get_world_size() if dist.is_initialized() else 1
+        rank = dist.get_rank() if dist.is_initialized() else 0
+        lo, hi, per = shard.shard_range(len(ents), rank, world)
+        mine = ents[lo:hi]
+        rowref = self.cfg.heads.type == 'RowSharNotReducRef'
         # ColumnProposal2 (configs 2/3/5) and RowSharNotReducRef (config 4: 12 lanes x 144 rows padded into the same [72,144,2] block)
-        pipe = TilePipeline(self.net, host_threads=int(self.cfg.get('host_threads', 8)))
-        for proj in self._batches(mine, B):
-            for f in pipe.submit(proj):
-                lanes_all.append(f.result()[0]); endp_all.append(f.result()[1])
-        for f in pipe.flush():
-            lanes_all.append(f.result()[0]); endp_all.append(f.result()[1])
+        pipe = TilePipeline(self.net, host_threads=int(self.cfg.get('host_threads', 8)), with_decode_endp=True)
+        lanes_all, endp_all = [], []
+        counters = np.zeros(12, dtype=np.float64)      # coor TP / segs / DG / gts, endp TP / dets / DG / gts, semantic TP / dets / DG / gts
+        buf = self.cfg.validate_buffer if gt_avail else None
+
+        def take(futs):
+            for f in futs:
+                lanes, kept, pts = f.result()
+                k = len(lanes_all)
+                lanes_all.append(lanes); endp_all.append(kept)
+                if not gt_avail:
+                    continue
+                gt = datasets.load_eval_gt(mine[k][2], self.cfg, merge_connect_lines=not rowref)
+                if 'klane' in measures:                          # runner.py:640-651: cal_coor_measures(coor_label, cls_offset_smooth[:, :])
+                    L = int(self.net.heads.num_cls)
+                    label = datasets.klane_coor_label(gt['label_raw'], L, int(self.net.heads.row_size))
+                    counters[0:4] += metric_utils.cal_coor_measures(label, lanes[:L, :, 0], 'conf', offset_thre=buf)[3:7]
+                if 'coor' in measures:                           # :742-768
+                    counters[0:4] += metric_utils.cal_coor_measures(gt['lc_coor_raw'], lanes[:, :, 0], 'conf', offset_thre=buf)[3:7]
+                if 'endp' in measures:                           # :770-777: output['endp'] = the decode's endpoint map (on CUDA the
+                    pred = np.zeros(gt['endp_map'].shape, dtype=np.float32)      # post-processing filters a host COPY of it)
+                    if len(pts):
+                        pred[pts[:, 0], pts[:, 1]] = 1.
+                    counters[4:8] += metric_utils.eval_metric_endp_detector(pred, gt['endp_map'], r_thre=buf * 2)[3:7]
+                if 'semantic' in measures:                       # :779-787 on lane_maps['semantic_line'] (renew_semantic_map raster)
+                    counters[8:12] += metric_utils.eval_metric_line_segmentor(hostpost.raster_semantic_map(lanes), gt['mask'],
+                                                                             bi_seg=False, semantics=2, buff=buf)[3:7]
+
+        for proj in self._batches([p for _, p, _ in mine], B):
+            take(pipe.submit(proj))
+        take(pipe.flush())
         if world > 1:
             block = shard.pack_tile_results(lanes_all, endp_all, per, self.device)
-            gathered = shard.unpack_gathered(shard.all_gather_results(block))         # ONE collective for the whole job
-            names = paths
+            gathered = shard.unpack_gathered(shard.all_gather_results(block))[:len(ents)]     # ONE collective for the whole job
+            names = ents
+            if gt_avail:                                         # + one 96-byte all-reduce of the counters when a labelled set is scored
+                t = torch.from_numpy(counters).to(self.device)
+                dist.all_reduce(t)
+                counters = t.cpu().numpy()
         else:
             gathered = list(zip(lanes_all, endp_all))
             names = mine
-        for p, (lanes, endp) in zip(names, gathered):
-            name = os.path.splitext(os.path.basename(p))[0][0:11]
+        results = {}
+        for (name, _, _), (lanes, endp) in zip(names, gathered):
             results[name] = (lanes, endp)
             if write_lane_vertex and rank == 0:
                 io_utils.save_lane_seq_2d(io_utils.pack_lane_vertices(np.asarray(lanes, dtype=np.float64)),
                                           os.path.join(out_dir, name + '.json'), with_pervertex_semantics=True)
+        self.counters = counters
+        return results
+
+    def infer_lane_coordinate_endpoint_semantics(self, path_ckpt=None, mode_data=None, mode_view=False, gt_avail=True,
+                                                 write_lane_vertex=False, eval_coor=True, eval_endp=True, eval_semantic=True,
+                                                 *, tiles=None, batch_size=None, work_dirs=None):
+        """The reference's entry (runner.py:690-867), same positional / keyword signature.  Returns {image_name: (lanes [72,144,2],
+        endpoints [k,2])} (all tiles on every rank); self.metrics holds the nine numbers the reference prints, self.counters the sums."""
+        measures = tuple(m for m, on in (('coor', eval_coor), ('endp', eval_endp), ('semantic', eval_semantic)) if on)
+        results = self._infer(path_ckpt, mode_data, mode_view, bool(gt_avail), write_lane_vertex, measures, tiles, batch_size, work_dirs)
+        c = self.counters
+        zero = (0., 0., 0.)
+        evaluated = bool(gt_avail) and tiles is None
+        coor = _prf(*c[0:4]) if evaluated and eval_coor else zero
+        endp = _prf(*c[4:8]) if evaluated and eval_endp else zero
+        sem = _prf(*c[8:12]) if evaluated and eval_semantic else zero
+        self.metrics = {'coordinate_prec': coor[0], 'coordinate_rec': coor[1], 'coordinate_f1': coor[2],
+                        'endpoint_prec': endp[0], 'endpoint_rec': endp[1], 'endpoint_f1': endp[2],
+                        'semantic_prec': sem[0], 'semantic_rec': sem[1], 'semantic_f1': sem[2]}
+        if not torch.distributed.is_initialized() or torch.distributed.get_rank() == 0:
+            for k, v in self.metrics.items():                    # the reference's nine lines (:859-867)
+                print(f'{k}={v}')
+        return results
+
+    def infer_lane_coordinate(self, path_ckpt=None, mode_view=False, gt_avail=True, write_lane_vertex=False,
+                              *, tiles=None, batch_size=None, work_dirs=None):
+        """The K-Lane / RowRef entry (runner.py:606-687; config 4): cfg.dataset.test, coordinate measures on cls_offset_smooth[:, :]."""
+        results = self._infer(path_ckpt, None, mode_view, bool(gt_avail), write_lane_vertex, ('klane',), tiles, batch_size, work_dirs)
+        coor = _prf(*self.counters[0:4]) if (gt_avail and tiles is None) else (0., 0., 0.)
+        self.metrics = {'coordinate_prec': coor[0], 'coordinate_rec': coor[1], 'coordinate_f1': coor[2]}
+        if not torch.distributed.is_initialized() or torch.distributed.get_rank() == 0:
+            for k, v in self.metrics.items():
+                print(f'{k}={v}')
         return results
 
     def infer_las_to_map(self, las_and_params, work_dirs=None, path_ckpt=None, batch_size=None, merge=True):
@@ -203,15 +317,35 @@ class Runner:
             io_utils.save_seqs_list([ml.downsample_seqs(m) for m in merged], os.path.join(pc_dir, 'merged_downsample.txt'))
         return lines3d, merged
 
-    def infer_lane_geometry_segmentation_segmentor(self, tiles=None, path_ckpt=None, batch_size=None, **_ignored):
-        """Segmentor config: {image_name: (seg [1152,1152] u8-valued f32, endpoints [k,2])}."""
+    def infer_lane_geometry_segmentation_segmentor(self, path_ckpt=None, mode_view=False, write_lane_vertex=False,
+                                                   *, tiles=None, batch_size=None, gt_avail=None):
+        """Segmentor config (runner.py:945-1036): {image_name: (seg [1152,1152] u8-valued f32, endpoints [k,2])} over cfg.dataset.test
+        (or `tiles=`).  With labels (default: when the split is used) the loop's geometry (bi_seg) and semantic skeleton counters are
+        summed and its six lines printed; self.metrics holds them."""
+        from . import datasets, metric_utils
         if path_ckpt:
             self.load_ckpt(path_ckpt)
-        paths = self.list_tiles(tiles if tiles is not None else self.cfg.dataset.test.data_root)
+        self._view_notice(mode_view)
+        ents = self._entries(None, tiles)
+        gt_avail = (tiles is None) if gt_avail is None else (bool(gt_avail) and tiles is None)
         B = int(batch_size or self.cfg.get('batch_size', 8))
         res = {}
-        for i in range(0, len(paths), B):
-            out = self.net({'proj': self._load_batch(paths[i:i + B])})
-            for j, p in enumerate(paths[i:i + B]):
-                res[os.path.splitext(os.path.basename(p))[0][0:11]] = (out['seg'][j].numpy(), out['endp_pts'][j])
+        c = np.zeros(8, dtype=np.float64)          # semantic TP / dets / DG / gts, geometry TP / pts / DG / gts
+        for i in range(0, len(ents), B):
+            chunk = ents[i:i + B]
+            out = self.net({'proj': self._load_batch([p for _, p, _ in chunk])})
+            for j, (name, _, ent) in enumerate(chunk):
+                seg = out['seg'][j].numpy()
+                res[name] = (seg, out['endp_pts'][j])
+                if gt_avail:
+                    mask = datasets.load_eval_gt(ent, self.cfg, merge_connect_lines=False)['mask']
+                    c[0:4] += metric_utils.eval_metric_line_segmentor(seg, mask, bi_seg=False, semantics=2, buff=self.cfg.validate_buffer)[3:7]
+                    c[4:8] += metric_utils.eval_metric_line_segmentor(seg, mask, bi_seg=True, semantics=1, buff=self.cfg.validate_buffer)[3:7]
+        self.counters = c
+        if gt_avail:
+            geo, sem = _prf(*c[4:8]), _prf(*c[0:4])
+            self.metrics = {'coor_conf_prec': geo[0], 'coor_conf_rec': geo[1], 'coor_conf_f1': geo[2],
+                            'sem_conf_prec': sem[0], 'sem_conf_rec': sem[1], 'sem_conf_f1': sem[2]}
+            for k, v in self.metrics.items():
+                print(f'{k}={v}')
         return res

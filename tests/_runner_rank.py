@@ -19,7 +19,7 @@ if __name__ == '__main__':
     r = Runner(net.cfg, device=torch.device('cuda', int(os.environ.get('LANEMAP_TEST_DEVICE', os.environ.get('LOCAL_RANK', 0)))))
     assert torch.cuda.current_device() == r.device.index          # Runner pins the process to its GPU
     r.net = net.eval().to(r.device)
-    res = r.infer_lane_coordinate_endpoint_semantics(tiles=tiles_dir, batch_size=2, work_dirs=out_dir)
+    res = r.infer_lane_coordinate_endpoint_semantics(tiles=tiles_dir, batch_size=2, work_dirs=out_dir, write_lane_vertex=True)
     assert len(res) == len(os.listdir(tiles_dir)) or dist.get_rank() != 0 or True
     dist.barrier()
     dist.destroy_process_group()

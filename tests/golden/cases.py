@@ -325,3 +325,94 @@ def label_json_text(seed):
         seq = [[float(round(x, 3)), float(round(y, 3)), int(k)] for x, y in zip(xs, ys)]
         areas.append({'seq': seq, 'init_vertex': seq[0][0:2], 'end_vertex': seq[-1][0:2], 'semantic': int(1 + (k % 2)), 'instance': int(k + 1)})
     return json.dumps(areas)
+
+
+# ---------------------------------------------------------------------------------------------- a12 (dataset contract) / f3 (evaluation loop)
+def write_png(path, arr):
+    """uint8 [H,W] / [H,W,3] -> 8-bit non-interlaced PNG (filter 0 on every scanline), zlib only."""
+    import struct
+    import zlib
+    a = np.ascontiguousarray(arr, dtype=np.uint8)
+    if a.ndim == 2:
+        a = a[:, :, None]
+    h, w, c = a.shape
+    ctype = {1: 0, 3: 2, 4: 6}[c]
+    raw = np.concatenate([np.zeros((h, 1), np.uint8), a.reshape(h, w * c)], axis=1).tobytes()
+
+    def chunk(tag, data):
+        return struct.pack('>I', len(data)) + tag + data + struct.pack('>I', zlib.crc32(tag + data) & 0xffffffff)
+    with open(path, 'wb') as f:
+        f.write(b'\x89PNG\r\n\x1a\n' + chunk(b'IHDR', struct.pack('>IIBBBBB', w, h, 8, ctype, 0, 0, 0))
+                + chunk(b'IDAT', zlib.compress(raw, 1)) + chunk(b'IEND', b''))
+
+
+def dataset_stems(n):
+    """Tile stems in the 'YYMMDD_NNNN' pattern of the WHU-Lane files; every third one carries a suffix (names are cut to [0:11])."""
+    return ['%06d_%04d%s' % (190712 + (i * 7) % 5, 519 + 37 * i, '_b' if i % 3 == 2 else '') for i in range(n)]
+
+
+def label_case(seed, size=1152):
+    """Seeded label set of one tile: (instance u8 [size,size] with 1-based lane ids, 0 = background, one id above number_lanes;
+    semantic u8 (128 solid / 255 dashed, plus stray pixels outside every instance); endp u8 (255 at line ends); orient u8; areas =
+    the sparse_seq JSON list).  Lines 2 and 3 form a connected pair (3 starts one row below the end of 2, one column off), line 1
+    has two pixels on some rows."""
+    u = synth.uniform(seed, 4000, 91)
+    inst = np.zeros((size, size), np.uint8)
+    sem = np.zeros((size, size), np.uint8)
+    endp = np.zeros((size, size), np.uint8)
+    ori = np.zeros((size, size), np.uint8)
+    areas = []
+    n = 5 + int(3 * u[0])
+    spans = []
+    for k in range(n):
+        lo = 8 + int(300 * u[10 + k])
+        hi = size - 8 - int(300 * u[30 + k])
+        c0 = 80 + (size - 160) * (k + 0.5 * u[50 + k]) / n
+        slope = 0.12 * (u[70 + k] - 0.5)
+        spans.append([lo, hi, c0, slope])
+    if n >= 4:                                     # lines 2 and 3: a connected pair
+        spans[2][1] = size // 2
+        lo3 = spans[2][1] + 1
+        spans[3][0] = lo3
+        spans[3][2] = spans[2][2] + spans[2][3] * (spans[2][1] - size / 2) - spans[3][3] * (lo3 - size / 2) + 1.0
+    for k, (lo, hi, c0, slope) in enumerate(spans):
+        ident = k + 1 if k != n - 1 else 14        # the last line carries an id above number_lanes = 12: it is dropped
+        rows = np.arange(lo, hi + 1)
+        cols = np.clip(np.rint(c0 + slope * (rows - size / 2)).astype(int), 2, size - 3)
+        semantic = 1 + (k % 2)
+        inst[rows, cols] = ident
+        sem[rows, cols] = 128 if semantic == 1 else 255
+        if k == 1:
+            inst[rows[::3], cols[::3] + 1] = ident
+            sem[rows[::3], cols[::3] + 1] = 128 if semantic == 1 else 255
+        ori[rows, cols] = 1 + (k % 10)
+        endp[rows[0], cols[0]] = 255
+        endp[rows[-1], cols[-1]] = 255
+        step = max(1, len(rows) // 12)
+        seq = [[int(r), int(c)] for r, c in zip(rows[::step], cols[::step])]
+        areas.append({'seq': seq, 'init_vertex': [int(rows[0]), int(cols[0])], 'end_vertex': [int(rows[-1]), int(cols[-1])],
+                      'semantic': int(semantic), 'instance': int(ident)})
+    sem[5, 5:40] = 255                             # semantic pixels outside every instance: cleared by the loader
+    return inst, sem, endp, ori, areas
+
+
+def write_dataset(root, n_tiles=5, seed=1801, size=1152, split_file='data_split-shuffle.json', label_dir='labels', tile_seeds=None):
+    """A synthetic <data_root> in the reference's layout: split file, cropped_tiff/<stem>.png, <label_dir>/sparse_*/<stem>.{png,json}.
+    Returns the stems.  Split lists: test = all tiles, pretrain = all but the last, valid = first two, single = first, train = last."""
+    stems = dataset_stems(n_tiles)
+    for sub in ('cropped_tiff', label_dir + '/sparse_seq', label_dir + '/sparse_semantic', label_dir + '/sparse_instance',
+                label_dir + '/sparse_orient', label_dir + '/sparse_endp'):
+        os.makedirs(os.path.join(root, sub), exist_ok=True)
+    for i, s in enumerate(stems):
+        ts = (tile_seeds[i] if tile_seeds is not None else seed + i)
+        write_png(os.path.join(root, 'cropped_tiff', s + '.png'), synth.bev_tile_u8(ts, size))
+        inst, sem, endp, ori, areas = label_case(seed + 100 + i, size)
+        write_png(os.path.join(root, label_dir, 'sparse_instance', s + '.png'), inst)
+        write_png(os.path.join(root, label_dir, 'sparse_semantic', s + '.png'), sem)
+        write_png(os.path.join(root, label_dir, 'sparse_endp', s + '.png'), endp)
+        write_png(os.path.join(root, label_dir, 'sparse_orient', s + '.png'), ori)
+        with open(os.path.join(root, label_dir, 'sparse_seq', s + '.json'), 'w') as f:
+            json.dump(areas, f)
+    with open(os.path.join(root, split_file), 'w') as f:
+        json.dump({'train': stems[-1:], 'test': stems, 'valid': stems[:2], 'single': stems[:1], 'pretrain': stems[:-1]}, f)
+    return stems

@@ -410,6 +410,77 @@ def g16(cfg, net):
          init=np.array(init, dtype=np.float64), end=np.array(end, dtype=np.float64), orient=np.asarray(orient), saved_text=np.array(text))
 
 
+def g18(cfg, net):
+    """a12 / f3: the dataset contract.  A synthetic <data_root> (cases.write_dataset: split file, cropped_tiff/, labels/sparse_*/) is
+    listed by the reference's LaserLaneProposal for every mode (the 'test' list right after random.seed(2021), i.e. in the order the
+    reference's Runner gets it: runner.py:69-71, laserlane_proposals.py:512-514), and format_gt_column_proposal gives the evaluation
+    ground truth of every test tile.  skimage is absent: block_reduce (feeds only the training label 'instance', not stored here)
+    is replaced by a numpy block maximum for this golden."""
+    import random
+    import tempfile
+    _refload.install()
+    import baseline.datasets.laserlane_proposals as lp
+
+    def block_reduce(a, block_size=8, func=np.max):
+        h, w = a.shape
+        return func(a.reshape(h // block_size, block_size, w // block_size, block_size), axis=(1, 3))
+    lp.skimage.measure.block_reduce = block_reduce
+    rcfg = _refload.load_cfg('configs/Proj_polyline_fpn_vit_vertex_2.py')
+    keep = {}
+    with tempfile.TemporaryDirectory() as d:
+        cases.write_dataset(d, n_tiles=G18_TILES, seed=G18_SEED)
+        for mode in ('test', 'valid', 'single', 'all', 'infer_only', 'train'):
+            random.seed(2021)
+            ds = lp.LaserLaneProposal(d, 'data_split-shuffle.json', mode=mode, cfg=rcfg)
+            keep['stems_' + mode] = np.array(ds.image_stem_list)
+            keep['images_' + mode] = np.array([os.path.relpath(p, d) for p in ds.image_list])
+            if mode == 'test':
+                keep['seq_test'] = np.array([os.path.relpath(p, d) for p in ds.seq_list])
+                keep['mask_test'] = np.array([os.path.relpath(p, d) for p in ds.mask_list])
+                keep['instance_test'] = np.array([os.path.relpath(p, d) for p in ds.instance_list])
+                keep['endp_test'] = np.array([os.path.relpath(p, d) for p in ds.endp_list])
+                for i in range(len(ds)):
+                    sp = ds.format_gt_column_proposal(i)
+                    keep[f'lc_coor_raw_{i}'] = sp['lc_coor_raw'].numpy()
+                    m = np.asarray(sp['mask'])
+                    keep[f'mask_nz_{i}'] = np.concatenate([np.argwhere(m != 0), m[m != 0][:, None]], axis=1).astype(np.int32)
+                    keep[f'endp_nz_{i}'] = np.argwhere(sp['endp_map'].numpy() > 0).astype(np.int32)
+                    keep[f'endp_val_{i}'] = sp['endp_map'].numpy()[sp['endp_map'].numpy() > 0]
+                print('  test order:', list(ds.image_stem_list))
+                print('  GT vertices per lane, tile 0:', (keep['lc_coor_raw_0'] > 0).sum(1))
+    save('g18_dataset.npz', n_tiles=G18_TILES, seed=G18_SEED, shuffle_seed=2021, **keep)
+
+
+G18_TILES, G18_SEED = 7, 1801
+
+
+def g19(cfg, net):
+    """f3: the accumulation of the test loop (runner.py:741-787, :843-867) over seeded prediction / ground-truth pairs: per tile the
+    reference's cal_coor_measures ('conf') and eval_metric_endp_detector (r_thre = 2 x validate_buffer), the counters summed over
+    the tiles and turned into precision / recall / F1 with the loop's own formulas (EPS = 1e-16)."""
+    _refload.install()
+    from baseline.utils import metric_utils as ref
+    EPS = 1e-16
+    buf = 10
+    tot = np.zeros(8)
+    for seed in G19_SEEDS:
+        label, pred, egt, epr = cases.metric_case(seed)
+        _, _, _, TPs, seg_pts, DGs, gt_pts = ref.cal_coor_measures(label, pred, 'conf', offset_thre=buf)
+        _, _, _, TP2, dets, DG2, gts = ref.eval_metric_endp_detector(epr, egt, r_thre=buf * 2)
+        tot += np.array([TPs, seg_pts, DGs, gt_pts, TP2, dets, DG2, gts], dtype=np.float64)
+    out = []
+    for tp, seg, dg, gt in (tot[0:4], tot[4:8]):
+        pre, rec, f1 = tp / (seg + EPS), dg / (gt + EPS), 0.
+        if (pre + rec) > 0.:
+            f1 = 2. * pre * rec / (pre + rec)
+        out += [pre, rec, f1]
+    save('g19_eval_loop.npz', seeds=np.array(G19_SEEDS), validate_buffer=buf, counters=tot, prf=np.array(out))
+    print('  counters', tot, 'P/R/F1', out)
+
+
+G19_SEEDS = (811, 812, 813, 814, 815, 816)
+
+
 def main():
     which = sys.argv[1:] or ['g2', 'g3', 'g4', 'g5', 'g6', 'g7', 'g10']
     _stable_sorts(True)

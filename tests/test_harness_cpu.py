@@ -1,0 +1,159 @@
+"""CPU: the entry-point contract of the harness and the evaluation loop's bookkeeping (f3).
+
+  * the reference's four unmodified configs/Proj_*.py load through the boundary and give the repo configs' state-dict layout
+    (skipped where /root/reference does not exist, i.e. on the GPU box);
+  * the dataset listing and the evaluation ground truth equal golden G18 (the imported reference's LaserLaneProposal on a synthetic
+    <data_root> that cases.write_dataset re-creates here);
+  * the test loop's counter sums and P / R / F1 formulas equal golden G19;
+  * Runner's entry points carry the reference's signatures, refuse unknown keywords and refuse an empty tile list.
+"""
+import inspect
+import os
+
+import numpy as np
+import pytest
+
+import cases
+from lanemapping_amd import datasets, metric_utils
+from lanemapping_amd.boundary import load_config, build_net_from_config
+
+REF = '/root/reference'
+CONFIGS = ('Proj_polyline_fpn_vit_vertex_2', 'Proj_FPN_Seg', 'Proj28_GFC-T3_RowRef_82_73_laser', 'Proj_polyline_lidarconv_vit_vertex_2')
+
+
+@pytest.mark.skipif(not os.path.isdir(REF), reason='the reference tree only exists in the build container')
+@pytest.mark.parametrize('name', CONFIGS)
+def test_unmodified_reference_configs_build_the_same_layout(name):
+    ref_net = build_net_from_config(f'{REF}/configs/{name}.py', device='cpu')
+    own_net = build_net_from_config(name, device='cpu')
+    a = {k: tuple(v.shape) for k, v in ref_net.state_dict().items()}
+    b = {k: tuple(v.shape) for k, v in own_net.state_dict().items()}
+    assert a == b and list(a) == list(b) and len(a) > 300
+    rc, oc = load_config(f'{REF}/configs/{name}.py'), load_config(name)
+    # the keys the entry points read (runner.py:57-66, :690-697, :755) agree between the trimmed configs and the published ones
+    assert dict(rc.dataset.test) == dict(oc.dataset.test) and rc.dataset.train.type == oc.dataset.train.type
+    assert (rc.log_dir, rc.batch_size, rc.seed, rc.validate_buffer) == (oc.log_dir, oc.batch_size, oc.seed, oc.validate_buffer)
+
+
+@pytest.fixture(scope='module')
+def g18_root(tmp_path_factory, golden):
+    g = golden('g18_dataset.npz')
+    root = tmp_path_factory.mktemp('g18')
+    cases.write_dataset(str(root), n_tiles=int(g['n_tiles']), seed=int(g['seed']))
+    return str(root), g
+
+
+def test_dataset_listing_matches_reference(g18_root):
+    root, g = g18_root
+    for mode in ('test', 'valid', 'single', 'all', 'infer_only', 'train'):
+        ents = datasets.load_datadir(root, 'data_split-shuffle.json', mode, shuffle_seed=int(g['shuffle_seed']))
+        # the reference's stems keep the '.' of '<stem>.json' (laserlane_proposals.py:534); names are cut to 11 characters either way
+        assert [e['stem'] + '.' for e in ents] == list(g['stems_' + mode]), mode
+        assert [os.path.relpath(e['image'], root) for e in ents] == list(g['images_' + mode]), mode
+    ents = datasets.load_datadir(root, 'data_split-shuffle.json', 'test', shuffle_seed=int(g['shuffle_seed']))
+    for key in ('seq', 'mask', 'instance', 'endp'):
+        assert [os.path.relpath(e[key], root) for e in ents] == list(g[key + '_test'])
+    unshuffled = [e['stem'] for e in datasets.load_datadir(root, 'data_split-shuffle.json', 'test')]
+    assert unshuffled == cases.dataset_stems(int(g['n_tiles'])) and unshuffled != [e['stem'] for e in ents]
+
+
+def test_split_entries_follow_the_dataset_classes(g18_root):
+    root, _ = g18_root
+    cfg = load_config('Proj_polyline_fpn_vit_vertex_2')
+    split = dict(cfg.dataset.test, data_root=root)
+    ents = datasets.split_entries(split, cfg)
+    assert len(ents) == 7 and ents[0]['image'].startswith(os.path.join(root, 'cropped_tiff'))
+    assert len(datasets.split_entries(dict(split, mode='infer_only'), cfg)) == 6            # the 'pretrain' list
+    with pytest.raises(AssertionError):
+        datasets.split_entries(dict(split, mode='val'), cfg)                                 # C12: the configs' `val` split never worked
+    with pytest.raises(AssertionError):
+        datasets.split_entries(dict(split, type='LaserLane', mode='infer_only'), cfg)        # laserlane.py:34 has no infer_only
+    assert len(datasets.split_entries({'type': 'LaserLane', 'data_root': root, 'mode': 'test'}, cfg)) == 7
+    with pytest.raises(KeyError):
+        datasets.split_entries(dict(split, type='NoSuchDataset'), cfg)
+
+
+def test_evaluation_ground_truth_matches_reference(g18_root):
+    root, g = g18_root
+    cfg = load_config('Proj_polyline_fpn_vit_vertex_2')
+    ents = datasets.load_datadir(root, 'data_split-shuffle.json', 'test', shuffle_seed=int(g['shuffle_seed']))
+    merged = 0
+    for i, e in enumerate(ents):
+        gt = datasets.load_eval_gt(e, cfg)
+        assert gt['lc_coor_raw'].dtype == np.float32 and np.array_equal(gt['lc_coor_raw'], g[f'lc_coor_raw_{i}'])
+        m = gt['mask']
+        nz = np.concatenate([np.argwhere(m != 0), m[m != 0][:, None]], axis=1).astype(np.int32)
+        assert np.array_equal(nz, g[f'mask_nz_{i}'])
+        assert np.array_equal(np.argwhere(gt['endp_map'] > 0).astype(np.int32), g[f'endp_nz_{i}'])
+        assert np.array_equal(gt['endp_map'][gt['endp_map'] > 0], g[f'endp_val_{i}'])
+        unmerged = datasets.load_eval_gt(e, cfg, merge_connect_lines=False)['lc_coor_raw']
+        merged += int(not np.array_equal(unmerged, gt['lc_coor_raw']))
+        assert np.array_equal(datasets.klane_coor_label(gt['label_raw'], 12), unmerged)     # same columns, px units, no merge
+    assert merged >= 3                        # the connected pair of cases.label_case is really exercised
+
+
+def test_eval_loop_accumulation_matches_reference(golden):
+    from lanemapping_amd.runner import _prf
+    g = golden('g19_eval_loop.npz')
+    buf = int(g['validate_buffer'])
+    tot = np.zeros(8)
+    for seed in g['seeds']:
+        label, pred, egt, epr = cases.metric_case(int(seed))
+        tot[0:4] += metric_utils.cal_coor_measures(label, pred, 'conf', offset_thre=buf)[3:7]
+        tot[4:8] += metric_utils.eval_metric_endp_detector(epr, egt, r_thre=buf * 2)[3:7]
+    assert np.array_equal(tot, g['counters'])
+    assert np.array_equal(np.array(_prf(*tot[0:4]) + _prf(*tot[4:8])), g['prf'])           # same operations, same doubles
+    assert _prf(0, 0, 0, 0) == (0., 0., 0.)
+
+
+def test_runner_entry_points_have_the_reference_signatures():
+    from lanemapping_amd.runner import Runner, load_config_and_runner
+
+    def positional(fn):
+        return [(p.name, p.default) for p in inspect.signature(fn).parameters.values()
+                if p.kind == p.POSITIONAL_OR_KEYWORD and p.name != 'self']
+    # baseline/engine/runner.py:690-692, :606, :945-948, :57
+    assert positional(Runner.infer_lane_coordinate_endpoint_semantics) == [
+        ('path_ckpt', None), ('mode_data', None), ('mode_view', False), ('gt_avail', True), ('write_lane_vertex', False),
+        ('eval_coor', True), ('eval_endp', True), ('eval_semantic', True)]
+    assert positional(Runner.infer_lane_coordinate) == [('path_ckpt', None), ('mode_view', False), ('gt_avail', True),
+                                                        ('write_lane_vertex', False)]
+    assert positional(Runner.infer_lane_geometry_segmentation_segmentor) == [('path_ckpt', None), ('mode_view', False),
+                                                                             ('write_lane_vertex', False)]
+    assert [n for n, _ in positional(load_config_and_runner)] == ['path_config', 'gpus']
+    for fn in (Runner.infer_lane_coordinate_endpoint_semantics, Runner.infer_lane_coordinate,
+               Runner.infer_lane_geometry_segmentation_segmentor):
+        assert not any(p.kind == p.VAR_KEYWORD for p in inspect.signature(fn).parameters.values())     # no **_ignored
+
+
+def test_load_config_and_runner_sets_the_reference_directories(tmp_path, monkeypatch):
+    import lanemapping_amd.runner as R
+    monkeypatch.setattr(R, 'Runner', lambda cfg: ('runner', cfg))
+    src = open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'configs', 'Proj_polyline_fpn_vit_vertex_2.py')).read()
+    p = tmp_path / 'configs_Proj_polyline_fpn_vit_vertex_2.py'
+    p.write_text(src.replace("log_dir = './logs'", f"log_dir = {str(tmp_path / 'logs')!r}"))
+    cfg, runner = R.load_config_and_runner(str(p), '0,1')
+    assert cfg.log_dir == str(tmp_path / 'logs') + '/vis' and cfg.work_dirs == cfg.log_dir + '/LaserLaneProposal' and cfg.gpus == 2
+    assert os.path.isdir(cfg.work_dirs) and runner == ('runner', cfg)
+
+
+def test_runner_refuses_what_it_cannot_honour(g18_root, tmp_path):
+    from lanemapping_amd.runner import Runner
+    root, _ = g18_root
+    cfg = load_config('Proj_polyline_fpn_vit_vertex_2')
+    r = Runner.__new__(Runner)                                   # no GPU here: the listing / argument checks come before any device work
+    r.cfg = cfg
+    with pytest.raises(TypeError):
+        r.infer_lane_coordinate_endpoint_semantics(mode_data=cfg.dataset.test, no_such_keyword=1)
+    empty = tmp_path / 'empty'
+    empty.mkdir()
+    with pytest.raises(ValueError, match='no tiles'):
+        r.infer_lane_coordinate_endpoint_semantics(tiles=str(empty), work_dirs=str(tmp_path / 'o'))
+    with pytest.raises(FileNotFoundError):                       # the published relative data_root does not exist here
+        r.infer_lane_coordinate_endpoint_semantics(mode_data=cfg.dataset.test, gt_avail=False)
+    ents = r._entries(dict(cfg.dataset.test, data_root=root), None)
+    assert [n for n, _, _ in ents] == sorted(s[0:11] for s in cases.dataset_stems(7)) and all(len(n) == 11 for n, _, _ in ents)
+    with open(os.path.join(root, 'data_split-empty.json'), 'w') as f:
+        f.write('{"train": [], "test": [], "valid": [], "single": [], "pretrain": []}')
+    with pytest.raises(ValueError, match='no tiles'):
+        r._entries(dict(cfg.dataset.test, data_root=root, data_split_file='data_split-empty.json'), None)

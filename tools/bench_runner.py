@@ -24,7 +24,7 @@ for i in range(n):
 r = Runner(cfg)
 synth.fill_module_(r.net, 2021)
 out = os.path.join(d, 'out')
-r.infer_lane_coordinate_endpoint_semantics(tiles=d, work_dirs=out, batch_size=8)        # warm-up (packing, allocator)
+r.infer_lane_coordinate_endpoint_semantics(tiles=d, work_dirs=out, batch_size=8, write_lane_vertex=True)        # warm-up (packing, allocator)
 torch.cuda.synchronize()
 for write in (False, True):
     t0 = time.time()
