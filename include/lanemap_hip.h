@@ -84,6 +84,24 @@ int lm_conv3x3_winograd_implicit_bf16x3(void* stream, const float* x, int ldx, c
                                         const float* shift, const float* res, int ldr, float* y, int ldy, int B, int H, int W,
                                         int Cin, int Cout, int dil, int act, double* gn_partial);
 
+/* Winograd F(4x4,3x3) on the fp32 matrix cores (csrc/conv_wino44.hip): the same layers (postprojector.py:322-338,597-647) with 36
+ * products per 4x4 output block - 0.5625x the matrix work of the F(2x2) kernels above, exact fp32 MFMA, no transformed tensor in HBM.
+ * Results are NOT bit-identical to the F(2x2) family (transform constants up to 8 and down to 1/24: profiles/r3_f44_numerics_study.txt);
+ * lm_conv3x3_winograd44_twin_f32 is the materialising twin (V and M in a workspace, three plain kernels) with identical bits.
+ * wu_frag: U = G g G^T (fp64 -> fp32) per wave fragment, [36][Cin/8][CoutP/32][64 lanes][4]:
+ *   wu_frag[xi][u][nt][lane][e] = U[xi][nt*32 + (lane & 31)][8 u + 4 (lane >> 5) + e], CoutP % 64 == 0, Cin % 16 == 0.
+ * wu (twin): U as [36][CoutP][Cin].  gn_partial: [B][lm_winograd44_gn_chunks][Cout][2] doubles -> lm_gn_finalize. */
+int lm_winograd44_supported(int H, int W, int Cin, int dil);
+int lm_winograd44_gn_chunks(int H, int W, int dil);
+long lm_winograd44_tiles(int B, int H, int W, int dil);
+long lm_winograd44_twin_workspace_bytes(int B, int H, int W, int Cin, int CoutP, int dil);
+int lm_conv3x3_winograd44_f32(void* stream, const float* x, int ldx, const float* wu_frag, int CoutP, const float* scale,
+                              const float* shift, const float* res, int ldr, float* y, int ldy, int B, int H, int W,
+                              int Cin, int Cout, int dil, int act, double* gn_partial);
+int lm_conv3x3_winograd44_twin_f32(void* stream, const float* x, int ldx, const float* wu, int CoutP, const float* scale,
+                                   const float* shift, const float* res, int ldr, float* y, int ldy, int B, int H, int W,
+                                   int Cin, int Cout, int dil, int act, void* workspace, long workspace_bytes);
+
 /* Same convolution + first pass of GroupNorm(C,C) (postprojector.py:512-515,608-647): also writes per (image, 64-row
  * chunk, channel) sum / sum of squares of the outputs, gn_partial [B][Ho*Wo/64][Cout][2] doubles -> lm_gn_finalize. */
 int lm_conv2d_nhwc_mfma_f32_gnstats(void* stream, const float* x, int ldx, const float* wp, int CoutP, const float* shift,

@@ -45,6 +45,12 @@ SIGNATURES = {
     'lm_winograd_implicit_supported': (i32, [i32, i32, i32, i32]),
     'lm_conv3x3_winograd_implicit_f32': (i32, [vp, vp, i32, vp, i32, vp, vp, vp, i32, vp, i32, i32, i32, i32, i32, i32, i32, i32, vp]),
     'lm_conv3x3_winograd_implicit_bf16x3': (i32, [vp, vp, i32, vp, i32, vp, vp, vp, i32, vp, i32, i32, i32, i32, i32, i32, i32, i32, vp]),
+    'lm_winograd44_supported': (i32, [i32, i32, i32, i32]),
+    'lm_winograd44_gn_chunks': (i32, [i32, i32, i32]),
+    'lm_winograd44_tiles': (i64, [i32, i32, i32, i32]),
+    'lm_winograd44_twin_workspace_bytes': (i64, [i32, i32, i32, i32, i32, i32]),
+    'lm_conv3x3_winograd44_f32': (i32, [vp, vp, i32, vp, i32, vp, vp, vp, i32, vp, i32, i32, i32, i32, i32, i32, i32, i32, vp]),
+    'lm_conv3x3_winograd44_twin_f32': (i32, [vp, vp, i32, vp, i32, vp, vp, vp, i32, vp, i32, i32, i32, i32, i32, i32, i32, i32, vp, i64]),
     'lm_conv2d_nhwc_mfma_f32_gnstats': (i32, [vp, vp, i32, vp, i32, vp, vp, i32, vp] + [i32] * 11),
     'lm_gn_finalize': (i32, [vp, vp, vp, i32, i32, i32, i32, f32]),
     'lm_gn_finalize_split': (i32, [vp, vp, vp, i32, i32, i32, i32, f32, i32]),

@@ -1,0 +1,834 @@
+// Winograd F(4x4, 3x3) convolution on the fp32 matrix cores: the 3x3 / stride 1 / pad == dilation layers of the FPN
+// (baseline/models/pcencoder/postprojector.py:322-338 BasicBlock convs, :597-599 smooth*, :615-647 conv2/conv3/semantic_branch*)
+// with 36 instead of 144 multiplies per 4x4 output block and (cin, cout) pair - 2.25 per output against 4 for F(2x2, 3x3)
+// (conv_wino.hip) and 9 for the direct sum: 0.5625x the matrix work of the kernels of conv_wino.hip, still exact fp32 MFMA.
+//
+//   Y = A^T [ sum_cin (G g G^T) .* (B^T d B) ] A      interpolation points 0, +-1, +-2, inf (Lavin & Gray)
+//   B^T = [4 0 -5 0 1 0; 0 -4 -4 1 1 0; 0 4 -4 -1 1 0; 0 -2 -1 2 1 0; 0 2 -1 -2 1 0; 0 4 0 -5 0 1]
+//   A^T = [1 1 1 1 1 0; 0 1 -1 2 -2 0; 0 1 1 4 4 0; 0 1 -1 8 -8 1]
+//   G   = [1/4 0 0; -1/6 -1/6 -1/6; -1/6 1/6 -1/6; 1/24 1/12 1/6; 1/24 -1/12 1/6; 0 0 1]   (U = G g G^T in fp64 at pack time, ops.pack_wino44)
+//
+// Numerics were priced before the kernel was written (tests/study_winograd_f44.py, profiles/r3_f44_numerics_study.txt): through the
+// whole config-2 network the raw outputs stay within 2.5e-5 .. 7.6e-5 of the reference on scales 6.5 .. 43 (F(2x2): 1.4e-5 .. 5.7e-5),
+// no thresholded decision outside the reference's own margin.  The results are NOT bit-identical to the F(2x2) family; they ARE
+// bit-identical between the two implementations in this file, which share every arithmetic helper:
+//   * the materialising twin (wino44_input_kernel -> V in HBM, wino44_gemm_kernel -> M in HBM, wino44_output_kernel): three plain
+//     kernels, test infrastructure for the fused one (lm_conv3x3_winograd44_twin_f32);
+//   * wino44_kernel: one workgroup = 32 tiles (512 output pixels) x 64 output channels, no V / M tensor in HBM.
+//
+// wino44_kernel.  36 accumulators of a 32 x 32 block are 576 registers, so the 36 xi are split over the four waves of the workgroup by
+// QUADRANT of the 6 x 6 transform: wave (qa, qb) owns xi = (i, j) with i in 3 qa .. 3 qa + 2, j in 3 qb .. 3 qb + 2 for all 32 tiles and
+// all 64 channels: 9 xi x 2 channel blocks x 16 = 288 accumulator registers, one wave per SIMD.  Every wave reads only its own nine
+// planes of V (LDS) and its own nine planes of U (global -> registers, ring of 6 register sets 5 steps ahead): no operand is fetched
+// twice inside a workgroup.  Per 16-channel unit of the input:
+//   1. the RAW 6 x 6 patches of the 32 tiles (6 patch rows x 144 cells of 16 channels; horizontally adjacent tiles share two columns)
+//      arrive in LDS through global_load_lds gathers straight from the NHWC tensor (zero block for padding), issued during the
+//      previous unit's MFMA phases, double-buffered;
+//   2. per 8-channel half: TRANSFORM phase - the 256 threads compute V = B^T d B for the half ONCE (thread = tile x channel pair x
+//      half of the first pass: 30 ds_read_b64, 72 packed FMAs / adds, 18 ds_write_b64) into V[xi][k half][tile][4] (36 KB);
+//      MFMA phase - per xi of the wave one ds_read_b128 A fragment, two B fragments, 8 MFMAs (4 k steps x 2 channel blocks).
+//   f32 MFMA shares the SIMD's vector ALUs, so the transform is NOT hidden - it costs 72 packed VALU per 72 MFMAs - but
+//   it is paid once per 64 output channels, and 36 products replace 4 x 16.
+// Epilogue: the output transform is linear in the products, so every wave folds its quadrant into a partial 4 x 4 output block
+// (A^T restricted to its three rows / columns: 2-7 operations per element and output row), the partials of one output row go through LDS
+// (131 KB, [wave][x][tile][64 channels] - the exchange is also the transpose that gives 16-byte stores), wave w sums the four partials
+// of output column x = w in wave order and runs the tail (BN scale / shift, residual, ReLU, GroupNorm partial sums, stores).
+#include "common.h"
+
+#include <cstdlib>
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
+namespace {
+
+constexpr int QBM = 32, QBN = 64, QSEG = 4;
+constexpr int QNCELL = 144;                     // cells (one pixel x 16 channels = 64 B) per patch row: 36 tile slots x 4 columns
+constexpr int QLPW = 14;                        // patch loads per wave and unit (1 KB each)
+constexpr int QRAWF = QLPW * 4 * 256;           // floats of one raw buffer (56 KB; cells 864.. are zero-source padding)
+constexpr int QVF = 36 * 256;                   // floats of the V buffer: 36 planes x [2 k halves][32 tiles][4]
+constexpr int QBD = 5, QRING = 6;               // B fragments run 5 steps ahead in a ring of 6 register sets
+static_assert(6 * QNCELL * 16 <= QRAWF, "patch loads cover the unit");
+
+__device__ __attribute__((aligned(16))) float g_w44_zeros[1024 + 32];   // zero source for padding cells, any channel unit (Cin <= 1024)
+
+struct W44Geom {
+    int B, H, W, dil, Ty, Tx;   // Ty x Tx tiles of 4 x 4 outputs per (image, phase); dil * dil phases
+    int Timg, Tpad;             // real tiles per image, and that count rounded up to 32 (a workgroup never straddles images)
+    long T;
+};
+
+W44Geom geom44(int B, int H, int W, int dil) {
+    W44Geom g;
+    g.B = B; g.H = H; g.W = W; g.dil = dil;
+    g.Ty = ((H + dil - 1) / dil + 3) / 4;
+    g.Tx = ((W + dil - 1) / dil + 3) / 4;
+    g.Timg = dil * dil * g.Ty * g.Tx;
+    g.Tpad = (g.Timg + QBM - 1) / QBM * QBM;
+    g.T = (long)B * g.Tpad;
+    return g;
+}
+
+// tile t of an image -> phase and tile coordinates (linear order: phase, ty, tx)
+__device__ __forceinline__ void tile44_decode(const W44Geom& g, int t, int& pa, int& pb, int& ty, int& tx) {
+    tx = t % g.Tx;
+    t /= g.Tx;
+    ty = t % g.Ty;
+    const int ph = t / g.Ty;
+    pa = ph / g.dil;
+    pb = ph - pa * g.dil;
+}
+
+// ---- the arithmetic both implementations share -------------------------------------------------------------------------------------
+// 1-D input transform t = B^T d, fixed association (the fused kernel issues the same operations as packed instructions:
+// fmaf(-5, d2, d4) = fma(-d2, 5, d4) bit for bit)
+__device__ __forceinline__ void w44_bt(const float (&d)[6], float (&t)[6]) {
+#pragma clang fp contract(off)
+    t[0] = __builtin_fmaf(4.f, d[0], __builtin_fmaf(-5.f, d[2], d[4]));
+    t[5] = __builtin_fmaf(4.f, d[1], __builtin_fmaf(-5.f, d[3], d[5]));
+    const float p = __builtin_fmaf(-4.f, d[2], d[4]), q = __builtin_fmaf(-4.f, d[1], d[3]);
+    t[1] = p + q;
+    t[2] = p - q;
+    const float r = d[4] - d[2], s = d[3] - d[1];
+    t[3] = __builtin_fmaf(2.f, s, r);
+    t[4] = __builtin_fmaf(-2.f, s, r);
+}
+
+// 1-D output transform restricted to index group G (0: products 0, 1, 2; 1: products 3, 4, 5), output Y: (A^T)[Y][3 G .. 3 G + 2] . m
+template <int G, int Y>
+__device__ __forceinline__ float w44_at(float m0, float m1, float m2) {
+#pragma clang fp contract(off)
+    if constexpr (G == 0) {
+        if constexpr (Y == 0) return m0 + (m1 + m2);
+        else if constexpr (Y == 2) return m1 + m2;
+        else return m1 - m2;                                   // Y = 1, 3
+    } else {
+        if constexpr (Y == 0) return m0 + m1;
+        else if constexpr (Y == 1) return 2.f * (m0 - m1);
+        else if constexpr (Y == 2) return 4.f * (m0 + m1);
+        else return __builtin_fmaf(8.f, m0 - m1, m2);
+    }
+}
+
+// partial output (Y, X) of quadrant (QA, QB) from its nine products m[ii][jj] = M[3 QA + ii][3 QB + jj]: rows first, then columns
+template <int QA, int QB, int Y, int X>
+__device__ __forceinline__ float w44_partial(const float (&m)[3][3]) {
+    const float z0 = w44_at<QA, Y>(m[0][0], m[1][0], m[2][0]);
+    const float z1 = w44_at<QA, Y>(m[0][1], m[1][1], m[2][1]);
+    const float z2 = w44_at<QA, Y>(m[0][2], m[1][2], m[2][2]);
+    return w44_at<QB, X>(z0, z1, z2);
+}
+
+// ===================================================================================================================================
+// Materialising twin (test infrastructure: plain kernels, one thread per element)
+// V[xi][m][c] = (B^T d B)[xi] of the 6 x 6 patch of tile m (zero padded), rows first, then columns
+__global__ __launch_bounds__(256) void wino44_input_kernel(const float* __restrict__ x, int ldx, W44Geom g, int C, float* __restrict__ V) {
+    const long e = (long)blockIdx.x * 256 + threadIdx.x;
+    if (e >= g.T * C) return;
+    const int c = (int)(e % C);
+    const long m = e / C;
+    const int b = (int)(m / g.Tpad), t = (int)(m - (long)b * g.Tpad);
+    float d[6][6];
+    int pa = 0, pb = 0, ty = 0, tx = 0;
+    const bool real = t < g.Timg;
+    if (real) tile44_decode(g, t, pa, pb, ty, tx);
+#pragma unroll
+    for (int i = 0; i < 6; ++i)
+#pragma unroll
+        for (int j = 0; j < 6; ++j) {
+            const int yy = (4 * ty + i - 1) * g.dil + pa, xx = (4 * tx + j - 1) * g.dil + pb;
+            const bool ok = real && (4 * ty + i - 1) >= 0 && (4 * tx + j - 1) >= 0 && yy < g.H && xx < g.W;
+            d[i][j] = ok ? x[(((long)b * g.H + yy) * g.W + xx) * ldx + c] : 0.f;
+        }
+    float w[6][6];
+#pragma unroll
+    for (int j = 0; j < 6; ++j) {                       // first pass: over the patch rows, per column
+        const float col[6] = {d[0][j], d[1][j], d[2][j], d[3][j], d[4][j], d[5][j]};
+        float t6[6];
+        w44_bt(col, t6);
+#pragma unroll
+        for (int i = 0; i < 6; ++i) w[i][j] = t6[i];
+    }
+#pragma unroll
+    for (int i = 0; i < 6; ++i) {                       // second pass: over the columns, per transformed row
+        float t6[6];
+        w44_bt(w[i], t6);
+#pragma unroll
+        for (int j = 0; j < 6; ++j) V[((long)(6 * i + j) * g.T + m) * C + c] = t6[j];
+    }
+}
+
+// M[xi][m][n] = sum_c V[xi][m][c] U[xi][n][c]: one wave per (32 tiles, 32 channels, xi); the MFMA sequence of wino44_kernel (8-channel
+// units in ascending order, k step e pairs channel 8 u + e with 8 u + 4 + e)
+__global__ __launch_bounds__(64) void wino44_gemm_kernel(const float* __restrict__ V, const float* __restrict__ U, float* __restrict__ M, long T,
+                                                         int C, int CoutP) {
+    const int lane = threadIdx.x;
+    const long m0 = (long)blockIdx.x * 32;
+    const int n0 = blockIdx.y * 32, xi = blockIdx.z;
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+    const float* a = V + ((long)xi * T + m0 + (lane & 31)) * C + 4 * (lane >> 5);
+    const float* b = U + ((long)xi * CoutP + n0 + (lane & 31)) * C + 4 * (lane >> 5);
+    for (int u = 0; u < C / 8; ++u) {
+        const f32x4 av = *reinterpret_cast<const f32x4*>(a + 8 * u), bv = *reinterpret_cast<const f32x4*>(b + 8 * u);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[e], bv[e], acc, 0, 0, 0);
+    }
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int i = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+        M[((long)xi * T + m0 + i) * CoutP + n0 + (lane & 31)] = acc[r];
+    }
+}
+
+struct W44Epi {
+    const float* scale; const float* shift; const float* res; float* y;
+    int ldr, ldy, Cout, act;
+};
+
+template <int Y, int X>
+__device__ __forceinline__ float w44_combine(const float (&q)[2][2][3][3]) {
+#pragma clang fp contract(off)
+    const float p00 = w44_partial<0, 0, Y, X>(q[0][0]), p01 = w44_partial<0, 1, Y, X>(q[0][1]);
+    const float p10 = w44_partial<1, 0, Y, X>(q[1][0]), p11 = w44_partial<1, 1, Y, X>(q[1][1]);
+    return ((p00 + p01) + p10) + p11;                  // wave order of wino44_kernel: w = 2 qa + qb
+}
+
+__device__ __forceinline__ float w44_tail(float v, int n, const W44Epi& e, long pix) {
+#pragma clang fp contract(off)
+    const float sh = e.shift ? e.shift[n] : 0.f;
+    v = e.scale ? v * e.scale[n] + sh : v + sh;
+    if (e.res) v += e.res[pix * e.ldr + n];
+    if (e.act == LM_ACT_RELU) v = fmaxf(v, 0.f);
+    return v;
+}
+
+// thread = (tile m, channel n): the 36 products -> four quadrant partials per output, summed in wave order, tail, 16 guarded stores
+__global__ __launch_bounds__(256) void wino44_output_kernel(const float* __restrict__ M, W44Geom g, int CoutP, W44Epi e) {
+    const long idx = (long)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= g.T * e.Cout) return;
+    const int n = (int)(idx % e.Cout);
+    const long m = idx / e.Cout;
+    const int b = (int)(m / g.Tpad), t = (int)(m - (long)b * g.Tpad);
+    if (t >= g.Timg) return;
+    int pa, pb, ty, tx;
+    tile44_decode(g, t, pa, pb, ty, tx);
+    float q[2][2][3][3];
+#pragma unroll
+    for (int i = 0; i < 6; ++i)
+#pragma unroll
+        for (int j = 0; j < 6; ++j) q[i / 3][j / 3][i % 3][j % 3] = M[((long)(6 * i + j) * g.T + m) * CoutP + n];
+    float o[4][4];
+#define LM_W44_ROW(Y) \
+    o[Y][0] = w44_combine<Y, 0>(q); o[Y][1] = w44_combine<Y, 1>(q); o[Y][2] = w44_combine<Y, 2>(q); o[Y][3] = w44_combine<Y, 3>(q);
+    LM_W44_ROW(0) LM_W44_ROW(1) LM_W44_ROW(2) LM_W44_ROW(3)
+#undef LM_W44_ROW
+#pragma unroll
+    for (int yy = 0; yy < 4; ++yy)
+#pragma unroll
+        for (int xx = 0; xx < 4; ++xx) {
+            const int oy = (4 * ty + yy) * g.dil + pa, ox = (4 * tx + xx) * g.dil + pb;
+            if (oy >= g.H || ox >= g.W) continue;
+            const long pix = ((long)b * g.H + oy) * g.W + ox;
+            e.y[pix * e.ldy + n] = w44_tail(o[yy][xx], n, e, pix);
+        }
+}
+
+// ===================================================================================================================================
+// The fused kernel
+struct W44Params {
+    const float* x; const float* U; const float* scale; const float* shift; const float* res; float* y; const float* zeros;
+    int ldx, ldr, ldy, C, Cout, NT, act;      // NT = CoutP / 32 channel blocks in U
+    int n_inner;                               // workgroup order: N tile inner
+    double* gn_part;
+    W44Geom g;
+};
+
+// packed fp32 pairs (two channels of a lane).  Plain asm (not volatile): the scheduler may move them, the arithmetic is fixed.
+__device__ __forceinline__ f32x2 pk_fma(const f32x2 a, const f32x2 b, const f32x2 c) {          // a b + c
+    f32x2 r;
+    asm("v_pk_fma_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+    return r;
+}
+__device__ __forceinline__ f32x2 pk_fnma(const f32x2 a, const f32x2 b, const f32x2 c) {         // (-a) b + c
+    f32x2 r;
+    asm("v_pk_fma_f32 %0, %1, %2, %3 neg_lo:[1,0,0] neg_hi:[1,0,0]" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+    return r;
+}
+__device__ __forceinline__ f32x2 pk_add(const f32x2 a, const f32x2 b) {
+    f32x2 r;
+    asm("v_pk_add_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+__device__ __forceinline__ f32x2 pk_sub(const f32x2 a, const f32x2 b) {
+    f32x2 r;
+    asm("v_pk_add_f32 %0, %1, %2 neg_lo:[0,1] neg_hi:[0,1]" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+
+struct W44K {
+    f32x2 c2, c4, c5;
+};
+
+// w44_bt on channel pairs
+__device__ __forceinline__ void pk_bt(const f32x2 (&d)[6], f32x2 (&t)[6], const W44K& k) {
+    t[0] = pk_fma(d[0], k.c4, pk_fnma(d[2], k.c5, d[4]));
+    t[5] = pk_fma(d[1], k.c4, pk_fnma(d[3], k.c5, d[5]));
+    const f32x2 p = pk_fnma(d[2], k.c4, d[4]), q = pk_fnma(d[1], k.c4, d[3]);
+    t[1] = pk_add(p, q);
+    t[2] = pk_sub(p, q);
+    const f32x2 r = pk_sub(d[4], d[2]), s = pk_sub(d[3], d[1]);
+    t[3] = pk_fma(s, k.c2, r);
+    t[4] = pk_fnma(s, k.c2, r);
+}
+
+// TRANSFORM phase of one 8-channel half: this thread = (tile, channel pair, LOWER).  First pass over the patch rows for its three
+// transformed rows (LOWER = false: i = 0, 1, 2 from patch rows 0..4; true: i = 5, 3, 4 from patch rows 1..5), second pass over the
+// columns, 18 planes stored.  rawh = raw buffer + 8 * half; roff[c] = float offset of patch column c of the tile (+ 2 * channel pair)
+template <bool LOWER>
+__device__ __forceinline__ void w44_transform(const float* rawh, float* V, const int (&roff)[6], int voff, const W44K& k) {
+    constexpr int ROWF = QNCELL * 16;
+    f32x2 w[3][6];
+#pragma unroll
+    for (int c = 0; c < 6; ++c) {
+        const float* s = rawh + roff[c] + (LOWER ? ROWF : 0);
+        const f32x2 e0 = *reinterpret_cast<const f32x2*>(s), e1 = *reinterpret_cast<const f32x2*>(s + ROWF);
+        const f32x2 e2 = *reinterpret_cast<const f32x2*>(s + 2 * ROWF), e3 = *reinterpret_cast<const f32x2*>(s + 3 * ROWF);
+        const f32x2 e4 = *reinterpret_cast<const f32x2*>(s + 4 * ROWF);
+        if constexpr (!LOWER) {       // e = d0 .. d4
+            w[0][c] = pk_fma(e0, k.c4, pk_fnma(e2, k.c5, e4));
+            const f32x2 p = pk_fnma(e2, k.c4, e4), q = pk_fnma(e1, k.c4, e3);
+            w[1][c] = pk_add(p, q);
+            w[2][c] = pk_sub(p, q);
+        } else {                      // e = d1 .. d5
+            w[0][c] = pk_fma(e0, k.c4, pk_fnma(e2, k.c5, e4));                   // t5 = 4 d1 - 5 d3 + d5
+            const f32x2 r = pk_sub(e3, e1), s2 = pk_sub(e2, e0);                 // r = d4 - d2, s = d3 - d1
+            w[1][c] = pk_fma(s2, k.c2, r);
+            w[2][c] = pk_fnma(s2, k.c2, r);
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        const int ip = LOWER ? (i == 0 ? 5 : (i == 1 ? 3 : 4)) : i;
+        f32x2 t[6];
+        pk_bt(w[i], t, k);
+#pragma unroll
+        for (int j = 0; j < 6; ++j) *reinterpret_cast<f32x2*>(V + (6 * ip + j) * 256 + voff) = t[j];
+    }
+}
+
+// B fragment loads bypass the compiler's wait-count bookkeeping (conv_wino.hip): explicit s_waitcnt vmcnt(N), tied to the destination
+// registers through "+v" operands.
+__device__ __forceinline__ void q_bload2(f32x4 (&b)[2], unsigned voff, const float* sbase) {
+    asm volatile("global_load_dwordx4 %0, %2, %3\n\t"
+                 "global_load_dwordx4 %1, %2, %3 offset:1024"
+                 : "=&v"(b[0]), "=&v"(b[1]) : "v"(voff), "s"(sbase) : "memory");
+}
+template <int N>
+__device__ __forceinline__ void q_bwait(f32x4 (&b)[2]) {
+    asm volatile("s_waitcnt vmcnt(%2)" : "+v"(b[0]), "+v"(b[1]) : "n"(N) : "memory");
+}
+
+// One step (one xi of the wave) of an MFMA phase: 8 MFMAs = 4 k steps x 2 channel blocks.  S = step within the unit (0..17: two phases
+// of nine); the B fragments of step S + 5 and (S < QLPW) patch load S of the NEXT unit are issued first.  NWAIT = loads that may stay
+// outstanding when this step's B fragments are needed = 10 younger B loads + the patch loads of steps S-5 .. S.
+template <int S, int NWAIT, bool NEXT>
+__device__ __forceinline__ void w44_step(f32x16& acc0, f32x16& acc1, f32x4 (&bq)[QRING][2], unsigned bvoff, const float* bpre,
+                                         const float* anext, const f32x4& a_cur, f32x4& a_nxt, const float* const (&gsrc)[QLPW], long goff,
+                                         float* rawld, int wave) {
+    typedef __attribute__((address_space(1))) const void gptr_t;
+    typedef __attribute__((address_space(3))) void lptr_t;
+#ifndef LM_QABL_NOB
+    q_bload2(bq[(S + QBD) % QRING], bvoff, bpre);
+#endif
+#ifndef LM_QABL_NOGLDS
+    if constexpr (S < QLPW)
+        __builtin_amdgcn_global_load_lds((gptr_t*)(gsrc[S] + goff), (lptr_t*)(rawld + (S * 4 + wave) * 256), 16, 0, 0);
+#endif
+    f32x4 (&b)[2] = bq[S % QRING];
+#if !defined(LM_QABL_NOB) && !defined(LM_QABL_NOGLDS)
+    q_bwait<NWAIT>(b);
+#else
+    q_bwait<0>(b);
+#endif
+    acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a_cur[0], b[0][0], acc0, 0, 0, 0);
+    __builtin_amdgcn_sched_barrier(0);
+    if constexpr (NEXT) a_nxt = *reinterpret_cast<const f32x4*>(anext);
+    __builtin_amdgcn_sched_barrier(0);
+    acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a_cur[0], b[1][0], acc1, 0, 0, 0);
+#pragma unroll
+    for (int t = 1; t < 4; ++t) {
+        acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a_cur[t], b[0][t], acc0, 0, 0, 0);
+        acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a_cur[t], b[1][t], acc1, 0, 0, 0);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+}
+
+// Epilogue, first pass of the output transform IN PLACE (once): the three products of a column (rows 3 QA .. 3 QA + 2 of the wave's
+// quadrant) become the three values every output row's w44_at<QA, Y> is made of - the same operations w44_at performs, each done once:
+//   QA = 0: (m0, m1, m2) -> (m0 + (m1 + m2), m1 - m2, m1 + m2);   QA = 1: (m3, m4, m5) -> (m3 + m4, m3 - m4, m5)
+template <int QA>
+__device__ __forceinline__ void w44_rows_inplace(f32x16 (&acc)[9][2]) {
+#pragma unroll
+    for (int jj = 0; jj < 3; ++jj)
+#pragma unroll
+        for (int blk = 0; blk < 2; ++blk)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+#pragma clang fp contract(off)
+                const float m0 = acc[jj][blk][r], m1 = acc[3 + jj][blk][r], m2 = acc[6 + jj][blk][r];
+                if constexpr (QA == 0) {
+                    const float s = m1 + m2;
+                    acc[jj][blk][r] = m0 + s;
+                    acc[3 + jj][blk][r] = m1 - m2;
+                    acc[6 + jj][blk][r] = s;
+                } else {
+                    acc[jj][blk][r] = m0 + m1;
+                    acc[3 + jj][blk][r] = m0 - m1;
+                }
+            }
+}
+// w44_at<QA, Y> from the in-place triple (t0, t1, t2) of w44_rows_inplace
+template <int QA, int Y>
+__device__ __forceinline__ float w44_at_inplace(float t0, float t1, float t2) {
+#pragma clang fp contract(off)
+    if constexpr (QA == 0) return Y == 0 ? t0 : (Y == 2 ? t2 : t1);
+    else {
+        if constexpr (Y == 0) return t0;
+        else if constexpr (Y == 1) return 2.f * t1;
+        else if constexpr (Y == 2) return 4.f * t0;
+        else return __builtin_fmaf(8.f, t1, t2);
+    }
+}
+// this wave's partial outputs of output row Y -> xw[x][tile][64 channels] (the exchange buffer of this wave)
+template <int QA, int QB, int Y>
+__device__ __forceinline__ void w44_row_partials(const f32x16 (&acc)[9][2], float* xw) {
+#pragma unroll
+    for (int blk = 0; blk < 2; ++blk)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+#pragma clang fp contract(off)
+            const float z0 = w44_at_inplace<QA, Y>(acc[0][blk][r], acc[3][blk][r], acc[6][blk][r]);
+            const float z1 = w44_at_inplace<QA, Y>(acc[1][blk][r], acc[4][blk][r], acc[7][blk][r]);
+            const float z2 = w44_at_inplace<QA, Y>(acc[2][blk][r], acc[5][blk][r], acc[8][blk][r]);
+            float* o = xw + ((r & 3) + 8 * (r >> 2)) * 64 + blk * 32;
+            o[0 * 32 * 64] = w44_at<QB, 0>(z0, z1, z2);
+            o[1 * 32 * 64] = w44_at<QB, 1>(z0, z1, z2);
+            o[2 * 32 * 64] = w44_at<QB, 2>(z0, z1, z2);
+            o[3 * 32 * 64] = w44_at<QB, 3>(z0, z1, z2);
+        }
+}
+template <int Y>
+__device__ __forceinline__ void w44_row_partials_q(int wave, const f32x16 (&acc)[9][2], float* xw) {
+    if (wave == 0) w44_row_partials<0, 0, Y>(acc, xw);
+    else if (wave == 1) w44_row_partials<0, 1, Y>(acc, xw);
+    else if (wave == 2) w44_row_partials<1, 0, Y>(acc, xw);
+    else w44_row_partials<1, 1, Y>(acc, xw);
+}
+
+__global__ __launch_bounds__(256) void wino44_kernel(W44Params p) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];      // raw[2][QRAWF] | V[QVF]; the epilogue's exchange buffer over all of it
+    float* const raw0 = smem;
+    float* const Vbuf = smem + 2 * QRAWF;
+    typedef __attribute__((address_space(1))) const void gptr_t;
+    typedef __attribute__((address_space(3))) void lptr_t;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int n_tiles = (p.Cout + QBN - 1) / QBN;
+    unsigned mblk, ntile;
+    if (p.n_inner) {      // XCD-contiguous, N tile inner: the N tiles of an M block run side by side on one XCD (input lines shared in its L2)
+        const unsigned bid = blockIdx.x, per = gridDim.x / 8;
+        const unsigned lin = bid < per * 8 ? (bid % 8) * per + bid / 8 : bid;
+        mblk = lin / (unsigned)n_tiles;
+        ntile = lin % (unsigned)n_tiles;
+    } else {              // XCD-aware order, N tile outer (conv_wino.hip): an XCD streams one N tile's U from its L2
+        const unsigned bid = blockIdx.x, mb = gridDim.x / (unsigned)n_tiles, mbx = mb / 8, full = mbx * 8 * (unsigned)n_tiles;
+        if (bid < full) {
+            const unsigned xcd = bid % 8, idx = bid / 8;
+            ntile = idx / mbx;
+            mblk = xcd * mbx + idx % mbx;
+        } else {
+            const unsigned r = bid - full;
+            mblk = 8 * mbx + r / (unsigned)n_tiles;
+            ntile = r % (unsigned)n_tiles;
+        }
+    }
+    const long m0 = (long)mblk * QBM;
+    const int n0 = (int)ntile * QBN;
+    const W44Geom& g = p.g;
+    const int bi = (int)(m0 / g.Tpad);
+    const int t0 = (int)(m0 - (long)bi * g.Tpad);
+    // run table: the 32 tiles are consecutive in the linear (phase, ty, tx) order = up to QSEG runs of horizontally adjacent tiles.
+    // Run k holds tiles ts[k] .. ts[k+1]-1 and occupies tile SLOTS ts[k] + k .. ts[k+1] + k (one spill slot for patch columns 4, 5 of
+    // its last tile); iy0 / ix0 = input pixel of patch cell (0, 0) of its first tile, oy0 / ox0 = output pixel (0, 0) of that tile
+    int ts[QSEG + 1], sn[QSEG], iy0[QSEG], ix0[QSEG], oy0[QSEG], ox0[QSEG];
+    {
+        int at = 0, t = t0;
+        int tx = t0 % g.Tx, rest = t0 / g.Tx;
+        int ty = rest % g.Ty, ph = rest / g.Ty;
+        int pa = ph / g.dil, pb = ph - pa * g.dil;
+#pragma unroll
+        for (int s_ = 0; s_ < QSEG; ++s_) {
+            ts[s_] = at;
+            const bool real = t < g.Timg && at < QBM;
+            const int n = at < QBM ? min(QBM - at, g.Tx - tx) : 0;
+            sn[s_] = real ? n : 0;
+            iy0[s_] = (4 * ty - 1) * g.dil + pa;
+            ix0[s_] = (4 * tx - 1) * g.dil + pb;
+            oy0[s_] = 4 * ty * g.dil + pa;
+            ox0[s_] = 4 * tx * g.dil + pb;
+            at += n;
+            t += n;
+            tx += n;
+            if (tx >= g.Tx) {
+                tx = 0;
+                if (++ty >= g.Ty) {
+                    ty = 0;
+                    if (++pb >= g.dil) {
+                        pb = 0;
+                        ++pa;
+                    }
+                }
+            }
+        }
+        ts[QSEG] = at;
+    }
+    // patch loads: load s of wave w fills chunks (s * 4 + w) * 64 .. + 63 of the raw buffer; chunk = 16 B = channel quad cq of a cell;
+    // cell = patch row r x position pos; position = 16 (slot >> 2) + 4 c + (slot & 3) for column c (0..3) of tile slot `slot`: the cells
+    // one column of consecutive tiles needs are neighbours in LDS (the transform's ds_read_b64 then conflicts two-way at most)
+    const float* gsrc[QLPW];
+    const int img_pix0 = bi * g.H * g.W;
+#pragma unroll
+    for (int s_ = 0; s_ < QLPW; ++s_) {
+        const int cell = (s_ * 4 + wave) * 16 + (lane >> 2);
+        const int cq = lane & 3;
+        const int r = cell / QNCELL;
+        const int pos = cell - r * QNCELL;
+        const int slot = 4 * (pos >> 4) + (pos & 3), cc = (pos >> 2) & 3;
+        int n = sn[0], yb = iy0[0], xb = ix0[0], s0 = 0;
+#pragma unroll
+        for (int k = 1; k < QSEG; ++k)
+            if (slot >= ts[k] + k) {
+                n = sn[k]; yb = iy0[k]; xb = ix0[k]; s0 = ts[k] + k;
+            }
+        const int lc = 4 * (slot - s0) + cc;
+        const int yy = yb + r * g.dil, xx = xb + lc * g.dil;
+        const bool ok = r < 6 && n > 0 && lc < 4 * n + 2 && (unsigned)yy < (unsigned)g.H && (unsigned)xx < (unsigned)g.W;
+        gsrc[s_] = ok ? p.x + (long)(img_pix0 + yy * g.W + xx) * p.ldx + cq * 4 : p.zeros + cq * 4;
+    }
+    // transform share: tile = lane & 31, LOWER = wave >> 1 (wave-uniform), channel pair of the 8-channel half skewed by the tile slot so
+    // that the 32 lanes of a ds_read_b64 pass hit 16 different bank pairs
+    int roff[6], tvoff;
+    {
+        const int tl = lane & 31;
+        int sg = 0;
+#pragma unroll
+        for (int k = 1; k < QSEG; ++k) sg += (ts[k] < QBM && tl >= ts[k]) ? 1 : 0;
+        const int slot = tl + sg, slot1 = slot + 1;
+        const int cp = (2 * (wave & 1) + (lane >> 5) + (slot >> 2)) & 3;
+        const int pos0 = 16 * (slot >> 2) + (slot & 3), pos1 = 16 * (slot1 >> 2) + (slot1 & 3);
+#pragma unroll
+        for (int c = 0; c < 6; ++c) roff[c] = ((c < 4 ? pos0 + 4 * c : pos1 + 4 * (c - 4)) * 16) + 2 * cp;
+        tvoff = (cp >> 1) * 128 + tl * 4 + (cp & 1) * 2;
+    }
+    const bool lower = (wave >> 1) != 0;
+    const W44K kk = {f32x2{2.f, 2.f}, f32x2{4.f, 4.f}, f32x2{5.f, 5.f}};
+    // MFMA operands: A = V plane xi at [k half = lane >> 5][tile = lane & 31][4]; this wave's planes xi = xi00 + 6 ii + jj
+    const int qa = wave >> 1, qb = wave & 1;
+    const int xi00 = 18 * qa + 3 * qb;
+    const float* const Vq = Vbuf + xi00 * 256 + (lane >> 5) * 128 + (lane & 31) * 4;
+    const int nun = p.C / 16;                                    // 16-channel units
+    const unsigned bvoff = (unsigned)lane * 16u;
+    const long ustride = (long)p.NT * 256;                       // floats between 8-channel halves in U
+    const long xstride = (long)(2 * nun) * ustride;              // floats between xi planes in U
+    const float* const bbase = p.U + (long)xi00 * xstride + (long)(n0 >> 5) * 256;
+
+    f32x16 acc[9][2];
+#pragma unroll
+    for (int k = 0; k < 9; ++k)
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[k][b][r] = 0.f;
+    f32x4 bq[QRING][2];
+    // prologue: raw unit 0, B of steps 0 .. 4
+#pragma unroll
+    for (int s_ = 0; s_ < QLPW; ++s_)
+        __builtin_amdgcn_global_load_lds((gptr_t*)gsrc[s_], (lptr_t*)(raw0 + (s_ * 4 + wave) * 256), 16, 0, 0);
+#define LM_QXI(K) (6 * ((K) / 3) + (K) % 3)
+#pragma unroll
+    for (int k = 0; k < QBD; ++k) q_bload2(bq[k], bvoff, bbase + (long)LM_QXI(k) * xstride);
+    q_bwait<0>(bq[0]);
+    __builtin_amdgcn_s_barrier();
+
+    // B fragments of step S5 = S + 5 of the unit (S5 >= 18: first phase of the next unit)
+#define LM_QBPRE(S5) ((S5) < 18 ? bu + (long)((S5) / 9) * ustride + (long)LM_QXI((S5) % 9) * xstride : bu_next + (long)LM_QXI((S5) - 18) * xstride)
+#define LM_QSTEP(S, NW, AC, AN) \
+    w44_step<S, NW, ((S) % 9) < 8>(acc[(S) % 9][0], acc[(S) % 9][1], bq, bvoff, LM_QBPRE((S) + QBD), Vq + LM_QXI(((S) % 9) + 1 < 9 ? ((S) % 9) + 1 : 0) * 256, \
+                                   AC, AN, gsrc, goff, rawn, wave)
+    for (int u = 0; u < nun; ++u) {
+        const float* const rawc = raw0 + (u & 1) * QRAWF;
+        float* const rawn = raw0 + ((u + 1) & 1) * QRAWF;
+        const long goff = u + 1 < nun ? (long)(u + 1) * 16 : 0;            // (nothing left to fetch: harmless re-read of unit 0)
+        const float* const bu = bbase + (long)(2 * u) * ustride;
+        const float* const bu_next = bbase + (long)(u + 1 < nun ? 2 * (u + 1) : 0) * ustride;
+        f32x4 a0, a1;
+        // ---- channels 16 u .. 16 u + 7
+        if (lower) w44_transform<true>(rawc, Vbuf, roff, tvoff, kk);
+        else w44_transform<false>(rawc, Vbuf, roff, tvoff, kk);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        a0 = *reinterpret_cast<const f32x4*>(Vq);
+        LM_QSTEP(0, 12, a0, a1); LM_QSTEP(1, 12, a1, a0); LM_QSTEP(2, 13, a0, a1);
+        LM_QSTEP(3, 14, a1, a0); LM_QSTEP(4, 15, a0, a1); LM_QSTEP(5, 16, a1, a0);
+        LM_QSTEP(6, 16, a0, a1); LM_QSTEP(7, 16, a1, a0); LM_QSTEP(8, 16, a0, a1);
+        __builtin_amdgcn_s_barrier();                                       // V is free again
+        // ---- channels 16 u + 8 .. 16 u + 15
+        if (lower) w44_transform<true>(rawc + 8, Vbuf, roff, tvoff, kk);
+        else w44_transform<false>(rawc + 8, Vbuf, roff, tvoff, kk);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        a0 = *reinterpret_cast<const f32x4*>(Vq);
+        LM_QSTEP(9, 16, a0, a1);  LM_QSTEP(10, 16, a1, a0); LM_QSTEP(11, 16, a0, a1);
+        LM_QSTEP(12, 16, a1, a0); LM_QSTEP(13, 16, a0, a1); LM_QSTEP(14, 15, a1, a0);
+        LM_QSTEP(15, 14, a0, a1); LM_QSTEP(16, 13, a1, a0); LM_QSTEP(17, 12, a0, a1);
+        q_bwait<8>(bq[0]);                     // this wave's patch loads (steps 0 .. 13) have landed: only steps 14 .. 17's B loads are younger
+        __builtin_amdgcn_s_barrier();          // V free, raw(u) free, raw(u + 1) landed
+    }
+#undef LM_QSTEP
+#undef LM_QBPRE
+#undef LM_QXI
+    static_assert(QLPW == 14 && QBD == 5 && QRING == 6, "NWAIT table above");
+#pragma unroll
+    for (int k = 0; k < QRING; ++k) q_bwait<0>(bq[k]);
+
+    // ---- epilogue
+    float* const xw = smem + wave * (4 * 32 * 64) + (4 * (lane >> 5)) * 64 + (lane & 31);      // this wave's exchange block, this lane's origin
+    const int q4 = (lane & 15) * 4;
+    const int n = n0 + q4;
+    f32x4 sc = {1.f, 1.f, 1.f, 1.f}, sh = {0.f, 0.f, 0.f, 0.f};
+    if (n < p.Cout) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+            if (n + e < p.Cout) {
+                if (p.scale) sc[e] = p.scale[n + e];
+                if (p.shift) sh[e] = p.shift[n + e];
+            }
+    }
+    const bool vec = (n + 3 < p.Cout) && ((p.ldy & 3) == 0) && (!p.res || (p.ldr & 3) == 0);
+    f32x4 gs = {0.f, 0.f, 0.f, 0.f}, gq = {0.f, 0.f, 0.f, 0.f};
+    constexpr int NP = 8;                                   // passes: tile = 4 pass + lane / 16
+    int pix0[NP];
+    unsigned nyx[NP];                                       // valid output rows (low 3 bits) and columns (next 3) of the tile, 0 = no tile
+#pragma unroll
+    for (int pass = 0; pass < NP; ++pass) {
+        const int tl = pass * 4 + (lane >> 4);
+        int nn = sn[0], oy = oy0[0], oxb = ox0[0], tb = 0;
+#pragma unroll
+        for (int k = 1; k < QSEG; ++k)
+            if (tl >= ts[k]) {
+                nn = sn[k]; oy = oy0[k]; oxb = ox0[k]; tb = ts[k];
+            }
+        const int ox = oxb + 4 * (tl - tb) * g.dil;
+        pix0[pass] = img_pix0 + oy * g.W + ox;
+        unsigned v = 0;
+        if (nn > 0 && oy < g.H && ox < g.W) {
+            const int ny = min(4, (g.H - oy + g.dil - 1) / g.dil), nx = min(4, (g.W - ox + g.dil - 1) / g.dil);
+            v = (unsigned)ny | ((unsigned)nx << 3);
+        }
+        nyx[pass] = v;
+    }
+    const int xcol = wave;                                  // this wave sums and stores output column x = wave of every tile
+    if (wave < 2) w44_rows_inplace<0>(acc);
+    else w44_rows_inplace<1>(acc);
+#define LM_QROW(Y)                                                                                                              \
+    {                                                                                                                           \
+        __syncthreads();                       /* patch / V buffers (Y = 0) or the previous row's partials are no longer read */ \
+        w44_row_partials_q<Y>(wave, acc, xw);                                                                                   \
+        __syncthreads();                                                                                                        \
+        if (n < p.Cout) {                                                                                                       \
+            _Pragma("unroll") for (int pass = 0; pass < NP; ++pass) {                                                           \
+                const unsigned v_ = nyx[pass];                                                                                  \
+                if ((int)(v_ & 7u) <= (Y) || (int)(v_ >> 3) <= xcol) continue;                                                  \
+                const int tl = pass * 4 + (lane >> 4);                                                                          \
+                const float* s_ = smem + (xcol * 32 + tl) * 64 + q4;                                                            \
+                const f32x4 p0 = *reinterpret_cast<const f32x4*>(s_), p1 = *reinterpret_cast<const f32x4*>(s_ + 4 * 32 * 64);   \
+                const f32x4 p2 = *reinterpret_cast<const f32x4*>(s_ + 8 * 32 * 64), p3 = *reinterpret_cast<const f32x4*>(s_ + 12 * 32 * 64); \
+                const long pix = pix0[pass] + ((Y) * g.W + xcol) * g.dil;                                                       \
+                w44_store(p, p0, p1, p2, p3, sc, sh, gs, gq, vec, n, pix);                                                      \
+            }                                                                                                                   \
+        }                                                                                                                       \
+    }
+    // (the tail of one output position: a lambda keeps the macro short)
+    auto w44_store = [](const W44Params& p, const f32x4 p0, const f32x4 p1, const f32x4 p2, const f32x4 p3, const f32x4 sc, const f32x4 sh,
+                        f32x4& gs, f32x4& gq, bool vec, int n, long pix) {
+#pragma clang fp contract(off)
+        f32x4 v;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const float s = ((p0[e] + p1[e]) + p2[e]) + p3[e];
+            v[e] = p.scale ? s * sc[e] + sh[e] : s + sh[e];
+        }
+        if (p.gn_part) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                gs[e] += v[e];
+                gq[e] = __builtin_fmaf(v[e], v[e], gq[e]);
+            }
+        }
+        if (vec) {
+            if (p.res) {
+                const f32x4 rr = *reinterpret_cast<const f32x4*>(p.res + pix * p.ldr + n);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] += rr[e];
+            }
+            if (p.act == LM_ACT_RELU) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
+            }
+            *reinterpret_cast<f32x4*>(p.y + pix * p.ldy + n) = v;
+        } else {
+            for (int e = 0; e < 4 && n + e < p.Cout; ++e) {
+                float u = v[e];
+                if (p.res) u += p.res[pix * p.ldr + n + e];
+                if (p.act == LM_ACT_RELU) u = fmaxf(u, 0.f);
+                p.y[pix * p.ldy + n + e] = u;
+            }
+        }
+    };
+    LM_QROW(0) LM_QROW(1) LM_QROW(2) LM_QROW(3)
+#undef LM_QROW
+    if (p.gn_part) {      // fixed-order reduction: the 4 lanes that share a channel quad, then the four waves through LDS
+#pragma unroll
+        for (int o = 16; o < 64; o <<= 1)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                gs[e] += __shfl_xor(gs[e], o);
+                gq[e] += __shfl_xor(gq[e], o);
+            }
+        __syncthreads();
+        if (lane < 16) {
+            *reinterpret_cast<f32x4*>(smem + ((wave * 16 + lane) * 2) * 4) = gs;
+            *reinterpret_cast<f32x4*>(smem + ((wave * 16 + lane) * 2 + 1) * 4) = gq;
+        }
+        __syncthreads();
+        if (wave == 0 && lane < 16 && n < p.Cout) {
+#pragma clang fp contract(off)
+            f32x4 s = gs, q = gq;
+#pragma unroll
+            for (int w = 1; w < 4; ++w) {
+                const f32x4 a = *reinterpret_cast<const f32x4*>(smem + ((w * 16 + lane) * 2) * 4);
+                const f32x4 b = *reinterpret_cast<const f32x4*>(smem + ((w * 16 + lane) * 2 + 1) * 4);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    s[e] += a[e];
+                    q[e] += b[e];
+                }
+            }
+            const long chunk = t0 / 32;
+            double* o = p.gn_part + (((long)bi * (g.Tpad / 32) + chunk) * p.Cout + n) * 2;
+            for (int e = 0; e < 4 && n + e < p.Cout; ++e) {
+                o[2 * e] = (double)s[e];
+                o[2 * e + 1] = (double)q[e];
+            }
+        }
+    }
+}
+
+// runs of adjacent tiles a 32-tile block can touch: floor((QBM - 2) / Tx) + 2
+bool w44_ok(const W44Geom& g) { return (QBM - 2) / g.Tx + 2 <= QSEG; }
+
+int w44_zeros(const float** out) {      // per device (a process may drive several)
+    static const float* cache[64] = {nullptr};
+    int dev = 0;
+    LM_HIP(hipGetDevice(&dev));
+    LM_REQUIRE(dev >= 0 && dev < 64, "conv_wino44: device index %d", dev);
+    if (!cache[dev]) {
+        void* sym = nullptr;
+        LM_HIP(hipGetSymbolAddress(&sym, HIP_SYMBOL(g_w44_zeros)));
+        cache[dev] = (const float*)sym;
+    }
+    *out = cache[dev];
+    return LM_OK;
+}
+
+}  // namespace
+
+// 1 if lm_conv3x3_winograd44_f32 covers the shape
+LM_API int lm_winograd44_supported(int H, int W, int Cin, int dil) {
+    if (dil < 1 || H < 1 || W < 1 || Cin < 16 || Cin % 16 != 0 || Cin > 1024) return 0;
+    return w44_ok(geom44(1, H, W, dil)) ? 1 : 0;
+}
+
+// 32-tile chunks per image of the GroupNorm partial sums written by lm_conv3x3_winograd44_f32 (-> lm_gn_finalize's nchunk)
+LM_API int lm_winograd44_gn_chunks(int H, int W, int dil) { return dil < 1 ? 0 : geom44(1, H, W, dil).Tpad / 32; }
+
+// Winograd-domain products the F(4x4) kernels execute per launch: 36 per tile and (cin, cout) pair (for the executed-FLOP roofline)
+LM_API long lm_winograd44_tiles(int B, int H, int W, int dil) { return dil < 1 ? 0 : geom44(B, H, W, dil).T; }
+
+LM_API long lm_winograd44_twin_workspace_bytes(int B, int H, int W, int Cin, int CoutP, int dil) {
+    if (dil < 1) return 0;
+    return 36 * geom44(B, H, W, dil).T * (long)(Cin + CoutP) * (long)sizeof(float);
+}
+
+// y = act(conv3x3(x; pad = dil) * scale + shift + res), NHWC, through Winograd F(4x4, 3x3) without V / M tensors in HBM.
+// wu_frag = U = G g G^T (fp64 -> fp32) repacked per wave fragment, [36][Cin/8][CoutP/32][64][4] floats:
+//   wu_frag[xi][u][nt][lane][e] = U[xi][nt*32 + (lane & 31)][8 u + 4 (lane >> 5) + e]     (ops.pack_wino44_fragments), CoutP % 64 == 0
+// gn_partial (optional, needs res == NULL and act == none): [B][lm_winograd44_gn_chunks][Cout][2] doubles -> lm_gn_finalize.
+LM_API int lm_conv3x3_winograd44_f32(void* stream, const float* x, int ldx, const float* wu_frag, int CoutP, const float* scale,
+                                     const float* shift, const float* res, int ldr, float* y, int ldy, int B, int H, int W,
+                                     int Cin, int Cout, int dil, int act, double* gn_partial) {
+    LM_REQUIRE(x && wu_frag && y, "conv_wino44: null pointer");
+    LM_REQUIRE(lm_winograd44_supported(H, W, Cin, dil) && B > 0, "conv_wino44: unsupported shape (H=%d W=%d Cin=%d dil=%d)", H, W, Cin, dil);
+    LM_REQUIRE(CoutP >= Cout && CoutP % QBN == 0, "conv_wino44: CoutP=%d must be Cout=%d rounded up to %d", CoutP, Cout, QBN);
+    LM_REQUIRE(ldx >= Cin && ldx % 4 == 0 && ldy >= Cout, "conv_wino44: bad leading dimension");
+    LM_REQUIRE(act == LM_ACT_NONE || act == LM_ACT_RELU, "conv_wino44: activation %d not supported", act);
+    LM_REQUIRE(!gn_partial || (res == nullptr && act == LM_ACT_NONE && Cout % 4 == 0), "conv_wino44(gn stats): no residual / activation");
+    W44Params p;
+    p.g = geom44(B, H, W, dil);
+    LM_REQUIRE((long)B * H * W * ldx < (1L << 40) && (long)B * H * W < (1L << 31) && p.g.T < (1L << 31), "conv_wino44: tensor too large");
+    p.x = x; p.U = wu_frag; p.scale = scale; p.shift = shift; p.res = res; p.y = y;
+    p.ldx = ldx; p.ldr = ldr; p.ldy = ldy; p.C = Cin; p.Cout = Cout; p.NT = CoutP / 32; p.act = act;
+    p.gn_part = gn_partial;
+    if (int e = w44_zeros(&p.zeros)) return e;
+    static const int order = getenv("LANEMAP_W44_ORDER") ? atoi(getenv("LANEMAP_W44_ORDER")) : -1;      // 0: N outer, 1: N inner (experiments)
+    // an input larger than the 256 MB Infinity Cache would be re-read from HBM once per N tile in the N-outer order: N inner there
+    p.n_inner = order >= 0 ? order : ((long)B * H * W * Cin * 4 > (256L << 20) ? 1 : 0);
+    const size_t lds = (size_t)(2 * QRAWF + QVF) * sizeof(float);
+    static_assert(4 * 4 * 32 * 64 <= 2 * QRAWF + QVF, "the exchange buffer of the epilogue fits");
+    const long blocks = (p.g.T / QBM) * ((Cout + QBN - 1) / QBN);
+    LM_REQUIRE(blocks > 0 && blocks < (1L << 31) && p.g.T % QBM == 0, "conv_wino44: bad grid %ld", blocks);
+    if (int e = lm_ensure_dynamic_lds((const void*)wino44_kernel, lds)) return e;
+    hipLaunchKernelGGL(wino44_kernel, dim3((unsigned)blocks), dim3(256), lds, (hipStream_t)stream, p);
+    LM_LAUNCH_CHECK();
+    return LM_OK;
+}
+
+// The same convolution through the materialising twin (bit-identical results; test infrastructure).  wu = U as [36][CoutP][Cin]
+// (ops.pack_wino44); workspace >= lm_winograd44_twin_workspace_bytes.
+LM_API int lm_conv3x3_winograd44_twin_f32(void* stream, const float* x, int ldx, const float* wu, int CoutP, const float* scale,
+                                          const float* shift, const float* res, int ldr, float* y, int ldy, int B, int H, int W,
+                                          int Cin, int Cout, int dil, int act, void* workspace, long workspace_bytes) {
+    LM_REQUIRE(x && wu && y && workspace, "conv_wino44_twin: null pointer");
+    LM_REQUIRE(Cin > 0 && Cin % 8 == 0 && dil >= 1 && B > 0 && H > 0 && W > 0, "conv_wino44_twin: bad shape");
+    LM_REQUIRE(CoutP >= Cout && CoutP % 32 == 0 && ldx >= Cin && ldy >= Cout, "conv_wino44_twin: bad CoutP / leading dimension");
+    LM_REQUIRE(act == LM_ACT_NONE || act == LM_ACT_RELU, "conv_wino44_twin: activation %d not supported", act);
+    LM_REQUIRE(lm_winograd44_twin_workspace_bytes(B, H, W, Cin, CoutP, dil) <= workspace_bytes, "conv_wino44_twin: workspace too small");
+    const W44Geom g = geom44(B, H, W, dil);
+    LM_REQUIRE(g.T * (long)(Cin > Cout ? Cin : Cout) < (1L << 31) * 256L && g.T / 32 < 65536L * 32768L, "conv_wino44_twin: too large");
+    float* V = (float*)workspace;
+    float* M = V + 36 * g.T * Cin;
+    hipStream_t s = (hipStream_t)stream;
+    hipLaunchKernelGGL(wino44_input_kernel, dim3((unsigned)((g.T * Cin + 255) / 256)), dim3(256), 0, s, x, ldx, g, Cin, V);
+    LM_LAUNCH_CHECK();
+    hipLaunchKernelGGL(wino44_gemm_kernel, dim3((unsigned)(g.T / 32), (unsigned)(CoutP / 32), 36), dim3(64), 0, s, (const float*)V, wu, M,
+                       g.T, Cin, CoutP);
+    LM_LAUNCH_CHECK();
+    W44Epi e;
+    e.scale = scale; e.shift = shift; e.res = res; e.y = y; e.ldr = ldr; e.ldy = ldy; e.Cout = Cout; e.act = act;
+    hipLaunchKernelGGL(wino44_output_kernel, dim3((unsigned)((g.T * Cout + 255) / 256)), dim3(256), 0, s, (const float*)M, g, CoutP, e);
+    LM_LAUNCH_CHECK();
+    return LM_OK;
+}

@@ -113,6 +113,31 @@ def pack_wino_fragments_bf16x3(wu):
     return t.permute(1, 4, 2, 0, 6, 3, 5, 7).contiguous().reshape(16, ci // 16, cop // 32, 3, 64, 8)
 
 
+_W44_G = [[1 / 4, 0, 0], [-1 / 6, -1 / 6, -1 / 6], [-1 / 6, 1 / 6, -1 / 6], [1 / 24, 1 / 12, 1 / 6], [1 / 24, -1 / 12, 1 / 6], [0, 0, 1]]
+
+
+def pack_wino44(w):
+    """[Cout,Cin,3,3] -> Winograd F(4x4,3x3) weights U = G g G^T as [36, CoutP, Cin] (xi = 6 i + j), CoutP = Cout rounded up to 64.
+    The product is formed in fp64 and rounded to fp32 once (G carries 1/6, 1/12, 1/24: csrc/conv_wino44.hip)."""
+    co, ci, kh, kw = w.shape
+    assert kh == 3 and kw == 3
+    G = torch.tensor(_W44_G, device=w.device, dtype=torch.float64)
+    U = torch.einsum('ij,ocjk,lk->iloc', G, w.double(), G).reshape(36, co, ci).float()
+    cop = (co + 63) // 64 * 64
+    p = torch.zeros((36, cop, ci), device=w.device, dtype=torch.float32)
+    p[:, :co, :] = U
+    return p.contiguous()
+
+
+def pack_wino44_fragments(wu):
+    """pack_wino44 output U [36, CoutP, Cin] -> the per-wave-fragment order of lm_conv3x3_winograd44_f32:
+    [36][Cin/8][CoutP/32][lane 64][4] with lane = khalf * 32 + row, channel = u*8 + khalf*4 + e."""
+    xi, cop, ci = wu.shape
+    assert xi == 36 and cop % 64 == 0 and ci % 16 == 0
+    t = wu.reshape(36, cop // 32, 32, ci // 8, 2, 4)                       # xi, nt, row, u, khalf, e
+    return t.permute(0, 3, 1, 4, 2, 5).contiguous().reshape(36, ci // 8, cop // 32, 64, 4)
+
+
 def pack_small(w):
     """[Cout<=16,Cin,KH,KW] -> [KH*KW, Cin, 16]."""
     co, ci, kh, kw = w.shape
@@ -288,6 +313,58 @@ def conv_wino_implicit(x, wf, cout, dil=1, scale=None, shift=None, res=None, act
     stats = torch.empty((B, cout, 2), device=x.device, dtype=torch.float32)
     check(lib().lm_gn_finalize(_stream(), _ptr(part), _ptr(stats), B, H * W, cout, part.shape[1], gn_eps))
     return y, stats
+
+
+def wino44_supported(H, W, cin, dil=1):
+    return bool(lib().lm_winograd44_supported(int(H), int(W), int(cin), int(dil)))
+
+
+def conv_wino44(x, wf, cout, dil=1, scale=None, shift=None, res=None, act=ACT_NONE, out=None, gn_eps=None, gn_split=1):
+    """3x3 / stride 1 / pad = dil convolution via Winograd F(4x4,3x3), exact fp32 MFMA, no transformed tensors in HBM
+    (csrc/conv_wino44.hip wino44_kernel: 0.5625x the matrix work of the F(2x2) kernels).  wf = pack_wino44_fragments(pack_wino44(w)).
+    NOT bit-identical to the F(2x2) family (different rounding; priced in profiles/r3_f44_numerics_study.txt); bit-identical to
+    conv_wino44_twin.  With gn_eps returns (y, stats) like conv_wino_implicit."""
+    x, ldx = as_nhwc(x)
+    B, cin, H, W = x.shape
+    cop = wf.shape[2] * 32
+    y = out if out is not None else new_act(B, cout, H, W, x.device)
+    y_, ldy = as_nhwc(y)
+    assert y_.data_ptr() == y.data_ptr(), 'conv_wino44: `out` must already be NHWC-stored'
+    r, ldr = (None, 0) if res is None else as_nhwc(res)
+    part = None
+    if gn_eps is not None:
+        part = torch.empty((B, lib().lm_winograd44_gn_chunks(H, W, dil), cout, 2), device=x.device, dtype=torch.float64)
+    tiles = lib().lm_winograd44_tiles(B, H, W, dil)
+    _hooked(f'wino44 {cin}->{cout} k3x3 d{dil} @{H}x{W} B{B}', 2.0 * B * H * W * cout * cin * 9,
+            lambda: check(lib().lm_conv3x3_winograd44_f32(_stream(), _ptr(x), ldx, _ptr(wf), cop, _ptr(scale), _ptr(shift), _ptr(r), ldr,
+                                                          _ptr(y), ldy, B, H, W, cin, cout, dil, act, _ptr(part))),
+            2.0 * 36 * tiles * cin * cout)
+    if gn_eps is None:
+        return y
+    if gn_split > 1:
+        stats = torch.empty((gn_split, B, cout // gn_split, 2), device=x.device, dtype=torch.float32)
+        check(lib().lm_gn_finalize_split(_stream(), _ptr(part), _ptr(stats), B, H * W, cout, part.shape[1], gn_eps, gn_split))
+        return y, stats
+    stats = torch.empty((B, cout, 2), device=x.device, dtype=torch.float32)
+    check(lib().lm_gn_finalize(_stream(), _ptr(part), _ptr(stats), B, H * W, cout, part.shape[1], gn_eps))
+    return y, stats
+
+
+def conv_wino44_twin(x, wu, cout, dil=1, scale=None, shift=None, res=None, act=ACT_NONE, out=None):
+    """The same convolution through the materialising twin (V and M tensors in HBM, three plain kernels): test infrastructure,
+    bit-identical to conv_wino44.  wu = pack_wino44(w)."""
+    x, ldx = as_nhwc(x)
+    B, cin, H, W = x.shape
+    cop = wu.shape[1]
+    y = out if out is not None else new_act(B, cout, H, W, x.device)
+    y_, ldy = as_nhwc(y)
+    assert y_.data_ptr() == y.data_ptr(), 'conv_wino44_twin: `out` must already be NHWC-stored'
+    r, ldr = (None, 0) if res is None else as_nhwc(res)
+    need = lib().lm_winograd44_twin_workspace_bytes(B, H, W, cin, cop, dil)
+    ws = torch.empty(need, device=x.device, dtype=torch.uint8)
+    check(lib().lm_conv3x3_winograd44_twin_f32(_stream(), _ptr(x), ldx, _ptr(wu), cop, _ptr(scale), _ptr(shift), _ptr(r), ldr,
+                                               _ptr(y), ldy, B, H, W, cin, cout, dil, act, _ptr(ws), need))
+    return y
 
 
 def conv_mfma_gnstats(x, wp, cout, kh, kw, stride, pad, dil, shift, eps=1e-5):

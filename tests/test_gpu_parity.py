@@ -1217,6 +1217,50 @@ def test_conv_winograd_implicit_bit_identical(dev, B, cin, cout, H, W, dil):
         assert torch.equal(st, st2)                          # deterministic
 
 
+@pytest.mark.parametrize('B,cin,cout,H,W,dil', [(2, 128, 128, 60, 64, 1), (1, 256, 200, 61, 75, 1), (2, 128, 64, 120, 130, 2),
+                                                (1, 160, 256, 85, 187, 3), (1, 64, 64, 288, 288, 1), (1, 256, 256, 144, 144, 2),
+                                                (2, 256, 512, 144, 144, 1), (1, 16, 70, 64, 300, 1)])
+def test_conv_winograd44_bit_identical_to_twin(dev, B, cin, cout, H, W, dil):
+    """lm_conv3x3_winograd44_f32 (Winograd F(4x4,3x3), exact fp32 MFMA, 36 xi split over the four waves by quadrant, no V / M tensor in
+    HBM) produces the SAME BITS as its materialising twin (three plain kernels sharing its arithmetic helpers) on ragged sizes,
+    dilations 1-3, one to sixteen channel units, channel counts that are not multiples of the 64-channel N tile, with BN scale / shift,
+    residual and ReLU; both are within 1e-4 of the tensor scale of an fp64 convolution (the price of F(4x4)'s transform constants:
+    profiles/r3_f44_numerics_study.txt); channel slices as operands; GroupNorm statistics from the epilogue; deterministic."""
+    from lanemapping_amd import ops
+    assert ops.wino44_supported(H, W, cin, dil)
+    g = torch.Generator().manual_seed(B * 1000 + cin + H + dil)
+    x = torch.randn((B, cin, H, W), generator=g)
+    w = torch.randn((cout, cin, 3, 3), generator=g) / (cin * 9) ** 0.5
+    scale, shift = torch.rand(cout, generator=g) + 0.5, torch.randn(cout, generator=g)
+    res = torch.randn((B, cout, H, W), generator=g)
+    xd = x.to(dev).permute(0, 2, 3, 1).contiguous().permute(0, 3, 1, 2)
+    rd = res.to(dev).permute(0, 2, 3, 1).contiguous().permute(0, 3, 1, 2)
+    wu = ops.pack_wino44(w.to(dev))
+    wf = ops.pack_wino44_fragments(wu)
+    sd, bd = scale.to(dev), shift.to(dev)
+    y0 = ops.conv_wino44_twin(xd, wu, cout, dil, scale=sd, shift=bd, res=rd, act=ops.ACT_RELU)
+    y1 = ops.conv_wino44(xd, wf, cout, dil, scale=sd, shift=bd, res=rd, act=ops.ACT_RELU)
+    want = F.relu(F.conv2d(x.double(), w.double(), None, 1, dil, dil) * scale.double().view(1, -1, 1, 1) + shift.double().view(1, -1, 1, 1)
+                  + res.double()).float()
+    _close(y0, want, 1e-4, 'winograd F(4x4) twin vs fp64')
+    _close(y1, want, 1e-4, 'winograd F(4x4) vs fp64')
+    assert torch.equal(y0, y1), float((y0 - y1).abs().max())
+    assert torch.equal(y1, ops.conv_wino44(xd, wf, cout, dil, scale=sd, shift=bd, res=rd, act=ops.ACT_RELU))      # deterministic
+    # a channel slice of a wider tensor as input, and a channel slice as output; no scale / residual / activation
+    wide = ops.new_act(B, cin + 32, H, W, dev).normal_()
+    wide[:, 16:16 + cin].copy_(xd)
+    outw = ops.new_act(B, cout + 8, H, W, dev).zero_()
+    ops.conv_wino44(wide[:, 16:16 + cin], wf, cout, dil, shift=bd, out=outw[:, 4:4 + cout])
+    y2 = ops.conv_wino44_twin(xd, wu, cout, dil, shift=bd)
+    assert torch.equal(outw[:, 4:4 + cout], y2) and float(outw[:, :4].abs().max()) == 0 and float(outw[:, 4 + cout:].abs().max()) == 0
+    if cout in (64, 128, 256):                             # (channel counts the standalone statistics kernel takes)
+        y3, st = ops.conv_wino44(xd, wf, cout, dil, shift=bd, gn_eps=1e-5)
+        assert torch.equal(y3, y2)
+        _close(st, ops.gn_stats(y3, 1e-5), 2e-5, 'gn stats from the F(4x4) epilogue')
+        y4, st2 = ops.conv_wino44(xd, wf, cout, dil, shift=bd, gn_eps=1e-5)
+        assert torch.equal(st, st2)
+
+
 @pytest.mark.parametrize('B,cin,cout,H,W,dil', [(2, 128, 128, 48, 44, 1), (1, 256, 200, 43, 61, 1), (1, 160, 256, 85, 87, 2), (2, 256, 512, 144, 144, 1),
                                                 (1, 32, 64, 100, 96, 1), (2, 96, 32, 60, 90, 1)])      # (two slots; six slots, one N tile half empty)
 def test_conv_winograd_bf16x3_vs_fp64(dev, B, cin, cout, H, W, dil):
