@@ -29,10 +29,11 @@
 //      MFMA phase - per xi of the wave one ds_read_b128 A fragment, two B fragments, 8 MFMAs (4 k steps x 2 channel blocks).
 //   f32 MFMA shares the SIMD's vector ALUs, so the transform is NOT hidden - it costs 72 packed VALU per 72 MFMAs - but
 //   it is paid once per 64 output channels, and 36 products replace 4 x 16.
-// Epilogue: the output transform is linear in the products, so every wave folds its quadrant into a partial 4 x 4 output block
-// (A^T restricted to its three rows / columns: 2-7 operations per element and output row), the partials of one output row go through LDS
-// (131 KB, [wave][x][tile][64 channels] - the exchange is also the transpose that gives 16-byte stores), wave w sums the four partials
-// of output column x = w in wave order and runs the tail (BN scale / shift, residual, ReLU, GroupNorm partial sums, stores).
+// Epilogue: the 36 products of an output block sit in four different waves, so they meet in LDS: per 32-channel block every wave stores
+// its nine planes straight from the accumulator registers (M[xi][tile][32 channels], 144 KB), then every thread takes one (tile, channel
+// quad): 36 ds_read_b128, A^T M A (100 operations per element), the tail (BN scale / shift, residual, ReLU, GroupNorm partial sums) and
+// sixteen 16-byte stores.  (The first version folded each wave's quadrant into partial outputs in registers and exchanged those: 2.8 k
+// VALU per lane plus as many accumulator reads, spills, 114 k cycles per workgroup against 17 k for this one.)
 #include "common.h"
 
 #include <cstdlib>
@@ -48,7 +49,11 @@ constexpr int QNCELL = 144;                     // cells (one pixel x 16 channel
 constexpr int QLPW = 14;                        // patch loads per wave and unit (1 KB each)
 constexpr int QRAWF = QLPW * 4 * 256;           // floats of one raw buffer (56 KB; cells 864.. are zero-source padding)
 constexpr int QVF = 36 * 256;                   // floats of the V buffer: 36 planes x [2 k halves][32 tiles][4]
-constexpr int QBD = 5, QRING = 6;               // B fragments run 5 steps ahead in a ring of 6 register sets
+#ifndef LM_QBD
+#define LM_QBD 5
+#define LM_QRING 6
+#endif
+constexpr int QBD = LM_QBD, QRING = LM_QRING;   // B fragments run QBD steps ahead in a ring of QRING register sets
 static_assert(6 * QNCELL * 16 <= QRAWF, "patch loads cover the unit");
 
 __device__ __attribute__((aligned(16))) float g_w44_zeros[1024 + 32];   // zero source for padding cells, any channel unit (Cin <= 1024)
@@ -95,29 +100,15 @@ __device__ __forceinline__ void w44_bt(const float (&d)[6], float (&t)[6]) {
     t[4] = __builtin_fmaf(-2.f, s, r);
 }
 
-// 1-D output transform restricted to index group G (0: products 0, 1, 2; 1: products 3, 4, 5), output Y: (A^T)[Y][3 G .. 3 G + 2] . m
-template <int G, int Y>
-__device__ __forceinline__ float w44_at(float m0, float m1, float m2) {
+// 1-D output transform y = A^T m, fixed association
+template <typename T>
+__device__ __forceinline__ void w44_at(const T (&m)[6], T (&y)[4]) {
 #pragma clang fp contract(off)
-    if constexpr (G == 0) {
-        if constexpr (Y == 0) return m0 + (m1 + m2);
-        else if constexpr (Y == 2) return m1 + m2;
-        else return m1 - m2;                                   // Y = 1, 3
-    } else {
-        if constexpr (Y == 0) return m0 + m1;
-        else if constexpr (Y == 1) return 2.f * (m0 - m1);
-        else if constexpr (Y == 2) return 4.f * (m0 + m1);
-        else return __builtin_fmaf(8.f, m0 - m1, m2);
-    }
-}
-
-// partial output (Y, X) of quadrant (QA, QB) from its nine products m[ii][jj] = M[3 QA + ii][3 QB + jj]: rows first, then columns
-template <int QA, int QB, int Y, int X>
-__device__ __forceinline__ float w44_partial(const float (&m)[3][3]) {
-    const float z0 = w44_at<QA, Y>(m[0][0], m[1][0], m[2][0]);
-    const float z1 = w44_at<QA, Y>(m[0][1], m[1][1], m[2][1]);
-    const float z2 = w44_at<QA, Y>(m[0][2], m[1][2], m[2][2]);
-    return w44_at<QB, X>(z0, z1, z2);
+    const T s1 = m[1] + m[2], d1 = m[1] - m[2], s3 = m[3] + m[4], d3 = m[3] - m[4];
+    y[0] = (m[0] + s1) + s3;
+    y[1] = d3 * 2.f + d1;                   // (a product by a power of two is exact: no contraction question)
+    y[2] = s3 * 4.f + s1;
+    y[3] = (d3 * 8.f + d1) + m[5];
 }
 
 // ===================================================================================================================================
@@ -188,14 +179,6 @@ struct W44Epi {
     int ldr, ldy, Cout, act;
 };
 
-template <int Y, int X>
-__device__ __forceinline__ float w44_combine(const float (&q)[2][2][3][3]) {
-#pragma clang fp contract(off)
-    const float p00 = w44_partial<0, 0, Y, X>(q[0][0]), p01 = w44_partial<0, 1, Y, X>(q[0][1]);
-    const float p10 = w44_partial<1, 0, Y, X>(q[1][0]), p11 = w44_partial<1, 1, Y, X>(q[1][1]);
-    return ((p00 + p01) + p10) + p11;                  // wave order of wino44_kernel: w = 2 qa + qb
-}
-
 __device__ __forceinline__ float w44_tail(float v, int n, const W44Epi& e, long pix) {
 #pragma clang fp contract(off)
     const float sh = e.shift ? e.shift[n] : 0.f;
@@ -205,7 +188,7 @@ __device__ __forceinline__ float w44_tail(float v, int n, const W44Epi& e, long 
     return v;
 }
 
-// thread = (tile m, channel n): the 36 products -> four quadrant partials per output, summed in wave order, tail, 16 guarded stores
+// thread = (tile m, channel n): the 36 products -> A^T M A (rows first, then columns), tail, 16 guarded stores
 __global__ __launch_bounds__(256) void wino44_output_kernel(const float* __restrict__ M, W44Geom g, int CoutP, W44Epi e) {
     const long idx = (long)blockIdx.x * 256 + threadIdx.x;
     if (idx >= g.T * e.Cout) return;
@@ -215,25 +198,28 @@ __global__ __launch_bounds__(256) void wino44_output_kernel(const float* __restr
     if (t >= g.Timg) return;
     int pa, pb, ty, tx;
     tile44_decode(g, t, pa, pb, ty, tx);
-    float q[2][2][3][3];
+    float z[4][6];
 #pragma unroll
-    for (int i = 0; i < 6; ++i)
+    for (int j = 0; j < 6; ++j) {
+        float col[6], y4[4];
 #pragma unroll
-        for (int j = 0; j < 6; ++j) q[i / 3][j / 3][i % 3][j % 3] = M[((long)(6 * i + j) * g.T + m) * CoutP + n];
-    float o[4][4];
-#define LM_W44_ROW(Y) \
-    o[Y][0] = w44_combine<Y, 0>(q); o[Y][1] = w44_combine<Y, 1>(q); o[Y][2] = w44_combine<Y, 2>(q); o[Y][3] = w44_combine<Y, 3>(q);
-    LM_W44_ROW(0) LM_W44_ROW(1) LM_W44_ROW(2) LM_W44_ROW(3)
-#undef LM_W44_ROW
+        for (int i = 0; i < 6; ++i) col[i] = M[((long)(6 * i + j) * g.T + m) * CoutP + n];
+        w44_at(col, y4);
 #pragma unroll
-    for (int yy = 0; yy < 4; ++yy)
+        for (int yy = 0; yy < 4; ++yy) z[yy][j] = y4[yy];
+    }
+#pragma unroll
+    for (int yy = 0; yy < 4; ++yy) {
+        float o[4];
+        w44_at(z[yy], o);
 #pragma unroll
         for (int xx = 0; xx < 4; ++xx) {
             const int oy = (4 * ty + yy) * g.dil + pa, ox = (4 * tx + xx) * g.dil + pb;
             if (oy >= g.H || ox >= g.W) continue;
             const long pix = ((long)b * g.H + oy) * g.W + ox;
-            e.y[pix * e.ldy + n] = w44_tail(o[yy][xx], n, e, pix);
+            e.y[pix * e.ldy + n] = w44_tail(o[xx], n, e, pix);
         }
+    }
 }
 
 // ===================================================================================================================================
@@ -284,19 +270,28 @@ __device__ __forceinline__ void pk_bt(const f32x2 (&d)[6], f32x2 (&t)[6], const 
     t[4] = pk_fnma(s, k.c2, r);
 }
 
-// TRANSFORM phase of one 8-channel half: this thread = (tile, channel pair, LOWER).  First pass over the patch rows for its three
-// transformed rows (LOWER = false: i = 0, 1, 2 from patch rows 0..4; true: i = 5, 3, 4 from patch rows 1..5), second pass over the
-// columns, 18 planes stored.  rawh = raw buffer + 8 * half; roff[c] = float offset of patch column c of the tile (+ 2 * channel pair)
-template <bool LOWER>
-__device__ __forceinline__ void w44_transform(const float* rawh, float* V, const int (&roff)[6], int voff, const W44K& k) {
+// Transform of one 8-channel half, this thread = (tile, channel pair, LOWER): first pass over the patch rows for its three transformed
+// rows (LOWER = false: i = 0, 1, 2 from patch rows 0..4; true: i = 5, 3, 4 from patch rows 1..5), second pass over the columns, 18
+// planes stored.  The 30 ds_read_b64 of the patch are NOT part of the transform phase: w44_preread issues them one column per step
+// behind the MFMAs of the PREVIOUS phase (LDS instructions are free there), so the phase itself is 72 packed VALU
+// instructions and 18 ds_write_b64.  rawrow = raw buffer + 8 * half + (LOWER ? one patch row : 0); roff[c] = float offset of patch
+// column c of the tile (+ 2 * channel pair).
+struct W44Patch {
+    f32x2 e[6][5];           // [patch column][patch row 0..4 (LOWER: 1..5)]
+};
+template <int C>
+__device__ __forceinline__ void w44_preread(W44Patch& d, const float* rawrow, const int (&roff)[6]) {
     constexpr int ROWF = QNCELL * 16;
+    const float* s = rawrow + roff[C];
+#pragma unroll
+    for (int r = 0; r < 5; ++r) d.e[C][r] = *reinterpret_cast<const f32x2*>(s + r * ROWF);
+}
+template <bool LOWER>
+__device__ __forceinline__ void w44_transform(const W44Patch& d, float* V, int voff, const W44K& k) {
     f32x2 w[3][6];
 #pragma unroll
     for (int c = 0; c < 6; ++c) {
-        const float* s = rawh + roff[c] + (LOWER ? ROWF : 0);
-        const f32x2 e0 = *reinterpret_cast<const f32x2*>(s), e1 = *reinterpret_cast<const f32x2*>(s + ROWF);
-        const f32x2 e2 = *reinterpret_cast<const f32x2*>(s + 2 * ROWF), e3 = *reinterpret_cast<const f32x2*>(s + 3 * ROWF);
-        const f32x2 e4 = *reinterpret_cast<const f32x2*>(s + 4 * ROWF);
+        const f32x2 e0 = d.e[c][0], e1 = d.e[c][1], e2 = d.e[c][2], e3 = d.e[c][3], e4 = d.e[c][4];
         if constexpr (!LOWER) {       // e = d0 .. d4
             w[0][c] = pk_fma(e0, k.c4, pk_fnma(e2, k.c5, e4));
             const f32x2 p = pk_fnma(e2, k.c4, e4), q = pk_fnma(e1, k.c4, e3);
@@ -331,104 +326,91 @@ __device__ __forceinline__ void q_bwait(f32x4 (&b)[2]) {
     asm volatile("s_waitcnt vmcnt(%2)" : "+v"(b[0]), "+v"(b[1]) : "n"(N) : "memory");
 }
 
+#ifdef LM_QPROF                             // (tools/build_variant.sh probe: per-phase shader-clock cycles of wave 0, one record per workgroup)
+constexpr int QPROF_WG = 16384;
+__device__ unsigned long long g_qprof[QPROF_WG][12];
+#define LM_QTICK(slot)                                       \
+    {                                                        \
+        const long long t_now = clock64();                   \
+        qprof[slot] += t_now - t_last;                       \
+        t_last = t_now;                                      \
+    }
+#else
+#define LM_QTICK(slot)
+#endif
+
+// The wave's 288 accumulator registers exceed the 256 AGPRs: the compiler keeps 32 of them in VGPRs and, left to itself, swaps
+// accumulators between the two files inside the loop (48 v_accvgpr_read + 48 v_accvgpr_write per phase, 8 cycles of matrix time each).
+// The ninth xi therefore accumulates through this wrapper, which pins its two blocks to VGPRs; the other eight fill the AGPRs exactly.
+__device__ __forceinline__ void mfma_vgpr(f32x16& acc, float a, float b) {
+    asm volatile("v_mfma_f32_32x32x2_f32 %0, %1, %2, %0" : "+v"(acc) : "v"(a), "v"(b));
+}
+template <bool VACC>
+__device__ __forceinline__ void q_mfma(f32x16& acc, float a, float b) {
+    if constexpr (VACC) mfma_vgpr(acc, a, b);
+    else acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc, 0, 0, 0);
+}
+// Patch loads of unit u + 2 go out in the SECOND phase of unit u (steps 9..17: two per step in 9..13, one in 14..17), into the buffer
+// whose last reads (the pre-reads of unit u's second half) were issued a phase earlier.
+constexpr int q_ndma(int S) { return S < 9 ? 0 : (S < 14 ? 2 : 1); }
+constexpr int q_dma0(int S) { return S < 9 ? 0 : (S < 14 ? 2 * (S - 9) : 10 + (S - 14)); }
+// loads that may stay outstanding when the B fragments of step S are needed: 2 QBD younger B loads + the patch loads of steps S-QBD .. S
+constexpr int q_nwait(int S) {
+    int c = 0;
+    for (int j = S - QBD; j <= S; ++j) c += q_ndma(((j % 18) + 18) % 18);
+    return 2 * QBD + c;
+}
+static_assert(q_dma0(17) + q_ndma(17) == QLPW, "the second phase issues every patch load of a unit");
+
 // One step (one xi of the wave) of an MFMA phase: 8 MFMAs = 4 k steps x 2 channel blocks.  S = step within the unit (0..17: two phases
-// of nine); the B fragments of step S + 5 and (S < QLPW) patch load S of the NEXT unit are issued first.  NWAIT = loads that may stay
-// outstanding when this step's B fragments are needed = 10 younger B loads + the patch loads of steps S-5 .. S.
-template <int S, int NWAIT, bool NEXT>
+// of nine); the B fragments of step S + QBD and the patch loads of this step (q_ndma) are issued first; q_nwait(S) loads may stay
+// outstanding when this step's B fragments are needed.  Behind the first MFMA: the A fragment of the next step and (steps 0..5 of a
+// phase) one column of the NEXT phase's patch pre-read.
+template <int S, bool NEXT>
 __device__ __forceinline__ void w44_step(f32x16& acc0, f32x16& acc1, f32x4 (&bq)[QRING][2], unsigned bvoff, const float* bpre,
                                          const float* anext, const f32x4& a_cur, f32x4& a_nxt, const float* const (&gsrc)[QLPW], long goff,
-                                         float* rawld, int wave) {
+                                         float* rawld, int wave, W44Patch& pre, const float* prerow, const int (&roff)[6]) {
     typedef __attribute__((address_space(1))) const void gptr_t;
     typedef __attribute__((address_space(3))) void lptr_t;
 #ifndef LM_QABL_NOB
     q_bload2(bq[(S + QBD) % QRING], bvoff, bpre);
 #endif
 #ifndef LM_QABL_NOGLDS
-    if constexpr (S < QLPW)
-        __builtin_amdgcn_global_load_lds((gptr_t*)(gsrc[S] + goff), (lptr_t*)(rawld + (S * 4 + wave) * 256), 16, 0, 0);
+#pragma unroll
+    for (int i = 0; i < q_ndma(S); ++i) {
+        constexpr int L0 = q_dma0(S);
+        __builtin_amdgcn_global_load_lds((gptr_t*)(gsrc[L0 + i] + goff), (lptr_t*)(rawld + ((L0 + i) * 4 + wave) * 256), 16, 0, 0);
+    }
 #endif
     f32x4 (&b)[2] = bq[S % QRING];
 #if !defined(LM_QABL_NOB) && !defined(LM_QABL_NOGLDS)
-    q_bwait<NWAIT>(b);
+    q_bwait<q_nwait(S)>(b);
 #else
     q_bwait<0>(b);
 #endif
-    acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a_cur[0], b[0][0], acc0, 0, 0, 0);
+    constexpr bool VACC = (S % 9) == 8;
+    q_mfma<VACC>(acc0, a_cur[0], b[0][0]);
     __builtin_amdgcn_sched_barrier(0);
     if constexpr (NEXT) a_nxt = *reinterpret_cast<const f32x4*>(anext);
+#ifndef LM_QABL_NOT
+    if constexpr ((S % 9) < 6) w44_preread<S % 9>(pre, prerow, roff);
+#endif
     __builtin_amdgcn_sched_barrier(0);
-    acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a_cur[0], b[1][0], acc1, 0, 0, 0);
+    q_mfma<VACC>(acc1, a_cur[0], b[1][0]);
 #pragma unroll
     for (int t = 1; t < 4; ++t) {
-        acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a_cur[t], b[0][t], acc0, 0, 0, 0);
-        acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a_cur[t], b[1][t], acc1, 0, 0, 0);
+        q_mfma<VACC>(acc0, a_cur[t], b[0][t]);
+        q_mfma<VACC>(acc1, a_cur[t], b[1][t]);
     }
     __builtin_amdgcn_sched_barrier(0);
-}
-
-// Epilogue, first pass of the output transform IN PLACE (once): the three products of a column (rows 3 QA .. 3 QA + 2 of the wave's
-// quadrant) become the three values every output row's w44_at<QA, Y> is made of - the same operations w44_at performs, each done once:
-//   QA = 0: (m0, m1, m2) -> (m0 + (m1 + m2), m1 - m2, m1 + m2);   QA = 1: (m3, m4, m5) -> (m3 + m4, m3 - m4, m5)
-template <int QA>
-__device__ __forceinline__ void w44_rows_inplace(f32x16 (&acc)[9][2]) {
-#pragma unroll
-    for (int jj = 0; jj < 3; ++jj)
-#pragma unroll
-        for (int blk = 0; blk < 2; ++blk)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-#pragma clang fp contract(off)
-                const float m0 = acc[jj][blk][r], m1 = acc[3 + jj][blk][r], m2 = acc[6 + jj][blk][r];
-                if constexpr (QA == 0) {
-                    const float s = m1 + m2;
-                    acc[jj][blk][r] = m0 + s;
-                    acc[3 + jj][blk][r] = m1 - m2;
-                    acc[6 + jj][blk][r] = s;
-                } else {
-                    acc[jj][blk][r] = m0 + m1;
-                    acc[3 + jj][blk][r] = m0 - m1;
-                }
-            }
-}
-// w44_at<QA, Y> from the in-place triple (t0, t1, t2) of w44_rows_inplace
-template <int QA, int Y>
-__device__ __forceinline__ float w44_at_inplace(float t0, float t1, float t2) {
-#pragma clang fp contract(off)
-    if constexpr (QA == 0) return Y == 0 ? t0 : (Y == 2 ? t2 : t1);
-    else {
-        if constexpr (Y == 0) return t0;
-        else if constexpr (Y == 1) return 2.f * t1;
-        else if constexpr (Y == 2) return 4.f * t0;
-        else return __builtin_fmaf(8.f, t1, t2);
-    }
-}
-// this wave's partial outputs of output row Y -> xw[x][tile][64 channels] (the exchange buffer of this wave)
-template <int QA, int QB, int Y>
-__device__ __forceinline__ void w44_row_partials(const f32x16 (&acc)[9][2], float* xw) {
-#pragma unroll
-    for (int blk = 0; blk < 2; ++blk)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-#pragma clang fp contract(off)
-            const float z0 = w44_at_inplace<QA, Y>(acc[0][blk][r], acc[3][blk][r], acc[6][blk][r]);
-            const float z1 = w44_at_inplace<QA, Y>(acc[1][blk][r], acc[4][blk][r], acc[7][blk][r]);
-            const float z2 = w44_at_inplace<QA, Y>(acc[2][blk][r], acc[5][blk][r], acc[8][blk][r]);
-            float* o = xw + ((r & 3) + 8 * (r >> 2)) * 64 + blk * 32;
-            o[0 * 32 * 64] = w44_at<QB, 0>(z0, z1, z2);
-            o[1 * 32 * 64] = w44_at<QB, 1>(z0, z1, z2);
-            o[2 * 32 * 64] = w44_at<QB, 2>(z0, z1, z2);
-            o[3 * 32 * 64] = w44_at<QB, 3>(z0, z1, z2);
-        }
-}
-template <int Y>
-__device__ __forceinline__ void w44_row_partials_q(int wave, const f32x16 (&acc)[9][2], float* xw) {
-    if (wave == 0) w44_row_partials<0, 0, Y>(acc, xw);
-    else if (wave == 1) w44_row_partials<0, 1, Y>(acc, xw);
-    else if (wave == 2) w44_row_partials<1, 0, Y>(acc, xw);
-    else w44_row_partials<1, 1, Y>(acc, xw);
 }
 
 __global__ __launch_bounds__(256) void wino44_kernel(W44Params p) {
+#ifdef LM_QPROF
+    long long qprof[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    long long t_last = clock64();
+    const long long t_first = t_last;
+#endif
     extern __shared__ __attribute__((aligned(16))) float smem[];      // raw[2][QRAWF] | V[QVF]; the epilogue's exchange buffer over all of it
     float* const raw0 = smem;
     float* const Vbuf = smem + 2 * QRAWF;
@@ -553,174 +535,234 @@ __global__ __launch_bounds__(256) void wino44_kernel(W44Params p) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[k][b][r] = 0.f;
     f32x4 bq[QRING][2];
-    // prologue: raw unit 0, B of steps 0 .. 4
+    W44Patch pre;
+    const int lowoff = lower ? QNCELL * 16 : 0;               // LOWER threads read patch rows 1..5
+    LM_QTICK(0)
+    // prologue: raw units 0 and 1, B of steps 0 .. QBD-1, pre-read of unit 0's first half
 #pragma unroll
     for (int s_ = 0; s_ < QLPW; ++s_)
         __builtin_amdgcn_global_load_lds((gptr_t*)gsrc[s_], (lptr_t*)(raw0 + (s_ * 4 + wave) * 256), 16, 0, 0);
+    {
+        const long goff1 = nun > 1 ? 16 : 0;
+#pragma unroll
+        for (int s_ = 0; s_ < QLPW; ++s_)
+            __builtin_amdgcn_global_load_lds((gptr_t*)(gsrc[s_] + goff1), (lptr_t*)(raw0 + QRAWF + (s_ * 4 + wave) * 256), 16, 0, 0);
+    }
 #define LM_QXI(K) (6 * ((K) / 3) + (K) % 3)
 #pragma unroll
     for (int k = 0; k < QBD; ++k) q_bload2(bq[k], bvoff, bbase + (long)LM_QXI(k) * xstride);
-    q_bwait<0>(bq[0]);
+    q_bwait<0>(bq[0]);                         // (everything: the wait counts of the first steps assume nothing older is in flight)
     __builtin_amdgcn_s_barrier();
+    w44_preread<0>(pre, raw0 + lowoff, roff); w44_preread<1>(pre, raw0 + lowoff, roff); w44_preread<2>(pre, raw0 + lowoff, roff);
+    w44_preread<3>(pre, raw0 + lowoff, roff); w44_preread<4>(pre, raw0 + lowoff, roff); w44_preread<5>(pre, raw0 + lowoff, roff);
+    LM_QTICK(1)
 
-    // B fragments of step S5 = S + 5 of the unit (S5 >= 18: first phase of the next unit)
+    // B fragments of step S5 = S + QBD of the unit (S5 >= 18: first phase of the next unit)
 #define LM_QBPRE(S5) ((S5) < 18 ? bu + (long)((S5) / 9) * ustride + (long)LM_QXI((S5) % 9) * xstride : bu_next + (long)LM_QXI((S5) - 18) * xstride)
-#define LM_QSTEP(S, NW, AC, AN) \
-    w44_step<S, NW, ((S) % 9) < 8>(acc[(S) % 9][0], acc[(S) % 9][1], bq, bvoff, LM_QBPRE((S) + QBD), Vq + LM_QXI(((S) % 9) + 1 < 9 ? ((S) % 9) + 1 : 0) * 256, \
-                                   AC, AN, gsrc, goff, rawn, wave)
+#define LM_QSTEP(S, AC, AN) \
+    w44_step<S, ((S) % 9) < 8>(acc[(S) % 9][0], acc[(S) % 9][1], bq, bvoff, LM_QBPRE((S) + QBD), Vq + LM_QXI(((S) % 9) + 1 < 9 ? ((S) % 9) + 1 : 0) * 256, \
+                               AC, AN, gsrc, goff, rawc_w, wave, pre, (S) < 9 ? rawc + 8 + lowoff : rawn + lowoff, roff)
     for (int u = 0; u < nun; ++u) {
-        const float* const rawc = raw0 + (u & 1) * QRAWF;
-        float* const rawn = raw0 + ((u + 1) & 1) * QRAWF;
-        const long goff = u + 1 < nun ? (long)(u + 1) * 16 : 0;            // (nothing left to fetch: harmless re-read of unit 0)
+        const float* const rawc = raw0 + (u & 1) * QRAWF;              // unit u
+        float* const rawc_w = raw0 + (u & 1) * QRAWF;                  // ... and the destination of unit u + 2's patch loads (second phase)
+        const float* const rawn = raw0 + ((u + 1) & 1) * QRAWF;        // unit u + 1 (pre-read in the second phase)
+        const long goff = u + 2 < nun ? (long)(u + 2) * 16 : 0;            // (nothing left to fetch: harmless re-read of unit 0)
         const float* const bu = bbase + (long)(2 * u) * ustride;
         const float* const bu_next = bbase + (long)(u + 1 < nun ? 2 * (u + 1) : 0) * ustride;
         f32x4 a0, a1;
-        // ---- channels 16 u .. 16 u + 7
-        if (lower) w44_transform<true>(rawc, Vbuf, roff, tvoff, kk);
-        else w44_transform<false>(rawc, Vbuf, roff, tvoff, kk);
+        // ---- channels 16 u .. 16 u + 7 (patch pre-read during the previous phase)
+#ifndef LM_QABL_NOT
+        if (lower) w44_transform<true>(pre, Vbuf, tvoff, kk);
+        else w44_transform<false>(pre, Vbuf, tvoff, kk);
+#endif
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        LM_QTICK(2)
         __builtin_amdgcn_s_barrier();
+        LM_QTICK(3)
         a0 = *reinterpret_cast<const f32x4*>(Vq);
-        LM_QSTEP(0, 12, a0, a1); LM_QSTEP(1, 12, a1, a0); LM_QSTEP(2, 13, a0, a1);
-        LM_QSTEP(3, 14, a1, a0); LM_QSTEP(4, 15, a0, a1); LM_QSTEP(5, 16, a1, a0);
-        LM_QSTEP(6, 16, a0, a1); LM_QSTEP(7, 16, a1, a0); LM_QSTEP(8, 16, a0, a1);
+        LM_QSTEP(0, a0, a1); LM_QSTEP(1, a1, a0); LM_QSTEP(2, a0, a1);
+        LM_QSTEP(3, a1, a0); LM_QSTEP(4, a0, a1); LM_QSTEP(5, a1, a0);
+        LM_QSTEP(6, a0, a1); LM_QSTEP(7, a1, a0); LM_QSTEP(8, a0, a1);
+        LM_QTICK(4)
         __builtin_amdgcn_s_barrier();                                       // V is free again
+        LM_QTICK(5)
         // ---- channels 16 u + 8 .. 16 u + 15
-        if (lower) w44_transform<true>(rawc + 8, Vbuf, roff, tvoff, kk);
-        else w44_transform<false>(rawc + 8, Vbuf, roff, tvoff, kk);
+#ifndef LM_QABL_NOT
+        if (lower) w44_transform<true>(pre, Vbuf, tvoff, kk);
+        else w44_transform<false>(pre, Vbuf, tvoff, kk);
+#endif
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        LM_QTICK(2)
+        // unit u + 1 (patch loads of the previous unit's second phase, or of the prologue) is pre-read in the phase that follows: every
+        // load older than the 18 B loads of the phase just finished has landed
+        q_bwait<2 * 9>(bq[0]);
+        LM_QTICK(6)
         __builtin_amdgcn_s_barrier();
+        LM_QTICK(3)
         a0 = *reinterpret_cast<const f32x4*>(Vq);
-        LM_QSTEP(9, 16, a0, a1);  LM_QSTEP(10, 16, a1, a0); LM_QSTEP(11, 16, a0, a1);
-        LM_QSTEP(12, 16, a1, a0); LM_QSTEP(13, 16, a0, a1); LM_QSTEP(14, 15, a1, a0);
-        LM_QSTEP(15, 14, a0, a1); LM_QSTEP(16, 13, a1, a0); LM_QSTEP(17, 12, a0, a1);
-        q_bwait<8>(bq[0]);                     // this wave's patch loads (steps 0 .. 13) have landed: only steps 14 .. 17's B loads are younger
-        __builtin_amdgcn_s_barrier();          // V free, raw(u) free, raw(u + 1) landed
+        LM_QSTEP(9, a0, a1);  LM_QSTEP(10, a1, a0); LM_QSTEP(11, a0, a1);
+        LM_QSTEP(12, a1, a0); LM_QSTEP(13, a0, a1); LM_QSTEP(14, a1, a0);
+        LM_QSTEP(15, a0, a1); LM_QSTEP(16, a1, a0); LM_QSTEP(17, a0, a1);
+        LM_QTICK(4)
+        __builtin_amdgcn_s_barrier();          // V free
+        LM_QTICK(5)
     }
 #undef LM_QSTEP
 #undef LM_QBPRE
 #undef LM_QXI
-    static_assert(QLPW == 14 && QBD == 5 && QRING == 6, "NWAIT table above");
+    static_assert(18 % QRING == 0 && QBD < QRING, "eighteen steps per unit walk the ring a whole number of times");
 #pragma unroll
     for (int k = 0; k < QRING; ++k) q_bwait<0>(bq[k]);
 
-    // ---- epilogue
-    float* const xw = smem + wave * (4 * 32 * 64) + (4 * (lane >> 5)) * 64 + (lane & 31);      // this wave's exchange block, this lane's origin
-    const int q4 = (lane & 15) * 4;
-    const int n = n0 + q4;
-    f32x4 sc = {1.f, 1.f, 1.f, 1.f}, sh = {0.f, 0.f, 0.f, 0.f};
-    if (n < p.Cout) {
-#pragma unroll
-        for (int e = 0; e < 4; ++e)
-            if (n + e < p.Cout) {
-                if (p.scale) sc[e] = p.scale[n + e];
-                if (p.shift) sh[e] = p.shift[n + e];
-            }
-    }
-    const bool vec = (n + 3 < p.Cout) && ((p.ldy & 3) == 0) && (!p.res || (p.ldr & 3) == 0);
-    f32x4 gs = {0.f, 0.f, 0.f, 0.f}, gq = {0.f, 0.f, 0.f, 0.f};
-    constexpr int NP = 8;                                   // passes: tile = 4 pass + lane / 16
-    int pix0[NP];
-    unsigned nyx[NP];                                       // valid output rows (low 3 bits) and columns (next 3) of the tile, 0 = no tile
-#pragma unroll
-    for (int pass = 0; pass < NP; ++pass) {
-        const int tl = pass * 4 + (lane >> 4);
+    LM_QTICK(7)
+#ifdef LM_QABL_NOEPI
+    if (p.act != 12345) return;
+#endif
+    // ---- epilogue: the products of one 32-channel block go to LDS as M[xi][tile][32 channels] (144 KB; straight from the accumulator
+    // registers), every thread takes one (tile, channel quad): 36 ds_read_b128, A^T M A (rows first, then columns: w44_at), tail, 16 stores
+    const int etile = tid >> 3, ecq = tid & 7;
+    int epix0;
+    int eny = 0, enx = 0;                                   // valid output rows / columns of this thread's tile (0: no tile)
+    {
         int nn = sn[0], oy = oy0[0], oxb = ox0[0], tb = 0;
 #pragma unroll
         for (int k = 1; k < QSEG; ++k)
-            if (tl >= ts[k]) {
+            if (etile >= ts[k]) {
                 nn = sn[k]; oy = oy0[k]; oxb = ox0[k]; tb = ts[k];
             }
-        const int ox = oxb + 4 * (tl - tb) * g.dil;
-        pix0[pass] = img_pix0 + oy * g.W + ox;
-        unsigned v = 0;
+        const int ox = oxb + 4 * (etile - tb) * g.dil;
+        epix0 = img_pix0 + oy * g.W + ox;
         if (nn > 0 && oy < g.H && ox < g.W) {
-            const int ny = min(4, (g.H - oy + g.dil - 1) / g.dil), nx = min(4, (g.W - ox + g.dil - 1) / g.dil);
-            v = (unsigned)ny | ((unsigned)nx << 3);
+            eny = min(4, (g.H - oy + g.dil - 1) / g.dil);
+            enx = min(4, (g.W - ox + g.dil - 1) / g.dil);
         }
-        nyx[pass] = v;
     }
-    const int xcol = wave;                                  // this wave sums and stores output column x = wave of every tile
-    if (wave < 2) w44_rows_inplace<0>(acc);
-    else w44_rows_inplace<1>(acc);
-#define LM_QROW(Y)                                                                                                              \
-    {                                                                                                                           \
-        __syncthreads();                       /* patch / V buffers (Y = 0) or the previous row's partials are no longer read */ \
-        w44_row_partials_q<Y>(wave, acc, xw);                                                                                   \
-        __syncthreads();                                                                                                        \
-        if (n < p.Cout) {                                                                                                       \
-            _Pragma("unroll") for (int pass = 0; pass < NP; ++pass) {                                                           \
-                const unsigned v_ = nyx[pass];                                                                                  \
-                if ((int)(v_ & 7u) <= (Y) || (int)(v_ >> 3) <= xcol) continue;                                                  \
-                const int tl = pass * 4 + (lane >> 4);                                                                          \
-                const float* s_ = smem + (xcol * 32 + tl) * 64 + q4;                                                            \
-                const f32x4 p0 = *reinterpret_cast<const f32x4*>(s_), p1 = *reinterpret_cast<const f32x4*>(s_ + 4 * 32 * 64);   \
-                const f32x4 p2 = *reinterpret_cast<const f32x4*>(s_ + 8 * 32 * 64), p3 = *reinterpret_cast<const f32x4*>(s_ + 12 * 32 * 64); \
-                const long pix = pix0[pass] + ((Y) * g.W + xcol) * g.dil;                                                       \
-                w44_store(p, p0, p1, p2, p3, sc, sh, gs, gq, vec, n, pix);                                                      \
-            }                                                                                                                   \
-        }                                                                                                                       \
+    float* const mw = smem + xi00 * 1024 + (4 * (lane >> 5)) * 32 + (lane & 31);      // this wave's planes, this lane's origin
+    const float* const mr = smem + etile * 32 + ecq * 4;
+    f32x4 gsum[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}}, gsq[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+#pragma unroll
+    for (int blk = 0; blk < 2; ++blk) {
+        const int n = n0 + blk * 32 + ecq * 4;
+        const bool vec = (n + 3 < p.Cout) && ((p.ldy & 3) == 0) && (!p.res || (p.ldr & 3) == 0);
+        // residual (BasicBlock identity): the sixteen 16-byte loads of this thread's outputs go out BEFORE the exchange - inside the
+        // store loop each was a memory round trip of its own in front of a store (y may alias res as far as the compiler knows)
+        f32x4 rpre[16];
+        if (vec && p.res) {
+#pragma unroll
+            for (int q = 0; q < 16; ++q) {
+                const bool ok = (q >> 2) < eny && (q & 3) < enx;
+                const long pix = epix0 + ((q >> 2) * g.W + (q & 3)) * g.dil;
+                rpre[q] = ok ? *reinterpret_cast<const f32x4*>(p.res + pix * p.ldr + n) : f32x4{0.f, 0.f, 0.f, 0.f};
+            }
+        }
+        // (LDS-only barriers: __syncthreads() would also wait for the previous block's global stores to be acknowledged)
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();          // patch / V buffers (blk 0) or the previous block's products are no longer read
+#pragma unroll
+        for (int k = 0; k < 9; ++k)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) mw[(6 * (k / 3) + k % 3) * 1024 + ((r & 3) + 8 * (r >> 2)) * 32] = acc[k][blk][r];
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        LM_QTICK(8)
+        __builtin_amdgcn_s_barrier();
+        LM_QTICK(9)
+        if (n < p.Cout && eny > 0) {
+            f32x4 z[4][6];
+#pragma unroll
+            for (int j = 0; j < 6; ++j) {
+                f32x4 col[6], y4[4];
+#pragma unroll
+                for (int i = 0; i < 6; ++i) col[i] = *reinterpret_cast<const f32x4*>(mr + (6 * i + j) * 1024);
+                w44_at(col, y4);
+#pragma unroll
+                for (int yy = 0; yy < 4; ++yy) z[yy][j] = y4[yy];
+            }
+            f32x4 sc = {1.f, 1.f, 1.f, 1.f}, sh = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+                if (n + e < p.Cout) {
+                    if (p.scale) sc[e] = p.scale[n + e];
+                    if (p.shift) sh[e] = p.shift[n + e];
+                }
+#pragma unroll
+            for (int yy = 0; yy < 4; ++yy) {
+                if (yy >= eny) break;
+                f32x4 o[4];
+                w44_at(z[yy], o);
+#pragma unroll
+                for (int xx = 0; xx < 4; ++xx) {
+#pragma clang fp contract(off)
+                    if (xx >= enx) break;
+                    const long pix = epix0 + (yy * g.W + xx) * g.dil;
+                    f32x4 v;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] = p.scale ? o[xx][e] * sc[e] + sh[e] : o[xx][e] + sh[e];
+                    if (p.gn_part) {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            gsum[blk][e] += v[e];
+                            gsq[blk][e] = __builtin_fmaf(v[e], v[e], gsq[blk][e]);
+                        }
+                    }
+                    if (vec) {
+                        if (p.res) {
+                            const f32x4 rr = rpre[yy * 4 + xx];
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) v[e] += rr[e];
+                        }
+                        if (p.act == LM_ACT_RELU) {
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
+                        }
+                        *reinterpret_cast<f32x4*>(p.y + pix * p.ldy + n) = v;
+                    } else {
+                        for (int e = 0; e < 4 && n + e < p.Cout; ++e) {
+                            float u = v[e];
+                            if (p.res) u += p.res[pix * p.ldr + n + e];
+                            if (p.act == LM_ACT_RELU) u = fmaxf(u, 0.f);
+                            p.y[pix * p.ldy + n + e] = u;
+                        }
+                    }
+                }
+            }
+        }
     }
-    // (the tail of one output position: a lambda keeps the macro short)
-    auto w44_store = [](const W44Params& p, const f32x4 p0, const f32x4 p1, const f32x4 p2, const f32x4 p3, const f32x4 sc, const f32x4 sh,
-                        f32x4& gs, f32x4& gq, bool vec, int n, long pix) {
-#pragma clang fp contract(off)
-        f32x4 v;
+    LM_QTICK(10)
+#ifdef LM_QPROF
+    if (tid == 0) {
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            const float s = ((p0[e] + p1[e]) + p2[e]) + p3[e];
-            v[e] = p.scale ? s * sc[e] + sh[e] : s + sh[e];
-        }
-        if (p.gn_part) {
+        for (int k = 0; k < 11; ++k) g_qprof[blockIdx.x % QPROF_WG][k] = (unsigned long long)qprof[k];
+        g_qprof[blockIdx.x % QPROF_WG][11] = (unsigned long long)(clock64() - t_first);
+    }
+#endif
+    if (p.gn_part) {      // fixed-order reduction: the 8 lanes of a wave that share a channel quad, then the four waves through LDS
 #pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                gs[e] += v[e];
-                gq[e] = __builtin_fmaf(v[e], v[e], gq[e]);
-            }
-        }
-        if (vec) {
-            if (p.res) {
-                const f32x4 rr = *reinterpret_cast<const f32x4*>(p.res + pix * p.ldr + n);
+        for (int blk = 0; blk < 2; ++blk)
 #pragma unroll
-                for (int e = 0; e < 4; ++e) v[e] += rr[e];
-            }
-            if (p.act == LM_ACT_RELU) {
+            for (int o = 8; o < 64; o <<= 1)
 #pragma unroll
-                for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
-            }
-            *reinterpret_cast<f32x4*>(p.y + pix * p.ldy + n) = v;
-        } else {
-            for (int e = 0; e < 4 && n + e < p.Cout; ++e) {
-                float u = v[e];
-                if (p.res) u += p.res[pix * p.ldr + n + e];
-                if (p.act == LM_ACT_RELU) u = fmaxf(u, 0.f);
-                p.y[pix * p.ldy + n + e] = u;
-            }
-        }
-    };
-    LM_QROW(0) LM_QROW(1) LM_QROW(2) LM_QROW(3)
-#undef LM_QROW
-    if (p.gn_part) {      // fixed-order reduction: the 4 lanes that share a channel quad, then the four waves through LDS
-#pragma unroll
-        for (int o = 16; o < 64; o <<= 1)
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                gs[e] += __shfl_xor(gs[e], o);
-                gq[e] += __shfl_xor(gq[e], o);
-            }
+                for (int e = 0; e < 4; ++e) {
+                    gsum[blk][e] += __shfl_xor(gsum[blk][e], o);
+                    gsq[blk][e] += __shfl_xor(gsq[blk][e], o);
+                }
         __syncthreads();
-        if (lane < 16) {
-            *reinterpret_cast<f32x4*>(smem + ((wave * 16 + lane) * 2) * 4) = gs;
-            *reinterpret_cast<f32x4*>(smem + ((wave * 16 + lane) * 2 + 1) * 4) = gq;
+        if (lane < 8) {
+#pragma unroll
+            for (int blk = 0; blk < 2; ++blk) {
+                *reinterpret_cast<f32x4*>(smem + (((wave * 2 + blk) * 8 + lane) * 2) * 4) = gsum[blk];
+                *reinterpret_cast<f32x4*>(smem + (((wave * 2 + blk) * 8 + lane) * 2 + 1) * 4) = gsq[blk];
+            }
         }
         __syncthreads();
-        if (wave == 0 && lane < 16 && n < p.Cout) {
+        if (tid < 16) {
 #pragma clang fp contract(off)
-            f32x4 s = gs, q = gq;
+            const int blk = tid >> 3, cq = tid & 7;
+            const int n = n0 + blk * 32 + cq * 4;
+            f32x4 s = {0.f, 0.f, 0.f, 0.f}, q = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-            for (int w = 1; w < 4; ++w) {
-                const f32x4 a = *reinterpret_cast<const f32x4*>(smem + ((w * 16 + lane) * 2) * 4);
-                const f32x4 b = *reinterpret_cast<const f32x4*>(smem + ((w * 16 + lane) * 2 + 1) * 4);
+            for (int w = 0; w < 4; ++w) {
+                const f32x4 a = *reinterpret_cast<const f32x4*>(smem + (((w * 2 + blk) * 8 + cq) * 2) * 4);
+                const f32x4 b = *reinterpret_cast<const f32x4*>(smem + (((w * 2 + blk) * 8 + cq) * 2 + 1) * 4);
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
                     s[e] += a[e];
@@ -755,6 +797,23 @@ int w44_zeros(const float** out) {      // per device (a process may drive sever
 }
 
 }  // namespace
+
+#ifdef LM_QPROF
+extern "C" __attribute__((visibility("default"))) int lm_qprof_read(unsigned long long* out, int reset) {
+    static unsigned long long host[QPROF_WG][12];
+    if (hipMemcpyFromSymbol(host, HIP_SYMBOL(g_qprof), sizeof(host)) != hipSuccess) return 1;
+    for (int k = 0; k < 13; ++k) out[k] = 0;
+    for (int w = 0; w < QPROF_WG; ++w) {
+        for (int k = 0; k < 12; ++k) out[k] += host[w][k];
+        if (host[w][11]) ++out[12];
+    }
+    if (reset) {
+        static unsigned long long zero[QPROF_WG][12];
+        if (hipMemcpyToSymbol(HIP_SYMBOL(g_qprof), zero, sizeof(zero)) != hipSuccess) return 1;
+    }
+    return 0;
+}
+#endif
 
 // 1 if lm_conv3x3_winograd44_f32 covers the shape
 LM_API int lm_winograd44_supported(int H, int W, int Cin, int dil) {
@@ -797,7 +856,7 @@ LM_API int lm_conv3x3_winograd44_f32(void* stream, const float* x, int ldx, cons
     // an input larger than the 256 MB Infinity Cache would be re-read from HBM once per N tile in the N-outer order: N inner there
     p.n_inner = order >= 0 ? order : ((long)B * H * W * Cin * 4 > (256L << 20) ? 1 : 0);
     const size_t lds = (size_t)(2 * QRAWF + QVF) * sizeof(float);
-    static_assert(4 * 4 * 32 * 64 <= 2 * QRAWF + QVF, "the exchange buffer of the epilogue fits");
+    static_assert(36 * 32 * 32 <= 2 * QRAWF + QVF, "the product buffer of the epilogue fits");
     const long blocks = (p.g.T / QBM) * ((Cout + QBN - 1) / QBN);
     LM_REQUIRE(blocks > 0 && blocks < (1L << 31) && p.g.T % QBM == 0, "conv_wino44: bad grid %ld", blocks);
     if (int e = lm_ensure_dynamic_lds((const void*)wino44_kernel, lds)) return e;
