@@ -148,6 +148,8 @@ def second_line(args):
         cmd += ['--host-cores', str(args.host_cores)]
     if args.host_threads is not None:
         cmd += ['--host-threads', str(args.host_threads)]
+    if getattr(args, 'graphs', False):
+        cmd += ['--graphs']                      # (the second line runs in the headline's launch mode)
     if args.no_graphs:
         cmd += ['--no-graphs']
     try:
@@ -177,8 +179,10 @@ def main():
     ap.add_argument('--warmup', type=int, default=3)
     ap.add_argument('--cpu-budget-s', type=float, default=25.0)
     ap.add_argument('--no-cpu-baseline', action='store_true')
-    ap.add_argument('--no-second-line', action='store_true',
-                    help='skip the declared second measurement (the same workload with LANEMAP_WINO_BF16X3=1, run in a child process at N = 1)')
+    ap.add_argument('--second-line', action='store_true',
+                    help='also run the declared second measurement (the same workload with LANEMAP_WINO_BF16X3=1, in a child process at N = 1). '
+                         'Off by default since round 4: the exact-fp32 F(4x4) headline is faster than the split-precision F(2x2) line')
+    ap.add_argument('--no-second-line', action='store_true', help='(accepted for older command lines: the second line is off unless --second-line)')
     ap.add_argument('--host-threads', type=int, default=None, help='post-processing pool threads per pipeline (default 8; max(1, K - 1) under --host-cores K)')
     ap.add_argument('--host-cores', type=int, default=None,
                     help='per-rank host budget: pin this process (rank r) to K of the cores it may use, cores [r*K, (r+1)*K), BEFORE any GPU call - '
@@ -482,7 +486,7 @@ def main():
     def kclass(kind):
         k = kind.split(' ', 1)[0]
         return {'wino_gemm': 'wino_gemm_kernel', 'wino_implicit': 'wino_implicit_kernel', 'wino_input': 'wino_input_kernel',
-                'wino_bf16x3': 'wino_rows_split_kernel<bf16x3>'}.get(k, 'conv_mfma_kernel')
+                'wino_bf16x3': 'wino_rows_split_kernel<bf16x3>', 'wino44': 'wino44_kernel'}.get(k, 'conv_mfma_kernel')
     # peak of the dtype a kernel class issues: exact-fp32 MFMA, or (opt-in LANEMAP_WINO_BF16X3=1) bf16 MFMA fed with 3-way split fp32 operands
     peak_of = lambda c: BF16_PEAK_TFLOPS if 'bf16x3' in c else MFMA_F32_PEAK_TFLOPS
     cls = {}
@@ -547,7 +551,8 @@ def main():
                    max(1, sum(p_.host_tiles for p_ in [pipe] + extra_pipes))},
         'roofline': {'bound': 'mfma',
                      'kernel': 'every MFMA convolution / GEMM launch of a step (' + ', '.join(sorted(per_class)) + ')',
-                     # EXECUTED view: FLOPs the matrix cores really issue (Winograd F(2x2,3x3) launches: 16/36 of the direct count)
+                     # EXECUTED view: FLOPs the matrix cores really issue (Winograd F(4x4,3x3) launches: 36/144 of the direct count,
+                     # F(2x2,3x3) launches: 16/36)
                      # / summed HIP-event time of those launches (the HBM-bound Winograd input transforms included)
                      'achieved': executed_tflops, 'peak': MFMA_F32_PEAK_TFLOPS, 'unit': 'TFLOP/s',
                      # time-weighted utilisation: sum_k (executed_k / peak_k) / sum_k t_k  (== achieved / peak when every launch is fp32 MFMA)
@@ -561,7 +566,7 @@ def main():
                      'dominant_kernel': dominant, 'per_kernel': per_class,
                      'note': 'achieved / frac = executed MFMA FLOPs / launch time / fp32 MFMA peak (always <= 1). algorithmic_equiv_tflops = '
                              'direct-convolution FLOPs (SURVEY 8d: 2 per MAC of the 3x3 sums) / the same time: it exceeds the executed figure '
-                             'because Winograd does 16 multiplies where the direct sum does 36'},
+                             'because Winograd F(4x4,3x3) does 36 multiplies where the direct sum does 144 (F(2x2,3x3): 16 for 36)'},
     }
     if args.workload == 'fused' and rast['pairs']:
         rms = sum(a.elapsed_time(b) for a, b in rast['pairs']) / len(rast['pairs'])
@@ -587,7 +592,7 @@ def main():
         result['roofline'].update({'achieved': d['executed_tflops'], 'peak': d['peak'], 'frac': d['frac'],
                                    'fp32_product_tflops': d['executed_tflops'] / 6.0,
                                    'kernel': dominant + ' (the Winograd GEMMs; the other MFMA launches of a step are listed in per_kernel)'})
-    if rank == 0 and world == 1 and not split_on and not args.no_second_line and args.workload in ('fused', 'tiles', 'rowref'):
+    if rank == 0 and world == 1 and not split_on and args.second_line and not args.no_second_line and args.workload in ('fused', 'tiles', 'rowref'):
         result['second_line'] = second_line(args)
     if rank == 0:
         # the CPU path timed on this node's own host cores in the same run, next to the 1 / 2 / 4 / 8-GPU numbers (north_star); at N > 1

@@ -38,6 +38,16 @@ WINO_IMPLICIT_MIN_CIN = int(os.environ.get('LANEMAP_WINO_IMPLICIT_MIN_CIN', '64'
 # product; fp32-rounding-class error, profiles/r2_split_precision_study.txt; csrc/conv_wino.hip wino_rows_split_kernel).
 # Off by default because its results are not bit-identical to the fp32 kernels; 1.2-1.4x faster per layer, bench.py's second line.
 WINO_BF16X3 = os.environ.get('LANEMAP_WINO_BF16X3', '0') != '0'
+# Winograd F(4x4,3x3) (csrc/conv_wino44.hip, round 4): 36 products per 4x4 output block instead of 4 x 16 - 0.5625x the matrix work of
+# the F(2x2) kernels, still exact fp32 MFMA; 1.3-1.5x faster per layer on every FPN shape.  Not bit-identical to the F(2x2) family
+# (transform constants up to 8 and down to 1/24; numerics priced in profiles/r3_f44_numerics_study.txt and held by the parity suite).
+# Takes every 3x3 / stride-1 layer it supports (Cin % 16 == 0, tile rows of >= 15 tiles); LANEMAP_WINO_F44=0 switches back to F(2x2).
+WINO_F44 = os.environ.get('LANEMAP_WINO_F44', '1') != '0' and not WINO_BF16X3
+WINO_F44_MIN_CIN = int(os.environ.get('LANEMAP_WINO_F44_MIN_CIN', '64'))
+
+
+def _frag44(w):
+    return ops.pack_wino44_fragments(ops.pack_wino44(w))
 
 
 def _frag(wu):
@@ -149,6 +159,8 @@ class FPNEncoder(PackedModule):
                             u = P[k + q] = ops.pack_wino(conv.weight)
                         if WINO_IMPLICIT and conv.in_channels >= WINO_IMPLICIT_MIN_CIN and conv.in_channels % 32 == 0:
                             P[k + q + 'f'] = _frag(u if u is not None else ops.pack_wino(conv.weight))
+                        if WINO_F44 and conv.in_channels >= WINO_F44_MIN_CIN and conv.in_channels % 16 == 0:
+                            P[k + q + 'q'] = _frag44(conv.weight)
                 if blk.downsample is not None:
                     P[k + '.wd'] = ops.pack_mfma(blk.downsample[0].weight)
                     P[k + '.sd'], P[k + '.bd'] = ops.fold_bn(blk.downsample[1])
@@ -161,6 +173,8 @@ class FPNEncoder(PackedModule):
                 P[name + '.wu'] = ops.pack_wino(m.weight)
                 if WINO_IMPLICIT:
                     P[name + '.wuf'] = _frag(P[name + '.wu'])
+                if WINO_F44 and m.in_channels % 16 == 0:
+                    P[name + '.wuq'] = _frag44(m.weight)
         # the two branches convolve p2 and p3 with different weights: one GEMM with the output channels concatenated reads V once
         # per 4 N tiles instead of per 2 (same values per channel: an output column does not depend on its neighbours)
         a, b2 = self.semantic_branch, self.semantic_branch2
@@ -170,12 +184,16 @@ class FPNEncoder(PackedModule):
             P['semantic_branch_ab.b'] = torch.cat([a.bias, b2.bias]).float().contiguous()
             if WINO_IMPLICIT:
                 P['semantic_branch_ab.wuf'] = _frag(P['semantic_branch_ab.wu'])
+            if WINO_F44 and a.in_channels % 16 == 0:
+                P['semantic_branch_ab.wuq'] = _frag44(torch.cat([a.weight, b2.weight], dim=0))
             if ('conv2.wu' in P and 'conv3.wu' in P and self.conv2.out_channels == self.conv3.out_channels
                     and self.gn12.eps == self.gn22.eps):           # likewise conv2 / conv3 on p4
                 P['conv23.wu'] = ops.pack_wino(torch.cat([self.conv2.weight, self.conv3.weight], dim=0))
                 P['conv23.b'] = torch.cat([self.conv2.bias, self.conv3.bias]).float().contiguous()
                 if WINO_IMPLICIT:
                     P['conv23.wuf'] = _frag(P['conv23.wu'])
+                if WINO_F44 and self.conv2.in_channels % 16 == 0:
+                    P['conv23.wuq'] = _frag44(torch.cat([self.conv2.weight, self.conv3.weight], dim=0))
         if self.out is not None:
             P['out.w'] = ops.pack_mfma(self.out.weight)
         for name in ('feature_layer', 'output_layer_binary_seg', 'output_layer_endp'):
@@ -191,6 +209,8 @@ class FPNEncoder(PackedModule):
     @staticmethod
     def _c3(x, P, wkey, cout, stride, dil, **epi):
         """3x3 convolution, pad = dilation: Winograd when its transformed weights were packed, else the direct kernel."""
+        if (wkey + 'uq') in P and stride == 1 and ops.wino44_supported(x.shape[2], x.shape[3], x.shape[1], dil):
+            return ops.conv_wino44(x, P[wkey + 'uq'], cout, dil, **epi)
         if (wkey + 'uf') in P and stride == 1 and ops.wino_implicit_supported(x.shape[2], x.shape[3], x.shape[1], dil):
             return ops.conv_wino_implicit(x, P[wkey + 'uf'], cout, dil, **epi)
         if (wkey + 'u') in P and stride == 1:
@@ -218,7 +238,9 @@ class FPNEncoder(PackedModule):
         def conv_stats(src, conv, cout, gn, share=None):
             # conv3x3 + bias with the GroupNorm statistics coming out of the conv epilogue
             eps = getattr(self, gn).eps
-            if (conv + '.wuf') in P and not isinstance(src, ops.WinoInput) and ops.wino_implicit_supported(src.shape[2], src.shape[3], src.shape[1], 1):
+            if (conv + '.wuq') in P and not isinstance(src, ops.WinoInput) and ops.wino44_supported(src.shape[2], src.shape[3], src.shape[1], 1):
+                t, st = ops.conv_wino44(src, P[conv + '.wuq'], cout, 1, shift=P[conv + '.b'], gn_eps=eps)
+            elif (conv + '.wuf') in P and not isinstance(src, ops.WinoInput) and ops.wino_implicit_supported(src.shape[2], src.shape[3], src.shape[1], 1):
                 t, st = ops.conv_wino_implicit(src, P[conv + '.wuf'], cout, 1, shift=P[conv + '.b'], gn_eps=eps)     # no V tensor
             elif (conv + '.wu') in P:                           # Winograd; p2/p3/p4 are transformed once for both branches
                 if share is not None:
@@ -234,7 +256,8 @@ class FPNEncoder(PackedModule):
             return t, st
 
         t, st = pre_a4 if pre_a4 is not None else conv_stats(p4, conv_a, p4.shape[1], gn_a, share='p4')
-        imp_b = (conv_b + '.wuf') in P and ops.wino_implicit_supported(h, w, t.shape[1], 1)
+        imp_b = (((conv_b + '.wuf') in P and ops.wino_implicit_supported(h, w, t.shape[1], 1))
+                 or ((conv_b + '.wuq') in P and ops.wino44_supported(h, w, t.shape[1], 1)))
         if (not imp_b and FUSE_UP_WINO and (conv_b + '.wu') in P and (h, w) == (2 * t.shape[2], 2 * t.shape[3]) and t.shape[1] in (128, 256)):
             # s4 feeds only conv_b: its Winograd input comes straight from t, the upsampled 256-channel tensor is never written
             s4 = ops.wino_transform_gn_up2(t, st, P[gn_a + '.g'], P[gn_a + '.b'])
@@ -295,7 +318,10 @@ class FPNEncoder(PackedModule):
             ch = self.semantic_branch.out_channels
             pre_a, pre_b = [], []
             for key, src in (('p2', p2), ('p3', p3)):
-                if 'semantic_branch_ab.wuf' in P and ops.wino_implicit_supported(src.shape[2], src.shape[3], src.shape[1], 1):
+                if 'semantic_branch_ab.wuq' in P and ops.wino44_supported(src.shape[2], src.shape[3], src.shape[1], 1):
+                    t, st = ops.conv_wino44(src, P['semantic_branch_ab.wuq'], 2 * ch, 1, shift=P['semantic_branch_ab.b'],
+                                            gn_eps=self.gn11.eps, gn_split=2)
+                elif 'semantic_branch_ab.wuf' in P and ops.wino_implicit_supported(src.shape[2], src.shape[3], src.shape[1], 1):
                     t, st = ops.conv_wino_implicit(src, P['semantic_branch_ab.wuf'], 2 * ch, 1, shift=P['semantic_branch_ab.b'],
                                                    gn_eps=self.gn11.eps, gn_split=2)
                 else:
@@ -307,7 +333,9 @@ class FPNEncoder(PackedModule):
         a4 = b4 = None
         if 'conv23.wu' in P:
             c4o = self.conv2.out_channels
-            if 'conv23.wuf' in P and ops.wino_implicit_supported(p4.shape[2], p4.shape[3], p4.shape[1], 1):
+            if 'conv23.wuq' in P and ops.wino44_supported(p4.shape[2], p4.shape[3], p4.shape[1], 1):
+                t, st = ops.conv_wino44(p4, P['conv23.wuq'], 2 * c4o, 1, shift=P['conv23.b'], gn_eps=self.gn12.eps, gn_split=2)
+            elif 'conv23.wuf' in P and ops.wino_implicit_supported(p4.shape[2], p4.shape[3], p4.shape[1], 1):
                 t, st = ops.conv_wino_implicit(p4, P['conv23.wuf'], 2 * c4o, 1, shift=P['conv23.b'], gn_eps=self.gn12.eps, gn_split=2)
             else:
                 shared['p4'] = ops.wino_transform(p4, 1, dedicated=True)
