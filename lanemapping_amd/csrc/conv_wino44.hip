@@ -100,15 +100,17 @@ __device__ __forceinline__ void w44_bt(const float (&d)[6], float (&t)[6]) {
     t[4] = __builtin_fmaf(-2.f, s, r);
 }
 
-// 1-D output transform y = A^T m, fixed association
+// 1-D output transform y = A^T m, fixed association (T = float in the twin, four channels of a lane in the fused kernel)
+__device__ __forceinline__ float w44_fma(float k, float a, float c) { return __builtin_fmaf(k, a, c); }
+__device__ __forceinline__ f32x4 w44_fma(float k, f32x4 a, f32x4 c) { return __builtin_elementwise_fma(f32x4{k, k, k, k}, a, c); }
 template <typename T>
 __device__ __forceinline__ void w44_at(const T (&m)[6], T (&y)[4]) {
 #pragma clang fp contract(off)
     const T s1 = m[1] + m[2], d1 = m[1] - m[2], s3 = m[3] + m[4], d3 = m[3] - m[4];
     y[0] = (m[0] + s1) + s3;
-    y[1] = d3 * 2.f + d1;                   // (a product by a power of two is exact: no contraction question)
-    y[2] = s3 * 4.f + s1;
-    y[3] = (d3 * 8.f + d1) + m[5];
+    y[1] = w44_fma(2.f, d3, d1);
+    y[2] = w44_fma(4.f, s3, s1);
+    y[3] = w44_fma(8.f, d3, d1) + m[5];
 }
 
 // ===================================================================================================================================
@@ -328,7 +330,7 @@ __device__ __forceinline__ void q_bwait(f32x4 (&b)[2]) {
 
 #ifdef LM_QPROF                             // (tools/build_variant.sh probe: per-phase shader-clock cycles of wave 0, one record per workgroup)
 constexpr int QPROF_WG = 16384;
-__device__ unsigned long long g_qprof[QPROF_WG][12];
+__device__ unsigned long long g_qprof[QPROF_WG][16];
 #define LM_QTICK(slot)                                       \
     {                                                        \
         const long long t_now = clock64();                   \
@@ -405,9 +407,44 @@ __device__ __forceinline__ void w44_step(f32x16& acc0, f32x16& acc1, f32x4 (&bq)
     __builtin_amdgcn_sched_barrier(0);
 }
 
+// Tail of one (tile, channel quad) of the fused epilogue, 16-byte path: second pass of the output transform row by row, scale / shift
+// (v * 1 + 0 = v exactly: absent vectors need no second code path), GroupNorm partial sums, residual (prefetched), ReLU as
+// fmaxf(v, 0 or -inf), stores.  FULL = every output of the tile exists (no per-store checks).
+template <bool FULL>
+__device__ __forceinline__ void w44_tail_vec(const f32x4 (&z)[4][6], const f32x4 (&rpre)[16], float* yp, int rowstep, int colstep, const f32x4 sc,
+                                             const f32x4 sh, float relu_lo, bool has_res, bool gn, f32x4& gsum, f32x4& gsq, int eny, int enx) {
+#pragma unroll
+    for (int yy = 0; yy < 4; ++yy) {
+        f32x4 o[4];
+        w44_at(z[yy], o);
+#pragma unroll
+        for (int xx = 0; xx < 4; ++xx) {
+#pragma clang fp contract(off)
+            if (!FULL && !(yy < eny && xx < enx)) continue;
+            f32x4 v = o[xx] * sc + sh;
+            if (gn) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    gsum[e] += v[e];
+                    gsq[e] = __builtin_fmaf(v[e], v[e], gsq[e]);
+                }
+            }
+            if (has_res) v += rpre[yy * 4 + xx];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], relu_lo);
+#ifdef LM_QABL_NOSTORE                       // (timing ablation: keep the values alive, store one of sixteen)
+            if (yy + xx == 0) *reinterpret_cast<f32x4*>(yp + yy * rowstep + xx * colstep) = v;
+            else asm volatile("" :: "v"(v));
+#else
+            *reinterpret_cast<f32x4*>(yp + yy * rowstep + xx * colstep) = v;
+#endif
+        }
+    }
+}
+
 __global__ __launch_bounds__(256) void wino44_kernel(W44Params p) {
 #ifdef LM_QPROF
-    long long qprof[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    long long qprof[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
     long long t_last = clock64();
     const long long t_first = t_last;
 #endif
@@ -640,32 +677,55 @@ __global__ __launch_bounds__(256) void wino44_kernel(W44Params p) {
     float* const mw = smem + xi00 * 1024 + (4 * (lane >> 5)) * 32 + (lane & 31);      // this wave's planes, this lane's origin
     const float* const mr = smem + etile * 32 + ecq * 4;
     f32x4 gsum[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}}, gsq[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+    const bool full = eny == 4 && enx == 4;
+    const int ebase = eny > 0 ? epix0 : img_pix0;                 // (a missing tile reads - and never writes - pixel 0 of its image)
+    const int ey1 = max(eny - 1, 0), ex1 = max(enx - 1, 0);
+    const float relu_lo = p.act == LM_ACT_RELU ? 0.f : -__builtin_inff();               // fmaxf(v, -inf) = v
+    const bool has_res = p.res != nullptr, gn = p.gn_part != nullptr;
+    LM_QTICK(8)
 #pragma unroll
     for (int blk = 0; blk < 2; ++blk) {
         const int n = n0 + blk * 32 + ecq * 4;
         const bool vec = (n + 3 < p.Cout) && ((p.ldy & 3) == 0) && (!p.res || (p.ldr & 3) == 0);
         // residual (BasicBlock identity): the sixteen 16-byte loads of this thread's outputs go out BEFORE the exchange - inside the
-        // store loop each was a memory round trip of its own in front of a store (y may alias res as far as the compiler knows)
-        f32x4 rpre[16];
-        if (vec && p.res) {
+        // store loop each was a memory round trip of its own in front of a store (y may alias res as far as the compiler knows).
+        // Branch-free: offsets clamped into the tile's valid part (equal to the true offsets wherever an output exists)
+        f32x4 sc = {1.f, 1.f, 1.f, 1.f}, sh = {0.f, 0.f, 0.f, 0.f};             // (v * 1 + 0 = v exactly: same bits as the twin's `v + shift`)
+        if (vec) {
+            if (p.scale) sc = *reinterpret_cast<const f32x4*>(p.scale + n);
+            if (p.shift) sh = *reinterpret_cast<const f32x4*>(p.shift + n);
+        } else {
 #pragma unroll
-            for (int q = 0; q < 16; ++q) {
-                const bool ok = (q >> 2) < eny && (q & 3) < enx;
-                const long pix = epix0 + ((q >> 2) * g.W + (q & 3)) * g.dil;
-                rpre[q] = ok ? *reinterpret_cast<const f32x4*>(p.res + pix * p.ldr + n) : f32x4{0.f, 0.f, 0.f, 0.f};
-            }
+            for (int e = 0; e < 4; ++e)
+                if (n + e < p.Cout) {
+                    if (p.scale) sc[e] = p.scale[n + e];
+                    if (p.shift) sh[e] = p.shift[n + e];
+                }
+        }
+        f32x4 rpre[16];
+#ifdef LM_QABL_NORES
+        if (false) {
+#else
+        if (vec && has_res) {
+#endif
+            const float* const rp = p.res + (long)ebase * p.ldr + n;
+            const int rs = g.W * g.dil * p.ldr, cs = g.dil * p.ldr;
+#pragma unroll
+            for (int q = 0; q < 16; ++q) rpre[q] = *reinterpret_cast<const f32x4*>(rp + min(q >> 2, ey1) * rs + min(q & 3, ex1) * cs);
         }
         // (LDS-only barriers: __syncthreads() would also wait for the previous block's global stores to be acknowledged)
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        LM_QTICK(9)
         __builtin_amdgcn_s_barrier();          // patch / V buffers (blk 0) or the previous block's products are no longer read
+        LM_QTICK(10)
 #pragma unroll
         for (int k = 0; k < 9; ++k)
 #pragma unroll
             for (int r = 0; r < 16; ++r) mw[(6 * (k / 3) + k % 3) * 1024 + ((r & 3) + 8 * (r >> 2)) * 32] = acc[k][blk][r];
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        LM_QTICK(8)
+        LM_QTICK(12)
         __builtin_amdgcn_s_barrier();
-        LM_QTICK(9)
+        LM_QTICK(13)
         if (n < p.Cout && eny > 0) {
             f32x4 z[4][6];
 #pragma unroll
@@ -677,61 +737,42 @@ __global__ __launch_bounds__(256) void wino44_kernel(W44Params p) {
 #pragma unroll
                 for (int yy = 0; yy < 4; ++yy) z[yy][j] = y4[yy];
             }
-            f32x4 sc = {1.f, 1.f, 1.f, 1.f}, sh = {0.f, 0.f, 0.f, 0.f};
+            float* const yp = p.y + (long)ebase * p.ldy + n;
+            const int rowstep = g.W * g.dil * p.ldy, colstep = g.dil * p.ldy;
+            if (vec) {
+                if (full) w44_tail_vec<true>(z, rpre, yp, rowstep, colstep, sc, sh, relu_lo, has_res, gn, gsum[blk], gsq[blk], eny, enx);
+                else w44_tail_vec<false>(z, rpre, yp, rowstep, colstep, sc, sh, relu_lo, has_res, gn, gsum[blk], gsq[blk], eny, enx);
+            } else {                           // channel counts / leading dimensions that rule out 16-byte accesses: element by element
+                // (fully unrolled with guards: a run-time index into z would move the array - on the 16-byte path too - to scratch memory)
 #pragma unroll
-            for (int e = 0; e < 4; ++e)
-                if (n + e < p.Cout) {
-                    if (p.scale) sc[e] = p.scale[n + e];
-                    if (p.shift) sh[e] = p.shift[n + e];
-                }
+                for (int yy = 0; yy < 4; ++yy) {
+                    f32x4 o[4];
+                    w44_at(z[yy], o);
 #pragma unroll
-            for (int yy = 0; yy < 4; ++yy) {
-                if (yy >= eny) break;
-                f32x4 o[4];
-                w44_at(z[yy], o);
-#pragma unroll
-                for (int xx = 0; xx < 4; ++xx) {
+                    for (int xx = 0; xx < 4; ++xx) {
 #pragma clang fp contract(off)
-                    if (xx >= enx) break;
-                    const long pix = epix0 + (yy * g.W + xx) * g.dil;
-                    f32x4 v;
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) v[e] = p.scale ? o[xx][e] * sc[e] + sh[e] : o[xx][e] + sh[e];
-                    if (p.gn_part) {
+                        const f32x4 v = o[xx] * sc + sh;
 #pragma unroll
                         for (int e = 0; e < 4; ++e) {
-                            gsum[blk][e] += v[e];
-                            gsq[blk][e] = __builtin_fmaf(v[e], v[e], gsq[blk][e]);
-                        }
-                    }
-                    if (vec) {
-                        if (p.res) {
-                            const f32x4 rr = rpre[yy * 4 + xx];
-#pragma unroll
-                            for (int e = 0; e < 4; ++e) v[e] += rr[e];
-                        }
-                        if (p.act == LM_ACT_RELU) {
-#pragma unroll
-                            for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
-                        }
-                        *reinterpret_cast<f32x4*>(p.y + pix * p.ldy + n) = v;
-                    } else {
-                        for (int e = 0; e < 4 && n + e < p.Cout; ++e) {
+                            if (!(yy < eny && xx < enx && n + e < p.Cout)) continue;
+                            if (gn) {
+                                gsum[blk][e] += v[e];
+                                gsq[blk][e] = __builtin_fmaf(v[e], v[e], gsq[blk][e]);
+                            }
                             float u = v[e];
-                            if (p.res) u += p.res[pix * p.ldr + n + e];
-                            if (p.act == LM_ACT_RELU) u = fmaxf(u, 0.f);
-                            p.y[pix * p.ldy + n + e] = u;
+                            if (has_res) u += p.res[((long)ebase + (yy * g.W + xx) * g.dil) * p.ldr + n + e];
+                            yp[yy * rowstep + xx * colstep + e] = fmaxf(u, relu_lo);
                         }
                     }
                 }
             }
         }
+        LM_QTICK(14)
     }
-    LM_QTICK(10)
 #ifdef LM_QPROF
     if (tid == 0) {
 #pragma unroll
-        for (int k = 0; k < 11; ++k) g_qprof[blockIdx.x % QPROF_WG][k] = (unsigned long long)qprof[k];
+        for (int k = 0; k < 15; ++k) g_qprof[blockIdx.x % QPROF_WG][k] = (unsigned long long)qprof[k];
         g_qprof[blockIdx.x % QPROF_WG][11] = (unsigned long long)(clock64() - t_first);
     }
 #endif
@@ -800,15 +841,15 @@ int w44_zeros(const float** out) {      // per device (a process may drive sever
 
 #ifdef LM_QPROF
 extern "C" __attribute__((visibility("default"))) int lm_qprof_read(unsigned long long* out, int reset) {
-    static unsigned long long host[QPROF_WG][12];
+    static unsigned long long host[QPROF_WG][16];
     if (hipMemcpyFromSymbol(host, HIP_SYMBOL(g_qprof), sizeof(host)) != hipSuccess) return 1;
-    for (int k = 0; k < 13; ++k) out[k] = 0;
+    for (int k = 0; k < 17; ++k) out[k] = 0;
     for (int w = 0; w < QPROF_WG; ++w) {
-        for (int k = 0; k < 12; ++k) out[k] += host[w][k];
-        if (host[w][11]) ++out[12];
+        for (int k = 0; k < 16; ++k) out[k] += host[w][k];
+        if (host[w][11]) ++out[16];
     }
     if (reset) {
-        static unsigned long long zero[QPROF_WG][12];
+        static unsigned long long zero[QPROF_WG][16];
         if (hipMemcpyToSymbol(HIP_SYMBOL(g_qprof), zero, sizeof(zero)) != hipSuccess) return 1;
     }
     return 0;

@@ -9,8 +9,8 @@ import torch
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), '..', '..'))
 from lanemapping_amd import ops  # noqa: E402
 
-NAMES = ['set-up', 'prologue', 'transform', 'barrier after T', 'MFMA phases', 'barrier after M', 'patch-load wait', 'drain', 'epi in-place',
-         'epi partials', 'epi rest', 'total']
+NAMES = ['set-up', 'prologue', 'transform', 'barrier after T', 'MFMA phases', 'barrier after M', 'patch-load wait', 'drain', 'epi set-up',
+         'epi residual issue', 'epi barrier 1', 'TOTAL', 'epi product stores', 'epi barrier 2', 'epi transform + tail', '-']
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 8
 dev = torch.device('cuda:0')
 lib = ops.lib()
@@ -23,11 +23,11 @@ for cin, cout, hw, dil in [(256, 256, 288, 1), (256, 256, 144, 2), (128, 128, 14
     y = ops.new_act(B, cout, hw, hw, dev)
     ops.conv_wino44(x, wf, cout, dil, res=res, act=ops.ACT_RELU, out=y)
     torch.cuda.synchronize()
-    buf = (C.c_ulonglong * 13)()
+    buf = (C.c_ulonglong * 17)()
     lib.lm_qprof_read(buf, 1)
     ops.conv_wino44(x, wf, cout, dil, res=res, act=ops.ACT_RELU, out=y)
     torch.cuda.synchronize()
     lib.lm_qprof_read(buf, 1)
-    n = max(1, buf[12])
+    n = max(1, buf[16])
     print(f'{cin}->{cout} d{dil}@{hw} B{B}: {n} workgroup records; cycles per workgroup: ' +
-          ', '.join(f'{NAMES[k]} {buf[k] / n:.0f}' for k in range(12)), flush=True)
+          ', '.join(f'{NAMES[k]} {buf[k] / n:.0f}' for k in range(15)), flush=True)
