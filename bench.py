@@ -11,6 +11,7 @@ fixed-shape polyline blocks when N > 1.  `--workload tiles` = configs[1] (pre-ra
 (RowRef head, batch 8), `lidar` = configs[4] (sparse-conv encoder).  Rank 0 prints ONE JSON line.
 """
 import argparse
+import datetime
 import json
 import os
 import sys
@@ -129,7 +130,7 @@ def host_budget(world, local_world, local_rank, cores_avail, allowed, host_cores
     if host_cores < 1:
         raise SystemExit('--host-cores must be >= 1')
     k = min(host_cores, len(allowed))
-    mine = allowed[(local_rank * k) % len(allowed):][:k] or allowed[:k]
+    mine = [allowed[(local_rank * k + i) % len(allowed)] for i in range(k)]      # (wraps: never a short slice at the tail)
     return {'k': k, 'cores': mine, 'graphs': k <= 4 and not no_graphs and workload in ('fused', 'tiles', 'rowref'), 'auto': auto}
 
 
@@ -401,7 +402,9 @@ def main():
     # tiles, this rank's slice must be the block it sent bit for bit and must unpack to the results of its last batch; the verdict
     # of all ranks is combined so that rank 0's line speaks for the job
     gather_check = 'n/a (1 rank)'
-    if world > 1:
+    if world > 1 and not inflight:
+        gather_check = 'n/a (no batch was gathered: --steps 0)'
+    elif world > 1:
         ok = 0
         if inflight:
             comm.synchronize()
@@ -524,6 +527,9 @@ def main():
     mfma_traffic = pmc.get('mfma_bytes_per_step')
     # the counters were collected on other kernel sources than the ones that ran (None: no counters were collected for this workload)
     traffic_stale = (pmc.get('csrc_sha16') != csrc_sha16()) if pmc else None
+    split_on = os.environ.get('LANEMAP_WINO_BF16X3', '0') != '0'
+    if split_on or os.environ.get('LANEMAP_WINO_F44', '1') == '0':
+        mfma_traffic, traffic_stale = None, None        # the counters were collected on the default kernels (fp32 F(4x4)), not on this run's
     n_lines = int(np.mean([(np.count_nonzero(l[:, :, 0] > 0, axis=1) >= 2).sum() for l, _ in last])) if last else 0
     what = {'tiles': 'pre-rasterised tile', 'fused': 'LAS points', 'lidar': 'LiDAR point cloud', 'rowref': 'pre-rasterised tile'}[args.workload]
     workload = {
@@ -583,7 +589,6 @@ def main():
                                              'physically emitted as u8 HWC (its information content, 1/4 of the bytes) because its only consumer, '
                                              'the stem kernel, applies u8 / 255 itself (bit-identical); frac_moved = the honest numerator of this '
                                              'design (16 B per point + the 3 x H x W u8 tile) / time / peak; traffic = what the counters saw'}
-    split_on = os.environ.get('LANEMAP_WINO_BF16X3', '0') != '0'
     if split_on and dominant and 'bf16x3' in dominant:
         # opt-in split-precision run: the headline object describes the dominant kernel in ITS arithmetic (six bf16 MFMA products per fp32
         # product, priced against the dense bf16 peak); fp32_product_tflops = the fp32 products it stands for / the same time
@@ -594,15 +599,26 @@ def main():
                                    'kernel': dominant + ' (the Winograd GEMMs; the other MFMA launches of a step are listed in per_kernel)'})
     if rank == 0 and world == 1 and not split_on and args.second_line and not args.no_second_line and args.workload in ('fused', 'tiles', 'rowref'):
         result['second_line'] = second_line(args)
+    # the CPU path timed on this node's own host cores in the same run, next to the 1 / 2 / 4 / 8-GPU numbers (north_star).  At N > 1 the
+    # other ranks must not burn cores meanwhile: an NCCL barrier is a stream synchronise that may spin, so they finish their GPU work in a
+    # barrier FIRST and are then parked on a key of the rendezvous store (a blocking socket read) until rank 0 has its number
+    store = None
+    if world > 1:
+        dist.barrier()
+        torch.cuda.synchronize()
+        store = dist.distributed_c10d._get_default_store()
     if rank == 0:
-        # the CPU path timed on this node's own host cores in the same run, next to the 1 / 2 / 4 / 8-GPU numbers (north_star); at N > 1
-        # the other ranks are parked in the barrier below meanwhile, so the oracle has the host to itself
         if not args.no_cpu_baseline and affinity0 is not None and args.host_cores is not None:
             os.sched_setaffinity(0, affinity0)          # the CPU path gets the node's cores back, not this rank's slice
         result['cpu_baseline'] = None if args.no_cpu_baseline else cpu_baseline(args.cpu_budget_s)
+        if result['cpu_baseline'] is not None and world > 1:
+            result['cpu_baseline']['measured_with'] = f'{world - 1} other rank(s) of this job idle on the node (blocked on a store key, not spinning)'
         print(json.dumps(result), flush=True)
+        if store is not None:
+            store.set('lanemap_cpu_baseline_done', '1')
+    elif store is not None:
+        store.wait(['lanemap_cpu_baseline_done'], datetime.timedelta(seconds=max(600.0, 40.0 * args.cpu_budget_s)))
     if world > 1:
-        dist.barrier()
         dist.destroy_process_group()
 
 

@@ -1786,6 +1786,25 @@ extern "C" __attribute__((visibility("default"))) int lm_iprof_read(unsigned lon
 }
 #endif
 
+namespace {
+// Address of a zero-source symbol ON THE CURRENT DEVICE (a __device__ variable has one instance per device: a process that switches
+// devices must not hand the first device's pointer to a kernel on another one).  which = 0: g_wino_zero, 1: g_wino_zeros.
+int wino_symbol_per_device(int which, const float** out) {
+    static const float* cache[2][64] = {{nullptr}, {nullptr}};
+    int dev = 0;
+    LM_HIP(hipGetDevice(&dev));
+    LM_REQUIRE(dev >= 0 && dev < 64, "conv_wino: device index %d", dev);
+    if (!cache[which][dev]) {
+        void* sym = nullptr;
+        if (which == 0) LM_HIP(hipGetSymbolAddress(&sym, HIP_SYMBOL(g_wino_zero)));
+        else LM_HIP(hipGetSymbolAddress(&sym, HIP_SYMBOL(g_wino_zeros)));
+        cache[which][dev] = (const float*)sym;
+    }
+    *out = cache[which][dev];
+    return LM_OK;
+}
+}  // namespace
+
 LM_API long lm_conv3x3_winograd_workspace_bytes(int B, int H, int W, int Cin, int dil) {
     if (dil < 1) return 0;
     return 16 * geom(B, H, W, dil).T * (long)Cin * (long)sizeof(float);
@@ -1852,13 +1871,7 @@ LM_API int lm_winograd_gemm_f32(void* stream, const void* V, const float* wu, in
     p.V = (const float*)V; p.U = wu; p.scale = scale; p.shift = shift; p.res = res; p.y = y;
     p.ldr = ldr; p.ldy = ldy; p.C = Cin; p.Cout = Cout; p.CoutP = CoutP; p.act = act;
     p.gn_part = gn_partial;
-    static const float* zero = nullptr;
-    if (!zero) {
-        void* sym = nullptr;
-        LM_HIP(hipGetSymbolAddress(&sym, HIP_SYMBOL(g_wino_zero)));
-        zero = (const float*)sym;
-    }
-    p.zero = zero;
+    if (int e = wino_symbol_per_device(0, &p.zero)) return e;
     hipStream_t s = (hipStream_t)stream;
     // 128 x 64 tiles: 4 output + 1 temporary accumulator sets = 246 registers -> two workgroups per CU (the tile / slab / buffering
     // variants that were measured against it in round 1 are listed in profiles/README.md; their code is gone)
@@ -1898,13 +1911,7 @@ int wino_implicit_launch(int mode, void* stream, const float* x, int ldx, const 
     p.x = x; p.U = wu_frag; p.scale = scale; p.shift = shift; p.res = res; p.y = y;
     p.ldx = ldx; p.ldr = ldr; p.ldy = ldy; p.C = Cin; p.Cout = Cout; p.NT = CoutP / 32; p.act = act;
     p.gn_part = gn_partial;
-    static const float* zeros = nullptr;
-    if (!zeros) {
-        void* sym = nullptr;
-        LM_HIP(hipGetSymbolAddress(&sym, HIP_SYMBOL(g_wino_zeros)));
-        zeros = (const float*)sym;
-    }
-    p.zeros = zeros;
+    if (int e = wino_symbol_per_device(1, &p.zeros)) return e;
     p.n_inner = 0;
     if (mode == 1) {        // split-precision GEMM, ROWS geometry (wino_rows_split_kernel)
         const size_t rlds = (size_t)(4 * RRAWH > 2 * RXCH ? 4 * RRAWH : 2 * RXCH) * sizeof(float);

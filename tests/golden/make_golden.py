@@ -337,7 +337,71 @@ def g14(cfg, net):
 
 
 G15_GAINS = {'heads.offset2.2.weight': 0.02, 'heads.offset2.2.bias': 0.02}     # |offset2| stays inside one bin
-G15_TILES = (2021, 2023)
+G15_SCREEN = tuple(range(2021, 2041))      # tile seeds offered to the stability screen (round 4: 20 instead of 3)
+G15_KEEP = 10
+G17_SCREEN = tuple(range(3101, 3113))      # LAS cloud seeds offered to the screen of the headline-chain golden
+G17_KEEP = 4
+G17_RASTER = dict(local_min_ele=-0.5, ele_reso=0.02)                              # bench.py's rasteriser parameters
+
+
+def _stable_net():
+    """The reference net with the G15 gains, and a spy that keeps a copy of what the decode returned (the post-processing mutates it)."""
+    cfg2, net2 = ref_net(seed=2021)
+    synth.apply_gains_(net2, G15_GAINS)
+    cap = {}
+    orig = net2.heads.get_exist_coor_endp_dict
+
+    def spy(out):
+        d = orig(out)
+        cap['dec'] = {k: (v.detach().clone() if torch.is_tensor(v) else v) for k, v in d.items()}
+        return d
+    net2.heads.get_exist_coor_endp_dict = spy
+    return net2, cap
+
+
+def _screen(net2, cap, x, noise_key):
+    """The reference's final output for x, or None when it is not identical for x + 1e-5 n and x - 1e-5 n (n = seeded +-1 noise):
+    which vertices exist, their semantics, the kept endpoints; columns within 1e-2 px."""
+    def run(t):
+        with torch.no_grad():
+            return _quiet(net2, {'proj': t})
+    noise = torch.from_numpy(((synth.uniform(noise_key, x.numel()) > 0.5).astype(np.float32) * 2 - 1).reshape(x.shape))
+    o = run(x)
+    dec = cap['dec']
+    V = o['lane_maps']['cls_offset_smooth'][0]
+    E = np.stack(np.nonzero(o['lane_maps']['endp_by_cls'][0]), axis=1)
+    for sgn in (1.0, -1.0):
+        o2 = run(x + sgn * 1e-5 * noise)
+        V2 = o2['lane_maps']['cls_offset_smooth'][0]
+        E2 = np.stack(np.nonzero(o2['lane_maps']['endp_by_cls'][0]), axis=1)
+        if not (np.array_equal(V[:, :, 0] > 0, V2[:, :, 0] > 0) and np.array_equal(V[:, :, 1], V2[:, :, 1]) and np.array_equal(E, E2)
+                and float(np.abs(V[:, :, 0] - V2[:, :, 0]).max()) < 1e-2):
+            return None
+    nl = int((np.count_nonzero(V[:, :, 0] > 0, axis=1) >= 2).sum())
+    D = np.stack(np.nonzero(dec['endp'][0].numpy()), axis=1).astype(np.int32)
+    # MARGIN of the endpoint decisions (round 4): the endpoint pick - top-K scores, <= 20 px clustering, the sample nearest the centroid
+    # - is a near-tie wherever a pixel enters or leaves the top K, and the 1e-5 screen above does not see every such case (tile 2033: the
+    # reference itself moves one endpoint by a pixel under a 1e-4 perturbation; so does an exact direct-convolution path).  Like the class
+    # flips of G10 (reference margin < 1e-4), an endpoint may differ only where the reference's OWN decision changes under a perturbation of
+    # the tolerance's size: four more runs at 1e-4 (two noise patterns, both signs) give, per endpoint of the unperturbed run, whether it is
+    # present in all of them (`*_firm`), and the union of everything any run produced (`*_any`); `lines_firm` = the polylines survive too.
+    dset, eset = {tuple(r) for r in D}, {tuple(r) for r in E}
+    d_firm, e_firm, d_any, e_any, lines_firm = set(dset), set(eset), set(dset), set(eset), True
+    for key in (1, 2):
+        n4 = torch.from_numpy(((synth.uniform(synth.fnv1a64('margin%d' % key) ^ noise_key, x.numel()) > 0.5).astype(np.float32) * 2 - 1).reshape(x.shape))
+        for sgn in (1.0, -1.0):
+            o4 = run(x + sgn * 1e-4 * n4)
+            V4 = o4['lane_maps']['cls_offset_smooth'][0]
+            E4 = {tuple(r) for r in np.stack(np.nonzero(o4['lane_maps']['endp_by_cls'][0]), axis=1)}
+            D4 = {tuple(r) for r in np.stack(np.nonzero(cap['dec']['endp'][0].numpy()), axis=1)}
+            d_firm &= D4; e_firm &= E4; d_any |= D4; e_any |= E4
+            lines_firm = lines_firm and np.array_equal(V[:, :, 0] > 0, V4[:, :, 0] > 0) and np.array_equal(V[:, :, 1], V4[:, :, 1])
+    as_arr = lambda st: np.array(sorted(st), dtype=np.int32).reshape(-1, 2)
+    info = (f'{nl} lines, {len(E)} endpoints ({len(e_firm)} firm under 1e-4; decode: {len(D)}, {len(d_firm)} firm), lines firm: {lines_firm}, '
+            f'max |cls_offset - proposal origin| {float((dec["cls_offset"][0] - (2 * torch.arange(72)[:, None] - 4)).abs().max()):.3f}')
+    return {'V': V, 'E': E.astype(np.int32), 'prop_conf': dec['prop_conf'][0].numpy(), 'prop_v_ext': dec['prop_v_ext'][0].numpy().astype(np.uint8),
+            'cls_offset': dec['cls_offset'][0].numpy(), 'endp': D, 'endp_firm': as_arr(d_firm), 'endp_any': as_arr(d_any),
+            'E_firm': as_arr(e_firm), 'E_any': as_arr(e_any), 'lines_firm': np.array(lines_firm)}, info
 
 
 def g15(cfg, net):
@@ -346,49 +410,55 @@ def g15(cfg, net):
     layer is scaled by 0.02 (vertex columns then stay inside their bin) and the tiles are SCREENED: kept only if the reference's
     own final output - which vertices exist, their semantics, the kept endpoints - is identical for x, x + 1e-5 n and x - 1e-5 n
     (n = seeded +-1 noise) and the columns move by < 1e-2 px.  An implementation that matches the decode within 1e-4 must then
-    reproduce the reference's polylines exactly.  (Screen run over tile seeds 2021..2023: 2022 failed, 2021 and 2023 passed.)"""
-    cfg2, net2 = ref_net(seed=2021)
-    synth.apply_gains_(net2, G15_GAINS)
-    keep = {}
-
-    cap = {}
-    orig = net2.heads.get_exist_coor_endp_dict
-
-    def spy(out):          # the post-processing mutates the decode dictionary in place: keep a copy of what the decode returned
-        d = orig(out)
-        cap['dec'] = {k: (v.detach().clone() if torch.is_tensor(v) else v) for k, v in d.items()}
-        return d
-    net2.heads.get_exist_coor_endp_dict = spy
-
-    def run(x):
-        with torch.no_grad():
-            o = _quiet(net2, {'proj': x})
-        return o
-
-    for i, ts in enumerate(G15_TILES):
+    reproduce the reference's polylines exactly.  Round 4: tile seeds 2021 .. 2040 go through the screen, the first G15_KEEP stable
+    ones are kept (round 3 kept 2021 and 2023 of three)."""
+    net2, cap = _stable_net()
+    keep, kept, failed = {}, [], []
+    for ts in G15_SCREEN:
+        if len(kept) == G15_KEEP:
+            break
         x = torch.from_numpy(synth.bev_batch([ts], 1152))
-        noise = torch.from_numpy(((synth.uniform(synth.fnv1a64('g15noise') ^ ts, x.numel()) > 0.5).astype(np.float32) * 2 - 1).reshape(x.shape))
-        o = run(x)
-        dec = cap['dec']
-        V = o['lane_maps']['cls_offset_smooth'][0]
-        E = np.stack(np.nonzero(o['lane_maps']['endp_by_cls'][0]), axis=1)
-        for sgn in (1.0, -1.0):
-            o2 = run(x + sgn * 1e-5 * noise)
-            V2 = o2['lane_maps']['cls_offset_smooth'][0]
-            E2 = np.stack(np.nonzero(o2['lane_maps']['endp_by_cls'][0]), axis=1)
-            assert np.array_equal(V[:, :, 0] > 0, V2[:, :, 0] > 0) and np.array_equal(V[:, :, 1], V2[:, :, 1]) and np.array_equal(E, E2), \
-                f'tile {ts} is not stable under a 1e-5 input perturbation'
-            assert float(np.abs(V[:, :, 0] - V2[:, :, 0]).max()) < 1e-2
-        nl = int((np.count_nonzero(V[:, :, 0] > 0, axis=1) >= 2).sum())
-        print(f'  tile {ts}: {nl} lines, {len(E)} endpoints, max |cls_offset - proposal origin| '
-              f'{float((dec["cls_offset"][0] - (2 * torch.arange(72)[:, None] - 4)).abs().max()):.3f}')
-        keep[f'V{i}'] = V
-        keep[f'E{i}'] = E.astype(np.int32)
-        keep[f'prop_conf{i}'] = dec['prop_conf'][0].numpy()
-        keep[f'prop_v_ext{i}'] = dec['prop_v_ext'][0].numpy().astype(np.uint8)
-        keep[f'cls_offset{i}'] = dec['cls_offset'][0].numpy()
-        keep[f'endp{i}'] = np.stack(np.nonzero(dec['endp'][0].numpy()), axis=1).astype(np.int32)
-    save('g15_e2e_stable.npz', tile_seeds=np.array(G15_TILES), weight_seed=2021,
+        r = _screen(net2, cap, x, synth.fnv1a64('g15noise') ^ ts)
+        if r is None:
+            failed.append(ts)
+            print(f'  tile {ts}: not stable under a 1e-5 input perturbation - skipped')
+            continue
+        print(f'  tile {ts}: {r[1]}')
+        for k, v in r[0].items():
+            keep[f'{k}{len(kept)}'] = v
+        kept.append(ts)
+    save('g15_e2e_stable.npz', tile_seeds=np.array(kept), screened_out=np.array(failed), weight_seed=2021,
+         gain_keys=np.array(list(G15_GAINS)), gain_values=np.array(list(G15_GAINS.values())), **keep)
+
+
+def g17(cfg, net):
+    """The HEADLINE chain as one golden (round 4): a seeded 4,194,304-point LAS-shaped cloud (synth.las_points) is rasterised by the C
+    oracle (oracle/raster_ref.c, bench.py's parameters), the REFERENCE net (G15 gains) runs on u8 / 255 of that tile - the load_img
+    contract, laserlane_proposals.py:85-98 - and the result goes through the G15 stability screen.  The GPU test feeds the same points
+    to lm_bev_raster_batch -> TilePipeline and must reproduce the reference's polylines.  (The rasteriser itself stays parity-unpinned:
+    the reference has none; what this pins is the composition raster -> u8 tile -> stem -> ... -> polylines.)"""
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), '..', '..'))
+    from oracle import raster_ref
+    net2, cap = _stable_net()
+    keep, kept, failed = {}, [], []
+    for cs in G17_SCREEN:
+        if len(kept) == G17_KEEP:
+            break
+        pts = synth.las_points(cs)
+        u8 = raster_ref.raster(pts, raster_ref.params(**G17_RASTER), 1152, 1152)
+        x = torch.from_numpy((u8.astype(np.float32) / np.float32(255.0)).transpose(2, 0, 1).copy())[None]
+        r = _screen(net2, cap, x, synth.fnv1a64('g17noise') ^ cs)
+        if r is None:
+            failed.append(cs)
+            print(f'  cloud {cs}: not stable under a 1e-5 input perturbation - skipped')
+            continue
+        print(f'  cloud {cs}: {r[1]}, {int((u8[:, :, 0] > 0).sum())} occupied pixels')
+        for k, v in r[0].items():
+            keep[f'{k}{len(kept)}'] = v
+        keep[f'tile_crc{len(kept)}'] = np.array(int(np.frombuffer(u8.tobytes(), dtype=np.uint8).astype(np.uint64).sum()))
+        kept.append(cs)
+    save('g17_chain.npz', cloud_seeds=np.array(kept), screened_out=np.array(failed), weight_seed=2021, n_points=4194304,
+         raster_keys=np.array(list(G17_RASTER)), raster_values=np.array(list(G17_RASTER.values())),
          gain_keys=np.array(list(G15_GAINS)), gain_values=np.array(list(G15_GAINS.values())), **keep)
 
 

@@ -126,22 +126,42 @@ def test_g15_stable_end_to_end(golden, synth_sd):
     chain reproduces the reference's cls_offset_smooth and kept endpoints EXACTLY in structure, columns within 1e-4 px-equivalents."""
     g = golden('g15_e2e_stable.npz')
     sd = g15_state_dict(synth_sd, g)
-    for i, ts in enumerate(g['tile_seeds']):
+    assert len(g['tile_seeds']) >= 8
+    for i, ts in enumerate(g['tile_seeds'][:4]):        # (the GPU test covers all of them; four keep the CPU suite inside its minutes)
         x = torch.from_numpy(synth.bev_batch([int(ts)], 1152))
-        with torch.no_grad():
-            raw = net_ref.detector_forward(sd, x)
-        d = decode_ref.decode_column_proposals({k: v.numpy() for k, v in raw.items()})
-        np.testing.assert_allclose(d['prop_conf'][0].numpy(), g[f'prop_conf{i}'], atol=1e-5)
-        np.testing.assert_allclose(d['cls_offset'][0].numpy(), g[f'cls_offset{i}'], atol=1e-5)        # absolute
-        np.testing.assert_array_equal(d['prop_v_ext'][0].numpy().astype(np.uint8), g[f'prop_v_ext{i}'])
-        np.testing.assert_array_equal(np.stack(np.nonzero(d['endp'][0].numpy()), axis=1), g[f'endp{i}'])
-        V, E, _ = postproc_ref.assemble_tile(d['prop_conf'][0, :, 1].numpy(), d['prop_v_ext'][0].numpy(),
-                                             d['cls_offset'][0].numpy(), d['bi_seg'][0].numpy(), d['endp'][0].numpy())
-        W = g[f'V{i}']
-        np.testing.assert_array_equal(V[:, :, 0] > 0, W[:, :, 0] > 0)
-        np.testing.assert_array_equal(V[:, :, 1], W[:, :, 1])
-        np.testing.assert_allclose(V[:, :, 0], W[:, :, 0], atol=1e-4)
-        np.testing.assert_array_equal(np.stack(np.nonzero(E), axis=1).reshape(-1, 2), g[f'E{i}'].reshape(-1, 2))
+        _check_stable_chain(g, i, sd, x)
+
+
+def test_g17_headline_chain(golden, synth_sd):
+    """Golden G17 (round 4): LAS-shaped clouds -> C raster oracle -> u8 / 255 -> the oracle net / decode / assembly reproduces what
+    the REFERENCE net produced on the same rasterised tile (stability-screened): the oracle side of the headline chain is pinned
+    as a chain, not only by parts."""
+    from oracle import raster_ref
+    g = golden('g17_chain.npz')
+    sd = g15_state_dict(synth_sd, g)
+    kw = {str(k): float(v) for k, v in zip(g['raster_keys'], g['raster_values'])}
+    for i, cs in enumerate(g['cloud_seeds'][:2]):
+        u8 = raster_ref.raster(synth.las_points(int(cs), int(g['n_points'])), raster_ref.params(**kw), 1152, 1152)
+        assert int(u8.astype(np.uint64).sum()) == int(g[f'tile_crc{i}'])
+        x = torch.from_numpy((u8.astype(np.float32) / np.float32(255.0)).transpose(2, 0, 1).copy())[None]
+        _check_stable_chain(g, i, sd, x)
+
+
+def _check_stable_chain(g, i, sd, x):
+    with torch.no_grad():
+        raw = net_ref.detector_forward(sd, x)
+    d = decode_ref.decode_column_proposals({k: v.numpy() for k, v in raw.items()})
+    np.testing.assert_allclose(d['prop_conf'][0].numpy(), g[f'prop_conf{i}'], atol=1e-5)
+    np.testing.assert_allclose(d['cls_offset'][0].numpy(), g[f'cls_offset{i}'], atol=1e-5)        # absolute
+    np.testing.assert_array_equal(d['prop_v_ext'][0].numpy().astype(np.uint8), g[f'prop_v_ext{i}'])
+    np.testing.assert_array_equal(np.stack(np.nonzero(d['endp'][0].numpy()), axis=1), g[f'endp{i}'])
+    V, E, _ = postproc_ref.assemble_tile(d['prop_conf'][0, :, 1].numpy(), d['prop_v_ext'][0].numpy(),
+                                         d['cls_offset'][0].numpy(), d['bi_seg'][0].numpy(), d['endp'][0].numpy())
+    W = g[f'V{i}']
+    np.testing.assert_array_equal(V[:, :, 0] > 0, W[:, :, 0] > 0)
+    np.testing.assert_array_equal(V[:, :, 1], W[:, :, 1])
+    np.testing.assert_allclose(V[:, :, 0], W[:, :, 0], atol=1e-4)
+    np.testing.assert_array_equal(np.stack(np.nonzero(E), axis=1).reshape(-1, 2), g[f'E{i}'].reshape(-1, 2))
 
 
 def test_g8_rowref_oracle(golden):
