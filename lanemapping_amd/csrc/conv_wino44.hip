@@ -25,7 +25,7 @@
 //      arrive in LDS through global_load_lds gathers straight from the NHWC tensor (zero block for padding), issued during the
 //      previous unit's MFMA phases, double-buffered;
 //   2. per 8-channel half: TRANSFORM phase - the 256 threads compute V = B^T d B for the half ONCE (thread = tile x channel pair x
-//      half of the first pass: 30 ds_read_b64, 72 packed FMAs / adds, 18 ds_write_b64) into V[xi][k half][tile][4] (36 KB);
+//      half of the first pass: 30 ds_read_b64, 72 packed FMAs / adds, 18 ds_write_b64) into V[xi][channel pair][tile][2] (36 KB);
 //      MFMA phase - per xi of the wave one ds_read_b128 A fragment, two B fragments, 8 MFMAs (4 k steps x 2 channel blocks).
 //   f32 MFMA shares the SIMD's vector ALUs, so the transform is NOT hidden - it costs 72 packed VALU per 72 MFMAs - but
 //   it is paid once per 64 output channels, and 36 products replace 4 x 16.
@@ -48,7 +48,7 @@ constexpr int QBM = 32, QBN = 64, QSEG = 4;
 constexpr int QNCELL = 144;                     // cells (one pixel x 16 channels = 64 B) per patch row: 36 tile slots x 4 columns
 constexpr int QLPW = 14;                        // patch loads per wave and unit (1 KB each)
 constexpr int QRAWF = QLPW * 4 * 256;           // floats of one raw buffer (56 KB; cells 864.. are zero-source padding)
-constexpr int QVF = 36 * 256;                   // floats of the V buffer: 36 planes x [2 k halves][32 tiles][4]
+constexpr int QVF = 36 * 256;                   // floats of the V buffer: 36 planes x [4 channel pairs][32 tiles][2]
 #ifndef LM_QBD
 #define LM_QBD 5
 #define LM_QRING 6
@@ -364,6 +364,14 @@ constexpr int q_nwait(int S) {
 }
 static_assert(q_dma0(17) + q_ndma(17) == QLPW, "the second phase issues every patch load of a unit");
 
+// A fragment of one xi: V plane [4 channel pairs][32 tiles][2] - the 16 lanes of a ds_write_b64 group of the transform (16 tiles of one
+// channel pair) and the 32 lanes of a read pass here cover contiguous bytes: conflict-free on both sides ([2 k halves][32 tiles][4] with
+// one ds_read_b128 made the transform's stores two-way conflicted).  Lane (tile, k half) takes pairs 2 k and 2 k + 1: channels 4 k .. 4 k + 3
+__device__ __forceinline__ f32x4 q_aread(const float* v) {
+    const f32x2 lo = *reinterpret_cast<const f32x2*>(v), hi = *reinterpret_cast<const f32x2*>(v + 64);
+    return f32x4{lo[0], lo[1], hi[0], hi[1]};
+}
+
 // One step (one xi of the wave) of an MFMA phase: 8 MFMAs = 4 k steps x 2 channel blocks.  S = step within the unit (0..17: two phases
 // of nine); the B fragments of step S + QBD and the patch loads of this step (q_ndma) are issued first; q_nwait(S) loads may stay
 // outstanding when this step's B fragments are needed.  Behind the first MFMA: the A fragment of the next step and (steps 0..5 of a
@@ -393,7 +401,7 @@ __device__ __forceinline__ void w44_step(f32x16& acc0, f32x16& acc1, f32x4 (&bq)
     constexpr bool VACC = (S % 9) == 8;
     q_mfma<VACC>(acc0, a_cur[0], b[0][0]);
     __builtin_amdgcn_sched_barrier(0);
-    if constexpr (NEXT) a_nxt = *reinterpret_cast<const f32x4*>(anext);
+    if constexpr (NEXT) a_nxt = q_aread(anext);
 #ifndef LM_QABL_NOT
     if constexpr ((S % 9) < 6) w44_preread<S % 9>(pre, prerow, roff);
 #endif
@@ -550,14 +558,14 @@ __global__ __launch_bounds__(256) void wino44_kernel(W44Params p) {
         const int pos0 = 16 * (slot >> 2) + (slot & 3), pos1 = 16 * (slot1 >> 2) + (slot1 & 3);
 #pragma unroll
         for (int c = 0; c < 6; ++c) roff[c] = ((c < 4 ? pos0 + 4 * c : pos1 + 4 * (c - 4)) * 16) + 2 * cp;
-        tvoff = (cp >> 1) * 128 + tl * 4 + (cp & 1) * 2;
+        tvoff = cp * 64 + tl * 2;
     }
     const bool lower = (wave >> 1) != 0;
     const W44K kk = {f32x2{2.f, 2.f}, f32x2{4.f, 4.f}, f32x2{5.f, 5.f}};
-    // MFMA operands: A = V plane xi at [k half = lane >> 5][tile = lane & 31][4]; this wave's planes xi = xi00 + 6 ii + jj
+    // MFMA operands: A = V plane xi, channel pairs 2 (lane >> 5) and 2 (lane >> 5) + 1 of tile lane & 31; this wave's planes xi = xi00 + 6 ii + jj
     const int qa = wave >> 1, qb = wave & 1;
     const int xi00 = 18 * qa + 3 * qb;
-    const float* const Vq = Vbuf + xi00 * 256 + (lane >> 5) * 128 + (lane & 31) * 4;
+    const float* const Vq = Vbuf + xi00 * 256 + (lane >> 5) * 128 + (lane & 31) * 2;       // channel pairs 2 (lane >> 5) and 2 (lane >> 5) + 1
     const int nun = p.C / 16;                                    // 16-channel units
     const unsigned bvoff = (unsigned)lane * 16u;
     const long ustride = (long)p.NT * 256;                       // floats between 8-channel halves in U
@@ -575,20 +583,21 @@ __global__ __launch_bounds__(256) void wino44_kernel(W44Params p) {
     W44Patch pre;
     const int lowoff = lower ? QNCELL * 16 : 0;               // LOWER threads read patch rows 1..5
     LM_QTICK(0)
-    // prologue: raw units 0 and 1, B of steps 0 .. QBD-1, pre-read of unit 0's first half
+    // prologue: raw unit 0, B of steps 0 .. QBD-1, THEN raw unit 1: the wait below leaves unit 1's loads (the youngest) in flight - they
+    // are only needed before the second MFMA phase, and being older than every load of the loop they do not enter its wait counts
 #pragma unroll
     for (int s_ = 0; s_ < QLPW; ++s_)
         __builtin_amdgcn_global_load_lds((gptr_t*)gsrc[s_], (lptr_t*)(raw0 + (s_ * 4 + wave) * 256), 16, 0, 0);
+#define LM_QXI(K) (6 * ((K) / 3) + (K) % 3)
+#pragma unroll
+    for (int k = 0; k < QBD; ++k) q_bload2(bq[k], bvoff, bbase + (long)LM_QXI(k) * xstride);
     {
         const long goff1 = nun > 1 ? 16 : 0;
 #pragma unroll
         for (int s_ = 0; s_ < QLPW; ++s_)
             __builtin_amdgcn_global_load_lds((gptr_t*)(gsrc[s_] + goff1), (lptr_t*)(raw0 + QRAWF + (s_ * 4 + wave) * 256), 16, 0, 0);
     }
-#define LM_QXI(K) (6 * ((K) / 3) + (K) % 3)
-#pragma unroll
-    for (int k = 0; k < QBD; ++k) q_bload2(bq[k], bvoff, bbase + (long)LM_QXI(k) * xstride);
-    q_bwait<0>(bq[0]);                         // (everything: the wait counts of the first steps assume nothing older is in flight)
+    q_bwait<QLPW>(bq[0]);                      // unit 0 and the first B fragments have landed (this wave's part; the barrier collects all parts)
     __builtin_amdgcn_s_barrier();
     w44_preread<0>(pre, raw0 + lowoff, roff); w44_preread<1>(pre, raw0 + lowoff, roff); w44_preread<2>(pre, raw0 + lowoff, roff);
     w44_preread<3>(pre, raw0 + lowoff, roff); w44_preread<4>(pre, raw0 + lowoff, roff); w44_preread<5>(pre, raw0 + lowoff, roff);
@@ -616,7 +625,7 @@ __global__ __launch_bounds__(256) void wino44_kernel(W44Params p) {
         LM_QTICK(2)
         __builtin_amdgcn_s_barrier();
         LM_QTICK(3)
-        a0 = *reinterpret_cast<const f32x4*>(Vq);
+        a0 = q_aread(Vq);
         LM_QSTEP(0, a0, a1); LM_QSTEP(1, a1, a0); LM_QSTEP(2, a0, a1);
         LM_QSTEP(3, a1, a0); LM_QSTEP(4, a0, a1); LM_QSTEP(5, a1, a0);
         LM_QSTEP(6, a0, a1); LM_QSTEP(7, a1, a0); LM_QSTEP(8, a0, a1);
@@ -636,7 +645,7 @@ __global__ __launch_bounds__(256) void wino44_kernel(W44Params p) {
         LM_QTICK(6)
         __builtin_amdgcn_s_barrier();
         LM_QTICK(3)
-        a0 = *reinterpret_cast<const f32x4*>(Vq);
+        a0 = q_aread(Vq);
         LM_QSTEP(9, a0, a1);  LM_QSTEP(10, a1, a0); LM_QSTEP(11, a0, a1);
         LM_QSTEP(12, a1, a0); LM_QSTEP(13, a0, a1); LM_QSTEP(14, a1, a0);
         LM_QSTEP(15, a0, a1); LM_QSTEP(16, a1, a0); LM_QSTEP(17, a0, a1);

@@ -383,11 +383,11 @@ def _screen(net2, cap, x, noise_key):
     # - is a near-tie wherever a pixel enters or leaves the top K, and the 1e-5 screen above does not see every such case (tile 2033: the
     # reference itself moves one endpoint by a pixel under a 1e-4 perturbation; so does an exact direct-convolution path).  Like the class
     # flips of G10 (reference margin < 1e-4), an endpoint may differ only where the reference's OWN decision changes under a perturbation of
-    # the tolerance's size: four more runs at 1e-4 (two noise patterns, both signs) give, per endpoint of the unperturbed run, whether it is
+    # the tolerance's size: eight more runs at 1e-4 (four noise patterns, both signs) give, per endpoint of the unperturbed run, whether it is
     # present in all of them (`*_firm`), and the union of everything any run produced (`*_any`); `lines_firm` = the polylines survive too.
     dset, eset = {tuple(r) for r in D}, {tuple(r) for r in E}
     d_firm, e_firm, d_any, e_any, lines_firm = set(dset), set(eset), set(dset), set(eset), True
-    for key in (1, 2):
+    for key in (1, 2, 3, 4):
         n4 = torch.from_numpy(((synth.uniform(synth.fnv1a64('margin%d' % key) ^ noise_key, x.numel()) > 0.5).astype(np.float32) * 2 - 1).reshape(x.shape))
         for sgn in (1.0, -1.0):
             o4 = run(x + sgn * 1e-4 * n4)
