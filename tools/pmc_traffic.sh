@@ -26,7 +26,7 @@ for wl in ('fused', 'tiles'):
         f = glob.glob('$O/%s_%s/*counter_collection.csv' % (wl, c))[0]
         for r in csv.DictReader(open(f)):
             n = r['Kernel_Name']
-            k = ('wino44' if 'wino44_kernel' in n else 'wino_gemm' if 'wino_gemm' in n else 'wino_implicit' if ('wino_implicit' in n or 'wino_dual' in n or 'wino_pipe' in n) else 'wino_input' if 'wino_input' in n else
+            k = ('wino44' if 'wino44_kernel' in n else 'wino_rows' if 'wino_rows' in n else 'wino_gemm' if 'wino_gemm' in n else 'wino_implicit' if ('wino_implicit' in n or 'wino_dual' in n or 'wino_pipe' in n) else 'wino_input' if 'wino_input' in n else
                  'conv_mfma' if 'conv_mfma' in n else 'raster_partition' if 'raster_partition' in n else 'raster_band' if 'raster_band' in n else None)
             if k is None: continue
             per[k][c] += float(r['Counter_Value'])
@@ -36,7 +36,7 @@ for wl in ('fused', 'tiles'):
     KB = 1024.0
     def bytes_of(k):
         return (2.0 * per[k]['FETCH_SIZE'] + per[k]['WRITE_SIZE']) * KB / steps
-    mfma = sum(bytes_of(k) for k in ('wino44', 'wino_gemm', 'wino_implicit', 'wino_input', 'conv_mfma') if k in per)
+    mfma = sum(bytes_of(k) for k in ('wino44', 'wino_rows', 'wino_gemm', 'wino_implicit', 'wino_input', 'conv_mfma') if k in per)
     rast = sum(bytes_of(k) for k in ('raster_partition', 'raster_band') if k in per)
     out[wl] = {'mfma_bytes_per_step': mfma, 'raster_bytes_per_step': rast if rast else None, 'csrc_sha16': csrc_sha16(),
                'source': 'profiles/${TAG}_pmc_traffic.txt (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes on bench.py --workload %s --streams 1; FETCH x 2 + WRITE, KiB units)' % wl}
