@@ -235,14 +235,15 @@ struct W44Params {
 };
 
 // packed fp32 pairs (two channels of a lane).  Plain asm (not volatile): the scheduler may move them, the arithmetic is fixed.
+// (the multiplier b is one of three wave-uniform constant pairs: an SGPR-pair operand - with a "v" constraint every use cost a v_mov_b64)
 __device__ __forceinline__ f32x2 pk_fma(const f32x2 a, const f32x2 b, const f32x2 c) {          // a b + c
     f32x2 r;
-    asm("v_pk_fma_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+    asm("v_pk_fma_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "s"(b), "v"(c));
     return r;
 }
 __device__ __forceinline__ f32x2 pk_fnma(const f32x2 a, const f32x2 b, const f32x2 c) {         // (-a) b + c
     f32x2 r;
-    asm("v_pk_fma_f32 %0, %1, %2, %3 neg_lo:[1,0,0] neg_hi:[1,0,0]" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+    asm("v_pk_fma_f32 %0, %1, %2, %3 neg_lo:[1,0,0] neg_hi:[1,0,0]" : "=v"(r) : "v"(a), "s"(b), "v"(c));
     return r;
 }
 __device__ __forceinline__ f32x2 pk_add(const f32x2 a, const f32x2 b) {
@@ -260,59 +261,126 @@ struct W44K {
     f32x2 c2, c4, c5;
 };
 
-// w44_bt on channel pairs
+// w44_bt on channel pairs.  Source order = issue order (the scheduler leaves opaque asm statements where they stand and puts an s_nop
+// between two that depend on each other): the six first-level operations, then the six that consume them - same arithmetic
 __device__ __forceinline__ void pk_bt(const f32x2 (&d)[6], f32x2 (&t)[6], const W44K& k) {
-    t[0] = pk_fma(d[0], k.c4, pk_fnma(d[2], k.c5, d[4]));
-    t[5] = pk_fma(d[1], k.c4, pk_fnma(d[3], k.c5, d[5]));
+    const f32x2 a = pk_fnma(d[2], k.c5, d[4]), b = pk_fnma(d[3], k.c5, d[5]);
     const f32x2 p = pk_fnma(d[2], k.c4, d[4]), q = pk_fnma(d[1], k.c4, d[3]);
+    const f32x2 r = pk_sub(d[4], d[2]), s = pk_sub(d[3], d[1]);
+    t[0] = pk_fma(d[0], k.c4, a);
+    t[5] = pk_fma(d[1], k.c4, b);
     t[1] = pk_add(p, q);
     t[2] = pk_sub(p, q);
-    const f32x2 r = pk_sub(d[4], d[2]), s = pk_sub(d[3], d[1]);
     t[3] = pk_fma(s, k.c2, r);
     t[4] = pk_fnma(s, k.c2, r);
 }
 
-// Transform of one 8-channel half, this thread = (tile, channel pair, LOWER): first pass over the patch rows for its three transformed
-// rows (LOWER = false: i = 0, 1, 2 from patch rows 0..4; true: i = 5, 3, 4 from patch rows 1..5), second pass over the columns, 18
-// planes stored.  The 30 ds_read_b64 of the patch are NOT part of the transform phase: w44_preread issues them one column per step
-// behind the MFMAs of the PREVIOUS phase (LDS instructions are free there), so the phase itself is 72 packed VALU
-// instructions and 18 ds_write_b64.  rawrow = raw buffer + 8 * half + (LOWER ? one patch row : 0); roff[c] = float offset of patch
-// column c of the tile (+ 2 * channel pair).
-struct W44Patch {
-    f32x2 e[6][5];           // [patch column][patch row 0..4 (LOWER: 1..5)]
-};
+// Transform of one 8-channel half (a SLOT of nine MFMA steps), this thread = (tile, channel pair, LOWER): first pass over the patch rows
+// for its three transformed rows (LOWER = false: i = 0, 1, 2 from patch rows 0..4; true: i = 5, 3, 4 from patch rows 1..5), second pass
+// over the columns, 18 planes.  Round 4, third version: NOTHING of it has a phase of its own any more - the pieces ride behind the
+// MFMAs of the slot BEFORE the one that multiplies their result (an LDS instruction behind an f32 MFMA is free, a VALU instruction costs
+// ~8 cycles of matrix time wherever it stands: DESIGN 3.3), which removes the phase's latency parts (LDS store drain, barrier, first
+// A-fragment read with nothing to overlap: ~450 of its 1,040 cycles).  V stays SINGLE-buffered (a second 36 KB buffer does not fit
+// beside two 56 KB patch buffers): a plane of V(s+1) may be overwritten once its owner wave has read V(s)'s - so the slot has a
+// barrier in the middle, the nine planes of every quadrant are split into EARLY ones (local index k <= 4, read in steps 0..4: their
+// successors are stored in steps 5..7, behind the mid barrier) and LATE ones (k >= 5, read in steps 5..8: their successors stay in
+// their registers over the end of the slot and are stored in steps 0..3 of the next one, visible behind ITS mid barrier).
+// Rows by class: A = the row with i % 3 == 0 (planes k = 0..2: early), B = i % 3 == 1 (k = 3, 4 early; k = 5 late), C = i % 3 == 2 (late).
+// Step k of a slot:   0: read cols 0, 1 | store late 0, 1        1: pass 1 of cols 0, 1 | read cols 2, 3 | store late 2, 3
+//   2: pass 1 of cols 2, 3 | read cols 4, 5 | store late 4, 5     3: pass 1 of cols 4, 5 | store late 6, 7      4: pass 2 of row A
+//   -- mid barrier --   5: pass 2 of row B | store A 0..2         6: pass 2 of row C | store A 3..5             7: store B early (4)
+// rawrow = raw buffer + 8 * half + (LOWER ? one patch row : 0); roff[c] = float offset of patch column c of the tile (+ 2 * channel pair).
+struct W44Xf {
+    f32x2 e[6][5];           // [patch column][patch row 0..4 (LOWER: 1..5)] - two columns live at a time
+    f32x2 w[3][6];           // first-pass results by class: [A, B, C][column]
+    f32x2 tA[6], tB[6], tC[6];     // second-pass results; the late planes - (B, j = 2), (B, 5), (C, 0..5) - stay here over the end of the slot
+};                                 // and are stored in steps 0..3 of the next one, before steps 5 / 6 compute their successors
 template <int C>
-__device__ __forceinline__ void w44_preread(W44Patch& d, const float* rawrow, const int (&roff)[6]) {
+__device__ __forceinline__ void w44_preread(W44Xf& d, const float* rawrow, const int (&roff)[6]) {
     constexpr int ROWF = QNCELL * 16;
     const float* s = rawrow + roff[C];
 #pragma unroll
     for (int r = 0; r < 5; ++r) d.e[C][r] = *reinterpret_cast<const f32x2*>(s + r * ROWF);
 }
-template <bool LOWER>
-__device__ __forceinline__ void w44_transform(const W44Patch& d, float* V, int voff, const W44K& k) {
-    f32x2 w[3][6];
-#pragma unroll
-    for (int c = 0; c < 6; ++c) {
-        const f32x2 e0 = d.e[c][0], e1 = d.e[c][1], e2 = d.e[c][2], e3 = d.e[c][3], e4 = d.e[c][4];
-        if constexpr (!LOWER) {       // e = d0 .. d4
-            w[0][c] = pk_fma(e0, k.c4, pk_fnma(e2, k.c5, e4));
-            const f32x2 p = pk_fnma(e2, k.c4, e4), q = pk_fnma(e1, k.c4, e3);
-            w[1][c] = pk_add(p, q);
-            w[2][c] = pk_sub(p, q);
-        } else {                      // e = d1 .. d5
-            w[0][c] = pk_fma(e0, k.c4, pk_fnma(e2, k.c5, e4));                   // t5 = 4 d1 - 5 d3 + d5
-            const f32x2 r = pk_sub(e3, e1), s2 = pk_sub(e2, e0);                 // r = d4 - d2, s = d3 - d1
-            w[1][c] = pk_fma(s2, k.c2, r);
-            w[2][c] = pk_fnma(s2, k.c2, r);
-        }
+// first pass of patch columns C and C + 1 (first-level operations of both, then the second level: no dependent neighbours):
+// (upper) t0, t1, t2 -> classes A, B, C; (lower) t5, t3, t4 -> classes C, A, B
+template <bool LOWER, int C>
+__device__ __forceinline__ void w44_pass1x2(W44Xf& d, const W44K& k) {
+    const f32x2 (&e)[5] = d.e[C];
+    const f32x2 (&f)[5] = d.e[C + 1];
+    if constexpr (!LOWER) {           // e = d0 .. d4
+        const f32x2 a0 = pk_fnma(e[2], k.c5, e[4]), a1 = pk_fnma(f[2], k.c5, f[4]);
+        const f32x2 p0 = pk_fnma(e[2], k.c4, e[4]), p1 = pk_fnma(f[2], k.c4, f[4]);
+        const f32x2 q0 = pk_fnma(e[1], k.c4, e[3]), q1 = pk_fnma(f[1], k.c4, f[3]);
+        d.w[0][C] = pk_fma(e[0], k.c4, a0);
+        d.w[0][C + 1] = pk_fma(f[0], k.c4, a1);
+        d.w[1][C] = pk_add(p0, q0);
+        d.w[1][C + 1] = pk_add(p1, q1);
+        d.w[2][C] = pk_sub(p0, q0);
+        d.w[2][C + 1] = pk_sub(p1, q1);
+    } else {                          // e = d1 .. d5
+        const f32x2 a0 = pk_fnma(e[2], k.c5, e[4]), a1 = pk_fnma(f[2], k.c5, f[4]);
+        const f32x2 r0 = pk_sub(e[3], e[1]), r1 = pk_sub(f[3], f[1]);            // r = d4 - d2
+        const f32x2 s0 = pk_sub(e[2], e[0]), s1 = pk_sub(f[2], f[0]);            // s = d3 - d1
+        d.w[2][C] = pk_fma(e[0], k.c4, a0);                                      // t5 = 4 d1 - 5 d3 + d5  (i = 5: class C)
+        d.w[2][C + 1] = pk_fma(f[0], k.c4, a1);
+        d.w[0][C] = pk_fma(s0, k.c2, r0);                                        // t3 (i = 3: class A)
+        d.w[0][C + 1] = pk_fma(s1, k.c2, r1);
+        d.w[1][C] = pk_fnma(s0, k.c2, r0);                                       // t4 (i = 4: class B)
+        d.w[1][C + 1] = pk_fnma(s1, k.c2, r1);
     }
+}
+// the LDS part of step K's transform share.  vA / vB / vC = V + plane offset of the thread's class-A / B / C row + its element offset
+template <int K>
+__device__ __forceinline__ void w44_xf_lds(W44Xf& d, const float* rawrow, const int (&roff)[6], float* vA, float* vB, float* vC) {
+    auto st = [](float* v, int j, const f32x2 t) { *reinterpret_cast<f32x2*>(v + j * 256) = t; };
+    if constexpr (K == 0) {
+        st(vB, 2, d.tB[2]); st(vB, 5, d.tB[5]);
+        w44_preread<0>(d, rawrow, roff); w44_preread<1>(d, rawrow, roff);
+    } else if constexpr (K == 1) {
+        st(vC, 0, d.tC[0]); st(vC, 1, d.tC[1]);
+        w44_preread<2>(d, rawrow, roff); w44_preread<3>(d, rawrow, roff);
+    } else if constexpr (K == 2) {
+        st(vC, 2, d.tC[2]); st(vC, 3, d.tC[3]);
+        w44_preread<4>(d, rawrow, roff); w44_preread<5>(d, rawrow, roff);
+    } else if constexpr (K == 3) {
+        st(vC, 4, d.tC[4]); st(vC, 5, d.tC[5]);
+    } else if constexpr (K == 5) {
+        st(vA, 0, d.tA[0]); st(vA, 1, d.tA[1]); st(vA, 2, d.tA[2]);
+    } else if constexpr (K == 6) {
+        st(vA, 3, d.tA[3]); st(vA, 4, d.tA[4]); st(vA, 5, d.tA[5]);
+    } else if constexpr (K == 7) {
+        st(vB, 0, d.tB[0]); st(vB, 1, d.tB[1]); st(vB, 3, d.tB[3]); st(vB, 4, d.tB[4]);
+    }
+}
+// the VALU part of step K's transform share (issued LAST behind the step's first MFMA: everything queued behind a VALU instruction
+// waits for the MFMA in front of it to leave the pipe)
+template <int K>
+__device__ __forceinline__ void w44_xf_valu(W44Xf& d, bool lower, const W44K& k) {
+    if constexpr (K >= 1 && K <= 3) {
+        if (lower) w44_pass1x2<true, 2 * K - 2>(d, k);
+        else w44_pass1x2<false, 2 * K - 2>(d, k);
+    } else if constexpr (K == 4) {
+        pk_bt(d.w[0], d.tA, k);
+    } else if constexpr (K == 5) {
+        pk_bt(d.w[1], d.tB, k);
+    } else if constexpr (K == 6) {
+        pk_bt(d.w[2], d.tC, k);
+    }
+}
+// the whole transform of one slot at once (prologue: V(0) has nobody to hide behind): every plane stored; the first slot stores the late
+// ones again in its steps 0..3 (the same bits)
+__device__ __forceinline__ void w44_xf_all(W44Xf& d, const float* rawrow, const int (&roff)[6], float* vA, float* vB, float* vC, bool lower,
+                                           const W44K& k) {
+    w44_preread<0>(d, rawrow, roff); w44_preread<1>(d, rawrow, roff); w44_preread<2>(d, rawrow, roff);
+    w44_preread<3>(d, rawrow, roff); w44_preread<4>(d, rawrow, roff); w44_preread<5>(d, rawrow, roff);
+    w44_xf_valu<1>(d, lower, k); w44_xf_valu<2>(d, lower, k); w44_xf_valu<3>(d, lower, k);
+    w44_xf_valu<4>(d, lower, k); w44_xf_valu<5>(d, lower, k); w44_xf_valu<6>(d, lower, k);
 #pragma unroll
-    for (int i = 0; i < 3; ++i) {
-        const int ip = LOWER ? (i == 0 ? 5 : (i == 1 ? 3 : 4)) : i;
-        f32x2 t[6];
-        pk_bt(w[i], t, k);
-#pragma unroll
-        for (int j = 0; j < 6; ++j) *reinterpret_cast<f32x2*>(V + (6 * ip + j) * 256 + voff) = t[j];
+    for (int j = 0; j < 6; ++j) {
+        *reinterpret_cast<f32x2*>(vA + j * 256) = d.tA[j];
+        *reinterpret_cast<f32x2*>(vB + j * 256) = d.tB[j];
+        *reinterpret_cast<f32x2*>(vC + j * 256) = d.tC[j];
     }
 }
 
@@ -372,16 +440,18 @@ __device__ __forceinline__ f32x4 q_aread(const float* v) {
     return f32x4{lo[0], lo[1], hi[0], hi[1]};
 }
 
-// One step (one xi of the wave) of an MFMA phase: 8 MFMAs = 4 k steps x 2 channel blocks.  S = step within the unit (0..17: two phases
+// One step (one xi of the wave) of a slot: 8 MFMAs = 4 k steps x 2 channel blocks.  S = step within the 16-channel unit (0..17: two slots
 // of nine); the B fragments of step S + QBD and the patch loads of this step (q_ndma) are issued first; q_nwait(S) loads may stay
-// outstanding when this step's B fragments are needed.  Behind the first MFMA: the A fragment of the next step and (steps 0..5 of a
-// phase) one column of the NEXT phase's patch pre-read.
-template <int S, bool NEXT>
+// outstanding when this step's B fragments are needed.  Behind the first MFMA: the A fragment of the next step (not across a barrier:
+// steps 4 and 8 leave it to the loop), the LDS part of this step's transform share, then its VALU part.
+template <int S>
 __device__ __forceinline__ void w44_step(f32x16& acc0, f32x16& acc1, f32x4 (&bq)[QRING][2], unsigned bvoff, const float* bpre,
                                          const float* anext, const f32x4& a_cur, f32x4& a_nxt, const float* const (&gsrc)[QLPW], long goff,
-                                         float* rawld, int wave, W44Patch& pre, const float* prerow, const int (&roff)[6]) {
+                                         float* rawld, int wave, W44Xf& xf, const float* prerow, const int (&roff)[6], float* vA, float* vB,
+                                         float* vC, bool lower, const W44K& kk) {
     typedef __attribute__((address_space(1))) const void gptr_t;
     typedef __attribute__((address_space(3))) void lptr_t;
+    constexpr int K = S % 9;
 #ifndef LM_QABL_NOB
     q_bload2(bq[(S + QBD) % QRING], bvoff, bpre);
 #endif
@@ -398,12 +468,14 @@ __device__ __forceinline__ void w44_step(f32x16& acc0, f32x16& acc1, f32x4 (&bq)
 #else
     q_bwait<0>(b);
 #endif
-    constexpr bool VACC = (S % 9) == 8;
+    constexpr bool VACC = K == 8;
     q_mfma<VACC>(acc0, a_cur[0], b[0][0]);
     __builtin_amdgcn_sched_barrier(0);
-    if constexpr (NEXT) a_nxt = q_aread(anext);
+    if constexpr (K != 4 && K != 8) a_nxt = q_aread(anext);
 #ifndef LM_QABL_NOT
-    if constexpr ((S % 9) < 6) w44_preread<S % 9>(pre, prerow, roff);
+    w44_xf_lds<K>(xf, prerow, roff, vA, vB, vC);
+    __builtin_amdgcn_sched_barrier(0);
+    w44_xf_valu<K>(xf, lower, kk);
 #endif
     __builtin_amdgcn_sched_barrier(0);
     q_mfma<VACC>(acc1, a_cur[0], b[1][0]);
@@ -561,6 +633,10 @@ __global__ __launch_bounds__(256) void wino44_kernel(W44Params p) {
         tvoff = cp * 64 + tl * 2;
     }
     const bool lower = (wave >> 1) != 0;
+    // plane rows of this thread by class (A: i % 3 == 0, B: == 1, C: == 2): upper threads i = 0, 1, 2; lower threads i = 3, 4, 5
+    float* const vA = Vbuf + (lower ? 3 : 0) * (6 * 256) + tvoff;
+    float* const vB = Vbuf + (lower ? 4 : 1) * (6 * 256) + tvoff;
+    float* const vC = Vbuf + (lower ? 5 : 2) * (6 * 256) + tvoff;
     const W44K kk = {f32x2{2.f, 2.f}, f32x2{4.f, 4.f}, f32x2{5.f, 5.f}};
     // MFMA operands: A = V plane xi, channel pairs 2 (lane >> 5) and 2 (lane >> 5) + 1 of tile lane & 31; this wave's planes xi = xi00 + 6 ii + jj
     const int qa = wave >> 1, qb = wave & 1;
@@ -580,11 +656,11 @@ __global__ __launch_bounds__(256) void wino44_kernel(W44Params p) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[k][b][r] = 0.f;
     f32x4 bq[QRING][2];
-    W44Patch pre;
+    W44Xf xf;
     const int lowoff = lower ? QNCELL * 16 : 0;               // LOWER threads read patch rows 1..5
     LM_QTICK(0)
     // prologue: raw unit 0, B of steps 0 .. QBD-1, THEN raw unit 1: the wait below leaves unit 1's loads (the youngest) in flight - they
-    // are only needed before the second MFMA phase, and being older than every load of the loop they do not enter its wait counts
+    // are only needed before the second slot, and being older than every load of the loop they do not enter its wait counts
 #pragma unroll
     for (int s_ = 0; s_ < QLPW; ++s_)
         __builtin_amdgcn_global_load_lds((gptr_t*)gsrc[s_], (lptr_t*)(raw0 + (s_ * 4 + wave) * 256), 16, 0, 0);
@@ -599,60 +675,61 @@ __global__ __launch_bounds__(256) void wino44_kernel(W44Params p) {
     }
     q_bwait<QLPW>(bq[0]);                      // unit 0 and the first B fragments have landed (this wave's part; the barrier collects all parts)
     __builtin_amdgcn_s_barrier();
-    w44_preread<0>(pre, raw0 + lowoff, roff); w44_preread<1>(pre, raw0 + lowoff, roff); w44_preread<2>(pre, raw0 + lowoff, roff);
-    w44_preread<3>(pre, raw0 + lowoff, roff); w44_preread<4>(pre, raw0 + lowoff, roff); w44_preread<5>(pre, raw0 + lowoff, roff);
     LM_QTICK(1)
+    // V(0): the only transform with nothing to hide behind
+#ifndef LM_QABL_NOT
+    w44_xf_all(xf, raw0 + lowoff, roff, vA, vB, vC, lower, kk);
+#endif
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    LM_QTICK(2)
+    __builtin_amdgcn_s_barrier();
+    LM_QTICK(3)
 
-    // B fragments of step S5 = S + QBD of the unit (S5 >= 18: first phase of the next unit)
+    // B fragments of step S5 = S + QBD of the unit (S5 >= 18: first slot of the next unit)
 #define LM_QBPRE(S5) ((S5) < 18 ? bu + (long)((S5) / 9) * ustride + (long)LM_QXI((S5) % 9) * xstride : bu_next + (long)LM_QXI((S5) - 18) * xstride)
 #define LM_QSTEP(S, AC, AN) \
-    w44_step<S, ((S) % 9) < 8>(acc[(S) % 9][0], acc[(S) % 9][1], bq, bvoff, LM_QBPRE((S) + QBD), Vq + LM_QXI(((S) % 9) + 1 < 9 ? ((S) % 9) + 1 : 0) * 256, \
-                               AC, AN, gsrc, goff, rawc_w, wave, pre, (S) < 9 ? rawc + 8 + lowoff : rawn + lowoff, roff)
+    w44_step<S>(acc[(S) % 9][0], acc[(S) % 9][1], bq, bvoff, LM_QBPRE((S) + QBD), Vq + LM_QXI(((S) % 9) + 1 < 9 ? ((S) % 9) + 1 : 0) * 256, \
+                AC, AN, gsrc, goff, rawc_w, wave, xf, (S) < 9 ? rawc + 8 + lowoff : rawn + lowoff, roff, vA, vB, vC, lower, kk)
+    // the barrier in the middle of a slot: this wave's late stores (steps 0..3) are done; behind it every wave's are, and the early
+    // planes are free (every wave has read V(s)'s in steps 0..4)
+#define LM_QMID(AN)                                          \
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");       \
+    LM_QTICK(4)                                              \
+    __builtin_amdgcn_s_barrier();                            \
+    LM_QTICK(5)                                              \
+    AN = q_aread(Vq + LM_QXI(5) * 256);
     for (int u = 0; u < nun; ++u) {
         const float* const rawc = raw0 + (u & 1) * QRAWF;              // unit u
-        float* const rawc_w = raw0 + (u & 1) * QRAWF;                  // ... and the destination of unit u + 2's patch loads (second phase)
-        const float* const rawn = raw0 + ((u + 1) & 1) * QRAWF;        // unit u + 1 (pre-read in the second phase)
+        float* const rawc_w = raw0 + (u & 1) * QRAWF;                  // ... and the destination of unit u + 2's patch loads (second slot)
+        const float* const rawn = raw0 + ((u + 1) & 1) * QRAWF;        // unit u + 1 (pre-read in the second slot)
         const long goff = u + 2 < nun ? (long)(u + 2) * 16 : 0;            // (nothing left to fetch: harmless re-read of unit 0)
         const float* const bu = bbase + (long)(2 * u) * ustride;
         const float* const bu_next = bbase + (long)(u + 1 < nun ? 2 * (u + 1) : 0) * ustride;
         f32x4 a0, a1;
-        // ---- channels 16 u .. 16 u + 7 (patch pre-read during the previous phase)
-#ifndef LM_QABL_NOT
-        if (lower) w44_transform<true>(pre, Vbuf, tvoff, kk);
-        else w44_transform<false>(pre, Vbuf, tvoff, kk);
-#endif
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        LM_QTICK(2)
-        __builtin_amdgcn_s_barrier();
-        LM_QTICK(3)
+        // ---- slot 2 u: channels 16 u .. 16 u + 7 multiplied, channels 16 u + 8 .. 16 u + 15 transformed behind the MFMAs
         a0 = q_aread(Vq);
-        LM_QSTEP(0, a0, a1); LM_QSTEP(1, a1, a0); LM_QSTEP(2, a0, a1);
-        LM_QSTEP(3, a1, a0); LM_QSTEP(4, a0, a1); LM_QSTEP(5, a1, a0);
-        LM_QSTEP(6, a0, a1); LM_QSTEP(7, a1, a0); LM_QSTEP(8, a0, a1);
-        LM_QTICK(4)
-        __builtin_amdgcn_s_barrier();                                       // V is free again
-        LM_QTICK(5)
-        // ---- channels 16 u + 8 .. 16 u + 15
-#ifndef LM_QABL_NOT
-        if (lower) w44_transform<true>(pre, Vbuf, tvoff, kk);
-        else w44_transform<false>(pre, Vbuf, tvoff, kk);
-#endif
+        LM_QSTEP(0, a0, a1); LM_QSTEP(1, a1, a0); LM_QSTEP(2, a0, a1); LM_QSTEP(3, a1, a0); LM_QSTEP(4, a0, a1);
+        LM_QMID(a1)
+        LM_QSTEP(5, a1, a0); LM_QSTEP(6, a0, a1); LM_QSTEP(7, a1, a0); LM_QSTEP(8, a0, a1);
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        LM_QTICK(2)
-        // unit u + 1 (patch loads of the previous unit's second phase, or of the prologue) is pre-read in the phase that follows: every
-        // load older than the 18 B loads of the phase just finished has landed
+        LM_QTICK(4)
+        // unit u + 1 (patch loads of the previous unit's second slot, or of the prologue) is pre-read in the slot that follows: every
+        // load older than the 18 B loads of the slot just finished has landed
         q_bwait<2 * 9>(bq[0]);
         LM_QTICK(6)
-        __builtin_amdgcn_s_barrier();
-        LM_QTICK(3)
+        __builtin_amdgcn_s_barrier();          // V(2 u + 1)'s early planes complete
+        LM_QTICK(5)
+        // ---- slot 2 u + 1: channels 16 u + 8 .. multiplied, the next unit's first half transformed, unit u + 2's patches requested
         a0 = q_aread(Vq);
-        LM_QSTEP(9, a0, a1);  LM_QSTEP(10, a1, a0); LM_QSTEP(11, a0, a1);
-        LM_QSTEP(12, a1, a0); LM_QSTEP(13, a0, a1); LM_QSTEP(14, a1, a0);
-        LM_QSTEP(15, a0, a1); LM_QSTEP(16, a1, a0); LM_QSTEP(17, a0, a1);
+        LM_QSTEP(9, a0, a1);  LM_QSTEP(10, a1, a0); LM_QSTEP(11, a0, a1); LM_QSTEP(12, a1, a0); LM_QSTEP(13, a0, a1);
+        LM_QMID(a1)
+        LM_QSTEP(14, a1, a0); LM_QSTEP(15, a0, a1); LM_QSTEP(16, a1, a0); LM_QSTEP(17, a0, a1);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         LM_QTICK(4)
-        __builtin_amdgcn_s_barrier();          // V free
+        __builtin_amdgcn_s_barrier();
         LM_QTICK(5)
     }
+#undef LM_QMID
 #undef LM_QSTEP
 #undef LM_QBPRE
 #undef LM_QXI
