@@ -195,7 +195,7 @@ def main():
                          "(pre-rasterised, batch 8); rowref = configs[3] (Proj28_GFC-T3_RowRef head, pre-rasterised, batch 8); lidar = "
                          "configs[4] (sparse-conv LiDAR encoder path, batch 8 point clouds, parity unpinned)")
     ap.add_argument('--streams', type=int, default=None,
-                    help='split every batch over this many HIP streams (fills launch tails); default 4, 1 for lidar '
+                    help='split every batch over this many HIP streams (fills launch tails); default 4 (fused: 2, lidar: 1) '
                          '(its data-dependent launch sizes need host round trips, which serialise sub-batches)')
     ap.add_argument('--conv-detail', action='store_true', help='per-shape table of the MFMA launches on stderr')
     ap.add_argument('--no-stream-check', action='store_true', help='skip the bitwise multi-stream == single-stream check')
@@ -272,7 +272,9 @@ def main():
     pipe = TilePipeline(net, host_threads=args.host_threads, use_graph=args.graphs)
     # whole-batch reference / instrumented passes launch kernel by kernel (the roofline hook brackets every launch with events)
     pipe_eager = pipe if not args.graphs else TilePipeline(net, host_threads=args.host_threads, use_graph=False)
-    nstream = max(1, args.streams if args.streams is not None else (1 if args.workload == 'lidar' else 4))
+    # default streams per workload (measured with the round-4 kernels, 10-step runs on one box): fused (batch 16) 2 streams 362-363 tiles/s,
+    # 4 streams 355-357, 3: 344, 1: 341; tiles (batch 8) 347-348 for 2 / 3 / 4; rowref 344 with 4, 331 with 2
+    nstream = max(1, args.streams if args.streams is not None else {'lidar': 1, 'fused': 2}.get(args.workload, 4))
     nstream = min(nstream, batch)
     extra_streams = [torch.cuda.Stream(device=dev) for _ in range(nstream - 1)]
     extra_pipes = [TilePipeline(net, host_threads=args.host_threads, use_graph=args.graphs) for _ in range(nstream - 1)]
