@@ -614,8 +614,10 @@ __global__ __launch_bounds__(256) void wino44_kernel(W44Params p) {
             }
         const int lc = 4 * (slot - s0) + cc;
         const int yy = yb + r * g.dil, xx = xb + lc * g.dil;
-        const bool ok = r < 6 && n > 0 && lc < 4 * n + 2 && (unsigned)yy < (unsigned)g.H && (unsigned)xx < (unsigned)g.W;
-        gsrc[s_] = ok ? p.x + (long)(img_pix0 + yy * g.W + xx) * p.ldx + cq * 4 : p.zeros + cq * 4;
+        // (bitwise &: the short-circuit form became five divergent branches per load in the set-up)
+        const bool ok = (r < 6) & (n > 0) & (lc < 4 * n + 2) & ((unsigned)yy < (unsigned)g.H) & ((unsigned)xx < (unsigned)g.W);
+        const long eoff = ok ? (long)(img_pix0 + yy * g.W + xx) * p.ldx : 0;
+        gsrc[s_] = (ok ? p.x : p.zeros) + eoff + cq * 4;
     }
     // transform share: tile = lane & 31, LOWER = wave >> 1 (wave-uniform), channel pair of the 8-channel half skewed by the tile slot so
     // that the 32 lanes of a ds_read_b64 pass hit 16 different bank pairs

@@ -12,7 +12,7 @@ agg = collections.defaultdict(lambda: collections.defaultdict(list))
 for r in csv.DictReader(open(f)):
     n = r['Kernel_Name']
     if 'wino44_kernel' not in n and 'wino_pipe' not in n and 'wino_dual' not in n: continue
-    agg[(n.split('(')[0][-24:], r['Grid_Size'])][r['Counter_Name']].append(float(r['Counter_Value']))
+    agg[(n.replace('(anonymous namespace)::', '').split('(')[0], r['Grid_Size'])][r['Counter_Name']].append(float(r['Counter_Value']))
 for k, d in sorted(agg.items()):
     m = {n: sum(v) / len(v) for n, v in d.items()}
     cyc = m['GRBM_GUI_ACTIVE'] / 8
