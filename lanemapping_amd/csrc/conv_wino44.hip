@@ -22,13 +22,14 @@
 // planes of V (LDS) and its own nine planes of U (global -> registers, ring of 6 register sets 5 steps ahead): no operand is fetched
 // twice inside a workgroup.  Per 16-channel unit of the input:
 //   1. the RAW 6 x 6 patches of the 32 tiles (6 patch rows x 144 cells of 16 channels; horizontally adjacent tiles share two columns)
-//      arrive in LDS through global_load_lds gathers straight from the NHWC tensor (zero block for padding), issued during the
-//      previous unit's MFMA phases, double-buffered;
-//   2. per 8-channel half: TRANSFORM phase - the 256 threads compute V = B^T d B for the half ONCE (thread = tile x channel pair x
-//      half of the first pass: 30 ds_read_b64, 72 packed FMAs / adds, 18 ds_write_b64) into V[xi][channel pair][tile][2] (36 KB);
-//      MFMA phase - per xi of the wave one ds_read_b128 A fragment, two B fragments, 8 MFMAs (4 k steps x 2 channel blocks).
-//   f32 MFMA shares the SIMD's vector ALUs, so the transform is NOT hidden - it costs 72 packed VALU per 72 MFMAs - but
-//   it is paid once per 64 output channels, and 36 products replace 4 x 16.
+//      arrive in LDS through global_load_lds gathers straight from the NHWC tensor (zero block for padding), requested two units ahead,
+//      double-buffered;
+//   2. per 8-channel half (a SLOT of nine steps, one per xi of the wave: one A fragment from LDS, two B fragments, 8 MFMAs = 4 k steps
+//      x 2 channel blocks): the 256 threads compute V = B^T d B of the NEXT half once (thread = tile x channel pair x half of the first
+//      pass: 30 ds_read_b64, 72 packed FMAs / adds, 18 ds_write_b64 into V[xi][channel pair][tile][2], 36 KB, single-buffered) in pieces
+//      that ride behind the first MFMA of each step - see W44Xf for the early / late plane split and the barrier in the middle of a slot.
+//   f32 MFMA shares the SIMD's vector ALUs, so the transform's arithmetic is NOT hidden wherever it stands - it costs 72
+//   packed VALU per 72 MFMAs - but it is paid once per 64 output channels, and 36 products replace 4 x 16.
 // Epilogue: the 36 products of an output block sit in four different waves, so they meet in LDS: per 32-channel block every wave stores
 // its nine planes straight from the accumulator registers (M[xi][tile][32 channels], 144 KB), then every thread takes one (tile, channel
 // quad): 36 ds_read_b128, A^T M A (100 operations per element), the tail (BN scale / shift, residual, ReLU, GroupNorm partial sums) and
