@@ -800,7 +800,17 @@ __global__ __launch_bounds__(256) void wino44_kernel(W44Params p) {
             const float* const rp = p.res + (long)ebase * p.ldr + n;
             const int rs = g.W * g.dil * p.ldr, cs = g.dil * p.ldr;
 #pragma unroll
-            for (int q = 0; q < 16; ++q) rpre[q] = *reinterpret_cast<const f32x4*>(rp + min(q >> 2, ey1) * rs + min(q & 3, ex1) * cs);
+            for (int q = 0; q < 16; ++q) {
+#if defined(LM_QEXP) && LM_QEXP == 1          // (timing experiments: every load from the tile's first pixel / four loads only / non-temporal)
+                rpre[q] = *reinterpret_cast<const f32x4*>(rp);
+#elif defined(LM_QEXP) && LM_QEXP == 2
+                rpre[q] = q < 4 ? *reinterpret_cast<const f32x4*>(rp + min(q >> 2, ey1) * rs + min(q & 3, ex1) * cs) : f32x4{0.f, 0.f, 0.f, 0.f};
+#elif defined(LM_QEXP) && LM_QEXP == 3
+                rpre[q] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(rp + min(q >> 2, ey1) * rs + min(q & 3, ex1) * cs));
+#else
+                rpre[q] = *reinterpret_cast<const f32x4*>(rp + min(q >> 2, ey1) * rs + min(q & 3, ex1) * cs);
+#endif
+            }
         }
         // (LDS-only barriers: __syncthreads() would also wait for the previous block's global stores to be acknowledged)
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
