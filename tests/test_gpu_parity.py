@@ -1402,6 +1402,49 @@ def test_conv_winograd44_bit_identical_to_twin(dev, B, cin, cout, H, W, dil):
         assert torch.equal(st, st2)
 
 
+def test_conv_winograd44_random_shapes_vs_twin(dev):
+    """Thirty seeded random shapes through wino44_kernel and its twin: bit-identical, twice (the fused loop synchronises its single V
+    buffer with a barrier in the middle of every slot and keeps late planes in registers across slots - a race would show as a run-to-run
+    or kernel-to-twin difference on some shape).  Ragged sizes, dilation 1-3, 1-20 channel units, any Cout, with / without scale, residual,
+    ReLU; image widths from the narrowest supported tile row (15 tiles) up."""
+    from lanemapping_amd import ops
+    rng = np.random.RandomState(4404)
+    done = 0
+    while done < 30:
+        dil = int(rng.choice([1, 1, 1, 2, 2, 3]))
+        W = int(rng.randint(57 * dil, 57 * dil + 140))
+        H = int(rng.randint(5, 90))
+        cin = 16 * int(rng.randint(1, 21))
+        cout = int(rng.choice([rng.randint(1, 40), 64, 128, rng.randint(65, 300)]))
+        B = int(rng.randint(1, 3))
+        if not ops.wino44_supported(H, W, cin, dil):
+            continue
+        done += 1
+        g = torch.Generator().manual_seed(1000 + done)
+        x = ops.new_act(B, cin, H, W, dev)
+        x.copy_(torch.randn((B, cin, H, W), generator=g).to(dev))
+        w = (torch.randn((cout, cin, 3, 3), generator=g) / (cin * 9) ** 0.5).to(dev)
+        use_scale, use_res, relu = bool(rng.randint(2)), bool(rng.randint(2)), bool(rng.randint(2))
+        sc = (torch.rand(cout, generator=g) + 0.5).to(dev) if use_scale else None
+        sh = torch.randn(cout, generator=g).to(dev)
+        res = None
+        if use_res:
+            res = ops.new_act(B, cout, H, W, dev)
+            res.copy_(torch.randn((B, cout, H, W), generator=g).to(dev))
+        act = ops.ACT_RELU if relu else ops.ACT_NONE
+        wu = ops.pack_wino44(w)
+        wf = ops.pack_wino44_fragments(wu)
+        y0 = ops.conv_wino44_twin(x, wu, cout, dil, scale=sc, shift=sh, res=res, act=act)
+        y1 = ops.conv_wino44(x, wf, cout, dil, scale=sc, shift=sh, res=res, act=act)
+        y2 = ops.conv_wino44(x, wf, cout, dil, scale=sc, shift=sh, res=res, act=act)
+        tag = f'shape {done}: B{B} {cin}->{cout} {H}x{W} d{dil} scale={use_scale} res={use_res} relu={relu}'
+        assert torch.equal(y0, y1), (tag, float((y0 - y1).abs().max()))
+        assert torch.equal(y1, y2), tag
+        if cin % 32 == 0:                       # (and against the direct MFMA kernel where it takes the shape: the twin shares the fused kernel's arithmetic)
+            yd = ops.conv_mfma(x, ops.pack_mfma(w), cout, 3, 3, 1, dil, dil, scale=sc, shift=sh, res=res, act=act)
+            _close(y1, yd, 1e-4, tag + ' vs direct')
+
+
 @pytest.mark.parametrize('B,cin,cout,H,W,dil', [(2, 128, 128, 48, 44, 1), (1, 256, 200, 43, 61, 1), (1, 160, 256, 85, 87, 2), (2, 256, 512, 144, 144, 1),
                                                 (1, 32, 64, 100, 96, 1), (2, 96, 32, 60, 90, 1)])      # (two slots; six slots, one N tile half empty)
 def test_conv_winograd_bf16x3_vs_fp64(dev, B, cin, cout, H, W, dil):
