@@ -791,36 +791,35 @@ __global__ __launch_bounds__(256) void wino44_kernel(W44Params p) {
                     if (p.shift) sh[e] = p.shift[n + e];
                 }
         }
+        // residual (BasicBlock identity): the sixteen 16-byte loads of this thread's outputs are issued BETWEEN the product stores of the
+        // exchange - issuing them costs ~140 cycles apiece here (cold lines, eight 128-byte segments 4 KB apart per wave instruction:
+        // profiles/r4_wino44_residual_issue_experiment.txt), the LDS store path drains its queue meanwhile; inside the store loop of the tail
+        // each would be a memory round trip of its own in front of a store (y may alias res as far as the compiler knows).
+        // Branch-free: offsets clamped into the tile's valid part (equal to the true offsets wherever an output exists)
         f32x4 rpre[16];
 #ifdef LM_QABL_NORES
-        if (false) {
+        const bool load_res = false;
 #else
-        if (vec && has_res) {
+        const bool load_res = vec && has_res;
 #endif
-            const float* const rp = p.res + (long)ebase * p.ldr + n;
-            const int rs = g.W * g.dil * p.ldr, cs = g.dil * p.ldr;
-#pragma unroll
-            for (int q = 0; q < 16; ++q) {
-#if defined(LM_QEXP) && LM_QEXP == 1          // (timing experiments: every load from the tile's first pixel / four loads only / non-temporal)
-                rpre[q] = *reinterpret_cast<const f32x4*>(rp);
-#elif defined(LM_QEXP) && LM_QEXP == 2
-                rpre[q] = q < 4 ? *reinterpret_cast<const f32x4*>(rp + min(q >> 2, ey1) * rs + min(q & 3, ex1) * cs) : f32x4{0.f, 0.f, 0.f, 0.f};
-#elif defined(LM_QEXP) && LM_QEXP == 3
-                rpre[q] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(rp + min(q >> 2, ey1) * rs + min(q & 3, ex1) * cs));
-#else
-                rpre[q] = *reinterpret_cast<const f32x4*>(rp + min(q >> 2, ey1) * rs + min(q & 3, ex1) * cs);
-#endif
-            }
-        }
+        const float* const rp = p.res + (long)ebase * p.ldr + n;
+        const int rs = g.W * g.dil * p.ldr, cs = g.dil * p.ldr;
         // (LDS-only barriers: __syncthreads() would also wait for the previous block's global stores to be acknowledged)
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         LM_QTICK(9)
         __builtin_amdgcn_s_barrier();          // patch / V buffers (blk 0) or the previous block's products are no longer read
         LM_QTICK(10)
 #pragma unroll
-        for (int k = 0; k < 9; ++k)
+        for (int k = 0; k < 9; ++k) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) mw[(6 * (k / 3) + k % 3) * 1024 + ((r & 3) + 8 * (r >> 2)) * 32] = acc[k][blk][r];
+            if (k < 8 && load_res) {
+#pragma unroll
+                for (int q = 2 * k; q < 2 * k + 2; ++q)
+                    rpre[q] = *reinterpret_cast<const f32x4*>(rp + min(q >> 2, ey1) * rs + min(q & 3, ex1) * cs);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         LM_QTICK(12)
         __builtin_amdgcn_s_barrier();
