@@ -619,6 +619,10 @@ __global__ __launch_bounds__(256) void wino44_kernel(W44Params p) {
         const bool ok = (r < 6) & (n > 0) & (lc < 4 * n + 2) & ((unsigned)yy < (unsigned)g.H) & ((unsigned)xx < (unsigned)g.W);
         const long eoff = ok ? (long)(img_pix0 + yy * g.W + xx) * p.ldx : 0;
         gsrc[s_] = (ok ? p.x : p.zeros) + eoff + cq * 4;
+        // unit 0's patch load s goes out as soon as its source is known: issuing a load of cold, scattered lines stalls ~140 cycles
+        // (profiles/r4_wino44_residual_issue_experiment.txt) - the address arithmetic of load s + 1 runs meanwhile
+        __builtin_amdgcn_global_load_lds((gptr_t*)gsrc[s_], (lptr_t*)(raw0 + (s_ * 4 + wave) * 256), 16, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
     }
     // transform share: tile = lane & 31, LOWER = wave >> 1 (wave-uniform), channel pair of the 8-channel half skewed by the tile slot so
     // that the 32 lanes of a ds_read_b64 pass hit 16 different bank pairs
@@ -662,11 +666,8 @@ __global__ __launch_bounds__(256) void wino44_kernel(W44Params p) {
     W44Xf xf;
     const int lowoff = lower ? QNCELL * 16 : 0;               // LOWER threads read patch rows 1..5
     LM_QTICK(0)
-    // prologue: raw unit 0, B of steps 0 .. QBD-1, THEN raw unit 1: the wait below leaves unit 1's loads (the youngest) in flight - they
+    // prologue: (raw unit 0 was requested while the sources were computed,) B of steps 0 .. QBD-1, THEN raw unit 1: the wait below leaves unit 1's loads (the youngest) in flight - they
     // are only needed before the second slot, and being older than every load of the loop they do not enter its wait counts
-#pragma unroll
-    for (int s_ = 0; s_ < QLPW; ++s_)
-        __builtin_amdgcn_global_load_lds((gptr_t*)gsrc[s_], (lptr_t*)(raw0 + (s_ * 4 + wave) * 256), 16, 0, 0);
 #define LM_QXI(K) (6 * ((K) / 3) + (K) % 3)
 #pragma unroll
     for (int k = 0; k < QBD; ++k) q_bload2(bq[k], bvoff, bbase + (long)LM_QXI(k) * xstride);
