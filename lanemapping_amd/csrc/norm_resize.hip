@@ -171,6 +171,11 @@ struct Proj1x1 {
 // paid up to three serial memory round trips - the counters showed 73 % of the wave cycles parked at s_waitcnt with 8 waves per SIMD
 // (tools/prof_gn_pmc.sh).  Now the statistics and every tap of every term are loaded first (up to 6 + 6 16-byte loads in flight per
 // lane), then the arithmetic runs in the old order: same bits.
+// 16 bytes at element `elem` of a wave-uniform base: byte offset kept in 32 bits so that the access becomes scalar base + vector offset
+__device__ __forceinline__ f32x4 ld_quad(const float* base, unsigned elem) {
+    return *reinterpret_cast<const f32x4*>(reinterpret_cast<const char*>(base) + (elem << 2));
+}
+
 template <int N, int SAME>
 __global__ __launch_bounds__(256) void gn_relu_upsample_sum_kernel(GnSum P, const float* __restrict__ gamma, const float* __restrict__ beta,
                                                                    float* __restrict__ y, int Ho, int Wo, int C, int c4shift, Proj1x1 Q) {
@@ -193,20 +198,22 @@ __global__ __launch_bounds__(256) void gn_relu_upsample_sum_kernel(GnSum P, cons
 #pragma unroll
     for (int k = 0; k < N; ++k) {
         const GnTerm& T = P.t[k];
-        const f32x4* st = reinterpret_cast<const f32x4*>(T.stats + ((long)b * C + c) * 2);      // (mean, rstd) x 4 channels
-        st0[k] = st[0];
-        st1[k] = st[1];
-        const float* xb = T.x + (long)b * T.Hi * T.Wi * T.ld + c;
+        // (wave-uniform 64-bit bases + 32-bit per-lane element offsets: scalar base / vector offset addressing instead of a 64-bit
+        // multiply-add chain per tap; an image of a term stays below 2^31 elements - checked by the launcher)
+        const float* stb = T.stats + (long)b * C * 2;                 // (mean, rstd) x 4 channels
+        st0[k] = ld_quad(stb, (unsigned)(c * 2));
+        st1[k] = ld_quad(stb, (unsigned)(c * 2 + 4));
+        const float* xb = T.x + (long)b * T.Hi * T.Wi * T.ld;
         if ((SAME >> k) & 1) {
-            tap[k][0] = *reinterpret_cast<const f32x4*>(xb + ((long)oy * T.Wi + ox) * T.ld);
+            tap[k][0] = ld_quad(xb, (unsigned)((oy * T.Wi + ox) * T.ld + c));
         } else {
             int y0, y1, x0, x1;
             bilin_axis(oy, T.Hi, Ho, y0, y1, wy0[k], wy1[k]);
             bilin_axis(ox, T.Wi, Wo, x0, x1, wx0[k], wx1[k]);
-            tap[k][0] = *reinterpret_cast<const f32x4*>(xb + ((long)y0 * T.Wi + x0) * T.ld);
-            tap[k][1] = *reinterpret_cast<const f32x4*>(xb + ((long)y0 * T.Wi + x1) * T.ld);
-            tap[k][2] = *reinterpret_cast<const f32x4*>(xb + ((long)y1 * T.Wi + x0) * T.ld);
-            tap[k][3] = *reinterpret_cast<const f32x4*>(xb + ((long)y1 * T.Wi + x1) * T.ld);
+            tap[k][0] = ld_quad(xb, (unsigned)((y0 * T.Wi + x0) * T.ld + c));
+            tap[k][1] = ld_quad(xb, (unsigned)((y0 * T.Wi + x1) * T.ld + c));
+            tap[k][2] = ld_quad(xb, (unsigned)((y1 * T.Wi + x0) * T.ld + c));
+            tap[k][3] = ld_quad(xb, (unsigned)((y1 * T.Wi + x1) * T.ld + c));
         }
     }
     // ---- phase 2: arithmetic, term by term
@@ -265,7 +272,11 @@ __global__ __launch_bounds__(256) void gn_relu_upsample_sum_kernel(GnSum P, cons
             const bool upper = (lane & mask) != 0;
 #pragma unroll
             for (int jj = 0; jj < half; ++jj) {
-                const float send = upper ? part[jj] : part[jj + half], keep = upper ? part[jj + half] : part[jj];
+                // (two plain selects: left to itself the compiler turns them into `part[upper ? jj : jj + half]`, a run-time index it
+                // resolves with a compare + select per array element - ~200 of the kernel's 500 VALU instructions, profiles/README.md)
+                float lo = part[jj], hi = part[jj + half];
+                asm volatile("" : "+v"(lo), "+v"(hi));
+                const float send = upper ? lo : hi, keep = upper ? hi : lo;
                 part[jj] = keep + __shfl_xor(send, mask);
             }
         }
@@ -273,6 +284,95 @@ __global__ __launch_bounds__(256) void gn_relu_upsample_sum_kernel(GnSum P, cons
         const unsigned li = (unsigned)c >> 2;
         const int n = 4 * (int)(li & 1) + 2 * (int)((li >> 1) & 1) + (int)((li >> 2) & 1);
         if (li < 8 && n < Q.cout) Q.y1[(long)((b * Ho + oy) * Wo + ox) * Q.ldy1 + n] = part[0] + (Q.bias ? Q.bias[n] : 0.f);
+    }
+}
+
+// ----------------------------------------------------------------------------- one GN + ReLU + bilinear term, source staged in LDS
+// The one-term up-sampling call (s4 of the semantic branches: 256 channels, 144^2 -> 288^2, 0.68 GB written per 8 tiles) ran at 2.7 TB/s
+// in the kernel above against 5.8 TB/s for the same-size case: four 16-byte taps per output quad from the vector cache, each normalised
+// again by every output that touches it.  Here a workgroup owns UT_R x UT_C output pixels x all channels: the source block it needs
+// (<= UT_SR x UT_SC pixels for scales <= 1/2 + eps, checked by the launcher) is read ONCE, normalised + ReLU'd once per element and kept
+// in LDS; the outputs then blend four ds_read_b128 taps.  Same per-element arithmetic (lm_gn_relu, then lm_bilerp with lm_bilin_axis
+// weights) => same bits as gn_relu_upsample_kernel / gn_relu_upsample_sum_kernel<1, 0>.
+constexpr int UT_R = 8, UT_C = 16;
+
+__global__ __launch_bounds__(256) void gn_relu_up_lds_kernel(GnTerm T, const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                             float* __restrict__ y, int Ho, int Wo, int C, int SR, int SC) {
+    extern __shared__ __attribute__((aligned(16))) float ups[];       // [SR * SC][C] normalised source block
+    __shared__ int ty0[UT_R], ty1[UT_R], tx0[UT_C], tx1[UT_C];        // taps (relative to the block origin) and weights of the tile's rows / columns
+    __shared__ float twy0[UT_R], twy1[UT_R], twx0[UT_C], twx1[UT_C];
+    const int tid = threadIdx.x, c4n = C / 4;
+    const int oy0 = blockIdx.y * UT_R, ox0 = blockIdx.x * UT_C, b = blockIdx.z;
+    const int ny = min(UT_R, Ho - oy0), nx = min(UT_C, Wo - ox0);
+    int sy0, sx0, i1;
+    float w0, w1;
+    bilin_axis(oy0, T.Hi, Ho, sy0, i1, w0, w1);                       // block origin = first tap of the first row / column
+    bilin_axis(ox0, T.Wi, Wo, sx0, i1, w0, w1);
+    if (tid < UT_R) {
+        int a0, a1;
+        bilin_axis(min(oy0 + tid, Ho - 1), T.Hi, Ho, a0, a1, w0, w1);
+        ty0[tid] = a0 - sy0; ty1[tid] = a1 - sy0; twy0[tid] = w0; twy1[tid] = w1;
+    } else if (tid >= 64 && tid < 64 + UT_C) {
+        const int t = tid - 64;
+        int a0, a1;
+        bilin_axis(min(ox0 + t, Wo - 1), T.Wi, Wo, a0, a1, w0, w1);
+        tx0[t] = a0 - sx0; tx1[t] = a1 - sx0; twx0[t] = w0; twx1[t] = w1;
+    }
+    // ---- phase 1: source block -> LDS.  256 % (C/4) == 0: a thread keeps one channel quad and walks the pixels
+    const int cq = tid % c4n, pstep = 256 / c4n, p0 = tid / c4n;
+    const int c = cq * 4;
+    f32x4 a, g;
+    {
+        const f32x4 gm = *reinterpret_cast<const f32x4*>(gamma + c), bt = *reinterpret_cast<const f32x4*>(beta + c);
+        const f32x4* st = reinterpret_cast<const f32x4*>(T.stats + ((long)b * C + c) * 2);      // (mean, rstd) x 4 channels
+        const f32x4 st0 = st[0], st1 = st[1];
+        const float mean[4] = {st0[0], st0[2], st1[0], st1[2]}, rstd[4] = {st0[1], st0[3], st1[1], st1[3]};
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            float ae, ge;
+            lm_gn_affine(mean[e], rstd[e], gm[e], bt[e], ae, ge);
+            a[e] = ae;
+            g[e] = ge;
+        }
+    }
+    const int nsrc = SR * SC;
+    const float* xb = T.x + (long)b * T.Hi * T.Wi * T.ld + c;
+    constexpr int UNR = 4;                                             // loads in flight per thread and round
+    for (int pb = p0; pb < nsrc; pb += pstep * UNR) {
+        f32x4 v[UNR];
+#pragma unroll
+        for (int u = 0; u < UNR; ++u) {
+            const int pp = pb + u * pstep;
+            const int r = pp / SC, q = pp - r * SC;
+            const int yy = min(sy0 + r, T.Hi - 1), xx = min(sx0 + q, T.Wi - 1);     // (clamped: rows / columns past the image are never blended)
+            if (pp < nsrc) v[u] = *reinterpret_cast<const f32x4*>(xb + ((long)yy * T.Wi + xx) * T.ld);
+        }
+#pragma unroll
+        for (int u = 0; u < UNR; ++u) {
+            const int pp = pb + u * pstep;
+            if (pp < nsrc) {
+                f32x4 o;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) o[e] = lm_gn_relu(v[u][e], a[e], g[e]);
+                *reinterpret_cast<f32x4*>(ups + (long)pp * C + c) = o;
+            }
+        }
+    }
+    __syncthreads();
+    // ---- phase 2: outputs
+    const long obase = ((long)b * Ho + oy0) * Wo + ox0;
+    for (int pp = p0; pp < UT_R * UT_C; pp += pstep) {
+        const int r = pp / UT_C, q = pp % UT_C;
+        if (r >= ny || q >= nx) continue;
+        const float* s0 = ups + (long)(ty0[r] * SC) * C + c;
+        const float* s1 = ups + (long)(ty1[r] * SC) * C + c;
+        const f32x4 v00 = *reinterpret_cast<const f32x4*>(s0 + tx0[q] * C), v01 = *reinterpret_cast<const f32x4*>(s0 + tx1[q] * C);
+        const f32x4 v10 = *reinterpret_cast<const f32x4*>(s1 + tx0[q] * C), v11 = *reinterpret_cast<const f32x4*>(s1 + tx1[q] * C);
+        const float wy0 = twy0[r], wy1 = twy1[r], wx0 = twx0[q], wx1 = twx1[q];
+        f32x4 o;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) o[e] = lm_bilerp(v00[e], v01[e], v10[e], v11[e], wy0, wy1, wx0, wx1);
+        __builtin_nontemporal_store(o, reinterpret_cast<f32x4*>(y + (obase + (long)r * Wo + q) * C + c));
     }
 }
 
@@ -459,6 +559,25 @@ LM_API int lm_gn_relu_upsample(void* stream, const float* x, const float* stats,
 }
 
 namespace {
+// Source rows (columns) the tiles of `tile` output rows need at most: last second tap - first first tap + 1, from the SAME float
+// arithmetic as lm_bilin_axis (IEEE single precision on both sides, no contraction), so the kernel's LDS block is exactly large enough.
+int up_block_extent(int in, int out, int tile) {
+#pragma clang fp contract(off)
+    const float scale = (out > 1) ? (float)(in - 1) / (float)(out - 1) : 0.f;
+    auto tap0 = [&](int o) {
+        int i0 = (int)(scale * (float)o);
+        return i0 > in - 1 ? in - 1 : i0;
+    };
+    int ext = 1;
+    for (int o0 = 0; o0 < out; o0 += tile) {
+        const int ol = (o0 + tile - 1 < out ? o0 + tile - 1 : out - 1);
+        const int last0 = tap0(ol), last1 = last0 + (last0 < in - 1 ? 1 : 0);
+        const int e = last1 - tap0(o0) + 1;
+        if (e > ext) ext = e;
+    }
+    return ext;
+}
+
 int launch_gn_sum(void* stream, int n, const float* const* x, const float* const* stats, const int* Hi, const int* Wi, const int* ldx,
                   const float* gamma, const float* beta, float* y, int B, int Ho, int Wo, int C, Proj1x1 Q) {
     LM_REQUIRE(n >= 1 && n <= 3 && x && stats && Hi && Wi && gamma && beta && C > 0 && C % 4 == 0, "gn_relu_upsample_sum: bad args");
@@ -471,6 +590,8 @@ int launch_gn_sum(void* stream, int n, const float* const* x, const float* const
         LM_REQUIRE(x[q] && stats[q] && Hi[q] > 0 && Wi[q] > 0, "gn_relu_upsample_sum: bad term %d", q);
         const int ld = ldx ? ldx[q] : C;
         LM_REQUIRE(ld >= C && ld % 4 == 0, "gn_relu_upsample_sum: bad leading dimension %d of term %d", ld, q);
+        LM_REQUIRE((long)Hi[q] * Wi[q] * ld < (1L << 30), "gn_relu_upsample_sum: term %d: an image of %ld elements does not fit 32-bit byte offsets", q,
+                   (long)Hi[q] * Wi[q] * ld);
         P.t[k] = GnTerm{x[q], stats[q], Hi[q], Wi[q], ld};
     }
     const int c4n = C / 4;
@@ -482,6 +603,19 @@ int launch_gn_sum(void* stream, int n, const float* const* x, const float* const
     int same = 0;
     for (int k = 0; k < n; ++k)
         if (Hi[k] == Ho && Wi[k] == Wo) same |= 1 << k;
+    if (n == 1 && same == 0 && !Q.w && y && 256 % c4n == 0 && Hi[0] > 1 && Wi[0] > 1 && Ho >= 2 * Hi[0] - 1 && Wo >= 2 * Wi[0] - 1) {
+        // one up-sampling term (scale <= 1/2): source block staged in LDS
+        static const bool lds_up = [] { const char* e = getenv("LM_GN_UP_LDS"); return !e || atoi(e) != 0; }();
+        const int SR = up_block_extent(Hi[0], Ho, UT_R), SC = up_block_extent(Wi[0], Wo, UT_C);
+        const size_t lds = (size_t)SR * SC * C * sizeof(float);
+        if (lds_up && lds <= 72 * 1024) {
+            if (int e = lm_ensure_dynamic_lds((const void*)gn_relu_up_lds_kernel, lds)) return e;
+            hipLaunchKernelGGL(gn_relu_up_lds_kernel, dim3((unsigned)lm_cdiv(Wo, UT_C), (unsigned)lm_cdiv(Ho, UT_R), (unsigned)B), dim3(256), lds,
+                               (hipStream_t)stream, P.t[0], gamma, beta, y, Ho, Wo, C, SR, SC);
+            LM_LAUNCH_CHECK();
+            return LM_OK;
+        }
+    }
     const dim3 grid((unsigned)lm_cdiv((long)Wo * c4n, 256), (unsigned)Ho, (unsigned)B);
 #define LM_GNS(NN, SS)                                                                                                           \
     case (NN) * 8 + (SS):                                                                                                        \

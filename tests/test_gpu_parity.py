@@ -13,6 +13,7 @@ import cases
 from lanemapping_amd import synth
 
 pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def _close(a, ref, tol=1e-4, name=''):
@@ -164,6 +165,54 @@ def test_gn_relu_upsample_sum(dev):
     y2 = ops.gn_relu_upsample_sum(terms[:2], gd, bd, (40, 56))
     _close(y2, ref - F.interpolate(F.relu(F.group_norm(xs[2], 64, gamma, beta, 1e-5)), size=(40, 56), mode='bilinear', align_corners=True),
            1e-5, 'sum of 2 terms')
+
+
+@pytest.mark.parametrize('B,C,hi,wi,ho,wo,ld', [(2, 256, 36, 36, 72, 72, 256), (1, 128, 37, 21, 75, 50, 128), (2, 64, 20, 28, 56, 57, 96),
+                                                 (1, 256, 144, 144, 288, 288, 384), (2, 32, 9, 5, 40, 56, 32)])
+def test_gn_relu_upsample_one_term_lds_block(dev, B, C, hi, wi, ho, wo, ld):
+    """The one-term up-sampling call (gn_relu_up_lds_kernel: source block normalised once and staged in LDS) against the per-output
+    kernel of lm_gn_relu_upsample, bit for bit: ragged tiles (Ho % 8, Wo % 16 != 0), channel slices of a wider tensor (ld > C), scales
+    below 1/2, and the s4 shape of the semantic branches."""
+    from lanemapping_amd import ops
+    g = torch.Generator().manual_seed(B * 1000 + C + hi)
+    wide = (torch.randn(B, hi, wi, ld, generator=g) * 2 + 0.3).to(dev)
+    x = wide[..., ld - C:].permute(0, 3, 1, 2)                    # NHWC-stored channel slice, [B,C,H,W] view
+    dense = x.contiguous(memory_format=torch.channels_last)
+    st = ops.gn_stats(dense)
+    gamma, beta = (torch.rand(C, generator=g) + 0.5).to(dev), torch.randn(C, generator=g).to(dev)
+    want = ops.gn_relu_upsample(dense, st, gamma, beta, (ho, wo))
+    got = ops.gn_relu_upsample_sum([(x, st)], gamma, beta, (ho, wo))
+    assert torch.equal(got, want), float((got - want).abs().max())
+    ref = F.interpolate(F.relu(F.group_norm(dense.float(), C, gamma, beta, 1e-5)), size=(ho, wo), mode='bilinear', align_corners=True)
+    _close(got, ref, 1e-5, 'one term, LDS block')
+
+
+@pytest.mark.parametrize('cin,cout,B,h,w,mode', [(64, 256, 2, 72, 72, 'up'), (128, 256, 1, 36, 40, 'up'), (64, 128, 2, 40, 24, 'res'),
+                                                 (64, 200, 1, 33, 17, 'up'), (256, 256, 1, 36, 36, 'up'), (64, 256, 1, 24, 24, 'rows')])
+def test_conv1x1_lateral_residuals(dev, cin, cout, B, h, w, mode):
+    """1x1 convolutions of the FPN's lateral layers (tiny-K 64 x 64 tiles of conv_mfma_kernel): bilinear `_upsample_add` residual, plain
+    residual and a row-periodic one, against torch in fp64."""
+    from lanemapping_amd import ops
+    g = torch.Generator().manual_seed(cin + cout + h)
+    x = torch.randn(B, cin, h, w, generator=g)
+    wt = torch.randn(cout, cin, 1, 1, generator=g) / cin ** 0.5
+    bias = torch.randn(cout, generator=g)
+    ref = F.conv2d(x.double(), wt.double(), bias.double())
+    xd = ops.to_nhwc(x.to(dev)) if hasattr(ops, 'to_nhwc') else x.to(dev).contiguous(memory_format=torch.channels_last)
+    wp = ops.pack_mfma(wt.to(dev))
+    if mode == 'up':
+        coarse = torch.randn(B, cout, (h + 1) // 2, (w + 1) // 2, generator=g)
+        ref = ref + F.interpolate(coarse.double(), size=(h, w), mode='bilinear', align_corners=True)
+        y = ops.conv_mfma(xd, wp, cout, shift=bias.to(dev), res_up=coarse.to(dev).contiguous(memory_format=torch.channels_last))
+    elif mode == 'res':
+        r = torch.randn(B, cout, h, w, generator=g)
+        ref = F.relu(ref + r.double())
+        y = ops.conv_mfma(xd, wp, cout, shift=bias.to(dev), res=r.to(dev).contiguous(memory_format=torch.channels_last), act=ops.ACT_RELU)
+    else:
+        r = torch.randn(h * w, cout, generator=g)                 # one residual row per pixel of an image, shared by the batch
+        ref = ref + r.double().t().reshape(1, cout, h, w)
+        y = ops.conv_mfma(xd, wp, cout, shift=bias.to(dev), res=r.to(dev), res_rows=h * w)
+    _close(y, ref.float(), 2e-5, f'1x1 {cin}->{cout} {mode}')
 
 
 # ----------------------------------------------------------------------------------------------- goldens
