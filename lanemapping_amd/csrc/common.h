@@ -47,9 +47,10 @@ enum { LM_ACT_NONE = 0, LM_ACT_RELU = 1, LM_ACT_GELU = 2 };
 // operators and do not prevent that), explicit fmaf where a fused multiply-add is wanted.  The same bits in every kernel that uses
 // them (norm_resize.hip, the fused Winograd input transform, the bilinear residual of the convolution epilogue).
 // Source index follows ATen: scale = (in-1)/(out-1) in fp32, src = scale*dst, i0 = floor(src), i1 = min(i0+1, in-1), w1 = src - i0.
-__device__ __forceinline__ void lm_bilin_axis(int o, int in, int out, int& i0, int& i1, float& w0, float& w1) {
+// (lm_bilin_axis_scaled: the same with the scale computed once by the caller - on the host the IEEE single-precision quotient is the
+// same float, hipcc divides correctly rounded by default)
+__device__ __forceinline__ void lm_bilin_axis_scaled(int o, int in, float scale, int& i0, int& i1, float& w0, float& w1) {
 #pragma clang fp contract(off)
-    const float scale = (out > 1) ? (float)(in - 1) / (float)(out - 1) : 0.f;
     const float src = scale * (float)o;
     i0 = (int)src;
     if (i0 > in - 1) i0 = in - 1;
@@ -57,6 +58,28 @@ __device__ __forceinline__ void lm_bilin_axis(int o, int in, int out, int& i0, i
     w1 = fminf(fmaxf(src - (float)i0, 0.f), 1.f);
     w0 = 1.f - w1;
 }
+__device__ __forceinline__ void lm_bilin_axis(int o, int in, int out, int& i0, int& i1, float& w0, float& w1) {
+#pragma clang fp contract(off)
+    const float scale = (out > 1) ? (float)(in - 1) / (float)(out - 1) : 0.f;
+    lm_bilin_axis_scaled(o, in, scale, i0, i1, w0, w1);
+}
+#endif
+// Division of n < 2^31 by an invariant divisor d >= 1 (Granlund & Montgomery, round-up variant): q = (mulhi(n, mul) + n) >> sh with
+// sh = ceil(log2 d), mul = floor(2^32 (2^sh - d) / d) + 1; the sum stays below 2^32 for n < 2^31.  3 VALU instructions instead of the
+// ~25 of a 32-bit (or ~60 of a 64-bit) division by a run-time value.
+struct LmFastDiv {
+    unsigned d, mul, sh;
+};
+static inline LmFastDiv lm_fastdiv_make(unsigned d) {
+    LmFastDiv f;
+    f.d = d;
+    f.sh = 0;
+    while ((1ull << f.sh) < d) ++f.sh;
+    f.mul = (unsigned)((((1ull << f.sh) - d) << 32) / d + 1);
+    return f;
+}
+#ifdef __HIPCC__
+__device__ __forceinline__ unsigned lm_fastdiv(unsigned n, const LmFastDiv& f) { return (__umulhi(n, f.mul) + n) >> f.sh; }
 __device__ __forceinline__ void lm_gn_affine(float mean, float rstd, float gamma, float beta, float& a, float& g) {
 #pragma clang fp contract(off)
     a = rstd * gamma;                        // gn(v) = v * a + g

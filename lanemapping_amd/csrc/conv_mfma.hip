@@ -43,6 +43,8 @@ struct ConvParams {
     double* gn_part;   // optional [B][chunks][Cout][2] per-channel (sum, sum of squares) of the outputs of each wave tile
     int gn_chunks;     // chunks per batch element = (Ho*Wo / BM) * (BM / WM)
     int res_hi, res_wi; // > 0: `res` is a coarse [B][res_hi][res_wi][ldr] map added through bilinear (align_corners) interpolation
+    float res_sy, res_sx;   // its source scales (res_hi - 1) / (Ho - 1), (res_wi - 1) / (Wo - 1): lm_bilin_axis's quotient, taken on the host
+    LmFastDiv div_wo, div_ho, div_rr;   // output pixel -> (b, oy, ox) and m % res_rows without run-time divisions (M < 2^31)
 };
 
 __device__ __forceinline__ float gelu_erf(float v) { return 0.5f * v * (1.0f + erff(v * 0.70710678118654752440f)); }
@@ -95,10 +97,12 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64) void conv_mfma_kernel(C
             a_ix0[i] = 0;
             a_off[i] = m < p.M ? (int)m : -1;   // output row; its input rows come from the rulebook
         } else if (m < p.M) {
-            int ox = (int)(m % p.Wo);
-            long t = m / p.Wo;
-            int oy = (int)(t % p.Ho);
-            int b = (int)(t / p.Ho);
+            // (set-up and epilogue index math is what bounds the tiny-K layers: two 64-bit divisions per row cost ~300 VALU instructions
+            // in front of 32 MFMAs - profiles/README.md, round 4)
+            const unsigned t = lm_fastdiv((unsigned)m, p.div_wo);
+            const int ox = (int)((unsigned)m - t * p.div_wo.d);
+            const int b = (int)lm_fastdiv(t, p.div_ho);
+            const int oy = (int)(t - (unsigned)b * p.div_ho.d);
             a_iy0[i] = oy * p.stride - p.pad_h;
             a_ix0[i] = ox * p.stride - p.pad_w;
             a_off[i] = ((b * p.H + a_iy0[i]) * p.W + a_ix0[i]) * p.ldx + lc4;
@@ -254,19 +258,21 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64) void conv_mfma_kernel(C
                     gq[e] = fmaf(v[e], v[e], gq[e]);
                 }
             }
-            const long rrow = p.res_rows ? (m % p.res_rows) : m;
+            const long rrow = p.res_rows ? (long)((unsigned)m - lm_fastdiv((unsigned)m, p.div_rr) * p.div_rr.d) : m;
             if (vec) {
                 if (p.res && p.res_hi) {
                     // residual = F.interpolate(coarse, size=(Ho, Wo), bilinear, align_corners=True)[m]: `_upsample_add` of the FPN
                     // (postprojector.py:549-561) without materialising the upsampled map; same fixed-order blend as
                     // lm_upsample_bilinear_nhwc (common.h), so the sum is bit-identical to adding that kernel's output
                     const unsigned mm = (unsigned)m;
-                    const int ox = (int)(mm % (unsigned)p.Wo), q = (int)(mm / (unsigned)p.Wo);
-                    const int oy = q % p.Ho, bi = q / p.Ho;
+                    const unsigned q = lm_fastdiv(mm, p.div_wo);
+                    const int ox = (int)(mm - q * p.div_wo.d);
+                    const int bi = (int)lm_fastdiv(q, p.div_ho);
+                    const int oy = (int)(q - (unsigned)bi * p.div_ho.d);
                     int y0, y1, x0, x1;
                     float wy0, wy1, wx0, wx1;
-                    lm_bilin_axis(oy, p.res_hi, p.Ho, y0, y1, wy0, wy1);
-                    lm_bilin_axis(ox, p.res_wi, p.Wo, x0, x1, wx0, wx1);
+                    lm_bilin_axis_scaled(oy, p.res_hi, p.res_sy, y0, y1, wy0, wy1);
+                    lm_bilin_axis_scaled(ox, p.res_wi, p.res_sx, x0, x1, wx0, wx1);
                     const float* rb = p.res + (long)bi * p.res_hi * p.res_wi * p.ldr + n;
                     const f32x4 r00 = *reinterpret_cast<const f32x4*>(rb + ((long)y0 * p.res_wi + x0) * p.ldr);
                     const f32x4 r01 = *reinterpret_cast<const f32x4*>(rb + ((long)y0 * p.res_wi + x1) * p.ldr);
@@ -369,6 +375,12 @@ static int conv_dispatch(void* stream, const float* x, int ldx, const float* wp,
     p.gn_chunks = 0;
     p.nbr = nullptr;
     p.taps_real = 0;
+    LM_REQUIRE(p.M < (1L << 31) && res_rows >= 0, "conv_mfma: %ld output pixels do not fit 32-bit indices", p.M);
+    p.div_wo = lm_fastdiv_make((unsigned)p.Wo);
+    p.div_ho = lm_fastdiv_make((unsigned)p.Ho);
+    p.div_rr = lm_fastdiv_make((unsigned)(res_rows > 0 ? res_rows : 1));
+    p.res_sy = (res_hi > 0 && p.Ho > 1) ? (float)(res_hi - 1) / (float)(p.Ho - 1) : 0.f;
+    p.res_sx = (res_wi > 0 && p.Wo > 1) ? (float)(res_wi - 1) / (float)(p.Wo - 1) : 0.f;
     if (int e = zero_block(&p.zero)) return e;
     hipStream_t s = (hipStream_t)stream;
     if (gn_part) {   // statistics mode: 128x128 tiles of 64-row wave tiles, images must be whole numbers of tiles
@@ -456,6 +468,8 @@ LM_API int lm_conv_gather_mfma_f32(void* stream, const float* x, int ldx, const 
     LM_REQUIRE(M < (1L << 31) && (long)slabs * CoutP * p.Cin < (1L << 31), "conv_gather: problem too large (M=%ld)", M);
     p.gn_part = nullptr;
     p.gn_chunks = 0;
+    p.div_wo = p.div_ho = p.div_rr = lm_fastdiv_make(1);
+    p.res_sy = p.res_sx = 0.f;
     p.nbr = nbr;
     p.taps_real = taps;
     if (int e = zero_block(&p.zero)) return e;
