@@ -7,6 +7,8 @@
 //                            (heads/polyline_fpn_vit_vertex_2.py:183-189,232-237,249)
 #include "common.h"
 
+#include <type_traits>
+
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 namespace {
@@ -68,6 +70,151 @@ __global__ __launch_bounds__(256) void stem_kernel(const void* __restrict__ xin,
             for (int e = 0; e < 4; ++e) o[e] = fmaxf(acc[4 * q + e] * scale[4 * q + e] + shift[4 * q + e], 0.f);
             out[q] = o;
         }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// The same stem on the matrix cores (round 4).  The VALU kernel above reads 256 B of weights per (tap, channel) and wave through the
+// scalar cache and waits for them in front of every 32 packed FMAs: it runs at ~0.55 of the packed-fp32 peak (the scalar cache is shared
+// by neighbouring CUs).  v_mfma_f32_32x32x2_f32 has the same peak and takes both operands from LDS with lane-linear ds_read_b32: the
+// weights sit there in fragment order (39 KB, staged once per persistent workgroup), the pixels in the channel-interleaved patch.
+//   k'' = ky * 22 + (kx * 3 + c): the 21 (kx, c) of a patch row are consecutive floats of the channel-interleaved LDS patch, index 21 is a
+//   pad with zero weight (fma(x, 0, acc) = acc exactly), so the two k of an MFMA (lanes 0-31 / 32-63) are always NEIGHBOURS in LDS: the
+//   lane's base address carries the + 1, every read is base + immediate.  K'' = 154 -> 77 k pairs.
+// The accumulation is the same fmaf chain in the same (ky, kx, c) order as the VALU kernel (the MFMA adds its two products in k order):
+// bit-identical outputs (test_stem_mfma_bit_identical_to_valu).  Persistent workgroups (weights loaded once), two per CU.
+// ---------------------------------------------------------------------------------------------
+constexpr int SMW = 112;            // floats per patch row: 37 pixels x 3 channels + 1 pad
+constexpr int SMJ = 77;             // k pairs
+typedef float f32x16s __attribute__((ext_vector_type(16)));
+
+template <bool U8>
+__global__ __launch_bounds__(256, 2) void stem_mfma_kernel(const void* __restrict__ xin, const float* __restrict__ w,
+                                                           const float* __restrict__ scale, const float* __restrict__ shift,
+                                                           float* __restrict__ y, int H, int W, int Ho, int Wo, LmFastDiv div_tx, LmFastDiv div_ty,
+                                                           int ntiles) {
+    __shared__ float in[SP * SMW];
+    __shared__ float wl[SMJ * 2 * 64];                             // B operands in fragment order [k pair][channel block][lane]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int l32 = lane & 31, half = lane >> 5;
+    // weights: B operand of k pair j and channel block nb, lane l = w''[2 j + l / 32][32 nb + l % 32]; staged once per (persistent) workgroup
+    for (int i = tid; i < SMJ * 2 * 64; i += 256) {
+        const int j = i >> 7, nb = (i >> 6) & 1, l = i & 63;
+        const int ky = (2 * j) / 22, idx = (2 * j) % 22 + (l >> 5);
+        wl[i] = idx == 21 ? 0.f : w[(ky * 21 + idx) * 64 + nb * 32 + (l & 31)];
+    }
+    float sc[2], sh[2];
+#pragma unroll
+    for (int nb = 0; nb < 2; ++nb) {
+        sc[nb] = scale[nb * 32 + l32];
+        sh[nb] = shift[nb * 32 + l32];
+    }
+    // this lane's pixels: M block mb of the wave = tile rows 4 wave + 2 mb, + 1; pixel l32 of it = (row l32 / 16, column l32 % 16)
+    int abase[2];
+#pragma unroll
+    for (int mb = 0; mb < 2; ++mb) abase[mb] = (2 * (4 * wave + 2 * mb + (l32 >> 4))) * SMW + (2 * (l32 & 15)) * 3 + half;
+    // patch staging: element k of this thread is patch cell i = tid + 256 k = (row r, column q, channel c), the same for every tile:
+    // source offset relative to the tile's first patch pixel and (r, q) for the bounds are made once
+    constexpr int NST = (SP * SMW + 255) / 256;
+    int poff[NST], prq[NST];
+#pragma unroll
+    for (int k = 0; k < NST; ++k) {
+        const int i = tid + k * 256;
+        const int r = i / SMW, e = i - r * SMW;
+        const int q = e / 3, c = e - q * 3;
+        const bool cell = i < SP * SMW && q < SP;                  // (the pad column and the tail of the last round hold zeros)
+        poff[k] = U8 ? (r * W + q) * 3 + c : c * H * W + r * W + q;
+        prq[k] = cell ? (r << 16) | q : -1;
+    }
+    auto tile_origin = [&](int t, int& b, int& oy0, int& ox0) {
+        const unsigned row = lm_fastdiv((unsigned)t, div_tx);       // tile row over the whole batch
+        b = (int)lm_fastdiv(row, div_ty);
+        oy0 = (int)(row - (unsigned)b * div_ty.d) * ST;
+        ox0 = (int)((unsigned)t - row * div_tx.d) * ST;
+    };
+    unsigned raw[NST], okmask = 0;                                 // loaded values, untouched until they are written to LDS: a conversion
+    auto fetch = [&](int t) {                                      // or select right behind the load would put the wait in front of the MFMAs
+        int b, oy0, ox0;
+        tile_origin(t, b, oy0, ox0);
+        const int iy0 = oy0 * 2 - 3, ix0 = ox0 * 2 - 3;
+        const long base = U8 ? (((long)b * H + iy0) * W + ix0) * 3 : ((long)b * 3 * H + iy0) * W + ix0;
+        okmask = 0;
+#pragma unroll
+        for (int k = 0; k < NST; ++k) {
+            // (unconditional load from a clamped address, select later: a load under a branch makes the compiler wait at the join)
+            const int r = prq[k] >> 16, q = prq[k] & 0xffff;
+            const bool ok = (prq[k] >= 0) & ((unsigned)(iy0 + r) < (unsigned)H) & ((unsigned)(ix0 + q) < (unsigned)W);
+            okmask |= ok ? 1u << k : 0u;
+            const long src = ok ? base + poff[k] : 0;
+            if (U8) raw[k] = static_cast<const unsigned char*>(xin)[src];
+            else raw[k] = static_cast<const unsigned*>(xin)[src];
+        }
+    };
+    int t = blockIdx.x;
+    if (t < ntiles) fetch(t);
+    for (; t < ntiles; t += gridDim.x) {
+        int b, oy0, ox0;
+        tile_origin(t, b, oy0, ox0);
+        __syncthreads();                                           // the previous tile's reads are done
+#pragma unroll
+        for (int k = 0; k < NST; ++k) {
+            const int i = tid + k * 256;
+            const float val = U8 ? (float)raw[k] / 255.0f : __uint_as_float(raw[k]);
+            if (i < SP * SMW) in[i] = (okmask >> k) & 1u ? val : 0.f;
+        }
+        __syncthreads();
+        if (t + (int)gridDim.x < ntiles) fetch(t + gridDim.x);     // the next tile's patch travels under this tile's MFMAs
+        f32x16s acc[2][2];
+#pragma unroll
+        for (int mb = 0; mb < 2; ++mb)
+#pragma unroll
+            for (int nb = 0; nb < 2; ++nb)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[mb][nb][r] = 0.f;
+        // operands of k pair j + 1 are read from LDS BEFORE the four MFMAs of pair j are issued (the compiler left to itself reads them right
+        // in front of their use and waits ~2 LDS round trips per 16 MFMAs)
+        float av[2][2], wv[2][2];
+        auto rd = [&](int j, float (&a)[2], float (&wq)[2]) {
+            const int koff = ((2 * j) / 22) * SMW + (2 * j) % 22;
+#pragma unroll
+            for (int mb = 0; mb < 2; ++mb) a[mb] = in[abase[mb] + koff];
+#pragma unroll
+            for (int nb = 0; nb < 2; ++nb) wq[nb] = wl[(j * 2 + nb) * 64 + lane];
+        };
+        rd(0, av[0], wv[0]);
+#pragma unroll
+        for (int j = 0; j < SMJ; ++j) {
+            if (j + 1 < SMJ) rd(j + 1, av[(j + 1) & 1], wv[(j + 1) & 1]);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int mb = 0; mb < 2; ++mb)
+#pragma unroll
+                for (int nb = 0; nb < 2; ++nb)
+                    acc[mb][nb] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[j & 1][mb], wv[j & 1][nb], acc[mb][nb], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        // accumulator register r of (mb, nb): pixel (r % 4) + 8 (r / 4) + 4 half of the M block, channel 32 nb + l32, i.e. tile row
+        // 4 wave + 2 mb + (r >> 3), tile column (r & 3) + 8 ((r >> 2) & 1) + 4 half.  Wave-uniform base + 32-bit lane offset; tiles inside
+        // the image (all but the last row / column of tiles) store without per-element bounds
+        float* const yt = y + (((long)b * Ho + oy0) * Wo + ox0) * 64;
+        const unsigned lbyte = (unsigned)((4 * wave * Wo + 4 * half) * 64 + l32) << 2;
+        auto store_tile = [&](auto guarded) {
+#pragma unroll
+            for (int mb = 0; mb < 2; ++mb)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int ry = 2 * mb + (r >> 3), cx = (r & 3) + 8 * ((r >> 2) & 1);
+                    // (wave-uniform row pointer + this lane's 32-bit byte offset: scalar base / vector offset stores, no address VALU)
+                    char* const rowp = reinterpret_cast<char*>(yt) + (long)((ry * Wo + cx) * 64) * 4;
+                    if (!decltype(guarded)::value || (oy0 + 4 * wave + ry < Ho && ox0 + cx + 4 * half < Wo)) {
+#pragma unroll
+                        for (int nb = 0; nb < 2; ++nb)
+                            *reinterpret_cast<float*>(rowp + nb * 128 + lbyte) = fmaxf(acc[mb][nb][r] * sc[nb] + sh[nb], 0.f);
+                    }
+                }
+        };
+        if (oy0 + ST <= Ho && ox0 + ST <= Wo) store_tile(std::false_type{});      // (wave-uniform: one branch per tile, straight-line stores)
+        else store_tile(std::true_type{});
     }
 }
 
@@ -155,16 +302,32 @@ __global__ __launch_bounds__(256) void small_conv_kernel(SmallConvParams p) {
     }
 }
 
+template <bool U8>
+int launch_stem(void* stream, const void* x, const float* w_k64, const float* scale, const float* shift, float* y, int B, int H, int W, int Ho,
+                int Wo) {
+    // LM_STEM_VALU=1: the VALU kernel (one workgroup per 16 x 16 tile); default: the MFMA kernel, persistent workgroups
+    static const bool valu = [] { const char* e = getenv("LM_STEM_VALU"); return e && atoi(e) != 0; }();
+    const int tx = lm_cdiv(Wo, ST), ty = lm_cdiv(Ho, ST);
+    if (valu) {
+        hipLaunchKernelGGL(stem_kernel<U8>, dim3(tx, ty, B), dim3(256), 0, (hipStream_t)stream, x, w_k64, scale, shift, y, H, W, Ho, Wo);
+    } else {
+        const long ntiles = (long)tx * ty * B;
+        LM_REQUIRE(ntiles < (1L << 31), "stem: too many tiles");
+        const int grid = (int)(ntiles < 512 ? ntiles : 512);          // two resident workgroups per CU
+        hipLaunchKernelGGL(stem_mfma_kernel<U8>, dim3(grid), dim3(256), 0, (hipStream_t)stream, x, w_k64, scale, shift, y, H, W, Ho, Wo,
+                           lm_fastdiv_make((unsigned)tx), lm_fastdiv_make((unsigned)ty), (int)ntiles);
+    }
+    LM_LAUNCH_CHECK();
+    return LM_OK;
+}
+
 }  // namespace
 
 LM_API int lm_stem_conv7x7_bn_relu(void* stream, const float* x_chw, const float* w_k64, const float* scale,
                                    const float* shift, float* y_nhwc, int B, int H, int W) {
     LM_REQUIRE(x_chw && w_k64 && scale && shift && y_nhwc, "stem: null pointer");
     const int Ho = (H + 6 - 7) / 2 + 1, Wo = (W + 6 - 7) / 2 + 1;
-    dim3 grid(lm_cdiv(Wo, ST), lm_cdiv(Ho, ST), B);
-    hipLaunchKernelGGL(stem_kernel<false>, grid, dim3(256), 0, (hipStream_t)stream, (const void*)x_chw, w_k64, scale, shift, y_nhwc, H, W, Ho, Wo);
-    LM_LAUNCH_CHECK();
-    return LM_OK;
+    return launch_stem<false>(stream, (const void*)x_chw, w_k64, scale, shift, y_nhwc, B, H, W, Ho, Wo);
 }
 
 // the same stem on a u8 HWC tile [B][H][W][3] (x = u8 / 255 applied on the fly): bit-identical to lm_tile_ingest_u8 + the f32 stem
@@ -172,10 +335,7 @@ LM_API int lm_stem_conv7x7_bn_relu_u8(void* stream, const unsigned char* x_hwc3,
                                       const float* shift, float* y_nhwc, int B, int H, int W) {
     LM_REQUIRE(x_hwc3 && w_k64 && scale && shift && y_nhwc, "stem_u8: null pointer");
     const int Ho = (H + 6 - 7) / 2 + 1, Wo = (W + 6 - 7) / 2 + 1;
-    dim3 grid(lm_cdiv(Wo, ST), lm_cdiv(Ho, ST), B);
-    hipLaunchKernelGGL(stem_kernel<true>, grid, dim3(256), 0, (hipStream_t)stream, (const void*)x_hwc3, w_k64, scale, shift, y_nhwc, H, W, Ho, Wo);
-    LM_LAUNCH_CHECK();
-    return LM_OK;
+    return launch_stem<true>(stream, (const void*)x_hwc3, w_k64, scale, shift, y_nhwc, B, H, W, Ho, Wo);
 }
 
 LM_API int lm_maxpool3x3s2_nhwc(void* stream, const float* x, float* y, int B, int H, int W, int C) {

@@ -215,6 +215,41 @@ def test_conv1x1_lateral_residuals(dev, cin, cout, B, h, w, mode):
     _close(y, ref.float(), 2e-5, f'1x1 {cin}->{cout} {mode}')
 
 
+_STEM_AB = r"""
+import sys, numpy as np, torch
+from lanemapping_amd import ops
+dev = torch.device('cuda:0')
+g = torch.Generator().manual_seed(77)
+w = (torch.randn(7, 7, 3, 64, generator=g) / 12).to(dev)
+s, sh = (torch.rand(64, generator=g) + 0.5).to(dev), torch.randn(64, generator=g).to(dev)
+out = {}
+for k, shape in enumerate([(2, 96, 96), (1, 130, 75), (3, 33, 200), (40, 64, 64)]):          # (40 tiles of 4 x 4 blocks: > 512 workgroups of work)
+    B, H, W = shape
+    u8 = torch.randint(0, 256, (B, H, W, 3), generator=g, dtype=torch.uint8).to(dev)
+    out[f'u8_{k}'] = ops.stem(u8, w, s, sh).permute(0, 2, 3, 1).cpu().numpy()
+    f32 = (u8.permute(0, 3, 1, 2).float() / 255.0 + 0.01 * torch.randn(B, 3, H, W, generator=g).to(dev)).contiguous()
+    out[f'f32_{k}'] = ops.stem(f32, w, s, sh).permute(0, 2, 3, 1).cpu().numpy()
+np.savez(sys.argv[1], **out)
+"""
+
+
+def test_stem_mfma_bit_identical_to_valu(dev, tmp_path):
+    """stem_mfma_kernel (7x7 s2 stem on v_mfma_f32_32x32x2_f32: weights resident in VGPRs, zero-weight pads so that the two k of an MFMA
+    are neighbours in LDS, persistent workgroups) against the VALU stem_kernel (LM_STEM_VALU=1, read once per process) on the same inputs,
+    bit for bit: u8 HWC and f32 planar tiles, ragged sizes, more tiles than resident workgroups."""
+    import subprocess
+    import sys
+    res = {}
+    for tag, env in (('mfma', {}), ('valu', {'LM_STEM_VALU': '1'})):
+        path = str(tmp_path / f'{tag}.npz')
+        subprocess.run([sys.executable, '-c', _STEM_AB, path], check=True, env={**os.environ, **env, 'PYTHONPATH': ROOT}, cwd=ROOT)
+        res[tag] = np.load(path)
+    for k in res['mfma'].files:
+        a, b = res['mfma'][k], res['valu'][k]
+        assert np.isfinite(a).all() and a.shape == b.shape
+        assert np.array_equal(a, b), (k, float(np.abs(a - b).max()))
+
+
 # ----------------------------------------------------------------------------------------------- goldens
 def test_fpn_golden_g2(dev, net, golden):
     g = golden('g2_fpn.npz')
