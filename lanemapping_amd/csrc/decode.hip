@@ -131,6 +131,7 @@ struct TopkParams {
     unsigned* cand_cnt;          // [B]
     unsigned long long* cand;    // [B][CAP]
     int H, W, clip, K;
+    LmFastDiv div_wc;            // flat crop index -> (row, column) without a run-time (64-bit) division per element
 };
 
 __device__ __forceinline__ unsigned score_key(float logit) {
@@ -142,21 +143,51 @@ __device__ __forceinline__ unsigned level_bin(unsigned key, int level) {
     return level == 0 ? (key >> 20) : (level == 1 ? ((key >> 10) & 1023u) : (key & 1023u));
 }
 
-// Walk hist level `lv` from the top bin down; returns the bin where the running count reaches `need`
-// and leaves in `need` what is still wanted inside that bin.
-__device__ void pick_bin(const unsigned* h, unsigned& need, unsigned& bin) {
-    unsigned acc = 0;
-    for (int b = NB - 1; b >= 0; --b) {
-        const unsigned c = h[b];
-        if (acc + c >= need) {
-            bin = (unsigned)b;
-            need -= acc;
-            return;
-        }
-        acc += c;
+// Walk hist level `lv` from the top bin down: the bin where the running count reaches `need`, and in `need` what is still wanted inside
+// that bin - by a whole workgroup (>= 256 threads; every thread gets the result): thread t < 256 owns bins 4t .. 4t+3, an LDS suffix
+// scan over the 256 four-bin sums finds the owner of the threshold bin.  (Rounds 1-3 walked the bins in one thread: up to 1024 dependent loads per
+// level, in EVERY workgroup of the later passes - pass 3, three levels, took 157 us per 16 tiles against 39 us for pass 0.)
+// tmp: 258 words of LDS.  Conventions of the walk: (NB - 1, 0) for need == 0 and (0, 0) when fewer than `need` keys exist.
+__device__ void pick_bin_block(const unsigned* h, unsigned& need, unsigned& bin, unsigned* tmp) {
+    const int t = threadIdx.x;
+    unsigned c[4] = {0u, 0u, 0u, 0u}, s = 0;
+    if (t < 256) {
+        const uint4 v = *reinterpret_cast<const uint4*>(h + 4 * t);
+        c[0] = v.x; c[1] = v.y; c[2] = v.z; c[3] = v.w;
+        s = v.x + v.y + v.z + v.w;
+        tmp[t] = s;
     }
-    bin = 0;
-    need = 0;
+    if (t == 0) {
+        tmp[256] = need == 0 ? (unsigned)(NB - 1) : 0u;
+        tmp[257] = 0u;
+    }
+    __syncthreads();
+    for (int off = 1; off < 256; off <<= 1) {                      // inclusive suffix sums: tmp[t] = keys in bins 4t .. NB-1
+        unsigned add = 0;
+        if (t + off < 256) add = tmp[t + off];
+        __syncthreads();
+        if (t < 256) tmp[t] += add;
+        __syncthreads();
+    }
+    if (t < 256 && need > 0) {
+        const unsigned incl = tmp[t], above = incl - s;
+        if (above < need && incl >= need) {                        // exactly one thread
+            unsigned acc = above;
+#pragma unroll
+            for (int k = 3; k >= 0; --k) {
+                if (acc + c[k] >= need) {
+                    tmp[256] = (unsigned)(4 * t + k);
+                    tmp[257] = need - acc;
+                    break;
+                }
+                acc += c[k];
+            }
+        }
+    }
+    __syncthreads();
+    bin = tmp[256];
+    need = tmp[257];
+    __syncthreads();
 }
 
 __global__ __launch_bounds__(256) void zero_u32_kernel(unsigned* __restrict__ p, long n) {
@@ -167,31 +198,30 @@ __global__ __launch_bounds__(256) void zero_u32_kernel(unsigned* __restrict__ p,
 template <int LEVEL>   // 0,1,2 = histogram passes; 3 = candidate compaction
 __global__ __launch_bounds__(256) void topk_pass_kernel(TopkParams p) {
     __shared__ unsigned lh[NB];
-    __shared__ unsigned sel[4];   // prefix bins of the previous levels + threshold info
+    __shared__ unsigned pb_tmp[258];
     const int b = blockIdx.y;
     const int Hc = p.H - 2 * p.clip, Wc = p.W - 2 * p.clip;
     const long n = (long)Hc * Wc;
     unsigned* hist = p.hist + (long)b * 3 * NB;
     if (LEVEL < 3)
         for (int i = threadIdx.x; i < NB; i += 256) lh[i] = 0;
-    if (threadIdx.x == 0) {
+    unsigned prefix = 0;     // key bits fixed by previous levels
+    bool take_ties = false;
+    {
         unsigned need = (unsigned)p.K, bin = 0;
+#pragma unroll
         for (int lv = 0; lv < LEVEL && lv < 3; ++lv) {
-            pick_bin(hist + lv * NB, need, bin);
-            sel[lv] = bin;
+            pick_bin_block(hist + lv * NB, need, bin, pb_tmp);
+            prefix |= bin << (20 - 10 * lv);
         }
         // LEVEL 3: `need` = how many keys EQUAL to the threshold T are still wanted, hist[2][bin] = how many exist.  If more exist
         // than are wanted, the ties are ranked by index in topk_ties_kernel (lowest flat index first) and this pass skips them
-        if (LEVEL == 3) sel[3] = (hist[2 * NB + bin] == need) ? 1u : 0u;
+        if (LEVEL == 3) take_ties = hist[2 * NB + bin] == need;
     }
     __syncthreads();
-    unsigned prefix = 0;     // key bits fixed by previous levels
-    if (LEVEL >= 1) prefix = sel[0] << 20;
-    if (LEVEL >= 2) prefix |= sel[1] << 10;
-    if (LEVEL >= 3) prefix |= sel[2];
     const float* lp = p.logit + (long)b * p.H * p.W;
     for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
-        const int y = (int)(i / Wc), x = (int)(i - (long)y * Wc);
+        const int y = (int)lm_fastdiv((unsigned)i, p.div_wc), x = (int)((unsigned)i - (unsigned)y * (unsigned)Wc);
         const unsigned key = score_key(lp[(long)(y + p.clip) * p.W + x + p.clip]);
         if (LEVEL == 0) {
             atomicAdd(&lh[key >> 20], 1u);
@@ -200,7 +230,7 @@ __global__ __launch_bounds__(256) void topk_pass_kernel(TopkParams p) {
         } else if (LEVEL == 2) {
             if ((key >> 10) == (prefix >> 10)) atomicAdd(&lh[key & 1023u], 1u);
         } else {
-            if (key > prefix || (key == prefix && sel[3])) {   // prefix == exact threshold key T; at most K candidates in total
+            if (key > prefix || (key == prefix && take_ties)) {   // prefix == exact threshold key T; at most K candidates in total
                 const unsigned slot = atomicAdd(p.cand_cnt + b, 1u);
                 if (slot < CAP) p.cand[(long)b * CAP + slot] = ((unsigned long long)key << 32) | (unsigned)(0xFFFFFFFFu - (unsigned)i);
             }
@@ -222,22 +252,17 @@ __global__ __launch_bounds__(1024) void topk_ties_kernel(TopkParams p) {
     __shared__ unsigned wave_tot[16];
     const int b = blockIdx.x;
     const unsigned* hist = p.hist + (long)b * 3 * NB;
-    if (threadIdx.x == 0) {
-        unsigned need = (unsigned)p.K, bin = 0, key = 0;
-        pick_bin(hist, need, bin);
-        key = bin << 20;
-        pick_bin(hist + NB, need, bin);
-        key |= bin << 10;
-        pick_bin(hist + 2 * NB, need, bin);
-        key |= bin;
-        sh[0] = key;
-        sh[1] = need;
-        sh[2] = hist[2 * NB + bin];
-        sh[3] = p.cand_cnt[b];                                  // candidates with key > T (pass 3 is complete)
+    __shared__ unsigned pb_tmp[258];
+    unsigned need = (unsigned)p.K, bin = 0, T = 0;
+#pragma unroll
+    for (int lv = 0; lv < 3; ++lv) {
+        pick_bin_block(hist + lv * NB, need, bin, pb_tmp);
+        T |= bin << (20 - 10 * lv);
     }
+    if (threadIdx.x == 0) sh[3] = p.cand_cnt[b];                // candidates with key > T (pass 3 is complete)
     __syncthreads();
-    const unsigned T = sh[0], need = sh[1], base = sh[3];
-    if (sh[2] == need || need == 0) return;
+    const unsigned base = sh[3];
+    if (hist[2 * NB + bin] == need || need == 0) return;
     const int Wc = p.W - 2 * p.clip;
     const long n = (long)(p.H - 2 * p.clip) * Wc;
     const float* lp = p.logit + (long)b * p.H * p.W;
@@ -247,7 +272,7 @@ __global__ __launch_bounds__(1024) void topk_ties_kernel(TopkParams p) {
         const long i = i0 + threadIdx.x;
         bool tie = false;
         if (i < n) {
-            const int y = (int)(i / Wc), x = (int)(i - (long)y * Wc);
+            const int y = (int)lm_fastdiv((unsigned)i, p.div_wc), x = (int)((unsigned)i - (unsigned)y * (unsigned)Wc);
             tie = score_key(lp[(long)(y + p.clip) * p.W + x + p.clip]) == T;
         }
         const unsigned long long m = __ballot(tie);
@@ -347,6 +372,8 @@ LM_API int lm_endp_topk(void* stream, const float* endp_logit, void* workspace, 
     p.cand_cnt = (unsigned*)(ws + (size_t)B * 3 * NB * sizeof(unsigned));
     p.cand = (unsigned long long*)(ws + (size_t)B * (3 * NB + 4) * sizeof(unsigned));
     p.H = H; p.W = W; p.clip = clip; p.K = K;
+    LM_REQUIRE(W > 2 * clip && H > 2 * clip && (long)(H - 2 * clip) * (W - 2 * clip) < (1L << 31), "endp_topk: bad crop (H=%d W=%d clip=%d)", H, W, clip);
+    p.div_wc = lm_fastdiv_make((unsigned)(W - 2 * clip));
     // (a kernel, not hipMemsetAsync: the call sits inside HIP-graph captures of the tile pipeline, and replays of a captured memset
     // node were observed to leave the histograms of the previous replay in place)
     const long zero_words = (long)B * (3 * NB + 4);

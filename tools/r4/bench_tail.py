@@ -57,3 +57,9 @@ ms_s = timed(lambda: ops.stem(t, w7, s, sh))
 c1 = ops.stem(t, w7, s, sh)
 ms_p = timed(lambda: ops.maxpool3x3s2(c1))
 print(f'stem (u8) B{B}: {ms_s:.3f} ms   max-pool: {ms_p:.3f} ms')
+
+# endpoint top-K (radix select over the cropped 1152^2 logit map)
+from lanemapping_amd import decode  # noqa: E402
+lg = torch.randn(B, 1, 1152, 1152, device=dev)
+ms = timed(lambda: ops.endp_topk(lg, decode.TOPK, decode.CLIP))
+print(f'endp_topk B{B}: {ms:.3f} ms')
