@@ -63,3 +63,9 @@ from lanemapping_amd import decode  # noqa: E402
 lg = torch.randn(B, 1, 1152, 1152, device=dev)
 ms = timed(lambda: ops.endp_topk(lg, decode.TOPK, decode.CLIP))
 print(f'endp_topk B{B}: {ms:.3f} ms')
+
+# head: proposal tokens (8 x 8 bilinear pooling of the segmentation map x the 16-channel row features)
+seg = torch.randn(B, 1, 288, 288, device=dev)
+rowf = ops.new_act(B, 16, 144, 144, dev).normal_()
+ms = timed(lambda: ops.head_tokens(seg, rowf, 72, 2, 4, -0.3))
+print(f'head_tokens B{B}: {ms:.3f} ms')
