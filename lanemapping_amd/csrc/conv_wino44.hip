@@ -237,6 +237,34 @@ struct W44Params {
 
 // packed fp32 pairs (two channels of a lane).  Plain asm (not volatile): the scheduler may move them, the arithmetic is fixed.
 // (the multiplier b is one of three wave-uniform constant pairs: an SGPR-pair operand - with a "v" constraint every use cost a v_mov_b64)
+#ifdef LM_W44_SCALAR_XF
+// experiment: the same operations as plain (unpacked) f32 VALU instructions, two per pair (MI355X_MICROARCH.md: packed f32 VALU beside MFMAs
+// costs ~11-13 cycles beyond its issue slot, plain v_fma_f32 / v_add_f32 are hidden fillers)
+__device__ __forceinline__ float sc_fma(float a, float b, float c) {
+    float r;
+    asm("v_fma_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "s"(b), "v"(c));
+    return r;
+}
+__device__ __forceinline__ float sc_fnma(float a, float b, float c) {
+    float r;
+    asm("v_fma_f32 %0, -%1, %2, %3" : "=v"(r) : "v"(a), "s"(b), "v"(c));
+    return r;
+}
+__device__ __forceinline__ float sc_add(float a, float b) {
+    float r;
+    asm("v_add_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+__device__ __forceinline__ float sc_sub(float a, float b) {
+    float r;
+    asm("v_sub_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+__device__ __forceinline__ f32x2 pk_fma(const f32x2 a, const f32x2 b, const f32x2 c) { return f32x2{sc_fma(a[0], b[0], c[0]), sc_fma(a[1], b[0], c[1])}; }
+__device__ __forceinline__ f32x2 pk_fnma(const f32x2 a, const f32x2 b, const f32x2 c) { return f32x2{sc_fnma(a[0], b[0], c[0]), sc_fnma(a[1], b[0], c[1])}; }
+__device__ __forceinline__ f32x2 pk_add(const f32x2 a, const f32x2 b) { return f32x2{sc_add(a[0], b[0]), sc_add(a[1], b[1])}; }
+__device__ __forceinline__ f32x2 pk_sub(const f32x2 a, const f32x2 b) { return f32x2{sc_sub(a[0], b[0]), sc_sub(a[1], b[1])}; }
+#else
 __device__ __forceinline__ f32x2 pk_fma(const f32x2 a, const f32x2 b, const f32x2 c) {          // a b + c
     f32x2 r;
     asm("v_pk_fma_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "s"(b), "v"(c));
@@ -257,6 +285,7 @@ __device__ __forceinline__ f32x2 pk_sub(const f32x2 a, const f32x2 b) {
     asm("v_pk_add_f32 %0, %1, %2 neg_lo:[0,1] neg_hi:[0,1]" : "=v"(r) : "v"(a), "v"(b));
     return r;
 }
+#endif
 
 struct W44K {
     f32x2 c2, c4, c5;
