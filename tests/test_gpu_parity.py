@@ -1900,7 +1900,7 @@ def test_detector_config5_headline_points_vs_oracle(dev):
 
 @pytest.mark.parametrize('switch', ['LANEMAP_WINO_F44=0', 'LANEMAP_WINO_F44=0 LANEMAP_WINO_IMPLICIT=0', 'LANEMAP_WINOGRAD=0', 'LANEMAP_GRAPHS=1',
                                     'LANEMAP_WINO_BF16X3=1', 'LANEMAP_WINO_F44=0 LANEMAP_WINO_DUAL=1',
-                                    'LANEMAP_WINO_F44=0 LANEMAP_WINO_IMPLICIT=0 LANEMAP_FUSE_UP_WINO=0', 'LANEMAP_MERGE_BRANCH_CONVS=0'])
+                                    'LANEMAP_WINO_F44=0 LANEMAP_WINO_IMPLICIT=0 LANEMAP_FUSE_UP_WINO=0', 'LANEMAP_MERGE_BRANCH_CONVS=0', 'LM_STEM_VALU=1 LM_GN_UP_LDS=0'])
 def test_goldens_under_every_advertised_switch(switch):
     """README's runtime switches are read once per process, so each non-default setting gets its own interpreter: the end-to-end
     goldens (G10: one full tile against the reference's outputs, margin-aware; G15: two stability-screened tiles whose final
