@@ -148,6 +148,7 @@ struct GnTerm {
     const float* x;
     const float* stats;
     int Hi, Wi, ld;      // ld: floats between pixels of x (>= C: a term may be a channel slice of a wider tensor)
+    float sy, sx;        // lm_bilin_axis's source scales (Hi - 1) / (Ho - 1), (Wi - 1) / (Wo - 1): the same IEEE quotients, taken on the host
 };
 struct GnSum {
     GnTerm t[3];
@@ -180,13 +181,10 @@ template <int N, int SAME>
 __global__ __launch_bounds__(256) void gn_relu_upsample_sum_kernel(GnSum P, const float* __restrict__ gamma, const float* __restrict__ beta,
                                                                    float* __restrict__ y, int Ho, int Wo, int C, int c4shift, Proj1x1 Q) {
     __shared__ __attribute__((aligned(16))) float wl[256 * 8];   // projection weights [C][8] (cout padded with zeros)
-    if (Q.w) {
-        for (int k = threadIdx.x; k < C * 8; k += 256) wl[k] = (k & 7) < Q.cout ? Q.w[(k >> 3) * 16 + (k & 7)] : 0.f;
-        __syncthreads();
-    }
     const unsigned c4n = (unsigned)C / 4;
-    const unsigned j = blockIdx.x * 256u + threadIdx.x;       // (column, channel quad) inside the output row
-    if (j >= (unsigned)Wo * c4n) return;                      // (a multiple of C/4: the lanes of a pixel leave together)
+    const unsigned j0 = blockIdx.x * 256u + threadIdx.x;      // (column, channel quad) inside the output row
+    const bool live = j0 < (unsigned)Wo * c4n;                // (a multiple of C/4: the lanes of a pixel are live together)
+    const unsigned j = live ? j0 : 0u;                        // (dead threads of the row's last workgroup load pixel 0 and store nothing)
     const int ox = c4shift >= 0 ? (int)(j >> c4shift) : (int)(j / c4n);
     const int c = (int)(j - (unsigned)ox * c4n) * 4;
     const int oy = (int)blockIdx.y, b = (int)blockIdx.z;
@@ -208,14 +206,21 @@ __global__ __launch_bounds__(256) void gn_relu_upsample_sum_kernel(GnSum P, cons
             tap[k][0] = ld_quad(xb, (unsigned)((oy * T.Wi + ox) * T.ld + c));
         } else {
             int y0, y1, x0, x1;
-            bilin_axis(oy, T.Hi, Ho, y0, y1, wy0[k], wy1[k]);
-            bilin_axis(ox, T.Wi, Wo, x0, x1, wx0[k], wx1[k]);
+            lm_bilin_axis_scaled(oy, T.Hi, T.sy, y0, y1, wy0[k], wy1[k]);
+            lm_bilin_axis_scaled(ox, T.Wi, T.sx, x0, x1, wx0[k], wx1[k]);
             tap[k][0] = ld_quad(xb, (unsigned)((y0 * T.Wi + x0) * T.ld + c));
             tap[k][1] = ld_quad(xb, (unsigned)((y0 * T.Wi + x1) * T.ld + c));
             tap[k][2] = ld_quad(xb, (unsigned)((y1 * T.Wi + x0) * T.ld + c));
             tap[k][3] = ld_quad(xb, (unsigned)((y1 * T.Wi + x1) * T.ld + c));
         }
     }
+    // the projection weights are staged BEHIND the taps' loads: in front of them (rounds 2-3) every workgroup paid two memory round
+    // trips in a row - weights, barrier, taps
+    if (Q.w) {
+        for (int k = threadIdx.x; k < C * 8; k += 256) wl[k] = (k & 7) < Q.cout ? Q.w[(k >> 3) * 16 + (k & 7)] : 0.f;
+        __syncthreads();
+    }
+    if (!live) return;
     // ---- phase 2: arithmetic, term by term
     f32x4 acc = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
@@ -306,16 +311,16 @@ __global__ __launch_bounds__(256) void gn_relu_up_lds_kernel(GnTerm T, const flo
     const int ny = min(UT_R, Ho - oy0), nx = min(UT_C, Wo - ox0);
     int sy0, sx0, i1;
     float w0, w1;
-    bilin_axis(oy0, T.Hi, Ho, sy0, i1, w0, w1);                       // block origin = first tap of the first row / column
-    bilin_axis(ox0, T.Wi, Wo, sx0, i1, w0, w1);
+    lm_bilin_axis_scaled(oy0, T.Hi, T.sy, sy0, i1, w0, w1);           // block origin = first tap of the first row / column
+    lm_bilin_axis_scaled(ox0, T.Wi, T.sx, sx0, i1, w0, w1);
     if (tid < UT_R) {
         int a0, a1;
-        bilin_axis(min(oy0 + tid, Ho - 1), T.Hi, Ho, a0, a1, w0, w1);
+        lm_bilin_axis_scaled(min(oy0 + tid, Ho - 1), T.Hi, T.sy, a0, a1, w0, w1);
         ty0[tid] = a0 - sy0; ty1[tid] = a1 - sy0; twy0[tid] = w0; twy1[tid] = w1;
     } else if (tid >= 64 && tid < 64 + UT_C) {
         const int t = tid - 64;
         int a0, a1;
-        bilin_axis(min(ox0 + t, Wo - 1), T.Wi, Wo, a0, a1, w0, w1);
+        lm_bilin_axis_scaled(min(ox0 + t, Wo - 1), T.Wi, T.sx, a0, a1, w0, w1);
         tx0[t] = a0 - sx0; tx1[t] = a1 - sx0; twx0[t] = w0; twx1[t] = w1;
     }
     // ---- phase 1: source block -> LDS.  256 % (C/4) == 0: a thread keeps one channel quad and walks the pixels
@@ -592,7 +597,8 @@ int launch_gn_sum(void* stream, int n, const float* const* x, const float* const
         LM_REQUIRE(ld >= C && ld % 4 == 0, "gn_relu_upsample_sum: bad leading dimension %d of term %d", ld, q);
         LM_REQUIRE((long)Hi[q] * Wi[q] * ld < (1L << 30), "gn_relu_upsample_sum: term %d: an image of %ld elements does not fit 32-bit byte offsets", q,
                    (long)Hi[q] * Wi[q] * ld);
-        P.t[k] = GnTerm{x[q], stats[q], Hi[q], Wi[q], ld};
+        P.t[k] = GnTerm{x[q], stats[q], Hi[q], Wi[q], ld, Ho > 1 ? (float)(Hi[q] - 1) / (float)(Ho - 1) : 0.f,
+                        Wo > 1 ? (float)(Wi[q] - 1) / (float)(Wo - 1) : 0.f};
     }
     const int c4n = C / 4;
     LM_REQUIRE(256 % c4n == 0 || !Q.w, "gn_relu_upsample_sum: the fused 1x1 projection needs C/4 = %d to divide 256", c4n);
