@@ -321,6 +321,110 @@ int launch_stem(void* stream, const void* x, const float* w_k64, const float* sc
     return LM_OK;
 }
 
+// ---------------------------------------------------------------------------------------------
+// 3x3 convolutions with 16 input channels and <= 16 output channels on the matrix cores (round 4): head_common_layers / orient of
+// ColumnProposal2 (heads/polyline_fpn_vit_vertex_2.py:183-189,232-237; 16 -> 16 @288^2 stride 1 and 2, 16 -> 8 @144^2).  The VALU kernel
+// above streams 1 KB of weights per tap and wave through the scalar cache and waits for every 16-byte input load: ~0.4 of the packed
+// rate.  Here: v_mfma_f32_16x16x4_f32, M = 16 pixels of an output row, N = 16 output channels, K = 4 input channels; the 36 weight
+// fragments of the 3 x 3 x 16 reduction stay in VGPRs (persistent workgroups), the input patch of a 16 x 16 output tile sits in LDS with
+// the channels of a pixel permuted (position 4 (c % 4) + c / 4) so that the four values a lane feeds into the four MFMAs of a tap - channels
+// h, 4 + h, 8 + h, 12 + h for k slot h = lane / 16 - are ONE ds_read_b128.  Same (tap, channel)-ascending fmaf chain per output as the VALU
+// kernel (padding taps add fma(0, w, acc) = acc): bit-identical (test_small_conv_mfma_bit_identical_to_valu).
+// ---------------------------------------------------------------------------------------------
+template <int STRIDE>
+__global__ __launch_bounds__(256) void small_conv3x3_mfma_kernel(SmallConvParams p, LmFastDiv div_tx, LmFastDiv div_ty, int ntiles) {
+    constexpr int R = 15 * STRIDE + 3;                                 // patch edge (pixels)
+    extern __shared__ __attribute__((aligned(16))) float patch[];       // [R][R][16 permuted channels]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int l16 = lane & 15, h = lane >> 4;
+    // weights: B operand of (tap, channel group j) = w[(tap * 16 + 4 j + h) * 16 + l16]
+    float wr[9][4];
+#pragma unroll
+    for (int t = 0; t < 9; ++t)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) wr[t][j] = p.w[(t * 16 + 4 * j + h) * 16 + l16];
+    float sc = 1.f, sh = 0.f;
+    const bool has_sc = p.scale != nullptr, has_sh = p.shift != nullptr;
+    if (has_sc && l16 < p.Cout) sc = p.scale[l16];
+    if (has_sh && l16 < p.Cout) sh = p.shift[l16];
+    for (int t = blockIdx.x; t < ntiles; t += gridDim.x) {
+        const unsigned trow = lm_fastdiv((unsigned)t, div_tx);
+        const int b = (int)lm_fastdiv(trow, div_ty);
+        const int oy0 = (int)(trow - (unsigned)b * div_ty.d) * 16, ox0 = (int)((unsigned)t - trow * div_tx.d) * 16;
+        const int iy0 = oy0 * STRIDE - 1, ix0 = ox0 * STRIDE - 1;
+        __syncthreads();                                               // the previous tile's reads are done
+        // patch: R * R pixels x 4 channel quads; quad g of a pixel (channels 4 g .. 4 g + 3) goes to positions g, 4 + g, 8 + g, 12 + g
+        constexpr int NCH = R * R * 4;
+        for (int i0 = 0; i0 < NCH; i0 += 256 * 4) {
+            f32x4 v[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int i = i0 + u * 256 + tid;
+                const int pix = i >> 2, g = i & 3;
+                const int r = pix / R, q = pix - r * R;
+                const int iy = iy0 + r, ix = ix0 + q;
+                // (unconditional load from a clamped address + select: a load under a branch is waited for at the join)
+                const bool ok = (i < NCH) & ((unsigned)iy < (unsigned)p.H) & ((unsigned)ix < (unsigned)p.W);
+                const long src = ok ? (((long)b * p.H + iy) * p.W + ix) * p.ldx + 4 * g : 0;
+                const f32x4 ld = *reinterpret_cast<const f32x4*>(p.x + src);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[u][e] = ok ? (p.pre_relu ? fmaxf(ld[e], 0.f) : ld[e]) : 0.f;
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int i = i0 + u * 256 + tid;
+                if (i < NCH) {
+                    float* d = patch + (i >> 2) * 16 + (i & 3);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) d[4 * e] = v[u][e];
+                }
+            }
+        }
+        __syncthreads();
+        // wave w: output rows 4 w .. 4 w + 3 of the tile, one 16-pixel M block each
+#pragma unroll
+        for (int mb = 0; mb < 4; ++mb) {
+            const int ry = 4 * wave + mb;
+            f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int tp = 0; tp < 9; ++tp) {
+                const int ky = tp / 3, kx = tp % 3;
+                const f32x4 a = *reinterpret_cast<const f32x4*>(patch + ((ry * STRIDE + ky) * R + l16 * STRIDE + kx) * 16 + 4 * h);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a[j], wr[tp][j], acc, 0, 0, 0);
+            }
+            // accumulator register r: pixel 4 h + r of the row, output channel l16
+            const int oy = oy0 + ry;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int ox = ox0 + 4 * h + r;
+                if (oy < p.Ho && ox < p.Wo && l16 < p.Cout) {
+                    float v = acc[r];
+                    if (has_sc) v *= sc;
+                    if (has_sh) v += sh;
+                    if (p.act == LM_ACT_RELU) v = fmaxf(v, 0.f);
+                    p.y[(((long)b * p.Ho + oy) * p.Wo + ox) * p.ldy + l16] = v;
+                }
+            }
+        }
+    }
+}
+
+template <int STRIDE>
+int launch_small_mfma(const SmallConvParams& p, hipStream_t stream) {
+    constexpr int R = 15 * STRIDE + 3;
+    const size_t lds = (size_t)R * R * 16 * sizeof(float);
+    if (int e = lm_ensure_dynamic_lds((const void*)small_conv3x3_mfma_kernel<STRIDE>, lds)) return e;
+    const int tx = lm_cdiv(p.Wo, 16), ty = lm_cdiv(p.Ho, 16);
+    const long ntiles = (long)tx * ty * p.B;
+    LM_REQUIRE(ntiles < (1L << 31), "small_conv: too many tiles");
+    const int grid = (int)(ntiles < 1024 ? ntiles : 1024);
+    hipLaunchKernelGGL(small_conv3x3_mfma_kernel<STRIDE>, dim3(grid), dim3(256), lds, stream, p, lm_fastdiv_make((unsigned)tx),
+                       lm_fastdiv_make((unsigned)ty), (int)ntiles);
+    LM_LAUNCH_CHECK();
+    return LM_OK;
+}
+
 }  // namespace
 
 LM_API int lm_stem_conv7x7_bn_relu(void* stream, const float* x_chw, const float* w_k64, const float* scale,
@@ -360,6 +464,11 @@ LM_API int lm_conv2d_nhwc_small(void* stream, const float* x, int ldx, const flo
     p.Ho = (H + 2 * pad_h - KH) / stride + 1;
     p.Wo = (W + 2 * pad_w - KW) / stride + 1;
     p.M = (long)B * p.Ho * p.Wo;
+    if (Cin == 16 && KH == 3 && KW == 3 && pad_h == 1 && pad_w == 1 && (stride == 1 || stride == 2) && act != LM_ACT_GELU) {
+        // LM_SMALL_CONV_VALU=1: the VALU kernel for these shapes too
+        static const bool valu = [] { const char* e = getenv("LM_SMALL_CONV_VALU"); return e && atoi(e) != 0; }();
+        if (!valu) return stride == 1 ? launch_small_mfma<1>(p, (hipStream_t)stream) : launch_small_mfma<2>(p, (hipStream_t)stream);
+    }
     hipLaunchKernelGGL(small_conv_kernel, dim3(lm_cdiv(p.M, 256)), dim3(256), 0, (hipStream_t)stream, p);
     LM_LAUNCH_CHECK();
     return LM_OK;

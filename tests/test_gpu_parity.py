@@ -250,6 +250,51 @@ def test_stem_mfma_bit_identical_to_valu(dev, tmp_path):
         assert np.array_equal(a, b), (k, float(np.abs(a - b).max()))
 
 
+_SMALL_AB = r"""
+import sys, numpy as np, torch
+from lanemapping_amd import ops
+dev = torch.device('cuda:0')
+g = torch.Generator().manual_seed(78)
+out = {}
+for k, (B, H, W, cout, stride, pre, act, ld) in enumerate([(2, 48, 48, 16, 1, False, ops.ACT_NONE, 16), (1, 50, 37, 16, 2, False, ops.ACT_RELU, 16),
+                                                          (3, 33, 70, 8, 1, True, ops.ACT_NONE, 16), (2, 144, 144, 5, 2, False, ops.ACT_NONE, 24),
+                                                          (24, 96, 96, 16, 1, False, ops.ACT_RELU, 16)]):
+    wide = torch.randn(B, H, W, ld, generator=g).to(dev)
+    x = wide[..., :16].permute(0, 3, 1, 2)                    # NHWC-stored, pixel stride ld
+    w = ops.pack_small((torch.randn(cout, 16, 3, 3, generator=g) / 12).to(dev))
+    sc = (torch.rand(cout, generator=g) + 0.5).to(dev) if k % 2 == 0 else None
+    sh = torch.randn(cout, generator=g).to(dev)
+    y = ops.conv_small(x, w, cout, 3, 3, stride, 1, scale=sc, shift=sh, pre_relu=pre, act=act)
+    out[f'y{k}'] = y.permute(0, 2, 3, 1).cpu().numpy()
+np.savez(sys.argv[1], **out)
+"""
+
+
+def test_small_conv_mfma_bit_identical_to_valu(dev, tmp_path):
+    """small_conv3x3_mfma_kernel (16-input-channel 3x3 convolutions of the head on v_mfma_f32_16x16x4_f32) against the VALU
+    small_conv_kernel (LM_SMALL_CONV_VALU=1, read once per process), bit for bit: strides 1 / 2, ragged sizes, Cout < 16, scale / shift,
+    pre-ReLU, ReLU, a channel slice of a wider tensor, more tiles than resident workgroups; and against torch."""
+    import subprocess
+    import sys
+    res = {}
+    for tag, env in (('mfma', {}), ('valu', {'LM_SMALL_CONV_VALU': '1'})):
+        path = str(tmp_path / f'{tag}.npz')
+        subprocess.run([sys.executable, '-c', _SMALL_AB, path], check=True, env={**os.environ, **env, 'PYTHONPATH': ROOT}, cwd=ROOT)
+        res[tag] = np.load(path)
+    for k in res['mfma'].files:
+        a, b = res['mfma'][k], res['valu'][k]
+        assert np.isfinite(a).all() and a.shape == b.shape
+        assert np.array_equal(a, b), (k, float(np.abs(a - b).max()))
+    from lanemapping_amd import ops
+    g = torch.Generator().manual_seed(5)
+    x = torch.randn(2, 16, 40, 56, generator=g)
+    w = torch.randn(16, 16, 3, 3, generator=g) / 12
+    bias = torch.randn(16, generator=g)
+    for stride in (1, 2):
+        y = ops.conv_small(x.to(dev), ops.pack_small(w.to(dev)), 16, 3, 3, stride, 1, shift=bias.to(dev))
+        _close(y, F.conv2d(x, w, bias, stride, 1), 1e-5, f'small conv 16->16 s{stride}')
+
+
 # ----------------------------------------------------------------------------------------------- goldens
 def test_fpn_golden_g2(dev, net, golden):
     g = golden('g2_fpn.npz')
@@ -1900,7 +1945,7 @@ def test_detector_config5_headline_points_vs_oracle(dev):
 
 @pytest.mark.parametrize('switch', ['LANEMAP_WINO_F44=0', 'LANEMAP_WINO_F44=0 LANEMAP_WINO_IMPLICIT=0', 'LANEMAP_WINOGRAD=0', 'LANEMAP_GRAPHS=1',
                                     'LANEMAP_WINO_BF16X3=1', 'LANEMAP_WINO_F44=0 LANEMAP_WINO_DUAL=1',
-                                    'LANEMAP_WINO_F44=0 LANEMAP_WINO_IMPLICIT=0 LANEMAP_FUSE_UP_WINO=0', 'LANEMAP_MERGE_BRANCH_CONVS=0', 'LM_STEM_VALU=1 LM_GN_UP_LDS=0'])
+                                    'LANEMAP_WINO_F44=0 LANEMAP_WINO_IMPLICIT=0 LANEMAP_FUSE_UP_WINO=0', 'LANEMAP_MERGE_BRANCH_CONVS=0', 'LM_STEM_VALU=1 LM_GN_UP_LDS=0 LM_SMALL_CONV_VALU=1'])
 def test_goldens_under_every_advertised_switch(switch):
     """README's runtime switches are read once per process, so each non-default setting gets its own interpreter: the end-to-end
     goldens (G10: one full tile against the reference's outputs, margin-aware; G15: two stability-screened tiles whose final

@@ -69,3 +69,11 @@ seg = torch.randn(B, 1, 288, 288, device=dev)
 rowf = ops.new_act(B, 16, 144, 144, dev).normal_()
 ms = timed(lambda: ops.head_tokens(seg, rowf, 72, 2, 4, -0.3))
 print(f'head_tokens B{B}: {ms:.3f} ms')
+
+# head convolutions: 16 -> 16 3x3 @288^2 stride 1 / 2, 16 -> 8 @144^2
+for hw, cout, stride in ((288, 16, 1), (288, 16, 2), (144, 8, 1)):
+    xi = ops.new_act(B, 16, hw, hw, dev).normal_()
+    w16 = ops.pack_small(torch.randn(cout, 16, 3, 3, device=dev) / 12)
+    bias = torch.randn(cout, device=dev)
+    ms = timed(lambda: ops.conv_small(xi, w16, cout, 3, 3, stride, 1, shift=bias))
+    print(f'small conv 16->{cout} 3x3 s{stride} @{hw} B{B}: {ms:.3f} ms')
