@@ -95,6 +95,8 @@ __global__ __launch_bounds__(256, 2) void stem_mfma_kernel(const void* __restric
                                                            int ntiles) {
     __shared__ float in[SP * SMW];
     __shared__ float wl[SMJ * 2 * 64];                             // B operands in fragment order [k pair][channel block][lane]
+    __shared__ float u8lut[256];                                   // u8 / 255 (the reference's to_tensor) as a table: the IEEE division costs ~10
+    u8lut[threadIdx.x] = (float)threadIdx.x / 255.0f;              // VALU instructions per element, and fp32 VALU time is MFMA time here
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int l32 = lane & 31, half = lane >> 5;
     // weights: B operand of k pair j and channel block nb, lane l = w''[2 j + l / 32][32 nb + l % 32]; staged once per (persistent) workgroup
@@ -159,7 +161,7 @@ __global__ __launch_bounds__(256, 2) void stem_mfma_kernel(const void* __restric
 #pragma unroll
         for (int k = 0; k < NST; ++k) {
             const int i = tid + k * 256;
-            const float val = U8 ? (float)raw[k] / 255.0f : __uint_as_float(raw[k]);
+            const float val = U8 ? u8lut[raw[k] & 255u] : __uint_as_float(raw[k]);
             if (i < SP * SMW) in[i] = (okmask >> k) & 1u ? val : 0.f;
         }
         __syncthreads();
