@@ -27,7 +27,49 @@ __device__ __forceinline__ void bilin_axis(int o, int in, int out, int& i0, int&
     w0 = 1.f - w1;
 }
 
+// 8 x 8 average of the bilinearly up-sampled (x 4 rows, x 4 columns) proposal window at token (h, w): `tap(y, x, ok)` returns the
+// segmentation value of source row y, window column x (ok: inside the un-padded map, else the conv bias).  ONE expression for both
+// kernels below, so the compiler forms the same multiply-adds in both: identical bits.
+template <typename Tap>
+__device__ __forceinline__ float pooled_window(int h, int w, int Hs, int Hr, int win, int col0, int Ws, float seg_bias, Tap tap) {
+    float sum = 0.f;
+    for (int r = 0; r < 8; ++r) {
+        int y0, y1;
+        float wy0, wy1;
+        bilin_axis(8 * h + r, Hs, 8 * Hr, y0, y1, wy0, wy1);
+        for (int q = 0; q < 8; ++q) {
+            int x0, x1;
+            float wx0, wx1;
+            bilin_axis(8 * w + q, win, 8 * FW, x0, x1, wx0, wx1);
+            const int c0 = col0 + x0, c1 = col0 + x1;
+            const bool ok0 = (unsigned)c0 < (unsigned)Ws, ok1 = (unsigned)c1 < (unsigned)Ws;
+            const float v00 = ok0 ? tap(y0, x0, c0) : seg_bias;
+            const float v01 = ok1 ? tap(y0, x1, c1) : seg_bias;
+            const float v10 = ok0 ? tap(y1, x0, c0) : seg_bias;
+            const float v11 = ok1 ? tap(y1, x1, c1) : seg_bias;
+            sum += wy0 * (wx0 * v00 + wx1 * v01) + wy1 * (wx0 * v10 + wx1 * v11);
+        }
+    }
+    return sum * (1.0f / 64.0f);
+}
+
+__device__ __forceinline__ void write_tokens(const float* __restrict__ row, float* __restrict__ tok, float pooled, int b, int p, int h, int w,
+                                             int P, int Hr, int Wr, int prop_width, int half_buff) {
+    const int rc = prop_width * p + w - half_buff;      // column in the un-padded row feature map
+    float* tr = tok + (((long)b * P + p) * Hr + h) * (NCH * FW) + w;
+    if ((unsigned)rc < (unsigned)Wr) {
+        const float* rp = row + (((long)b * Hr + h) * Wr + rc) * NCH;
+#pragma unroll
+        for (int c = 0; c < NCH; ++c) tr[c * FW] = pooled * rp[c];
+    } else {
+#pragma unroll
+        for (int c = 0; c < NCH; ++c) tr[c * FW] = pooled * 0.f;
+    }
+}
+
 // seg [B,Hs,Ws] (Hs=Ws=288), row [B,Hr,Wr,16] NHWC (Hr=Wr=144), tok [B*P*Hr, 160]
+// (rounds 1-3: one thread per token, its 256 taps gathered from global memory - the vector-memory path serves a 64-lane gather of
+// 4-byte elements at a fraction of its line rate: 0.275 ms per 16 tiles; kept behind LM_HEAD_TOKENS_GATHER=1)
 __global__ __launch_bounds__(256) void head_tokens_kernel(const float* __restrict__ seg, const float* __restrict__ row,
                                                           float* __restrict__ tok, float seg_bias, int P, int Hr, int Wr,
                                                           int prop_width, int half_buff, long total) {
@@ -43,35 +85,43 @@ __global__ __launch_bounds__(256) void head_tokens_kernel(const float* __restric
     const int win = 2 * FW;                             // 20 source columns per proposal
     const int col0 = 2 * prop_width * p - 2 * half_buff;   // first source column of the window (may be < 0)
     const float* sb = seg + (long)b * Hs * Ws;
-    float sum = 0.f;
-    for (int r = 0; r < 8; ++r) {
-        int y0, y1;
-        float wy0, wy1;
-        bilin_axis(8 * h + r, Hs, 8 * Hr, y0, y1, wy0, wy1);
-        for (int q = 0; q < 8; ++q) {
-            int x0, x1;
-            float wx0, wx1;
-            bilin_axis(8 * w + q, win, 8 * FW, x0, x1, wx0, wx1);
-            const int c0 = col0 + x0, c1 = col0 + x1;
-            const bool ok0 = (unsigned)c0 < (unsigned)Ws, ok1 = (unsigned)c1 < (unsigned)Ws;
-            const float v00 = ok0 ? sb[(long)y0 * Ws + c0] : seg_bias;
-            const float v01 = ok1 ? sb[(long)y0 * Ws + c1] : seg_bias;
-            const float v10 = ok0 ? sb[(long)y1 * Ws + c0] : seg_bias;
-            const float v11 = ok1 ? sb[(long)y1 * Ws + c1] : seg_bias;
-            sum += wy0 * (wx0 * v00 + wx1 * v01) + wy1 * (wx0 * v10 + wx1 * v11);
-        }
+    const float pooled = pooled_window(h, w, Hs, Hr, win, col0, Ws, seg_bias, [&](int y, int, int c) { return sb[(long)y * Ws + c]; });
+    write_tokens(row, tok, pooled, b, p, h, w, P, Hr, Wr, prop_width, half_buff);
+}
+
+// Round 4: one workgroup per (image, proposal, block of HT token rows); the source rows its tokens touch x the proposal's 20 window
+// columns are staged in LDS once (<= HT_ROWS x 20 floats), the 256 taps per token come from there.  Same expression, same order
+// (pooled_window): bit-identical to the gather kernel.
+constexpr int HT = 24;             // token rows per workgroup (x 10 window columns = 240 of 256 threads)
+constexpr int HT_ROWS = 64;        // source rows staged at most (24 token rows span 8 * 24 / 4 + 2 = 50)
+__global__ __launch_bounds__(256) void head_tokens_lds_kernel(const float* __restrict__ seg, const float* __restrict__ row,
+                                                              float* __restrict__ tok, float seg_bias, int P, int Hr, int Wr,
+                                                              int prop_width, int half_buff, int hblocks) {
+    __shared__ float win_s[HT_ROWS * 2 * FW];
+    const int tid = threadIdx.x;
+    const int hb = blockIdx.x % hblocks, bp = blockIdx.x / hblocks;
+    const int p = bp % P, b = bp / P;
+    const int Hs = 2 * Hr, Ws = 2 * Wr;
+    const int win = 2 * FW;
+    const int col0 = 2 * prop_width * p - 2 * half_buff;
+    const int h0 = hb * HT, h1 = min(h0 + HT, Hr);
+    int ya, yb, dummy;
+    float f0, f1;
+    bilin_axis(8 * h0, Hs, 8 * Hr, ya, dummy, f0, f1);                  // first source row of the block
+    bilin_axis(8 * (h1 - 1) + 7, Hs, 8 * Hr, dummy, yb, f0, f1);        // last one (second tap of the last output row)
+    const int nrows = yb - ya + 1;                                       // (the launcher checks the bound HT_ROWS)
+    const float* sb = seg + (long)b * Hs * Ws;
+    for (int i = tid; i < nrows * win; i += 256) {
+        const int r = i / win, x = i - r * win;
+        const int c = col0 + x;
+        win_s[i] = (unsigned)c < (unsigned)Ws ? sb[(long)(ya + r) * Ws + c] : seg_bias;
     }
-    const float pooled = sum * (1.0f / 64.0f);
-    const int rc = prop_width * p + w - half_buff;      // column in the un-padded row feature map
-    float* tr = tok + (((long)b * P + p) * Hr + h) * (NCH * FW) + w;
-    if ((unsigned)rc < (unsigned)Wr) {
-        const float* rp = row + (((long)b * Hr + h) * Wr + rc) * NCH;
-#pragma unroll
-        for (int c = 0; c < NCH; ++c) tr[c * FW] = pooled * rp[c];
-    } else {
-#pragma unroll
-        for (int c = 0; c < NCH; ++c) tr[c * FW] = pooled * 0.f;
-    }
+    __syncthreads();
+    const int hl = tid / FW, w = tid - hl * FW;
+    const int h = h0 + hl;
+    if (hl >= HT || h >= h1) return;
+    const float pooled = pooled_window(h, w, Hs, Hr, win, col0, Ws, seg_bias, [&](int y, int x, int) { return win_s[(y - ya) * win + x]; });
+    write_tokens(row, tok, pooled, b, p, h, w, P, Hr, Wr, prop_width, half_buff);
 }
 
 // hid [M, ldh] (ext | cls | off hidden, D each) -> ext2 [M,3], cls2 [M,10], off2 [M,10]
@@ -140,6 +190,16 @@ LM_API int lm_head_tokens(void* stream, const float* seg, const float* row_nhwc1
     LM_REQUIRE(seg && row_nhwc16 && tok, "head_tokens: null pointer");
     LM_REQUIRE(prop_width + 2 * half_buff == FW, "head_tokens: prop_fea_width must be %d", FW);
     const long total = (long)B * P * Hr * FW;
+    static const bool gather = [] { const char* e = getenv("LM_HEAD_TOKENS_GATHER"); return e && atoi(e) != 0; }();
+    const int hblocks = lm_cdiv(Hr, HT);
+    // source rows a block of HT token rows can touch: (8 HT - 1) * (2 Hr - 1) / (8 Hr - 1) + 3
+    const bool fits = (long)(8 * HT - 1) * (2 * Hr - 1) / (8 * Hr - 1) + 3 <= HT_ROWS && (long)B * P * hblocks < (1L << 31);
+    if (!gather && fits) {
+        hipLaunchKernelGGL(head_tokens_lds_kernel, dim3((unsigned)((long)B * P * hblocks)), dim3(256), 0, (hipStream_t)stream, seg, row_nhwc16, tok,
+                           seg_bias, P, Hr, Wr, prop_width, half_buff, hblocks);
+        LM_LAUNCH_CHECK();
+        return LM_OK;
+    }
     hipLaunchKernelGGL(head_tokens_kernel, dim3(lm_cdiv(total, 256)), dim3(256), 0, (hipStream_t)stream,
                        seg, row_nhwc16, tok, seg_bias, P, Hr, Wr, prop_width, half_buff, total);
     LM_LAUNCH_CHECK();
