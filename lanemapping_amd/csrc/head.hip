@@ -158,6 +158,66 @@ __global__ __launch_bounds__(256) void head_stage2_kernel(const float* __restric
     else stage2_rows<10>(hr, D, w2 + 13L * D, b2 + 13, off2 + m * 10);
 }
 
+// Round 4: the same rows through LDS.  In the kernel above a lane reads ITS row with 16-byte loads one row pitch (1.2 KB) apart from its
+// neighbours' - 64 cache lines per wave instruction - and the weights come 40 bytes at a time through the scalar cache: 0.19 ms per 16
+// tiles for 0.2 GB.  Here a workgroup of 128 threads stages its 128 rows x D floats of one branch with coalesced loads (row stride D + 1
+// in LDS: conflict-free 4-byte reads), then every thread walks its row: the same k-ascending fmaf chain, identical bits.
+constexpr int S2R = 128;
+template <int NOUT>
+__device__ __forceinline__ void stage2_rows_lds(const float* hl, int D, const float* __restrict__ w, const float* __restrict__ b,
+                                                float* __restrict__ out) {
+    float acc[NOUT];
+#pragma unroll
+    for (int n = 0; n < NOUT; ++n) acc[n] = 0.f;
+    for (int k = 0; k < D; k += 4) {
+        float v[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = hl[k + e];
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+#pragma unroll
+            for (int n = 0; n < NOUT; ++n) acc[n] = fmaf(v[e], w[n * D + k + e], acc[n]);
+    }
+#pragma unroll
+    for (int n = 0; n < NOUT; ++n) out[n] = acc[n] + b[n];
+}
+
+__global__ __launch_bounds__(S2R) void head_stage2_lds_kernel(const float* __restrict__ hid, int ldh, int D, const float* __restrict__ w2,
+                                                             const float* __restrict__ b2, float* __restrict__ ext2,
+                                                             float* __restrict__ cls2, float* __restrict__ off2, long M) {
+    extern __shared__ float rows_s[];                          // [S2R][D + 1]
+    const int tid = threadIdx.x;
+    const long m0 = (long)blockIdx.x * S2R;
+    const int br = blockIdx.y;
+    const int d4 = D / 4, nrow = (int)min((long)S2R, M - m0);
+    const float* hb = hid + m0 * ldh + br * D;
+    for (int i0 = 0; i0 < nrow * d4; i0 += S2R * 4) {          // 16-byte chunks, four in flight per thread
+        f32x4 v[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int i = min(i0 + u * S2R + tid, nrow * d4 - 1);
+            const int r = i / d4, c = i - r * d4;
+            v[u] = *reinterpret_cast<const f32x4*>(hb + (long)r * ldh + 4 * c);
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int i = i0 + u * S2R + tid;
+            if (i < nrow * d4) {
+                const int r = i / d4, c = i - r * d4;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) rows_s[r * (D + 1) + 4 * c + e] = v[u][e];
+            }
+        }
+    }
+    __syncthreads();
+    const long m = m0 + tid;
+    if (m >= M) return;
+    const float* hl = rows_s + tid * (D + 1);
+    if (br == 0) stage2_rows_lds<3>(hl, D, w2, b2, ext2 + m * 3);
+    else if (br == 1) stage2_rows_lds<10>(hl, D, w2 + 3L * D, b2 + 3, cls2 + m * 10);
+    else stage2_rows_lds<10>(hl, D, w2 + 13L * D, b2 + 13, off2 + m * 10);
+}
+
 // tok [B*P, L] (L = Hr*160, already in (h, cw) order), wt [2][L] -> conf [B*P, 2]
 __global__ __launch_bounds__(256) void head_conf_kernel(const float* __restrict__ tok, const float* __restrict__ wt,
                                                         const float* __restrict__ bias, float* __restrict__ conf, int L) {
@@ -210,6 +270,15 @@ LM_API int lm_head_stage2(void* stream, const float* hid, int ldh, int D, const 
                           float* ext2, float* cls2, float* off2, long M) {
     LM_REQUIRE(hid && w2 && b2 && ext2 && cls2 && off2, "head_stage2: null pointer");
     LM_REQUIRE(D % 4 == 0 && ldh % 4 == 0, "head_stage2: D=%d and ldh=%d must be multiples of 4", D, ldh);
+    static const bool direct = [] { const char* e = getenv("LM_HEAD_STAGE2_DIRECT"); return e && atoi(e) != 0; }();
+    const size_t lds = (size_t)S2R * (D + 1) * sizeof(float);
+    if (!direct && lds <= 64 * 1024 && M < (1L << 31)) {
+        if (int e = lm_ensure_dynamic_lds((const void*)head_stage2_lds_kernel, lds)) return e;
+        hipLaunchKernelGGL(head_stage2_lds_kernel, dim3(lm_cdiv(M, S2R), 3), dim3(S2R), lds, (hipStream_t)stream, hid, ldh, D, w2, b2, ext2, cls2,
+                           off2, M);
+        LM_LAUNCH_CHECK();
+        return LM_OK;
+    }
     hipLaunchKernelGGL(head_stage2_kernel, dim3(lm_cdiv(M, 256), 3), dim3(256), 0, (hipStream_t)stream,
                        hid, ldh, D, w2, b2, ext2, cls2, off2, M);
     LM_LAUNCH_CHECK();

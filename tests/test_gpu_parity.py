@@ -305,6 +305,12 @@ for k, (B, Hr, P) in enumerate([(2, 144, 72), (1, 40, 20), (3, 25, 12)]):       
     seg = torch.randn(B, 1, 2 * Hr, 2 * Hr, generator=g).to(dev)
     row = torch.randn(B, Hr, Hr, 16, generator=g).to(dev).permute(0, 3, 1, 2)
     out[f'tok{k}'] = ops.head_tokens(seg, row, P, 2, 4, -0.37).cpu().numpy()
+for k, (B, P, R, D, ld) in enumerate([(2, 72, 144, 100, 300), (1, 5, 37, 64, 200), (1, 3, 50, 104, 312)]):      # (M = 185: a ragged last block of rows)
+    hid = torch.randn(B * P * R, ld, generator=g).to(dev)
+    w2 = (torch.randn(23, D, generator=g) / 10).to(dev)
+    b2 = torch.randn(23, generator=g).to(dev)
+    for name, t in zip(('ext', 'cls', 'off'), ops.head_stage2(hid, D, w2, b2, B, P, R)):
+        out[f'{name}{k}'] = t.cpu().numpy()
 np.savez(sys.argv[1], **out)
 """
 
@@ -312,11 +318,12 @@ np.savez(sys.argv[1], **out)
 def test_head_tokens_lds_bit_identical_to_gather(dev, tmp_path):
     """head_tokens_lds_kernel (the proposal window's source rows staged in LDS, one workgroup per (image, proposal, 24 token rows)) against
     the one-thread-per-token gather kernel (LM_HEAD_TOKENS_GATHER=1, read once per process): the same expression in the same order, bit for
-    bit - the BASELINE shape, a small one and one with a ragged last block; proposals whose window leaves the map (conv-bias columns)."""
+    bit - the BASELINE shape, a small one and one with a ragged last block; proposals whose window leaves the map (conv-bias columns).
+    Also head_stage2_lds_kernel (rows staged through LDS with coalesced loads) against the one-row-per-lane kernel (LM_HEAD_STAGE2_DIRECT=1)."""
     import subprocess
     import sys
     res = {}
-    for tag, env in (('lds', {}), ('gather', {'LM_HEAD_TOKENS_GATHER': '1'})):
+    for tag, env in (('lds', {}), ('gather', {'LM_HEAD_TOKENS_GATHER': '1', 'LM_HEAD_STAGE2_DIRECT': '1'})):
         path = str(tmp_path / f'{tag}.npz')
         subprocess.run([sys.executable, '-c', _TOKENS_AB, path], check=True, env={**os.environ, **env, 'PYTHONPATH': ROOT}, cwd=ROOT)
         res[tag] = np.load(path)
@@ -1976,7 +1983,7 @@ def test_detector_config5_headline_points_vs_oracle(dev):
 
 @pytest.mark.parametrize('switch', ['LANEMAP_WINO_F44=0', 'LANEMAP_WINO_F44=0 LANEMAP_WINO_IMPLICIT=0', 'LANEMAP_WINOGRAD=0', 'LANEMAP_GRAPHS=1',
                                     'LANEMAP_WINO_BF16X3=1', 'LANEMAP_WINO_F44=0 LANEMAP_WINO_DUAL=1',
-                                    'LANEMAP_WINO_F44=0 LANEMAP_WINO_IMPLICIT=0 LANEMAP_FUSE_UP_WINO=0', 'LANEMAP_MERGE_BRANCH_CONVS=0', 'LM_STEM_VALU=1 LM_GN_UP_LDS=0 LM_SMALL_CONV_VALU=1 LM_HEAD_TOKENS_GATHER=1'])
+                                    'LANEMAP_WINO_F44=0 LANEMAP_WINO_IMPLICIT=0 LANEMAP_FUSE_UP_WINO=0', 'LANEMAP_MERGE_BRANCH_CONVS=0', 'LM_STEM_VALU=1 LM_GN_UP_LDS=0 LM_SMALL_CONV_VALU=1 LM_HEAD_TOKENS_GATHER=1 LM_HEAD_STAGE2_DIRECT=1'])
 def test_goldens_under_every_advertised_switch(switch):
     """README's runtime switches are read once per process, so each non-default setting gets its own interpreter: the end-to-end
     goldens (G10: one full tile against the reference's outputs, margin-aware; G15: two stability-screened tiles whose final

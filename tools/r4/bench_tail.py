@@ -77,3 +77,9 @@ for hw, cout, stride in ((288, 16, 1), (288, 16, 2), (144, 8, 1)):
     bias = torch.randn(cout, device=dev)
     ms = timed(lambda: ops.conv_small(xi, w16, cout, 3, 3, stride, 1, shift=bias))
     print(f'small conv 16->{cout} 3x3 s{stride} @{hw} B{B}: {ms:.3f} ms')
+
+# head: second Conv1d of ext2 / cls2 / offset2 on the hidden rows (M = B * 72 * 144 rows of 3 x 100 floats)
+hid = torch.randn(B * 72 * 144, 300, device=dev)
+w2, b2 = torch.randn(23, 100, device=dev) / 10, torch.randn(23, device=dev)
+ms = timed(lambda: ops.head_stage2(hid, 100, w2, b2, B, 72, 144))
+print(f'head_stage2 B{B}: {ms:.3f} ms')
