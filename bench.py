@@ -274,7 +274,7 @@ def main():
     pipe_eager = pipe if not args.graphs else TilePipeline(net, host_threads=args.host_threads, use_graph=False)
     # default streams per workload (measured with the round-4 kernels, 10-step runs on one box): fused (batch 16) 2 streams 362-363 tiles/s,
     # 4 streams 355-357, 3: 344, 1: 341; tiles (batch 8) 347-348 for 2 / 3 / 4; rowref 344 with 4, 331 with 2
-    nstream = max(1, args.streams if args.streams is not None else {'lidar': 1, 'fused': 2}.get(args.workload, 4))
+    nstream = max(1, args.streams if args.streams is not None else {'lidar': 1, 'fused': 2, 'tiles': 2}.get(args.workload, 4))
     nstream = min(nstream, batch)
     extra_streams = [torch.cuda.Stream(device=dev) for _ in range(nstream - 1)]
     extra_pipes = [TilePipeline(net, host_threads=args.host_threads, use_graph=args.graphs) for _ in range(nstream - 1)]
