@@ -138,7 +138,7 @@ def second_line(args):
     """The declared SECOND measurement (route b): the same workload, same steps, with the Winograd GEMMs on the bf16
     matrix cores through exact three-way operand splits (LANEMAP_WINO_BF16X3=1, csrc/conv_wino.hip wino_rows_split_kernel).  Its outputs
     are NOT bit-identical to the fp32 kernels (error of the class of an fp32 rounding; the integer decisions of the goldens are unchanged:
-    tests/test_gpu_parity.py test_goldens_under_every_advertised_switch), so it never replaces `value`: exact fp32 stays the headline.
+    tests/test_gpu_2_goldens.py test_goldens_under_every_advertised_switch), so it never replaces `value`: exact fp32 stays the headline.
     Run in a child process after the headline has been timed - the switch is read when the weights are packed."""
     import subprocess
     cmd = [sys.executable, os.path.join(ROOT, 'bench.py'), '--steps', str(args.steps), '--warmup', str(args.warmup), '--workload', args.workload,
@@ -195,8 +195,8 @@ def main():
                          "(pre-rasterised, batch 8); rowref = configs[3] (Proj28_GFC-T3_RowRef head, pre-rasterised, batch 8); lidar = "
                          "configs[4] (sparse-conv LiDAR encoder path, batch 8 point clouds, parity unpinned)")
     ap.add_argument('--streams', type=int, default=None,
-                    help='split every batch over this many HIP streams (fills launch tails); default 4 (fused: 2, lidar: 1) '
-                         '(its data-dependent launch sizes need host round trips, which serialise sub-batches)')
+                    help='split every batch over this many HIP streams (fills launch tails); default per workload: fused 2, tiles 2, '
+                         'rowref 4, lidar 1 (its data-dependent launch sizes need host round trips, which serialise sub-batches)')
     ap.add_argument('--conv-detail', action='store_true', help='per-shape table of the MFMA launches on stderr')
     ap.add_argument('--no-stream-check', action='store_true', help='skip the bitwise multi-stream == single-stream check')
     ap.add_argument('--graphs', action='store_true', help='replay the device part of every sub-batch as one HIP graph (TilePipeline use_graph)')
@@ -231,7 +231,7 @@ def main():
     if args.host_threads is None:
         args.host_threads = 8 if args.host_cores is None else max(1, host_cores_per_rank - 1)
     import torch.distributed as dist
-    # test hooks (tests/test_gpu_parity.py exercises the N>1 code path on a 1-GPU box): every rank on one device, gloo backend
+    # test hooks (tests/test_gpu_9_bench.py exercises the N>1 code path on a 1-GPU box): every rank on one device, gloo backend
     dev_index = int(os.environ.get('LANEMAP_BENCH_DEVICE', local_rank))
     backend = os.environ.get('LANEMAP_BENCH_BACKEND', 'nccl')
     if world > 1:

@@ -157,8 +157,9 @@ class Runner:
         ents = self._entries(mode_data, tiles)
         if tiles is not None:
             gt_avail = False                                     # an explicit tile list carries no labels
-        out_dir = work_dirs or self.cfg.work_dirs
-        os.makedirs(out_dir, exist_ok=True)
+        out_dir = work_dirs or self.cfg.get('work_dirs', './work_dirs')
+        if write_lane_vertex:
+            os.makedirs(out_dir, exist_ok=True)
         B = int(batch_size or self.cfg.get('batch_size', 8))
         dist = torch.distributed
         world = dist.get_world_size() if dist.is_initialized() else 1
