@@ -24,7 +24,6 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 MFMA_F32_PEAK_TFLOPS = 157.3      # /opt/skills/guides/MI355X_MICROARCH.md: dense fp32 MFMA peak
-BF16_PEAK_TFLOPS = 2500.0         # same guide: dense bf16 MFMA peak (only used for the opt-in split-precision kernel)
 HBM_PEAK_GBS = 8000.0             # same guide: HBM3E 8 TB/s
 BATCH = 8
 N_PTS = 4194304                   # points per tile of the fused workload
@@ -134,45 +133,6 @@ def host_budget(world, local_world, local_rank, cores_avail, allowed, host_cores
     return {'k': k, 'cores': mine, 'graphs': k <= 4 and not no_graphs and workload in ('fused', 'tiles', 'rowref'), 'auto': auto}
 
 
-def second_line(args):
-    """The declared SECOND measurement (route b): the same workload, same steps, with the Winograd GEMMs on the bf16
-    matrix cores through exact three-way operand splits (LANEMAP_WINO_BF16X3=1, csrc/conv_wino.hip wino_rows_split_kernel).  Its outputs
-    are NOT bit-identical to the fp32 kernels (error of the class of an fp32 rounding; the integer decisions of the goldens are unchanged:
-    tests/test_gpu_2_goldens.py test_goldens_under_every_advertised_switch), so it never replaces `value`: exact fp32 stays the headline.
-    Run in a child process after the headline has been timed - the switch is read when the weights are packed."""
-    import subprocess
-    cmd = [sys.executable, os.path.join(ROOT, 'bench.py'), '--steps', str(args.steps), '--warmup', str(args.warmup), '--workload', args.workload,
-           '--no-cpu-baseline', '--no-second-line']
-    if args.streams is not None:
-        cmd += ['--streams', str(args.streams)]
-    if args.host_cores is not None:
-        cmd += ['--host-cores', str(args.host_cores)]
-    if args.host_threads is not None:
-        cmd += ['--host-threads', str(args.host_threads)]
-    if getattr(args, 'graphs', False):
-        cmd += ['--graphs']                      # (the second line runs in the headline's launch mode)
-    if args.no_graphs:
-        cmd += ['--no-graphs']
-    try:
-        r = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=dict(os.environ, LANEMAP_WINO_BF16X3='1'))
-        lines = [l for l in r.stdout.split('\n') if l.startswith('{')]
-        if r.returncode != 0 or not lines:
-            return {'error': (r.stderr or r.stdout)[-400:]}
-        d = json.loads(lines[-1])
-    except (subprocess.TimeoutExpired, ValueError) as e:
-        return {'error': repr(e)[:400]}
-    roof = d.get('roofline') or {}
-    per = roof.get('per_kernel') or {}
-    return {'declared': 'opt-in LANEMAP_WINO_BF16X3=1: Winograd GEMMs as six bf16 MFMA products of exact three-way splits, fp32 accumulation; '
-                        'not bit-identical to the fp32 path, the headline `value` above is exact fp32',
-            'dtype': d.get('dtype'), 'metric': d.get('metric'), 'value': d.get('value'), 'unit': d.get('unit'), 'steps': d.get('steps'),
-            'warmup': d.get('warmup'), 'ms_per_step': d.get('ms_per_step'),
-            'winograd_ms_per_step': sum(v['ms_per_step'] for k, v in per.items() if k.startswith('wino')),
-            'roofline': {k: roof.get(k) for k in ('bound', 'kernel', 'achieved', 'peak', 'unit', 'frac', 'fp32_product_tflops', 'kernel_ms_per_step',
-                                                   'dominant_kernel', 'scope')},
-            'per_kernel': per}
-
-
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
@@ -180,10 +140,6 @@ def main():
     ap.add_argument('--warmup', type=int, default=3)
     ap.add_argument('--cpu-budget-s', type=float, default=25.0)
     ap.add_argument('--no-cpu-baseline', action='store_true')
-    ap.add_argument('--second-line', action='store_true',
-                    help='also run the declared second measurement (the same workload with LANEMAP_WINO_BF16X3=1, in a child process at N = 1). '
-                         'Off by default since round 4: the exact-fp32 F(4x4) headline is faster than the split-precision F(2x2) line')
-    ap.add_argument('--no-second-line', action='store_true', help='(accepted for older command lines: the second line is off unless --second-line)')
     ap.add_argument('--host-threads', type=int, default=None, help='post-processing pool threads per pipeline (default 8; max(1, K - 1) under --host-cores K)')
     ap.add_argument('--host-cores', type=int, default=None,
                     help='per-rank host budget: pin this process (rank r) to K of the cores it may use, cores [r*K, (r+1)*K), BEFORE any GPU call - '
@@ -487,13 +443,11 @@ def main():
         torch.cuda.synchronize()
         prof['on'] = False
 
-    # ---- aggregate per kernel class.  kind strings: 'wino_gemm ...', 'wino_input ...', 'conv ...', 'gemm ...', 'spconv ...'
+    # ---- aggregate per kernel class.  kind strings: 'wino44 ...', 'conv ...', 'gemm ...', 'spconv ...'
     def kclass(kind):
         k = kind.split(' ', 1)[0]
-        return {'wino_gemm': 'wino_gemm_kernel', 'wino_implicit': 'wino_implicit_kernel', 'wino_input': 'wino_input_kernel',
-                'wino_bf16x3': 'wino_rows_split_kernel<bf16x3>', 'wino44': 'wino44_kernel'}.get(k, 'conv_mfma_kernel')
-    # peak of the dtype a kernel class issues: exact-fp32 MFMA, or (opt-in LANEMAP_WINO_BF16X3=1) bf16 MFMA fed with 3-way split fp32 operands
-    peak_of = lambda c: BF16_PEAK_TFLOPS if 'bf16x3' in c else MFMA_F32_PEAK_TFLOPS
+        return {'wino44': 'wino44_kernel'}.get(k, 'conv_mfma_kernel')
+    peak_of = lambda c: MFMA_F32_PEAK_TFLOPS          # every MFMA launch of the path is exact fp32
     cls = {}
     per_kind = {}
     for a, b, kind, fl, ex in prof['pairs']:
@@ -529,9 +483,8 @@ def main():
     mfma_traffic = pmc.get('mfma_bytes_per_step')
     # the counters were collected on other kernel sources than the ones that ran (None: no counters were collected for this workload)
     traffic_stale = (pmc.get('csrc_sha16') != csrc_sha16()) if pmc else None
-    split_on = os.environ.get('LANEMAP_WINO_BF16X3', '0') != '0'
-    if split_on or os.environ.get('LANEMAP_WINO_F44', '1') == '0':
-        mfma_traffic, traffic_stale = None, None        # the counters were collected on the default kernels (fp32 F(4x4)), not on this run's
+    if os.environ.get('LANEMAP_WINO_F44', '1') == '0':
+        mfma_traffic, traffic_stale = None, None        # the counters were collected on the default kernels (F(4x4)), not on this run's
     n_lines = int(np.mean([(np.count_nonzero(l[:, :, 0] > 0, axis=1) >= 2).sum() for l, _ in last])) if last else 0
     what = {'tiles': 'pre-rasterised tile', 'fused': 'LAS points', 'lidar': 'LiDAR point cloud', 'rowref': 'pre-rasterised tile'}[args.workload]
     workload = {
@@ -559,14 +512,13 @@ def main():
                    max(1, sum(p_.host_tiles for p_ in [pipe] + extra_pipes))},
         'roofline': {'bound': 'mfma',
                      'kernel': 'every MFMA convolution / GEMM launch of a step (' + ', '.join(sorted(per_class)) + ')',
-                     # EXECUTED view: FLOPs the matrix cores really issue (Winograd F(4x4,3x3) launches: 36/144 of the direct count,
-                     # F(2x2,3x3) launches: 16/36)
-                     # / summed HIP-event time of those launches (the HBM-bound Winograd input transforms included)
+                     # EXECUTED view: FLOPs the matrix cores really issue (Winograd F(4x4,3x3) launches: 36/144 of the direct count)
+                     # / summed HIP-event time of those launches
                      'achieved': executed_tflops, 'peak': MFMA_F32_PEAK_TFLOPS, 'unit': 'TFLOP/s',
                      # time-weighted utilisation: sum_k (executed_k / peak_k) / sum_k t_k  (== achieved / peak when every launch is fp32 MFMA)
                      'frac': (sum(e[3] / peak_of(k) for k, e in cls.items()) / (conv_ms * 1e-3) / 1e12) if conv_ms > 0 else 0.0,
                      'traffic': mfma_traffic, 'traffic_source': pmc.get('source'), 'traffic_stale': traffic_stale,
-                     'algorithmic_equiv_tflops': alg_tflops,
+                     'algorithmic_equiv_tflops': alg_tflops, 'frac_survey_8d': alg_tflops / MFMA_F32_PEAK_TFLOPS,
                      'scope': roof_scope, 'launches_per_step': prof['launches'] / rs,
                      'executed_gflop_per_step': exe / rs / 1e9, 'algorithmic_gflop_per_step': alg / rs / 1e9,
                      'kernel_ms_per_step': conv_ms / rs,
@@ -574,33 +526,25 @@ def main():
                      'dominant_kernel': dominant, 'per_kernel': per_class,
                      'note': 'achieved / frac = executed MFMA FLOPs / launch time / fp32 MFMA peak (always <= 1). algorithmic_equiv_tflops = '
                              'direct-convolution FLOPs (SURVEY 8d: 2 per MAC of the 3x3 sums) / the same time: it exceeds the executed figure '
-                             'because Winograd F(4x4,3x3) does 36 multiplies where the direct sum does 144 (F(2x2,3x3): 16 for 36)'},
+                             'because Winograd F(4x4,3x3) does 36 multiplies where the direct sum does 144; frac_survey_8d = algorithmic_equiv_tflops / peak (SURVEY 8(d)\'s definition: it can exceed 1 for the same reason)'},
     }
     if args.workload == 'fused' and rast['pairs']:
         rms = sum(a.elapsed_time(b) for a, b in rast['pairs']) / len(rast['pairs'])
         algb = (16.0 * N_PTS + 3 * 1152 * 1152 * 4) * batch
         movedb = (16.0 * N_PTS + 3 * 1152 * 1152) * batch          # what this design has to move: the tile leaves as u8
         result['raster_roofline'] = {'bound': 'hbm', 'kernel': 'raster_partition_kernel + raster_band_kernel',
-                                     'achieved': algb / (rms * 1e-3) / 1e9, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
-                                     'frac': algb / (rms * 1e-3) / 1e9 / HBM_PEAK_GBS,
-                                     'frac_moved': movedb / (rms * 1e-3) / 1e9 / HBM_PEAK_GBS, 'moved_bytes_per_step': movedb,
+                                     # frac / achieved: the bytes THIS design has to move (16 B per point + the 3 x H x W u8 tile);
+                                     # frac_survey_8d: SURVEY 8(d)'s numerator (16 B per point + a 3 x H x W f32 tile that is never written)
+                                     'achieved': movedb / (rms * 1e-3) / 1e9, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
+                                     'frac': movedb / (rms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                                     'frac_survey_8d': algb / (rms * 1e-3) / 1e9 / HBM_PEAK_GBS, 'survey_8d_bytes_per_step': algb,
                                      'traffic': pmc.get('raster_bytes_per_step'), 'traffic_source': pmc.get('source'), 'traffic_stale': traffic_stale,
-                                     'algorithmic_bytes_per_step': algb, 'ms_per_step': rms,
+                                     'algorithmic_bytes_per_step': movedb, 'ms_per_step': rms,
                                      'scope': roof_scope + ('; each timed raster launch is queued behind an untimed one, so the event bracket holds GPU execution only' if (nstream > 1 or args.graphs) else ''),
-                                     'note': 'achieved = SURVEY 8(d) algorithmic bytes (16 B per point + the 3 x H x W f32 tile) / time; the tile is '
-                                             'physically emitted as u8 HWC (its information content, 1/4 of the bytes) because its only consumer, '
-                                             'the stem kernel, applies u8 / 255 itself (bit-identical); frac_moved = the honest numerator of this '
-                                             'design (16 B per point + the 3 x H x W u8 tile) / time / peak; traffic = what the counters saw'}
-    if split_on and dominant and 'bf16x3' in dominant:
-        # opt-in split-precision run: the headline object describes the dominant kernel in ITS arithmetic (six bf16 MFMA products per fp32
-        # product, priced against the dense bf16 peak); fp32_product_tflops = the fp32 products it stands for / the same time
-        d = per_class[dominant]
-        result['dtype'] = 'bf16x3'
-        result['roofline'].update({'achieved': d['executed_tflops'], 'peak': d['peak'], 'frac': d['frac'],
-                                   'fp32_product_tflops': d['executed_tflops'] / 6.0,
-                                   'kernel': dominant + ' (the Winograd GEMMs; the other MFMA launches of a step are listed in per_kernel)'})
-    if rank == 0 and world == 1 and not split_on and args.second_line and not args.no_second_line and args.workload in ('fused', 'tiles', 'rowref'):
-        result['second_line'] = second_line(args)
+                                     'note': 'achieved / frac = the bytes this design must move (16 B per point + the 3 x H x W u8 HWC tile: its only '
+                                             'consumer, the stem kernel, applies u8 / 255 itself, bit-identical) / time / peak; frac_survey_8d = '
+                                             'SURVEY 8(d) bytes (the same points + a 3 x H x W f32 tile, 4x the tile bytes, never written) / the same '
+                                             'time; traffic = what the counters saw'}
     # the CPU path timed on this node's own host cores in the same run, next to the 1 / 2 / 4 / 8-GPU numbers (north_star).  At N > 1 the
     # other ranks must not burn cores meanwhile: an NCCL barrier is a stream synchronise that may spin, so they finish their GPU work in a
     # barrier FIRST and are then parked on a key of the rendezvous store (a blocking socket read) until rank 0 has its number

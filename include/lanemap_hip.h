@@ -44,49 +44,9 @@ int lm_conv2d_nhwc_mfma_resup_f32(void* stream, const float* x, int ldx, const f
                                   int B, int H, int W, int Cin, int Cout, int KH, int KW, int stride, int pad_h, int pad_w,
                                   int dil, int act);
 
-/* 3x3 / stride 1 / pad == dilation convolution through Winograd F(2x2,3x3) (same layers, 2.25x fewer multiplies; fp32 error
- * at the level of a re-ordered direct sum).  wu: transformed weights [16][CoutP][Cin] = (G g G^T)[xi = 4i + j];
- * workspace: the transformed input V, lm_conv3x3_winograd_workspace_bytes(B, H, W, Cin, dil) bytes.  act: none / ReLU. */
-long lm_conv3x3_winograd_workspace_bytes(int B, int H, int W, int Cin, int dil);
-/* The two halves separately: several convolutions reading the same tensor share one input transform V; the GEMM can also
- * emit the GroupNorm(C,C) partial sums of its output (gn_partial [B][lm_winograd_gn_chunks][Cout][2] doubles, NULL = off;
- * finish with lm_gn_finalize) like lm_conv2d_nhwc_mfma_f32_gnstats does for the direct kernel. */
-int lm_winograd_gn_chunks(int H, int W, int dil);
-int lm_winograd_input_transform_f32(void* stream, const float* x, int ldx, int B, int H, int W, int Cin, int dil, void* V,
-                                    long V_bytes);
-/* V of bilinear_align_corners_x2(relu(gn(t; stats, gamma, beta))) [B][2Hi][2Wi][C] without materialising that tensor: the FPN's
- * s4 = _upsample(relu(gn(conv(p4)))) feeding one 3x3 convolution (postprojector.py:615-621).  Bit-identical to lm_gn_relu_upsample
- * followed by lm_winograd_input_transform_f32.  C = 128 or 256. */
-int lm_winograd_input_transform_gn_up2_f32(void* stream, const float* t, int ldt, const float* stats, const float* gamma,
-                                           const float* beta, int B, int Hi, int Wi, int C, void* V, long V_bytes);
-int lm_winograd_gemm_f32(void* stream, const void* V, const float* wu, int CoutP, const float* scale, const float* shift,
-                         const float* res, int ldr, float* y, int ldy, int B, int H, int W, int Cin, int Cout, int dil, int act,
-                         double* gn_partial);
-int lm_conv3x3_winograd_f32(void* stream, const float* x, int ldx, const float* wu, int CoutP, const float* scale,
-                            const float* shift, const float* res, int ldr, float* y, int ldy, int B, int H, int W, int Cin,
-                            int Cout, int dil, int act, void* workspace, long workspace_bytes);
-
-/* The same convolution without the transformed-input tensor V in HBM (wino_implicit_kernel: the raw 4x4 patches of 64 tiles are staged
- * in LDS per 16-channel slab, transformed there once per workgroup, all 16 xi accumulate in registers): bit-identical y to
- * lm_conv3x3_winograd_f32, no workspace.  wu_frag = U repacked per wave fragment, [16][Cin/16][CoutP/32][2][64][4]:
- *   wu_frag[xi][cs][nt][kk][lane][e] = U[xi][nt*32 + (lane & 31)][cs*16 + kk*8 + (lane >> 5)*4 + e].
- * lm_winograd_implicit_supported: 1 when the shape is covered (tile rows of >= 21 tiles, Cin % 32 == 0, Cin <= 1024). */
-int lm_winograd_implicit_supported(int H, int W, int Cin, int dil);
-int lm_conv3x3_winograd_implicit_f32(void* stream, const float* x, int ldx, const float* wu_frag, int CoutP, const float* scale,
-                                     const float* shift, const float* res, int ldr, float* y, int ldy, int B, int H, int W,
-                                     int Cin, int Cout, int dil, int act, double* gn_partial);
-/* The same convolution with the GEMM on the bf16 matrix cores ("bf16x3"): every fp32 operand (transformed input V, transformed weight
- * U) is split EXACTLY into three bf16 pieces and six of the nine piece products are accumulated in fp32 - the error class of an fp32
- * rounding (profiles/r2_split_precision_study.txt), NOT bit-identical to the fp32 kernels; 2.67x less matrix time.
- * wu_frag3: U split and repacked per wave fragment, [16][Cin/16][CoutP/32][3 pieces][64 lanes][8 bf16]:
- *   piece k of U[xi][nt*32 + (lane & 31)][cs*16 + 4*(lane >> 5) + (e & 3) + 8*(e >> 2)], e = 0..7. */
-int lm_conv3x3_winograd_implicit_bf16x3(void* stream, const float* x, int ldx, const void* wu_frag3, int CoutP, const float* scale,
-                                        const float* shift, const float* res, int ldr, float* y, int ldy, int B, int H, int W,
-                                        int Cin, int Cout, int dil, int act, double* gn_partial);
-
-/* Winograd F(4x4,3x3) on the fp32 matrix cores (csrc/conv_wino44.hip): the same layers (postprojector.py:322-338,597-647) with 36
- * products per 4x4 output block - 0.5625x the matrix work of the F(2x2) kernels above, exact fp32 MFMA, no transformed tensor in HBM.
- * Results are NOT bit-identical to the F(2x2) family (transform constants up to 8 and down to 1/24: profiles/r3_f44_numerics_study.txt);
+/* Winograd F(4x4,3x3) on the fp32 matrix cores (csrc/conv_wino44.hip): the 3x3 / stride-1 layers (postprojector.py:322-338,597-647) with 36
+ * products per 4x4 output block instead of 144 (3x3 / stride 1 / pad == dilation), exact fp32 MFMA, no transformed tensor in HBM.
+ * Error at the level of a re-ordered direct sum (transform constants up to 8 and down to 1/24: profiles/r3_f44_numerics_study.txt);
  * lm_conv3x3_winograd44_twin_f32 is the materialising twin (V and M in a workspace, three plain kernels) with identical bits.
  * wu_frag: U = G g G^T (fp64 -> fp32) per wave fragment, [36][Cin/8][CoutP/32][64 lanes][4]:
  *   wu_frag[xi][u][nt][lane][e] = U[xi][nt*32 + (lane & 31)][8 u + 4 (lane >> 5) + e], CoutP % 64 == 0, Cin % 16 == 0.

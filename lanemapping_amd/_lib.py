@@ -36,15 +36,6 @@ SIGNATURES = {
                                       i32, i32, i32, i32, i32, i32, i32, i32, i32, i32, i32, i32]),
     'lm_conv2d_nhwc_mfma_resup_f32': (i32, [vp, vp, i32, vp, i32, vp, vp, vp, i32, i32, i32, vp, i32,
                                             i32, i32, i32, i32, i32, i32, i32, i32, i32, i32, i32, i32]),
-    'lm_conv3x3_winograd_workspace_bytes': (i64, [i32, i32, i32, i32, i32]),
-    'lm_winograd_gn_chunks': (i32, [i32, i32, i32]),
-    'lm_winograd_input_transform_f32': (i32, [vp, vp, i32, i32, i32, i32, i32, i32, vp, i64]),
-    'lm_winograd_input_transform_gn_up2_f32': (i32, [vp, vp, i32, vp, vp, vp, i32, i32, i32, i32, vp, i64]),
-    'lm_winograd_gemm_f32': (i32, [vp, vp, vp, i32, vp, vp, vp, i32, vp, i32, i32, i32, i32, i32, i32, i32, i32, vp]),
-    'lm_conv3x3_winograd_f32': (i32, [vp, vp, i32, vp, i32, vp, vp, vp, i32, vp, i32, i32, i32, i32, i32, i32, i32, i32, vp, i64]),
-    'lm_winograd_implicit_supported': (i32, [i32, i32, i32, i32]),
-    'lm_conv3x3_winograd_implicit_f32': (i32, [vp, vp, i32, vp, i32, vp, vp, vp, i32, vp, i32, i32, i32, i32, i32, i32, i32, i32, vp]),
-    'lm_conv3x3_winograd_implicit_bf16x3': (i32, [vp, vp, i32, vp, i32, vp, vp, vp, i32, vp, i32, i32, i32, i32, i32, i32, i32, i32, vp]),
     'lm_winograd44_supported': (i32, [i32, i32, i32, i32]),
     'lm_winograd44_gn_chunks': (i32, [i32, i32, i32]),
     'lm_winograd44_tiles': (i64, [i32, i32, i32, i32]),

@@ -6,15 +6,15 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, 'csrc')
 LIB = os.path.join(HERE, 'liblanemap_hip.so')
-SOURCES = ['errors.cpp', 'conv_mfma.hip', 'conv_wino.hip', 'conv_wino44.hip', 'conv_direct.hip', 'norm_resize.hip', 'vit.hip', 'head.hip',
+SOURCES = ['errors.cpp', 'conv_mfma.hip', 'conv_wino44.hip', 'conv_direct.hip', 'norm_resize.hip', 'vit.hip', 'head.hip',
            'decode.hip', 'raster.hip', 'rowref.hip', 'prim.hip', 'lidar.hip', 'postproc.cpp', 'backproject.cpp', 'png_reader.cpp', 'lane_json.cpp', 'merge_lines.cpp', 'skeleton.cpp']
 
 
 # integer-output kernels whose fp32 index math must match the C oracle bit for bit
 EXACT_FP = {'raster.hip', 'lidar.hip', 'backproject.cpp', 'merge_lines.cpp'}
-# per-source extra flags.  conv_wino.hip: the SLP vectoriser packs the Winograd transform's adds into v_pk_add_f32 plus a dozen
+# per-source extra flags.  conv_wino44.hip: the SLP vectoriser packs the Winograd transform's adds into v_pk_add_f32 plus a dozen
 # v_mov shuffles per group; packed f32 VALU beside MFMAs costs issue slots (MI355X_MICROARCH.md, filler price list)
-EXTRA_FLAGS = {'conv_wino.hip': ['-fno-slp-vectorize'], 'conv_wino44.hip': ['-fno-slp-vectorize']}
+EXTRA_FLAGS = {'conv_wino44.hip': ['-fno-slp-vectorize']}
 
 
 def _stale():

@@ -375,25 +375,9 @@ LM_API int lm_bev_raster_batch(void* stream, const float* points_xyzi, const lon
     const long HW = (long)H * W;
     // (launching the two passes per group of 8 / 4 / 2 tiles, so that a group's records - 17.7 MB per tile - could stay inside the 256 MB
     // Infinity Cache between them, measured 25.3 / 27.1 / 27.4 us per tile against 23.8 for all 16 at once: the launch tails cost more)
-    // Round 4 experiment, LM_RASTER_OVERLAP=G: groups of G tiles, the band pass of group g on a helper stream so that it runs BESIDE the
-    // partition pass of group g + 1 (records of at most two groups live; the band pass's latency-bound phases under the other's stream).
-    static const int overlap = [] { const char* e = getenv("LM_RASTER_OVERLAP"); return e ? atoi(e) : 0; }();
-    const int group = (overlap > 0 && overlap < MAX_TILES) ? overlap : MAX_TILES;
-    hipStream_t side = nullptr;
-    hipEvent_t ev_part = nullptr, ev_band = nullptr;
-    if (group < MAX_TILES) {
-        static hipStream_t side_s[64] = {nullptr};
-        static hipEvent_t ev_s[64][2] = {{nullptr, nullptr}};
-        int dev = 0;
-        LM_HIP(hipGetDevice(&dev));
-        LM_REQUIRE(dev >= 0 && dev < 64, "bev_raster: device index %d", dev);
-        if (!side_s[dev]) {
-            LM_HIP(hipStreamCreateWithFlags(&side_s[dev], hipStreamNonBlocking));
-            LM_HIP(hipEventCreateWithFlags(&ev_s[dev][0], hipEventDisableTiming));
-            LM_HIP(hipEventCreateWithFlags(&ev_s[dev][1], hipEventDisableTiming));
-        }
-        side = side_s[dev]; ev_part = ev_s[dev][0]; ev_band = ev_s[dev][1];
-    }
+    // (round 4 also tried the band pass of group g on a helper stream beside the partition pass of group g + 1: it lost,
+    // profiles/r4_raster_overlap_experiment.txt; removed in round 5)
+    const int group = MAX_TILES;
     for (int b0 = 0; b0 < B; b0 += group) {
         const int nb = (B - b0) < group ? (B - b0) : group;
         BatchArgs A;
@@ -413,20 +397,10 @@ LM_API int lm_bev_raster_batch(void* stream, const float* points_xyzi, const lon
                                reinterpret_cast<const f32x4*>(points_xyzi), A, cnt, rec, nblk_max, H, W, nbands, band_rows);
             LM_LAUNCH_CHECK();
         }
-        hipStream_t bs = s;
-        if (side) {                            // band pass of this group on the helper stream, behind this group's partition pass
-            LM_HIP(hipEventRecord(ev_part, s));
-            LM_HIP(hipStreamWaitEvent(side, ev_part, 0));
-            bs = side;
-        }
-        hipLaunchKernelGGL(raster_band_kernel, dim3(nbands, nb), dim3(BT), lds, bs, cnt, rec, BA, nblk_max,
+        hipLaunchKernelGGL(raster_band_kernel, dim3(nbands, nb), dim3(BT), lds, s, cnt, rec, BA, nblk_max,
                            out_chw ? out_chw + (long)b0 * 3 * HW : nullptr, out_hwc_u8 ? out_hwc_u8 + (long)b0 * 3 * HW : nullptr,
                            H, W, nbands, band_rows);
         LM_LAUNCH_CHECK();
-    }
-    if (side) {                                // the caller's stream continues behind the last band pass
-        LM_HIP(hipEventRecord(ev_band, side));
-        LM_HIP(hipStreamWaitEvent(s, ev_band, 0));
     }
     return LM_OK;
 }

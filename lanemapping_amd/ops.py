@@ -73,46 +73,6 @@ def pack_mfma(w):
     return p.contiguous()
 
 
-def pack_wino(w):
-    """[Cout,Cin,3,3] -> Winograd F(2x2,3x3) weights U = G g G^T as [16, CoutP, Cin] (xi = 4 i + j), fp32."""
-    co, ci, kh, kw = w.shape
-    assert kh == 3 and kw == 3
-    G = torch.tensor([[1., 0., 0.], [.5, .5, .5], [.5, -.5, .5], [0., 0., 1.]], device=w.device, dtype=torch.float32)
-    U = torch.einsum('ij,ocjk,lk->iloc', G, w.float(), G).reshape(16, co, ci)
-    cop = (co + 127) // 128 * 128
-    p = torch.zeros((16, cop, ci), device=w.device, dtype=torch.float32)
-    p[:, :co, :] = U
-    return p.contiguous()
-
-
-def pack_wino_fragments(wu):
-    """pack_wino output U [16, CoutP, Cin] -> the per-wave-fragment order of lm_conv3x3_winograd_implicit_f32:
-    [16][Cin/16][CoutP/32][kk 2][lane 64][4] with lane = fhalf * 32 + row, k = cs*16 + kk*8 + fhalf*4 + e."""
-    xi, cop, ci = wu.shape
-    assert xi == 16 and cop % 32 == 0 and ci % 16 == 0
-    t = wu.reshape(16, cop // 32, 32, ci // 16, 2, 2, 4)                 # xi, nt, row, cs, kk, fhalf, e
-    return t.permute(0, 3, 1, 4, 5, 2, 6).contiguous().reshape(16, ci // 16, cop // 32, 2, 64, 4)
-
-
-def pack_wino_fragments_bf16x3(wu):
-    """pack_wino output U [16, CoutP, Cin] -> three EXACT bf16 pieces (U = u1 + u2 + u3: top 8 significant bits, then the next 8, then
-    the last 8, by truncation) in the per-wave-fragment order of lm_conv3x3_winograd_implicit_bf16x3:
-    [16][Cin/16][CoutP/32][piece 3][lane 64][8] bf16 with lane = khalf * 32 + row, channel = cs*16 + 8*(e >> 2) + 4*khalf + (e & 3)."""
-    xi, cop, ci = wu.shape
-    assert xi == 16 and cop % 32 == 0 and ci % 16 == 0 and wu.dtype == torch.float32
-    pieces, r = [], wu
-    for _ in range(3):
-        top = (r.contiguous().view(torch.int32) & -65536).view(torch.float32)
-        pieces.append(top)
-        r = r - top
-    assert float(r.abs().max()) == 0.0
-    t = torch.stack(pieces).to(torch.bfloat16)                                   # exact: every piece is a bf16 value
-    # channel c of a 16-channel slab = 8 * hi + 4 * khalf + lo (hi, khalf in 0..1, lo in 0..3): lane half `khalf` holds the channels of
-    # its two fp32 A fragments, element e = 4 * hi + lo
-    t = t.reshape(3, 16, cop // 32, 32, ci // 16, 2, 2, 4)                       # piece, xi, nt, row, cs, hi, khalf, lo
-    return t.permute(1, 4, 2, 0, 6, 3, 5, 7).contiguous().reshape(16, ci // 16, cop // 32, 3, 64, 8)
-
-
 _W44_G = [[1 / 4, 0, 0], [-1 / 6, -1 / 6, -1 / 6], [-1 / 6, 1 / 6, -1 / 6], [1 / 24, 1 / 12, 1 / 6], [1 / 24, -1 / 12, 1 / 6], [0, 0, 1]]
 
 
@@ -195,124 +155,11 @@ def conv_mfma(x, wp, cout, kh=1, kw=1, stride=1, pad=0, dil=1, scale=None, shift
     return out
 
 
-_wino_ws = {}
-
-
-class WinoInput:
-    """Winograd-transformed input V = B^T d B of one NHWC tensor (lm_winograd_input_transform_f32); may feed several
-    convolutions.  `buf` is either a dedicated tensor (shared transforms) or the per-stream scratch buffer."""
-
-    def __init__(self, buf, B, cin, H, W, dil):
-        self.buf, self.B, self.cin, self.H, self.W, self.dil = buf, B, cin, H, W, dil
-
-
 def _hooked(kind, flops, launch, executed=None):
     if _conv_hook is not None:
         _conv_hook(kind, flops, launch, executed)
     else:
         launch()
-
-
-def _wino_buf(need, device, dedicated):
-    if dedicated:
-        return torch.empty(need, device=device, dtype=torch.uint8)
-    key = (device, _stream().value)
-    ws = _wino_ws.get(key)
-    if ws is None or ws.numel() < need:
-        ws = _wino_ws[key] = torch.empty(need, device=device, dtype=torch.uint8)
-    return ws
-
-
-def wino_transform(x, dil=1, dedicated=False):
-    x, ldx = as_nhwc(x)
-    B, cin, H, W = x.shape
-    ws = _wino_buf(lib().lm_conv3x3_winograd_workspace_bytes(B, H, W, cin, dil), x.device, dedicated)
-    _hooked(f'wino_input {cin} d{dil} @{H}x{W} B{B}', 0.0,
-            lambda: check(lib().lm_winograd_input_transform_f32(_stream(), _ptr(x), ldx, B, H, W, cin, dil, _ptr(ws), ws.numel())))
-    return WinoInput(ws, B, cin, H, W, dil)
-
-
-def wino_transform_gn_up2(t, stats, gamma, beta, dedicated=False):
-    """Winograd input of bilinear_x2(relu(gn(t))) straight from t (the upsampled tensor is never written); == wino_transform(
-    gn_relu_upsample(t, ...)) bit for bit.  C = 128 or 256."""
-    t, ld = as_nhwc(t)                                  # may be a channel slice of a wider NHWC tensor (ld > C)
-    B, cin, Hi, Wi = t.shape
-    H, W = 2 * Hi, 2 * Wi
-    ws = _wino_buf(lib().lm_conv3x3_winograd_workspace_bytes(B, H, W, cin, 1), t.device, dedicated)
-    _hooked(f'wino_input {cin} (gn+relu+up2 fused) @{H}x{W} B{B}', 0.0,
-            lambda: check(lib().lm_winograd_input_transform_gn_up2_f32(_stream(), _ptr(t), ld, _ptr(stats), _ptr(gamma), _ptr(beta),
-                                                                       B, Hi, Wi, cin, _ptr(ws), ws.numel())))
-    return WinoInput(ws, B, cin, H, W, 1)
-
-
-def conv_wino(x, wu, cout, dil=1, scale=None, shift=None, res=None, act=ACT_NONE, out=None, gn_eps=None, gn_split=1):
-    """3x3 / stride 1 / pad = dil convolution via Winograd F(2x2,3x3).  x: an NHWC-stored tensor or a WinoInput (shared
-    transform).  With gn_eps the GroupNorm(C,C) statistics of the output come out of the GEMM epilogue: returns (y, stats);
-    gn_split > 1: stats [gn_split, B, cout / gn_split, 2], one contiguous block per channel group."""
-    vi = x if isinstance(x, WinoInput) else wino_transform(x, dil)
-    B, cin, H, W = vi.B, vi.cin, vi.H, vi.W
-    y = out if out is not None else new_act(B, cout, H, W, vi.buf.device)
-    y_, ldy = as_nhwc(y)
-    assert y_.data_ptr() == y.data_ptr(), 'conv_wino: `out` must already be NHWC-stored'
-    r, ldr = (None, 0) if res is None else as_nhwc(res)
-    part = None
-    if gn_eps is not None:
-        nchunk = lib().lm_winograd_gn_chunks(H, W, vi.dil)
-        # every chunk the finalize pass reads is written by the GEMM (chunks made of padding rows only are stored as zeros)
-        part = torch.empty((B, nchunk, cout, 2), device=vi.buf.device, dtype=torch.float64)
-    tiles = lib().lm_conv3x3_winograd_workspace_bytes(B, H, W, cin, vi.dil) // (64 * cin)
-    _hooked(f'wino_gemm {cin}->{cout} k3x3 d{vi.dil} @{H}x{W} B{B}', 2.0 * B * H * W * cout * cin * 9,
-            lambda: check(lib().lm_winograd_gemm_f32(_stream(), _ptr(vi.buf), _ptr(wu), wu.shape[1], _ptr(scale), _ptr(shift), _ptr(r), ldr,
-                                                     _ptr(y), ldy, B, H, W, cin, cout, vi.dil, act, _ptr(part))),
-            2.0 * 16 * tiles * cin * cout)
-    if gn_eps is None:
-        return y
-    if gn_split > 1:
-        stats = torch.empty((gn_split, B, cout // gn_split, 2), device=vi.buf.device, dtype=torch.float32)
-        check(lib().lm_gn_finalize_split(_stream(), _ptr(part), _ptr(stats), B, H * W, cout, part.shape[1], gn_eps, gn_split))
-        return y, stats
-    stats = torch.empty((B, cout, 2), device=vi.buf.device, dtype=torch.float32)
-    check(lib().lm_gn_finalize(_stream(), _ptr(part), _ptr(stats), B, H * W, cout, part.shape[1], gn_eps))
-    return y, stats
-
-
-def wino_implicit_supported(H, W, cin, dil=1):
-    return bool(lib().lm_winograd_implicit_supported(int(H), int(W), int(cin), int(dil)))
-
-
-def conv_wino_implicit(x, wf, cout, dil=1, scale=None, shift=None, res=None, act=ACT_NONE, out=None, gn_eps=None, gn_split=1):
-    # wf: fp32 fragments (pack_wino_fragments: exact-fp32 MFMA, bit-identical to conv_wino) or bf16x3 fragments
-    # (pack_wino_fragments_bf16x3: six bf16 MFMAs per multiply, fp32-rounding-class error, not bit-identical; wino_rows_split_kernel)
-    """3x3 / stride 1 / pad = dil convolution via Winograd F(2x2,3x3) WITHOUT the transformed-input tensor in HBM (the raw patches are
-    transformed in LDS, once per workgroup and 16-channel slab).  wf = pack_wino_fragments(pack_wino(w)).  Same bits as conv_wino;
-    with gn_eps returns (y, stats) (gn_split: statistics laid out per channel group, see conv_wino)."""
-    x, ldx = as_nhwc(x)
-    B, cin, H, W = x.shape
-    cop = wf.shape[2] * 32
-    y = out if out is not None else new_act(B, cout, H, W, x.device)
-    y_, ldy = as_nhwc(y)
-    assert y_.data_ptr() == y.data_ptr(), 'conv_wino_implicit: `out` must already be NHWC-stored'
-    r, ldr = (None, 0) if res is None else as_nhwc(res)
-    part = None
-    if gn_eps is not None:
-        part = torch.empty((B, lib().lm_winograd_gn_chunks(H, W, dil), cout, 2), device=x.device, dtype=torch.float64)
-    tiles = lib().lm_conv3x3_winograd_workspace_bytes(B, H, W, cin, dil) // (64 * cin)
-    split = wf.dtype == torch.bfloat16
-    fn = lib().lm_conv3x3_winograd_implicit_bf16x3 if split else lib().lm_conv3x3_winograd_implicit_f32
-    # executed FLOPs: the Winograd-domain products; the bf16x3 kernel issues six bf16 MFMA products per fp32 product
-    _hooked(f'{"wino_bf16x3" if split else "wino_implicit"} {cin}->{cout} k3x3 d{dil} @{H}x{W} B{B}', 2.0 * B * H * W * cout * cin * 9,
-            lambda: check(fn(_stream(), _ptr(x), ldx, _ptr(wf), cop, _ptr(scale), _ptr(shift), _ptr(r), ldr,
-                             _ptr(y), ldy, B, H, W, cin, cout, dil, act, _ptr(part))),
-            2.0 * 16 * tiles * cin * cout * (6 if split else 1))
-    if gn_eps is None:
-        return y
-    if gn_split > 1:
-        stats = torch.empty((gn_split, B, cout // gn_split, 2), device=x.device, dtype=torch.float32)
-        check(lib().lm_gn_finalize_split(_stream(), _ptr(part), _ptr(stats), B, H * W, cout, part.shape[1], gn_eps, gn_split))
-        return y, stats
-    stats = torch.empty((B, cout, 2), device=x.device, dtype=torch.float32)
-    check(lib().lm_gn_finalize(_stream(), _ptr(part), _ptr(stats), B, H * W, cout, part.shape[1], gn_eps))
-    return y, stats
 
 
 def wino44_supported(H, W, cin, dil=1):

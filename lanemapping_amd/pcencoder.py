@@ -22,27 +22,12 @@ from .registry import PCENCODER
 from .packing import PackedModule
 
 _LAYERS = {'resnet18': [2, 2, 2, 2], 'resnet34': [3, 4, 6, 3]}
-# 3x3 / stride-1 convolutions with >= WINO_MIN_CIN input channels go through Winograd F(2x2,3x3) (csrc/conv_wino.hip:
-# 1.25-1.66x the direct MFMA kernel on those shapes; the 64-channel layers stay direct).  LANEMAP_WINOGRAD=0 disables it.
-USE_WINOGRAD = os.environ.get('LANEMAP_WINOGRAD', '1') != '0'
-WINO_MIN_CIN = int(os.environ.get('LANEMAP_WINO_MIN_CIN', '128'))
-MERGE_BRANCH_CONVS = os.environ.get('LANEMAP_MERGE_BRANCH_CONVS', '1') != '0'   # conv_b of both semantic branches on p2 / p3 as one GEMM
-FUSE_UP_WINO = os.environ.get('LANEMAP_FUSE_UP_WINO', '1') != '0'    # s4: GN + ReLU + x2 upsample fused into the Winograd input transform
-# Winograd without the V tensor in HBM (csrc/conv_wino.hip wino_implicit_kernel: the raw patches are transformed in LDS, bit-identical
-# results): every 3x3 / stride-1 convolution with >= WINO_IMPLICIT_MIN_CIN input channels whose tile rows are wide enough
-# (lm_winograd_implicit_supported), 6-25 % faster than transform + streaming GEMM per layer and without its 4x-inflated HBM round trip
-# (also pays on the 64-channel layers, where the materialising path lost to the direct kernel).  LANEMAP_WINO_IMPLICIT=0 switches back.
-WINO_IMPLICIT = os.environ.get('LANEMAP_WINO_IMPLICIT', '1') != '0'
-WINO_IMPLICIT_MIN_CIN = int(os.environ.get('LANEMAP_WINO_IMPLICIT_MIN_CIN', '64'))
-# Opt-in: the same convolutions with their GEMM on the bf16 matrix cores through exact 3-way operand splits (6 bf16 MFMAs per fp32
-# product; fp32-rounding-class error, profiles/r2_split_precision_study.txt; csrc/conv_wino.hip wino_rows_split_kernel).
-# Off by default because its results are not bit-identical to the fp32 kernels; 1.2-1.4x faster per layer, bench.py's second line.
-WINO_BF16X3 = os.environ.get('LANEMAP_WINO_BF16X3', '0') != '0'
-# Winograd F(4x4,3x3) (csrc/conv_wino44.hip, round 4): 36 products per 4x4 output block instead of 4 x 16 - 0.5625x the matrix work of
-# the F(2x2) kernels, still exact fp32 MFMA; 1.3-1.5x faster per layer on every FPN shape.  Not bit-identical to the F(2x2) family
-# (transform constants up to 8 and down to 1/24; numerics priced in profiles/r3_f44_numerics_study.txt and held by the parity suite).
-# Takes every 3x3 / stride-1 layer it supports (Cin % 16 == 0, tile rows of >= 15 tiles); LANEMAP_WINO_F44=0 switches back to F(2x2).
-WINO_F44 = os.environ.get('LANEMAP_WINO_F44', '1') != '0' and not WINO_BF16X3
+MERGE_BRANCH_CONVS = os.environ.get('LANEMAP_MERGE_BRANCH_CONVS', '1') != '0'   # conv_b of both semantic branches on p2 / p3 as one launch
+# Winograd F(4x4,3x3) (csrc/conv_wino44.hip): every 3x3 / stride-1 convolution with >= WINO_F44_MIN_CIN input channels that the kernel
+# supports (Cin % 16 == 0, tile rows wide enough: lm_winograd44_supported) - 36 products per 4x4 output block instead of 144, exact fp32
+# MFMA, no transformed tensor in HBM.  Everything else, and everything under LANEMAP_WINO_F44=0, runs the direct implicit-GEMM kernel
+# (csrc/conv_mfma.hip).  The F(2x2,3x3) family of rounds 1-3 was removed in round 5 (history: profiles/README.md).
+WINO_F44 = os.environ.get('LANEMAP_WINO_F44', '1') != '0'
 WINO_F44_MIN_CIN = int(os.environ.get('LANEMAP_WINO_F44_MIN_CIN', '64'))
 
 
@@ -50,8 +35,8 @@ def _frag44(w):
     return ops.pack_wino44_fragments(ops.pack_wino44(w))
 
 
-def _frag(wu):
-    return ops.pack_wino_fragments_bf16x3(wu) if WINO_BF16X3 else ops.pack_wino_fragments(wu)
+def _f44_ok(conv):
+    return WINO_F44 and conv.kernel_size == (3, 3) and conv.stride == (1, 1) and conv.in_channels >= WINO_F44_MIN_CIN and conv.in_channels % 16 == 0
 
 
 class _ResBlock(nn.Module):
@@ -150,17 +135,9 @@ class FPNEncoder(PackedModule):
                 P[k + '.s1'], P[k + '.b1'] = ops.fold_bn(blk.bn1)
                 P[k + '.w2'] = ops.pack_mfma(blk.conv2.weight)
                 P[k + '.s2'], P[k + '.b2'] = ops.fold_bn(blk.bn2)
-                if USE_WINOGRAD:
-                    for q, conv, ok in (('.w1u', blk.conv1, blk.stride == 1), ('.w2u', blk.conv2, True)):
-                        if not ok:
-                            continue
-                        u = None
-                        if conv.in_channels >= WINO_MIN_CIN:
-                            u = P[k + q] = ops.pack_wino(conv.weight)
-                        if WINO_IMPLICIT and conv.in_channels >= WINO_IMPLICIT_MIN_CIN and conv.in_channels % 32 == 0:
-                            P[k + q + 'f'] = _frag(u if u is not None else ops.pack_wino(conv.weight))
-                        if WINO_F44 and conv.in_channels >= WINO_F44_MIN_CIN and conv.in_channels % 16 == 0:
-                            P[k + q + 'q'] = _frag44(conv.weight)
+                for q, conv in (('.w1q', blk.conv1), ('.w2q', blk.conv2)):
+                    if _f44_ok(conv):
+                        P[k + q] = _frag44(conv.weight)
                 if blk.downsample is not None:
                     P[k + '.wd'] = ops.pack_mfma(blk.downsample[0].weight)
                     P[k + '.sd'], P[k + '.bd'] = ops.fold_bn(blk.downsample[1])
@@ -169,31 +146,19 @@ class FPNEncoder(PackedModule):
             m = getattr(self, name)
             P[name + '.w'] = ops.pack_mfma(m.weight)
             P[name + '.b'] = m.bias.float().contiguous()
-            if USE_WINOGRAD and m.kernel_size == (3, 3) and m.in_channels >= WINO_MIN_CIN:
-                P[name + '.wu'] = ops.pack_wino(m.weight)
-                if WINO_IMPLICIT:
-                    P[name + '.wuf'] = _frag(P[name + '.wu'])
-                if WINO_F44 and m.in_channels % 16 == 0:
-                    P[name + '.wuq'] = _frag44(m.weight)
-        # the two branches convolve p2 and p3 with different weights: one GEMM with the output channels concatenated reads V once
-        # per 4 N tiles instead of per 2 (same values per channel: an output column does not depend on its neighbours)
+            if _f44_ok(m):
+                P[name + '.wq'] = _frag44(m.weight)
+        # the two branches convolve p2 and p3 with different weights: one launch with the output channels concatenated transforms each
+        # input patch once per 4 N tiles instead of per 2 (same values per channel: an output column does not depend on its neighbours)
         a, b2 = self.semantic_branch, self.semantic_branch2
-        if (MERGE_BRANCH_CONVS and 'semantic_branch.wu' in P and 'semantic_branch2.wu' in P and a.out_channels == b2.out_channels
+        if (MERGE_BRANCH_CONVS and 'semantic_branch.wq' in P and 'semantic_branch2.wq' in P and a.out_channels == b2.out_channels
                 and self.gn11.eps == self.gn21.eps):
-            P['semantic_branch_ab.wu'] = ops.pack_wino(torch.cat([a.weight, b2.weight], dim=0))
+            P['semantic_branch_ab.wq'] = _frag44(torch.cat([a.weight, b2.weight], dim=0))
             P['semantic_branch_ab.b'] = torch.cat([a.bias, b2.bias]).float().contiguous()
-            if WINO_IMPLICIT:
-                P['semantic_branch_ab.wuf'] = _frag(P['semantic_branch_ab.wu'])
-            if WINO_F44 and a.in_channels % 16 == 0:
-                P['semantic_branch_ab.wuq'] = _frag44(torch.cat([a.weight, b2.weight], dim=0))
-            if ('conv2.wu' in P and 'conv3.wu' in P and self.conv2.out_channels == self.conv3.out_channels
+            if ('conv2.wq' in P and 'conv3.wq' in P and self.conv2.out_channels == self.conv3.out_channels
                     and self.gn12.eps == self.gn22.eps):           # likewise conv2 / conv3 on p4
-                P['conv23.wu'] = ops.pack_wino(torch.cat([self.conv2.weight, self.conv3.weight], dim=0))
+                P['conv23.wq'] = _frag44(torch.cat([self.conv2.weight, self.conv3.weight], dim=0))
                 P['conv23.b'] = torch.cat([self.conv2.bias, self.conv3.bias]).float().contiguous()
-                if WINO_IMPLICIT:
-                    P['conv23.wuf'] = _frag(P['conv23.wu'])
-                if WINO_F44 and self.conv2.in_channels % 16 == 0:
-                    P['conv23.wuq'] = _frag44(torch.cat([self.conv2.weight, self.conv3.weight], dim=0))
         if self.out is not None:
             P['out.w'] = ops.pack_mfma(self.out.weight)
         for name in ('feature_layer', 'output_layer_binary_seg', 'output_layer_endp'):
@@ -208,13 +173,10 @@ class FPNEncoder(PackedModule):
     # -------------------------------------------------------------------------------- forward
     @staticmethod
     def _c3(x, P, wkey, cout, stride, dil, **epi):
-        """3x3 convolution, pad = dilation: Winograd when its transformed weights were packed, else the direct kernel."""
-        if (wkey + 'uq') in P and stride == 1 and ops.wino44_supported(x.shape[2], x.shape[3], x.shape[1], dil):
-            return ops.conv_wino44(x, P[wkey + 'uq'], cout, dil, **epi)
-        if (wkey + 'uf') in P and stride == 1 and ops.wino_implicit_supported(x.shape[2], x.shape[3], x.shape[1], dil):
-            return ops.conv_wino_implicit(x, P[wkey + 'uf'], cout, dil, **epi)
-        if (wkey + 'u') in P and stride == 1:
-            return ops.conv_wino(x, P[wkey + 'u'], cout, dil, **epi)
+        """3x3 convolution, pad = dilation: Winograd F(4x4,3x3) when its fragments were packed and the shape is covered, else the
+        direct kernel."""
+        if (wkey + 'q') in P and stride == 1 and ops.wino44_supported(x.shape[2], x.shape[3], x.shape[1], dil):
+            return ops.conv_wino44(x, P[wkey + 'q'], cout, dil, **epi)
         return ops.conv_mfma(x, P[wkey], cout, 3, 3, stride, dil, dil, **epi)
 
     def _block(self, x, P, key, blk):
@@ -227,48 +189,27 @@ class FPNEncoder(PackedModule):
     def _conv3(self, x, P, name, cout):
         return self._c3(x, P, name + '.w', cout, 1, 1, shift=P[name + '.b'])
 
-    def _semantic(self, P, p2, p3, p4, conv_a, gn_a, conv_b, gn_b, shared, proj, pre=None, pre_a4=None):
+    def _conv_stats(self, P, src, conv, cout, gn):
+        """conv3x3 + bias with the GroupNorm statistics coming out of the conv epilogue."""
+        eps = getattr(self, gn).eps
+        if (conv + '.wq') in P and ops.wino44_supported(src.shape[2], src.shape[3], src.shape[1], 1):
+            return ops.conv_wino44(src, P[conv + '.wq'], cout, 1, shift=P[conv + '.b'], gn_eps=eps)
+        if (src.shape[2] * src.shape[3]) % 128 == 0:      # whole 128-row tiles per image: statistics from the direct kernel's epilogue
+            return ops.conv_mfma_gnstats(src, P[conv + '.w'], cout, 3, 3, 1, 1, 1, P[conv + '.b'], eps)
+        t = self._conv3(src, P, conv, cout)               # ragged image size: separate statistics kernel
+        return t, ops.gn_stats(t, eps)
+
+    def _semantic(self, P, p2, p3, p4, conv_a, gn_a, conv_b, gn_b, proj, pre=None, pre_a4=None):
         """One of the two branches (reference :615-621 / :641-647): s2 + s3 + s4 at p2's size, followed by the branch's 1x1 output
         layer `proj` = (packed weight, bias, cout, out) - the only consumer of the sum, so the 128-channel sum is never written
-        (lm_gn_relu_upsample_sum_conv1x1).  `shared` caches the Winograd input transforms of p2 / p3 / p4, which both branches
-        convolve (with different weights)."""
+        (lm_gn_relu_upsample_sum_conv1x1).  pre / pre_a4: (tensor, statistics) pairs of the merged launches (channel slices)."""
         h, w = p2.shape[2:]
         c_half = self.semantic_branch.out_channels
-
-        def conv_stats(src, conv, cout, gn, share=None):
-            # conv3x3 + bias with the GroupNorm statistics coming out of the conv epilogue
-            eps = getattr(self, gn).eps
-            if (conv + '.wuq') in P and not isinstance(src, ops.WinoInput) and ops.wino44_supported(src.shape[2], src.shape[3], src.shape[1], 1):
-                t, st = ops.conv_wino44(src, P[conv + '.wuq'], cout, 1, shift=P[conv + '.b'], gn_eps=eps)
-            elif (conv + '.wuf') in P and not isinstance(src, ops.WinoInput) and ops.wino_implicit_supported(src.shape[2], src.shape[3], src.shape[1], 1):
-                t, st = ops.conv_wino_implicit(src, P[conv + '.wuf'], cout, 1, shift=P[conv + '.b'], gn_eps=eps)     # no V tensor
-            elif (conv + '.wu') in P:                           # Winograd; p2/p3/p4 are transformed once for both branches
-                if share is not None:
-                    if share not in shared:
-                        shared[share] = ops.wino_transform(src, 1, dedicated=True)
-                    src = shared[share]
-                t, st = ops.conv_wino(src, P[conv + '.wu'], cout, 1, shift=P[conv + '.b'], gn_eps=eps)
-            elif (src.shape[2] * src.shape[3]) % 128 == 0:    # whole 128-row tiles per image: statistics from the epilogue
-                t, st = ops.conv_mfma_gnstats(src, P[conv + '.w'], cout, 3, 3, 1, 1, 1, P[conv + '.b'], eps)
-            else:                                              # ragged image size: separate statistics kernel
-                t = self._conv3(src, P, conv, cout)
-                st = ops.gn_stats(t, eps)
-            return t, st
-
-        t, st = pre_a4 if pre_a4 is not None else conv_stats(p4, conv_a, p4.shape[1], gn_a, share='p4')
-        imp_b = (((conv_b + '.wuf') in P and ops.wino_implicit_supported(h, w, t.shape[1], 1))
-                 or ((conv_b + '.wuq') in P and ops.wino44_supported(h, w, t.shape[1], 1)))
-        if (not imp_b and FUSE_UP_WINO and (conv_b + '.wu') in P and (h, w) == (2 * t.shape[2], 2 * t.shape[3]) and t.shape[1] in (128, 256)):
-            # s4 feeds only conv_b: its Winograd input comes straight from t, the upsampled 256-channel tensor is never written
-            s4 = ops.wino_transform_gn_up2(t, st, P[gn_a + '.g'], P[gn_a + '.b'])
-        else:
-            s4 = ops.gn_relu_upsample_sum([(t, st)], P[gn_a + '.g'], P[gn_a + '.b'], (h, w))   # 256 ch at 288^2 (t may be a channel slice)
-        if pre is not None:                                                             # s2, s3 from the merged GEMMs (channel slices)
-            terms = [pre[0], pre[1]]
-        else:
-            terms = [conv_stats(p2, conv_b, c_half, gn_b, share='p2'),                  # s2
-                     conv_stats(p3, conv_b, c_half, gn_b, share='p3')]                  # s3
-        terms.append(conv_stats(s4, conv_b, c_half, gn_b))                              # s4
+        t, st = pre_a4 if pre_a4 is not None else self._conv_stats(P, p4, conv_a, p4.shape[1], gn_a)
+        s4 = ops.gn_relu_upsample_sum([(t, st)], P[gn_a + '.g'], P[gn_a + '.b'], (h, w))       # 256 ch at 288^2 (t may be a channel slice)
+        terms = [pre[0] if pre is not None and pre[0] is not None else self._conv_stats(P, p2, conv_b, c_half, gn_b),       # s2
+                 pre[1] if pre is not None and pre[1] is not None else self._conv_stats(P, p3, conv_b, c_half, gn_b)]       # s3
+        terms.append(self._conv_stats(P, s4, conv_b, c_half, gn_b))                             # s4
         # (s2 + s3) + s4, each term GN + ReLU + bilinear to p2's size, and the 1x1 output layer, in one pass
         return ops.gn_relu_upsample_sum(terms, P[gn_b + '.g'], P[gn_b + '.b'], (h, w), proj=proj, keep_sum=False)
 
@@ -312,42 +253,25 @@ class FPNEncoder(PackedModule):
         p4 = self._conv3(p4, P, 'smooth1', 256)
         p3 = self._conv3(p3, P, 'smooth2', 256)
         p2 = self._conv3(p2, P, 'smooth3', 256)
-        shared = {}
-        pre_a = pre_b = None
-        if 'semantic_branch_ab.wu' in P:
+        pre_a, pre_b = [None, None], [None, None]
+        if 'semantic_branch_ab.wq' in P:
             ch = self.semantic_branch.out_channels
-            pre_a, pre_b = [], []
-            for key, src in (('p2', p2), ('p3', p3)):
-                if 'semantic_branch_ab.wuq' in P and ops.wino44_supported(src.shape[2], src.shape[3], src.shape[1], 1):
-                    t, st = ops.conv_wino44(src, P['semantic_branch_ab.wuq'], 2 * ch, 1, shift=P['semantic_branch_ab.b'],
-                                            gn_eps=self.gn11.eps, gn_split=2)
-                elif 'semantic_branch_ab.wuf' in P and ops.wino_implicit_supported(src.shape[2], src.shape[3], src.shape[1], 1):
-                    t, st = ops.conv_wino_implicit(src, P['semantic_branch_ab.wuf'], 2 * ch, 1, shift=P['semantic_branch_ab.b'],
-                                                   gn_eps=self.gn11.eps, gn_split=2)
-                else:
-                    shared[key] = ops.wino_transform(src, 1, dedicated=True)
-                    t, st = ops.conv_wino(shared[key], P['semantic_branch_ab.wu'], 2 * ch, 1, shift=P['semantic_branch_ab.b'],
-                                          gn_eps=self.gn11.eps, gn_split=2)              # statistics per branch half: [2, B, ch, 2]
-                pre_a.append((t[:, :ch], st[0]))
-                pre_b.append((t[:, ch:], st[1]))
+            for i, src in enumerate((p2, p3)):
+                if ops.wino44_supported(src.shape[2], src.shape[3], src.shape[1], 1):
+                    t, st = ops.conv_wino44(src, P['semantic_branch_ab.wq'], 2 * ch, 1, shift=P['semantic_branch_ab.b'],
+                                            gn_eps=self.gn11.eps, gn_split=2)              # statistics per branch half: [2, B, ch, 2]
+                    pre_a[i], pre_b[i] = (t[:, :ch], st[0]), (t[:, ch:], st[1])
         a4 = b4 = None
-        if 'conv23.wu' in P:
+        if 'conv23.wq' in P and ops.wino44_supported(p4.shape[2], p4.shape[3], p4.shape[1], 1):
             c4o = self.conv2.out_channels
-            if 'conv23.wuq' in P and ops.wino44_supported(p4.shape[2], p4.shape[3], p4.shape[1], 1):
-                t, st = ops.conv_wino44(p4, P['conv23.wuq'], 2 * c4o, 1, shift=P['conv23.b'], gn_eps=self.gn12.eps, gn_split=2)
-            elif 'conv23.wuf' in P and ops.wino_implicit_supported(p4.shape[2], p4.shape[3], p4.shape[1], 1):
-                t, st = ops.conv_wino_implicit(p4, P['conv23.wuf'], 2 * c4o, 1, shift=P['conv23.b'], gn_eps=self.gn12.eps, gn_split=2)
-            else:
-                shared['p4'] = ops.wino_transform(p4, 1, dedicated=True)
-                t, st = ops.conv_wino(shared['p4'], P['conv23.wu'], 2 * c4o, 1, shift=P['conv23.b'], gn_eps=self.gn12.eps, gn_split=2)
+            t, st = ops.conv_wino44(p4, P['conv23.wq'], 2 * c4o, 1, shift=P['conv23.b'], gn_eps=self.gn12.eps, gn_split=2)
             a4, b4 = (t[:, :c4o], st[0]), (t[:, c4o:], st[1])
-        fea_up = self._semantic(P, p2, p3, p4, 'conv2', 'gn12', 'semantic_branch', 'gn11', shared,
+        fea_up = self._semantic(P, p2, p3, p4, 'conv2', 'gn12', 'semantic_branch', 'gn11',
                                 (P['feature_layer.w'], P['feature_layer.b'], 8, fea_up_out), pre_a, a4)
         seg288 = ops.conv_small(fea_up, P['output_layer_binary_seg.w'], 3, shift=P['output_layer_binary_seg.b'], pre_relu=True)
         bi_seg = ops.upsample_to_chw(seg288, (H, W))
-        endp288 = self._semantic(P, p2, p3, p4, 'conv3', 'gn22', 'semantic_branch2', 'gn21', shared,
+        endp288 = self._semantic(P, p2, p3, p4, 'conv3', 'gn22', 'semantic_branch2', 'gn21',
                                  (P['output_layer_endp.w'], P['output_layer_endp.b'], 1, None), pre_b, b4)
-        del shared
         endp = ops.upsample_to_chw(endp288, (H, W))
         return fea, fea_up, bi_seg, endp
 

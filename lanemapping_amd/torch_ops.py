@@ -15,7 +15,7 @@ Two levels:
     op computes from the tensors it is handed) and the stage's STRUCTURE (which layers, strides, dilations) as a string: the name
     under which the module registered itself (``stage_name``: class name + a process-wide counter, never recycled).  Round 2 passed
     ``id(module)``: a process-local integer that could alias a recycled id and hid the weights from the graph.
-  * kernel ops - one per device kernel family (``conv2d_mfma``, ``conv3x3_winograd``, ``conv3x3_winograd44``, ``stem_conv7x7``, ``gn_relu_upsample``,
+  * kernel ops - one per device kernel family (``conv2d_mfma``, ``conv3x3_winograd44``, ``stem_conv7x7``, ``gn_relu_upsample``,
     ``layernorm_rows``, ``attention``, ``linear_mfma``, ``decode_proposals``, ``decode_semantic``, ``endp_topk``, ``tile_ingest``, ...).
 Activations are logically NCHW, stored channels-last (ops.new_act); fake kernels return the same strides.
 """
@@ -106,16 +106,6 @@ def _conv2d_mfma(x: Tensor, w_packed: Tensor, cout: int, kh: int, kw: int, strid
 def _conv2d_mfma_fake(x, w_packed, cout, kh, kw, stride, pad, dil, scale, shift, res, act):
     Ho, Wo = _out_hw(x.shape[2], x.shape[3], kh, kw, stride, pad, dil)
     return _fake_act(x, x.shape[0], cout, Ho, Wo)
-
-
-def _conv3x3_winograd(x: Tensor, wu: Tensor, cout: int, dil: int, scale: Optional[Tensor], shift: Optional[Tensor],
-                      res: Optional[Tensor], act: int) -> Tensor:
-    return _ops.conv_wino(x, wu, cout, dil, scale=scale, shift=shift, res=res, act=act)
-
-
-def _conv3x3_winograd_implicit(x: Tensor, wu_frag: Tensor, cout: int, dil: int, scale: Optional[Tensor], shift: Optional[Tensor],
-                               res: Optional[Tensor], act: int) -> Tensor:
-    return _ops.conv_wino_implicit(x, wu_frag, cout, dil, scale=scale, shift=shift, res=res, act=act)
 
 
 def _conv3x3_winograd44(x: Tensor, wu_frag: Tensor, cout: int, dil: int, scale: Optional[Tensor], shift: Optional[Tensor],
@@ -216,9 +206,7 @@ def _endp_topk_fake(endp_logits, K, clip):
 
 
 conv2d_mfma = _define('conv2d_mfma', _conv2d_mfma, _conv2d_mfma_fake)
-conv3x3_winograd = _define('conv3x3_winograd', _conv3x3_winograd, _conv3x3_fake)
-conv3x3_winograd_implicit = _define('conv3x3_winograd_implicit', _conv3x3_winograd_implicit, _conv3x3_fake)
-conv3x3_winograd44 = _define('conv3x3_winograd44', _conv3x3_winograd44, _conv3x3_fake)      # F(4x4,3x3): the FPN's default 3x3 route (round 4)
+conv3x3_winograd44 = _define('conv3x3_winograd44', _conv3x3_winograd44, _conv3x3_fake)      # F(4x4,3x3): the FPN's 3x3 / stride-1 route
 stem_conv7x7 = _define('stem_conv7x7', _stem, _stem_fake)
 maxpool3x3s2 = _define('maxpool3x3s2', _maxpool, _maxpool_fake)
 gn_stats = _define('gn_stats', _gn_stats, _gn_stats_fake)
@@ -340,6 +328,6 @@ def _polyline_assemble_fake(prop_conf, prop_v_ext, cls_offset, bi_seg_rows, endp
 
 polyline_assemble = _define('polyline_assemble', _polyline_assemble, _polyline_assemble_fake, device='cpu')
 
-OP_NAMES = ['conv2d_mfma', 'conv3x3_winograd', 'conv3x3_winograd_implicit', 'conv3x3_winograd44', 'stem_conv7x7', 'maxpool3x3s2', 'gn_stats', 'gn_relu_upsample',
+OP_NAMES = ['conv2d_mfma', 'conv3x3_winograd44', 'stem_conv7x7', 'maxpool3x3s2', 'gn_stats', 'gn_relu_upsample',
             'upsample_bilinear', 'layernorm_rows', 'attention', 'linear_mfma', 'tile_ingest', 'decode_proposals', 'decode_semantic',
             'decode_orient', 'endp_topk', 'bev_raster', 'fpn_encoder', 'vit_backbone', 'colprop_head', 'endp_cluster', 'polyline_assemble']

@@ -769,7 +769,7 @@ def test_torch_ops_registered_with_schema_and_fake_kernels():
         x = torch.empty((2, 16, 16, 64), device='cuda').permute(0, 3, 1, 2)
         y = torch.ops.lanemap_hip.conv2d_mfma(x, torch.empty((9, 128, 64), device='cuda'), 96, 3, 3, 2, 1, 1, None, None, None, 1)
         assert tuple(y.shape) == (2, 96, 8, 8) and y.stride(1) == 1
-        y = torch.ops.lanemap_hip.conv3x3_winograd(x, torch.empty((16, 128, 64), device='cuda'), 128, 2, None, None, None, 0)
+        y = torch.ops.lanemap_hip.conv3x3_winograd44(x, torch.empty((36, 8, 4, 64, 4), device='cuda'), 128, 2, None, None, None, 0)
         assert tuple(y.shape) == (2, 128, 16, 16)
         s = torch.ops.lanemap_hip.stem_conv7x7(torch.empty((3, 64, 48, 3), device='cuda', dtype=torch.uint8), torch.empty((7, 7, 3, 64), device='cuda'),
                                                torch.empty(64, device='cuda'), torch.empty(64, device='cuda'))
@@ -830,37 +830,33 @@ def test_stage_ops_take_weights_and_a_stage_name():
                                               torch.empty((1, 8, 288, 288), device='cuda'), w, n1)
 
 
-def test_winograd_weight_packers_layout_and_exact_split():
-    """Host-side packers of the implicit Winograd kernels (ops.pack_wino*): U = G g G^T against a direct fp64 evaluation, the
-    per-wave-fragment order documented in include/lanemap_hip.h, and the three-way bf16 split of U being EXACT (u1 + u2 + u3 == U bit
-    for bit, every piece representable in bf16)."""
+
+def test_winograd44_weight_packers_layout():
+    """Host-side packers of wino44_kernel (ops.pack_wino44*): U = G g G^T of F(4x4,3x3) against a direct fp64 evaluation (formed in fp64,
+    rounded to fp32 once), CoutP padded to the 64-channel N tile with zero rows, and the per-wave-fragment order documented in
+    include/lanemap_hip.h: wu_frag[xi][u][nt][lane][e] = U[xi][nt*32 + (lane & 31)][8 u + 4 (lane >> 5) + e]."""
     from lanemapping_amd import ops
     g = torch.Generator().manual_seed(11)
     cout, cin = 72, 48
     w = torch.randn((cout, cin, 3, 3), generator=g)
-    wu = ops.pack_wino(w)
-    assert wu.shape == (16, 128, cin) and float(wu[:, cout:].abs().max()) == 0.0
-    G = np.array([[1, 0, 0], [.5, .5, .5], [.5, -.5, .5], [0, 0, 1]])
-    want = np.einsum('ij,ocjk,lk->iloc', G, w.double().numpy(), G).reshape(16, cout, cin)
-    np.testing.assert_allclose(wu[:, :cout].numpy(), want, rtol=0, atol=2e-7 * np.abs(want).max())
-    wf = ops.pack_wino_fragments(wu)
-    assert wf.shape == (16, cin // 16, 4, 2, 64, 4)
+    wu = ops.pack_wino44(w)
+    assert wu.shape == (36, 128, cin) and wu.dtype == torch.float32 and float(wu[:, cout:].abs().max()) == 0.0
+    G = np.array([[1 / 4, 0, 0], [-1 / 6, -1 / 6, -1 / 6], [-1 / 6, 1 / 6, -1 / 6], [1 / 24, 1 / 12, 1 / 6], [1 / 24, -1 / 12, 1 / 6], [0, 0, 1]])
+    want = np.einsum('ij,ocjk,lk->iloc', G, w.double().numpy(), G).reshape(36, cout, cin)
+    np.testing.assert_allclose(wu[:, :cout].numpy(), want, rtol=6e-8, atol=1e-12)       # formed in fp64, ONE rounding to fp32 (half an ulp)
+    wf = ops.pack_wino44_fragments(wu)
+    assert wf.shape == (36, cin // 8, 4, 64, 4)
     rng = np.random.default_rng(3)
-    for _ in range(200):
-        xi, cs, nt, kk, lane, e = (int(rng.integers(0, n)) for n in (16, cin // 16, 4, 2, 64, 4))
-        assert float(wf[xi, cs, nt, kk, lane, e]) == float(wu[xi, nt * 32 + (lane & 31), cs * 16 + kk * 8 + (lane >> 5) * 4 + e])
-    w3 = ops.pack_wino_fragments_bf16x3(wu)
-    assert w3.dtype == torch.bfloat16 and w3.shape == (16, cin // 16, 4, 3, 64, 8)
-    # undo the fragment order: channel = cs*16 + 8*(e >> 2) + 4*khalf + (e & 3), lane = khalf*32 + row
-    back = torch.zeros((3, 16, 128, cin), dtype=torch.float64)
-    for khalf in range(2):
-        for e in range(8):
-            ch = torch.arange(cin // 16) * 16 + 8 * (e >> 2) + 4 * khalf + (e & 3)
-            blk = w3[:, :, :, :, khalf * 32:khalf * 32 + 32, e].double()          # xi, cs, nt, piece, row
-            back[:, :, :, ch] = blk.permute(3, 0, 2, 4, 1).reshape(3, 16, 128, cin // 16)
-    total = (back[0] + back[1] + back[2]).float()                                 # three bf16 values: their fp64 sum is exact
-    assert torch.equal(total, wu), float((total - wu).abs().max())
-    assert float(back[1].abs().max()) <= float(back[0].abs().max()) * 2.0 ** -7 and float(back[2].abs().max()) <= float(back[0].abs().max()) * 2.0 ** -15
+    for _ in range(300):
+        xi, u, nt, lane, e = (int(rng.integers(0, n)) for n in (36, cin // 8, 4, 64, 4))
+        assert float(wf[xi, u, nt, lane, e]) == float(wu[xi, nt * 32 + (lane & 31), 8 * u + 4 * (lane >> 5) + e])
+    # F(4x4,3x3) identity on one tile in fp64: A^T [(G g G^T) o (B^T d B)] A == the direct 3x3 correlation
+    Bt = np.array([[4, 0, -5, 0, 1, 0], [0, -4, -4, 1, 1, 0], [0, 4, -4, -1, 1, 0], [0, -2, -1, 2, 1, 0], [0, 2, -1, -2, 1, 0], [0, 4, 0, -5, 0, 1]], dtype=np.float64)
+    At = np.array([[1, 1, 1, 1, 1, 0], [0, 1, -1, 2, -2, 0], [0, 1, 1, 4, 4, 0], [0, 1, -1, 8, -8, 1]], dtype=np.float64)
+    d, k = rng.standard_normal((6, 6)), rng.standard_normal((3, 3))
+    y = At @ ((G @ k @ G.T) * (Bt @ d @ Bt.T)) @ At.T
+    ref = np.array([[(d[i:i + 3, j:j + 3] * k).sum() for j in range(4)] for i in range(4)])
+    np.testing.assert_allclose(y, ref, rtol=0, atol=1e-12)
 
 
 def test_bench_host_budget_per_rank():

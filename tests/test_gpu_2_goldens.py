@@ -252,6 +252,23 @@ def test_multi_stream_pipeline_bitwise_equals_single_stream(dev, net):
             assert np.array_equal(la, lb) and np.array_equal(ea, eb), f'tile {t}, repetition {rep}'
 
 
+# How many stability-screened tiles may differ from the reference in a SOFT endpoint decision (one the reference itself changes under a
+# 1e-4 perturbation: `margin_ok` below) before the test fails.  Not a silent budget: every run prints the count, and with
+# LANEMAP_PARITY_LOG=<file> appends it to that file (profiles/r5_g15_g17_exact_counts.txt holds the counts of the default route and of
+# LANEMAP_WINO_F44=0 on an MI355X).
+_SOFT_BUDGET = 2
+
+
+def _log_exact(tag, exact, seeds):
+    route = 'direct (LANEMAP_WINO_F44=0)' if os.environ.get('LANEMAP_WINO_F44', '1') == '0' else 'F(4x4) default'
+    line = (f'{tag} [{route}]: {sum(exact)} of {len(seeds)} stability-screened tiles identical to the reference in EVERY endpoint; soft-decision '
+            f'differences on seeds {[s for s, e in zip(seeds, exact) if not e]}')
+    print(line)
+    if os.environ.get('LANEMAP_PARITY_LOG'):
+        with open(os.environ['LANEMAP_PARITY_LOG'], 'a') as f:
+            f.write(line + '\n')
+
+
 def _g15_net(dev, synth_sd, g):
     from lanemapping_amd.boundary import build_net_from_config
     net = build_net_from_config('Proj_polyline_fpn_vit_vertex_2', device='cpu')
@@ -314,7 +331,8 @@ def test_end_to_end_stable_golden_g15(dev, golden, synth_sd):
     c = net.heads._compact
     res = TilePipeline(net).run_batch(x)
     exact = [_check_stable_golden(g, i, i, c, o, res, f'G15 tile {seeds[i]} (entry {i} of a batch of 16)') for i in range(len(seeds))]
-    assert sum(exact) >= len(seeds) - 2, f'only {sum(exact)} of {len(seeds)} tiles are identical to the reference in every endpoint'
+    _log_exact('G15', exact, seeds)
+    assert sum(exact) >= len(seeds) - _SOFT_BUDGET, f'only {sum(exact)} of {len(seeds)} tiles are identical to the reference in every endpoint'
 
 
 def test_headline_chain_golden_g17(dev, golden, synth_sd):
@@ -341,6 +359,7 @@ def test_headline_chain_golden_g17(dev, golden, synth_sd):
     c = net.heads._compact
     res = TilePipeline(net).run_batch(tiles)
     exact = [_check_stable_golden(g, i, i, c, o, res, f'G17 cloud {seeds[i]}') for i in range(len(seeds))]
+    _log_exact('G17', exact, seeds)
     assert sum(exact) >= len(seeds) - 1
 
 
@@ -464,9 +483,8 @@ def test_tile_pipeline_graph_replay_bit_identical(dev):
     assert len(graph._graphs) == 0
 
 
-@pytest.mark.parametrize('switch', ['LANEMAP_WINO_F44=0', 'LANEMAP_WINO_F44=0 LANEMAP_WINO_IMPLICIT=0', 'LANEMAP_WINOGRAD=0', 'LANEMAP_GRAPHS=1',
-                                    'LANEMAP_WINO_BF16X3=1', 'LANEMAP_WINO_F44=0 LANEMAP_WINO_DUAL=1',
-                                    'LANEMAP_WINO_F44=0 LANEMAP_WINO_IMPLICIT=0 LANEMAP_FUSE_UP_WINO=0', 'LANEMAP_MERGE_BRANCH_CONVS=0', 'LM_STEM_VALU=1 LM_GN_UP_LDS=0 LM_SMALL_CONV_VALU=1 LM_HEAD_TOKENS_GATHER=1 LM_HEAD_STAGE2_DIRECT=1'])
+@pytest.mark.parametrize('switch', ['LANEMAP_WINO_F44=0', 'LANEMAP_GRAPHS=1', 'LANEMAP_MERGE_BRANCH_CONVS=0',
+                                    'LM_STEM_VALU=1 LM_GN_UP_LDS=0 LM_SMALL_CONV_VALU=1 LM_HEAD_TOKENS_GATHER=1 LM_HEAD_STAGE2_DIRECT=1'])
 def test_goldens_under_every_advertised_switch(switch):
     """README's runtime switches are read once per process, so each non-default setting gets its own interpreter: the end-to-end
     goldens (G10: one full tile against the reference's outputs, margin-aware; G15: two stability-screened tiles whose final

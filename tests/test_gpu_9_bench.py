@@ -22,7 +22,7 @@ def test_bench_default_command(dev):
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    r = subprocess.run([sys.executable, os.path.join(root, 'bench.py'), '--steps', '2', '--warmup', '1', '--cpu-budget-s', '3', '--second-line'],
+    r = subprocess.run([sys.executable, os.path.join(root, 'bench.py'), '--steps', '2', '--warmup', '1', '--cpu-budget-s', '3'],
                        capture_output=True, text=True, timeout=900, cwd=root)
     assert r.returncode == 0, r.stderr[-2000:]
     lines = [l for l in r.stdout.strip().split('\n') if l.startswith('{')]
@@ -37,23 +37,16 @@ def test_bench_default_command(dev):
     rf = d['roofline']
     assert {'bound', 'achieved', 'peak', 'unit', 'frac', 'traffic', 'algorithmic_equiv_tflops', 'per_kernel'} <= set(rf)
     assert 0.0 < rf['frac'] <= 1.0 and abs(rf['frac'] - rf['achieved'] / rf['peak']) < 1e-9
-    split_run = os.environ.get('LANEMAP_WINO_BF16X3', '0') != '0'       # the suite itself run under the switch: that process IS the split line
-    assert split_run or rf['algorithmic_equiv_tflops'] >= rf['achieved']
+    f44 = os.environ.get('LANEMAP_WINO_F44', '1') != '0'                 # (the suite itself may run under the switch)
+    assert rf['algorithmic_equiv_tflops'] >= rf['achieved'] and abs(rf['frac_survey_8d'] - rf['algorithmic_equiv_tflops'] / rf['peak']) < 1e-9
     assert all(0.0 <= v['frac'] <= 1.0 for v in rf['per_kernel'].values())
     rr = d['raster_roofline']
-    assert rr['bound'] == 'hbm' and 0.1 < rr['frac'] < 1.0
+    # frac = the bytes the design moves (u8 tile); frac_survey_8d = SURVEY 8(d)'s numerator (f32 tile): same time, more bytes
+    assert rr['bound'] == 'hbm' and 0.1 < rr['frac'] < 1.0 and rr['frac'] < rr['frac_survey_8d'] < 1.0
+    assert abs(rr['frac'] - rr['achieved'] / rr['peak']) < 1e-9
     assert {'value', 'unit', 'cores', 'kind', 'sample'} <= set(d['cpu_baseline']) and d['cpu_baseline']['value'] > 0
-    # the declared second line: the same workload with the split-precision Winograd GEMMs, priced against the bf16 peak; never the headline
-    if split_run:
-        assert d['dtype'] == 'bf16x3' and 'second_line' not in d and rf['peak'] > 1000
-        return
-    assert d['dtype'] == 'f32'
-    sl = d['second_line']
-    assert 'error' not in sl, sl
-    assert sl['dtype'] == 'bf16x3' and sl['steps'] == 2 and sl['unit'] == d['unit'] and sl['value'] > 10
-    assert 'bf16x3' in sl['roofline']['dominant_kernel'] and sl['roofline']['peak'] > 1000 and 0.0 < sl['roofline']['frac'] <= 1.0
-    # (round 3 asserted that the split line's Winograd class is the faster one; since round 4 the exact-fp32 headline runs F(4x4,3x3))
-    assert sl['winograd_ms_per_step'] > 0 and rf['winograd_ms_per_step'] > 0 and 'wino44_kernel' in rf['per_kernel']
+    assert d['dtype'] == 'f32' and 'second_line' not in d
+    assert (rf['winograd_ms_per_step'] > 0) == f44 and ('wino44_kernel' in rf['per_kernel']) == f44
 
 
 def test_bench_self_launch_two_ranks(dev):
@@ -155,7 +148,7 @@ def test_bench_other_workloads(dev, workload):
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     r = subprocess.run([sys.executable, os.path.join(root, 'bench.py'), '--workload', workload, '--steps', '2', '--warmup', '1',
-                        '--no-cpu-baseline', '--no-second-line'], capture_output=True, text=True, timeout=900, cwd=root)
+                        '--no-cpu-baseline'], capture_output=True, text=True, timeout=900, cwd=root)
     assert r.returncode == 0, r.stderr[-2000:]
     d = json.loads([l for l in r.stdout.strip().split('\n') if l.startswith('{')][-1])
     assert d['value'] > 10 and 0.0 < d['roofline']['frac'] <= 1.0 and d['config']['tiles_per_step_per_gpu'] == 8
@@ -169,7 +162,7 @@ def test_bench_hip_graphs_four_streams(dev):
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     r = subprocess.run([sys.executable, os.path.join(root, 'bench.py'), '--workload', 'tiles', '--graphs', '--streams', '4', '--steps', '3', '--warmup', '1',
-                        '--no-cpu-baseline', '--no-second-line'], capture_output=True, text=True, timeout=900, cwd=root)
+                        '--no-cpu-baseline'], capture_output=True, text=True, timeout=900, cwd=root)
     assert r.returncode == 0, r.stderr[-2000:]
     d = json.loads([l for l in r.stdout.strip().split('\n') if l.startswith('{')][-1])
     assert d['value'] > 10 and d['config']['hip_graphs'] is True and d['config']['streams'] == 4

@@ -50,22 +50,3 @@ for cout in (8, 1):
         torch.cuda.synchronize()
         res[name] = round(e0.elapsed_time(e1) / 20, 3)
     print(f'128 -> {cout}:', res)
-
-# s4 path: GN + ReLU + x2 upsample followed by the Winograd input transform vs the fused transform (256 ch, 144^2 -> 288^2)
-t4 = ops.new_act(B, 256, 144, 144, dev).normal_()
-st4 = ops.gn_stats(t4)
-g4, b4 = torch.rand(256, device=dev), torch.rand(256, device=dev)
-res = {}
-for name, fn in (('upsample + transform', lambda: ops.wino_transform(ops.gn_relu_upsample(t4, st4, g4, b4, (288, 288)), 1)),
-                 ('fused transform', lambda: ops.wino_transform_gn_up2(t4, st4, g4, b4))):
-    for _ in range(3):
-        fn()
-    torch.cuda.synchronize()
-    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    e0.record()
-    for _ in range(20):
-        fn()
-    e1.record()
-    torch.cuda.synchronize()
-    res[name] = round(e0.elapsed_time(e1) / 20, 3)
-print('s4 -> V:', res)

@@ -5,7 +5,6 @@ set -e
 cd "$(dirname "$0")/.."
 NAME=$1; SRC=$2; FLAGS=$3
 EXTRA=""
-[ "$SRC" = conv_wino.hip ] && EXTRA="-fno-slp-vectorize"
 [ "$SRC" = conv_wino44.hip ] && EXTRA="-fno-slp-vectorize"
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -fvisibility=hidden $EXTRA $FLAGS -x hip -c lanemapping_amd/csrc/$SRC -o tools/probes/${SRC}_$NAME.o
 OBJS=$(ls lanemapping_amd/build/*.o | grep -v "/$SRC.o")

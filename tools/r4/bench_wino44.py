@@ -1,4 +1,4 @@
-"""Per-layer timing of the Winograd F(4x4,3x3) kernel (csrc/conv_wino44.hip) against the shipped F(2x2) kernels (PIPE / DUAL) on the
+"""Per-layer timing of the Winograd F(4x4,3x3) kernel (csrc/conv_wino44.hip) against the direct implicit-GEMM kernel (csrc/conv_mfma.hip) on the
 FPN's layer shapes, plus error of both against an fp64 convolution on a crop.  Usage: python tools/r4/bench_wino44.py [B] [reps]"""
 import os
 import sys
@@ -36,11 +36,11 @@ for cin, cout, hw, dil in SHAPES:
     w = (torch.randn((cout, cin, 3, 3), generator=g) / (cin * 9) ** 0.5).to(dev)
     sc, sh = (torch.rand(cout, generator=g) + 0.5).to(dev), torch.randn(cout, generator=g).to(dev)
     res = ops.new_act(B, cout, hw, hw, dev).normal_()
-    wf2 = ops.pack_wino_fragments(ops.pack_wino(w))
+    wp = ops.pack_mfma(w)
     wf4 = ops.pack_wino44_fragments(ops.pack_wino44(w))
     y2 = ops.new_act(B, cout, hw, hw, dev)
     y4 = ops.new_act(B, cout, hw, hw, dev)
-    t2 = timed(lambda: ops.conv_wino_implicit(x, wf2, cout, dil, scale=sc, shift=sh, res=res, act=ops.ACT_RELU, out=y2))
+    t2 = timed(lambda: ops.conv_mfma(x, wp, cout, 3, 3, 1, dil, dil, scale=sc, shift=sh, res=res, act=ops.ACT_RELU, out=y2))
     t4 = timed(lambda: ops.conv_wino44(x, wf4, cout, dil, scale=sc, shift=sh, res=res, act=ops.ACT_RELU, out=y4))
     # error against fp64 on one image crop (the whole tensor would take the CPU minutes)
     c = 64
@@ -52,6 +52,6 @@ for cin, cout, hw, dil in SHAPES:
     flops = 2.0 * B * hw * hw * cin * cout * 9
     tiles = ops.lib().lm_winograd44_tiles(B, hw, hw, dil)
     ex = 2.0 * 36 * tiles * cin * cout
-    out.append(f'{cin}->{cout} d{dil}@{hw} B{B}: F(2x2) {t2:.3f} ms, F(4x4) {t4:.3f} ms (x{t2 / t4:.2f}; executed {ex / t4 / 1e9:.1f} TFLOP/s = {ex / t4 / 1e9 / 157.3:.2f} of peak, '
+    out.append(f'{cin}->{cout} d{dil}@{hw} B{B}: direct {t2:.3f} ms, F(4x4) {t4:.3f} ms (x{t2 / t4:.2f}; executed {ex / t4 / 1e9:.1f} TFLOP/s = {ex / t4 / 1e9 / 157.3:.2f} of peak, '
                f'direct-equivalent {flops / t4 / 1e9:.0f}) err vs fp64 {e2:.1e} / {e4:.1e} (scale {float(want.abs().max()):.1f})')
     print(out[-1], flush=True)

@@ -1,5 +1,5 @@
 """Whole-network error of the HIP path against the oracle (torch-CPU fp32 restatement, bit-identical to the reference on the goldens) under
-the 3x3-convolution route selected by the environment (default F(4x4); LANEMAP_WINO_F44=0: F(2x2); LANEMAP_WINOGRAD=0: direct MFMA).
+the 3x3-convolution route selected by the environment (default F(4x4); LANEMAP_WINO_F44=0: direct MFMA).
 Prints, per raw output, max |err|, the tensor scale and err / scale, and the decode-level errors on the G15 weight set (absolute)."""
 import os
 import sys
@@ -15,7 +15,7 @@ from lanemapping_amd.boundary import build_net_from_config  # noqa: E402
 from oracle import net_ref, decode_ref  # noqa: E402
 
 dev = torch.device('cuda:0')
-route = 'direct' if os.environ.get('LANEMAP_WINOGRAD', '1') == '0' else ('F(2x2)' if os.environ.get('LANEMAP_WINO_F44', '1') == '0' else 'F(4x4)')
+route = 'direct' if os.environ.get('LANEMAP_WINO_F44', '1') == '0' else 'F(4x4)'
 for gains, label in (({}, 'seeded weights (G10 set)'), ({'heads.offset2.2.weight': 0.02, 'heads.offset2.2.bias': 0.02}, 'G15 weight set')):
     net = build_net_from_config('Proj_polyline_fpn_vit_vertex_2', device='cpu')
     synth.fill_module_(net, 2021)

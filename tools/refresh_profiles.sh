@@ -1,14 +1,13 @@
 #!/bin/bash
-# Re-measure the committed evidence (round 4): bench lines (headline = fused, tiles, rowref, lidar, F(2x2) A/B, the opt-in second line),
+# Re-measure the committed evidence (round 5): bench lines (headline = fused, tiles, rowref, lidar, direct-kernel A/B),
 # raster micro-bench, per-layer Winograd table, phase profile, rocprofv3 kernel stats of the default command and of --streams 1
-# -> gpurun_out/refresh (copy what is to be judged into profiles/ as r4_*)
+# -> gpurun_out/refresh (copy what is to be judged into profiles/ as r5_*)
 R=${GRAFT_REPO_ROOT:?run through gpurun (GRAFT_REPO_ROOT is the repo copy on the GPU box)}
 O=$R/gpurun_out/refresh
 mkdir -p $O
 cd $R
 python bench.py --steps 10 --warmup 3 2>/dev/null | tail -1 > $O/bench_config3_fused.json
-LANEMAP_WINO_F44=0 python bench.py --steps 10 --warmup 3 --no-cpu-baseline 2>/dev/null | tail -1 > $O/bench_config3_fused_f22.json
-python bench.py --steps 10 --warmup 3 --no-cpu-baseline --second-line 2>/dev/null | tail -1 > $O/bench_config3_fused_second_line.json
+LANEMAP_WINO_F44=0 python bench.py --steps 10 --warmup 3 --no-cpu-baseline 2>/dev/null | tail -1 > $O/bench_config3_fused_direct.json
 python bench.py --workload tiles --steps 10 --warmup 3 --no-cpu-baseline 2>/dev/null | tail -1 > $O/bench_config2.json
 python bench.py --workload rowref --steps 5 --warmup 2 --no-cpu-baseline 2>/dev/null | tail -1 > $O/bench_config4_rowref.json
 python bench.py --workload lidar --steps 5 --warmup 2 --no-cpu-baseline 2>/dev/null | tail -1 > $O/bench_config5_lidar.json
