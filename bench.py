@@ -136,8 +136,8 @@ def host_budget(world, local_world, local_rank, cores_avail, allowed, host_cores
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
-    ap.add_argument('--steps', type=int, default=10)
-    ap.add_argument('--warmup', type=int, default=3)
+    ap.add_argument('--steps', type=int, default=100, help='timed steps (default 100: a >= 4 s timed region; windows of 20 steps are also reported)')
+    ap.add_argument('--warmup', type=int, default=5)
     ap.add_argument('--cpu-budget-s', type=float, default=25.0)
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--host-threads', type=int, default=None, help='post-processing pool threads per pipeline (default 8; max(1, K - 1) under --host-cores K)')
@@ -200,7 +200,7 @@ def main():
     dev = torch.device('cuda', dev_index)
     torch.cuda.set_device(dev)
 
-    from lanemapping_amd import synth, ops, shard
+    from lanemapping_amd import synth, ops, shard, trace
     from lanemapping_amd._lib import lib
     from lanemapping_amd.boundary import build_net_from_config
     from lanemapping_amd.pipeline import TilePipeline
@@ -273,7 +273,8 @@ def main():
                     main.wait_event(d[par])
             a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             a.record()
-            ops.bev_raster_batch(points, offs, rpar, out_u8=cur, u8_only=True)
+            with trace.stage('raster'):
+                ops.bev_raster_batch(points, offs, rpar, out_u8=cur, u8_only=True)
             b.record()
             ready = b
             if rast['on']:
@@ -341,14 +342,22 @@ def main():
         dist.barrier()
     rast['on'] = True
     prof['on'] = nstream == 1 and not args.graphs      # with >1 streams kernels overlap (and a graph replay bypasses the hook): the roofline is measured in its own pass below
+    trace.push('timed_steps')
+    marks = []                      # host clock after every 20th step (no synchronisation added: a step returns when the PREVIOUS batch's tiles are done)
     t0 = time.perf_counter()
-    for _ in range(args.steps):
+    for i_ in range(args.steps):
         step()
+        if (i_ + 1) % 20 == 0:
+            marks.append(time.perf_counter())
     last = drain()
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
     dt = time.perf_counter() - t0
+    trace.pop()
+    # tiles/s of every complete 20-step window inside the timed region (this rank): separates a 1 % change from box noise
+    win = [20 * batch * world / (b_ - a_) for a_, b_ in zip([t0] + marks[:-1], marks)]
+    windows = ({'steps_per_window': 20, 'n': len(win), 'min': min(win), 'median': float(np.median(win)), 'max': max(win)} if len(win) >= 2 else None)
     prof['on'] = False
     rast['on'] = False
     if world > 1:
@@ -505,6 +514,7 @@ def main():
         'config': {'workload': workload,
                    'tiles_per_step_per_gpu': batch, 'lines_per_tile': n_lines, 'host_threads': args.host_threads, 'streams': nstream, 'hip_graphs': bool(args.graphs and args.workload in ('fused', 'tiles', 'rowref')),      # (the LiDAR path sizes launches on the host: no capture)
                   
+                   'windows_tiles_per_s': windows,
                    'stream_check': stream_check, 'gather_check': gather_check, 'raster_check': raster_check,
                    'host_cores_per_rank': host_cores_per_rank, 'host_cores_pinned': args.host_cores is not None,
                    'host_cores_auto': host_cores_auto,       # N > 1 without --host-cores: usable cores / ranks on the node

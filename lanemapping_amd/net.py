@@ -7,7 +7,7 @@ losses are out of scope).  `Detector1stage` keeps the dead `conv1 = Conv2d(144,1
 import torch
 import torch.nn as nn
 
-from . import ops
+from . import ops, trace
 from .registry import NET, build_pcencoder, build_backbone, build_heads
 
 
@@ -30,15 +30,19 @@ class Detector1stage(nn.Module):
             proj = batch['proj']            # [B,3,H,W] f32 (the reference's tensor) or [B,H,W,3] uint8 (rasteriser / PNG output)
             B, H, W = (proj.shape[0], proj.shape[1], proj.shape[2]) if proj.dtype == torch.uint8 else (proj.shape[0], proj.shape[2], proj.shape[3])
             col = ops.new_act(B, 16, H // 4, W // 4, proj.device)
-            fea, fea_up, bi_seg, endp_est = self.pcencoder.fpn(proj, fea_up_out=col[:, 8:16])
+            with trace.stage('pcencoder'):
+                fea, fea_up, bi_seg, endp_est = self.pcencoder.fpn(proj, fea_up_out=col[:, 8:16])
         else:
-            fea, fea_up, bi_seg, endp_est = self.pcencoder(batch)
+            with trace.stage('pcencoder'):
+                fea, fea_up, bi_seg, endp_est = self.pcencoder(batch)
         if self.cfg.vit_seg == True:   # noqa: E712  (the reference compares with == True)
-            fea = self.backbone(fea)
-        if self.cfg.heads.type == 'RowSharNotReducRef':
-            out = self.heads(fea)
-        else:
-            out = self.heads(fea, fea_up, endp_est, col=col) if fused else self.heads(fea, fea_up, endp_est)
+            with trace.stage('backbone'):
+                fea = self.backbone(fea)
+        with trace.stage('heads'):
+            if self.cfg.heads.type == 'RowSharNotReducRef':
+                out = self.heads(fea)
+            else:
+                out = self.heads(fea, fea_up, endp_est, col=col) if fused else self.heads(fea, fea_up, endp_est)
         out['semantic_seg'] = bi_seg
         out['endp_est'] = endp_est
         return out

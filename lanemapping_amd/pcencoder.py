@@ -17,7 +17,7 @@ import os
 import torch
 import torch.nn as nn
 
-from . import ops
+from . import ops, trace
 from .registry import PCENCODER
 from .packing import PackedModule
 
@@ -230,14 +230,17 @@ class FPNEncoder(PackedModule):
             B, H, W, _ = x.shape
         else:
             B, _, H, W = x.shape
-        c1 = ops.maxpool3x3s2(ops.stem(x, P['stem_w'], P['stem_s'], P['stem_b']))
+        with trace.stage('fpn.stem'):
+            c1 = ops.maxpool3x3s2(ops.stem(x, P['stem_w'], P['stem_s'], P['stem_b']))
         feats = []
         t = c1
         for lname in ('layer1', 'layer2', 'layer3'):
-            for i, blk in enumerate(getattr(self, lname)):
-                t = self._block(t, P, f'{lname}.{i}', blk)
+            with trace.stage('fpn.' + lname):
+                for i, blk in enumerate(getattr(self, lname)):
+                    t = self._block(t, P, f'{lname}.{i}', blk)
             feats.append(t)
         c2, c3, c4 = feats
+        trace.push('fpn.topdown')
         fea = ops.conv_mfma(c4, P['out.w'], self.out.out_channels) if self.out is not None else None
         p4 = ops.conv_mfma(c4, P['toplayer.w'], 256, shift=P['toplayer.b'])
         # _upsample_add: the coarse map enters the lateral 1x1 convolution's epilogue through bilinear interpolation (a plain residual
@@ -253,6 +256,8 @@ class FPNEncoder(PackedModule):
         p4 = self._conv3(p4, P, 'smooth1', 256)
         p3 = self._conv3(p3, P, 'smooth2', 256)
         p2 = self._conv3(p2, P, 'smooth3', 256)
+        trace.pop()
+        trace.push('fpn.semantic')
         pre_a, pre_b = [None, None], [None, None]
         if 'semantic_branch_ab.wq' in P:
             ch = self.semantic_branch.out_channels
@@ -273,6 +278,7 @@ class FPNEncoder(PackedModule):
         endp288 = self._semantic(P, p2, p3, p4, 'conv3', 'gn22', 'semantic_branch2', 'gn21',
                                  (P['output_layer_endp.w'], P['output_layer_endp.b'], 1, None), pre_b, b4)
         endp = ops.upsample_to_chw(endp288, (H, W))
+        trace.pop()
         return fea, fea_up, bi_seg, endp
 
 

@@ -13,7 +13,7 @@ from concurrent.futures import ThreadPoolExecutor
 import numpy as np
 import torch
 
-from . import decode, hostpost, ops, torch_ops
+from . import decode, hostpost, ops, torch_ops, trace
 from ._lib import LanemapHipError
 
 
@@ -32,20 +32,73 @@ class TilePipeline:
             raise NotImplementedError(f'TilePipeline has no decode / polyline tail for heads.type={net.cfg.heads.type!r}')
         self.pool = ThreadPoolExecutor(max_workers=host_threads)
         self._pending = None
+        self._arenas = collections.OrderedDict()      # input shape -> ops.OutputArena (decode outputs of a batch in one device block)
+        self._slots, self._slot_next = [], 0           # ring of pinned staging blocks
         self.host_seconds = 0.0      # accumulated wall time of the per-tile host tasks (all threads) and their count
         self.host_tiles = 0
+
+    HOST_SLOTS = 3          # pinned staging blocks per pipeline (batch k is being filled while the pool still reads batch k - 1)
+
+    def _arena_for(self, proj):
+        """The read-back arena of this input shape (ops.OutputArena: the decode outputs of a batch in one device block)."""
+        key = (tuple(proj.shape), proj.dtype, proj.device) if torch.is_tensor(proj) else None
+        if key is None:
+            return None                                   # LiDAR point lists / batch dicts: per-tensor copies
+        a = self._arenas.get(key)
+        if a is None:
+            a = self._arenas[key] = ops.OutputArena()
+            while len(self._arenas) > self.MAX_GRAPHS:
+                self._arenas.popitem(last=False)
+        return a
+
+    def _host_slot(self, nbytes):
+        """Next pinned staging block of the ring (allocated once per pipeline, grown when a larger batch arrives); waits for the host
+        tasks that still read it - with a pipeline depth of 1 they finished two batches ago."""
+        if not self._slots:
+            self._slots = [{'block': None, 'futs': []} for _ in range(self.HOST_SLOTS)]
+        slot = self._slots[self._slot_next]
+        self._slot_next = (self._slot_next + 1) % self.HOST_SLOTS
+        for f in slot['futs']:
+            f.exception()                                 # (waits; the caller sees errors through its own futures)
+        slot['futs'] = []
+        if slot['block'] is None or slot['block'].numel() < nbytes:
+            slot['block'] = torch.empty(max(nbytes, 1), dtype=torch.uint8, pin_memory=True)
+        return slot
 
     def _gpu_stage(self, proj):
         if self.use_graph and torch.is_tensor(proj):      # (a tile tensor: the LiDAR path sizes its launches on the host and cannot be captured)
             dev, keep, crop = self._replay(proj)
         else:
-            dev, keep, crop = self._device_part(proj)
-        host = {k: torch.empty(v.shape, dtype=v.dtype, pin_memory=True) for k, v in dev.items()}
-        for k in dev:
-            host[k].copy_(dev[k], non_blocking=True)
+            arena = self._arena_for(proj)
+            with ops.output_arena(arena):
+                dev, keep, crop = self._device_part(proj)
+            if arena is not None:
+                arena.commit(proj.device)
+        # device -> pinned host: ONE copy when every result is a view of one arena block (every batch after the first of its shape),
+        # else one copy per tensor; the staging memory comes from the ring either way (no pinned allocation per batch)
+        views = []
+        stores = {v.untyped_storage().data_ptr() for v in dev.values()}
+        packed = len(stores) == 1 and len(dev) > 1
+        off = 0
+        for k, v in dev.items():
+            nb = v.numel() * v.element_size()
+            o = v.storage_offset() * v.element_size() if packed else (off + 255) // 256 * 256
+            views.append((k, o, nb, v))
+            off = o + nb
+        total = max(o + nb for _, o, nb, _ in views)
+        slot = self._host_slot(total)
+        hb = slot['block']
+        host = {k: hb[o:o + nb].view(v.dtype).view(v.shape) for k, o, nb, v in views}
+        if packed and all(v.is_contiguous() for v in dev.values()):
+            first = next(iter(dev.values()))
+            src = torch.empty(0, dtype=torch.uint8, device=first.device).set_(first.untyped_storage(), 0, (total,))
+            hb[:total].copy_(src, non_blocking=True)
+        else:
+            for k in dev:
+                host[k].copy_(dev[k], non_blocking=True)
         ev = torch.cuda.Event()
         ev.record()
-        return host, ev, keep, crop
+        return host, ev, keep, crop, slot
 
     MAX_GRAPHS = 4          # captured graphs kept per pipeline (each one pins a private activation pool: ~1 GB per tile of its batch)
 
@@ -75,10 +128,13 @@ class TilePipeline:
         if ent is None:
             static_in = torch.empty_like(proj)
             static_in.copy_(proj)
-            self._device_part(static_in)
+            arena = ops.OutputArena()                 # private to this graph: its kernels keep writing into this block
+            with ops.output_arena(arena):
+                self._device_part(static_in)
+            arena.commit(proj.device)
             torch.cuda.synchronize()
             graph = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(graph, stream=torch.cuda.Stream(device=proj.device)):
+            with torch.cuda.graph(graph, stream=torch.cuda.Stream(device=proj.device)), ops.output_arena(arena):
                 out = self._device_part(static_in)
             ent = (graph, static_in, out, wkey)
             self._graphs[key] = ent
@@ -103,11 +159,13 @@ class TilePipeline:
             crop = 0
         else:
             # decode kernels as dispatcher-visible custom ops (torch.ops.lanemap_hip.*, torch_ops.py)
+            trace.push('decode')
             prop_conf, v_ext, cls_conf, cls_idx, cls_offset = torch_ops.decode_proposals(
                 raw['proposal_conf'], raw['ext2'], raw['cls2'], raw['offset2'], float(cfg.exist_thre), heads.prop_width, heads.prop_half_buff)
             orient = torch_ops.decode_orient(raw['orient'])
             sem, biseg, rows = torch_ops.decode_semantic(raw['semantic_seg'], float(cfg.coor_thre))
             idx, score, status = torch_ops.endp_topk(raw['endp_est'], decode.TOPK, decode.CLIP)
+            trace.pop()
             dev = {'prop_conf': prop_conf, 'v_ext': v_ext, 'cls_offset': cls_offset, 'rows': rows, 'idx': idx, 'status': status}
             keep = (raw, sem, biseg, orient, cls_conf, cls_idx, dev)      # keep device buffers alive until the copies land
             crop = raw['endp_est'].shape[-1]
@@ -134,12 +192,14 @@ class TilePipeline:
         return (lanes, kept, pts) if self.with_decode_endp else (lanes, kept)
 
     def _finish(self, pending):
-        host, ev, keep, W = pending
+        host, ev, keep, W, slot = pending
         ev.synchronize()
         if not self.rowref and int(host['status'].max()) != 0:
             raise LanemapHipError('endpoint top-K candidate overflow')   # guard only: the compaction is tie-safe (<= K candidates)
         B = next(iter(host.values())).shape[0]
-        return [self.pool.submit(self._tile_task, host, b, W - 2 * decode.CLIP) for b in range(B)]
+        futs = [self.pool.submit(self._tile_task, host, b, W - 2 * decode.CLIP) for b in range(B)]
+        slot['futs'] = futs                               # the staging block is reused only after these have run
+        return futs
 
     def submit(self, proj):
         """Enqueue one batch; returns the futures of the PREVIOUS batch's tiles (software pipeline depth 1)."""
