@@ -145,6 +145,12 @@ long lm_endp_topk_workspace_bytes(int B);
 int lm_endp_topk(void* stream, const float* endp_logit, void* workspace, int* out_idx, float* out_score,
                  int* out_status, int B, int H, int W, int clip, int K);
 
+/* Gathers up to 8 device segments (bytes[s] % 4 == 0) into one block at dst + dst_offsets[s] (% 16 == 0): the decode outputs the host
+ * post-processing reads (prop_conf, v_ext, cls_offset, rows, idx, status) then travel in ONE device-to-host copy per batch - the per-batch
+ * body of Runner.infer_lane_coordinate_endpoint_semantics (baseline/engine/runner.py:725-740) moves them with one .cpu() per tensor. */
+int lm_pack_segments(void* stream, int n, const void* const* src, const long* bytes, const long* dst_offsets, void* dst);
+
+
 /* ---- LAS -> BEV rasteriser and tile ingest (build-defined, parity unpinned: the reference has no rasteriser;
  * pinned pieces: datasets/laserlane_proposals.py:85-98,618-636; utils/coor_img2pc.py:127-183;
  * utils/io_utils.py:125-150) */

@@ -68,6 +68,7 @@ SIGNATURES = {
     'lm_decode_semantic': (i32, [vp, vp, vp, vp, vp, i32, i32, i32, f32, i32]),
     'lm_endp_topk_workspace_bytes': (i64, [i32]),
     'lm_endp_topk': (i32, [vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32]),
+    'lm_pack_segments': (i32, [vp, i32, vp, vp, vp, vp]),
     'lm_bev_raster_workspace_bytes': (i64, [i32, i64, i32, i32]),
     'lm_bev_raster_batch': (i32, [vp, vp, C.POINTER(i64), C.POINTER(LmRasterParams), i32, vp, i64, vp, vp, i32, i32]),
     'lm_tile_ingest_u8': (i32, [vp, vp, vp, i32, i32, i32, i32]),

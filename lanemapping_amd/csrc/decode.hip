@@ -15,6 +15,8 @@
 // Ties: argmax -> lowest index; equal scores -> lower flat index first.
 #include "common.h"
 
+#define LM_PACK_MAX_SEGMENTS 8
+
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 namespace {
@@ -325,6 +327,34 @@ __global__ __launch_bounds__(1024) void topk_sort_kernel(TopkParams p, int* __re
     if (threadIdx.x == 0) out_status[b] = (cnt > (unsigned)CAP) ? 1 : 0;   // cannot happen since the tie-safe compaction (<= K candidates); kept as a guard
 }
 
+
+// ---- read-back packing: the decode outputs the host consumes (prop_conf, v_ext, cls_offset, rows, idx, status) gathered into ONE block, so a
+// batch costs one device-to-host copy instead of six.  Segment s = bytes[s] (a multiple of 4) from src[s] to dst + offs[s] (256-byte aligned).
+struct PackArgs {
+    const void* src[LM_PACK_MAX_SEGMENTS];
+    long offs[LM_PACK_MAX_SEGMENTS];
+    long words[LM_PACK_MAX_SEGMENTS];       // 4-byte words
+    long first_chunk[LM_PACK_MAX_SEGMENTS + 1];   // prefix sum of 16-byte chunks (the last chunk of a segment may be partial)
+    int n;
+};
+
+__global__ __launch_bounds__(256) void pack_segments_kernel(PackArgs a, unsigned char* __restrict__ dst) {
+    const long c = (long)blockIdx.x * 256 + threadIdx.x;
+    if (c >= a.first_chunk[a.n]) return;
+    int s = 0;
+#pragma unroll
+    for (int k = 1; k < LM_PACK_MAX_SEGMENTS; ++k) s += (k < a.n && c >= a.first_chunk[k]) ? 1 : 0;
+    const long w0 = (c - a.first_chunk[s]) * 4;
+    const unsigned* src = static_cast<const unsigned*>(a.src[s]) + w0;
+    unsigned* out = reinterpret_cast<unsigned*>(dst + a.offs[s]) + w0;
+    const long left = a.words[s] - w0;
+    if (left >= 4 && ((reinterpret_cast<unsigned long long>(src) & 15ull) == 0)) {
+        *reinterpret_cast<uint4*>(out) = *reinterpret_cast<const uint4*>(src);
+    } else {
+        for (int e = 0; e < 4 && e < left; ++e) out[e] = src[e];
+    }
+}
+
 }  // namespace
 
 LM_API int lm_decode_proposals(void* stream, const float* pconf, const float* ext2, const float* cls2, const float* off2,
@@ -391,6 +421,26 @@ LM_API int lm_endp_topk(void* stream, const float* endp_logit, void* workspace, 
     hipLaunchKernelGGL(topk_ties_kernel, dim3(B), dim3(1024), 0, s, p);
     LM_LAUNCH_CHECK();
     hipLaunchKernelGGL(topk_sort_kernel, dim3(B), dim3(1024), 0, s, p, out_idx, out_score, out_status);
+    LM_LAUNCH_CHECK();
+    return LM_OK;
+}
+
+LM_API int lm_pack_segments(void* stream, int n, const void* const* src, const long* bytes, const long* dst_offsets, void* dst) {
+    LM_REQUIRE(n >= 1 && n <= LM_PACK_MAX_SEGMENTS && src && bytes && dst_offsets && dst, "pack_segments: 1..%d segments", LM_PACK_MAX_SEGMENTS);
+    PackArgs a;
+    a.n = n;
+    a.first_chunk[0] = 0;
+    for (int s = 0; s < LM_PACK_MAX_SEGMENTS; ++s) {
+        const bool on = s < n;
+        LM_REQUIRE(!on || (src[s] && bytes[s] >= 0 && bytes[s] % 4 == 0 && dst_offsets[s] % 16 == 0), "pack_segments: segment %d: bytes %% 4, offset %% 16", s);
+        a.src[s] = on ? src[s] : nullptr;
+        a.offs[s] = on ? dst_offsets[s] : 0;
+        a.words[s] = on ? bytes[s] / 4 : 0;
+        a.first_chunk[s + 1] = a.first_chunk[s] + (a.words[s] + 3) / 4;
+    }
+    const long chunks = a.first_chunk[n];
+    if (chunks == 0) return LM_OK;
+    hipLaunchKernelGGL(pack_segments_kernel, dim3(lm_cdiv(chunks, 256)), dim3(256), 0, (hipStream_t)stream, a, static_cast<unsigned char*>(dst));
     LM_LAUNCH_CHECK();
     return LM_OK;
 }

@@ -427,66 +427,34 @@ def head_proposal_conf(tok, wt, bias, B, P):
 
 
 # ------------------------------------------------------------------------------- decode
-class OutputArena:
-    """One contiguous device block for the decode outputs the host reads back (prop_conf, v_ext, cls_offset, rows, idx, status): the
-    pipeline then needs ONE device-to-host copy per batch instead of six.  The first pass measures (outputs are ordinary tensors, `need`
-    accumulates); `commit()` allocates the block; later passes carve 256-byte aligned views out of it in call order.  Stream-ordered
-    reuse: the copy of batch k and the kernels of batch k + 1 that overwrite the block are queued on the same stream."""
-
-    def __init__(self):
-        self.block, self.need, self.off = None, 0, 0
-
-    def begin(self):
-        self.off = 0
-
-    def take(self, shape, dtype, device):
-        n = 1
-        for d in shape:
-            n *= int(d)
-        nbytes = n * torch.empty((), dtype=dtype).element_size()
-        off = (self.off + 255) // 256 * 256
-        self.off = off + nbytes
-        self.need = max(self.need, self.off)
-        if self.block is None or self.off > self.block.numel() or self.block.device != device:
-            return torch.empty(shape, device=device, dtype=dtype)       # measuring pass (or a larger batch than the block was made for)
-        return self.block[off:off + nbytes].view(dtype).view(shape)
-
-    def commit(self, device):
-        if self.need and (self.block is None or self.block.numel() < self.need or self.block.device != device):
-            self.block = torch.empty(self.need, device=device, dtype=torch.uint8)
-
-
-_arena_tls = __import__('threading').local()
-
-
-class output_arena:
-    def __init__(self, arena):
-        self.arena = arena
-
-    def __enter__(self):
-        _arena_tls.cur = self.arena
-        if self.arena is not None:
-            self.arena.begin()
-        return self.arena
-
-    def __exit__(self, *exc):
-        _arena_tls.cur = None
-        return False
-
-
-def _readback_empty(shape, dtype, device):
-    a = getattr(_arena_tls, 'cur', None)
-    return torch.empty(shape, device=device, dtype=dtype) if a is None else a.take(shape, dtype, device)
+def pack_readback(tensors, block=None):
+    """Gather device tensors (contiguous, byte sizes multiples of 4) into ONE uint8 device block at 256-byte aligned offsets
+    (lm_pack_segments); returns (block, [(offset, nbytes)]).  The pipeline then moves a batch's decode outputs to the host with one copy."""
+    offs, sizes, off = [], [], 0
+    for t in tensors:
+        assert t.is_contiguous()
+        nb = t.numel() * t.element_size()
+        off = (off + 255) // 256 * 256
+        offs.append(off); sizes.append(nb)
+        off += nb
+    if block is None or block.numel() < off or block.device != tensors[0].device:
+        block = torch.empty(max(off, 1), device=tensors[0].device, dtype=torch.uint8)
+    n = len(tensors)
+    src = (C.c_void_p * n)(*[t.data_ptr() for t in tensors])
+    nby = (C.c_long * n)(*sizes)
+    dof = (C.c_long * n)(*offs)
+    check(lib().lm_pack_segments(_stream(), n, src, nby, dof, _ptr(block)))
+    return block, list(zip(offs, sizes))
 
 
 def decode_proposals(pconf, ext2, cls2, off2, exist_thre, prop_width, half_buff):
     B, P, R, _ = cls2.shape
     dev = cls2.device
-    prop_conf = _readback_empty((B, P, 2), torch.float32, dev)
-    v_ext = _readback_empty((B, P, R), torch.float32, dev)
+    prop_conf = torch.empty((B, P, 2), device=dev, dtype=torch.float32)
+    v_ext = torch.empty((B, P, R), device=dev, dtype=torch.float32)
     cls_conf = torch.empty((B, P, R, 10), device=dev, dtype=torch.float32)
     cls_idx = torch.empty((B, P, R), device=dev, dtype=torch.int32)
-    cls_offset = _readback_empty((B, P, R), torch.float64, dev)
+    cls_offset = torch.empty((B, P, R), device=dev, dtype=torch.float64)
     check(lib().lm_decode_proposals(_stream(), _ptr(pconf.contiguous()), _ptr(ext2.contiguous()), _ptr(cls2.contiguous()),
                                     _ptr(off2.contiguous()), _ptr(prop_conf), _ptr(v_ext), _ptr(cls_conf), _ptr(cls_idx),
                                     _ptr(cls_offset), B, P, R, float(exist_thre), prop_width, half_buff))
@@ -509,7 +477,7 @@ def decode_semantic(logits_chw, thre, raw_mode=False, want_biseg=True):
     biseg = rows = None
     if want_biseg:
         biseg = torch.empty((B, H, W), device=x.device, dtype=torch.float32)
-        rows = _readback_empty((B, H // 8, W), torch.float32, x.device)
+        rows = torch.empty((B, H // 8, W), device=x.device, dtype=torch.float32)
     check(lib().lm_decode_semantic(_stream(), _ptr(x), _ptr(sem), _ptr(biseg), _ptr(rows), B, H, W, float(thre), int(raw_mode)))
     return sem, biseg, rows
 
@@ -519,9 +487,9 @@ def endp_topk(endp_logits, K=512, clip=20):
     B, C_, H, W = x.shape
     assert C_ == 1
     ws = torch.empty(lib().lm_endp_topk_workspace_bytes(B), device=x.device, dtype=torch.uint8)
-    idx = _readback_empty((B, K), torch.int32, x.device)
+    idx = torch.empty((B, K), device=x.device, dtype=torch.int32)
     score = torch.empty((B, K), device=x.device, dtype=torch.float32)
-    status = _readback_empty((B,), torch.int32, x.device)
+    status = torch.empty((B,), device=x.device, dtype=torch.int32)
     check(lib().lm_endp_topk(_stream(), _ptr(x), _ptr(ws), _ptr(idx), _ptr(score), _ptr(status), B, H, W, clip, K))
     return idx, score, status
 

@@ -32,24 +32,11 @@ class TilePipeline:
             raise NotImplementedError(f'TilePipeline has no decode / polyline tail for heads.type={net.cfg.heads.type!r}')
         self.pool = ThreadPoolExecutor(max_workers=host_threads)
         self._pending = None
-        self._arenas = collections.OrderedDict()      # input shape -> ops.OutputArena (decode outputs of a batch in one device block)
         self._slots, self._slot_next = [], 0           # ring of pinned staging blocks
         self.host_seconds = 0.0      # accumulated wall time of the per-tile host tasks (all threads) and their count
         self.host_tiles = 0
 
     HOST_SLOTS = 3          # pinned staging blocks per pipeline (batch k is being filled while the pool still reads batch k - 1)
-
-    def _arena_for(self, proj):
-        """The read-back arena of this input shape (ops.OutputArena: the decode outputs of a batch in one device block)."""
-        key = (tuple(proj.shape), proj.dtype, proj.device) if torch.is_tensor(proj) else None
-        if key is None:
-            return None                                   # LiDAR point lists / batch dicts: per-tensor copies
-        a = self._arenas.get(key)
-        if a is None:
-            a = self._arenas[key] = ops.OutputArena()
-            while len(self._arenas) > self.MAX_GRAPHS:
-                self._arenas.popitem(last=False)
-        return a
 
     def _host_slot(self, nbytes):
         """Next pinned staging block of the ring (allocated once per pipeline, grown when a larger batch arrives); waits for the host
@@ -67,38 +54,29 @@ class TilePipeline:
 
     def _gpu_stage(self, proj):
         if self.use_graph and torch.is_tensor(proj):      # (a tile tensor: the LiDAR path sizes its launches on the host and cannot be captured)
-            dev, keep, crop = self._replay(proj)
+            (block, layout), keep, crop = self._replay(proj)
         else:
-            arena = self._arena_for(proj)
-            with ops.output_arena(arena):
-                dev, keep, crop = self._device_part(proj)
-            if arena is not None:
-                arena.commit(proj.device)
-        # device -> pinned host: ONE copy when every result is a view of one arena block (every batch after the first of its shape),
-        # else one copy per tensor; the staging memory comes from the ring either way (no pinned allocation per batch)
-        views = []
-        stores = {v.untyped_storage().data_ptr() for v in dev.values()}
-        packed = len(stores) == 1 and len(dev) > 1
-        off = 0
-        for k, v in dev.items():
-            nb = v.numel() * v.element_size()
-            o = v.storage_offset() * v.element_size() if packed else (off + 255) // 256 * 256
-            views.append((k, o, nb, v))
-            off = o + nb
-        total = max(o + nb for _, o, nb, _ in views)
+            (block, layout), keep, crop = self._device_part(proj)
+        # device -> pinned host: ONE copy of the packed block; the staging memory comes from the ring (no pinned allocation per batch)
+        total = block.numel()
         slot = self._host_slot(total)
         hb = slot['block']
-        host = {k: hb[o:o + nb].view(v.dtype).view(v.shape) for k, o, nb, v in views}
-        if packed and all(v.is_contiguous() for v in dev.values()):
-            first = next(iter(dev.values()))
-            src = torch.empty(0, dtype=torch.uint8, device=first.device).set_(first.untyped_storage(), 0, (total,))
-            hb[:total].copy_(src, non_blocking=True)
-        else:
-            for k in dev:
-                host[k].copy_(dev[k], non_blocking=True)
+        hb[:total].copy_(block, non_blocking=True)
+        host = {k: hb[o:o + nb].view(dt).view(shape) for k, o, nb, dt, shape in layout}
         ev = torch.cuda.Event()
         ev.record()
-        return host, ev, keep, crop, slot
+        return host, ev, (keep, block), crop, slot
+
+    def _pack(self, dev):
+        """The tensors the host tasks read, gathered into one device block (ops.pack_readback: one kernel, capturable)."""
+        names = list(dev)
+        if len(names) == 1 and dev[names[0]].is_contiguous():          # (config 4: one tensor - nothing to gather)
+            t = dev[names[0]]
+            return t.view(-1).view(torch.uint8), [(names[0], 0, t.numel() * t.element_size(), t.dtype, tuple(t.shape))]
+        ts = [dev[k].contiguous() for k in names]
+        block, segs = ops.pack_readback(ts)
+        end = max(o + nb for o, nb in segs)
+        return block[:end], [(k, o, nb, t.dtype, tuple(t.shape)) for k, t, (o, nb) in zip(names, ts, segs)]
 
     MAX_GRAPHS = 4          # captured graphs kept per pipeline (each one pins a private activation pool: ~1 GB per tile of its batch)
 
@@ -128,13 +106,10 @@ class TilePipeline:
         if ent is None:
             static_in = torch.empty_like(proj)
             static_in.copy_(proj)
-            arena = ops.OutputArena()                 # private to this graph: its kernels keep writing into this block
-            with ops.output_arena(arena):
-                self._device_part(static_in)
-            arena.commit(proj.device)
+            self._device_part(static_in)
             torch.cuda.synchronize()
             graph = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(graph, stream=torch.cuda.Stream(device=proj.device)), ops.output_arena(arena):
+            with torch.cuda.graph(graph, stream=torch.cuda.Stream(device=proj.device)):
                 out = self._device_part(static_in)
             ent = (graph, static_in, out, wkey)
             self._graphs[key] = ent
@@ -147,7 +122,8 @@ class TilePipeline:
         return out
 
     def _device_part(self, proj):
-        """Every device-side launch of a batch (no host reads, no pinned allocations: capturable): raw net outputs + decode kernels."""
+        """Every device-side launch of a batch (no host reads, no pinned allocations: capturable): raw net outputs + decode kernels + the
+        gather of what the host reads into one block.  Returns ((block, layout), keep-alive, crop width)."""
         heads, cfg = self.net.heads, self.cfg
         # a [B,3,H,W] tile tensor (FPN path), a list of [N_i,4] point tensors (sparse-conv LiDAR path, config 5) or a batch dict
         batch = proj if isinstance(proj, dict) else ({'points': list(proj)} if isinstance(proj, (list, tuple)) else {'proj': proj})
@@ -169,7 +145,7 @@ class TilePipeline:
             dev = {'prop_conf': prop_conf, 'v_ext': v_ext, 'cls_offset': cls_offset, 'rows': rows, 'idx': idx, 'status': status}
             keep = (raw, sem, biseg, orient, cls_conf, cls_idx, dev)      # keep device buffers alive until the copies land
             crop = raw['endp_est'].shape[-1]
-        return dev, keep, crop
+        return self._pack(dev), keep, crop
 
     def _tile_task(self, host, b, crop_w):
         t0 = time.perf_counter()

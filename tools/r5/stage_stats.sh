@@ -10,6 +10,5 @@ cd /tmp && export TMPDIR=/tmp
 rocprofv3 --kernel-trace --marker-trace --hip-runtime-trace --output-format csv -d $OUT/trace -o p -- python3 $R/bench.py --steps $STEPS --warmup 2 --no-cpu-baseline $ARGS > $OUT/bench.json 2> $OUT/bench.err
 cd $R
 python3 tools/r5/stage_stats.py $OUT/trace $STEPS > $OUT/stage_stats.txt 2> $OUT/stage_stats.err
-head -3 $OUT/trace/*/*marker_api_trace.csv $OUT/trace/*/*hip_api_trace.csv $OUT/trace/*/*kernel_trace.csv > $OUT/headers.txt 2>&1
-rm -f $OUT/trace/*/*_trace.csv
+rm -rf $OUT/trace
 cat $OUT/stage_stats.txt $OUT/stage_stats.err | head -90
