@@ -114,23 +114,75 @@ def self_launch(args):
     sys.exit(max(abs(c) for c in codes))
 
 
-def host_budget(world, local_world, local_rank, cores_avail, allowed, host_cores, no_graphs, workload):
+def gpu_numa_topology():
+    """NUMA node of every GPU of this node WITHOUT touching HIP, and the CPUs of every NUMA node (the reference pins nothing:
+    baseline/engine/runner.py:89-104 leaves DataParallel's workers wherever the scheduler puts them).  GPUs = the amdgpu DRM cards in PCI
+    bus order - the order ROCr enumerates them in - re-indexed through HIP_VISIBLE_DEVICES / ROCR_VISIBLE_DEVICES when that is a plain index
+    list.  -> {'gpu_node': [node of local GPU 0, 1, ...], 'node_cpus': {node: [cpu, ...]}} or None when sysfs does not say."""
+    import glob
+    try:
+        cards = []
+        for c in glob.glob('/sys/class/drm/card[0-9]*'):
+            if '-' in os.path.basename(c):
+                continue
+            devp = os.path.join(c, 'device')
+            with open(os.path.join(devp, 'vendor')) as f:
+                if f.read().strip() != '0x1002':
+                    continue
+            with open(os.path.join(devp, 'numa_node')) as f:
+                node = int(f.read().strip())
+            cards.append((os.path.basename(os.path.realpath(devp)), node))
+        cards.sort()
+        nodes = [n for _, n in cards]
+        for var in ('HIP_VISIBLE_DEVICES', 'ROCR_VISIBLE_DEVICES'):
+            v = os.environ.get(var)
+            if v and all(t.strip().isdigit() for t in v.split(',')):
+                nodes = [nodes[int(t)] for t in v.split(',') if int(t) < len(nodes)]
+        if not nodes or any(n < 0 for n in nodes):
+            return None
+        node_cpus = {}
+        for n in set(nodes):
+            with open(f'/sys/devices/system/node/node{n}/cpulist') as f:
+                cpus = []
+                for part in f.read().strip().split(','):
+                    lo, _, hi = part.partition('-')
+                    cpus += list(range(int(lo), int(hi or lo) + 1))
+            node_cpus[n] = cpus
+        return {'gpu_node': nodes, 'node_cpus': node_cpus}
+    except (OSError, ValueError, IndexError):
+        return None
+
+
+def host_budget(world, local_world, local_rank, cores_avail, allowed, host_cores, no_graphs, workload, topo=None):
     """Per-rank host budget, decided before anything touches the GPU.  `--host-cores K` (the 1-GPU proxy of a rank on a shared node) or,
     when several ranks were launched without it, this rank's slice of the node: usable cores / ranks on the node, if that is <= 8
-    (8 ranks x 8 pool threads on the 16 usable cores of a box otherwise).  -> {'k': cores, 'cores': the CPU ids to pin to (None = leave
-    the affinity alone), 'graphs': switch HIP graphs on (k <= 4: one launch per sub-batch instead of ~350), 'auto': decided here}"""
+    (8 ranks x 8 pool threads on the 16 usable cores of a box otherwise).  The K cores come from the NUMA node of the rank's GPU when `topo`
+    (gpu_numa_topology) knows it and that node has K usable cores for each of its ranks; else a contiguous slice of the affinity mask.
+    -> {'k': cores, 'cores': the CPU ids to pin to (None = leave the affinity alone), 'graphs': switch HIP graphs on (k <= 4: one launch per
+    sub-batch instead of ~350), 'auto': decided here, 'numa_node': the node the cores were taken from (None: contiguous slice)}"""
     auto = False
     if world > 1 and host_cores is None:
         k_auto = max(1, cores_avail // max(1, local_world))
         if k_auto <= 8:
             host_cores, auto = k_auto, True
     if host_cores is None:
-        return {'k': None, 'cores': None, 'graphs': False, 'auto': False}
+        return {'k': None, 'cores': None, 'graphs': False, 'auto': False, 'numa_node': None}
     if host_cores < 1:
         raise SystemExit('--host-cores must be >= 1')
     k = min(host_cores, len(allowed))
-    mine = [allowed[(local_rank * k + i) % len(allowed)] for i in range(k)]      # (wraps: never a short slice at the tail)
-    return {'k': k, 'cores': mine, 'graphs': k <= 4 and not no_graphs and workload in ('fused', 'tiles', 'rowref'), 'auto': auto}
+    mine, node = None, None
+    if topo and local_rank < len(topo['gpu_node']) and local_world <= len(topo['gpu_node']):
+        node = topo['gpu_node'][local_rank]
+        peers = [r for r in range(local_world) if topo['gpu_node'][r] == node]           # the ranks whose GPUs hang off the same node
+        near = [c for c in topo['node_cpus'].get(node, []) if c in set(allowed)]
+        if len(near) >= k * len(peers):
+            j = peers.index(local_rank)
+            mine = near[j * k:(j + 1) * k]
+        else:
+            node = None
+    if mine is None:
+        mine = [allowed[(local_rank * k + i) % len(allowed)] for i in range(k)]      # (wraps: never a short slice at the tail)
+    return {'k': k, 'cores': mine, 'graphs': k <= 4 and not no_graphs and workload in ('fused', 'tiles', 'rowref'), 'auto': auto, 'numa_node': node}
 
 
 def main():
@@ -175,7 +227,7 @@ def main():
     cores_avail = usable_cores()
     affinity0 = set(os.sched_getaffinity(0)) if hasattr(os, 'sched_getaffinity') else None     # (restored for the cpu_baseline leg)
     hb = host_budget(world, int(os.environ.get('LOCAL_WORLD_SIZE', world)), local_rank, cores_avail, sorted(os.sched_getaffinity(0)),
-                     args.host_cores, args.no_graphs, args.workload)
+                     args.host_cores, args.no_graphs, args.workload, topo=gpu_numa_topology() if world > 1 else None)
     host_cores_auto = hb['auto']
     if hb['cores'] is not None:
         args.host_cores = hb['k']
@@ -518,6 +570,9 @@ def main():
                    'stream_check': stream_check, 'gather_check': gather_check, 'raster_check': raster_check,
                    'host_cores_per_rank': host_cores_per_rank, 'host_cores_pinned': args.host_cores is not None,
                    'host_cores_auto': host_cores_auto,       # N > 1 without --host-cores: usable cores / ranks on the node
+                   'host_numa_node': hb.get('numa_node'),
+                   # what the collective library saw: the proof that an N-GPU line really ran N RCCL ranks
+                   'rccl_ranks': dist.get_world_size() if world > 1 else 1, 'dist_backend': dist.get_backend() if world > 1 else None,
                    'host_postproc_ms_per_tile': 1e3 * sum(p_.host_seconds for p_ in [pipe] + extra_pipes) /
                    max(1, sum(p_.host_tiles for p_ in [pipe] + extra_pipes))},
         'roofline': {'bound': 'mfma',

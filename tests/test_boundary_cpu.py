@@ -876,7 +876,19 @@ def test_bench_host_budget_per_rank():
         seen |= set(hb['cores'])
     hb = bench.host_budget(2, 2, 1, 16, allowed, None, False, 'fused')
     assert hb['auto'] and hb['k'] == 8 and not hb['graphs'] and hb['cores'] == list(range(8, 16))
-    assert bench.host_budget(8, 8, 3, 128, allowed, None, False, 'fused') == {'k': None, 'cores': None, 'graphs': False, 'auto': False}
+    assert bench.host_budget(8, 8, 3, 128, allowed, None, False, 'fused') == {'k': None, 'cores': None, 'graphs': False, 'auto': False, 'numa_node': None}
+    # NUMA-aware pick: 8 GPUs on two nodes (0-3 on node 0 = cpus 0..63 and 128..191, 4-7 on node 1), 16 usable cores per node
+    topo = {'gpu_node': [0, 0, 0, 0, 1, 1, 1, 1], 'node_cpus': {0: list(range(0, 64)) + list(range(128, 192)), 1: list(range(64, 128)) + list(range(192, 256))}}
+    mask = list(range(0, 16)) + list(range(64, 80))
+    got = [bench.host_budget(8, 8, r, 32, mask, None, False, 'fused', topo=topo) for r in range(8)]
+    assert [g['numa_node'] for g in got] == [0, 0, 0, 0, 1, 1, 1, 1] and all(g['k'] == 4 for g in got)
+    assert got[0]['cores'] == [0, 1, 2, 3] and got[3]['cores'] == [12, 13, 14, 15] and got[4]['cores'] == [64, 65, 66, 67] and got[7]['cores'] == [76, 77, 78, 79]
+    flat = [c for g in got for c in g['cores']]
+    assert len(set(flat)) == 32                                                                  # disjoint over the ranks
+    # a node without enough usable cores for its ranks: fall back to the contiguous slice of the mask
+    hb = bench.host_budget(8, 8, 5, 32, list(range(0, 32)), None, False, 'fused', topo=topo)
+    assert hb['numa_node'] is None and hb['cores'] == [20, 21, 22, 23]
+    assert bench.gpu_numa_topology() is None or isinstance(bench.gpu_numa_topology()['gpu_node'], list)   # (no amdgpu card in the build container)
     hb = bench.host_budget(8, 8, 3, 128, allowed, 4, False, 'tiles')
     assert not hb['auto'] and hb['k'] == 4 and hb['graphs'] and hb['cores'] == [12, 13, 14, 15]
     assert not bench.host_budget(8, 8, 0, 16, allowed, None, True, 'fused')['graphs']            # --no-graphs
