@@ -189,6 +189,8 @@ int lm_polyline_assemble(const float* prop_conf, const float* prop_v_ext, const 
                          const float* bi_seg_rows, const int* endp_hw, int n_endp, int P, int R, float obj_thre,
                          int min_vertices, double* out_lanes, int* endp_keep);
 int lm_raster_polylines(const double* lanes, int P, int R, unsigned char* out);
+/* One segment of that rasteriser (cv2.line, thickness 1, LINE_8, restated from OpenCV's LineIterator: csrc/postproc.cpp) on a 1152 x 1152 map. */
+int lm_line8(unsigned char* out, int x1, int y1, int x2, int y2, int colour);
 int lm_trace_lines(const double* cols, int n, int R, const float* seg_rows, double* out);   /* polyline_utils.py:222-387 */
 /* BEV polylines -> LAS frame: baseline/utils/coor_img2pc.py:127-183 (+ :22-53, :59-73, :94-122).  bev_hwc [H][W][C] u8 is
  * modified in place (elevation fill of empty vertex pixels, like the reference); img_seqs [L][Vmax][2] (row, col);

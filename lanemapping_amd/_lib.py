@@ -76,6 +76,7 @@ SIGNATURES = {
     'lm_endp_cluster': (i32, [vp, i32, i32, i32, i32, i32, i32, i32, i32, vp, i32, vp, vp]),
     'lm_polyline_assemble': (i32, [vp, vp, vp, vp, vp, i32, i32, i32, f32, i32, vp, vp]),
     'lm_raster_polylines': (i32, [vp, i32, i32, vp]),
+    'lm_line8': (i32, [vp, i32, i32, i32, i32, i32]),
     'lm_trace_lines': (i32, [vp, i32, i32, vp, vp]),
     'lm_polyline_backproject': (i32, [vp, i32, i32, i32, vp, vp, i32, i32, vp, vp, vp]),
     'lm_skeletonize_lee_2d': (i64, [vp, i32, i32]),

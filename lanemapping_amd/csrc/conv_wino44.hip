@@ -725,12 +725,16 @@ __global__ __launch_bounds__(256) void wino44_kernel(W44Params p) {
                 AC, AN, gsrc, goff, rawc_w, wave, xf, (S) < 9 ? rawc + 8 + lowoff : rawn + lowoff, roff, vA, vB, vC, lower, kk)
     // the barrier in the middle of a slot: this wave's late stores (steps 0..3) are done; behind it every wave's are, and the early
     // planes are free (every wave has read V(s)'s in steps 0..4)
+#ifdef LM_QABL_NOMID                          // (timing ablation: what the barrier in the middle of a slot costs; results are wrong)
+#define LM_QMID(AN) AN = q_aread(Vq + LM_QXI(5) * 256);
+#else
 #define LM_QMID(AN)                                          \
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");       \
     LM_QTICK(4)                                              \
     __builtin_amdgcn_s_barrier();                            \
     LM_QTICK(5)                                              \
     AN = q_aread(Vq + LM_QXI(5) * 256);
+#endif
     for (int u = 0; u < nun; ++u) {
         const float* const rawc = raw0 + (u & 1) * QRAWF;              // unit u
         float* const rawc_w = raw0 + (u & 1) * QRAWF;                  // ... and the destination of unit u + 2's patch loads (second slot)

@@ -556,8 +556,41 @@ LM_API int lm_polyline_assemble(const float* prop_conf /*[P][2]*/, const float* 
     return LM_OK;
 }
 
-// polyline_utils.py:610-638 (renew_semantic_map) with cv2.line replaced by an own 8-connected Bresenham
-// (thickness 1, both end points drawn).  Parity against OpenCV's rasteriser is unpinned.
+// polyline_utils.py:610-638 (renew_semantic_map): cv2.line(map, pt1, pt2, color, thickness=1) = OpenCV's 8-connected Bresenham.
+// cv2 is not in the image and its source is not part of /root/reference (a third-party dependency, opencv-python, version not pinned by
+// the reference), so this restates the published algorithm of OpenCV 4.x `LineIterator` as `cv::line` drives it for thickness 1,
+// LINE_8, shift 0 (modules/imgproc/src/drawing.cpp: Line() -> LineIterator(img, pt1, pt2, 8, leftToRight = true)):
+//   * the segment is walked from its LEFT end point (end points swapped when pt2.x < pt1.x), so the pixels do not depend on the order
+//     of the end points;
+//   * major axis = the longer of |dx|, |dy| (ties: x), count = major + 1 pixels, both end points drawn;
+//   * err = major - 2 minor; per step: a minor-axis move is added when err < 0 (then err += 2 major - 2 minor, else err -= 2 minor).
+//     A tie (err == 0) keeps the minor coordinate - the textbook all-octant form (err = dx - dy, e2 = 2 err) used here until round 4
+//     takes the diagonal there and differs from OpenCV in up to major / 2 pixels of a segment.
+// PARITY UNPINNED against OpenCV itself (no reference-held vector); pinned to the hand-derived table of
+// tests/test_metrics_io_cpu.py::test_line8_opencv_table and to the independently written oracle (oracle/postproc_ref.py _line8).
+static void line8_opencv(unsigned char* out, int x1, int y1, int x2, int y2, unsigned char colour) {
+    if (x2 < x1) {                                       // leftToRight
+        std::swap(x1, x2);
+        std::swap(y1, y2);
+    }
+    const int dx = x2 - x1, ady = std::abs(y2 - y1), sy = y2 < y1 ? -1 : 1;
+    const bool ymajor = ady > dx;
+    const int major = ymajor ? ady : dx, minor = ymajor ? dx : ady;
+    int err = major - 2 * minor, x = x1, y = y1;
+    for (int k = 0; k <= major; ++k) {
+        if ((unsigned)y < (unsigned)IMG && (unsigned)x < (unsigned)IMG) out[(size_t)y * IMG + x] = colour;
+        const bool both = err < 0;
+        err += -2 * minor + (both ? 2 * major : 0);
+        if (ymajor) {
+            y += sy;
+            if (both) ++x;
+        } else {
+            ++x;
+            if (both) y += sy;
+        }
+    }
+}
+
 LM_API int lm_raster_polylines(const double* lanes /*[P][R][2]*/, int P, int R, unsigned char* out /*[1152][1152]*/) {
     LM_REQUIRE(lanes && out && R * 8 == IMG, "raster_polylines: bad args");
     std::memset(out, 0, (size_t)IMG * IMG);
@@ -566,25 +599,15 @@ LM_API int lm_raster_polylines(const double* lanes /*[P][R][2]*/, int P, int R, 
             const int c1 = (int)lanes[((size_t)i * R + r) * 2], c2 = (int)lanes[((size_t)i * R + r + 1) * 2];
             if (c1 < 0 || c2 < 0) continue;
             const int s1 = (int)lanes[((size_t)i * R + r) * 2 + 1], s2 = (int)lanes[((size_t)i * R + r + 1) * 2 + 1];
-            const unsigned char colour = (s1 == 2 || s2 == 2) ? 2 : 1;
-            int x0 = c1, y0 = r * 8 + 3, x1 = c2, y1 = (r + 1) * 8 + 3;
-            const int dx = std::abs(x1 - x0), dy = -std::abs(y1 - y0);
-            const int sx = x0 < x1 ? 1 : -1, sy = y0 < y1 ? 1 : -1;
-            int err = dx + dy;
-            for (;;) {
-                if ((unsigned)y0 < (unsigned)IMG && (unsigned)x0 < (unsigned)IMG) out[(size_t)y0 * IMG + x0] = colour;
-                if (x0 == x1 && y0 == y1) break;
-                const int e2 = 2 * err;
-                if (e2 >= dy) {
-                    err += dy;
-                    x0 += sx;
-                }
-                if (e2 <= dx) {
-                    err += dx;
-                    y0 += sy;
-                }
-            }
+            line8_opencv(out, c1, r * 8 + 3, c2, (r + 1) * 8 + 3, (s1 == 2 || s2 == 2) ? 2 : 1);
         }
+    return LM_OK;
+}
+
+// one segment of the rasteriser above on an IMG x IMG map (test hook of the OpenCV table)
+LM_API int lm_line8(unsigned char* out /*[1152][1152]*/, int x1, int y1, int x2, int y2, int colour) {
+    LM_REQUIRE(out, "line8: null pointer");
+    line8_opencv(out, x1, y1, x2, y2, (unsigned char)colour);
     return LM_OK;
 }
 

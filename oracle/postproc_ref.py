@@ -12,7 +12,7 @@ Restates, with the reference's quirks kept:
   smooth_semantics           <- utils/polyline_utils.py:448-586
   drop_short                 <- utils/polyline_utils.py:589-608
   raster_semantic_map        <- utils/polyline_utils.py:610-638 (cv2.line replaced by an own
-                                8-connected Bresenham: parity vs OpenCV unpinned)
+                                OpenCV's 8-connected Bresenham restated: parity vs OpenCV itself unpinned)
   lanes_to_json_records      <- utils/io_utils.py:58-93 and the packing at
                                 heads/polyline_fpn_vit_vertex_2.py:997-1000
 """
@@ -335,23 +335,23 @@ def drop_short(V, min_v=8):
 
 
 def _line8(img, x0, y0, x1, y1, colour):
-    """8-connected Bresenham, thickness 1, both end points drawn, clipped to the image."""
-    dx, dy = abs(x1 - x0), -abs(y1 - y0)
-    sx = 1 if x0 < x1 else -1
-    sy = 1 if y0 < y1 else -1
-    err = dx + dy
-    while True:
-        if 0 <= y0 < img.shape[0] and 0 <= x0 < img.shape[1]:
-            img[y0, x0] = colour
-        if x0 == x1 and y0 == y1:
-            break
-        e2 = 2 * err
-        if e2 >= dy:
-            err += dy
-            x0 += sx
-        if e2 <= dx:
-            err += dx
-            y0 += sy
+    """cv2.line(img, (x0, y0), (x1, y1), colour, thickness=1): OpenCV's 8-connected Bresenham as cv::line runs it (LineIterator with
+    leftToRight=True; OpenCV 4.x modules/imgproc/src/drawing.cpp - a third-party dependency of the reference, opencv-python, version not
+    pinned there).  Written from the error-term definition, not from the product's loop: pixel k of the walk from the LEFT end point has
+    minor-axis offset = the number of j in 1..k with  major - 2 * minor * j + 2 * major * (moves so far) < 0  evaluated step by step."""
+    if x1 < x0:
+        x0, y0, x1, y1 = x1, y1, x0, y0
+    dx, dy = x1 - x0, y1 - y0
+    sy = -1 if dy < 0 else 1
+    major, minor = (abs(dy), dx) if abs(dy) > dx else (dx, abs(dy))
+    ymajor = abs(dy) > dx
+    moved = 0
+    for k in range(major + 1):
+        x, y = (x0 + moved, y0 + sy * k) if ymajor else (x0 + k, y0 + sy * moved)
+        if 0 <= y < img.shape[0] and 0 <= x < img.shape[1]:
+            img[y, x] = colour
+        if major - 2 * minor * (k + 1) + 2 * major * moved < 0:          # err after k steps, before the decision of step k + 1
+            moved += 1
 
 
 def raster_semantic_map(V):

@@ -118,3 +118,83 @@ def test_label_json_golden_g16(golden, tmp_path):
     assert out.read_text() == str(g['saved_text'])
     back = io_utils.load_label_seq(str(out))
     assert np.array_equal(back[0], seq) and list(back[1]) == list(lens)
+
+
+def test_line8_opencv_table():
+    """cv2.line(thickness=1) as restated from OpenCV's LineIterator (csrc/postproc.cpp line8_opencv; oracle/postproc_ref.py _line8, written
+    independently): a HAND-DERIVED table for the segments renew_semantic_map draws (dy = 8 between consecutive anchor rows).  Walk from the
+    LEFT end point, err = major - 2 minor, a minor-axis move when err < 0 (err += 2 major - 2 minor), else err -= 2 minor:
+      dx = 4 (y major, err 0 -8 0 -8 ...): x moves on steps 2, 4, 6, 8;   dx = -4: the same walk from the other (left) end, upwards;
+      dx = 12 (x major, err -4 4 -12 -4 4 -12 ...): y moves on steps 1, 3, 4, 6, 7, 9, 10, 12.
+    The textbook all-octant Bresenham used until round 4 takes the diagonal at err == 0 and fails this table (dx = 2, 4, 6)."""
+    import ctypes as C
+    from lanemapping_amd._lib import lib, check
+    from oracle import postproc_ref
+    table = {      # (dx, dy) -> x offset per row (y major) or (x, y) pairs (x major), relative to the FIRST end point (x0, y0)
+        (0, 8): [0, 0, 0, 0, 0, 0, 0, 0, 0],
+        (1, 8): [0, 0, 0, 0, 0, 1, 1, 1, 1],              # err 6 4 2 0 -2 | 12 ...: the one move on step 5
+        (2, 8): [0, 0, 0, 1, 1, 1, 1, 2, 2],              # err 4 0 -4 8 4 0 -4 8: moves on steps 3, 7
+        (4, 8): [0, 0, 1, 1, 2, 2, 3, 3, 4],
+        (8, 8): [0, 1, 2, 3, 4, 5, 6, 7, 8],              # |dy| > dx is false: x major, err -8 each step -> every step diagonal
+        (-4, 8): [0, -1, -1, -2, -2, -3, -3, -4, -4],     # walked from the left end (row 8) upwards: row 8 - k has offset -4 + [0,0,1,1,2,2,3,3,4][k]
+        (-2, 8): [0, 0, -1, -1, -1, -1, -2, -2, -2],
+    }
+    xmajor = {(12, 8): [(0, 0), (1, 1), (2, 1), (3, 2), (4, 3), (5, 3), (6, 4), (7, 5), (8, 5), (9, 6), (10, 7), (11, 7), (12, 8)],
+              (-12, 8): [(-12, 8), (-11, 7), (-10, 7), (-9, 6), (-8, 5), (-7, 5), (-6, 4), (-5, 3), (-4, 3), (-3, 2), (-2, 1), (-1, 1), (0, 0)]}
+    x0, y0 = 500, 403
+    for (dx, dy), want in list(table.items()) + list(xmajor.items()):
+        pix = {(x0 + a, y0 + b) for a, b in want} if (dx, dy) in xmajor else {(x0 + a, y0 + r) for r, a in enumerate(want)}
+        img = np.zeros((1152, 1152), np.uint8)
+        check(lib().lm_line8(img.ctypes.data_as(C.c_void_p), x0, y0, x0 + dx, y0 + dy, 1))
+        got = {(int(c), int(r)) for r, c in zip(*np.nonzero(img))}
+        assert got == pix, ((dx, dy), sorted(got ^ pix))
+        ref = np.zeros((1152, 1152))
+        postproc_ref._line8(ref, x0, y0, x0 + dx, y0 + dy, 1)
+        assert np.array_equal(ref != 0, img != 0), (dx, dy)
+        back = np.zeros((1152, 1152), np.uint8)             # end-point order does not matter (leftToRight)
+        check(lib().lm_line8(back.ctypes.data_as(C.c_void_p), x0 + dx, y0 + dy, x0, y0, 1))
+        assert np.array_equal(back, img), (dx, dy)
+    # every dx the assembly can produce between two rows, product vs oracle, plus clipping at the map border
+    for dx in list(range(-40, 41)) + [-300, 300, 1151]:
+        a, b = np.zeros((1152, 1152), np.uint8), np.zeros((1152, 1152))
+        check(lib().lm_line8(a.ctypes.data_as(C.c_void_p), 10, 1139, 10 + dx, 1147, 2))
+        postproc_ref._line8(b, 10, 1139, 10 + dx, 1147, 2)
+        assert np.array_equal(a, b.astype(np.uint8)), dx
+
+
+def _endpoints(sk):
+    """Skeleton pixels with exactly one 8-neighbour."""
+    nb = ndi.convolve(sk.astype(np.int32), np.ones((3, 3), np.int32), mode='constant') - sk
+    return int(((sk == 1) & (nb == 1)).sum())
+
+
+def test_skeleton_published_shapes():
+    """The shapes thinning papers show (Lee, Kashyap & Chu 1994, figs. of rectangles, crosses and rings): what the published algorithm
+    GUARANTEES on them - topology (components, holes), a one-pixel-wide curve, the number of free ends, medial position within one pixel -
+    asserted on lm_skeletonize_lee_2d and on the literal 3-D restatement (oracle/skeleton_ref.py).  skimage is not importable in the build
+    container, so the pixel-exact answer of skimage.morphology.skeletonize(method='lee') itself stays UNPINNED."""
+    from oracle import skeleton_ref
+    shapes = {}
+    rect = np.zeros((20, 50), np.uint8); rect[6:12, 5:45] = 1                      # 6 x 40 rectangle (even thickness)
+    shapes['rectangle'] = (rect, dict(comp=1, holes=0, ends=2))
+    cross = np.zeros((41, 41), np.uint8); cross[17:24, 3:38] = 1; cross[3:38, 17:24] = 1      # 7-wide plus sign
+    shapes['cross'] = (cross, dict(comp=1, holes=0, ends=4))
+    yy, xx = np.mgrid[:61, :61]
+    rr = np.hypot(yy - 30, xx - 30)
+    ring = ((rr >= 14) & (rr <= 22)).astype(np.uint8)                                # annulus, 9 px thick
+    shapes['ring'] = (ring, dict(comp=1, holes=1, ends=0))
+    two = np.zeros((30, 60), np.uint8); two[4:9, 4:56] = 1; two[18:25, 10:50] = 1    # two separate bars
+    shapes['two bars'] = (two, dict(comp=2, holes=0, ends=4))
+    for name, (img, want) in shapes.items():
+        sk = mu.skeletonize_lee(img)
+        assert np.array_equal(sk, skeleton_ref.skeletonize_lee_ref(img)), name
+        assert np.all(sk <= img) and _components8(sk) == want['comp'] and _holes(sk) == want['holes'], name
+        assert _endpoints(sk) == want['ends'], (name, _endpoints(sk))
+        assert not (sk[:-1, :-1] & sk[1:, :-1] & sk[:-1, 1:] & sk[1:, 1:]).any(), name          # one pixel wide
+        assert np.array_equal(mu.skeletonize_lee(sk), sk), name                                    # idempotent
+    r = mu.skeletonize_lee(shapes['rectangle'][0])
+    rows = np.unique(np.nonzero(r)[0])
+    assert set(rows) <= {8, 9} and r.sum() >= 40 - 6            # on one of the two middle rows, at most half the thickness shorter at each end
+    ringsk = mu.skeletonize_lee(ring)
+    rad = rr[ringsk == 1]
+    assert rad.min() >= 16.5 and rad.max() <= 19.5               # the medial circle of the annulus (radius 18) within 1.5 px
