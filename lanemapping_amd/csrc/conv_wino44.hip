@@ -478,7 +478,7 @@ template <int S>
 __device__ __forceinline__ void w44_step(f32x16& acc0, f32x16& acc1, f32x4 (&bq)[QRING][2], unsigned bvoff, const float* bpre,
                                          const float* anext, const f32x4& a_cur, f32x4& a_nxt, const float* const (&gsrc)[QLPW], long goff,
                                          float* rawld, int wave, W44Xf& xf, const float* prerow, const int (&roff)[6], float* vA, float* vB,
-                                         float* vC, bool lower, const W44K& kk) {
+                                         float* vC, bool lower, const W44K& kk, const bool xf_on = true) {
     typedef __attribute__((address_space(1))) const void gptr_t;
     typedef __attribute__((address_space(3))) void lptr_t;
     constexpr int K = S % 9;
@@ -503,9 +503,11 @@ __device__ __forceinline__ void w44_step(f32x16& acc0, f32x16& acc1, f32x4 (&bq)
     __builtin_amdgcn_sched_barrier(0);
     if constexpr (K != 4 && K != 8) a_nxt = q_aread(anext);
 #ifndef LM_QABL_NOT
-    w44_xf_lds<K>(xf, prerow, roff, vA, vB, vC);
-    __builtin_amdgcn_sched_barrier(0);
-    w44_xf_valu<K>(xf, lower, kk);
+    if (xf_on) {
+        w44_xf_lds<K>(xf, prerow, roff, vA, vB, vC);
+        __builtin_amdgcn_sched_barrier(0);
+        w44_xf_valu<K>(xf, lower, kk);
+    }
 #endif
     __builtin_amdgcn_sched_barrier(0);
     q_mfma<VACC>(acc1, a_cur[0], b[1][0]);
@@ -722,11 +724,23 @@ __global__ __launch_bounds__(256) void wino44_kernel(W44Params p) {
 #define LM_QBPRE(S5) ((S5) < 18 ? bu + (long)((S5) / 9) * ustride + (long)LM_QXI((S5) % 9) * xstride : bu_next + (long)LM_QXI((S5) - 18) * xstride)
 #define LM_QSTEP(S, AC, AN) \
     w44_step<S>(acc[(S) % 9][0], acc[(S) % 9][1], bq, bvoff, LM_QBPRE((S) + QBD), Vq + LM_QXI(((S) % 9) + 1 < 9 ? ((S) % 9) + 1 : 0) * 256, \
-                AC, AN, gsrc, goff, rawc_w, wave, xf, (S) < 9 ? rawc + 8 + lowoff : rawn + lowoff, roff, vA, vB, vC, lower, kk)
+                AC, AN, gsrc, goff, rawc_w, wave, xf, (S) < 9 ? rawc + 8 + lowoff : rawn + lowoff, roff, vA, vB, vC, lower, kk, xf_on)
     // the barrier in the middle of a slot: this wave's late stores (steps 0..3) are done; behind it every wave's are, and the early
     // planes are free (every wave has read V(s)'s in steps 0..4)
+#ifdef LM_QABL_SHAREV                         // (timing ablation: only the workgroup of N tile 0 transforms - what sharing V between the N tiles of an M
+    const bool xf_on = ntile == 0;            //  block could save; results are wrong)
+#else
+    const bool xf_on = true;
+#endif
 #ifdef LM_QABL_NOMID                          // (timing ablation: what the barrier in the middle of a slot costs; results are wrong)
 #define LM_QMID(AN) AN = q_aread(Vq + LM_QXI(5) * 256);
+#elif defined(LM_QABL_SHAREV)
+#define LM_QMID(AN)                                          \
+    if (xf_on) {                                             \
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   \
+        __builtin_amdgcn_s_barrier();                        \
+    }                                                        \
+    AN = q_aread(Vq + LM_QXI(5) * 256);
 #else
 #define LM_QMID(AN)                                          \
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");       \
