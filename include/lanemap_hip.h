@@ -58,14 +58,6 @@ long lm_winograd44_twin_workspace_bytes(int B, int H, int W, int Cin, int CoutP,
 int lm_conv3x3_winograd44_f32(void* stream, const float* x, int ldx, const float* wu_frag, int CoutP, const float* scale,
                               const float* shift, const float* res, int ldr, float* y, int ldy, int B, int H, int W,
                               int Cin, int Cout, int dil, int act, double* gn_partial);
-/* The same convolution with the accumulators split over the four waves by OUTPUT CHANNEL (wino44r_kernel, round 5): every lane ends up with
- * the 36 products of its (tile, channel quad) pairs, so A^T M A runs in registers and the LDS exchange of the products is gone.  Same
- * products in the same order: bit-identical y.  wu_frag_r: [Cin/8][9][CoutP/16][2][64][4] (ops.pack_wino44_fragments_r):
- *   wu_frag_r[h][K][nb][d][lane][e] = U[xi][16 nb + (lane & 15)][8 h + c], q = 2 d + e / 2, ks = e % 2, kk = lane >> 4,
- *   xi = 6 (K / 3 + 3 (q >> 1)) + K % 3 + 3 (q & 1), c = (kk & 1 ? 4 : 0) + 2 ks + (kk >> 1). */
-int lm_conv3x3_winograd44r_f32(void* stream, const float* x, int ldx, const float* wu_frag_r, int CoutP, const float* scale,
-                               const float* shift, const float* res, int ldr, float* y, int ldy, int B, int H, int W,
-                               int Cin, int Cout, int dil, int act, double* gn_partial);
 int lm_conv3x3_winograd44_twin_f32(void* stream, const float* x, int ldx, const float* wu, int CoutP, const float* scale,
                                    const float* shift, const float* res, int ldr, float* y, int ldy, int B, int H, int W,
                                    int Cin, int Cout, int dil, int act, void* workspace, long workspace_bytes);

@@ -478,7 +478,7 @@ template <int S>
 __device__ __forceinline__ void w44_step(f32x16& acc0, f32x16& acc1, f32x4 (&bq)[QRING][2], unsigned bvoff, const float* bpre,
                                          const float* anext, const f32x4& a_cur, f32x4& a_nxt, const float* const (&gsrc)[QLPW], long goff,
                                          float* rawld, int wave, W44Xf& xf, const float* prerow, const int (&roff)[6], float* vA, float* vB,
-                                         float* vC, bool lower, const W44K& kk, const bool xf_on = true) {
+                                         float* vC, bool lower, const W44K& kk) {
     typedef __attribute__((address_space(1))) const void gptr_t;
     typedef __attribute__((address_space(3))) void lptr_t;
     constexpr int K = S % 9;
@@ -503,11 +503,9 @@ __device__ __forceinline__ void w44_step(f32x16& acc0, f32x16& acc1, f32x4 (&bq)
     __builtin_amdgcn_sched_barrier(0);
     if constexpr (K != 4 && K != 8) a_nxt = q_aread(anext);
 #ifndef LM_QABL_NOT
-    if (xf_on) {
-        w44_xf_lds<K>(xf, prerow, roff, vA, vB, vC);
-        __builtin_amdgcn_sched_barrier(0);
-        w44_xf_valu<K>(xf, lower, kk);
-    }
+    w44_xf_lds<K>(xf, prerow, roff, vA, vB, vC);
+    __builtin_amdgcn_sched_barrier(0);
+    w44_xf_valu<K>(xf, lower, kk);
 #endif
     __builtin_amdgcn_sched_barrier(0);
     q_mfma<VACC>(acc1, a_cur[0], b[1][0]);
@@ -724,23 +722,11 @@ __global__ __launch_bounds__(256) void wino44_kernel(W44Params p) {
 #define LM_QBPRE(S5) ((S5) < 18 ? bu + (long)((S5) / 9) * ustride + (long)LM_QXI((S5) % 9) * xstride : bu_next + (long)LM_QXI((S5) - 18) * xstride)
 #define LM_QSTEP(S, AC, AN) \
     w44_step<S>(acc[(S) % 9][0], acc[(S) % 9][1], bq, bvoff, LM_QBPRE((S) + QBD), Vq + LM_QXI(((S) % 9) + 1 < 9 ? ((S) % 9) + 1 : 0) * 256, \
-                AC, AN, gsrc, goff, rawc_w, wave, xf, (S) < 9 ? rawc + 8 + lowoff : rawn + lowoff, roff, vA, vB, vC, lower, kk, xf_on)
+                AC, AN, gsrc, goff, rawc_w, wave, xf, (S) < 9 ? rawc + 8 + lowoff : rawn + lowoff, roff, vA, vB, vC, lower, kk)
     // the barrier in the middle of a slot: this wave's late stores (steps 0..3) are done; behind it every wave's are, and the early
     // planes are free (every wave has read V(s)'s in steps 0..4)
-#ifdef LM_QABL_SHAREV                         // (timing ablation: only the workgroup of N tile 0 transforms - what sharing V between the N tiles of an M
-    const bool xf_on = ntile == 0;            //  block could save; results are wrong)
-#else
-    const bool xf_on = true;
-#endif
 #ifdef LM_QABL_NOMID                          // (timing ablation: what the barrier in the middle of a slot costs; results are wrong)
 #define LM_QMID(AN) AN = q_aread(Vq + LM_QXI(5) * 256);
-#elif defined(LM_QABL_SHAREV)
-#define LM_QMID(AN)                                          \
-    if (xf_on) {                                             \
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   \
-        __builtin_amdgcn_s_barrier();                        \
-    }                                                        \
-    AN = q_aread(Vq + LM_QXI(5) * 256);
 #else
 #define LM_QMID(AN)                                          \
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");       \
@@ -966,452 +952,6 @@ __global__ __launch_bounds__(256) void wino44_kernel(W44Params p) {
     }
 }
 
-// ===================================================================================================================================
-// wino44r_kernel (round 5): the same workgroup tile (32 tiles x 64 output channels, 16-channel units, the same patch DMA, transform
-// schedule, V buffer and barriers) with the accumulators split over the four waves by OUTPUT CHANNEL instead of by quadrant of the
-// transform: wave w owns channels 16 w .. 16 w + 15 of the tile for ALL 36 xi and all 32 tiles.
-//   * v_mfma_f32_16x16x4_f32 (same 64 FLOP / cycle / SIMD): A = U[xi] (16 channels x 4 k), B = V[xi] (4 k x 16 tiles), D lane l register r =
-//     (channel 4 (l / 16) + r, tile l % 16): 36 xi x 2 tile groups x 4 = 288 accumulator registers, as before.
-//   * every lane ends up holding the 36 products of two (tile, channel quad) pairs: A^T M A runs in REGISTERS.  The LDS exchange of the
-//     products (144 KB, 288 ds_write_b32 + 72 ds_read_b128 per lane, four barriers, 6.3 k + ~3 k skew of 227 k cycles per workgroup at
-//     Cin = 256, 10 k of 84 k at Cin = 64) and the barrier between the K loop and the epilogue are gone; waves leave the loop on their own.
-//   * the k order of a slot is unchanged - the two MFMAs of an 8-channel half contract channels (0, 4, 1, 5) then (2, 6, 3, 7), the chain
-//     0, 4, 1, 5, 2, 6, 3, 7 of the 32x32x2 kernel - so y is BIT-IDENTICAL to wino44_kernel and to the materialising twin.
-//   * step K of a slot multiplies the four planes the four quadrant waves of wino44_kernel took in their step K (xi = LM_QXI(K) + {0, 3, 18,
-//     21}): the early / late plane split of the single V buffer carries over unchanged; every wave now reads every plane (36 ds_read_b128
-//     per slot instead of 18 ds_read_b64: LDS reads behind an MFMA are free).
-//   V plane layout [k slot kk 0..3][tile % 16][tile / 16][k step ks 0..1]: the B fragment of a lane (both tile groups, both k steps) is one
-//   ds_read_b128, contiguous over the wave; channel c of the half sits at ks = (c & 3) >> 1, kk = 2 (c & 1) + (c >> 2), so the two channels
-//   of a transform thread are 128 floats apart (one ds_write2st64_b32), conflict-free over the 32 tiles.
-//   U fragments [Cin / 8][9 steps][CoutP / 16][2][64 lanes][4]: lane (m = l % 16, kk = l / 16), element e of load d: plane q = 2 d + e / 2 of the
-//   step, k step ks = e % 2 (ops.pack_wino44_fragments_r).
-__device__ __forceinline__ void mfma16_vgpr(f32x4& acc, float a, float b) {
-    asm volatile("v_mfma_f32_16x16x4_f32 %0, %1, %2, %0" : "+v"(acc) : "v"(a), "v"(b));
-}
-// 64 of the 72 accumulators are pinned to the AGPR file (all 256 of it), the eight of step 8 to VGPRs: left to the builtin the register
-// allocator kept MFMA destinations apart from their sources and moved accumulators between the files inside the loop (116 v_accvgpr_* per unit)
-__device__ __forceinline__ void mfma16_agpr(f32x4& acc, float a, float b) {
-    asm volatile("v_mfma_f32_16x16x4_f32 %0, %1, %2, %0" : "+a"(acc) : "v"(a), "v"(b));
-}
-template <bool VACC>
-__device__ __forceinline__ void r_mfma(f32x4& acc, float a, float b) {
-    if constexpr (VACC) mfma16_vgpr(acc, a, b);
-    else mfma16_agpr(acc, a, b);
-}
-constexpr int r_xi(int K, int q) { return 6 * (K / 3) + K % 3 + 18 * (q >> 1) + 3 * (q & 1); }
-
-// the V stores of the transform in the [kk][tile % 16][tile / 16][ks] plane layout: the thread's two channels are 128 floats apart
-template <int K>
-__device__ __forceinline__ void w44r_xf_lds(W44Xf& d, const float* rawrow, const int (&roff)[6], float* vA, float* vB, float* vC) {
-    auto st = [](float* v, int j, const f32x2 t) {
-        v[j * 256] = t[0];
-        v[j * 256 + 128] = t[1];
-    };
-    if constexpr (K == 0) {
-        st(vB, 2, d.tB[2]); st(vB, 5, d.tB[5]);
-        w44_preread<0>(d, rawrow, roff); w44_preread<1>(d, rawrow, roff);
-    } else if constexpr (K == 1) {
-        st(vC, 0, d.tC[0]); st(vC, 1, d.tC[1]);
-        w44_preread<2>(d, rawrow, roff); w44_preread<3>(d, rawrow, roff);
-    } else if constexpr (K == 2) {
-        st(vC, 2, d.tC[2]); st(vC, 3, d.tC[3]);
-        w44_preread<4>(d, rawrow, roff); w44_preread<5>(d, rawrow, roff);
-    } else if constexpr (K == 3) {
-        st(vC, 4, d.tC[4]); st(vC, 5, d.tC[5]);
-    } else if constexpr (K == 5) {
-        st(vA, 0, d.tA[0]); st(vA, 1, d.tA[1]); st(vA, 2, d.tA[2]);
-    } else if constexpr (K == 6) {
-        st(vA, 3, d.tA[3]); st(vA, 4, d.tA[4]); st(vA, 5, d.tA[5]);
-    } else if constexpr (K == 7) {
-        st(vB, 0, d.tB[0]); st(vB, 1, d.tB[1]); st(vB, 3, d.tB[3]); st(vB, 4, d.tB[4]);
-    }
-}
-__device__ __forceinline__ void w44r_xf_all(W44Xf& d, const float* rawrow, const int (&roff)[6], float* vA, float* vB, float* vC, bool lower,
-                                            const W44K& k) {
-    w44_preread<0>(d, rawrow, roff); w44_preread<1>(d, rawrow, roff); w44_preread<2>(d, rawrow, roff);
-    w44_preread<3>(d, rawrow, roff); w44_preread<4>(d, rawrow, roff); w44_preread<5>(d, rawrow, roff);
-    w44_xf_valu<1>(d, lower, k); w44_xf_valu<2>(d, lower, k); w44_xf_valu<3>(d, lower, k);
-    w44_xf_valu<4>(d, lower, k); w44_xf_valu<5>(d, lower, k); w44_xf_valu<6>(d, lower, k);
-#pragma unroll
-    for (int j = 0; j < 6; ++j) {
-        vA[j * 256] = d.tA[j][0]; vA[j * 256 + 128] = d.tA[j][1];
-        vB[j * 256] = d.tB[j][0]; vB[j * 256 + 128] = d.tB[j][1];
-        vC[j * 256] = d.tC[j][0]; vC[j * 256 + 128] = d.tC[j][1];
-    }
-}
-
-// One step of a slot: the four planes r_xi(K, 0..3), 16 MFMAs (4 planes x 2 tile groups x 2 k steps).  vb[0], vb[1] (planes 0, 1 of this
-// step) are in registers on entry; planes 2, 3 are read behind the first MFMA, planes 0, 1 of the NEXT step behind the eighth (not across
-// a barrier: steps 4 and 8 leave that to the loop).  Dependent MFMAs are four issues apart.
-template <int S>
-__device__ __forceinline__ void w44r_step(f32x4 (&acc)[4][2], f32x4 (&bq)[QRING][2], unsigned bvoff, const float* bpre, const float* vq,
-                                          f32x4 (&vb)[4], const float* const (&gsrc)[QLPW], long goff, float* rawld, int wave, W44Xf& xf,
-                                          const float* prerow, const int (&roff)[6], float* vA, float* vB, float* vC, bool lower,
-                                          const W44K& kk) {
-    typedef __attribute__((address_space(1))) const void gptr_t;
-    typedef __attribute__((address_space(3))) void lptr_t;
-    constexpr int K = S % 9;
-    q_bload2(bq[(S + QBD) % QRING], bvoff, bpre);
-#pragma unroll
-    for (int i = 0; i < q_ndma(S); ++i) {
-        constexpr int L0 = q_dma0(S);
-        __builtin_amdgcn_global_load_lds((gptr_t*)(gsrc[L0 + i] + goff), (lptr_t*)(rawld + ((L0 + i) * 4 + wave) * 256), 16, 0, 0);
-    }
-    f32x4 (&b)[2] = bq[S % QRING];
-    q_bwait<q_nwait(S)>(b);
-    constexpr bool VACC = K == 8;
-    r_mfma<VACC>(acc[0][0], b[0][0], vb[0][0]);
-    __builtin_amdgcn_sched_barrier(0);
-    vb[2] = *reinterpret_cast<const f32x4*>(vq + r_xi(K, 2) * 256);
-    vb[3] = *reinterpret_cast<const f32x4*>(vq + r_xi(K, 3) * 256);
-    w44r_xf_lds<K>(xf, prerow, roff, vA, vB, vC);
-    __builtin_amdgcn_sched_barrier(0);
-    w44_xf_valu<K>(xf, lower, kk);
-    __builtin_amdgcn_sched_barrier(0);
-    // planes 0, 1: (q, tg, ks) in the order (0,1,0) (1,0,0) (1,1,0) | (0,0,1) (0,1,1) (1,0,1) (1,1,1); b[0] = {q0 ks0, q0 ks1, q1 ks0, q1 ks1}
-    r_mfma<VACC>(acc[0][1], b[0][0], vb[0][2]);
-    r_mfma<VACC>(acc[1][0], b[0][2], vb[1][0]);
-    r_mfma<VACC>(acc[1][1], b[0][2], vb[1][2]);
-    r_mfma<VACC>(acc[0][0], b[0][1], vb[0][1]);
-    r_mfma<VACC>(acc[0][1], b[0][1], vb[0][3]);
-    r_mfma<VACC>(acc[1][0], b[0][3], vb[1][1]);
-    r_mfma<VACC>(acc[1][1], b[0][3], vb[1][3]);
-    __builtin_amdgcn_sched_barrier(0);
-    r_mfma<VACC>(acc[2][0], b[1][0], vb[2][0]);
-    __builtin_amdgcn_sched_barrier(0);
-    if constexpr (K != 4 && K != 8) {
-        vb[0] = *reinterpret_cast<const f32x4*>(vq + r_xi(K + 1, 0) * 256);
-        vb[1] = *reinterpret_cast<const f32x4*>(vq + r_xi(K + 1, 1) * 256);
-    }
-    __builtin_amdgcn_sched_barrier(0);
-    r_mfma<VACC>(acc[2][1], b[1][0], vb[2][2]);
-    r_mfma<VACC>(acc[3][0], b[1][2], vb[3][0]);
-    r_mfma<VACC>(acc[3][1], b[1][2], vb[3][2]);
-    r_mfma<VACC>(acc[2][0], b[1][1], vb[2][1]);
-    r_mfma<VACC>(acc[2][1], b[1][1], vb[2][3]);
-    r_mfma<VACC>(acc[3][0], b[1][3], vb[3][1]);
-    r_mfma<VACC>(acc[3][1], b[1][3], vb[3][3]);
-    __builtin_amdgcn_sched_barrier(0);
-}
-
-__global__ __launch_bounds__(256) void wino44r_kernel(W44Params p) {
-#ifdef LM_QPROF
-    long long qprof[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
-    long long t_last = clock64();
-    const long long t_first = t_last;
-#endif
-    extern __shared__ __attribute__((aligned(16))) float smem[];      // raw[2][QRAWF] | V[QVF]
-    float* const raw0 = smem;
-    float* const Vbuf = smem + 2 * QRAWF;
-    typedef __attribute__((address_space(1))) const void gptr_t;
-    typedef __attribute__((address_space(3))) void lptr_t;
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int n_tiles = (p.Cout + QBN - 1) / QBN;
-    unsigned mblk, ntile;
-    {      // XCD-contiguous, N tile inner (see wino44_kernel)
-        const unsigned bid = blockIdx.x, per = gridDim.x / 8;
-        const unsigned lin = bid < per * 8 ? (bid % 8) * per + bid / 8 : bid;
-        mblk = lin / (unsigned)n_tiles;
-        ntile = lin % (unsigned)n_tiles;
-    }
-    const long m0 = (long)mblk * QBM;
-    const int n0 = (int)ntile * QBN;
-    const W44Geom& g = p.g;
-    const int bi = (int)(m0 / g.Tpad);
-    const int t0 = (int)(m0 - (long)bi * g.Tpad);
-    int ts[QSEG + 1], sn[QSEG], iy0[QSEG], ix0[QSEG], oy0[QSEG], ox0[QSEG];
-    {
-        int at = 0, t = t0;
-        int tx = t0 % g.Tx, rest = t0 / g.Tx;
-        int ty = rest % g.Ty, ph = rest / g.Ty;
-        int pa = ph / g.dil, pb = ph - pa * g.dil;
-#pragma unroll
-        for (int s_ = 0; s_ < QSEG; ++s_) {
-            ts[s_] = at;
-            const bool real = t < g.Timg && at < QBM;
-            const int n = at < QBM ? min(QBM - at, g.Tx - tx) : 0;
-            sn[s_] = real ? n : 0;
-            iy0[s_] = (4 * ty - 1) * g.dil + pa;
-            ix0[s_] = (4 * tx - 1) * g.dil + pb;
-            oy0[s_] = 4 * ty * g.dil + pa;
-            ox0[s_] = 4 * tx * g.dil + pb;
-            at += n;
-            t += n;
-            tx += n;
-            if (tx >= g.Tx) {
-                tx = 0;
-                if (++ty >= g.Ty) {
-                    ty = 0;
-                    if (++pb >= g.dil) {
-                        pb = 0;
-                        ++pa;
-                    }
-                }
-            }
-        }
-        ts[QSEG] = at;
-    }
-    const float* gsrc[QLPW];
-    const int img_pix0 = bi * g.H * g.W;
-#pragma unroll
-    for (int s_ = 0; s_ < QLPW; ++s_) {
-        const int cell = (s_ * 4 + wave) * 16 + (lane >> 2);
-        const int cq = lane & 3;
-        const int r = cell / QNCELL;
-        const int pos = cell - r * QNCELL;
-        const int slot = 4 * (pos >> 4) + (pos & 3), cc = (pos >> 2) & 3;
-        int n = sn[0], yb = iy0[0], xb = ix0[0], s0 = 0;
-#pragma unroll
-        for (int k = 1; k < QSEG; ++k)
-            if (slot >= ts[k] + k) {
-                n = sn[k]; yb = iy0[k]; xb = ix0[k]; s0 = ts[k] + k;
-            }
-        const int lc = 4 * (slot - s0) + cc;
-        const int yy = yb + r * g.dil, xx = xb + lc * g.dil;
-        const bool ok = (r < 6) & (n > 0) & (lc < 4 * n + 2) & ((unsigned)yy < (unsigned)g.H) & ((unsigned)xx < (unsigned)g.W);
-        const long eoff = ok ? (long)(img_pix0 + yy * g.W + xx) * p.ldx : 0;
-        gsrc[s_] = (ok ? p.x : p.zeros) + eoff + cq * 4;
-        __builtin_amdgcn_global_load_lds((gptr_t*)gsrc[s_], (lptr_t*)(raw0 + (s_ * 4 + wave) * 256), 16, 0, 0);
-        __builtin_amdgcn_sched_barrier(0);
-    }
-    int roff[6], tvoff;
-    {
-        const int tl = lane & 31;
-        int sg = 0;
-#pragma unroll
-        for (int k = 1; k < QSEG; ++k) sg += (ts[k] < QBM && tl >= ts[k]) ? 1 : 0;
-        const int slot = tl + sg, slot1 = slot + 1;
-        const int cp = (2 * (wave & 1) + (lane >> 5) + (slot >> 2)) & 3;
-        const int pos0 = 16 * (slot >> 2) + (slot & 3), pos1 = 16 * (slot1 >> 2) + (slot1 & 3);
-#pragma unroll
-        for (int c = 0; c < 6; ++c) roff[c] = ((c < 4 ? pos0 + 4 * c : pos1 + 4 * (c - 4)) * 16) + 2 * cp;
-        // channels 2 cp, 2 cp + 1 of the half: ks = cp & 1, kk = cp >> 1 and (cp >> 1) + 2  (plane layout [kk][tile % 16][tile / 16][ks])
-        tvoff = (cp >> 1) * 64 + (tl & 15) * 4 + (tl >> 4) * 2 + (cp & 1);
-    }
-    const bool lower = (wave >> 1) != 0;
-    float* const vA = Vbuf + (lower ? 3 : 0) * (6 * 256) + tvoff;
-    float* const vB = Vbuf + (lower ? 4 : 1) * (6 * 256) + tvoff;
-    float* const vC = Vbuf + (lower ? 5 : 2) * (6 * 256) + tvoff;
-    const W44K kk = {f32x2{2.f, 2.f}, f32x2{4.f, 4.f}, f32x2{5.f, 5.f}};
-    const float* const Vq = Vbuf + lane * 4;
-    const int nun = p.C / 16;
-    const unsigned bvoff = (unsigned)lane * 16u;
-    const long sstride = (long)p.NT * 512;                       // floats between steps in U (NT = CoutP / 16 channel blocks)
-    const long hstride = 9 * sstride;                            // ... between 8-channel halves
-    const float* const bbase = p.U + (long)((n0 >> 4) + wave) * 512;
-
-    f32x4 acc[9][4][2];
-#pragma unroll
-    for (int k = 0; k < 9; ++k)
-#pragma unroll
-        for (int q = 0; q < 4; ++q)
-#pragma unroll
-            for (int b = 0; b < 2; ++b) acc[k][q][b] = f32x4{0.f, 0.f, 0.f, 0.f};
-    f32x4 bq[QRING][2];
-    f32x4 vb[4];
-    W44Xf xf;
-    const int lowoff = lower ? QNCELL * 16 : 0;
-    LM_QTICK(0)
-#pragma unroll
-    for (int k = 0; k < QBD; ++k) q_bload2(bq[k], bvoff, bbase + (long)k * sstride);
-    {
-        const long goff1 = nun > 1 ? 16 : 0;
-#pragma unroll
-        for (int s_ = 0; s_ < QLPW; ++s_)
-            __builtin_amdgcn_global_load_lds((gptr_t*)(gsrc[s_] + goff1), (lptr_t*)(raw0 + QRAWF + (s_ * 4 + wave) * 256), 16, 0, 0);
-    }
-    q_bwait<QLPW>(bq[0]);
-    __builtin_amdgcn_s_barrier();
-    LM_QTICK(1)
-    w44r_xf_all(xf, raw0 + lowoff, roff, vA, vB, vC, lower, kk);
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    LM_QTICK(2)
-    __builtin_amdgcn_s_barrier();
-    LM_QTICK(3)
-
-#define LM_RBPRE(S5) ((S5) < 18 ? bu + (long)((S5) / 9) * hstride + (long)((S5) % 9) * sstride : bu_next + (long)((S5) - 18) * sstride)
-#define LM_RSTEP(S) \
-    w44r_step<S>(acc[(S) % 9], bq, bvoff, LM_RBPRE((S) + QBD), Vq, vb, gsrc, goff, rawc_w, wave, xf, (S) < 9 ? rawc + 8 + lowoff : rawn + lowoff, \
-                 roff, vA, vB, vC, lower, kk)
-#define LM_RREAD(K)                                                           \
-    vb[0] = *reinterpret_cast<const f32x4*>(Vq + r_xi(K, 0) * 256);           \
-    vb[1] = *reinterpret_cast<const f32x4*>(Vq + r_xi(K, 1) * 256);
-#define LM_RMID                                              \
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");       \
-    LM_QTICK(4)                                              \
-    __builtin_amdgcn_s_barrier();                            \
-    LM_QTICK(5)                                              \
-    LM_RREAD(5)
-    for (int u = 0; u < nun; ++u) {
-        const float* const rawc = raw0 + (u & 1) * QRAWF;
-        float* const rawc_w = raw0 + (u & 1) * QRAWF;
-        const float* const rawn = raw0 + ((u + 1) & 1) * QRAWF;
-        const long goff = u + 2 < nun ? (long)(u + 2) * 16 : 0;
-        const float* const bu = bbase + (long)(2 * u) * hstride;
-        const float* const bu_next = bbase + (long)(u + 1 < nun ? 2 * (u + 1) : 0) * hstride;
-        LM_RREAD(0)
-        LM_RSTEP(0); LM_RSTEP(1); LM_RSTEP(2); LM_RSTEP(3); LM_RSTEP(4);
-        LM_RMID
-        LM_RSTEP(5); LM_RSTEP(6); LM_RSTEP(7); LM_RSTEP(8);
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        LM_QTICK(4)
-        q_bwait<2 * 9>(bq[0]);
-        LM_QTICK(6)
-        __builtin_amdgcn_s_barrier();
-        LM_QTICK(5)
-        LM_RREAD(0)
-        LM_RSTEP(9);  LM_RSTEP(10); LM_RSTEP(11); LM_RSTEP(12); LM_RSTEP(13);
-        LM_RMID
-        LM_RSTEP(14); LM_RSTEP(15); LM_RSTEP(16); LM_RSTEP(17);
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        LM_QTICK(4)
-        __builtin_amdgcn_s_barrier();
-        LM_QTICK(5)
-    }
-#undef LM_RMID
-#undef LM_RREAD
-#undef LM_RSTEP
-#undef LM_RBPRE
-#pragma unroll
-    for (int k = 0; k < QRING; ++k) q_bwait<0>(bq[k]);
-    asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");             // (the last inline-asm MFMAs have left the pipe before their accumulators are read)
-    LM_QTICK(7)
-
-    // ---- epilogue, in registers: lane (tile % 16 = lane & 15, channel quad lane >> 4 of the wave's 16 channels) holds the 36 products of
-    // tiles lane & 15 and 16 + (lane & 15): A^T M A (rows first, then columns: w44_at), tail, sixteen 16-byte stores, twice
-    const int ecq = lane >> 4;
-    const int n = n0 + 16 * wave + 4 * ecq;
-    const float relu_lo = p.act == LM_ACT_RELU ? 0.f : -__builtin_inff();
-    const bool has_res = p.res != nullptr, gn = p.gn_part != nullptr;
-    const bool vec = (n + 3 < p.Cout) && ((p.ldy & 3) == 0) && (!p.res || (p.ldr & 3) == 0);
-    f32x4 sc = {1.f, 1.f, 1.f, 1.f}, sh = {0.f, 0.f, 0.f, 0.f};
-    if (vec) {
-        if (p.scale) sc = *reinterpret_cast<const f32x4*>(p.scale + n);
-        if (p.shift) sh = *reinterpret_cast<const f32x4*>(p.shift + n);
-    } else {
-#pragma unroll
-        for (int e = 0; e < 4; ++e)
-            if (n + e < p.Cout) {
-                if (p.scale) sc[e] = p.scale[n + e];
-                if (p.shift) sh[e] = p.shift[n + e];
-            }
-    }
-    f32x4 gsum[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}}, gsq[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
-    LM_QTICK(8)
-#pragma unroll
-    for (int tg = 0; tg < 2; ++tg) {
-        const int etile = tg * 16 + (lane & 15);
-        int epix0, eny = 0, enx = 0;
-        {
-            int nn = sn[0], oy = oy0[0], oxb = ox0[0], tb = 0;
-#pragma unroll
-            for (int k = 1; k < QSEG; ++k)
-                if (etile >= ts[k]) {
-                    nn = sn[k]; oy = oy0[k]; oxb = ox0[k]; tb = ts[k];
-                }
-            const int ox = oxb + 4 * (etile - tb) * g.dil;
-            epix0 = img_pix0 + oy * g.W + ox;
-            if (nn > 0 && oy < g.H && ox < g.W) {
-                eny = min(4, (g.H - oy + g.dil - 1) / g.dil);
-                enx = min(4, (g.W - ox + g.dil - 1) / g.dil);
-            }
-        }
-        const bool full = eny == 4 && enx == 4;
-        const int ebase = eny > 0 ? epix0 : img_pix0;
-        const int ey1 = max(eny - 1, 0), ex1 = max(enx - 1, 0);
-        f32x4 rpre[16];
-        const bool load_res = vec && has_res;
-        const float* const rp = p.res + (long)ebase * p.ldr + n;
-        const int rs = g.W * g.dil * p.ldr, cs = g.dil * p.ldr;
-        if (load_res) {
-#pragma unroll
-            for (int q = 0; q < 16; ++q) rpre[q] = *reinterpret_cast<const f32x4*>(rp + min(q >> 2, ey1) * rs + min(q & 3, ex1) * cs);
-        }
-        LM_QTICK(12)
-        if (n < p.Cout && eny > 0) {
-            f32x4 z[4][6];
-#pragma unroll
-            for (int j = 0; j < 6; ++j) {
-                f32x4 col[6], y4[4];
-#pragma unroll
-                for (int i = 0; i < 6; ++i) col[i] = acc[3 * (i % 3) + (j % 3)][2 * (i / 3) + (j / 3)][tg];
-                w44_at(col, y4);
-#pragma unroll
-                for (int yy = 0; yy < 4; ++yy) z[yy][j] = y4[yy];
-            }
-            float* const yp = p.y + (long)ebase * p.ldy + n;
-            const int rowstep = g.W * g.dil * p.ldy, colstep = g.dil * p.ldy;
-            if (vec) {
-                if (full) w44_tail_vec<true>(z, rpre, yp, rowstep, colstep, sc, sh, relu_lo, has_res, gn, gsum[tg], gsq[tg], eny, enx);
-                else w44_tail_vec<false>(z, rpre, yp, rowstep, colstep, sc, sh, relu_lo, has_res, gn, gsum[tg], gsq[tg], eny, enx);
-            } else {
-#pragma unroll
-                for (int yy = 0; yy < 4; ++yy) {
-                    f32x4 o[4];
-                    w44_at(z[yy], o);
-#pragma unroll
-                    for (int xx = 0; xx < 4; ++xx) {
-#pragma clang fp contract(off)
-                        const f32x4 v = o[xx] * sc + sh;
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) {
-                            if (!(yy < eny && xx < enx && n + e < p.Cout)) continue;
-                            if (gn) {
-                                gsum[tg][e] += v[e];
-                                gsq[tg][e] = __builtin_fmaf(v[e], v[e], gsq[tg][e]);
-                            }
-                            float u = v[e];
-                            if (has_res) u += p.res[((long)ebase + (yy * g.W + xx) * g.dil) * p.ldr + n + e];
-                            yp[yy * rowstep + xx * colstep + e] = fmaxf(u, relu_lo);
-                        }
-                    }
-                }
-            }
-        }
-        LM_QTICK(14)
-    }
-#ifdef LM_QPROF
-    if (tid == 0) {
-#pragma unroll
-        for (int k = 0; k < 15; ++k) g_qprof[blockIdx.x % QPROF_WG][k] = (unsigned long long)qprof[k];
-        g_qprof[blockIdx.x % QPROF_WG][11] = (unsigned long long)(clock64() - t_first);
-    }
-#endif
-    if (p.gn_part) {
-        // the reduction tree of wino44_kernel (same bits): tiles 8 g .. 8 g + 7 pairwise over tile bits 0, 1, 2 (there: the 8 lanes of a wave
-        // that share a channel quad), then the four 8-tile groups in ascending order (there: the four waves through LDS)
-#pragma unroll
-        for (int tg = 0; tg < 2; ++tg)
-#pragma unroll
-            for (int o = 1; o < 8; o <<= 1)
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    gsum[tg][e] += __shfl_xor(gsum[tg][e], o);
-                    gsq[tg][e] += __shfl_xor(gsq[tg][e], o);
-                }
-        f32x4 s = {0.f, 0.f, 0.f, 0.f}, q = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-        for (int tg = 0; tg < 2; ++tg)
-#pragma unroll
-            for (int hi = 0; hi < 2; ++hi)
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-#pragma clang fp contract(off)
-                    s[e] += __shfl(gsum[tg][e], (lane & 48) + 8 * hi);
-                    q[e] += __shfl(gsq[tg][e], (lane & 48) + 8 * hi);
-                }
-        if ((lane & 15) == 0) {
-            const long chunk = t0 / 32;
-            double* o = p.gn_part + (((long)bi * (g.Tpad / 32) + chunk) * p.Cout + n) * 2;
-            for (int e = 0; e < 4 && n + e < p.Cout; ++e) {
-                o[2 * e] = (double)s[e];
-                o[2 * e + 1] = (double)q[e];
-            }
-        }
-    }
-}
-
 // runs of adjacent tiles a 32-tile block can touch: floor((QBM - 2) / Tx) + 2
 bool w44_ok(const W44Geom& g) { return (QBM - 2) / g.Tx + 2 <= QSEG; }
 
@@ -1496,36 +1036,6 @@ LM_API int lm_conv3x3_winograd44_f32(void* stream, const float* x, int ldx, cons
     LM_REQUIRE(blocks > 0 && blocks < (1L << 31) && p.g.T % QBM == 0, "conv_wino44: bad grid %ld", blocks);
     if (int e = lm_ensure_dynamic_lds((const void*)wino44_kernel, lds)) return e;
     hipLaunchKernelGGL(wino44_kernel, dim3((unsigned)blocks), dim3(256), lds, (hipStream_t)stream, p);
-    LM_LAUNCH_CHECK();
-    return LM_OK;
-}
-
-// The same convolution through wino44r_kernel (accumulators split by output channel, output transform in registers: see its header).
-// wu_frag_r: [Cin / 8][9][CoutP / 16][2][64][4] floats (ops.pack_wino44_fragments_r):
-//   wu_frag_r[h][K][nb][d][lane][e] = U[xi][16 nb + (lane & 15)][8 h + c],  q = 2 d + e / 2, ks = e % 2, kk = lane >> 4,
-//   xi = 6 (K / 3 + 3 (q >> 1)) + K % 3 + 3 (q & 1),  c = (kk & 1 ? 4 : 0) + 2 ks + (kk >> 1).   Bit-identical to lm_conv3x3_winograd44_f32.
-LM_API int lm_conv3x3_winograd44r_f32(void* stream, const float* x, int ldx, const float* wu_frag_r, int CoutP, const float* scale,
-                                      const float* shift, const float* res, int ldr, float* y, int ldy, int B, int H, int W,
-                                      int Cin, int Cout, int dil, int act, double* gn_partial) {
-    LM_REQUIRE(x && wu_frag_r && y, "conv_wino44r: null pointer");
-    LM_REQUIRE(lm_winograd44_supported(H, W, Cin, dil) && B > 0, "conv_wino44r: unsupported shape (H=%d W=%d Cin=%d dil=%d)", H, W, Cin, dil);
-    LM_REQUIRE(CoutP >= Cout && CoutP % QBN == 0, "conv_wino44r: CoutP=%d must be Cout=%d rounded up to %d", CoutP, Cout, QBN);
-    LM_REQUIRE(ldx >= Cin && ldx % 4 == 0 && ldy >= Cout, "conv_wino44r: bad leading dimension");
-    LM_REQUIRE(act == LM_ACT_NONE || act == LM_ACT_RELU, "conv_wino44r: activation %d not supported", act);
-    LM_REQUIRE(!gn_partial || (res == nullptr && act == LM_ACT_NONE && Cout % 4 == 0), "conv_wino44r(gn stats): no residual / activation");
-    W44Params p;
-    p.g = geom44(B, H, W, dil);
-    LM_REQUIRE((long)B * H * W * ldx < (1L << 40) && (long)B * H * W < (1L << 31) && p.g.T < (1L << 31), "conv_wino44r: tensor too large");
-    p.x = x; p.U = wu_frag_r; p.scale = scale; p.shift = shift; p.res = res; p.y = y;
-    p.ldx = ldx; p.ldr = ldr; p.ldy = ldy; p.C = Cin; p.Cout = Cout; p.NT = CoutP / 16; p.act = act;
-    p.gn_part = gn_partial;
-    p.n_inner = 1;
-    if (int e = w44_zeros(&p.zeros)) return e;
-    const size_t lds = (size_t)(2 * QRAWF + QVF) * sizeof(float);
-    const long blocks = (p.g.T / QBM) * ((Cout + QBN - 1) / QBN);
-    LM_REQUIRE(blocks > 0 && blocks < (1L << 31) && p.g.T % QBM == 0, "conv_wino44r: bad grid %ld", blocks);
-    if (int e = lm_ensure_dynamic_lds((const void*)wino44r_kernel, lds)) return e;
-    hipLaunchKernelGGL(wino44r_kernel, dim3((unsigned)blocks), dim3(256), lds, (hipStream_t)stream, p);
     LM_LAUNCH_CHECK();
     return LM_OK;
 }

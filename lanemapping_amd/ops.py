@@ -98,26 +98,6 @@ def pack_wino44_fragments(wu):
     return t.permute(0, 3, 1, 4, 2, 5).contiguous().reshape(36, ci // 8, cop // 32, 64, 4)
 
 
-def pack_wino44_fragments_r(wu):
-    """pack_wino44 output U [36, CoutP, Cin] -> the per-wave-fragment order of lm_conv3x3_winograd44r_f32 (wino44r_kernel: a wave owns 16
-    output channels for all 36 xi; v_mfma_f32_16x16x4_f32 with U as the A operand): [Cin/8][9 steps][CoutP/16][2][lane 64][4] with
-    lane = kk * 16 + m, element e of load d: plane q = 2 d + e // 2 of step K, k step ks = e % 2,
-    xi = 6 (K // 3 + 3 (q >> 1)) + K % 3 + 3 (q & 1), channel = 8 h + (4 if kk & 1 else 0) + 2 ks + (kk >> 1)."""
-    xi_n, cop, ci = wu.shape
-    assert xi_n == 36 and cop % 64 == 0 and ci % 16 == 0
-    dev = wu.device
-    K = torch.arange(9, device=dev).view(9, 1, 1, 1)
-    d = torch.arange(2, device=dev).view(1, 2, 1, 1)
-    lane = torch.arange(64, device=dev).view(1, 1, 64, 1)
-    e = torch.arange(4, device=dev).view(1, 1, 1, 4)
-    q, ks, kk, m = 2 * d + e // 2, e % 2, lane >> 4, lane & 15
-    xi = (6 * (K // 3 + 3 * (q >> 1)) + K % 3 + 3 * (q & 1)).expand(9, 2, 64, 4)
-    c = (4 * (kk & 1) + 2 * ks + (kk >> 1)).expand(9, 2, 64, 4)
-    m = m.expand(9, 2, 64, 4)
-    t = wu.reshape(36, cop // 16, 16, ci // 8, 8).permute(3, 1, 0, 2, 4)             # h, nb, xi, m, c
-    return t[:, :, xi, m, c].permute(0, 2, 1, 3, 4, 5).contiguous()                  # h, K, nb, d, lane, e
-
-
 def pack_small(w):
     """[Cout<=16,Cin,KH,KW] -> [KH*KW, Cin, 16]."""
     co, ci, kh, kw = w.shape
@@ -193,10 +173,7 @@ def conv_wino44(x, wf, cout, dil=1, scale=None, shift=None, res=None, act=ACT_NO
     conv_wino44_twin.  With gn_eps returns (y, stats) like conv_wino_implicit."""
     x, ldx = as_nhwc(x)
     B, cin, H, W = x.shape
-    if wf.dim() == 6:            # pack_wino44_fragments_r: wino44r_kernel (accumulators split by output channel, output transform in registers)
-        cop, fn = wf.shape[2] * 16, lib().lm_conv3x3_winograd44r_f32
-    else:                        # pack_wino44_fragments: wino44_kernel (split by quadrant of the transform, products exchanged through LDS)
-        cop, fn = wf.shape[2] * 32, lib().lm_conv3x3_winograd44_f32
+    cop, fn = wf.shape[2] * 32, lib().lm_conv3x3_winograd44_f32
     y = out if out is not None else new_act(B, cout, H, W, x.device)
     y_, ldy = as_nhwc(y)
     assert y_.data_ptr() == y.data_ptr(), 'conv_wino44: `out` must already be NHWC-stored'

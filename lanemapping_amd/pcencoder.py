@@ -31,13 +31,8 @@ WINO_F44 = os.environ.get('LANEMAP_WINO_F44', '1') != '0'
 WINO_F44_MIN_CIN = int(os.environ.get('LANEMAP_WINO_F44_MIN_CIN', '64'))
 
 
-# LANEMAP_W44_REG=0: wino44_kernel (accumulators split by quadrant of the transform, products exchanged through LDS) instead of
-# wino44r_kernel (split by output channel, output transform in registers); bit-identical convolution outputs
-W44_REG = os.environ.get('LANEMAP_W44_REG', '1') != '0'
-
-
 def _frag44(w):
-    return (ops.pack_wino44_fragments_r if W44_REG else ops.pack_wino44_fragments)(ops.pack_wino44(w))
+    return ops.pack_wino44_fragments(ops.pack_wino44(w))
 
 
 def _f44_ok(conv):

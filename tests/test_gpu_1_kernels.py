@@ -625,12 +625,8 @@ def test_conv_winograd44_bit_identical_to_twin(dev, B, cin, cout, H, W, dil):
     wu = ops.pack_wino44(w.to(dev))
     wf = ops.pack_wino44_fragments(wu)
     sd, bd = scale.to(dev), shift.to(dev)
-    wfr = ops.pack_wino44_fragments_r(wu)
     y0 = ops.conv_wino44_twin(xd, wu, cout, dil, scale=sd, shift=bd, res=rd, act=ops.ACT_RELU)
     y1 = ops.conv_wino44(xd, wf, cout, dil, scale=sd, shift=bd, res=rd, act=ops.ACT_RELU)
-    y1r = ops.conv_wino44(xd, wfr, cout, dil, scale=sd, shift=bd, res=rd, act=ops.ACT_RELU)          # wino44r_kernel (the default route)
-    assert torch.equal(y1r, y0), float((y1r - y0).abs().max())
-    assert torch.equal(y1r, ops.conv_wino44(xd, wfr, cout, dil, scale=sd, shift=bd, res=rd, act=ops.ACT_RELU))
     want = F.relu(F.conv2d(x.double(), w.double(), None, 1, dil, dil) * scale.double().view(1, -1, 1, 1) + shift.double().view(1, -1, 1, 1)
                   + res.double()).float()
     _close(y0, want, 1e-4, 'winograd F(4x4) twin vs fp64')
@@ -643,7 +639,7 @@ def test_conv_winograd44_bit_identical_to_twin(dev, B, cin, cout, H, W, dil):
     outw = ops.new_act(B, cout + 8, H, W, dev).zero_()
     y2 = ops.conv_wino44_twin(xd, wu, cout, dil, shift=bd)
     stats = []
-    for frag in (wf, wfr):
+    for frag in (wf,):
         outw = ops.new_act(B, cout + 8, H, W, dev).zero_()
         ops.conv_wino44(wide[:, 16:16 + cin], frag, cout, dil, shift=bd, out=outw[:, 4:4 + cout])
         assert torch.equal(outw[:, 4:4 + cout], y2) and float(outw[:, :4].abs().max()) == 0 and float(outw[:, 4 + cout:].abs().max()) == 0
@@ -654,8 +650,6 @@ def test_conv_winograd44_bit_identical_to_twin(dev, B, cin, cout, H, W, dil):
             y4, st2 = ops.conv_wino44(xd, frag, cout, dil, shift=bd, gn_eps=1e-5)
             assert torch.equal(st, st2)
             stats.append(st)
-    if len(stats) == 2:                                        # the register epilogue reduces in the exchange epilogue's order: same bits
-        assert torch.equal(stats[0], stats[1])
 
 
 def test_conv_winograd44_random_shapes_vs_twin(dev):
@@ -694,14 +688,9 @@ def test_conv_winograd44_random_shapes_vs_twin(dev):
         y0 = ops.conv_wino44_twin(x, wu, cout, dil, scale=sc, shift=sh, res=res, act=act)
         y1 = ops.conv_wino44(x, wf, cout, dil, scale=sc, shift=sh, res=res, act=act)
         y2 = ops.conv_wino44(x, wf, cout, dil, scale=sc, shift=sh, res=res, act=act)
-        wfr = ops.pack_wino44_fragments_r(wu)
-        y3 = ops.conv_wino44(x, wfr, cout, dil, scale=sc, shift=sh, res=res, act=act)
-        y4 = ops.conv_wino44(x, wfr, cout, dil, scale=sc, shift=sh, res=res, act=act)
         tag = f'shape {done}: B{B} {cin}->{cout} {H}x{W} d{dil} scale={use_scale} res={use_res} relu={relu}'
         assert torch.equal(y0, y1), (tag, float((y0 - y1).abs().max()))
         assert torch.equal(y1, y2), tag
-        assert torch.equal(y0, y3), (tag + ' (wino44r_kernel)', float((y0 - y3).abs().max()))
-        assert torch.equal(y3, y4), tag + ' (wino44r_kernel, run to run)'
         if cin % 32 == 0:                       # (and against the direct MFMA kernel where it takes the shape: the twin shares the fused kernel's arithmetic)
             yd = ops.conv_mfma(x, ops.pack_mfma(w), cout, 3, 3, 1, dil, dil, scale=sc, shift=sh, res=res, act=act)
             _close(y1, yd, 1e-4, tag + ' vs direct')
