@@ -589,41 +589,7 @@ __global__ __launch_bounds__(256) void wino44_kernel(W44Params p) {
     const W44Geom& g = p.g;
     const int bi = (int)(m0 / g.Tpad);
     const int t0 = (int)(m0 - (long)bi * g.Tpad);
-    // run table: the 32 tiles are consecutive in the linear (phase, ty, tx) order = up to QSEG runs of horizontally adjacent tiles.
-    // Run k holds tiles ts[k] .. ts[k+1]-1 and occupies tile SLOTS ts[k] + k .. ts[k+1] + k (one spill slot for patch columns 4, 5 of
-    // its last tile); iy0 / ix0 = input pixel of patch cell (0, 0) of its first tile, oy0 / ox0 = output pixel (0, 0) of that tile
-    int ts[QSEG + 1], sn[QSEG], iy0[QSEG], ix0[QSEG], oy0[QSEG], ox0[QSEG];
-    {
-        int at = 0, t = t0;
-        int tx = t0 % g.Tx, rest = t0 / g.Tx;
-        int ty = rest % g.Ty, ph = rest / g.Ty;
-        int pa = ph / g.dil, pb = ph - pa * g.dil;
-#pragma unroll
-        for (int s_ = 0; s_ < QSEG; ++s_) {
-            ts[s_] = at;
-            const bool real = t < g.Timg && at < QBM;
-            const int n = at < QBM ? min(QBM - at, g.Tx - tx) : 0;
-            sn[s_] = real ? n : 0;
-            iy0[s_] = (4 * ty - 1) * g.dil + pa;
-            ix0[s_] = (4 * tx - 1) * g.dil + pb;
-            oy0[s_] = 4 * ty * g.dil + pa;
-            ox0[s_] = 4 * tx * g.dil + pb;
-            at += n;
-            t += n;
-            tx += n;
-            if (tx >= g.Tx) {
-                tx = 0;
-                if (++ty >= g.Ty) {
-                    ty = 0;
-                    if (++pb >= g.dil) {
-                        pb = 0;
-                        ++pa;
-                    }
-                }
-            }
-        }
-        ts[QSEG] = at;
-    }
+#include "wino44_runtable.inc"
     // patch loads: load s of wave w fills chunks (s * 4 + w) * 64 .. + 63 of the raw buffer; chunk = 16 B = channel quad cq of a cell;
     // cell = patch row r x position pos; position = 16 (slot >> 2) + 4 c + (slot & 3) for column c (0..3) of tile slot `slot`: the cells
     // one column of consecutive tiles needs are neighbours in LDS (the transform's ds_read_b64 then conflicts two-way at most)
@@ -778,178 +744,316 @@ __global__ __launch_bounds__(256) void wino44_kernel(W44Params p) {
 #ifdef LM_QABL_NOEPI
     if (p.act != 12345) return;
 #endif
-    // ---- epilogue: the products of one 32-channel block go to LDS as M[xi][tile][32 channels] (144 KB; straight from the accumulator
-    // registers), every thread takes one (tile, channel quad): 36 ds_read_b128, A^T M A (rows first, then columns: w44_at), tail, 16 stores
-    const int etile = tid >> 3, ecq = tid & 7;
-    int epix0;
-    int eny = 0, enx = 0;                                   // valid output rows / columns of this thread's tile (0: no tile)
-    {
-        int nn = sn[0], oy = oy0[0], oxb = ox0[0], tb = 0;
+#include "wino44_epilogue.inc"
+}
+
+// ===================================================================================================================================
+// wino44s_kernel (round 5): the input transform leaves the matrix workgroups.
+//
+// In wino44_kernel every workgroup transforms its own patches: V = B^T d B of a 32-tile block is recomputed by each of the Cout / 64
+// workgroups that multiply it, and f32 MFMA shares the SIMD's vector ALUs, so those 72 packed VALU instructions per 72 MFMAs are 13.7 % of
+// the kernel (timing ablation profiles/r5_wino44_ablation.txt: 4.10 -> 3.54 ms at 256 -> 256 @288^2 with the transform compiled out).
+// Here a block's V is produced ONCE, by a light TRANSFORM workgroup (no MFMA: ~1/6 of a matrix workgroup's time), written to a scratch
+// buffer slot by slot and read by the block's matrix workgroups - one launch, two roles:
+//   T(m)      raw patches of M block m (global_load_lds, 8-channel halves, ring of 4) -> B^T d B in LDS -> 36 planes x 1 KB per slot to
+//             Vg[m][slot] with write-through (sc1) 16-byte stores -> flags[m] = slots published (sc1 store, one lane).
+//             Waves 0, 1 issue every load, waves 2, 3 every store: vmcnt counts loads and stores of ONE wave in one counter and they
+//             complete out of order with respect to each other, so a wave that waits by count must issue one kind only.
+//   C(m, nt)  a matrix workgroup of wino44_kernel WITHOUT transform, raw patches and mid-slot barriers: every wave DMAs the nine planes
+//             of ITS quadrant (global_load_lds ... sc1, ring of four slots, three slots ahead) and reads only those - no barrier in
+//             the K loop at all; B fragments, MFMA order, accumulators and the epilogue are wino44_kernel's: bit-identical y.
+// Placement-independent hand-off (MI355X_MICROARCH.md, inter-workgroup visibility, form R1): sc1 payload stores -> s_waitcnt on the
+// storing waves -> workgroup barrier -> sc1 flag store; consumer: relaxed agent-scope poll of the flag -> sc1 loads.
+// No assumption about dispatch order: roles come from TICKETS (atomicAdd on a per-XCD head, the XCD read from HW_REG_XCC_ID so that the
+// workgroups of an M block share an L2 for the input lines and U; other heads are tried when the own one is exhausted).  Ticket order per
+// head: T(0), T(1), C(0, *), T(2), C(1, *), ...: a workgroup that holds C(m, .) implies T(m)'s ticket was taken earlier by a workgroup
+// that is running or done - a consumer can wait for its producer, a producer waits for nobody: no deadlock under any dispatch order.
+constexpr int TRING = 4;                         // raw halves in flight (transform role)
+constexpr int TLPW = 14;                         // patch loads per LOADER wave and 8-channel half (27 KB = 27 x 1 KB, two loader waves)
+constexpr int TRAWF = TLPW * 2 * 256;            // floats of one raw half buffer (28 KB; cells 864.. are zero-source padding)
+constexpr int SRING = 4;                         // V slots in LDS (matrix role), three ahead
+static_assert(6 * QNCELL * 8 <= TRAWF, "patch loads cover the half");
+
+struct W44SParams {
+    W44Params p;
+    float* Vg;                                   // [M blocks][C / 8 slots][36][256]
+    unsigned* flags;                             // [M blocks] slots published by T(m)
+    unsigned* heads;                             // [8] ticket counters
+    int mblocks, n_tiles;
+};
+
+__device__ __forceinline__ void sc1_store_x4(float* gp, const f32x4 v) {
+    asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(gp), "v"(v) : "memory");
+}
+constexpr int qxi(int K) { return 6 * (K / 3) + K % 3; }
+
+template <int C>
+__device__ __forceinline__ void w44t_preread(W44Xf& d, const float* rawrow, const int (&roff)[6]) {
+    constexpr int ROWF = QNCELL * 8;
+    const float* s = rawrow + roff[C];
 #pragma unroll
-        for (int k = 1; k < QSEG; ++k)
-            if (etile >= ts[k]) {
-                nn = sn[k]; oy = oy0[k]; oxb = ox0[k]; tb = ts[k];
+    for (int r = 0; r < 5; ++r) d.e[C][r] = *reinterpret_cast<const f32x2*>(s + r * ROWF);
+}
+
+// one step of the matrix role: B fragments of step S + QBD, ONE plane of the V slot three ahead, then wino44_kernel's 8 MFMAs
+template <int S>
+__device__ __forceinline__ void w44c_step(f32x16& acc0, f32x16& acc1, f32x4 (&bq)[QRING][2], unsigned bvoff, const float* bpre, const float* anext,
+                                          const f32x4& a_cur, f32x4& a_nxt, const float* vsrc, float* vdst) {
+    typedef __attribute__((address_space(1))) const void gptr_t;
+    typedef __attribute__((address_space(3))) void lptr_t;
+    constexpr int K = S % 9;
+    q_bload2(bq[(S + QBD) % QRING], bvoff, bpre);
+    __builtin_amdgcn_global_load_lds((gptr_t*)vsrc, (lptr_t*)vdst, 16, 0, 16);          // aux 16 = sc1
+    f32x4 (&b)[2] = bq[S % QRING];
+    q_bwait<3 * QBD + 1>(b);          // younger than this step's B fragments: the plane of step S - QBD and 3 loads per step since
+    constexpr bool VACC = K == 8;
+    q_mfma<VACC>(acc0, a_cur[0], b[0][0]);
+    __builtin_amdgcn_sched_barrier(0);
+    a_nxt = *reinterpret_cast<const f32x4*>(anext);
+    __builtin_amdgcn_sched_barrier(0);
+    q_mfma<VACC>(acc1, a_cur[0], b[1][0]);
+#pragma unroll
+    for (int t = 1; t < 4; ++t) {
+        q_mfma<VACC>(acc0, a_cur[t], b[0][t]);
+        q_mfma<VACC>(acc1, a_cur[t], b[1][t]);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+}
+
+__global__ __launch_bounds__(256) void wino44s_kernel(W44SParams sp) {
+    const W44Params& p = sp.p;
+#ifdef LM_QPROF
+    long long qprof[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    long long t_last = clock64();
+    const long long t_first = t_last;
+#endif
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    __shared__ int s_ticket[2];
+    typedef __attribute__((address_space(1))) const void gptr_t;
+    typedef __attribute__((address_space(3))) void lptr_t;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int n_tiles = sp.n_tiles, grp = n_tiles + 1;
+    const int per = sp.mblocks / 8, rem = sp.mblocks % 8;
+    if (tid == 0) {
+        unsigned x;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(x));
+        x &= 7u;
+        int got = -1, q = 0;
+        for (; q < 8; ++q) {
+            const unsigned xq = (x + (unsigned)q) & 7u;
+            const unsigned cnt = (unsigned)((per + ((int)xq < rem ? 1 : 0)) * grp);
+            if (cnt == 0) continue;
+            const unsigned t = atomicAdd(&sp.heads[xq], 1u);
+            if (t < cnt) {
+                got = (int)t;
+                x = xq;
+                break;
             }
-        const int ox = oxb + 4 * (etile - tb) * g.dil;
-        epix0 = img_pix0 + oy * g.W + ox;
-        if (nn > 0 && oy < g.H && ox < g.W) {
-            eny = min(4, (g.H - oy + g.dil - 1) / g.dil);
-            enx = min(4, (g.W - ox + g.dil - 1) / g.dil);
+        }
+        s_ticket[0] = got;
+        s_ticket[1] = (int)x;
+    }
+    __syncthreads();
+    const int ticket = __builtin_amdgcn_readfirstlane(s_ticket[0]), xq = __builtin_amdgcn_readfirstlane(s_ticket[1]);
+    if (ticket < 0) return;                          // (cannot happen: tickets = workgroups)
+    int mblk, ntile;                                 // ntile < 0: transform role
+    {
+        const int Mx = per + (xq < rem ? 1 : 0), mlo = xq * per + (xq < rem ? xq : rem);
+        if (ticket == 0) {
+            mblk = mlo; ntile = -1;
+        } else {
+            const int u = ticket - 1;
+            if (u < (Mx - 1) * grp) {
+                const int k = u / grp, r = u - k * grp;
+                if (r == 0) { mblk = mlo + k + 1; ntile = -1; }
+                else { mblk = mlo + k; ntile = r - 1; }
+            } else {
+                mblk = mlo + Mx - 1; ntile = u - (Mx - 1) * grp;
+            }
         }
     }
-    float* const mw = smem + xi00 * 1024 + (4 * (lane >> 5)) * 32 + (lane & 31);      // this wave's planes, this lane's origin
-    const float* const mr = smem + etile * 32 + ecq * 4;
-    f32x4 gsum[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}}, gsq[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
-    const bool full = eny == 4 && enx == 4;
-    const int ebase = eny > 0 ? epix0 : img_pix0;                 // (a missing tile reads - and never writes - pixel 0 of its image)
-    const int ey1 = max(eny - 1, 0), ex1 = max(enx - 1, 0);
-    const float relu_lo = p.act == LM_ACT_RELU ? 0.f : -__builtin_inff();               // fmaxf(v, -inf) = v
-    const bool has_res = p.res != nullptr, gn = p.gn_part != nullptr;
-    LM_QTICK(8)
+    const long m0 = (long)mblk * QBM;
+    const W44Geom& g = p.g;
+    const int bi = (int)(m0 / g.Tpad);
+    const int t0 = (int)(m0 - (long)bi * g.Tpad);
+#include "wino44_runtable.inc"
+    const int img_pix0 = bi * g.H * g.W;
+    const int nslots = p.C / 8;
+    float* const Vgm = sp.Vg + (long)mblk * nslots * (36 * 256);
+
+    if (ntile < 0) {
+        // ================================================================================= transform role
+        float* const raw0 = smem;                                    // raw[TRING][TRAWF] | V[QVF]
+        float* const Vbuf = smem + TRING * TRAWF;
+        const bool loader = wave < 2;
+        // patch loads (loader waves 0, 1): load s of loader wave w fills 16-byte chunks (s * 2 + w) * 64 .. + 63 of a raw half buffer;
+        // chunk = channel quad cq (0, 1) of a cell; cell order as in wino44_kernel (position = 16 (slot >> 2) + 4 c + (slot & 3))
+        const float* gsrc[TLPW];
 #pragma unroll
-    for (int blk = 0; blk < 2; ++blk) {
-        const int n = n0 + blk * 32 + ecq * 4;
-        const bool vec = (n + 3 < p.Cout) && ((p.ldy & 3) == 0) && (!p.res || (p.ldr & 3) == 0);
-        // residual (BasicBlock identity): the sixteen 16-byte loads of this thread's outputs go out BEFORE the exchange - inside the
-        // store loop each was a memory round trip of its own in front of a store (y may alias res as far as the compiler knows).
-        // Branch-free: offsets clamped into the tile's valid part (equal to the true offsets wherever an output exists)
-        f32x4 sc = {1.f, 1.f, 1.f, 1.f}, sh = {0.f, 0.f, 0.f, 0.f};             // (v * 1 + 0 = v exactly: same bits as the twin's `v + shift`)
-        if (vec) {
-            if (p.scale) sc = *reinterpret_cast<const f32x4*>(p.scale + n);
-            if (p.shift) sh = *reinterpret_cast<const f32x4*>(p.shift + n);
-        } else {
+        for (int s_ = 0; s_ < TLPW; ++s_) {
+            const int chunk = (s_ * 2 + (wave & 1)) * 64 + lane;
+            const int cell = chunk >> 1, cq = chunk & 1;
+            const int r = cell / QNCELL;
+            const int pos = cell - r * QNCELL;
+            const int slot = 4 * (pos >> 4) + (pos & 3), cc = (pos >> 2) & 3;
+            int n = sn[0], yb = iy0[0], xb = ix0[0], s0 = 0;
 #pragma unroll
-            for (int e = 0; e < 4; ++e)
-                if (n + e < p.Cout) {
-                    if (p.scale) sc[e] = p.scale[n + e];
-                    if (p.shift) sh[e] = p.shift[n + e];
+            for (int k = 1; k < QSEG; ++k)
+                if (slot >= ts[k] + k) {
+                    n = sn[k]; yb = iy0[k]; xb = ix0[k]; s0 = ts[k] + k;
                 }
+            const int lc = 4 * (slot - s0) + cc;
+            const int yy = yb + r * g.dil, xx = xb + lc * g.dil;
+            const bool ok = (r < 6) & (n > 0) & (lc < 4 * n + 2) & ((unsigned)yy < (unsigned)g.H) & ((unsigned)xx < (unsigned)g.W);
+            const long eoff = ok ? (long)(img_pix0 + yy * g.W + xx) * p.ldx : 0;
+            gsrc[s_] = (ok ? p.x : p.zeros) + eoff + cq * 4;
         }
-        // residual (BasicBlock identity): the sixteen 16-byte loads of this thread's outputs are issued BETWEEN the product stores of the
-        // exchange - issuing them costs ~140 cycles apiece here (cold lines, eight 128-byte segments 4 KB apart per wave instruction:
-        // profiles/r4_wino44_residual_issue_experiment.txt), the LDS store path drains its queue meanwhile; inside the store loop of the tail
-        // each would be a memory round trip of its own in front of a store (y may alias res as far as the compiler knows).
-        // Branch-free: offsets clamped into the tile's valid part (equal to the true offsets wherever an output exists)
-        f32x4 rpre[16];
-#ifdef LM_QABL_NORES
-        const bool load_res = false;
-#else
-        const bool load_res = vec && has_res;
-#endif
-        const float* const rp = p.res + (long)ebase * p.ldr + n;
-        const int rs = g.W * g.dil * p.ldr, cs = g.dil * p.ldr;
-        // (LDS-only barriers: __syncthreads() would also wait for the previous block's global stores to be acknowledged)
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        LM_QTICK(9)
-        __builtin_amdgcn_s_barrier();          // patch / V buffers (blk 0) or the previous block's products are no longer read
-        LM_QTICK(10)
+        auto dma_half = [&](int h) {                                  // raw half h (channels 8 h .. 8 h + 7) -> ring slot h % TRING
+            const int hh = h < nslots ? h : nslots - 1;               // (past the end: a harmless re-read keeps the wait counts uniform)
+            float* const dst = raw0 + (h % TRING) * TRAWF;
 #pragma unroll
-        for (int k = 0; k < 9; ++k) {
-#pragma unroll
-            for (int r = 0; r < 16; ++r) mw[(6 * (k / 3) + k % 3) * 1024 + ((r & 3) + 8 * (r >> 2)) * 32] = acc[k][blk][r];
-            if (k < 8 && load_res) {
-#pragma unroll
-                for (int q = 2 * k; q < 2 * k + 2; ++q)
-                    rpre[q] = *reinterpret_cast<const f32x4*>(rp + min(q >> 2, ey1) * rs + min(q & 3, ex1) * cs);
-            }
-            __builtin_amdgcn_sched_barrier(0);
+            for (int s_ = 0; s_ < TLPW; ++s_)
+                __builtin_amdgcn_global_load_lds((gptr_t*)(gsrc[s_] + 8 * hh), (lptr_t*)(dst + (s_ * 2 + (wave & 1)) * 256), 16, 0, 0);
+        };
+        if (loader) {
+            dma_half(0); dma_half(1); dma_half(2);
         }
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        LM_QTICK(12)
-        __builtin_amdgcn_s_barrier();
-        LM_QTICK(13)
-        if (n < p.Cout && eny > 0) {
-            f32x4 z[4][6];
+        // transform share: as in wino44_kernel (tile = lane & 31, LOWER = wave >> 1, channel pair skewed by the tile slot); 32-byte cells
+        int roff[6], tvoff;
+        {
+            const int tl = lane & 31;
+            int sg = 0;
+#pragma unroll
+            for (int k = 1; k < QSEG; ++k) sg += (ts[k] < QBM && tl >= ts[k]) ? 1 : 0;
+            const int slot = tl + sg, slot1 = slot + 1;
+            const int cp = (2 * (wave & 1) + (lane >> 5) + (slot >> 2)) & 3;
+            const int pos0 = 16 * (slot >> 2) + (slot & 3), pos1 = 16 * (slot1 >> 2) + (slot1 & 3);
+#pragma unroll
+            for (int c = 0; c < 6; ++c) roff[c] = ((c < 4 ? pos0 + 4 * c : pos1 + 4 * (c - 4)) * 8) + 2 * cp;
+            // plane layout of the hand-off = the A fragment of the matrix role: [lane = (cp >> 1) * 32 + tile][4 channels], this pair at 2 (cp & 1)
+            tvoff = ((cp >> 1) * 32 + tl) * 4 + 2 * (cp & 1);
+        }
+        const bool lower = (wave >> 1) != 0;
+        float* const vA = Vbuf + (lower ? 3 : 0) * (6 * 256) + tvoff;
+        float* const vB = Vbuf + (lower ? 4 : 1) * (6 * 256) + tvoff;
+        float* const vC = Vbuf + (lower ? 5 : 2) * (6 * 256) + tvoff;
+        const W44K kk = {f32x2{2.f, 2.f}, f32x2{4.f, 4.f}, f32x2{5.f, 5.f}};
+        const int lowoff = lower ? QNCELL * 8 : 0;
+        W44Xf xf;
+        for (int h = 0; h < nslots; ++h) {
+            // loader waves: raw half h has landed (younger loads: halves h + 1, h + 2); storer waves: nothing to wait for here
+            if (loader) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * TLPW) : "memory");
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");        // (the copy-out reads of half h - 1)
+            __builtin_amdgcn_s_barrier();                             // A: raw(h) visible, V free, V(h - 2)'s stores complete on both storer waves
+            if (tid == 128 && h >= 2)                                 // (first lane of storer wave 2: its flag store stays in store order)
+                __hip_atomic_store(sp.flags + mblk, (unsigned)(h - 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (loader) dma_half(h + 3);                              // into the slot of half h - 1 (read before the previous barrier B)
+            const float* const rawrow = raw0 + (h % TRING) * TRAWF + lowoff;
+            w44t_preread<0>(xf, rawrow, roff); w44t_preread<1>(xf, rawrow, roff); w44t_preread<2>(xf, rawrow, roff);
+            w44t_preread<3>(xf, rawrow, roff); w44t_preread<4>(xf, rawrow, roff); w44t_preread<5>(xf, rawrow, roff);
+            w44_xf_valu<1>(xf, lower, kk); w44_xf_valu<2>(xf, lower, kk); w44_xf_valu<3>(xf, lower, kk);
+            w44_xf_valu<4>(xf, lower, kk); w44_xf_valu<5>(xf, lower, kk); w44_xf_valu<6>(xf, lower, kk);
 #pragma unroll
             for (int j = 0; j < 6; ++j) {
-                f32x4 col[6], y4[4];
-#pragma unroll
-                for (int i = 0; i < 6; ++i) col[i] = *reinterpret_cast<const f32x4*>(mr + (6 * i + j) * 1024);
-                w44_at(col, y4);
-#pragma unroll
-                for (int yy = 0; yy < 4; ++yy) z[yy][j] = y4[yy];
+                *reinterpret_cast<f32x2*>(vA + j * 256) = xf.tA[j];
+                *reinterpret_cast<f32x2*>(vB + j * 256) = xf.tB[j];
+                *reinterpret_cast<f32x2*>(vC + j * 256) = xf.tC[j];
             }
-            float* const yp = p.y + (long)ebase * p.ldy + n;
-            const int rowstep = g.W * g.dil * p.ldy, colstep = g.dil * p.ldy;
-            if (vec) {
-                if (full) w44_tail_vec<true>(z, rpre, yp, rowstep, colstep, sc, sh, relu_lo, has_res, gn, gsum[blk], gsq[blk], eny, enx);
-                else w44_tail_vec<false>(z, rpre, yp, rowstep, colstep, sc, sh, relu_lo, has_res, gn, gsum[blk], gsq[blk], eny, enx);
-            } else {                           // channel counts / leading dimensions that rule out 16-byte accesses: element by element
-                // (fully unrolled with guards: a run-time index into z would move the array - on the 16-byte path too - to scratch memory)
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();                             // B: V(h) complete, raw(h) no longer read
+            if (!loader) {                                            // storer waves: 18 planes each, 1 KB per instruction
+                float* const dst = Vgm + (long)h * (36 * 256) + (wave - 2) * (18 * 256) + lane * 4;
+                const float* const src = Vbuf + (wave - 2) * (18 * 256) + lane * 4;
 #pragma unroll
-                for (int yy = 0; yy < 4; ++yy) {
-                    f32x4 o[4];
-                    w44_at(z[yy], o);
-#pragma unroll
-                    for (int xx = 0; xx < 4; ++xx) {
-#pragma clang fp contract(off)
-                        const f32x4 v = o[xx] * sc + sh;
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) {
-                            if (!(yy < eny && xx < enx && n + e < p.Cout)) continue;
-                            if (gn) {
-                                gsum[blk][e] += v[e];
-                                gsq[blk][e] = __builtin_fmaf(v[e], v[e], gsq[blk][e]);
-                            }
-                            float u = v[e];
-                            if (has_res) u += p.res[((long)ebase + (yy * g.W + xx) * g.dil) * p.ldr + n + e];
-                            yp[yy * rowstep + xx * colstep + e] = fmaxf(u, relu_lo);
-                        }
-                    }
-                }
+                for (int k = 0; k < 18; ++k) sc1_store_x4(dst + k * 256, *reinterpret_cast<const f32x4*>(src + k * 256));
+                asm volatile("s_waitcnt vmcnt(18)" ::: "memory");     // everything older than this half's 18 stores - V(h - 1) - is complete
             }
         }
-        LM_QTICK(14)
+        if (!loader) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        if (tid == 128) __hip_atomic_store(sp.flags + mblk, (unsigned)nslots, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (loader) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // (the padding loads past the end land before the LDS is released)
+        return;
     }
-#ifdef LM_QPROF
-    if (tid == 0) {
+
+    // ===================================================================================== matrix role
+    const int n0 = ntile * QBN;
+    float* const Vb = smem;                                           // V[SRING][36][256]; the epilogue's exchange buffer over it
+    const int qa = wave >> 1, qb = wave & 1;
+    const int xi00 = 18 * qa + 3 * qb;
+    const int nun = p.C / 16;
+    const unsigned bvoff = (unsigned)lane * 16u;
+    const long ustride = (long)p.NT * 256;
+    const long xstride = (long)(2 * nun) * ustride;
+    const float* const bbase = p.U + (long)xi00 * xstride + (long)(n0 >> 5) * 256;
+    const float* const vsrc0 = Vgm + xi00 * 256 + lane * 4;          // + slot * 9216 + qxi(K) * 256
+    float* const vdst0 = Vb + xi00 * 256;                             // (wave-uniform LDS base of a DMA) + (slot & 3) * 9216 + qxi(K) * 256
+    const float* const Vq = Vb + xi00 * 256 + lane * 4;               // A fragment of plane K of ring slot r: Vq + r * 9216 + qxi(K) * 256
+
+    f32x16 acc[9][2];
 #pragma unroll
-        for (int k = 0; k < 15; ++k) g_qprof[blockIdx.x % QPROF_WG][k] = (unsigned long long)qprof[k];
-        g_qprof[blockIdx.x % QPROF_WG][11] = (unsigned long long)(clock64() - t_first);
-    }
-#endif
-    if (p.gn_part) {      // fixed-order reduction: the 8 lanes of a wave that share a channel quad, then the four waves through LDS
+    for (int k = 0; k < 9; ++k)
 #pragma unroll
-        for (int blk = 0; blk < 2; ++blk)
+        for (int b = 0; b < 2; ++b)
 #pragma unroll
-            for (int o = 8; o < 64; o <<= 1)
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    gsum[blk][e] += __shfl_xor(gsum[blk][e], o);
-                    gsq[blk][e] += __shfl_xor(gsq[blk][e], o);
-                }
-        __syncthreads();
-        if (lane < 8) {
-#pragma unroll
-            for (int blk = 0; blk < 2; ++blk) {
-                *reinterpret_cast<f32x4*>(smem + (((wave * 2 + blk) * 8 + lane) * 2) * 4) = gsum[blk];
-                *reinterpret_cast<f32x4*>(smem + (((wave * 2 + blk) * 8 + lane) * 2 + 1) * 4) = gsq[blk];
-            }
+            for (int r = 0; r < 16; ++r) acc[k][b][r] = 0.f;
+    f32x4 bq[QRING][2];
+    LM_QTICK(0)
+    int avail = 0;                                                    // slots of V(m) known to be published
+    auto need = [&](int want) {                                       // wait until `want` slots are published (rare after the start: T runs ~6x faster)
+        want = want < nslots ? want : nslots;
+        while (avail < want) {
+            avail = (int)__builtin_amdgcn_readfirstlane(__hip_atomic_load(sp.flags + mblk, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+            if (avail < want) __builtin_amdgcn_s_sleep(8);
         }
-        __syncthreads();
-        if (tid < 16) {
-#pragma clang fp contract(off)
-            const int blk = tid >> 3, cq = tid & 7;
-            const int n = n0 + blk * 32 + cq * 4;
-            f32x4 s = {0.f, 0.f, 0.f, 0.f}, q = {0.f, 0.f, 0.f, 0.f};
+    };
+    need(3);
+    LM_QTICK(1)
 #pragma unroll
-            for (int w = 0; w < 4; ++w) {
-                const f32x4 a = *reinterpret_cast<const f32x4*>(smem + (((w * 2 + blk) * 8 + cq) * 2) * 4);
-                const f32x4 b = *reinterpret_cast<const f32x4*>(smem + (((w * 2 + blk) * 8 + cq) * 2 + 1) * 4);
+    for (int sl = 0; sl < 3; ++sl) {
+        const int ss = sl < nslots ? sl : nslots - 1;
 #pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    s[e] += a[e];
-                    q[e] += b[e];
-                }
-            }
-            const long chunk = t0 / 32;
-            double* o = p.gn_part + (((long)bi * (g.Tpad / 32) + chunk) * p.Cout + n) * 2;
-            for (int e = 0; e < 4 && n + e < p.Cout; ++e) {
-                o[2 * e] = (double)s[e];
-                o[2 * e + 1] = (double)q[e];
-            }
-        }
+        for (int k = 0; k < 9; ++k)
+            __builtin_amdgcn_global_load_lds((gptr_t*)(vsrc0 + (long)ss * 9216 + qxi(k) * 256), (lptr_t*)(vdst0 + sl * 9216 + qxi(k) * 256), 16, 0, 16);
     }
+#pragma unroll
+    for (int k = 0; k < QBD; ++k) q_bload2(bq[k], bvoff, bbase + (long)qxi(k) * xstride);
+    q_bwait<0>(bq[0]);
+    LM_QTICK(3)
+    f32x4 a0 = *reinterpret_cast<const f32x4*>(Vq), a1;              // plane 0 of slot 0; every step prefetches the next step's plane
+#define LM_CBPRE(S5) ((S5) < 18 ? bu + (long)((S5) / 9) * ustride + (long)qxi((S5) % 9) * xstride : bu_next + (long)qxi((S5) - 18) * xstride)
+    // step S of unit u: slot 2 u + S / 9 in ring position (2 u + S / 9) & 3 = 2 (u & 1) + S / 9; its DMA fetches plane S % 9 of slot 2 u + S / 9 + 3
+#define LM_CSTEP(S, AC, AN)                                                                                                              \
+    w44c_step<S>(acc[(S) % 9][0], acc[(S) % 9][1], bq, bvoff, LM_CBPRE((S) + QBD),                                                        \
+                 ((S) % 9 == 8 ? ((S) < 9 ? vq1 : vq0n) : ((S) < 9 ? vq0 : vq1)) + qxi(((S) % 9 + 1) % 9) * 256, AC, AN,                    \
+                 ((S) < 9 ? vs0 : vs1) + qxi((S) % 9) * 256, ((S) < 9 ? vd0 : vd1) + qxi((S) % 9) * 256)
+    for (int u = 0; u < nun; ++u) {
+        need(2 * u + 5);                                              // the slots this unit's DMAs fetch: 2 u + 3, 2 u + 4
+        const int r0 = 2 * (u & 1);                                   // ring position of slot 2 u (slot 2 u + 1: r0 + 1)
+        const float* const vq0 = Vq + r0 * 9216;
+        const float* const vq1 = Vq + (r0 + 1) * 9216;
+        const float* const vq0n = Vq + ((r0 + 2) & 3) * 9216;        // slot 2 u + 2 (the next unit's first)
+        const int s3 = 2 * u + 3 < nslots ? 2 * u + 3 : nslots - 1, s4 = 2 * u + 4 < nslots ? 2 * u + 4 : nslots - 1;
+        const float* const vs0 = vsrc0 + (long)s3 * 9216;            // fetched during slot 2 u -> ring position (2 u + 3) & 3 = (r0 + 3) & 3
+        const float* const vs1 = vsrc0 + (long)s4 * 9216;            // fetched during slot 2 u + 1 -> ring position r0 (slot 2 u: consumed)
+        float* const vd0 = vdst0 + ((r0 + 3) & 3) * 9216;
+        float* const vd1 = vdst0 + r0 * 9216;
+        const float* const bu = bbase + (long)(2 * u) * ustride;
+        const float* const bu_next = bbase + (long)(u + 1 < nun ? 2 * (u + 1) : 0) * ustride;
+        LM_CSTEP(0, a0, a1); LM_CSTEP(1, a1, a0); LM_CSTEP(2, a0, a1); LM_CSTEP(3, a1, a0); LM_CSTEP(4, a0, a1);
+        LM_CSTEP(5, a1, a0); LM_CSTEP(6, a0, a1); LM_CSTEP(7, a1, a0); LM_CSTEP(8, a0, a1);
+        LM_CSTEP(9, a1, a0); LM_CSTEP(10, a0, a1); LM_CSTEP(11, a1, a0); LM_CSTEP(12, a0, a1); LM_CSTEP(13, a1, a0);
+        LM_CSTEP(14, a0, a1); LM_CSTEP(15, a1, a0); LM_CSTEP(16, a0, a1); LM_CSTEP(17, a1, a0);
+        LM_QTICK(4)
+    }
+#undef LM_CSTEP
+#undef LM_CBPRE
+#pragma unroll
+    for (int k = 0; k < QRING; ++k) q_bwait<0>(bq[k]);
+    LM_QTICK(7)
+#include "wino44_epilogue.inc"
 }
 
 // runs of adjacent tiles a 32-tile block can touch: floor((QBM - 2) / Tx) + 2
@@ -1036,6 +1140,52 @@ LM_API int lm_conv3x3_winograd44_f32(void* stream, const float* x, int ldx, cons
     LM_REQUIRE(blocks > 0 && blocks < (1L << 31) && p.g.T % QBM == 0, "conv_wino44: bad grid %ld", blocks);
     if (int e = lm_ensure_dynamic_lds((const void*)wino44_kernel, lds)) return e;
     hipLaunchKernelGGL(wino44_kernel, dim3((unsigned)blocks), dim3(256), lds, (hipStream_t)stream, p);
+    LM_LAUNCH_CHECK();
+    return LM_OK;
+}
+
+// Scratch of lm_conv3x3_winograd44s_f32: the transformed input of every M block ([T / 32][Cin / 8][36][256] floats, alive for one launch)
+// + the hand-off flags and ticket heads
+LM_API long lm_winograd44s_workspace_bytes(int B, int H, int W, int Cin, int dil) {
+    if (dil < 1 || Cin < 16) return 0;
+    const long mb = geom44(B, H, W, dil).T / QBM;
+    return mb * (Cin / 8) * 36L * 256L * (long)sizeof(float) + ((mb + 8) * (long)sizeof(unsigned) + 255) / 256 * 256;
+}
+
+// The same convolution with the input transform taken out of the matrix workgroups (wino44s_kernel: see its header): V of a 32-tile block
+// is produced once by a transform workgroup and read by the Cout / 64 matrix workgroups of the block through `workspace`.  Same wu_frag,
+// same products in the same order, same epilogue: bit-identical to lm_conv3x3_winograd44_f32.
+LM_API int lm_conv3x3_winograd44s_f32(void* stream, const float* x, int ldx, const float* wu_frag, int CoutP, const float* scale,
+                                      const float* shift, const float* res, int ldr, float* y, int ldy, int B, int H, int W,
+                                      int Cin, int Cout, int dil, int act, double* gn_partial, void* workspace, long workspace_bytes) {
+    LM_REQUIRE(x && wu_frag && y && workspace, "conv_wino44s: null pointer");
+    LM_REQUIRE(lm_winograd44_supported(H, W, Cin, dil) && B > 0, "conv_wino44s: unsupported shape (H=%d W=%d Cin=%d dil=%d)", H, W, Cin, dil);
+    LM_REQUIRE(CoutP >= Cout && CoutP % QBN == 0, "conv_wino44s: CoutP=%d must be Cout=%d rounded up to %d", CoutP, Cout, QBN);
+    LM_REQUIRE(ldx >= Cin && ldx % 4 == 0 && ldy >= Cout, "conv_wino44s: bad leading dimension");
+    LM_REQUIRE(act == LM_ACT_NONE || act == LM_ACT_RELU, "conv_wino44s: activation %d not supported", act);
+    LM_REQUIRE(!gn_partial || (res == nullptr && act == LM_ACT_NONE && Cout % 4 == 0), "conv_wino44s(gn stats): no residual / activation");
+    LM_REQUIRE(lm_winograd44s_workspace_bytes(B, H, W, Cin, dil) <= workspace_bytes, "conv_wino44s: workspace too small");
+    W44SParams sp;
+    W44Params& p = sp.p;
+    p.g = geom44(B, H, W, dil);
+    LM_REQUIRE((long)B * H * W * ldx < (1L << 40) && (long)B * H * W < (1L << 31) && p.g.T < (1L << 31), "conv_wino44s: tensor too large");
+    p.x = x; p.U = wu_frag; p.scale = scale; p.shift = shift; p.res = res; p.y = y;
+    p.ldx = ldx; p.ldr = ldr; p.ldy = ldy; p.C = Cin; p.Cout = Cout; p.NT = CoutP / 32; p.act = act;
+    p.gn_part = gn_partial;
+    p.n_inner = 1;
+    if (int e = w44_zeros(&p.zeros)) return e;
+    sp.mblocks = (int)(p.g.T / QBM);
+    sp.n_tiles = (Cout + QBN - 1) / QBN;
+    sp.Vg = (float*)workspace;
+    sp.flags = (unsigned*)((char*)workspace + (long)sp.mblocks * (Cin / 8) * 36L * 256L * (long)sizeof(float));
+    sp.heads = sp.flags + sp.mblocks;
+    const size_t lds = (size_t)(TRING * TRAWF + QVF) * sizeof(float);
+    static_assert(SRING * 36 * 256 <= TRING * TRAWF + QVF && 36 * 32 * 32 <= SRING * 36 * 256, "the matrix role's ring and the exchange buffer fit");
+    const long blocks = (long)sp.mblocks * (sp.n_tiles + 1);
+    LM_REQUIRE(blocks > 0 && blocks < (1L << 31) && p.g.T % QBM == 0, "conv_wino44s: bad grid %ld", blocks);
+    if (int e = lm_ensure_dynamic_lds((const void*)wino44s_kernel, lds)) return e;
+    LM_HIP(hipMemsetAsync(sp.flags, 0, (size_t)(sp.mblocks + 8) * sizeof(unsigned), (hipStream_t)stream));
+    hipLaunchKernelGGL(wino44s_kernel, dim3((unsigned)blocks), dim3(256), lds, (hipStream_t)stream, sp);
     LM_LAUNCH_CHECK();
     return LM_OK;
 }
