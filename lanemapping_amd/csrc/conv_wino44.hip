@@ -474,11 +474,11 @@ __device__ __forceinline__ f32x4 q_aread(const float* v) {
 // of nine); the B fragments of step S + QBD and the patch loads of this step (q_ndma) are issued first; q_nwait(S) loads may stay
 // outstanding when this step's B fragments are needed.  Behind the first MFMA: the A fragment of the next step (not across a barrier:
 // steps 4 and 8 leave it to the loop), the LDS part of this step's transform share, then its VALU part.
-template <int S>
+template <int S, bool PUB>
 __device__ __forceinline__ void w44_step(f32x16& acc0, f32x16& acc1, f32x4 (&bq)[QRING][2], unsigned bvoff, const float* bpre,
                                          const float* anext, const f32x4& a_cur, f32x4& a_nxt, const float* const (&gsrc)[QLPW], long goff,
                                          float* rawld, int wave, W44Xf& xf, const float* prerow, const int (&roff)[6], float* vA, float* vB,
-                                         float* vC, bool lower, const W44K& kk) {
+                                         float* vC, bool lower, const W44K& kk, float* vstore) {
     typedef __attribute__((address_space(1))) const void gptr_t;
     typedef __attribute__((address_space(3))) void lptr_t;
     constexpr int K = S % 9;
@@ -499,6 +499,10 @@ __device__ __forceinline__ void w44_step(f32x16& acc0, f32x16& acc1, f32x4 (&bq)
     q_bwait<0>(b);
 #endif
     constexpr bool VACC = K == 8;
+    // producer role: this step's A fragment = plane K of V(slot) for this lane goes to the hand-off buffer (a PLAIN store: acknowledged by the
+    // XCD's L2, which the consumers of the block share).  Stores and loads of a wave complete out of order with respect to each other, so
+    // the wait above allows only the YOUNGER LOADS to be outstanding (q_nwait): with stores in flight it waits a little longer, never too short.
+    if constexpr (PUB) asm volatile("global_store_dwordx4 %0, %1, %2" ::"v"(bvoff), "v"(a_cur), "s"(vstore) : "memory");
     q_mfma<VACC>(acc0, a_cur[0], b[0][0]);
     __builtin_amdgcn_sched_barrier(0);
     if constexpr (K != 4 && K != 8) a_nxt = q_aread(anext);
@@ -552,7 +556,11 @@ __device__ __forceinline__ void w44_tail_vec(const f32x4 (&z)[4][6], const f32x4
     }
 }
 
-__global__ __launch_bounds__(256) void wino44_kernel(W44Params p) {
+// The body of a matrix workgroup: M block `mblk`, N tile `ntile`.  PUB (wino44p_kernel's producer role): every step also stores its A
+// fragment - plane K of V(slot), 16 bytes per lane, the layout the consumer role reads - to vpub[slot][plane][lane], and the wave publishes
+// in fpub how many slots of ITS quadrant are complete.
+template <bool PUB>
+__device__ __forceinline__ void w44_body(const W44Params& p, const unsigned mblk, const unsigned ntile, float* const vpub, unsigned* const fpub) {
 #ifdef LM_QPROF
     long long qprof[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
     long long t_last = clock64();
@@ -565,25 +573,6 @@ __global__ __launch_bounds__(256) void wino44_kernel(W44Params p) {
     typedef __attribute__((address_space(3))) void lptr_t;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int n_tiles = (p.Cout + QBN - 1) / QBN;
-    unsigned mblk, ntile;
-    if (p.n_inner) {      // XCD-contiguous, N tile inner: the N tiles of an M block run side by side on one XCD (input lines shared in its L2)
-        const unsigned bid = blockIdx.x, per = gridDim.x / 8;
-        const unsigned lin = bid < per * 8 ? (bid % 8) * per + bid / 8 : bid;
-        mblk = lin / (unsigned)n_tiles;
-        ntile = lin % (unsigned)n_tiles;
-    } else {              // XCD-aware order, N tile outer (conv_wino.hip): an XCD streams one N tile's U from its L2
-        const unsigned bid = blockIdx.x, mb = gridDim.x / (unsigned)n_tiles, mbx = mb / 8, full = mbx * 8 * (unsigned)n_tiles;
-        if (bid < full) {
-            const unsigned xcd = bid % 8, idx = bid / 8;
-            ntile = idx / mbx;
-            mblk = xcd * mbx + idx % mbx;
-        } else {
-            const unsigned r = bid - full;
-            mblk = 8 * mbx + r / (unsigned)n_tiles;
-            ntile = r % (unsigned)n_tiles;
-        }
-    }
     const long m0 = (long)mblk * QBM;
     const int n0 = (int)ntile * QBN;
     const W44Geom& g = p.g;
@@ -650,6 +639,13 @@ __global__ __launch_bounds__(256) void wino44_kernel(W44Params p) {
     const long xstride = (long)(2 * nun) * ustride;              // floats between xi planes in U
     const float* const bbase = p.U + (long)xi00 * xstride + (long)(n0 >> 5) * 256;
 
+    // (producer role) this wave's quadrant of the hand-off buffer as a provably wave-uniform pointer: the stores take it as a scalar base
+    float* vpub_q = nullptr;
+    if constexpr (PUB) {
+        const unsigned long long a = reinterpret_cast<unsigned long long>(vpub + xi00 * 256);
+        vpub_q = reinterpret_cast<float*>(((unsigned long long)__builtin_amdgcn_readfirstlane((unsigned)(a >> 32)) << 32) |
+                                          (unsigned long long)__builtin_amdgcn_readfirstlane((unsigned)a));
+    }
     f32x16 acc[9][2];
 #pragma unroll
     for (int k = 0; k < 9; ++k)
@@ -687,8 +683,9 @@ __global__ __launch_bounds__(256) void wino44_kernel(W44Params p) {
     // B fragments of step S5 = S + QBD of the unit (S5 >= 18: first slot of the next unit)
 #define LM_QBPRE(S5) ((S5) < 18 ? bu + (long)((S5) / 9) * ustride + (long)LM_QXI((S5) % 9) * xstride : bu_next + (long)LM_QXI((S5) - 18) * xstride)
 #define LM_QSTEP(S, AC, AN) \
-    w44_step<S>(acc[(S) % 9][0], acc[(S) % 9][1], bq, bvoff, LM_QBPRE((S) + QBD), Vq + LM_QXI(((S) % 9) + 1 < 9 ? ((S) % 9) + 1 : 0) * 256, \
-                AC, AN, gsrc, goff, rawc_w, wave, xf, (S) < 9 ? rawc + 8 + lowoff : rawn + lowoff, roff, vA, vB, vC, lower, kk)
+    w44_step<S, PUB>(acc[(S) % 9][0], acc[(S) % 9][1], bq, bvoff, LM_QBPRE((S) + QBD), Vq + LM_QXI(((S) % 9) + 1 < 9 ? ((S) % 9) + 1 : 0) * 256, \
+                     AC, AN, gsrc, goff, rawc_w, wave, xf, (S) < 9 ? rawc + 8 + lowoff : rawn + lowoff, roff, vA, vB, vC, lower, kk,     \
+                     PUB ? vpu + ((S) / 9) * 9216 + LM_QXI((S) % 9) * 256 : nullptr)
     // the barrier in the middle of a slot: this wave's late stores (steps 0..3) are done; behind it every wave's are, and the early
     // planes are free (every wave has read V(s)'s in steps 0..4)
 #ifdef LM_QABL_NOMID                          // (timing ablation: what the barrier in the middle of a slot costs; results are wrong)
@@ -708,6 +705,13 @@ __global__ __launch_bounds__(256) void wino44_kernel(W44Params p) {
         const long goff = u + 2 < nun ? (long)(u + 2) * 16 : 0;            // (nothing left to fetch: harmless re-read of unit 0)
         const float* const bu = bbase + (long)(2 * u) * ustride;
         const float* const bu_next = bbase + (long)(u + 1 < nun ? 2 * (u + 1) : 0) * ustride;
+        float* const vpu = PUB ? vpub_q + (long)(2 * u) * 9216 : nullptr;                 // this wave's planes of slot 2 u in the hand-off buffer
+        if constexpr (PUB) {
+            // every wait of the loop leaves at most 21 operations of this wave outstanding (max of q_nwait) and stores complete in order
+            // among themselves: 26 stores were issued after V(2 u - 4)'s last one when step 17 of the previous unit waited, so slots
+            // 0 .. 2 u - 4 are complete here (and 0 .. 2 u - 3 in the middle of the unit, below)
+            if (u >= 2 && lane == 0) __hip_atomic_store(fpub, (unsigned)(2 * u - 3), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        }
         f32x4 a0, a1;
         // ---- slot 2 u: channels 16 u .. 16 u + 7 multiplied, channels 16 u + 8 .. 16 u + 15 transformed behind the MFMAs
         a0 = q_aread(Vq);
@@ -722,6 +726,9 @@ __global__ __launch_bounds__(256) void wino44_kernel(W44Params p) {
         LM_QTICK(6)
         __builtin_amdgcn_s_barrier();          // V(2 u + 1)'s early planes complete
         LM_QTICK(5)
+        if constexpr (PUB) {
+            if (u >= 1 && lane == 0) __hip_atomic_store(fpub, (unsigned)(2 * u - 2), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        }
         // ---- slot 2 u + 1: channels 16 u + 8 .. multiplied, the next unit's first half transformed, unit u + 2's patches requested
         a0 = q_aread(Vq);
         LM_QSTEP(9, a0, a1);  LM_QSTEP(10, a1, a0); LM_QSTEP(11, a0, a1); LM_QSTEP(12, a1, a0); LM_QSTEP(13, a0, a1);
@@ -739,6 +746,9 @@ __global__ __launch_bounds__(256) void wino44_kernel(W44Params p) {
     static_assert(18 % QRING == 0 && QBD < QRING, "eighteen steps per unit walk the ring a whole number of times");
 #pragma unroll
     for (int k = 0; k < QRING; ++k) q_bwait<0>(bq[k]);
+    if constexpr (PUB) {                       // (vmcnt(0) above: every store of the wave is complete)
+        if (lane == 0) __hip_atomic_store(fpub, (unsigned)(2 * nun), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    }
 
     LM_QTICK(7)
 #ifdef LM_QABL_NOEPI
@@ -747,55 +757,63 @@ __global__ __launch_bounds__(256) void wino44_kernel(W44Params p) {
 #include "wino44_epilogue.inc"
 }
 
+__global__ __launch_bounds__(256) void wino44_kernel(W44Params p) {
+    const int n_tiles = (p.Cout + QBN - 1) / QBN;
+    unsigned mblk, ntile;
+    if (p.n_inner) {      // XCD-contiguous, N tile inner: the N tiles of an M block run side by side on one XCD (input lines shared in its L2)
+        const unsigned bid = blockIdx.x, per = gridDim.x / 8;
+        const unsigned lin = bid < per * 8 ? (bid % 8) * per + bid / 8 : bid;
+        mblk = lin / (unsigned)n_tiles;
+        ntile = lin % (unsigned)n_tiles;
+    } else {              // XCD-aware order, N tile outer: an XCD streams one N tile's U from its L2
+        const unsigned bid = blockIdx.x, mb = gridDim.x / (unsigned)n_tiles, mbx = mb / 8, full = mbx * 8 * (unsigned)n_tiles;
+        if (bid < full) {
+            const unsigned xcd = bid % 8, idx = bid / 8;
+            ntile = idx / mbx;
+            mblk = xcd * mbx + idx % mbx;
+        } else {
+            const unsigned r = bid - full;
+            mblk = 8 * mbx + r / (unsigned)n_tiles;
+            ntile = r % (unsigned)n_tiles;
+        }
+    }
+    w44_body<false>(p, mblk, ntile, nullptr, nullptr);
+}
+
 // ===================================================================================================================================
-// wino44s_kernel (round 5): the input transform leaves the matrix workgroups.
+// wino44p_kernel (round 5): the N tiles of an M block share ONE input transform.
 //
 // In wino44_kernel every workgroup transforms its own patches: V = B^T d B of a 32-tile block is recomputed by each of the Cout / 64
-// workgroups that multiply it, and f32 MFMA shares the SIMD's vector ALUs, so those 72 packed VALU instructions per 72 MFMAs are 13.7 % of
-// the kernel (timing ablation profiles/r5_wino44_ablation.txt: 4.10 -> 3.54 ms at 256 -> 256 @288^2 with the transform compiled out).
-// Here a block's V is produced ONCE, by a light TRANSFORM workgroup (no MFMA: ~1/6 of a matrix workgroup's time), written to a scratch
-// buffer slot by slot and read by the block's matrix workgroups - one launch, two roles:
-//   T(m)      raw patches of M block m (global_load_lds, 8-channel halves, ring of 4) -> B^T d B in LDS -> 36 planes x 1 KB per slot to
-//             Vg[m][slot] with write-through (sc1) 16-byte stores -> flags[m] = slots published (sc1 store, one lane).
-//             Waves 0, 1 issue every load, waves 2, 3 every store: vmcnt counts loads and stores of ONE wave in one counter and they
-//             complete out of order with respect to each other, so a wave that waits by count must issue one kind only.
-//   C(m, nt)  a matrix workgroup of wino44_kernel WITHOUT transform, raw patches and mid-slot barriers: every wave DMAs the nine planes
-//             of ITS quadrant (global_load_lds ... sc1, ring of four slots, three slots ahead) and reads only those - no barrier in
-//             the K loop at all; B fragments, MFMA order, accumulators and the epilogue are wino44_kernel's: bit-identical y.
-// Placement-independent hand-off (MI355X_MICROARCH.md, inter-workgroup visibility, form R1): sc1 payload stores -> s_waitcnt on the
-// storing waves -> workgroup barrier -> sc1 flag store; consumer: relaxed agent-scope poll of the flag -> sc1 loads.
-// No assumption about dispatch order: roles come from TICKETS (atomicAdd on a per-XCD head, the XCD read from HW_REG_XCC_ID so that the
-// workgroups of an M block share an L2 for the input lines and U; other heads are tried when the own one is exhausted).  Ticket order per
-// head: T(0), T(1), C(0, *), T(2), C(1, *), ...: a workgroup that holds C(m, .) implies T(m)'s ticket was taken earlier by a workgroup
-// that is running or done - a consumer can wait for its producer, a producer waits for nobody: no deadlock under any dispatch order.
-constexpr int TRING = 4;                         // raw halves in flight (transform role)
-constexpr int TLPW = 14;                         // patch loads per LOADER wave and 8-channel half (27 KB = 27 x 1 KB, two loader waves)
-constexpr int TRAWF = TLPW * 2 * 256;            // floats of one raw half buffer (28 KB; cells 864.. are zero-source padding)
-constexpr int SRING = 4;                         // V slots in LDS (matrix role), three ahead
-static_assert(6 * QNCELL * 8 <= TRAWF, "patch loads cover the half");
+// workgroups that multiply it, and f32 MFMA shares the SIMD's vector ALUs, so those 72 packed VALU instructions per 72 MFMAs cost 13.7 %
+// of the kernel (timing ablation profiles/r5_wino44_ablation.txt: 4.10 -> 3.54 ms at 256 -> 256 @288^2 with the transform compiled out).
+// Here the workgroup of N tile 0 is the block's PRODUCER: wino44_kernel's body, whose waves additionally store every A fragment they
+// read - plane by plane, 16 bytes per lane, one store per MFMA step - to a scratch buffer and publish per wave how many 8-channel slots of
+// their quadrant are complete.  The workgroups of N tiles 1 .. are CONSUMERS: no patch gather, no transform, no barrier in the K loop -
+// every wave DMAs the nine planes of ITS quadrant (global_load_lds ... sc1 = past the L1, ring of four slots in LDS, three slots ahead)
+// and reads only those; B fragments, MFMA order, accumulators and the epilogue are wino44_kernel's: bit-identical y.
+//   * Roles come from TICKETS, not from blockIdx: thread 0 reads the XCD it runs on (HW_REG_XCC_ID) and takes the next ticket of THAT XCD's
+//     queue (atomicAdd; other queues when its own is empty).  Queue order P(0), P(1), [P(k + 2), C(k, 1 .. n - 1)] for k = 0, 1, ...: a
+//     workgroup that holds C(k, .) implies P(k)'s ticket was taken earlier by a workgroup that is running or done - a consumer may wait for
+//     its producer, a producer waits for nobody: no deadlock under ANY dispatch order; the two blocks of lookahead give a producer its
+//     head start (consumers are ~12 % faster than the producer and must not catch up).
+//   * The hand-off goes through the XCD's L2: plain stores (acknowledged by L2) -> flag (plain store of the same wave, behind a wait that
+//     proves the payload complete) -> consumer polls with sc1 loads and DMAs with sc1 (L1 bypassed, served by the L2 it shares with the
+//     producer).  That is only valid on ONE XCD, and it is VERIFIED, not assumed: the producer publishes the XCC id it runs on
+//     (write-through); a consumer on another XCD (a stolen ticket) does not touch the scratch buffer and runs wino44_kernel's body itself.
+//   * A wave's loads and stores share vmcnt and complete out of order with respect to each other: the producer's B-fragment waits allow only
+//     the YOUNGER LOADS to be outstanding (never too short; slightly longer while a store is in flight), and a slot is published three
+//     slots late, when 26 younger stores prove it complete under a wait that leaves at most 21 operations outstanding.
+constexpr int SRING = 4;                         // V slots in LDS (consumer role), three ahead
 
-struct W44SParams {
+struct W44PParams {
     W44Params p;
     float* Vg;                                   // [M blocks][C / 8 slots][36][256]
-    unsigned* flags;                             // [M blocks] slots published by T(m)
-    unsigned* heads;                             // [8] ticket counters
-    int mblocks, n_tiles;
+    unsigned* flags;                             // [M blocks][4 waves] slots published | then [M blocks] producer XCC id + 1 | then [8] ticket heads
+    int mblocks, n_tiles, look;                  // look: producers run this many M blocks ahead of the consumers in a queue
 };
-
-__device__ __forceinline__ void sc1_store_x4(float* gp, const f32x4 v) {
-    asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(gp), "v"(v) : "memory");
-}
 constexpr int qxi(int K) { return 6 * (K / 3) + K % 3; }
 
-template <int C>
-__device__ __forceinline__ void w44t_preread(W44Xf& d, const float* rawrow, const int (&roff)[6]) {
-    constexpr int ROWF = QNCELL * 8;
-    const float* s = rawrow + roff[C];
-#pragma unroll
-    for (int r = 0; r < 5; ++r) d.e[C][r] = *reinterpret_cast<const f32x2*>(s + r * ROWF);
-}
-
-// one step of the matrix role: B fragments of step S + QBD, ONE plane of the V slot three ahead, then wino44_kernel's 8 MFMAs
+// one step of the consumer role: B fragments of step S + QBD, ONE plane of the V slot three ahead, then wino44_kernel's 8 MFMAs
 template <int S>
 __device__ __forceinline__ void w44c_step(f32x16& acc0, f32x16& acc1, f32x4 (&bq)[QRING][2], unsigned bvoff, const float* bpre, const float* anext,
                                           const f32x4& a_cur, f32x4& a_nxt, const float* vsrc, float* vdst) {
@@ -820,7 +838,7 @@ __device__ __forceinline__ void w44c_step(f32x16& acc0, f32x16& acc1, f32x4 (&bq
     __builtin_amdgcn_sched_barrier(0);
 }
 
-__global__ __launch_bounds__(256) void wino44s_kernel(W44SParams sp) {
+__device__ __forceinline__ void w44_consumer(const W44PParams& sp, const int mblk, const int ntile) {
     const W44Params& p = sp.p;
 #ifdef LM_QPROF
     long long qprof[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
@@ -828,51 +846,10 @@ __global__ __launch_bounds__(256) void wino44s_kernel(W44SParams sp) {
     const long long t_first = t_last;
 #endif
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    __shared__ int s_ticket[2];
     typedef __attribute__((address_space(1))) const void gptr_t;
     typedef __attribute__((address_space(3))) void lptr_t;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int n_tiles = sp.n_tiles, grp = n_tiles + 1;
-    const int per = sp.mblocks / 8, rem = sp.mblocks % 8;
-    if (tid == 0) {
-        unsigned x;
-        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(x));
-        x &= 7u;
-        int got = -1, q = 0;
-        for (; q < 8; ++q) {
-            const unsigned xq = (x + (unsigned)q) & 7u;
-            const unsigned cnt = (unsigned)((per + ((int)xq < rem ? 1 : 0)) * grp);
-            if (cnt == 0) continue;
-            const unsigned t = atomicAdd(&sp.heads[xq], 1u);
-            if (t < cnt) {
-                got = (int)t;
-                x = xq;
-                break;
-            }
-        }
-        s_ticket[0] = got;
-        s_ticket[1] = (int)x;
-    }
-    __syncthreads();
-    const int ticket = __builtin_amdgcn_readfirstlane(s_ticket[0]), xq = __builtin_amdgcn_readfirstlane(s_ticket[1]);
-    if (ticket < 0) return;                          // (cannot happen: tickets = workgroups)
-    int mblk, ntile;                                 // ntile < 0: transform role
-    {
-        const int Mx = per + (xq < rem ? 1 : 0), mlo = xq * per + (xq < rem ? xq : rem);
-        if (ticket == 0) {
-            mblk = mlo; ntile = -1;
-        } else {
-            const int u = ticket - 1;
-            if (u < (Mx - 1) * grp) {
-                const int k = u / grp, r = u - k * grp;
-                if (r == 0) { mblk = mlo + k + 1; ntile = -1; }
-                else { mblk = mlo + k; ntile = r - 1; }
-            } else {
-                mblk = mlo + Mx - 1; ntile = u - (Mx - 1) * grp;
-            }
-        }
-    }
     const long m0 = (long)mblk * QBM;
     const W44Geom& g = p.g;
     const int bi = (int)(m0 / g.Tpad);
@@ -880,105 +857,8 @@ __global__ __launch_bounds__(256) void wino44s_kernel(W44SParams sp) {
 #include "wino44_runtable.inc"
     const int img_pix0 = bi * g.H * g.W;
     const int nslots = p.C / 8;
-    float* const Vgm = sp.Vg + (long)mblk * nslots * (36 * 256);
-
-    if (ntile < 0) {
-        // ================================================================================= transform role
-        float* const raw0 = smem;                                    // raw[TRING][TRAWF] | V[QVF]
-        float* const Vbuf = smem + TRING * TRAWF;
-        const bool loader = wave < 2;
-        // patch loads (loader waves 0, 1): load s of loader wave w fills 16-byte chunks (s * 2 + w) * 64 .. + 63 of a raw half buffer;
-        // chunk = channel quad cq (0, 1) of a cell; cell order as in wino44_kernel (position = 16 (slot >> 2) + 4 c + (slot & 3))
-        const float* gsrc[TLPW];
-#pragma unroll
-        for (int s_ = 0; s_ < TLPW; ++s_) {
-            const int chunk = (s_ * 2 + (wave & 1)) * 64 + lane;
-            const int cell = chunk >> 1, cq = chunk & 1;
-            const int r = cell / QNCELL;
-            const int pos = cell - r * QNCELL;
-            const int slot = 4 * (pos >> 4) + (pos & 3), cc = (pos >> 2) & 3;
-            int n = sn[0], yb = iy0[0], xb = ix0[0], s0 = 0;
-#pragma unroll
-            for (int k = 1; k < QSEG; ++k)
-                if (slot >= ts[k] + k) {
-                    n = sn[k]; yb = iy0[k]; xb = ix0[k]; s0 = ts[k] + k;
-                }
-            const int lc = 4 * (slot - s0) + cc;
-            const int yy = yb + r * g.dil, xx = xb + lc * g.dil;
-            const bool ok = (r < 6) & (n > 0) & (lc < 4 * n + 2) & ((unsigned)yy < (unsigned)g.H) & ((unsigned)xx < (unsigned)g.W);
-            const long eoff = ok ? (long)(img_pix0 + yy * g.W + xx) * p.ldx : 0;
-            gsrc[s_] = (ok ? p.x : p.zeros) + eoff + cq * 4;
-        }
-        auto dma_half = [&](int h) {                                  // raw half h (channels 8 h .. 8 h + 7) -> ring slot h % TRING
-            const int hh = h < nslots ? h : nslots - 1;               // (past the end: a harmless re-read keeps the wait counts uniform)
-            float* const dst = raw0 + (h % TRING) * TRAWF;
-#pragma unroll
-            for (int s_ = 0; s_ < TLPW; ++s_)
-                __builtin_amdgcn_global_load_lds((gptr_t*)(gsrc[s_] + 8 * hh), (lptr_t*)(dst + (s_ * 2 + (wave & 1)) * 256), 16, 0, 0);
-        };
-        if (loader) {
-            dma_half(0); dma_half(1); dma_half(2);
-        }
-        // transform share: as in wino44_kernel (tile = lane & 31, LOWER = wave >> 1, channel pair skewed by the tile slot); 32-byte cells
-        int roff[6], tvoff;
-        {
-            const int tl = lane & 31;
-            int sg = 0;
-#pragma unroll
-            for (int k = 1; k < QSEG; ++k) sg += (ts[k] < QBM && tl >= ts[k]) ? 1 : 0;
-            const int slot = tl + sg, slot1 = slot + 1;
-            const int cp = (2 * (wave & 1) + (lane >> 5) + (slot >> 2)) & 3;
-            const int pos0 = 16 * (slot >> 2) + (slot & 3), pos1 = 16 * (slot1 >> 2) + (slot1 & 3);
-#pragma unroll
-            for (int c = 0; c < 6; ++c) roff[c] = ((c < 4 ? pos0 + 4 * c : pos1 + 4 * (c - 4)) * 8) + 2 * cp;
-            // plane layout of the hand-off = the A fragment of the matrix role: [lane = (cp >> 1) * 32 + tile][4 channels], this pair at 2 (cp & 1)
-            tvoff = ((cp >> 1) * 32 + tl) * 4 + 2 * (cp & 1);
-        }
-        const bool lower = (wave >> 1) != 0;
-        float* const vA = Vbuf + (lower ? 3 : 0) * (6 * 256) + tvoff;
-        float* const vB = Vbuf + (lower ? 4 : 1) * (6 * 256) + tvoff;
-        float* const vC = Vbuf + (lower ? 5 : 2) * (6 * 256) + tvoff;
-        const W44K kk = {f32x2{2.f, 2.f}, f32x2{4.f, 4.f}, f32x2{5.f, 5.f}};
-        const int lowoff = lower ? QNCELL * 8 : 0;
-        W44Xf xf;
-        for (int h = 0; h < nslots; ++h) {
-            // loader waves: raw half h has landed (younger loads: halves h + 1, h + 2); storer waves: nothing to wait for here
-            if (loader) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * TLPW) : "memory");
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");        // (the copy-out reads of half h - 1)
-            __builtin_amdgcn_s_barrier();                             // A: raw(h) visible, V free, V(h - 2)'s stores complete on both storer waves
-            if (tid == 128 && h >= 2)                                 // (first lane of storer wave 2: its flag store stays in store order)
-                __hip_atomic_store(sp.flags + mblk, (unsigned)(h - 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            if (loader) dma_half(h + 3);                              // into the slot of half h - 1 (read before the previous barrier B)
-            const float* const rawrow = raw0 + (h % TRING) * TRAWF + lowoff;
-            w44t_preread<0>(xf, rawrow, roff); w44t_preread<1>(xf, rawrow, roff); w44t_preread<2>(xf, rawrow, roff);
-            w44t_preread<3>(xf, rawrow, roff); w44t_preread<4>(xf, rawrow, roff); w44t_preread<5>(xf, rawrow, roff);
-            w44_xf_valu<1>(xf, lower, kk); w44_xf_valu<2>(xf, lower, kk); w44_xf_valu<3>(xf, lower, kk);
-            w44_xf_valu<4>(xf, lower, kk); w44_xf_valu<5>(xf, lower, kk); w44_xf_valu<6>(xf, lower, kk);
-#pragma unroll
-            for (int j = 0; j < 6; ++j) {
-                *reinterpret_cast<f32x2*>(vA + j * 256) = xf.tA[j];
-                *reinterpret_cast<f32x2*>(vB + j * 256) = xf.tB[j];
-                *reinterpret_cast<f32x2*>(vC + j * 256) = xf.tC[j];
-            }
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            __builtin_amdgcn_s_barrier();                             // B: V(h) complete, raw(h) no longer read
-            if (!loader) {                                            // storer waves: 18 planes each, 1 KB per instruction
-                float* const dst = Vgm + (long)h * (36 * 256) + (wave - 2) * (18 * 256) + lane * 4;
-                const float* const src = Vbuf + (wave - 2) * (18 * 256) + lane * 4;
-#pragma unroll
-                for (int k = 0; k < 18; ++k) sc1_store_x4(dst + k * 256, *reinterpret_cast<const f32x4*>(src + k * 256));
-                asm volatile("s_waitcnt vmcnt(18)" ::: "memory");     // everything older than this half's 18 stores - V(h - 1) - is complete
-            }
-        }
-        if (!loader) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();
-        if (tid == 128) __hip_atomic_store(sp.flags + mblk, (unsigned)nslots, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        if (loader) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // (the padding loads past the end land before the LDS is released)
-        return;
-    }
-
-    // ===================================================================================== matrix role
+    const float* const Vgm = sp.Vg + (long)mblk * nslots * (36 * 256);
+    const unsigned* const fsub = sp.flags + (long)mblk * 4 + wave;   // slots of this wave's quadrant published by the producer's wave of the same index
     const int n0 = ntile * QBN;
     float* const Vb = smem;                                           // V[SRING][36][256]; the epilogue's exchange buffer over it
     const int qa = wave >> 1, qb = wave & 1;
@@ -1001,11 +881,11 @@ __global__ __launch_bounds__(256) void wino44s_kernel(W44SParams sp) {
             for (int r = 0; r < 16; ++r) acc[k][b][r] = 0.f;
     f32x4 bq[QRING][2];
     LM_QTICK(0)
-    int avail = 0;                                                    // slots of V(m) known to be published
-    auto need = [&](int want) {                                       // wait until `want` slots are published (rare after the start: T runs ~6x faster)
+    int avail = 0;                                                    // slots known to be published
+    auto need = [&](int want) {                                       // wait until `want` slots are published (rare after the start: the producer has a head start)
         want = want < nslots ? want : nslots;
         while (avail < want) {
-            avail = (int)__builtin_amdgcn_readfirstlane(__hip_atomic_load(sp.flags + mblk, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+            avail = (int)__builtin_amdgcn_readfirstlane(__hip_atomic_load(fsub, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
             if (avail < want) __builtin_amdgcn_s_sleep(8);
         }
     };
@@ -1056,6 +936,76 @@ __global__ __launch_bounds__(256) void wino44s_kernel(W44SParams sp) {
 #include "wino44_epilogue.inc"
 }
 
+__global__ __launch_bounds__(256) void wino44p_kernel(W44PParams sp) {
+    __shared__ int s_ticket[3];
+    const int tid = threadIdx.x;
+    const int n = sp.n_tiles;
+    const int per = sp.mblocks / 8, rem = sp.mblocks % 8;
+    unsigned* const ids = sp.flags + (long)sp.mblocks * 4;
+    unsigned* const heads = ids + sp.mblocks;
+    if (tid == 0) {
+        unsigned x;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(x));
+        x &= 7u;
+        int got = -1, home = 0;
+        for (int q = 0; q < 8; ++q) {
+            const unsigned xq = (x + (unsigned)q) & 7u;
+            const unsigned cnt = (unsigned)((per + ((int)xq < rem ? 1 : 0)) * n);
+            if (cnt == 0) continue;
+            const unsigned t = atomicAdd(&heads[xq], 1u);
+            if (t < cnt) {
+                got = (int)t;
+                home = (int)xq;
+                break;
+            }
+        }
+        s_ticket[0] = got;
+        s_ticket[1] = home;
+        s_ticket[2] = (int)x;
+    }
+    __syncthreads();
+    const int ticket = __builtin_amdgcn_readfirstlane(s_ticket[0]), home = __builtin_amdgcn_readfirstlane(s_ticket[1]);
+    const int xcc = __builtin_amdgcn_readfirstlane(s_ticket[2]);
+    if (ticket < 0) return;                          // (cannot happen: tickets = workgroups)
+    int mblk, ntile;
+    {
+        // queue of XCD `home`: P(0) .. P(L - 1), then for k = 0 .. Mx - 1: [P(k + L) while it exists] C(k, 1) .. C(k, n - 1)
+        const int Mx = per + (home < rem ? 1 : 0), mlo = home * per + (home < rem ? home : rem);
+        const int L = Mx < sp.look ? Mx : sp.look, Gf = Mx - L;
+        if (ticket < L) {
+            mblk = mlo + ticket; ntile = 0;
+        } else {
+            const int u = ticket - L;
+            if (u < Gf * n) {
+                const int k = u / n, r = u - k * n;
+                if (r == 0) { mblk = mlo + k + L; ntile = 0; }
+                else { mblk = mlo + k; ntile = r; }
+            } else {
+                const int v = u - Gf * n;
+                const int k = Gf + v / (n - 1);
+                mblk = mlo + k; ntile = 1 + v % (n - 1);
+            }
+        }
+    }
+    const int nslots = sp.p.C / 8;
+    if (ntile == 0) {                                // producer: publish the XCD it runs on (write-through: consumers on other XCDs must see it)
+        if (tid == 0) __hip_atomic_store(ids + mblk, (unsigned)xcc + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+        w44_body<true>(sp.p, (unsigned)mblk, 0u, sp.Vg + (long)mblk * nslots * (36 * 256), sp.flags + (long)mblk * 4 + wave);
+        return;
+    }
+    // consumer: is the producer on this XCD?  (It holds an earlier ticket, so it is running or done: the id arrives.)
+    if (tid == 0) {
+        unsigned id = 0;
+        while ((id = __hip_atomic_load(ids + mblk, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) == 0) __builtin_amdgcn_s_sleep(8);
+        s_ticket[0] = (int)id - 1;
+    }
+    __syncthreads();
+    const int pxcc = __builtin_amdgcn_readfirstlane(s_ticket[0]);
+    if (pxcc == xcc) w44_consumer(sp, mblk, ntile);
+    else w44_body<false>(sp.p, (unsigned)mblk, (unsigned)ntile, nullptr, nullptr);      // (stolen ticket: the hand-off buffer lives in another L2)
+}
+
 // runs of adjacent tiles a 32-tile block can touch: floor((QBM - 2) / Tx) + 2
 bool w44_ok(const W44Geom& g) { return (QBM - 2) / g.Tx + 2 <= QSEG; }
 
@@ -1079,10 +1029,11 @@ int w44_zeros(const float** out) {      // per device (a process may drive sever
 extern "C" __attribute__((visibility("default"))) int lm_qprof_read(unsigned long long* out, int reset) {
     static unsigned long long host[QPROF_WG][16];
     if (hipMemcpyFromSymbol(host, HIP_SYMBOL(g_qprof), sizeof(host)) != hipSuccess) return 1;
-    for (int k = 0; k < 17; ++k) out[k] = 0;
+    for (int k = 0; k < 34; ++k) out[k] = 0;                // [0..16]: matrix workgroups (slot 16 = records); [17..33]: transform-role workgroups
     for (int w = 0; w < QPROF_WG; ++w) {
-        for (int k = 0; k < 16; ++k) out[k] += host[w][k];
-        if (host[w][11]) ++out[16];
+        const int o = host[w][15] ? 17 : 0;
+        for (int k = 0; k < 15; ++k) out[o + k] += host[w][k];
+        if (host[w][11]) ++out[o + 16];
     }
     if (reset) {
         static unsigned long long zero[QPROF_WG][16];
@@ -1144,31 +1095,34 @@ LM_API int lm_conv3x3_winograd44_f32(void* stream, const float* x, int ldx, cons
     return LM_OK;
 }
 
-// Scratch of lm_conv3x3_winograd44s_f32: the transformed input of every M block ([T / 32][Cin / 8][36][256] floats, alive for one launch)
-// + the hand-off flags and ticket heads
-LM_API long lm_winograd44s_workspace_bytes(int B, int H, int W, int Cin, int dil) {
+// Scratch of lm_conv3x3_winograd44p_f32: the transformed input of every M block ([T / 32][Cin / 8][36][256] floats, alive for one launch)
+// + per M block four flags and the producer's XCC id + eight ticket heads
+LM_API long lm_winograd44p_workspace_bytes(int B, int H, int W, int Cin, int dil) {
     if (dil < 1 || Cin < 16) return 0;
     const long mb = geom44(B, H, W, dil).T / QBM;
-    return mb * (Cin / 8) * 36L * 256L * (long)sizeof(float) + ((mb + 8) * (long)sizeof(unsigned) + 255) / 256 * 256;
+    return mb * (Cin / 8) * 36L * 256L * (long)sizeof(float) + ((mb * 5 + 8) * (long)sizeof(unsigned) + 255) / 256 * 256;
 }
 
-// The same convolution with the input transform taken out of the matrix workgroups (wino44s_kernel: see its header): V of a 32-tile block
-// is produced once by a transform workgroup and read by the Cout / 64 matrix workgroups of the block through `workspace`.  Same wu_frag,
-// same products in the same order, same epilogue: bit-identical to lm_conv3x3_winograd44_f32.
-LM_API int lm_conv3x3_winograd44s_f32(void* stream, const float* x, int ldx, const float* wu_frag, int CoutP, const float* scale,
+// The same convolution with ONE input transform per M block (wino44p_kernel: see its header): the workgroup of N tile 0 also publishes the
+// transformed patches it multiplies, the workgroups of the other N tiles read them instead of gathering and transforming the patches
+// again.  Same wu_frag, same products in the same order, same epilogue: bit-identical to lm_conv3x3_winograd44_f32 (which it falls back
+// to when Cout <= 64: nothing to share).
+LM_API int lm_conv3x3_winograd44p_f32(void* stream, const float* x, int ldx, const float* wu_frag, int CoutP, const float* scale,
                                       const float* shift, const float* res, int ldr, float* y, int ldy, int B, int H, int W,
                                       int Cin, int Cout, int dil, int act, double* gn_partial, void* workspace, long workspace_bytes) {
-    LM_REQUIRE(x && wu_frag && y && workspace, "conv_wino44s: null pointer");
-    LM_REQUIRE(lm_winograd44_supported(H, W, Cin, dil) && B > 0, "conv_wino44s: unsupported shape (H=%d W=%d Cin=%d dil=%d)", H, W, Cin, dil);
-    LM_REQUIRE(CoutP >= Cout && CoutP % QBN == 0, "conv_wino44s: CoutP=%d must be Cout=%d rounded up to %d", CoutP, Cout, QBN);
-    LM_REQUIRE(ldx >= Cin && ldx % 4 == 0 && ldy >= Cout, "conv_wino44s: bad leading dimension");
-    LM_REQUIRE(act == LM_ACT_NONE || act == LM_ACT_RELU, "conv_wino44s: activation %d not supported", act);
-    LM_REQUIRE(!gn_partial || (res == nullptr && act == LM_ACT_NONE && Cout % 4 == 0), "conv_wino44s(gn stats): no residual / activation");
-    LM_REQUIRE(lm_winograd44s_workspace_bytes(B, H, W, Cin, dil) <= workspace_bytes, "conv_wino44s: workspace too small");
-    W44SParams sp;
+    if ((Cout + QBN - 1) / QBN < 2)
+        return lm_conv3x3_winograd44_f32(stream, x, ldx, wu_frag, CoutP, scale, shift, res, ldr, y, ldy, B, H, W, Cin, Cout, dil, act, gn_partial);
+    LM_REQUIRE(x && wu_frag && y && workspace, "conv_wino44p: null pointer");
+    LM_REQUIRE(lm_winograd44_supported(H, W, Cin, dil) && B > 0, "conv_wino44p: unsupported shape (H=%d W=%d Cin=%d dil=%d)", H, W, Cin, dil);
+    LM_REQUIRE(CoutP >= Cout && CoutP % QBN == 0, "conv_wino44p: CoutP=%d must be Cout=%d rounded up to %d", CoutP, Cout, QBN);
+    LM_REQUIRE(ldx >= Cin && ldx % 4 == 0 && ldy >= Cout, "conv_wino44p: bad leading dimension");
+    LM_REQUIRE(act == LM_ACT_NONE || act == LM_ACT_RELU, "conv_wino44p: activation %d not supported", act);
+    LM_REQUIRE(!gn_partial || (res == nullptr && act == LM_ACT_NONE && Cout % 4 == 0), "conv_wino44p(gn stats): no residual / activation");
+    LM_REQUIRE(lm_winograd44p_workspace_bytes(B, H, W, Cin, dil) <= workspace_bytes, "conv_wino44p: workspace too small");
+    W44PParams sp;
     W44Params& p = sp.p;
     p.g = geom44(B, H, W, dil);
-    LM_REQUIRE((long)B * H * W * ldx < (1L << 40) && (long)B * H * W < (1L << 31) && p.g.T < (1L << 31), "conv_wino44s: tensor too large");
+    LM_REQUIRE((long)B * H * W * ldx < (1L << 40) && (long)B * H * W < (1L << 31) && p.g.T < (1L << 31), "conv_wino44p: tensor too large");
     p.x = x; p.U = wu_frag; p.scale = scale; p.shift = shift; p.res = res; p.y = y;
     p.ldx = ldx; p.ldr = ldr; p.ldy = ldy; p.C = Cin; p.Cout = Cout; p.NT = CoutP / 32; p.act = act;
     p.gn_part = gn_partial;
@@ -1176,16 +1130,17 @@ LM_API int lm_conv3x3_winograd44s_f32(void* stream, const float* x, int ldx, con
     if (int e = w44_zeros(&p.zeros)) return e;
     sp.mblocks = (int)(p.g.T / QBM);
     sp.n_tiles = (Cout + QBN - 1) / QBN;
+    static const int look = getenv("LANEMAP_W44P_LOOK") ? atoi(getenv("LANEMAP_W44P_LOOK")) : 4;
+    sp.look = look < 1 ? 1 : look;
     sp.Vg = (float*)workspace;
     sp.flags = (unsigned*)((char*)workspace + (long)sp.mblocks * (Cin / 8) * 36L * 256L * (long)sizeof(float));
-    sp.heads = sp.flags + sp.mblocks;
-    const size_t lds = (size_t)(TRING * TRAWF + QVF) * sizeof(float);
-    static_assert(SRING * 36 * 256 <= TRING * TRAWF + QVF && 36 * 32 * 32 <= SRING * 36 * 256, "the matrix role's ring and the exchange buffer fit");
-    const long blocks = (long)sp.mblocks * (sp.n_tiles + 1);
-    LM_REQUIRE(blocks > 0 && blocks < (1L << 31) && p.g.T % QBM == 0, "conv_wino44s: bad grid %ld", blocks);
-    if (int e = lm_ensure_dynamic_lds((const void*)wino44s_kernel, lds)) return e;
-    LM_HIP(hipMemsetAsync(sp.flags, 0, (size_t)(sp.mblocks + 8) * sizeof(unsigned), (hipStream_t)stream));
-    hipLaunchKernelGGL(wino44s_kernel, dim3((unsigned)blocks), dim3(256), lds, (hipStream_t)stream, sp);
+    const size_t lds = (size_t)(2 * QRAWF + QVF) * sizeof(float);
+    static_assert(SRING * 36 * 256 <= 2 * QRAWF + QVF, "the consumer role's ring fits");
+    const long blocks = (long)sp.mblocks * sp.n_tiles;
+    LM_REQUIRE(blocks > 0 && blocks < (1L << 31) && p.g.T % QBM == 0, "conv_wino44p: bad grid %ld", blocks);
+    if (int e = lm_ensure_dynamic_lds((const void*)wino44p_kernel, lds)) return e;
+    LM_HIP(hipMemsetAsync(sp.flags, 0, (size_t)(sp.mblocks * 5 + 8) * sizeof(unsigned), (hipStream_t)stream));
+    hipLaunchKernelGGL(wino44p_kernel, dim3((unsigned)blocks), dim3(256), lds, (hipStream_t)stream, sp);
     LM_LAUNCH_CHECK();
     return LM_OK;
 }

@@ -627,7 +627,7 @@ def test_conv_winograd44_bit_identical_to_twin(dev, B, cin, cout, H, W, dil):
     sd, bd = scale.to(dev), shift.to(dev)
     y0 = ops.conv_wino44_twin(xd, wu, cout, dil, scale=sd, shift=bd, res=rd, act=ops.ACT_RELU)
     y1 = ops.conv_wino44(xd, wf, cout, dil, scale=sd, shift=bd, res=rd, act=ops.ACT_RELU, shared=False)          # wino44_kernel
-    y1s = ops.conv_wino44(xd, wf, cout, dil, scale=sd, shift=bd, res=rd, act=ops.ACT_RELU, shared=True)         # wino44s_kernel (shared V)
+    y1s = ops.conv_wino44(xd, wf, cout, dil, scale=sd, shift=bd, res=rd, act=ops.ACT_RELU, shared=True)         # wino44p_kernel (shared V)
     assert torch.equal(y1s, y0), float((y1s - y0).abs().max())
     assert torch.equal(y1s, ops.conv_wino44(xd, wf, cout, dil, scale=sd, shift=bd, res=rd, act=ops.ACT_RELU, shared=True))
     want = F.relu(F.conv2d(x.double(), w.double(), None, 1, dil, dil) * scale.double().view(1, -1, 1, 1) + shift.double().view(1, -1, 1, 1)
@@ -698,8 +698,8 @@ def test_conv_winograd44_random_shapes_vs_twin(dev):
         tag = f'shape {done}: B{B} {cin}->{cout} {H}x{W} d{dil} scale={use_scale} res={use_res} relu={relu}'
         assert torch.equal(y0, y1), (tag, float((y0 - y1).abs().max()))
         assert torch.equal(y1, y2), tag
-        assert torch.equal(y0, y3), (tag + ' (wino44s_kernel)', float((y0 - y3).abs().max()))
-        assert torch.equal(y3, y4), tag + ' (wino44s_kernel, run to run)'
+        assert torch.equal(y0, y3), (tag + ' (wino44p_kernel)', float((y0 - y3).abs().max()))
+        assert torch.equal(y3, y4), tag + ' (wino44p_kernel, run to run)'
         if cin % 32 == 0:                       # (and against the direct MFMA kernel where it takes the shape: the twin shares the fused kernel's arithmetic)
             yd = ops.conv_mfma(x, ops.pack_mfma(w), cout, 3, 3, 1, dil, dil, scale=sc, shift=sh, res=res, act=act)
             _close(y1, yd, 1e-4, tag + ' vs direct')
