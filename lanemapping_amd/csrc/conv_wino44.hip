@@ -643,8 +643,8 @@ __device__ __forceinline__ void w44_body(const W44Params& p, const unsigned mblk
     float* vpub_q = nullptr;
     if constexpr (PUB) {
         const unsigned long long a = reinterpret_cast<unsigned long long>(vpub + xi00 * 256);
-        vpub_q = reinterpret_cast<float*>(((unsigned long long)__builtin_amdgcn_readfirstlane((unsigned)(a >> 32)) << 32) |
-                                          (unsigned long long)__builtin_amdgcn_readfirstlane((unsigned)a));
+        const unsigned hi = (unsigned)__builtin_amdgcn_readfirstlane((int)(a >> 32)), lo = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)a);
+        vpub_q = reinterpret_cast<float*>(((unsigned long long)hi << 32) | (unsigned long long)lo);
     }
     f32x16 acc[9][2];
 #pragma unroll
@@ -937,6 +937,9 @@ __device__ __forceinline__ void w44_consumer(const W44PParams& sp, const int mbl
 }
 
 __global__ __launch_bounds__(256) void wino44p_kernel(W44PParams sp) {
+#ifdef LM_QPROF
+    const long long t_entry = clock64();
+#endif
     __shared__ int s_ticket[3];
     const int tid = threadIdx.x;
     const int n = sp.n_tiles;
@@ -991,7 +994,13 @@ __global__ __launch_bounds__(256) void wino44p_kernel(W44PParams sp) {
     if (ntile == 0) {                                // producer: publish the XCD it runs on (write-through: consumers on other XCDs must see it)
         if (tid == 0) __hip_atomic_store(ids + mblk, (unsigned)xcc + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+#ifdef LM_QPROF
+        const long long t_body = clock64();
+#endif
         w44_body<true>(sp.p, (unsigned)mblk, 0u, sp.Vg + (long)mblk * nslots * (36 * 256), sp.flags + (long)mblk * 4 + wave);
+#ifdef LM_QPROF
+        if (tid == 0) g_qprof[blockIdx.x % QPROF_WG][15] = (home != xcc ? 3ull : 1ull) | ((unsigned long long)(t_body - t_entry) << 8);
+#endif
         return;
     }
     // consumer: is the producer on this XCD?  (It holds an earlier ticket, so it is running or done: the id arrives.)
@@ -1002,8 +1011,14 @@ __global__ __launch_bounds__(256) void wino44p_kernel(W44PParams sp) {
     }
     __syncthreads();
     const int pxcc = __builtin_amdgcn_readfirstlane(s_ticket[0]);
+#ifdef LM_QPROF
+    const long long t_body = clock64();
+#endif
     if (pxcc == xcc) w44_consumer(sp, mblk, ntile);
     else w44_body<false>(sp.p, (unsigned)mblk, (unsigned)ntile, nullptr, nullptr);      // (stolen ticket: the hand-off buffer lives in another L2)
+#ifdef LM_QPROF
+    if (tid == 0) g_qprof[blockIdx.x % QPROF_WG][15] = (pxcc == xcc ? 0ull : 2ull) | ((unsigned long long)(t_body - t_entry) << 8);
+#endif
 }
 
 // runs of adjacent tiles a 32-tile block can touch: floor((QBM - 2) / Tx) + 2
@@ -1029,10 +1044,11 @@ int w44_zeros(const float** out) {      // per device (a process may drive sever
 extern "C" __attribute__((visibility("default"))) int lm_qprof_read(unsigned long long* out, int reset) {
     static unsigned long long host[QPROF_WG][16];
     if (hipMemcpyFromSymbol(host, HIP_SYMBOL(g_qprof), sizeof(host)) != hipSuccess) return 1;
-    for (int k = 0; k < 34; ++k) out[k] = 0;                // [0..16]: matrix workgroups (slot 16 = records); [17..33]: transform-role workgroups
+    for (int k = 0; k < 68; ++k) out[k] = 0;                // four groups of 17 by role (slot 15): 0 plain / consumer, 1 producer, 2 fallback, 3 stolen ticket
     for (int w = 0; w < QPROF_WG; ++w) {
-        const int o = host[w][15] ? 17 : 0;
+        const int o = 17 * (int)(host[w][15] & 3);
         for (int k = 0; k < 15; ++k) out[o + k] += host[w][k];
+        out[o + 15] += host[w][15] >> 8;                    // cycles between kernel entry and the start of the role's body (ticket, producer id)
         if (host[w][11]) ++out[o + 16];
     }
     if (reset) {
