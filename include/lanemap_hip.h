@@ -58,16 +58,6 @@ long lm_winograd44_twin_workspace_bytes(int B, int H, int W, int Cin, int CoutP,
 int lm_conv3x3_winograd44_f32(void* stream, const float* x, int ldx, const float* wu_frag, int CoutP, const float* scale,
                               const float* shift, const float* res, int ldr, float* y, int ldy, int B, int H, int W,
                               int Cin, int Cout, int dil, int act, double* gn_partial);
-/* The same convolution with ONE input transform per 32-tile block (wino44p_kernel, round 5): the workgroup of N tile 0 also publishes the
- * transformed patches V = B^T d B it multiplies (one 16-byte store per lane and MFMA step) to `workspace`; the workgroups of the other
- * Cout / 64 - 1 N tiles read them (LDS DMA past the L1, through the L2 they share with the producer) instead of gathering and transforming
- * the patches again.  Roles by ticket per XCD (no dispatch-order or placement assumption; a consumer that finds its producer on another
- * XCD runs the plain kernel body).  Same wu_frag, same products in the same order, same epilogue: bit-identical to
- * lm_conv3x3_winograd44_f32.  workspace: lm_winograd44p_workspace_bytes, alive for the launch. */
-long lm_winograd44p_workspace_bytes(int B, int H, int W, int Cin, int dil);
-int lm_conv3x3_winograd44p_f32(void* stream, const float* x, int ldx, const float* wu_frag, int CoutP, const float* scale,
-                               const float* shift, const float* res, int ldr, float* y, int ldy, int B, int H, int W,
-                               int Cin, int Cout, int dil, int act, double* gn_partial, void* workspace, long workspace_bytes);
 int lm_conv3x3_winograd44_twin_f32(void* stream, const float* x, int ldx, const float* wu, int CoutP, const float* scale,
                                    const float* shift, const float* res, int ldr, float* y, int ldy, int B, int H, int W,
                                    int Cin, int Cout, int dil, int act, void* workspace, long workspace_bytes);

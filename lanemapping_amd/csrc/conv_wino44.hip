@@ -474,11 +474,11 @@ __device__ __forceinline__ f32x4 q_aread(const float* v) {
 // of nine); the B fragments of step S + QBD and the patch loads of this step (q_ndma) are issued first; q_nwait(S) loads may stay
 // outstanding when this step's B fragments are needed.  Behind the first MFMA: the A fragment of the next step (not across a barrier:
 // steps 4 and 8 leave it to the loop), the LDS part of this step's transform share, then its VALU part.
-template <int S, bool PUB>
+template <int S>
 __device__ __forceinline__ void w44_step(f32x16& acc0, f32x16& acc1, f32x4 (&bq)[QRING][2], unsigned bvoff, const float* bpre,
                                          const float* anext, const f32x4& a_cur, f32x4& a_nxt, const float* const (&gsrc)[QLPW], long goff,
                                          float* rawld, int wave, W44Xf& xf, const float* prerow, const int (&roff)[6], float* vA, float* vB,
-                                         float* vC, bool lower, const W44K& kk, float* vstore) {
+                                         float* vC, bool lower, const W44K& kk) {
     typedef __attribute__((address_space(1))) const void gptr_t;
     typedef __attribute__((address_space(3))) void lptr_t;
     constexpr int K = S % 9;
@@ -499,10 +499,6 @@ __device__ __forceinline__ void w44_step(f32x16& acc0, f32x16& acc1, f32x4 (&bq)
     q_bwait<0>(b);
 #endif
     constexpr bool VACC = K == 8;
-    // producer role: this step's A fragment = plane K of V(slot) for this lane goes to the hand-off buffer (a PLAIN store: acknowledged by the
-    // XCD's L2, which the consumers of the block share).  Stores and loads of a wave complete out of order with respect to each other, so
-    // the wait above allows only the YOUNGER LOADS to be outstanding (q_nwait): with stores in flight it waits a little longer, never too short.
-    if constexpr (PUB) asm volatile("global_store_dwordx4 %0, %1, %2" ::"v"(bvoff), "v"(a_cur), "s"(vstore) : "memory");
     q_mfma<VACC>(acc0, a_cur[0], b[0][0]);
     __builtin_amdgcn_sched_barrier(0);
     if constexpr (K != 4 && K != 8) a_nxt = q_aread(anext);
@@ -556,11 +552,7 @@ __device__ __forceinline__ void w44_tail_vec(const f32x4 (&z)[4][6], const f32x4
     }
 }
 
-// The body of a matrix workgroup: M block `mblk`, N tile `ntile`.  PUB (wino44p_kernel's producer role): every step also stores its A
-// fragment - plane K of V(slot), 16 bytes per lane, the layout the consumer role reads - to vpub[slot][plane][lane], and the wave publishes
-// in fpub how many slots of ITS quadrant are complete.
-template <bool PUB>
-__device__ __forceinline__ void w44_body(const W44Params& p, const unsigned mblk, const unsigned ntile, float* const vpub, unsigned* const fpub) {
+__global__ __launch_bounds__(256) void wino44_kernel(W44Params p) {
 #ifdef LM_QPROF
     long long qprof[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
     long long t_last = clock64();
@@ -573,12 +565,65 @@ __device__ __forceinline__ void w44_body(const W44Params& p, const unsigned mblk
     typedef __attribute__((address_space(3))) void lptr_t;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int n_tiles = (p.Cout + QBN - 1) / QBN;
+    unsigned mblk, ntile;
+    if (p.n_inner) {      // XCD-contiguous, N tile inner: the N tiles of an M block run side by side on one XCD (input lines shared in its L2)
+        const unsigned bid = blockIdx.x, per = gridDim.x / 8;
+        const unsigned lin = bid < per * 8 ? (bid % 8) * per + bid / 8 : bid;
+        mblk = lin / (unsigned)n_tiles;
+        ntile = lin % (unsigned)n_tiles;
+    } else {              // XCD-aware order, N tile outer (conv_wino.hip): an XCD streams one N tile's U from its L2
+        const unsigned bid = blockIdx.x, mb = gridDim.x / (unsigned)n_tiles, mbx = mb / 8, full = mbx * 8 * (unsigned)n_tiles;
+        if (bid < full) {
+            const unsigned xcd = bid % 8, idx = bid / 8;
+            ntile = idx / mbx;
+            mblk = xcd * mbx + idx % mbx;
+        } else {
+            const unsigned r = bid - full;
+            mblk = 8 * mbx + r / (unsigned)n_tiles;
+            ntile = r % (unsigned)n_tiles;
+        }
+    }
     const long m0 = (long)mblk * QBM;
     const int n0 = (int)ntile * QBN;
     const W44Geom& g = p.g;
     const int bi = (int)(m0 / g.Tpad);
     const int t0 = (int)(m0 - (long)bi * g.Tpad);
-#include "wino44_runtable.inc"
+    // run table: the 32 tiles are consecutive in the linear (phase, ty, tx) order = up to QSEG runs of horizontally adjacent tiles.
+    // Run k holds tiles ts[k] .. ts[k+1]-1 and occupies tile SLOTS ts[k] + k .. ts[k+1] + k (one spill slot for patch columns 4, 5 of
+    // its last tile); iy0 / ix0 = input pixel of patch cell (0, 0) of its first tile, oy0 / ox0 = output pixel (0, 0) of that tile
+    int ts[QSEG + 1], sn[QSEG], iy0[QSEG], ix0[QSEG], oy0[QSEG], ox0[QSEG];
+    {
+        int at = 0, t = t0;
+        int tx = t0 % g.Tx, rest = t0 / g.Tx;
+        int ty = rest % g.Ty, ph = rest / g.Ty;
+        int pa = ph / g.dil, pb = ph - pa * g.dil;
+#pragma unroll
+        for (int s_ = 0; s_ < QSEG; ++s_) {
+            ts[s_] = at;
+            const bool real = t < g.Timg && at < QBM;
+            const int n = at < QBM ? min(QBM - at, g.Tx - tx) : 0;
+            sn[s_] = real ? n : 0;
+            iy0[s_] = (4 * ty - 1) * g.dil + pa;
+            ix0[s_] = (4 * tx - 1) * g.dil + pb;
+            oy0[s_] = 4 * ty * g.dil + pa;
+            ox0[s_] = 4 * tx * g.dil + pb;
+            at += n;
+            t += n;
+            tx += n;
+            if (tx >= g.Tx) {
+                tx = 0;
+                if (++ty >= g.Ty) {
+                    ty = 0;
+                    if (++pb >= g.dil) {
+                        pb = 0;
+                        ++pa;
+                    }
+                }
+            }
+        }
+        ts[QSEG] = at;
+    }
     // patch loads: load s of wave w fills chunks (s * 4 + w) * 64 .. + 63 of the raw buffer; chunk = 16 B = channel quad cq of a cell;
     // cell = patch row r x position pos; position = 16 (slot >> 2) + 4 c + (slot & 3) for column c (0..3) of tile slot `slot`: the cells
     // one column of consecutive tiles needs are neighbours in LDS (the transform's ds_read_b64 then conflicts two-way at most)
@@ -639,13 +684,6 @@ __device__ __forceinline__ void w44_body(const W44Params& p, const unsigned mblk
     const long xstride = (long)(2 * nun) * ustride;              // floats between xi planes in U
     const float* const bbase = p.U + (long)xi00 * xstride + (long)(n0 >> 5) * 256;
 
-    // (producer role) this wave's quadrant of the hand-off buffer as a provably wave-uniform pointer: the stores take it as a scalar base
-    float* vpub_q = nullptr;
-    if constexpr (PUB) {
-        const unsigned long long a = reinterpret_cast<unsigned long long>(vpub + xi00 * 256);
-        const unsigned hi = (unsigned)__builtin_amdgcn_readfirstlane((int)(a >> 32)), lo = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)a);
-        vpub_q = reinterpret_cast<float*>(((unsigned long long)hi << 32) | (unsigned long long)lo);
-    }
     f32x16 acc[9][2];
 #pragma unroll
     for (int k = 0; k < 9; ++k)
@@ -683,9 +721,8 @@ __device__ __forceinline__ void w44_body(const W44Params& p, const unsigned mblk
     // B fragments of step S5 = S + QBD of the unit (S5 >= 18: first slot of the next unit)
 #define LM_QBPRE(S5) ((S5) < 18 ? bu + (long)((S5) / 9) * ustride + (long)LM_QXI((S5) % 9) * xstride : bu_next + (long)LM_QXI((S5) - 18) * xstride)
 #define LM_QSTEP(S, AC, AN) \
-    w44_step<S, PUB>(acc[(S) % 9][0], acc[(S) % 9][1], bq, bvoff, LM_QBPRE((S) + QBD), Vq + LM_QXI(((S) % 9) + 1 < 9 ? ((S) % 9) + 1 : 0) * 256, \
-                     AC, AN, gsrc, goff, rawc_w, wave, xf, (S) < 9 ? rawc + 8 + lowoff : rawn + lowoff, roff, vA, vB, vC, lower, kk,     \
-                     PUB ? vpu + ((S) / 9) * 9216 + LM_QXI((S) % 9) * 256 : nullptr)
+    w44_step<S>(acc[(S) % 9][0], acc[(S) % 9][1], bq, bvoff, LM_QBPRE((S) + QBD), Vq + LM_QXI(((S) % 9) + 1 < 9 ? ((S) % 9) + 1 : 0) * 256, \
+                AC, AN, gsrc, goff, rawc_w, wave, xf, (S) < 9 ? rawc + 8 + lowoff : rawn + lowoff, roff, vA, vB, vC, lower, kk)
     // the barrier in the middle of a slot: this wave's late stores (steps 0..3) are done; behind it every wave's are, and the early
     // planes are free (every wave has read V(s)'s in steps 0..4)
 #ifdef LM_QABL_NOMID                          // (timing ablation: what the barrier in the middle of a slot costs; results are wrong)
@@ -705,13 +742,6 @@ __device__ __forceinline__ void w44_body(const W44Params& p, const unsigned mblk
         const long goff = u + 2 < nun ? (long)(u + 2) * 16 : 0;            // (nothing left to fetch: harmless re-read of unit 0)
         const float* const bu = bbase + (long)(2 * u) * ustride;
         const float* const bu_next = bbase + (long)(u + 1 < nun ? 2 * (u + 1) : 0) * ustride;
-        float* const vpu = PUB ? vpub_q + (long)(2 * u) * 9216 : nullptr;                 // this wave's planes of slot 2 u in the hand-off buffer
-        if constexpr (PUB) {
-            // every wait of the loop leaves at most 21 operations of this wave outstanding (max of q_nwait) and stores complete in order
-            // among themselves: 26 stores were issued after V(2 u - 4)'s last one when step 17 of the previous unit waited, so slots
-            // 0 .. 2 u - 4 are complete here (and 0 .. 2 u - 3 in the middle of the unit, below)
-            if (u >= 2 && lane == 0) __hip_atomic_store(fpub, (unsigned)(2 * u - 3), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-        }
         f32x4 a0, a1;
         // ---- slot 2 u: channels 16 u .. 16 u + 7 multiplied, channels 16 u + 8 .. 16 u + 15 transformed behind the MFMAs
         a0 = q_aread(Vq);
@@ -726,9 +756,6 @@ __device__ __forceinline__ void w44_body(const W44Params& p, const unsigned mblk
         LM_QTICK(6)
         __builtin_amdgcn_s_barrier();          // V(2 u + 1)'s early planes complete
         LM_QTICK(5)
-        if constexpr (PUB) {
-            if (u >= 1 && lane == 0) __hip_atomic_store(fpub, (unsigned)(2 * u - 2), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-        }
         // ---- slot 2 u + 1: channels 16 u + 8 .. multiplied, the next unit's first half transformed, unit u + 2's patches requested
         a0 = q_aread(Vq);
         LM_QSTEP(9, a0, a1);  LM_QSTEP(10, a1, a0); LM_QSTEP(11, a0, a1); LM_QSTEP(12, a1, a0); LM_QSTEP(13, a0, a1);
@@ -746,279 +773,183 @@ __device__ __forceinline__ void w44_body(const W44Params& p, const unsigned mblk
     static_assert(18 % QRING == 0 && QBD < QRING, "eighteen steps per unit walk the ring a whole number of times");
 #pragma unroll
     for (int k = 0; k < QRING; ++k) q_bwait<0>(bq[k]);
-    if constexpr (PUB) {                       // (vmcnt(0) above: every store of the wave is complete)
-        if (lane == 0) __hip_atomic_store(fpub, (unsigned)(2 * nun), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-    }
 
     LM_QTICK(7)
 #ifdef LM_QABL_NOEPI
     if (p.act != 12345) return;
 #endif
-#include "wino44_epilogue.inc"
-}
-
-__global__ __launch_bounds__(256) void wino44_kernel(W44Params p) {
-    const int n_tiles = (p.Cout + QBN - 1) / QBN;
-    unsigned mblk, ntile;
-    if (p.n_inner) {      // XCD-contiguous, N tile inner: the N tiles of an M block run side by side on one XCD (input lines shared in its L2)
-        const unsigned bid = blockIdx.x, per = gridDim.x / 8;
-        const unsigned lin = bid < per * 8 ? (bid % 8) * per + bid / 8 : bid;
-        mblk = lin / (unsigned)n_tiles;
-        ntile = lin % (unsigned)n_tiles;
-    } else {              // XCD-aware order, N tile outer: an XCD streams one N tile's U from its L2
-        const unsigned bid = blockIdx.x, mb = gridDim.x / (unsigned)n_tiles, mbx = mb / 8, full = mbx * 8 * (unsigned)n_tiles;
-        if (bid < full) {
-            const unsigned xcd = bid % 8, idx = bid / 8;
-            ntile = idx / mbx;
-            mblk = xcd * mbx + idx % mbx;
-        } else {
-            const unsigned r = bid - full;
-            mblk = 8 * mbx + r / (unsigned)n_tiles;
-            ntile = r % (unsigned)n_tiles;
-        }
-    }
-    w44_body<false>(p, mblk, ntile, nullptr, nullptr);
-}
-
-// ===================================================================================================================================
-// wino44p_kernel (round 5): the N tiles of an M block share ONE input transform.
-//
-// In wino44_kernel every workgroup transforms its own patches: V = B^T d B of a 32-tile block is recomputed by each of the Cout / 64
-// workgroups that multiply it, and f32 MFMA shares the SIMD's vector ALUs, so those 72 packed VALU instructions per 72 MFMAs cost 13.7 %
-// of the kernel (timing ablation profiles/r5_wino44_ablation.txt: 4.10 -> 3.54 ms at 256 -> 256 @288^2 with the transform compiled out).
-// Here the workgroup of N tile 0 is the block's PRODUCER: wino44_kernel's body, whose waves additionally store every A fragment they
-// read - plane by plane, 16 bytes per lane, one store per MFMA step - to a scratch buffer and publish per wave how many 8-channel slots of
-// their quadrant are complete.  The workgroups of N tiles 1 .. are CONSUMERS: no patch gather, no transform, no barrier in the K loop -
-// every wave DMAs the nine planes of ITS quadrant (global_load_lds ... sc1 = past the L1, ring of four slots in LDS, three slots ahead)
-// and reads only those; B fragments, MFMA order, accumulators and the epilogue are wino44_kernel's: bit-identical y.
-//   * Roles come from TICKETS, not from blockIdx: thread 0 reads the XCD it runs on (HW_REG_XCC_ID) and takes the next ticket of THAT XCD's
-//     queue (atomicAdd; other queues when its own is empty).  Queue order P(0), P(1), [P(k + 2), C(k, 1 .. n - 1)] for k = 0, 1, ...: a
-//     workgroup that holds C(k, .) implies P(k)'s ticket was taken earlier by a workgroup that is running or done - a consumer may wait for
-//     its producer, a producer waits for nobody: no deadlock under ANY dispatch order; the two blocks of lookahead give a producer its
-//     head start (consumers are ~12 % faster than the producer and must not catch up).
-//   * The hand-off goes through the XCD's L2: plain stores (acknowledged by L2) -> flag (plain store of the same wave, behind a wait that
-//     proves the payload complete) -> consumer polls with sc1 loads and DMAs with sc1 (L1 bypassed, served by the L2 it shares with the
-//     producer).  That is only valid on ONE XCD, and it is VERIFIED, not assumed: the producer publishes the XCC id it runs on
-//     (write-through); a consumer on another XCD (a stolen ticket) does not touch the scratch buffer and runs wino44_kernel's body itself.
-//   * A wave's loads and stores share vmcnt and complete out of order with respect to each other: the producer's B-fragment waits allow only
-//     the YOUNGER LOADS to be outstanding (never too short; slightly longer while a store is in flight), and a slot is published three
-//     slots late, when 26 younger stores prove it complete under a wait that leaves at most 21 operations outstanding.
-constexpr int SRING = 4;                         // V slots in LDS (consumer role), three ahead
-
-struct W44PParams {
-    W44Params p;
-    float* Vg;                                   // [M blocks][C / 8 slots][36][256]
-    unsigned* flags;                             // [M blocks][4 waves] slots published | then [M blocks] producer XCC id + 1 | then [8] ticket heads
-    int mblocks, n_tiles, look;                  // look: producers run this many M blocks ahead of the consumers in a queue
-};
-constexpr int qxi(int K) { return 6 * (K / 3) + K % 3; }
-
-// one step of the consumer role: B fragments of step S + QBD, ONE plane of the V slot three ahead, then wino44_kernel's 8 MFMAs
-template <int S>
-__device__ __forceinline__ void w44c_step(f32x16& acc0, f32x16& acc1, f32x4 (&bq)[QRING][2], unsigned bvoff, const float* bpre, const float* anext,
-                                          const f32x4& a_cur, f32x4& a_nxt, const float* vsrc, float* vdst) {
-    typedef __attribute__((address_space(1))) const void gptr_t;
-    typedef __attribute__((address_space(3))) void lptr_t;
-    constexpr int K = S % 9;
-    q_bload2(bq[(S + QBD) % QRING], bvoff, bpre);
-    __builtin_amdgcn_global_load_lds((gptr_t*)vsrc, (lptr_t*)vdst, 16, 0, 16);          // aux 16 = sc1
-    f32x4 (&b)[2] = bq[S % QRING];
-    q_bwait<3 * QBD + 1>(b);          // younger than this step's B fragments: the plane of step S - QBD and 3 loads per step since
-    constexpr bool VACC = K == 8;
-    q_mfma<VACC>(acc0, a_cur[0], b[0][0]);
-    __builtin_amdgcn_sched_barrier(0);
-    a_nxt = *reinterpret_cast<const f32x4*>(anext);
-    __builtin_amdgcn_sched_barrier(0);
-    q_mfma<VACC>(acc1, a_cur[0], b[1][0]);
-#pragma unroll
-    for (int t = 1; t < 4; ++t) {
-        q_mfma<VACC>(acc0, a_cur[t], b[0][t]);
-        q_mfma<VACC>(acc1, a_cur[t], b[1][t]);
-    }
-    __builtin_amdgcn_sched_barrier(0);
-}
-
-__device__ __forceinline__ void w44_consumer(const W44PParams& sp, const int mblk, const int ntile) {
-    const W44Params& p = sp.p;
-#ifdef LM_QPROF
-    long long qprof[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
-    long long t_last = clock64();
-    const long long t_first = t_last;
-#endif
-    extern __shared__ __attribute__((aligned(16))) float smem[];
-    typedef __attribute__((address_space(1))) const void gptr_t;
-    typedef __attribute__((address_space(3))) void lptr_t;
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const long m0 = (long)mblk * QBM;
-    const W44Geom& g = p.g;
-    const int bi = (int)(m0 / g.Tpad);
-    const int t0 = (int)(m0 - (long)bi * g.Tpad);
-#include "wino44_runtable.inc"
-    const int img_pix0 = bi * g.H * g.W;
-    const int nslots = p.C / 8;
-    const float* const Vgm = sp.Vg + (long)mblk * nslots * (36 * 256);
-    const unsigned* const fsub = sp.flags + (long)mblk * 4 + wave;   // slots of this wave's quadrant published by the producer's wave of the same index
-    const int n0 = ntile * QBN;
-    float* const Vb = smem;                                           // V[SRING][36][256]; the epilogue's exchange buffer over it
-    const int qa = wave >> 1, qb = wave & 1;
-    const int xi00 = 18 * qa + 3 * qb;
-    const int nun = p.C / 16;
-    const unsigned bvoff = (unsigned)lane * 16u;
-    const long ustride = (long)p.NT * 256;
-    const long xstride = (long)(2 * nun) * ustride;
-    const float* const bbase = p.U + (long)xi00 * xstride + (long)(n0 >> 5) * 256;
-    const float* const vsrc0 = Vgm + xi00 * 256 + lane * 4;          // + slot * 9216 + qxi(K) * 256
-    float* const vdst0 = Vb + xi00 * 256;                             // (wave-uniform LDS base of a DMA) + (slot & 3) * 9216 + qxi(K) * 256
-    const float* const Vq = Vb + xi00 * 256 + lane * 4;               // A fragment of plane K of ring slot r: Vq + r * 9216 + qxi(K) * 256
-
-    f32x16 acc[9][2];
-#pragma unroll
-    for (int k = 0; k < 9; ++k)
-#pragma unroll
-        for (int b = 0; b < 2; ++b)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[k][b][r] = 0.f;
-    f32x4 bq[QRING][2];
-    LM_QTICK(0)
-    int avail = 0;                                                    // slots known to be published
-    auto need = [&](int want) {                                       // wait until `want` slots are published (rare after the start: the producer has a head start)
-        want = want < nslots ? want : nslots;
-        while (avail < want) {
-            avail = (int)__builtin_amdgcn_readfirstlane(__hip_atomic_load(fsub, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
-            if (avail < want) __builtin_amdgcn_s_sleep(8);
-        }
-    };
-    need(3);
-    LM_QTICK(1)
-#pragma unroll
-    for (int sl = 0; sl < 3; ++sl) {
-        const int ss = sl < nslots ? sl : nslots - 1;
-#pragma unroll
-        for (int k = 0; k < 9; ++k)
-            __builtin_amdgcn_global_load_lds((gptr_t*)(vsrc0 + (long)ss * 9216 + qxi(k) * 256), (lptr_t*)(vdst0 + sl * 9216 + qxi(k) * 256), 16, 0, 16);
-    }
-#pragma unroll
-    for (int k = 0; k < QBD; ++k) q_bload2(bq[k], bvoff, bbase + (long)qxi(k) * xstride);
-    q_bwait<0>(bq[0]);
-    LM_QTICK(3)
-    f32x4 a0 = *reinterpret_cast<const f32x4*>(Vq), a1;              // plane 0 of slot 0; every step prefetches the next step's plane
-#define LM_CBPRE(S5) ((S5) < 18 ? bu + (long)((S5) / 9) * ustride + (long)qxi((S5) % 9) * xstride : bu_next + (long)qxi((S5) - 18) * xstride)
-    // step S of unit u: slot 2 u + S / 9 in ring position (2 u + S / 9) & 3 = 2 (u & 1) + S / 9; its DMA fetches plane S % 9 of slot 2 u + S / 9 + 3
-#define LM_CSTEP(S, AC, AN)                                                                                                              \
-    w44c_step<S>(acc[(S) % 9][0], acc[(S) % 9][1], bq, bvoff, LM_CBPRE((S) + QBD),                                                        \
-                 ((S) % 9 == 8 ? ((S) < 9 ? vq1 : vq0n) : ((S) < 9 ? vq0 : vq1)) + qxi(((S) % 9 + 1) % 9) * 256, AC, AN,                    \
-                 ((S) < 9 ? vs0 : vs1) + qxi((S) % 9) * 256, ((S) < 9 ? vd0 : vd1) + qxi((S) % 9) * 256)
-    for (int u = 0; u < nun; ++u) {
-        need(2 * u + 5);                                              // the slots this unit's DMAs fetch: 2 u + 3, 2 u + 4
-        const int r0 = 2 * (u & 1);                                   // ring position of slot 2 u (slot 2 u + 1: r0 + 1)
-        const float* const vq0 = Vq + r0 * 9216;
-        const float* const vq1 = Vq + (r0 + 1) * 9216;
-        const float* const vq0n = Vq + ((r0 + 2) & 3) * 9216;        // slot 2 u + 2 (the next unit's first)
-        const int s3 = 2 * u + 3 < nslots ? 2 * u + 3 : nslots - 1, s4 = 2 * u + 4 < nslots ? 2 * u + 4 : nslots - 1;
-        const float* const vs0 = vsrc0 + (long)s3 * 9216;            // fetched during slot 2 u -> ring position (2 u + 3) & 3 = (r0 + 3) & 3
-        const float* const vs1 = vsrc0 + (long)s4 * 9216;            // fetched during slot 2 u + 1 -> ring position r0 (slot 2 u: consumed)
-        float* const vd0 = vdst0 + ((r0 + 3) & 3) * 9216;
-        float* const vd1 = vdst0 + r0 * 9216;
-        const float* const bu = bbase + (long)(2 * u) * ustride;
-        const float* const bu_next = bbase + (long)(u + 1 < nun ? 2 * (u + 1) : 0) * ustride;
-        LM_CSTEP(0, a0, a1); LM_CSTEP(1, a1, a0); LM_CSTEP(2, a0, a1); LM_CSTEP(3, a1, a0); LM_CSTEP(4, a0, a1);
-        LM_CSTEP(5, a1, a0); LM_CSTEP(6, a0, a1); LM_CSTEP(7, a1, a0); LM_CSTEP(8, a0, a1);
-        LM_CSTEP(9, a1, a0); LM_CSTEP(10, a0, a1); LM_CSTEP(11, a1, a0); LM_CSTEP(12, a0, a1); LM_CSTEP(13, a1, a0);
-        LM_CSTEP(14, a0, a1); LM_CSTEP(15, a1, a0); LM_CSTEP(16, a0, a1); LM_CSTEP(17, a1, a0);
-        LM_QTICK(4)
-    }
-#undef LM_CSTEP
-#undef LM_CBPRE
-#pragma unroll
-    for (int k = 0; k < QRING; ++k) q_bwait<0>(bq[k]);
-    LM_QTICK(7)
-#include "wino44_epilogue.inc"
-}
-
-__global__ __launch_bounds__(256) void wino44p_kernel(W44PParams sp) {
-#ifdef LM_QPROF
-    const long long t_entry = clock64();
-#endif
-    __shared__ int s_ticket[3];
-    const int tid = threadIdx.x;
-    const int n = sp.n_tiles;
-    const int per = sp.mblocks / 8, rem = sp.mblocks % 8;
-    unsigned* const ids = sp.flags + (long)sp.mblocks * 4;
-    unsigned* const heads = ids + sp.mblocks;
-    if (tid == 0) {
-        unsigned x;
-        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(x));
-        x &= 7u;
-        int got = -1, home = 0;
-        for (int q = 0; q < 8; ++q) {
-            const unsigned xq = (x + (unsigned)q) & 7u;
-            const unsigned cnt = (unsigned)((per + ((int)xq < rem ? 1 : 0)) * n);
-            if (cnt == 0) continue;
-            const unsigned t = atomicAdd(&heads[xq], 1u);
-            if (t < cnt) {
-                got = (int)t;
-                home = (int)xq;
-                break;
-            }
-        }
-        s_ticket[0] = got;
-        s_ticket[1] = home;
-        s_ticket[2] = (int)x;
-    }
-    __syncthreads();
-    const int ticket = __builtin_amdgcn_readfirstlane(s_ticket[0]), home = __builtin_amdgcn_readfirstlane(s_ticket[1]);
-    const int xcc = __builtin_amdgcn_readfirstlane(s_ticket[2]);
-    if (ticket < 0) return;                          // (cannot happen: tickets = workgroups)
-    int mblk, ntile;
+    // ---- epilogue: the products of one 32-channel block go to LDS as M[xi][tile][32 channels] (144 KB; straight from the accumulator
+    // registers), every thread takes one (tile, channel quad): 36 ds_read_b128, A^T M A (rows first, then columns: w44_at), tail, 16 stores
+    const int etile = tid >> 3, ecq = tid & 7;
+    int epix0;
+    int eny = 0, enx = 0;                                   // valid output rows / columns of this thread's tile (0: no tile)
     {
-        // queue of XCD `home`: P(0) .. P(L - 1), then for k = 0 .. Mx - 1: [P(k + L) while it exists] C(k, 1) .. C(k, n - 1)
-        const int Mx = per + (home < rem ? 1 : 0), mlo = home * per + (home < rem ? home : rem);
-        const int L = Mx < sp.look ? Mx : sp.look, Gf = Mx - L;
-        if (ticket < L) {
-            mblk = mlo + ticket; ntile = 0;
+        int nn = sn[0], oy = oy0[0], oxb = ox0[0], tb = 0;
+#pragma unroll
+        for (int k = 1; k < QSEG; ++k)
+            if (etile >= ts[k]) {
+                nn = sn[k]; oy = oy0[k]; oxb = ox0[k]; tb = ts[k];
+            }
+        const int ox = oxb + 4 * (etile - tb) * g.dil;
+        epix0 = img_pix0 + oy * g.W + ox;
+        if (nn > 0 && oy < g.H && ox < g.W) {
+            eny = min(4, (g.H - oy + g.dil - 1) / g.dil);
+            enx = min(4, (g.W - ox + g.dil - 1) / g.dil);
+        }
+    }
+    float* const mw = smem + xi00 * 1024 + (4 * (lane >> 5)) * 32 + (lane & 31);      // this wave's planes, this lane's origin
+    const float* const mr = smem + etile * 32 + ecq * 4;
+    f32x4 gsum[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}}, gsq[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+    const bool full = eny == 4 && enx == 4;
+    const int ebase = eny > 0 ? epix0 : img_pix0;                 // (a missing tile reads - and never writes - pixel 0 of its image)
+    const int ey1 = max(eny - 1, 0), ex1 = max(enx - 1, 0);
+    const float relu_lo = p.act == LM_ACT_RELU ? 0.f : -__builtin_inff();               // fmaxf(v, -inf) = v
+    const bool has_res = p.res != nullptr, gn = p.gn_part != nullptr;
+    LM_QTICK(8)
+#pragma unroll
+    for (int blk = 0; blk < 2; ++blk) {
+        const int n = n0 + blk * 32 + ecq * 4;
+        const bool vec = (n + 3 < p.Cout) && ((p.ldy & 3) == 0) && (!p.res || (p.ldr & 3) == 0);
+        // residual (BasicBlock identity): the sixteen 16-byte loads of this thread's outputs go out BEFORE the exchange - inside the
+        // store loop each was a memory round trip of its own in front of a store (y may alias res as far as the compiler knows).
+        // Branch-free: offsets clamped into the tile's valid part (equal to the true offsets wherever an output exists)
+        f32x4 sc = {1.f, 1.f, 1.f, 1.f}, sh = {0.f, 0.f, 0.f, 0.f};             // (v * 1 + 0 = v exactly: same bits as the twin's `v + shift`)
+        if (vec) {
+            if (p.scale) sc = *reinterpret_cast<const f32x4*>(p.scale + n);
+            if (p.shift) sh = *reinterpret_cast<const f32x4*>(p.shift + n);
         } else {
-            const int u = ticket - L;
-            if (u < Gf * n) {
-                const int k = u / n, r = u - k * n;
-                if (r == 0) { mblk = mlo + k + L; ntile = 0; }
-                else { mblk = mlo + k; ntile = r; }
-            } else {
-                const int v = u - Gf * n;
-                const int k = Gf + v / (n - 1);
-                mblk = mlo + k; ntile = 1 + v % (n - 1);
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+                if (n + e < p.Cout) {
+                    if (p.scale) sc[e] = p.scale[n + e];
+                    if (p.shift) sh[e] = p.shift[n + e];
+                }
+        }
+        // residual (BasicBlock identity): the sixteen 16-byte loads of this thread's outputs are issued BETWEEN the product stores of the
+        // exchange - issuing them costs ~140 cycles apiece here (cold lines, eight 128-byte segments 4 KB apart per wave instruction:
+        // profiles/r4_wino44_residual_issue_experiment.txt), the LDS store path drains its queue meanwhile; inside the store loop of the tail
+        // each would be a memory round trip of its own in front of a store (y may alias res as far as the compiler knows).
+        // Branch-free: offsets clamped into the tile's valid part (equal to the true offsets wherever an output exists)
+        f32x4 rpre[16];
+#ifdef LM_QABL_NORES
+        const bool load_res = false;
+#else
+        const bool load_res = vec && has_res;
+#endif
+        const float* const rp = p.res + (long)ebase * p.ldr + n;
+        const int rs = g.W * g.dil * p.ldr, cs = g.dil * p.ldr;
+        // (LDS-only barriers: __syncthreads() would also wait for the previous block's global stores to be acknowledged)
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        LM_QTICK(9)
+        __builtin_amdgcn_s_barrier();          // patch / V buffers (blk 0) or the previous block's products are no longer read
+        LM_QTICK(10)
+#pragma unroll
+        for (int k = 0; k < 9; ++k) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) mw[(6 * (k / 3) + k % 3) * 1024 + ((r & 3) + 8 * (r >> 2)) * 32] = acc[k][blk][r];
+            if (k < 8 && load_res) {
+#pragma unroll
+                for (int q = 2 * k; q < 2 * k + 2; ++q)
+                    rpre[q] = *reinterpret_cast<const f32x4*>(rp + min(q >> 2, ey1) * rs + min(q & 3, ex1) * cs);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        LM_QTICK(12)
+        __builtin_amdgcn_s_barrier();
+        LM_QTICK(13)
+        if (n < p.Cout && eny > 0) {
+            f32x4 z[4][6];
+#pragma unroll
+            for (int j = 0; j < 6; ++j) {
+                f32x4 col[6], y4[4];
+#pragma unroll
+                for (int i = 0; i < 6; ++i) col[i] = *reinterpret_cast<const f32x4*>(mr + (6 * i + j) * 1024);
+                w44_at(col, y4);
+#pragma unroll
+                for (int yy = 0; yy < 4; ++yy) z[yy][j] = y4[yy];
+            }
+            float* const yp = p.y + (long)ebase * p.ldy + n;
+            const int rowstep = g.W * g.dil * p.ldy, colstep = g.dil * p.ldy;
+            if (vec) {
+                if (full) w44_tail_vec<true>(z, rpre, yp, rowstep, colstep, sc, sh, relu_lo, has_res, gn, gsum[blk], gsq[blk], eny, enx);
+                else w44_tail_vec<false>(z, rpre, yp, rowstep, colstep, sc, sh, relu_lo, has_res, gn, gsum[blk], gsq[blk], eny, enx);
+            } else {                           // channel counts / leading dimensions that rule out 16-byte accesses: element by element
+                // (fully unrolled with guards: a run-time index into z would move the array - on the 16-byte path too - to scratch memory)
+#pragma unroll
+                for (int yy = 0; yy < 4; ++yy) {
+                    f32x4 o[4];
+                    w44_at(z[yy], o);
+#pragma unroll
+                    for (int xx = 0; xx < 4; ++xx) {
+#pragma clang fp contract(off)
+                        const f32x4 v = o[xx] * sc + sh;
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            if (!(yy < eny && xx < enx && n + e < p.Cout)) continue;
+                            if (gn) {
+                                gsum[blk][e] += v[e];
+                                gsq[blk][e] = __builtin_fmaf(v[e], v[e], gsq[blk][e]);
+                            }
+                            float u = v[e];
+                            if (has_res) u += p.res[((long)ebase + (yy * g.W + xx) * g.dil) * p.ldr + n + e];
+                            yp[yy * rowstep + xx * colstep + e] = fmaxf(u, relu_lo);
+                        }
+                    }
+                }
+            }
+        }
+        LM_QTICK(14)
+    }
+#ifdef LM_QPROF
+    if (tid == 0) {
+#pragma unroll
+        for (int k = 0; k < 15; ++k) g_qprof[blockIdx.x % QPROF_WG][k] = (unsigned long long)qprof[k];
+        g_qprof[blockIdx.x % QPROF_WG][11] = (unsigned long long)(clock64() - t_first);
+    }
+#endif
+    if (p.gn_part) {      // fixed-order reduction: the 8 lanes of a wave that share a channel quad, then the four waves through LDS
+#pragma unroll
+        for (int blk = 0; blk < 2; ++blk)
+#pragma unroll
+            for (int o = 8; o < 64; o <<= 1)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    gsum[blk][e] += __shfl_xor(gsum[blk][e], o);
+                    gsq[blk][e] += __shfl_xor(gsq[blk][e], o);
+                }
+        __syncthreads();
+        if (lane < 8) {
+#pragma unroll
+            for (int blk = 0; blk < 2; ++blk) {
+                *reinterpret_cast<f32x4*>(smem + (((wave * 2 + blk) * 8 + lane) * 2) * 4) = gsum[blk];
+                *reinterpret_cast<f32x4*>(smem + (((wave * 2 + blk) * 8 + lane) * 2 + 1) * 4) = gsq[blk];
+            }
+        }
+        __syncthreads();
+        if (tid < 16) {
+#pragma clang fp contract(off)
+            const int blk = tid >> 3, cq = tid & 7;
+            const int n = n0 + blk * 32 + cq * 4;
+            f32x4 s = {0.f, 0.f, 0.f, 0.f}, q = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int w = 0; w < 4; ++w) {
+                const f32x4 a = *reinterpret_cast<const f32x4*>(smem + (((w * 2 + blk) * 8 + cq) * 2) * 4);
+                const f32x4 b = *reinterpret_cast<const f32x4*>(smem + (((w * 2 + blk) * 8 + cq) * 2 + 1) * 4);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    s[e] += a[e];
+                    q[e] += b[e];
+                }
+            }
+            const long chunk = t0 / 32;
+            double* o = p.gn_part + (((long)bi * (g.Tpad / 32) + chunk) * p.Cout + n) * 2;
+            for (int e = 0; e < 4 && n + e < p.Cout; ++e) {
+                o[2 * e] = (double)s[e];
+                o[2 * e + 1] = (double)q[e];
             }
         }
     }
-    const int nslots = sp.p.C / 8;
-    if (ntile == 0) {                                // producer: publish the XCD it runs on (write-through: consumers on other XCDs must see it)
-        if (tid == 0) __hip_atomic_store(ids + mblk, (unsigned)xcc + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-#ifdef LM_QPROF
-        const long long t_body = clock64();
-#endif
-        w44_body<true>(sp.p, (unsigned)mblk, 0u, sp.Vg + (long)mblk * nslots * (36 * 256), sp.flags + (long)mblk * 4 + wave);
-#ifdef LM_QPROF
-        if (tid == 0) g_qprof[blockIdx.x % QPROF_WG][15] = (home != xcc ? 3ull : 1ull) | ((unsigned long long)(t_body - t_entry) << 8);
-#endif
-        return;
-    }
-    // consumer: is the producer on this XCD?  (It holds an earlier ticket, so it is running or done: the id arrives.)
-    if (tid == 0) {
-        unsigned id = 0;
-        while ((id = __hip_atomic_load(ids + mblk, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) == 0) __builtin_amdgcn_s_sleep(8);
-        s_ticket[0] = (int)id - 1;
-    }
-    __syncthreads();
-    const int pxcc = __builtin_amdgcn_readfirstlane(s_ticket[0]);
-#ifdef LM_QPROF
-    const long long t_body = clock64();
-#endif
-    if (pxcc == xcc) w44_consumer(sp, mblk, ntile);
-    else w44_body<false>(sp.p, (unsigned)mblk, (unsigned)ntile, nullptr, nullptr);      // (stolen ticket: the hand-off buffer lives in another L2)
-#ifdef LM_QPROF
-    if (tid == 0) g_qprof[blockIdx.x % QPROF_WG][15] = (pxcc == xcc ? 0ull : 2ull) | ((unsigned long long)(t_body - t_entry) << 8);
-#endif
 }
 
 // runs of adjacent tiles a 32-tile block can touch: floor((QBM - 2) / Tx) + 2
@@ -1044,12 +975,10 @@ int w44_zeros(const float** out) {      // per device (a process may drive sever
 extern "C" __attribute__((visibility("default"))) int lm_qprof_read(unsigned long long* out, int reset) {
     static unsigned long long host[QPROF_WG][16];
     if (hipMemcpyFromSymbol(host, HIP_SYMBOL(g_qprof), sizeof(host)) != hipSuccess) return 1;
-    for (int k = 0; k < 68; ++k) out[k] = 0;                // four groups of 17 by role (slot 15): 0 plain / consumer, 1 producer, 2 fallback, 3 stolen ticket
+    for (int k = 0; k < 17; ++k) out[k] = 0;
     for (int w = 0; w < QPROF_WG; ++w) {
-        const int o = 17 * (int)(host[w][15] & 3);
-        for (int k = 0; k < 15; ++k) out[o + k] += host[w][k];
-        out[o + 15] += host[w][15] >> 8;                    // cycles between kernel entry and the start of the role's body (ticket, producer id)
-        if (host[w][11]) ++out[o + 16];
+        for (int k = 0; k < 16; ++k) out[k] += host[w][k];
+        if (host[w][11]) ++out[16];
     }
     if (reset) {
         static unsigned long long zero[QPROF_WG][16];
@@ -1107,56 +1036,6 @@ LM_API int lm_conv3x3_winograd44_f32(void* stream, const float* x, int ldx, cons
     LM_REQUIRE(blocks > 0 && blocks < (1L << 31) && p.g.T % QBM == 0, "conv_wino44: bad grid %ld", blocks);
     if (int e = lm_ensure_dynamic_lds((const void*)wino44_kernel, lds)) return e;
     hipLaunchKernelGGL(wino44_kernel, dim3((unsigned)blocks), dim3(256), lds, (hipStream_t)stream, p);
-    LM_LAUNCH_CHECK();
-    return LM_OK;
-}
-
-// Scratch of lm_conv3x3_winograd44p_f32: the transformed input of every M block ([T / 32][Cin / 8][36][256] floats, alive for one launch)
-// + per M block four flags and the producer's XCC id + eight ticket heads
-LM_API long lm_winograd44p_workspace_bytes(int B, int H, int W, int Cin, int dil) {
-    if (dil < 1 || Cin < 16) return 0;
-    const long mb = geom44(B, H, W, dil).T / QBM;
-    return mb * (Cin / 8) * 36L * 256L * (long)sizeof(float) + ((mb * 5 + 8) * (long)sizeof(unsigned) + 255) / 256 * 256;
-}
-
-// The same convolution with ONE input transform per M block (wino44p_kernel: see its header): the workgroup of N tile 0 also publishes the
-// transformed patches it multiplies, the workgroups of the other N tiles read them instead of gathering and transforming the patches
-// again.  Same wu_frag, same products in the same order, same epilogue: bit-identical to lm_conv3x3_winograd44_f32 (which it falls back
-// to when Cout <= 64: nothing to share).
-LM_API int lm_conv3x3_winograd44p_f32(void* stream, const float* x, int ldx, const float* wu_frag, int CoutP, const float* scale,
-                                      const float* shift, const float* res, int ldr, float* y, int ldy, int B, int H, int W,
-                                      int Cin, int Cout, int dil, int act, double* gn_partial, void* workspace, long workspace_bytes) {
-    if ((Cout + QBN - 1) / QBN < 2)
-        return lm_conv3x3_winograd44_f32(stream, x, ldx, wu_frag, CoutP, scale, shift, res, ldr, y, ldy, B, H, W, Cin, Cout, dil, act, gn_partial);
-    LM_REQUIRE(x && wu_frag && y && workspace, "conv_wino44p: null pointer");
-    LM_REQUIRE(lm_winograd44_supported(H, W, Cin, dil) && B > 0, "conv_wino44p: unsupported shape (H=%d W=%d Cin=%d dil=%d)", H, W, Cin, dil);
-    LM_REQUIRE(CoutP >= Cout && CoutP % QBN == 0, "conv_wino44p: CoutP=%d must be Cout=%d rounded up to %d", CoutP, Cout, QBN);
-    LM_REQUIRE(ldx >= Cin && ldx % 4 == 0 && ldy >= Cout, "conv_wino44p: bad leading dimension");
-    LM_REQUIRE(act == LM_ACT_NONE || act == LM_ACT_RELU, "conv_wino44p: activation %d not supported", act);
-    LM_REQUIRE(!gn_partial || (res == nullptr && act == LM_ACT_NONE && Cout % 4 == 0), "conv_wino44p(gn stats): no residual / activation");
-    LM_REQUIRE(lm_winograd44p_workspace_bytes(B, H, W, Cin, dil) <= workspace_bytes, "conv_wino44p: workspace too small");
-    W44PParams sp;
-    W44Params& p = sp.p;
-    p.g = geom44(B, H, W, dil);
-    LM_REQUIRE((long)B * H * W * ldx < (1L << 40) && (long)B * H * W < (1L << 31) && p.g.T < (1L << 31), "conv_wino44p: tensor too large");
-    p.x = x; p.U = wu_frag; p.scale = scale; p.shift = shift; p.res = res; p.y = y;
-    p.ldx = ldx; p.ldr = ldr; p.ldy = ldy; p.C = Cin; p.Cout = Cout; p.NT = CoutP / 32; p.act = act;
-    p.gn_part = gn_partial;
-    p.n_inner = 1;
-    if (int e = w44_zeros(&p.zeros)) return e;
-    sp.mblocks = (int)(p.g.T / QBM);
-    sp.n_tiles = (Cout + QBN - 1) / QBN;
-    static const int look = getenv("LANEMAP_W44P_LOOK") ? atoi(getenv("LANEMAP_W44P_LOOK")) : 4;
-    sp.look = look < 1 ? 1 : look;
-    sp.Vg = (float*)workspace;
-    sp.flags = (unsigned*)((char*)workspace + (long)sp.mblocks * (Cin / 8) * 36L * 256L * (long)sizeof(float));
-    const size_t lds = (size_t)(2 * QRAWF + QVF) * sizeof(float);
-    static_assert(SRING * 36 * 256 <= 2 * QRAWF + QVF, "the consumer role's ring fits");
-    const long blocks = (long)sp.mblocks * sp.n_tiles;
-    LM_REQUIRE(blocks > 0 && blocks < (1L << 31) && p.g.T % QBM == 0, "conv_wino44p: bad grid %ld", blocks);
-    if (int e = lm_ensure_dynamic_lds((const void*)wino44p_kernel, lds)) return e;
-    LM_HIP(hipMemsetAsync(sp.flags, 0, (size_t)(sp.mblocks * 5 + 8) * sizeof(unsigned), (hipStream_t)stream));
-    hipLaunchKernelGGL(wino44p_kernel, dim3((unsigned)blocks), dim3(256), lds, (hipStream_t)stream, sp);
     LM_LAUNCH_CHECK();
     return LM_OK;
 }

@@ -163,39 +163,17 @@ def _hooked(kind, flops, launch, executed=None):
         launch()
 
 
-# wino44p_kernel (csrc/conv_wino44.hip): the input transform of a 32-tile block is computed once by a transform workgroup and handed to the
-# block's Cout / 64 matrix workgroups through a scratch buffer (bit-identical to wino44_kernel).  LANEMAP_W44_SHARED=0: wino44_kernel
-# everywhere; LANEMAP_W44_SHARED_MIN_TILES: fewest 64-channel N tiles a layer needs to take the shared route.
-W44_SHARED = os.environ.get('LANEMAP_W44_SHARED', '1') != '0'
-W44_SHARED_MIN_TILES = int(os.environ.get('LANEMAP_W44_SHARED_MIN_TILES', '1'))
-_w44_ws = {}
-
-
-def _w44_workspace(need, device):
-    """Scratch of the shared-V kernel, one buffer per (device, stream), grown on demand (launches of a stream are serialised)."""
-    key = (device, _stream().value)
-    ws = _w44_ws.get(key)
-    if ws is None or ws.numel() < need:
-        ws = _w44_ws[key] = torch.empty(need, device=device, dtype=torch.uint8)
-    return ws
-
-
 def wino44_supported(H, W, cin, dil=1):
     return bool(lib().lm_winograd44_supported(int(H), int(W), int(cin), int(dil)))
 
 
-def conv_wino44(x, wf, cout, dil=1, scale=None, shift=None, res=None, act=ACT_NONE, out=None, gn_eps=None, gn_split=1, shared=None):
+def conv_wino44(x, wf, cout, dil=1, scale=None, shift=None, res=None, act=ACT_NONE, out=None, gn_eps=None, gn_split=1):
     """3x3 / stride 1 / pad = dil convolution via Winograd F(4x4,3x3), exact fp32 MFMA, no transformed tensors in HBM
     (csrc/conv_wino44.hip wino44_kernel: 0.5625x the matrix work of the F(2x2) kernels).  wf = pack_wino44_fragments(pack_wino44(w)).
-    Bit-identical to conv_wino44_twin.  shared: None = the default route (wino44p_kernel, the input transform of an M block computed once
-    and shared by its N tiles, unless LANEMAP_W44_SHARED=0), True / False force wino44p_kernel / wino44_kernel (same bits).  With gn_eps
-    returns (y, stats)."""
+    Bit-identical to conv_wino44_twin.  With gn_eps returns (y, stats)."""
     x, ldx = as_nhwc(x)
     B, cin, H, W = x.shape
     cop = wf.shape[2] * 32
-    ws = None
-    if (W44_SHARED and (cout + 63) // 64 >= W44_SHARED_MIN_TILES) if shared is None else shared:      # wino44p_kernel: V of an M block transformed once, shared by its N tiles
-        ws = _w44_workspace(lib().lm_winograd44p_workspace_bytes(B, H, W, cin, dil), x.device)
     y = out if out is not None else new_act(B, cout, H, W, x.device)
     y_, ldy = as_nhwc(y)
     assert y_.data_ptr() == y.data_ptr(), 'conv_wino44: `out` must already be NHWC-stored'
@@ -205,11 +183,8 @@ def conv_wino44(x, wf, cout, dil=1, scale=None, shift=None, res=None, act=ACT_NO
         part = torch.empty((B, lib().lm_winograd44_gn_chunks(H, W, dil), cout, 2), device=x.device, dtype=torch.float64)
     tiles = lib().lm_winograd44_tiles(B, H, W, dil)
     _hooked(f'wino44 {cin}->{cout} k3x3 d{dil} @{H}x{W} B{B}', 2.0 * B * H * W * cout * cin * 9,
-            (lambda: check(lib().lm_conv3x3_winograd44p_f32(_stream(), _ptr(x), ldx, _ptr(wf), cop, _ptr(scale), _ptr(shift), _ptr(r), ldr,
-                                                            _ptr(y), ldy, B, H, W, cin, cout, dil, act, _ptr(part), _ptr(ws), ws.numel())))
-            if ws is not None else
-            (lambda: check(lib().lm_conv3x3_winograd44_f32(_stream(), _ptr(x), ldx, _ptr(wf), cop, _ptr(scale), _ptr(shift), _ptr(r), ldr,
-                                                           _ptr(y), ldy, B, H, W, cin, cout, dil, act, _ptr(part)))),
+            lambda: check(lib().lm_conv3x3_winograd44_f32(_stream(), _ptr(x), ldx, _ptr(wf), cop, _ptr(scale), _ptr(shift), _ptr(r), ldr,
+                                                          _ptr(y), ldy, B, H, W, cin, cout, dil, act, _ptr(part))),
             2.0 * 36 * tiles * cin * cout)
     if gn_eps is None:
         return y

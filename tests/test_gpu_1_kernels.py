@@ -626,10 +626,7 @@ def test_conv_winograd44_bit_identical_to_twin(dev, B, cin, cout, H, W, dil):
     wf = ops.pack_wino44_fragments(wu)
     sd, bd = scale.to(dev), shift.to(dev)
     y0 = ops.conv_wino44_twin(xd, wu, cout, dil, scale=sd, shift=bd, res=rd, act=ops.ACT_RELU)
-    y1 = ops.conv_wino44(xd, wf, cout, dil, scale=sd, shift=bd, res=rd, act=ops.ACT_RELU, shared=False)          # wino44_kernel
-    y1s = ops.conv_wino44(xd, wf, cout, dil, scale=sd, shift=bd, res=rd, act=ops.ACT_RELU, shared=True)         # wino44p_kernel (shared V)
-    assert torch.equal(y1s, y0), float((y1s - y0).abs().max())
-    assert torch.equal(y1s, ops.conv_wino44(xd, wf, cout, dil, scale=sd, shift=bd, res=rd, act=ops.ACT_RELU, shared=True))
+    y1 = ops.conv_wino44(xd, wf, cout, dil, scale=sd, shift=bd, res=rd, act=ops.ACT_RELU)
     want = F.relu(F.conv2d(x.double(), w.double(), None, 1, dil, dil) * scale.double().view(1, -1, 1, 1) + shift.double().view(1, -1, 1, 1)
                   + res.double()).float()
     _close(y0, want, 1e-4, 'winograd F(4x4) twin vs fp64')
@@ -640,21 +637,15 @@ def test_conv_winograd44_bit_identical_to_twin(dev, B, cin, cout, H, W, dil):
     wide = ops.new_act(B, cin + 32, H, W, dev).normal_()
     wide[:, 16:16 + cin].copy_(xd)
     outw = ops.new_act(B, cout + 8, H, W, dev).zero_()
+    ops.conv_wino44(wide[:, 16:16 + cin], wf, cout, dil, shift=bd, out=outw[:, 4:4 + cout])
     y2 = ops.conv_wino44_twin(xd, wu, cout, dil, shift=bd)
-    stats = []
-    for shared in (False, True):
-        outw = ops.new_act(B, cout + 8, H, W, dev).zero_()
-        ops.conv_wino44(wide[:, 16:16 + cin], wf, cout, dil, shift=bd, out=outw[:, 4:4 + cout], shared=shared)
-        assert torch.equal(outw[:, 4:4 + cout], y2) and float(outw[:, :4].abs().max()) == 0 and float(outw[:, 4 + cout:].abs().max()) == 0
-        if cout in (64, 128, 256):                             # (channel counts the standalone statistics kernel takes)
-            y3, st = ops.conv_wino44(xd, wf, cout, dil, shift=bd, gn_eps=1e-5, shared=shared)
-            assert torch.equal(y3, y2)
-            _close(st, ops.gn_stats(y3, 1e-5), 2e-5, 'gn stats from the F(4x4) epilogue')
-            y4, st2 = ops.conv_wino44(xd, wf, cout, dil, shift=bd, gn_eps=1e-5, shared=shared)
-            assert torch.equal(st, st2)
-            stats.append(st)
-    if len(stats) == 2:                                        # the same epilogue in both kernels: same bits
-        assert torch.equal(stats[0], stats[1])
+    assert torch.equal(outw[:, 4:4 + cout], y2) and float(outw[:, :4].abs().max()) == 0 and float(outw[:, 4 + cout:].abs().max()) == 0
+    if cout in (64, 128, 256):                             # (channel counts the standalone statistics kernel takes)
+        y3, st = ops.conv_wino44(xd, wf, cout, dil, shift=bd, gn_eps=1e-5)
+        assert torch.equal(y3, y2)
+        _close(st, ops.gn_stats(y3, 1e-5), 2e-5, 'gn stats from the F(4x4) epilogue')
+        y4, st2 = ops.conv_wino44(xd, wf, cout, dil, shift=bd, gn_eps=1e-5)
+        assert torch.equal(st, st2)
 
 
 def test_conv_winograd44_random_shapes_vs_twin(dev):
@@ -691,15 +682,11 @@ def test_conv_winograd44_random_shapes_vs_twin(dev):
         wu = ops.pack_wino44(w)
         wf = ops.pack_wino44_fragments(wu)
         y0 = ops.conv_wino44_twin(x, wu, cout, dil, scale=sc, shift=sh, res=res, act=act)
-        y1 = ops.conv_wino44(x, wf, cout, dil, scale=sc, shift=sh, res=res, act=act, shared=False)
-        y2 = ops.conv_wino44(x, wf, cout, dil, scale=sc, shift=sh, res=res, act=act, shared=False)
-        y3 = ops.conv_wino44(x, wf, cout, dil, scale=sc, shift=sh, res=res, act=act, shared=True)
-        y4 = ops.conv_wino44(x, wf, cout, dil, scale=sc, shift=sh, res=res, act=act, shared=True)
+        y1 = ops.conv_wino44(x, wf, cout, dil, scale=sc, shift=sh, res=res, act=act)
+        y2 = ops.conv_wino44(x, wf, cout, dil, scale=sc, shift=sh, res=res, act=act)
         tag = f'shape {done}: B{B} {cin}->{cout} {H}x{W} d{dil} scale={use_scale} res={use_res} relu={relu}'
         assert torch.equal(y0, y1), (tag, float((y0 - y1).abs().max()))
         assert torch.equal(y1, y2), tag
-        assert torch.equal(y0, y3), (tag + ' (wino44p_kernel)', float((y0 - y3).abs().max()))
-        assert torch.equal(y3, y4), tag + ' (wino44p_kernel, run to run)'
         if cin % 32 == 0:                       # (and against the direct MFMA kernel where it takes the shape: the twin shares the fused kernel's arithmetic)
             yd = ops.conv_mfma(x, ops.pack_mfma(w), cout, 3, 3, 1, dil, dil, scale=sc, shift=sh, res=res, act=act)
             _close(y1, yd, 1e-4, tag + ' vs direct')

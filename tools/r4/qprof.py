@@ -23,20 +23,11 @@ for cin, cout, hw, dil in [(256, 256, 288, 1), (256, 256, 144, 2), (128, 128, 14
     y = ops.new_act(B, cout, hw, hw, dev)
     ops.conv_wino44(x, wf, cout, dil, res=res, act=ops.ACT_RELU, out=y)
     torch.cuda.synchronize()
-    buf = (C.c_ulonglong * 68)()
+    buf = (C.c_ulonglong * 17)()
     lib.lm_qprof_read(buf, 1)
-    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    e0.record()
     ops.conv_wino44(x, wf, cout, dil, res=res, act=ops.ACT_RELU, out=y)
-    e1.record()
     torch.cuda.synchronize()
-    print(f'launch {e0.elapsed_time(e1) * 1e3:.0f} us', end='; ')
     lib.lm_qprof_read(buf, 1)
     n = max(1, buf[16])
     print(f'{cin}->{cout} d{dil}@{hw} B{B}: {n} workgroup records; cycles per workgroup: ' +
-          ', '.join(f'{NAMES[k]} {buf[k] / n:.0f}' for k in range(15)) + f', start-up before the body {buf[15] / n:.0f}', flush=True)
-    for role, name in ((1, 'producer role'), (2, 'fallback (producer on another XCD)'), (3, 'producer on a stolen ticket')):
-        nr = int(buf[17 * role + 16])
-        if nr:
-            print(f'   {name}: {nr} records; ' + ', '.join(f'{NAMES[k]} {buf[17 * role + k] / nr:.0f}' for k in range(15)) +
-                  f', start-up before the body {buf[17 * role + 15] / nr:.0f}', flush=True)
+          ', '.join(f'{NAMES[k]} {buf[k] / n:.0f}' for k in range(15)), flush=True)

@@ -15,20 +15,15 @@ for cin, cout, hw, dil in [(256, 256, 288, 1), (256, 512, 144, 1), (256, 256, 14
     wf = ops.pack_wino44_fragments(ops.pack_wino44(w))
     res = ops.new_act(B, cout, hw, hw, dev).normal_()
     y = ops.new_act(B, cout, hw, hw, dev)
+    for _ in range(2):
+        ops.conv_wino44(x, wf, cout, dil, res=res, act=ops.ACT_RELU, out=y)
+    torch.cuda.synchronize()
+    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    a.record()
+    for _ in range(10):
+        ops.conv_wino44(x, wf, cout, dil, res=res, act=ops.ACT_RELU, out=y)
+    b.record()
+    torch.cuda.synchronize()
     tiles = ops.lib().lm_winograd44_tiles(B, hw, hw, dil)
-    out = []
-    ys = []
-    for shared in (False, True):
-        for _ in range(2):
-            ops.conv_wino44(x, wf, cout, dil, res=res, act=ops.ACT_RELU, out=y, shared=shared)
-        torch.cuda.synchronize()
-        ys.append(y.clone())
-        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        a.record()
-        for _ in range(10):
-            ops.conv_wino44(x, wf, cout, dil, res=res, act=ops.ACT_RELU, out=y, shared=shared)
-        b.record()
-        torch.cuda.synchronize()
-        ms = a.elapsed_time(b) / 10
-        out.append(f'{"shared-V" if shared else "wino44"} {ms:.3f} ms ({2.0 * 36 * tiles * cin * cout / ms / 1e9 / 157.3:.3f} of peak)')
-    print(f'{cin}->{cout} d{dil}@{hw} B{B}: ' + ', '.join(out) + (' same bits' if torch.equal(ys[0], ys[1]) else ' DIFFERENT BITS'), flush=True)
+    ms = a.elapsed_time(b) / 10
+    print(f'{cin}->{cout} d{dil}@{hw} B{B}: {ms:.3f} ms  ({2.0 * 36 * tiles * cin * cout / ms / 1e9 / 157.3:.3f} of peak)', flush=True)
