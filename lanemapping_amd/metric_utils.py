@@ -8,8 +8,11 @@
       sets hold a few dozen pixels, so an exact all-pairs distance gives the same counts).
   eval_metric_line_segmentor(seg_result, mask, bi_seg, semantics, buff)   <- :415-481
       semantic-line precision / recall / F1 on skeletons: the predicted class map is thinned (Lee-Kashyap-Chu, the algorithm behind
-      skimage's skeletonize(method='lee'); lm_skeletonize_lee_2d, host C++, PARITY UNPINNED because skimage is absent here) and
-      skeleton / ground-truth pixels are matched by nearest-neighbour distance < buff (scipy cKDTree like the reference).
+      skimage's skeletonize(method='lee'); lm_skeletonize_lee_2d, host C++) and skeleton / ground-truth pixels are matched by
+      nearest-neighbour distance < buff (scipy cKDTree like the reference).  SEMANTIC-LINE F1 IS PARITY UNPINNED: skimage and cv2 are not
+      in the build image, so neither the thinning nor the cv2.line raster of the predicted map (hostpost.raster_semantic_map) can be
+      compared with the libraries the reference calls; both restate the published algorithms and are held by known-answer tests
+      (tests/test_metrics_io_cpu.py: published thinning shapes, the OpenCV LineIterator table) and a literal 3-D restatement.
 Same return tuples as the reference.  Host-side: these run once per tile, far from the hot path.
 """
 import ctypes as C
