@@ -326,7 +326,7 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64) void conv_mfma_kernel(C
 
 template <int BM, int BN, int WM, int WN, bool GATHER = false, int TPS = 1>
 int launch(const ConvParams& p, hipStream_t stream) {
-    const size_t kloop = (size_t)2 * (BM + BN) * LDS_LD, stage = (size_t)4 * WM * (WN + 4);   // floats
+    const size_t kloop = (size_t)2 * (BM + BN) * LDS_LD, stage = (size_t)((BM / WM) * (BN / WN)) * WM * (WN + 4);   // floats (one staging tile per wave)
     const size_t lds = (kloop > stage ? kloop : stage) * sizeof(float);
     if (int e = lm_ensure_dynamic_lds((const void*)conv_mfma_kernel<BM, BN, WM, WN, GATHER, TPS>, lds)) return e;
     const long m_tiles = (p.M + BM - 1) / BM;
@@ -390,10 +390,13 @@ static int conv_dispatch(void* stream, const float* x, int ldx, const float* wp,
         return launch<128, 128, 64, 64>(p, s);
     }
     if (Cout <= 64) return launch<128, 64, 32, 64>(p, s);
-    {   // tiny-K layers (the FPN's 1x1 lateral / downsample convolutions, K = KH*KW*Cin <= 256) are epilogue- and HBM-bound: 64x64 tiles
-        // (4x the workgroups, 4 per CU) run them 15-25 % faster than 128x128 (0.599 -> 0.514 ms for 64->256 @288^2, B = 8)
+    {   // tiny-K layers (the FPN's 1x1 lateral / downsample convolutions, K = KH*KW*Cin <= 256) are epilogue- and HBM-bound: small wave
+        // tiles (more waves per output) run them 15-25 % faster than four 64 x 64 wave tiles (0.599 -> 0.514 ms for 64->256 @288^2, B = 8)
         static const long tiny_k = [] { const char* e = getenv("LM_CONV_TINYK"); return e ? atol(e) : 256L; }();
-        if ((long)KH * KW * Cin <= tiny_k) return launch<64, 64, 32, 32>(p, s);
+        // round 5: 128 x 128 tiles of EIGHT waves (32 x 64 sub-tiles, 4 accumulators per wave) beat the 64 x 64 / four-wave tiles of round 4 by
+        // 3-8 % on the laterals (64->256 @288^2 + upsample_add 1.021 -> 0.986 ms, 128->256 @144^2 0.336 -> 0.310, 256->256 @144^2 0.432 ->
+        // 0.396 at B = 16; 64 x 128, 64 x 256 and 128 x 256 tiles measured between); the k order of an output does not depend on the tile
+        if ((long)KH * KW * Cin <= tiny_k) return launch<128, 128, 32, 64>(p, s);
     }
     // small-M GEMMs (ViT tokens): 128x128 tiles would leave most of the 256 CUs idle -> 64x64 tiles, 4x the workgroups
     const long big_blocks = ((p.M + 127) / 128) * ((Cout + 127) / 128);
