@@ -17,7 +17,7 @@ HOST_TESTS = ('test_cpp_polyline_assembly_vs_reference_golden or test_cpp_assemb
               'or test_las_header_parse or test_png_reader_matches_pil or test_png_reader_hand_filtered_rows_and_errors '
               'or test_png_reader_survives_damaged_files or test_native_lane_json_is_json_dump_byte_for_byte '
               'or test_native_seqs_json_is_json_dump_byte_for_byte or test_merge_lines_golden_g13 or test_merge_lines_cpp_vs_oracle_random_roads '
-              'or test_skeleton_cpp_vs_3d_oracle or test_skeleton_properties or test_skeleton_known_answers or test_eval_metric_line_segmentor')
+              'or test_skeleton_cpp_vs_3d_oracle or test_skeleton_properties or test_skeleton_known_answers or test_skeleton_published_shapes or test_line8_opencv_table or test_eval_metric_line_segmentor')
 
 
 def test_host_cpp_clean_under_asan_ubsan():
