@@ -157,3 +157,61 @@ def test_runner_refuses_what_it_cannot_honour(g18_root, tmp_path):
         f.write('{"train": [], "test": [], "valid": [], "single": [], "pretrain": []}')
     with pytest.raises(ValueError, match='no tiles'):
         r._entries(dict(cfg.dataset.test, data_root=root, data_split_file='data_split-empty.json'), None)
+
+
+def test_stage_stats_tool_on_synthetic_traces(tmp_path):
+    """tools/r5/stage_stats.py on a hand-made rocprofv3 output directory (kernel / marker / HIP-API traces in the CSV layout of rocprofv3
+    1.x on the GPU boxes): only kernels that START inside the `timed_steps` range are counted, each is attributed to the innermost roctx
+    range open on the launching thread at its launch call (matched through the correlation id), copies and ATen kernels are tallied."""
+    import subprocess
+    import sys
+    ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    d = tmp_path / 'trace'
+    d.mkdir()
+    (d / 'p_marker_api_trace.csv').write_text(
+        '"Domain","Function","Process_Id","Thread_Id","Correlation_Id","Start_Timestamp","End_Timestamp"\n'
+        '"MARKER_CORE_RANGE_API","pcencoder",1,7,100,500,900\n'             # warm-up batch: before the timed range
+        '"MARKER_CORE_RANGE_API","timed_steps",1,7,101,1000,9000\n'
+        '"MARKER_CORE_RANGE_API","pcencoder",1,7,102,1100,5000\n'
+        '"MARKER_CORE_RANGE_API","fpn.layer1",1,7,103,1200,2000\n'
+        '"MARKER_CORE_RANGE_API","decode",1,7,104,5100,5200\n')
+    (d / 'p_hip_api_trace.csv').write_text(
+        '"Domain","Function","Process_Id","Thread_Id","Correlation_Id","Start_Timestamp","End_Timestamp"\n'
+        '"HIP_RUNTIME_API_EXT","hipLaunchKernel",1,7,1,600,610\n'
+        '"HIP_RUNTIME_API_EXT","hipLaunchKernel",1,7,2,1300,1310\n'
+        '"HIP_RUNTIME_API_EXT","hipLaunchKernel",1,7,3,3000,3010\n'
+        '"HIP_RUNTIME_API_EXT","hipMemcpyAsync",1,7,4,5150,5160\n'
+        '"HIP_RUNTIME_API_EXT","hipLaunchKernel",1,7,5,5150,5160\n')
+    hdr = ('"Kind","Agent_Id","Queue_Id","Stream_Id","Thread_Id","Dispatch_Id","Kernel_Id","Kernel_Name","Correlation_Id","Start_Timestamp",'
+           '"End_Timestamp","LDS_Block_Size","Scratch_Size","VGPR_Count","Accum_VGPR_Count","SGPR_Count","Workgroup_Size_X","Workgroup_Size_Y",'
+           '"Workgroup_Size_Z","Grid_Size_X","Grid_Size_Y","Grid_Size_Z"\n')
+    row = '"KERNEL_DISPATCH","Agent 2",1,0,7,{i},8,"{n}",{c},{s},{e},0,0,8,0,32,256,1,1,256,1,1\n'
+    (d / 'p_kernel_trace.csv').write_text(
+        hdr + row.format(i=1, n='(anonymous namespace)::wino44_kernel((anonymous namespace)::W44Params)', c=1, s=700, e=800)       # warm-up: not counted
+        + row.format(i=2, n='(anonymous namespace)::wino44_kernel((anonymous namespace)::W44Params)', c=2, s=1400, e=2400)
+        + row.format(i=3, n='void (anonymous namespace)::conv_mfma_kernel<64, 64, 32, 32, false, 1>((anonymous namespace)::ConvParams)', c=3, s=3100, e=3400)
+        + row.format(i=4, n='__amd_rocclr_copyBuffer', c=4, s=5170, e=5180)
+        + row.format(i=5, n='(anonymous namespace)::decode_orient_kernel(float const*, int, int, unsigned char*, long)', c=5, s=5190, e=5200))
+    r = subprocess.run([sys.executable, os.path.join(ROOT, 'tools', 'r5', 'stage_stats.py'), str(d), '2'], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, r.stderr
+    out = r.stdout
+    assert '4 kernel dispatches started inside the timed_steps range' in out and '1 dispatches outside it are not counted' in out
+    assert 'copy kernels 0.5 per step, ATen kernels 0.0 per step' in out
+    lines = {l.split()[0]: l for l in out.splitlines() if l and not l.startswith('#')}
+    assert 'wino44_kernel(W44Params)' in lines and ' 0.5/step' in lines['wino44_kernel(W44Params)']       # the warm-up launch is not in it
+    import re
+    stage = {m.group(1).strip(): float(m.group(2)) for m in re.finditer(r'^(.*?)\s+([0-9.]+) launches/step', out.split('## per stage')[1], re.M)}
+    assert stage['fpn.layer1'] == 0.5 and stage['pcencoder'] == 0.5 and stage['decode'] == 0.5      # innermost range wins; launches per step
+    assert stage['(no launch record)'] == 0.5                                                          # the copy has no Launch record
+
+
+def test_trace_ranges_are_free_when_off():
+    """lanemapping_amd.trace: without LANEMAP_ROCTX the stage ranges do not load any library."""
+    import importlib
+    from lanemapping_amd import trace
+    importlib.reload(trace)
+    assert trace.ENABLED == (os.environ.get('LANEMAP_ROCTX', '0') != '0')
+    if not trace.ENABLED:
+        with trace.stage('x'):
+            trace.push('y'); trace.pop(); trace.mark('z')
+        assert trace._lib is None
