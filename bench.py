@@ -197,7 +197,7 @@ def main():
                     help='per-rank host budget: pin this process (rank r) to K of the cores it may use, cores [r*K, (r+1)*K), BEFORE any GPU call - '
                          'the 1-GPU proxy for an 8-rank node where every rank only has usable_cores/8.  K <= 4 switches HIP graphs on (one '
                          'launch per sub-batch instead of ~350) unless --no-graphs')
-    ap.add_argument('--no-graphs', action='store_true', help='never switch HIP graphs on automatically')
+    ap.add_argument('--no-graphs', action='store_true', help='launch kernel by kernel (HIP graphs are the default for the fused / tiles / rowref workloads since round 5)')
     ap.add_argument('--workload', choices=['fused', 'tiles', 'rowref', 'lidar'], default='fused',
                     help="fused = BASELINE configs[2], the headline (on-GPU LAS->BEV raster + config 2, batch 16); tiles = configs[1] "
                          "(pre-rasterised, batch 8); rowref = configs[3] (Proj28_GFC-T3_RowRef head, pre-rasterised, batch 8); lidar = "
@@ -207,7 +207,9 @@ def main():
                          'rowref 4, lidar 1 (its data-dependent launch sizes need host round trips, which serialise sub-batches)')
     ap.add_argument('--conv-detail', action='store_true', help='per-shape table of the MFMA launches on stderr')
     ap.add_argument('--no-stream-check', action='store_true', help='skip the bitwise multi-stream == single-stream check')
-    ap.add_argument('--graphs', action='store_true', help='replay the device part of every sub-batch as one HIP graph (TilePipeline use_graph)')
+    ap.add_argument('--graphs', action='store_true', help='replay the device part of every sub-batch as one HIP graph (TilePipeline use_graph); the default since '
+                    'round 5 for the workloads that can be captured (fused, tiles, rowref): +1.4 %% on the headline in four interleaved 100-step runs, '
+                    'profiles/r5_graphs_ab.txt')
     args = ap.parse_args()
 
     if args.gpus < 1:
@@ -235,6 +237,10 @@ def main():
         torch.set_num_threads(max(1, hb['k']))
         if hb['graphs']:
             args.graphs = True
+    # round 5: graph replay is the default wherever the device part can be captured (the LiDAR path sizes launches on the host): 389.3-390.3
+    # against 382.0-385.3 tiles/s in four interleaved pairs of 100-step runs on one box (profiles/r5_graphs_ab.txt); `--no-graphs` = eager
+    if not args.no_graphs and args.workload in ('fused', 'tiles', 'rowref'):
+        args.graphs = True
     host_cores_per_rank = len(os.sched_getaffinity(0)) if args.host_cores is not None else min(cores_avail, len(os.sched_getaffinity(0)))
     if args.host_threads is None:
         args.host_threads = 8 if args.host_cores is None else max(1, host_cores_per_rank - 1)

@@ -131,7 +131,7 @@ def test_bench_eight_ranks_on_one_gpu(dev):
     if cores // 8 <= 8:              # the ranks split the node's cores: on the pool's 16-core boxes 2 per rank, graphs on
         assert d['config']['host_cores_auto'] is True and d['config']['host_cores_pinned'] is True
         assert d['config']['host_cores_per_rank'] == max(1, cores // 8)
-        assert d['config']['hip_graphs'] is (cores // 8 <= 4)
+        assert d['config']['hip_graphs'] is True                     # (the default of the capturable workloads since round 5)
         allowed = sorted(os.sched_getaffinity(0))
         slices = [bench_mod.host_budget(8, 8, lr, cores, allowed, None, False, 'tiles')['cores'] for lr in range(8)]
         if 8 * (cores // 8) <= len(allowed):
