@@ -10,7 +10,7 @@ mkdir -p $O
 cd /tmp && export TMPDIR=/tmp
 for wl in fused tiles; do
   for c in FETCH_SIZE WRITE_SIZE; do
-    rocprofv3 --pmc $c --output-format csv -d $O/${wl}_$c -o p -- python3 $R/bench.py --workload $wl --steps 2 --warmup 1 --streams 1 --no-cpu-baseline > /dev/null 2>> $R/gpurun_out/prof_stderr.log
+    rocprofv3 --pmc $c --output-format csv -d $O/${wl}_$c -o p -- python3 $R/bench.py --workload $wl --steps 2 --warmup 1 --streams 1 --no-graphs --no-cpu-baseline > /dev/null 2>> $R/gpurun_out/prof_stderr.log
   done
 done
 python3 - <<PY
