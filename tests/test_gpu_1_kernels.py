@@ -727,6 +727,34 @@ def test_raster_fuzz_vs_c_oracle(dev, seed):
         assert np.array_equal(out[b].cpu().numpy(), (want.astype(np.float32) / np.float32(255.0)).transpose(2, 0, 1))
 
 
+def test_pack_segments_vs_torch(dev):
+    """lm_pack_segments (ops.pack_readback: the decode outputs of a batch gathered into one block for ONE device-to-host copy): random
+    segment counts, sizes that are not multiples of 16 bytes, sources that are only 4-byte aligned, dtypes of every width the pipeline packs;
+    the block must hold every segment bit for bit at its 256-byte aligned offset and leave the gaps alone."""
+    from lanemapping_amd import ops
+    rng = np.random.RandomState(77)
+    for trial in range(12):
+        nseg = int(rng.randint(1, 9))
+        ts = []
+        for _ in range(nseg):
+            dt = [torch.float32, torch.float64, torch.int32, torch.float32][int(rng.randint(4))]
+            n = int(rng.choice([1, 3, 4, 5, 17, 72 * 2, 512, 72 * 144, 1000003]))
+            base = torch.randint(-2 ** 31, 2 ** 31 - 1, (n * (2 if dt == torch.float64 else 1) + 3,), dtype=torch.int32, device=dev)
+            off = int(rng.randint(0, 3)) * (2 if dt == torch.float64 else 1)          # 4-byte (8 for f64) aligned, not 16
+            ts.append(base[off:off + n * (2 if dt == torch.float64 else 1)].view(dt))
+        sentinel = torch.full((sum(t.numel() * t.element_size() for t in ts) + 256 * nseg + 64,), 0xA5, dtype=torch.uint8, device=dev)
+        block, segs = ops.pack_readback(ts, block=sentinel)
+        assert block.data_ptr() == sentinel.data_ptr()
+        torch.cuda.synchronize()
+        hb = block.cpu().numpy()
+        covered = np.zeros(hb.size, bool)
+        for t, (o, nb) in zip(ts, segs):
+            assert o % 256 == 0 and nb == t.numel() * t.element_size()
+            assert np.array_equal(hb[o:o + nb], t.contiguous().view(torch.uint8).cpu().numpy()), (trial, o, nb)
+            covered[o:o + nb] = True
+        assert np.all(hb[~covered] == 0xA5)                                          # nothing written outside the segments
+
+
 @pytest.mark.parametrize('n', [0, 1, 63, 4096, 4097, 70001, 5_000_011, 33_554_433])
 def test_exclusive_scan_u32(dev, n):
     """lm_exclusive_scan_u32 (the library's own three-phase scan, csrc/prim.hip) against numpy's cumsum, in place and out of place,
