@@ -739,7 +739,7 @@ def test_pack_segments_vs_torch(dev):
         for _ in range(nseg):
             dt = [torch.float32, torch.float64, torch.int32, torch.float32][int(rng.randint(4))]
             n = int(rng.choice([1, 3, 4, 5, 17, 72 * 2, 512, 72 * 144, 1000003]))
-            base = torch.randint(-2 ** 31, 2 ** 31 - 1, (n * (2 if dt == torch.float64 else 1) + 3,), dtype=torch.int32, device=dev)
+            base = torch.randint(-2 ** 31, 2 ** 31 - 1, (n * (2 if dt == torch.float64 else 1) + 8,), dtype=torch.int32, device=dev)
             off = int(rng.randint(0, 3)) * (2 if dt == torch.float64 else 1)          # 4-byte (8 for f64) aligned, not 16
             ts.append(base[off:off + n * (2 if dt == torch.float64 else 1)].view(dt))
         sentinel = torch.full((sum(t.numel() * t.element_size() for t in ts) + 256 * nseg + 64,), 0xA5, dtype=torch.uint8, device=dev)
