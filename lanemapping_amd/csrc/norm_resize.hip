@@ -381,6 +381,158 @@ __global__ __launch_bounds__(256) void gn_relu_up_lds_kernel(GnTerm T, const flo
     }
 }
 
+// ----------------------------------------------------------------------------- s2 + s3 + s4 with the up-sampled term staged in LDS (round 5)
+// The three-term call of the semantic branches - two same-size terms (s2, s4) and ONE up-sampled term (s3: 144^2 -> 288^2) followed by the
+// branch's 1x1 output layer - ran at 2.9 TB/s in gn_relu_upsample_sum_kernel<3, 5>: per output quad six 16-byte loads, three
+// (mean, rstd) pairs, three GroupNorm affines, the blend and the projection weights from LDS.  Here a workgroup owns UT_R x UT_C output
+// pixels x all channels, a thread keeps ONE channel quad for all its pixels: the affines of the three terms and its 4 x 8 projection
+// weights are made once per thread, the up-sampled term's source block is normalised once per element and staged in LDS (as in
+// gn_relu_up_lds_kernel), and an output quad costs two 16-byte global loads + four ds_read_b128.  Same per-element arithmetic in the
+// same order (lm_gn_relu per tap, lm_bilerp, (t0 + t1) + t2, the fmaf chain and the shuffle tree of the projection): SAME BITS as
+// gn_relu_upsample_sum_kernel<3, 5> (test_gn_sum_three_terms_lds_bit_identical).  C/4 lanes of a pixel sit in one wave (C/4 | 64).
+__global__ __launch_bounds__(256) void gn_sum3_lds_kernel(GnSum P, const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                          float* __restrict__ y, int Ho, int Wo, int C, int SR, int SC, Proj1x1 Q) {
+    extern __shared__ __attribute__((aligned(16))) float ups[];       // [SR * SC][C] normalised + ReLU'd source block of term 1
+    __shared__ int ty0[UT_R], ty1[UT_R], tx0[UT_C], tx1[UT_C];
+    __shared__ float twy0[UT_R], twy1[UT_R], twx0[UT_C], twx1[UT_C];
+    const int tid = threadIdx.x, c4n = C / 4;
+    const int oy0 = blockIdx.y * UT_R, ox0 = blockIdx.x * UT_C, b = blockIdx.z;
+    const int ny = min(UT_R, Ho - oy0), nx = min(UT_C, Wo - ox0);
+    const GnTerm& T0 = P.t[0];
+    const GnTerm& T1 = P.t[1];
+    const GnTerm& T2 = P.t[2];
+    int sy0, sx0, i1;
+    float w0, w1;
+    lm_bilin_axis_scaled(oy0, T1.Hi, T1.sy, sy0, i1, w0, w1);
+    lm_bilin_axis_scaled(ox0, T1.Wi, T1.sx, sx0, i1, w0, w1);
+    if (tid < UT_R) {
+        int a0, a1;
+        lm_bilin_axis_scaled(min(oy0 + tid, Ho - 1), T1.Hi, T1.sy, a0, a1, w0, w1);
+        ty0[tid] = a0 - sy0; ty1[tid] = a1 - sy0; twy0[tid] = w0; twy1[tid] = w1;
+    } else if (tid >= 64 && tid < 64 + UT_C) {
+        const int t = tid - 64;
+        int a0, a1;
+        lm_bilin_axis_scaled(min(ox0 + t, Wo - 1), T1.Wi, T1.sx, a0, a1, w0, w1);
+        tx0[t] = a0 - sx0; tx1[t] = a1 - sx0; twx0[t] = w0; twx1[t] = w1;
+    }
+    const int cq = tid % c4n, pstep = 256 / c4n, p0 = tid / c4n;
+    const int c = cq * 4;
+    // the three affines of this thread's channel quad
+    f32x4 a[3], g[3];
+    {
+        const f32x4 gm = *reinterpret_cast<const f32x4*>(gamma + c), bt = *reinterpret_cast<const f32x4*>(beta + c);
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            const f32x4* st = reinterpret_cast<const f32x4*>(P.t[k].stats + ((long)b * C + c) * 2);      // (mean, rstd) x 4 channels
+            const f32x4 st0 = st[0], st1 = st[1];
+            const float mean[4] = {st0[0], st0[2], st1[0], st1[2]}, rstd[4] = {st0[1], st0[3], st1[1], st1[3]};
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                float ae, ge;
+                lm_gn_affine(mean[e], rstd[e], gm[e], bt[e], ae, ge);
+                a[k][e] = ae;
+                g[k][e] = ge;
+            }
+        }
+    }
+    // projection weights of this thread's four channels, [e][8] (cout padded with zeros, like the LDS copy of the per-output kernel)
+    float pw[4][8];
+#pragma unroll
+    for (int e = 0; e < 4; ++e)
+#pragma unroll
+        for (int n = 0; n < 8; ++n) pw[e][n] = n < Q.cout ? Q.w[(c + e) * 16 + n] : 0.f;
+    // ---- phase 1: source block of the up-sampled term -> LDS
+    const int nsrc = SR * SC;
+    {
+        const float* xb = T1.x + (long)b * T1.Hi * T1.Wi * T1.ld + c;
+        constexpr int UNR = 4;
+        for (int pb = p0; pb < nsrc; pb += pstep * UNR) {
+            f32x4 v[UNR];
+#pragma unroll
+            for (int u = 0; u < UNR; ++u) {
+                const int pp = pb + u * pstep;
+                const int r = pp / SC, q = pp - r * SC;
+                const int yy = min(sy0 + r, T1.Hi - 1), xx = min(sx0 + q, T1.Wi - 1);
+                if (pp < nsrc) v[u] = *reinterpret_cast<const f32x4*>(xb + ((long)yy * T1.Wi + xx) * T1.ld);
+            }
+#pragma unroll
+            for (int u = 0; u < UNR; ++u) {
+                const int pp = pb + u * pstep;
+                if (pp < nsrc) {
+                    f32x4 o;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) o[e] = lm_gn_relu(v[u][e], a[1][e], g[1][e]);
+                    *reinterpret_cast<f32x4*>(ups + (long)pp * C + c) = o;
+                }
+            }
+        }
+    }
+    __syncthreads();
+    // ---- phase 2: outputs, UNR2 pixels of this thread in flight
+    const float* x0b = T0.x + (long)b * T0.Hi * T0.Wi * T0.ld + c;
+    const float* x2b = T2.x + (long)b * T2.Hi * T2.Wi * T2.ld + c;
+    const int lane = tid & 63;
+    const unsigned li = (unsigned)cq;
+    const int nsel = 4 * (int)(li & 1) + 2 * (int)((li >> 1) & 1) + (int)((li >> 2) & 1);
+    const float pbias = (li < 8 && nsel < Q.cout && Q.bias) ? Q.bias[nsel] : 0.f;
+    constexpr int UNR2 = 4;
+    for (int pb = p0; pb < UT_R * UT_C; pb += pstep * UNR2) {
+        f32x4 t0[UNR2], t2[UNR2];
+        bool live[UNR2];
+        int rr[UNR2], qq[UNR2];
+#pragma unroll
+        for (int u = 0; u < UNR2; ++u) {
+            const int pp = pb + u * pstep;
+            rr[u] = pp / UT_C; qq[u] = pp % UT_C;
+            live[u] = rr[u] < ny && qq[u] < nx;
+            const int oy = min(oy0 + rr[u], Ho - 1), ox = min(ox0 + qq[u], Wo - 1);       // (dead pixels load a valid one and store nothing)
+            t0[u] = *reinterpret_cast<const f32x4*>(x0b + ((long)oy * T0.Wi + ox) * T0.ld);
+            t2[u] = *reinterpret_cast<const f32x4*>(x2b + ((long)oy * T2.Wi + ox) * T2.ld);
+        }
+#pragma unroll
+        for (int u = 0; u < UNR2; ++u) {
+            const int r = min(rr[u], UT_R - 1), q = qq[u];
+            const float* s0 = ups + (long)(ty0[r] * SC) * C + c;
+            const float* s1 = ups + (long)(ty1[r] * SC) * C + c;
+            const f32x4 v00 = *reinterpret_cast<const f32x4*>(s0 + tx0[q] * C), v01 = *reinterpret_cast<const f32x4*>(s0 + tx1[q] * C);
+            const f32x4 v10 = *reinterpret_cast<const f32x4*>(s1 + tx0[q] * C), v11 = *reinterpret_cast<const f32x4*>(s1 + tx1[q] * C);
+            const float wy0 = twy0[r], wy1 = twy1[r], wx0 = twx0[q], wx1 = twx1[q];
+            f32x4 acc;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+#pragma clang fp contract(off)
+                const float o0 = lm_gn_relu(t0[u][e], a[0][e], g[0][e]);
+                const float o1 = lm_bilerp(v00[e], v01[e], v10[e], v11[e], wy0, wy1, wx0, wx1);
+                const float o2 = lm_gn_relu(t2[u][e], a[2][e], g[2][e]);
+                acc[e] = (o0 + o1) + o2;
+            }
+            const long opix = ((long)b * Ho + oy0 + rr[u]) * Wo + ox0 + qq[u];
+            if (y && live[u]) *reinterpret_cast<f32x4*>(y + opix * C + c) = acc;
+            // the 1x1 projection: the per-output kernel's fmaf chain and transpose-reduce, lane for lane
+            float part[8];
+#pragma unroll
+            for (int n = 0; n < 8; ++n) part[n] = 0.f;
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+#pragma unroll
+                for (int n = 0; n < 8; ++n) part[n] = fmaf(acc[e], pw[e][n], part[n]);
+#pragma unroll
+            for (int half = 4, mask = 1; half >= 1; half >>= 1, mask <<= 1) {
+                const bool upper = (lane & mask) != 0;
+#pragma unroll
+                for (int jj = 0; jj < half; ++jj) {
+                    float lo = part[jj], hi = part[jj + half];
+                    asm volatile("" : "+v"(lo), "+v"(hi));
+                    const float send = upper ? lo : hi, keep = upper ? hi : lo;
+                    part[jj] = keep + __shfl_xor(send, mask);
+                }
+            }
+            for (unsigned o = 8; o < (unsigned)c4n; o <<= 1) part[0] += __shfl_xor(part[0], (int)o);
+            if (live[u] && li < 8 && nsel < Q.cout) Q.y1[opix * Q.ldy1 + nsel] = part[0] + pbias;
+        }
+    }
+}
+
 // ----------------------------------------------------------------------------- plain bilinear, NHWC -> NHWC slice
 __global__ __launch_bounds__(256) void upsample_nhwc_kernel(const float* __restrict__ x, int ldx, const float* __restrict__ add, int lda,
                                                             float* __restrict__ y, int ldy, int Hi, int Wi, int Ho, int Wo,
@@ -618,6 +770,20 @@ int launch_gn_sum(void* stream, int n, const float* const* x, const float* const
             if (int e = lm_ensure_dynamic_lds((const void*)gn_relu_up_lds_kernel, lds)) return e;
             hipLaunchKernelGGL(gn_relu_up_lds_kernel, dim3((unsigned)lm_cdiv(Wo, UT_C), (unsigned)lm_cdiv(Ho, UT_R), (unsigned)B), dim3(256), lds,
                                (hipStream_t)stream, P.t[0], gamma, beta, y, Ho, Wo, C, SR, SC);
+            LM_LAUNCH_CHECK();
+            return LM_OK;
+        }
+    }
+    if (n == 3 && same == 5 && Q.w && c4n >= 8 && c4n <= 64 && (c4n & (c4n - 1)) == 0 && Hi[1] > 1 && Wi[1] > 1 && Ho >= 2 * Hi[1] - 1 &&
+        Wo >= 2 * Wi[1] - 1) {
+        // s2 + s3 + s4 (+ the branch's 1x1 output layer): the up-sampled middle term through LDS, affines and weights once per thread
+        static const bool lds_sum = [] { const char* e = getenv("LM_GN_SUM_LDS"); return !e || atoi(e) != 0; }();
+        const int SR = up_block_extent(Hi[1], Ho, UT_R), SC = up_block_extent(Wi[1], Wo, UT_C);
+        const size_t lds = (size_t)SR * SC * C * sizeof(float);
+        if (lds_sum && lds <= 64 * 1024) {
+            if (int e = lm_ensure_dynamic_lds((const void*)gn_sum3_lds_kernel, lds)) return e;
+            hipLaunchKernelGGL(gn_sum3_lds_kernel, dim3((unsigned)lm_cdiv(Wo, UT_C), (unsigned)lm_cdiv(Ho, UT_R), (unsigned)B), dim3(256), lds,
+                               (hipStream_t)stream, P, gamma, beta, y, Ho, Wo, C, SR, SC, Q);
             LM_LAUNCH_CHECK();
             return LM_OK;
         }

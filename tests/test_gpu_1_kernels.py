@@ -307,6 +307,52 @@ def test_head_tokens_lds_bit_identical_to_gather(dev, tmp_path):
         assert np.array_equal(a, b), (k, float(np.abs(a - b).max()))
 
 
+_GNSUM_AB = r"""
+import sys, numpy as np, torch
+from lanemapping_amd import ops
+dev = torch.device('cuda:0')
+g = torch.Generator().manual_seed(91)
+out = {}
+# (B, C, Ho, Wo, source size of the up-sampled middle term, leading dimensions of the three terms, cout): the semantic branches' shape
+# (128 channels, 288^2 <- 144^2, s2 / s3 channel slices of the merged 256-wide tensors, feature_layer 8 and output_layer_endp 1),
+# ragged tiles, a scale below 1/2, 64 and 256 channels
+for k, (B, C, Ho, Wo, Hm, Wm, lds, cout) in enumerate([(2, 128, 288, 288, 144, 144, (256, 256, 128), 8), (1, 128, 288, 288, 144, 144, (256, 256, 128), 1),
+                                                        (1, 128, 75, 50, 37, 21, (128, 160, 128), 5), (2, 64, 56, 57, 20, 28, (64, 64, 96), 8),
+                                                        (1, 256, 40, 72, 20, 36, (256, 256, 256), 3), (3, 32, 9, 17, 4, 8, (32, 48, 32), 2)]):
+    terms = []
+    for (h, w), ld in zip(((Ho, Wo), (Hm, Wm), (Ho, Wo)), lds):
+        wide = (torch.randn(B, h, w, ld, generator=g) * 2 + 0.3).to(dev)
+        x = wide[..., ld - C:].permute(0, 3, 1, 2)
+        terms.append((x, ops.gn_stats(x.contiguous(memory_format=torch.channels_last))))
+    gamma, beta = (torch.rand(C, generator=g) + 0.5).to(dev), torch.randn(C, generator=g).to(dev)
+    w16 = ops.pack_small((torch.randn(cout, C, 1, 1, generator=g) / 8).to(dev))
+    bias = torch.randn(cout, generator=g).to(dev)
+    ysum, y1 = ops.gn_relu_upsample_sum(terms, gamma, beta, (Ho, Wo), proj=(w16, bias, cout))
+    only = ops.gn_relu_upsample_sum(terms, gamma, beta, (Ho, Wo), proj=(w16, bias, cout), keep_sum=False)
+    nob = ops.gn_relu_upsample_sum(terms, gamma, beta, (Ho, Wo), proj=(w16, None, cout), keep_sum=False)
+    out[f'sum{k}'], out[f'y1_{k}'], out[f'only{k}'], out[f'nobias{k}'] = ysum.cpu().numpy(), y1.cpu().numpy(), only.cpu().numpy(), nob.cpu().numpy()
+np.savez(sys.argv[1], **out)
+"""
+
+
+def test_gn_sum_three_terms_lds_bit_identical(dev, tmp_path):
+    """gn_sum3_lds_kernel (round 5: s2 + s3 + s4 + the branch's 1x1 output layer with the up-sampled middle term staged in LDS, affines and
+    projection weights once per thread) against gn_relu_upsample_sum_kernel<3, 5> (LM_GN_SUM_LDS=0, read once per process): the same
+    arithmetic in the same order, bit for bit - the sum, the projection with and without bias, with and without writing the sum; the
+    BASELINE shape with channel-slice operands, ragged tiles, 32 / 64 / 128 / 256 channels."""
+    import subprocess
+    import sys
+    res = {}
+    for tag, env in (('lds', {}), ('per_output', {'LM_GN_SUM_LDS': '0'})):
+        path = str(tmp_path / f'{tag}.npz')
+        subprocess.run([sys.executable, '-c', _GNSUM_AB, path], check=True, env={**os.environ, **env, 'PYTHONPATH': ROOT}, cwd=ROOT)
+        res[tag] = np.load(path)
+    for k in res['lds'].files:
+        a, b = res['lds'][k], res['per_output'][k]
+        assert np.isfinite(a).all() and a.shape == b.shape
+        assert np.array_equal(a, b), (k, float(np.abs(a - b).max()))
+
+
 # ----------------------------------------------------------------------------------------------- raster / ingest
 def test_raster_vs_oracle_and_roundtrip(dev):
     from lanemapping_amd import ops
