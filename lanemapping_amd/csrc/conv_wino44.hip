@@ -48,14 +48,16 @@ namespace {
 constexpr int QBM = 32, QBN = 64, QSEG = 4;
 constexpr int QNCELL = 144;                     // cells (one pixel x 16 channels = 64 B) per patch row: 36 tile slots x 4 columns
 constexpr int QLPW = 14;                        // patch loads per wave and unit (1 KB each)
-constexpr int QRAWF = QLPW * 4 * 256;           // floats of one raw buffer (56 KB; cells 864.. are zero-source padding)
+constexpr int QGRP = 256 + 8;                   // floats between the 16-cell groups (one patch-load instruction each) of a raw buffer: 32 pad
+                                                // bytes move consecutive groups by 8 banks - see roff in wino44_kernel
+constexpr int QRAWF = QLPW * 4 * QGRP;          // floats of one raw buffer (57.75 KB; cells 864.. are zero-source padding)
 constexpr int QVF = 36 * 256;                   // floats of the V buffer: 36 planes x [4 channel pairs][32 tiles][2]
 #ifndef LM_QBD
 #define LM_QBD 5
 #define LM_QRING 6
 #endif
 constexpr int QBD = LM_QBD, QRING = LM_QRING;   // B fragments run QBD steps ahead in a ring of QRING register sets
-static_assert(6 * QNCELL * 16 <= QRAWF, "patch loads cover the unit");
+static_assert(6 * (QNCELL / 16) * QGRP <= QRAWF && QNCELL % 16 == 0, "patch loads cover the unit");
 
 __device__ __attribute__((aligned(16))) float g_w44_zeros[1024 + 32];   // zero source for padding cells, any channel unit (Cin <= 1024)
 
@@ -311,7 +313,7 @@ __device__ __forceinline__ void pk_bt(const f32x2 (&d)[6], f32x2 (&t)[6], const 
 // MFMAs of the slot BEFORE the one that multiplies their result (an LDS instruction behind an f32 MFMA is free, a VALU instruction costs
 // ~8 cycles of matrix time wherever it stands: DESIGN 3.3), which removes the phase's latency parts (LDS store drain, barrier, first
 // A-fragment read with nothing to overlap: ~450 of its 1,040 cycles).  V stays SINGLE-buffered (a second 36 KB buffer does not fit
-// beside two 56 KB patch buffers): a plane of V(s+1) may be overwritten once its owner wave has read V(s)'s - so the slot has a
+// beside two 57.75 KB patch buffers): a plane of V(s+1) may be overwritten once its owner wave has read V(s)'s - so the slot has a
 // barrier in the middle, the nine planes of every quadrant are split into EARLY ones (local index k <= 4, read in steps 0..4: their
 // successors are stored in steps 5..7, behind the mid barrier) and LATE ones (k >= 5, read in steps 5..8: their successors stay in
 // their registers over the end of the slot and are stored in steps 0..3 of the next one, visible behind ITS mid barrier).
@@ -327,7 +329,7 @@ struct W44Xf {
 };                                 // and are stored in steps 0..3 of the next one, before steps 5 / 6 compute their successors
 template <int C>
 __device__ __forceinline__ void w44_preread(W44Xf& d, const float* rawrow, const int (&roff)[6]) {
-    constexpr int ROWF = QNCELL * 16;
+    constexpr int ROWF = (QNCELL / 16) * QGRP;
     const float* s = rawrow + roff[C];
 #pragma unroll
     for (int r = 0; r < 5; ++r) d.e[C][r] = *reinterpret_cast<const f32x2*>(s + r * ROWF);
@@ -363,7 +365,11 @@ __device__ __forceinline__ void w44_pass1x2(W44Xf& d, const W44K& k) {
 // the LDS part of step K's transform share.  vA / vB / vC = V + plane offset of the thread's class-A / B / C row + its element offset
 template <int K>
 __device__ __forceinline__ void w44_xf_lds(W44Xf& d, const float* rawrow, const int (&roff)[6], float* vA, float* vB, float* vC) {
+#ifdef LM_QABL_NOVST                         // (PMC ablation: the transform without its V stores - whose LDS bank conflicts are they?)
+    auto st = [](float* v, int j, const f32x2 t) { asm volatile("" :: "v"(v), "v"(t)); };
+#else
     auto st = [](float* v, int j, const f32x2 t) { *reinterpret_cast<f32x2*>(v + j * 256) = t; };
+#endif
     if constexpr (K == 0) {
         st(vB, 2, d.tB[2]); st(vB, 5, d.tB[5]);
         w44_preread<0>(d, rawrow, roff); w44_preread<1>(d, rawrow, roff);
@@ -489,7 +495,7 @@ __device__ __forceinline__ void w44_step(f32x16& acc0, f32x16& acc1, f32x4 (&bq)
 #pragma unroll
     for (int i = 0; i < q_ndma(S); ++i) {
         constexpr int L0 = q_dma0(S);
-        __builtin_amdgcn_global_load_lds((gptr_t*)(gsrc[L0 + i] + goff), (lptr_t*)(rawld + ((L0 + i) * 4 + wave) * 256), 16, 0, 0);
+        __builtin_amdgcn_global_load_lds((gptr_t*)(gsrc[L0 + i] + goff), (lptr_t*)(rawld + ((L0 + i) * 4 + wave) * QGRP), 16, 0, 0);
     }
 #endif
     f32x4 (&b)[2] = bq[S % QRING];
@@ -626,7 +632,7 @@ __global__ __launch_bounds__(256) void wino44_kernel(W44Params p) {
     }
     // patch loads: load s of wave w fills chunks (s * 4 + w) * 64 .. + 63 of the raw buffer; chunk = 16 B = channel quad cq of a cell;
     // cell = patch row r x position pos; position = 16 (slot >> 2) + 4 c + (slot & 3) for column c (0..3) of tile slot `slot`: the cells
-    // one column of consecutive tiles needs are neighbours in LDS (the transform's ds_read_b64 then conflicts two-way at most)
+    // one column of consecutive tiles needs are neighbours in LDS; the 16 cells of a load are contiguous, consecutive loads QGRP floats apart
     const float* gsrc[QLPW];
     const int img_pix0 = bi * g.H * g.W;
 #pragma unroll
@@ -650,11 +656,15 @@ __global__ __launch_bounds__(256) void wino44_kernel(W44Params p) {
         gsrc[s_] = (ok ? p.x : p.zeros) + eoff + cq * 4;
         // unit 0's patch load s goes out as soon as its source is known: issuing a load of cold, scattered lines stalls ~140 cycles
         // (profiles/r4_wino44_residual_issue_experiment.txt) - the address arithmetic of load s + 1 runs meanwhile
-        __builtin_amdgcn_global_load_lds((gptr_t*)gsrc[s_], (lptr_t*)(raw0 + (s_ * 4 + wave) * 256), 16, 0, 0);
+        __builtin_amdgcn_global_load_lds((gptr_t*)gsrc[s_], (lptr_t*)(raw0 + (s_ * 4 + wave) * QGRP), 16, 0, 0);
         __builtin_amdgcn_sched_barrier(0);
     }
-    // transform share: tile = lane & 31, LOWER = wave >> 1 (wave-uniform), channel pair of the 8-channel half skewed by the tile slot so
-    // that the 32 lanes of a ds_read_b64 pass hit 16 different bank pairs
+    // transform share: tile = lane & 31, LOWER = wave >> 1 (wave-uniform).  Bank layout of the raw reads (round 5, measured with
+    // SQ_LDS_BANK_CONFLICT per ablation build, profiles/r5_wino44_lds_conflicts.txt): a ds_read_b64 is served in four groups of 16 lanes on
+    // 32 banks, so the 16 lanes of a group must cover all 16 bank pairs.  A lane's address modulo 32 floats is 16 (slot & 1) [cell parity]
+    // + 8 (group parity: consecutive 16-cell groups are QGRP = 264 floats apart) + 8 half + 2 cp: with the channel pair skewed by slot & 3
+    // the four slot bits map onto the four position bits - any 16 consecutive slots are conflict-free, a run break inside a group costs
+    // one cycle (before: cp skewed by slot >> 2 on 256-float groups, 8 positions for 16 lanes: 4.4-5.3 extra cycles per read)
     int roff[6], tvoff;
     {
         const int tl = lane & 31;
@@ -662,10 +672,17 @@ __global__ __launch_bounds__(256) void wino44_kernel(W44Params p) {
 #pragma unroll
         for (int k = 1; k < QSEG; ++k) sg += (ts[k] < QBM && tl >= ts[k]) ? 1 : 0;
         const int slot = tl + sg, slot1 = slot + 1;
-        const int cp = (2 * (wave & 1) + (lane >> 5) + (slot >> 2)) & 3;
+        const int cp = (2 * (wave & 1) + (lane >> 5) + slot) & 3;
         const int pos0 = 16 * (slot >> 2) + (slot & 3), pos1 = 16 * (slot1 >> 2) + (slot1 & 3);
 #pragma unroll
-        for (int c = 0; c < 6; ++c) roff[c] = ((c < 4 ? pos0 + 4 * c : pos1 + 4 * (c - 4)) * 16) + 2 * cp;
+        for (int c = 0; c < 6; ++c) {
+            const int pos = c < 4 ? pos0 + 4 * c : pos1 + 4 * (c - 4);
+            roff[c] = (pos >> 4) * QGRP + (pos & 15) * 16 + 2 * cp;
+        }
+#ifdef LM_QABL_LINREAD                        // (timing / PMC ablation: conflict-free raw reads by construction - wrong data; the most a better layout can buy)
+#pragma unroll
+        for (int c = 0; c < 6; ++c) roff[c] = c * 64 + tl * 2;
+#endif
         tvoff = cp * 64 + tl * 2;
     }
     const bool lower = (wave >> 1) != 0;
@@ -693,7 +710,7 @@ __global__ __launch_bounds__(256) void wino44_kernel(W44Params p) {
             for (int r = 0; r < 16; ++r) acc[k][b][r] = 0.f;
     f32x4 bq[QRING][2];
     W44Xf xf;
-    const int lowoff = lower ? QNCELL * 16 : 0;               // LOWER threads read patch rows 1..5
+    const int lowoff = lower ? (QNCELL / 16) * QGRP : 0;               // LOWER threads read patch rows 1..5
     LM_QTICK(0)
     // prologue: (raw unit 0 was requested while the sources were computed,) B of steps 0 .. QBD-1, THEN raw unit 1: the wait below leaves unit 1's loads (the youngest) in flight - they
     // are only needed before the second slot, and being older than every load of the loop they do not enter its wait counts
@@ -704,7 +721,7 @@ __global__ __launch_bounds__(256) void wino44_kernel(W44Params p) {
         const long goff1 = nun > 1 ? 16 : 0;
 #pragma unroll
         for (int s_ = 0; s_ < QLPW; ++s_)
-            __builtin_amdgcn_global_load_lds((gptr_t*)(gsrc[s_] + goff1), (lptr_t*)(raw0 + QRAWF + (s_ * 4 + wave) * 256), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((gptr_t*)(gsrc[s_] + goff1), (lptr_t*)(raw0 + QRAWF + (s_ * 4 + wave) * QGRP), 16, 0, 0);
     }
     q_bwait<QLPW>(bq[0]);                      // unit 0 and the first B fragments have landed (this wave's part; the barrier collects all parts)
     __builtin_amdgcn_s_barrier();
