@@ -65,6 +65,7 @@ struct W44Geom {
     int B, H, W, dil, Ty, Tx;   // Ty x Tx tiles of 4 x 4 outputs per (image, phase); dil * dil phases
     int Timg, Tpad;             // real tiles per image, and that count rounded up to 32 (a workgroup never straddles images)
     long T;
+    LmFastDiv dTx, dTy, ddil, dTpad;   // the divisions of wino44_kernel's set-up as multiply-high + shift (every dividend < 2^31)
 };
 
 W44Geom geom44(int B, int H, int W, int dil) {
@@ -75,6 +76,8 @@ W44Geom geom44(int B, int H, int W, int dil) {
     g.Timg = dil * dil * g.Ty * g.Tx;
     g.Tpad = (g.Timg + QBM - 1) / QBM * QBM;
     g.T = (long)B * g.Tpad;
+    g.dTx = lm_fastdiv_make((unsigned)g.Tx); g.dTy = lm_fastdiv_make((unsigned)g.Ty);
+    g.ddil = lm_fastdiv_make((unsigned)dil); g.dTpad = lm_fastdiv_make((unsigned)g.Tpad);
     return g;
 }
 
@@ -233,6 +236,7 @@ struct W44Params {
     const float* x; const float* U; const float* scale; const float* shift; const float* res; float* y; const float* zeros;
     int ldx, ldr, ldy, C, Cout, NT, act;      // NT = CoutP / 32 channel blocks in U
     int n_inner;                               // workgroup order: N tile inner
+    LmFastDiv dnt;                             // / number of N tiles
     double* gn_part;
     W44Geom g;
 };
@@ -435,6 +439,7 @@ __device__ __forceinline__ void q_bwait(f32x4 (&b)[2]) {
 #ifdef LM_QPROF                             // (tools/build_variant.sh probe: per-phase shader-clock cycles of wave 0, one record per workgroup)
 constexpr int QPROF_WG = 16384;
 __device__ unsigned long long g_qprof[QPROF_WG][16];
+__device__ unsigned long long g_qgap[QPROF_WG][3];      // first / last clock of the workgroup and the CU it ran on (lm_qgap_report: idle gaps between workgroups)
 #define LM_QTICK(slot)                                       \
     {                                                        \
         const long long t_now = clock64();                   \
@@ -576,8 +581,8 @@ __global__ __launch_bounds__(256) void wino44_kernel(W44Params p) {
     if (p.n_inner) {      // XCD-contiguous, N tile inner: the N tiles of an M block run side by side on one XCD (input lines shared in its L2)
         const unsigned bid = blockIdx.x, per = gridDim.x / 8;
         const unsigned lin = bid < per * 8 ? (bid % 8) * per + bid / 8 : bid;
-        mblk = lin / (unsigned)n_tiles;
-        ntile = lin % (unsigned)n_tiles;
+        mblk = lm_fastdiv(lin, p.dnt);
+        ntile = lin - mblk * (unsigned)n_tiles;
     } else {              // XCD-aware order, N tile outer (conv_wino.hip): an XCD streams one N tile's U from its L2
         const unsigned bid = blockIdx.x, mb = gridDim.x / (unsigned)n_tiles, mbx = mb / 8, full = mbx * 8 * (unsigned)n_tiles;
         if (bid < full) {
@@ -593,7 +598,7 @@ __global__ __launch_bounds__(256) void wino44_kernel(W44Params p) {
     const long m0 = (long)mblk * QBM;
     const int n0 = (int)ntile * QBN;
     const W44Geom& g = p.g;
-    const int bi = (int)(m0 / g.Tpad);
+    const int bi = (int)lm_fastdiv((unsigned)m0, g.dTpad);
     const int t0 = (int)(m0 - (long)bi * g.Tpad);
     // run table: the 32 tiles are consecutive in the linear (phase, ty, tx) order = up to QSEG runs of horizontally adjacent tiles.
     // Run k holds tiles ts[k] .. ts[k+1]-1 and occupies tile SLOTS ts[k] + k .. ts[k+1] + k (one spill slot for patch columns 4, 5 of
@@ -601,9 +606,9 @@ __global__ __launch_bounds__(256) void wino44_kernel(W44Params p) {
     int ts[QSEG + 1], sn[QSEG], iy0[QSEG], ix0[QSEG], oy0[QSEG], ox0[QSEG];
     {
         int at = 0, t = t0;
-        int tx = t0 % g.Tx, rest = t0 / g.Tx;
-        int ty = rest % g.Ty, ph = rest / g.Ty;
-        int pa = ph / g.dil, pb = ph - pa * g.dil;
+        const int rest = (int)lm_fastdiv((unsigned)t0, g.dTx), ph = (int)lm_fastdiv((unsigned)rest, g.dTy);
+        int tx = t0 - rest * g.Tx, ty = rest - ph * g.Ty;
+        int pa = (int)lm_fastdiv((unsigned)ph, g.ddil), pb = ph - pa * g.dil;
 #pragma unroll
         for (int s_ = 0; s_ < QSEG; ++s_) {
             ts[s_] = at;
@@ -635,25 +640,45 @@ __global__ __launch_bounds__(256) void wino44_kernel(W44Params p) {
     // one column of consecutive tiles needs are neighbours in LDS; the 16 cells of a load are contiguous, consecutive loads QGRP floats apart
     const float* gsrc[QLPW];
     const int img_pix0 = bi * g.H * g.W;
-#pragma unroll
-    for (int s_ = 0; s_ < QLPW; ++s_) {
-        const int cell = (s_ * 4 + wave) * 16 + (lane >> 2);
-        const int cq = lane & 3;
-        const int r = cell / QNCELL;
-        const int pos = cell - r * QNCELL;
-        const int slot = 4 * (pos >> 4) + (pos & 3), cc = (pos >> 2) & 3;
+    // Round 5: the set-up was 7.6 k cycles of address arithmetic per workgroup (tools/r4/qprof.py; 7.0 k with every cell served from the
+    // zero block: not memory) - the run search, nine run-time divisions and four exec-masked regions per load.  Now lane l describes
+    // tile SLOT l once (x / y pixel of its patch cell (0, 0), patch columns it may fetch: 4 (tiles left in its run) + 2, 0 without a run);
+    // a load covers the four slots 4 gq .. 4 gq + 3 of one patch row (q = 4 s + wave = 9 r + gq: wave-uniform) and looks its slot up
+    // with three ds_bpermute_b32; masks instead of selects keep the 64-bit offset out of divergent branches.
+    int tab_x, tab_y, tab_n;
+    {
         int n = sn[0], yb = iy0[0], xb = ix0[0], s0 = 0;
 #pragma unroll
-        for (int k = 1; k < QSEG; ++k)
-            if (slot >= ts[k] + k) {
-                n = sn[k]; yb = iy0[k]; xb = ix0[k]; s0 = ts[k] + k;
-            }
-        const int lc = 4 * (slot - s0) + cc;
-        const int yy = yb + r * g.dil, xx = xb + lc * g.dil;
-        // (bitwise &: the short-circuit form became five divergent branches per load in the set-up)
-        const bool ok = (r < 6) & (n > 0) & (lc < 4 * n + 2) & ((unsigned)yy < (unsigned)g.H) & ((unsigned)xx < (unsigned)g.W);
-        const long eoff = ok ? (long)(img_pix0 + yy * g.W + xx) * p.ldx : 0;
-        gsrc[s_] = (ok ? p.x : p.zeros) + eoff + cq * 4;
+        for (int k = 1; k < QSEG; ++k) {
+            const bool in = lane >= ts[k] + k;
+            n = in ? sn[k] : n;
+            yb = in ? iy0[k] : yb;
+            xb = in ? ix0[k] : xb;
+            s0 = in ? ts[k] + k : s0;
+        }
+        const int j = lane - s0;
+        tab_x = xb + 4 * j * g.dil;
+        tab_y = yb;
+        tab_n = n > 0 ? 4 * (n - j) + 2 : 0;
+    }
+    const int gcc = (lane >> 4) & 3, gccd = gcc * g.dil, gsl4 = ((lane >> 2) & 3) << 2, gcq4 = (lane & 3) * 4;
+#pragma unroll
+    for (int s_ = 0; s_ < QLPW; ++s_) {
+        const int q = s_ * 4 + wave;                      // 16-cell group: patch row r, tile slots 4 gq .. 4 gq + 3
+        const int r = q / (QNCELL / 16), gq = q - r * (QNCELL / 16);
+        const int idx = 16 * gq + gsl4;                   // (byte index of lane 4 gq + slot-in-group)
+        const int x0 = __builtin_amdgcn_ds_bpermute(idx, tab_x), y0 = __builtin_amdgcn_ds_bpermute(idx, tab_y);
+        const int nn = __builtin_amdgcn_ds_bpermute(idx, tab_n);
+        const int yy = y0 + r * g.dil, xx = x0 + gccd;
+        const bool ok = (r < 6) & (gcc < nn) & ((unsigned)yy < (unsigned)g.H) & ((unsigned)xx < (unsigned)g.W);
+#ifdef LM_QABL_ZEROSRC                        // (timing ablation: every patch cell comes from the zero block - what do the scattered input lines cost?)
+        gsrc[s_] = p.zeros + (ok ? 0 : 16) + gcq4;
+#else
+        const long m = -(long)ok;                         // all ones: the cell exists
+        const long eoff = ((long)(img_pix0 + yy * g.W + xx) * p.ldx) & m;
+        const unsigned long base = (unsigned long)p.zeros + (((unsigned long)p.x - (unsigned long)p.zeros) & (unsigned long)m);
+        gsrc[s_] = (const float*)base + eoff + gcq4;
+#endif
         // unit 0's patch load s goes out as soon as its source is known: issuing a load of cold, scattered lines stalls ~140 cycles
         // (profiles/r4_wino44_residual_issue_experiment.txt) - the address arithmetic of load s + 1 runs meanwhile
         __builtin_amdgcn_global_load_lds((gptr_t*)gsrc[s_], (lptr_t*)(raw0 + (s_ * 4 + wave) * QGRP), 16, 0, 0);
@@ -810,8 +835,8 @@ __global__ __launch_bounds__(256) void wino44_kernel(W44Params p) {
         const int ox = oxb + 4 * (etile - tb) * g.dil;
         epix0 = img_pix0 + oy * g.W + ox;
         if (nn > 0 && oy < g.H && ox < g.W) {
-            eny = min(4, (g.H - oy + g.dil - 1) / g.dil);
-            enx = min(4, (g.W - ox + g.dil - 1) / g.dil);
+            eny = min(4, (int)lm_fastdiv((unsigned)(g.H - oy + g.dil - 1), g.ddil));
+            enx = min(4, (int)lm_fastdiv((unsigned)(g.W - ox + g.dil - 1), g.ddil));
         }
     }
     float* const mw = smem + xi00 * 1024 + (4 * (lane >> 5)) * 32 + (lane & 31);      // this wave's planes, this lane's origin
@@ -922,7 +947,12 @@ __global__ __launch_bounds__(256) void wino44_kernel(W44Params p) {
     if (tid == 0) {
 #pragma unroll
         for (int k = 0; k < 15; ++k) g_qprof[blockIdx.x % QPROF_WG][k] = (unsigned long long)qprof[k];
-        g_qprof[blockIdx.x % QPROF_WG][11] = (unsigned long long)(clock64() - t_first);
+        const long long t_end = clock64();
+        g_qprof[blockIdx.x % QPROF_WG][11] = (unsigned long long)(t_end - t_first);
+        g_qgap[blockIdx.x % QPROF_WG][0] = (unsigned long long)t_first;
+        g_qgap[blockIdx.x % QPROF_WG][1] = (unsigned long long)t_end;
+        g_qgap[blockIdx.x % QPROF_WG][2] = ((unsigned long long)__builtin_amdgcn_s_getreg((3 << 11) | (0 << 6) | 20) << 16) |     // XCC_ID
+                                           (__builtin_amdgcn_s_getreg((15 << 11) | (0 << 6) | 4) & 0xff00u);                     // HW_ID: cu, sh, se
     }
 #endif
     if (p.gn_part) {      // fixed-order reduction: the 8 lanes of a wave that share a channel quad, then the four waves through LDS
@@ -1003,6 +1033,40 @@ extern "C" __attribute__((visibility("default"))) int lm_qprof_read(unsigned lon
     }
     return 0;
 }
+// idle time of a CU between two workgroups of the LAST launch (<= QPROF_WG workgroups): out = {workgroups, CUs seen, mean workgroup cycles,
+// mean gap, median gap, 90th percentile gap, cycles from the first start to the last end, sum of workgroup cycles / (CUs x that span)}
+extern "C" __attribute__((visibility("default"))) int lm_qgap_report(double* out) {
+    static unsigned long long host[QPROF_WG][3];
+    if (hipMemcpyFromSymbol(host, HIP_SYMBOL(g_qgap), sizeof(host)) != hipSuccess) return 1;
+    struct Rec { unsigned long long id, t0, t1; };
+    static Rec recs[QPROF_WG];
+    int n = 0;
+    for (int w = 0; w < QPROF_WG; ++w)
+        if (host[w][1]) recs[n++] = Rec{host[w][2], host[w][0], host[w][1]};
+    qsort(recs, n, sizeof(Rec), [](const void* a, const void* b) {
+        const Rec* x = (const Rec*)a; const Rec* y = (const Rec*)b;
+        if (x->id != y->id) return x->id < y->id ? -1 : 1;
+        return x->t0 < y->t0 ? -1 : (x->t0 > y->t0 ? 1 : 0);
+    });
+    static double gaps[QPROF_WG];
+    int ng = 0, ncu = 0;
+    double sumd = 0, sumg = 0;
+    unsigned long long tmin = ~0ull, tmax = 0;
+    for (int i = 0; i < n; ++i) {
+        sumd += (double)(recs[i].t1 - recs[i].t0);
+        if (recs[i].t0 < tmin) tmin = recs[i].t0;
+        if (recs[i].t1 > tmax) tmax = recs[i].t1;
+        if (i == 0 || recs[i].id != recs[i - 1].id) { ++ncu; continue; }
+        gaps[ng] = (double)recs[i].t0 - (double)recs[i - 1].t1;
+        sumg += gaps[ng++];
+    }
+    qsort(gaps, ng, sizeof(double), [](const void* a, const void* b) { return *(const double*)a < *(const double*)b ? -1 : (*(const double*)a > *(const double*)b ? 1 : 0); });
+    out[0] = n; out[1] = ncu; out[2] = n ? sumd / n : 0; out[3] = ng ? sumg / ng : 0; out[4] = ng ? gaps[ng / 2] : 0; out[5] = ng ? gaps[(int)(0.9 * ng)] : 0;
+    out[6] = (double)(tmax - tmin); out[7] = (ncu && tmax > tmin) ? sumd / ((double)ncu * (double)(tmax - tmin)) : 0;
+    static unsigned long long zero[QPROF_WG][3];
+    if (hipMemcpyToSymbol(HIP_SYMBOL(g_qgap), zero, sizeof(zero)) != hipSuccess) return 1;
+    return 0;
+}
 #endif
 
 // 1 if lm_conv3x3_winograd44_f32 covers the shape
@@ -1047,6 +1111,7 @@ LM_API int lm_conv3x3_winograd44_f32(void* stream, const float* x, int ldx, cons
     // 2.08 vs 2.16, 256->256 d2@144^2 1.146 vs 1.162.  LANEMAP_W44_ORDER=0 selects N outer (experiments).
     static const int order = getenv("LANEMAP_W44_ORDER") ? atoi(getenv("LANEMAP_W44_ORDER")) : 1;
     p.n_inner = order;
+    p.dnt = lm_fastdiv_make((unsigned)((Cout + QBN - 1) / QBN));
     const size_t lds = (size_t)(2 * QRAWF + QVF) * sizeof(float);
     static_assert(36 * 32 * 32 <= 2 * QRAWF + QVF, "the product buffer of the epilogue fits");
     const long blocks = (p.g.T / QBM) * ((Cout + QBN - 1) / QBN);

@@ -31,3 +31,9 @@ for cin, cout, hw, dil in [(256, 256, 288, 1), (256, 256, 144, 2), (128, 128, 14
     n = max(1, buf[16])
     print(f'{cin}->{cout} d{dil}@{hw} B{B}: {n} workgroup records; cycles per workgroup: ' +
           ', '.join(f'{NAMES[k]} {buf[k] / n:.0f}' for k in range(15)), flush=True)
+    if hasattr(lib, 'lm_qgap_report'):      # round 5: idle time of a CU between two workgroups of that launch
+        g = (C.c_double * 8)()
+        lib.lm_qgap_report.argtypes = [C.POINTER(C.c_double)]
+        lib.lm_qgap_report(g)
+        print(f'    {g[0]:.0f} workgroups on {g[1]:.0f} CUs: {g[2]:.0f} cycles per workgroup; gap between two workgroups of a CU mean {g[3]:.0f}, median {g[4]:.0f}, '
+              f'p90 {g[5]:.0f} cycles; launch span {g[6]:.0f} cycles, CUs busy {g[7]:.3f} of it', flush=True)
