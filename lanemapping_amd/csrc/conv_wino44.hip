@@ -531,6 +531,13 @@ __device__ __forceinline__ void w44_step(f32x16& acc0, f32x16& acc1, f32x4 (&bq)
 // Tail of one (tile, channel quad) of the fused epilogue, 16-byte path: second pass of the output transform row by row, scale / shift
 // (v * 1 + 0 = v exactly: absent vectors need no second code path), GroupNorm partial sums, residual (prefetched), ReLU as
 // fmaxf(v, 0 or -inf), stores.  FULL = every output of the tile exists (no per-store checks).
+// fmaxf without the canonicalising v_max_f32 v, v, v the compiler puts in front of it when the operand comes out of a select (it quiets
+// signalling NaNs, which no arithmetic result is): one instruction per element instead of two, the same bits for every other input
+__device__ __forceinline__ float w44_vmax(float a, float b) {
+    float r;
+    asm("v_max_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
 template <bool FULL>
 __device__ __forceinline__ void w44_tail_vec(const f32x4 (&z)[4][6], const f32x4 (&rpre)[16], float* yp, int rowstep, int colstep, const f32x4 sc,
                                              const f32x4 sh, float relu_lo, bool has_res, bool gn, f32x4& gsum, f32x4& gsq, int eny, int enx) {
@@ -552,7 +559,7 @@ __device__ __forceinline__ void w44_tail_vec(const f32x4 (&z)[4][6], const f32x4
             }
             if (has_res) v += rpre[yy * 4 + xx];
 #pragma unroll
-            for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], relu_lo);
+            for (int e = 0; e < 4; ++e) v[e] = w44_vmax(v[e], relu_lo);
 #ifdef LM_QABL_NOSTORE                       // (timing ablation: keep the values alive, store one of sixteen)
             if (yy + xx == 0) *reinterpret_cast<f32x4*>(yp + yy * rowstep + xx * colstep) = v;
             else asm volatile("" :: "v"(v));
