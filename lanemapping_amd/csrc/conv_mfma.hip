@@ -400,7 +400,10 @@ static int conv_dispatch(void* stream, const float* x, int ldx, const float* wp,
     }
     // small-M GEMMs (ViT tokens): 128x128 tiles would leave most of the 256 CUs idle -> 64x64 tiles, 4x the workgroups
     const long big_blocks = ((p.M + 127) / 128) * ((Cout + 127) / 128);
-    if (big_blocks < 512) return launch<64, 64, 32, 32>(p, s);
+    // (round 5: < 700 instead of < 512 - M = 5184 x N = 2048, 656 big tiles on 256 CUs = 2.56 rounds, runs 0.418 -> 0.353 ms per three launches on
+    // 64 x 64 tiles (78 -> 92 TFLOP/s); N = 3072 (984 big tiles, 3.84 rounds) is better left on 128 x 128: 0.463 vs 0.476.  LM_CONV_SMALLM overrides)
+    static const long small_m = [] { const char* e = getenv("LM_CONV_SMALLM"); return e ? atol(e) : 700L; }();
+    if (big_blocks < small_m) return launch<64, 64, 32, 32>(p, s);
 #ifdef LM_CONV_8WAVES
     return launch<128, 128, 64, 32>(p, s);
 #else

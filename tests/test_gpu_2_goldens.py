@@ -484,7 +484,7 @@ def test_tile_pipeline_graph_replay_bit_identical(dev):
 
 
 @pytest.mark.parametrize('switch', ['LANEMAP_WINO_F44=0', 'LANEMAP_GRAPHS=1', 'LANEMAP_MERGE_BRANCH_CONVS=0',
-                                    'LANEMAP_W44_ORDER=0 LM_CONV_TINYK=0 LANEMAP_WINO_F44_MIN_CIN=128 LM_RASTER_BAND_ROWS=16 LANEMAP_ROCTX=1',
+                                    'LANEMAP_W44_ORDER=0 LM_CONV_TINYK=0 LM_CONV_SMALLM=100 LANEMAP_WINO_F44_MIN_CIN=128 LM_RASTER_BAND_ROWS=16 LANEMAP_ROCTX=1',
                                     'LM_STEM_VALU=1 LM_GN_UP_LDS=0 LM_GN_SUM_LDS=0 LM_SMALL_CONV_VALU=1 LM_HEAD_TOKENS_GATHER=1 LM_HEAD_STAGE2_DIRECT=1'])
 def test_goldens_under_every_advertised_switch(switch):
     """README's runtime switches are read once per process, so each non-default setting gets its own interpreter: the end-to-end
