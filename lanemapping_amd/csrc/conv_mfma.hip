@@ -243,11 +243,20 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64) void conv_mfma_kernel(C
                 if (p.shift) sh[e] = p.shift[n + e];
             }
         f32x4 gs = {0.f, 0.f, 0.f, 0.f}, gq = {0.f, 0.f, 0.f, 0.f};   // GroupNorm(C,C) statistics of this wave tile
+        // Round 5: the 16-byte stores of a GROUP of passes go out together behind the group's loads and arithmetic.  One store per pass
+        // put an `s_waitcnt vmcnt(0)` at the top of the next pass (loads and stores share vmcnt, and the residual loads of a pass are
+        // pending on some path of the control-flow graph), i.e. every pass waited for the previous pass's store to be acknowledged:
+        // eight serialised memory round trips per wave tile on the 1 x 1 laterals
+        // (only the eight-wave tiles of the tiny-K layers, whose epilogue is the kernel: on the four-wave tiles the grouped stores cost the
+        // K-heavy layers 30 % - 64 -> 128 3 x 3 / stride 2 0.50 -> 0.64 ms, the N = 3072 GEMM 0.46 -> 0.62 - measured)
+        constexpr int NPASS = WM / RPI, GROUP = (BM / WM) * (BN / WN) == 8 ? (NPASS < 8 ? NPASS : 8) : 1;
+        static_assert(NPASS % GROUP == 0, "whole store groups");
+        f32x4 vout[GROUP];
 #pragma unroll
-        for (int pass = 0; pass < WM / RPI; ++pass) {
+        for (int pass = 0; pass < NPASS; ++pass) {
             const int row = pass * RPI + lane / LPR;
             const long m = m0 + wm0 + row;
-            if (m >= p.M) continue;
+            if (m < p.M) {
             f32x4 v = *reinterpret_cast<const f32x4*>(stage + row * ELD + c4);
 #pragma unroll
             for (int e = 0; e < 4; ++e) v[e] = p.scale ? v[e] * sc[e] + sh[e] : v[e] + sh[e];
@@ -290,7 +299,7 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64) void conv_mfma_kernel(C
                     if (p.act == LM_ACT_RELU) v[e] = fmaxf(v[e], 0.f);
                     else if (p.act == LM_ACT_GELU) v[e] = gelu_erf(v[e]);
                 }
-                *reinterpret_cast<f32x4*>(p.y + m * p.ldy + n) = v;
+                vout[pass % GROUP] = v;
             } else {
                 for (int e = 0; e < 4 && n + e < p.Cout; ++e) {
                     float u = v[e];
@@ -298,6 +307,14 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64) void conv_mfma_kernel(C
                     if (p.act == LM_ACT_RELU) u = fmaxf(u, 0.f);
                     else if (p.act == LM_ACT_GELU) u = gelu_erf(u);
                     p.y[m * p.ldy + n + e] = u;
+                }
+            }
+            }
+            if (vec && pass % GROUP == GROUP - 1) {
+#pragma unroll
+                for (int q = 0; q < GROUP; ++q) {
+                    const long ms = m0 + wm0 + (pass - (GROUP - 1) + q) * RPI + lane / LPR;
+                    if (ms < p.M) *reinterpret_cast<f32x4*>(p.y + ms * p.ldy + n) = vout[q];
                 }
             }
         }
