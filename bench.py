@@ -117,8 +117,9 @@ def self_launch(args):
 def gpu_numa_topology():
     """NUMA node of every GPU of this node WITHOUT touching HIP, and the CPUs of every NUMA node (the reference pins nothing:
     baseline/engine/runner.py:89-104 leaves DataParallel's workers wherever the scheduler puts them).  GPUs = the amdgpu DRM cards in PCI
-    bus order - the order ROCr enumerates them in - re-indexed through HIP_VISIBLE_DEVICES / ROCR_VISIBLE_DEVICES when that is a plain index
-    list.  -> {'gpu_node': [node of local GPU 0, 1, ...], 'node_cpus': {node: [cpu, ...]}} or None when sysfs does not say."""
+    bus order - the order ROCr enumerates them in (assumed, not checked: the chosen node and cores are printed in the bench line as
+    host_numa_node / host_cores so a wrong pin is visible) - re-indexed through ROCR_VISIBLE_DEVICES, then HIP_VISIBLE_DEVICES, when those are plain
+    index lists.  -> {'gpu_node': [node of local GPU 0, 1, ...], 'node_cpus': {node: [cpu, ...]}} or None when sysfs does not say."""
     import glob
     try:
         cards = []
@@ -134,10 +135,13 @@ def gpu_numa_topology():
             cards.append((os.path.basename(os.path.realpath(devp)), node))
         cards.sort()
         nodes = [n for _, n in cards]
-        for var in ('HIP_VISIBLE_DEVICES', 'ROCR_VISIBLE_DEVICES'):
+        # the runtime applies ROCR_VISIBLE_DEVICES first (ROCr filters the agents), then HIP_ / CUDA_VISIBLE_DEVICES index into what is left
+        for var in ('ROCR_VISIBLE_DEVICES', 'HIP_VISIBLE_DEVICES' if 'HIP_VISIBLE_DEVICES' in os.environ else 'CUDA_VISIBLE_DEVICES'):
             v = os.environ.get(var)
-            if v and all(t.strip().isdigit() for t in v.split(',')):
-                nodes = [nodes[int(t)] for t in v.split(',') if int(t) < len(nodes)]
+            if v:
+                if not all(t.strip().isdigit() for t in v.split(',')) or any(int(t) >= len(nodes) for t in v.split(',')):
+                    return None          # UUID lists / out-of-range indices: no guess - the caller falls back to a contiguous slice
+                nodes = [nodes[int(t)] for t in v.split(',')]
         if not nodes or any(n < 0 for n in nodes):
             return None
         node_cpus = {}
@@ -205,6 +209,13 @@ def main():
     ap.add_argument('--streams', type=int, default=None,
                     help='split every batch over this many HIP streams (fills launch tails); default per workload: fused 2, tiles 2, '
                          'rowref 4, lidar 1 (its data-dependent launch sizes need host round trips, which serialise sub-batches)')
+    ap.add_argument('--points', choices=['resident', 'host', 'las'], default='resident',
+                    help="fused workload only - where a step's point clouds come from.  resident (default, the contract's `value`): already in HBM.  "
+                         "host: 16 x 4,194,304 x 16 B of [x,y,z,intensity] f32 in PINNED HOST memory, uploaded every step on a copy stream into one of "
+                         "two device buffers while the previous step computes (the reference's read_las -> to_cuda, laserlane_proposals.py:618-636, "
+                         "runner.py:125-152).  las: the pinned host memory holds raw LAS point records (format 0, 20 B per point); they are uploaded "
+                         "the same way and decoded on the GPU (lm_las_decode_points) in front of the raster.  Both report the achieved H2D rate and "
+                         "the fraction of a resident-points window measured in the same run")
     ap.add_argument('--conv-detail', action='store_true', help='per-shape table of the MFMA launches on stderr')
     ap.add_argument('--no-stream-check', action='store_true', help='skip the bitwise multi-stream == single-stream check')
     ap.add_argument('--graphs', action='store_true', help='replay the device part of every sub-batch as one HIP graph (TilePipeline use_graph); the default since '
@@ -283,6 +294,38 @@ def main():
         # the rasteriser hands the tile over as u8 HWC (what a BEV tile IS: the reference's PNG; f32 = u8 / 255 is applied inside the
         # stem kernel, same bits) - a quarter of the bytes of the f32 planar tensor on both sides
         tiles = torch.empty((batch, 1152, 1152, 3), device=dev, dtype=torch.uint8)
+    if args.points != 'resident' and args.workload != 'fused':
+        raise SystemExit('--points host / las feeds the rasteriser: it needs --workload fused')
+    feed = None             # input-inclusive variants: pinned host source, two device buffers, a copy stream
+    if args.points != 'resident':
+        from lanemapping_amd import las_io
+        feed = {'stream': torch.cuda.Stream(device=dev), 'up_done': [None, None], 'read_done': [None, None], 'pairs': [], 'on': True}
+        if args.points == 'host':
+            feed['host'] = torch.cat([clouds[i % 4] for i in range(batch)]).pin_memory()
+            feed['dev'] = [points, torch.empty_like(points)]
+        else:
+            # LAS point-data records, format 0 (ASPRS LAS 1.2: X Y Z int32, intensity u16, 6 more bytes), scale 1 mm, offset 0
+            las_scale, rl = 1e-3, 20
+            recs = [synth.las_point_records(c.numpy(), las_scale) for c in clouds]
+            feed['host'] = torch.from_numpy(np.concatenate([recs[i % 4] for i in range(batch)])).pin_memory()
+            feed['dev'] = [torch.empty(feed['host'].shape, device=dev, dtype=torch.uint8) for _ in range(2)]
+            feed['decode'] = lambda rec_dev: [las_io.decode_points(rec_dev[i * N_PTS * rl:(i + 1) * N_PTS * rl], rl, N_PTS, [las_scale] * 3, [0.0] * 3,
+                                                                    None, False, out=points[i * N_PTS:(i + 1) * N_PTS]) for i in range(batch)]
+        feed['bytes'] = feed['host'].numel() * feed['host'].element_size()
+
+        def upload(slot):
+            """host -> device buffer `slot` on the copy stream, behind the last raster / decode that read that buffer"""
+            with torch.cuda.stream(feed['stream']):
+                if feed['read_done'][slot] is not None:
+                    feed['stream'].wait_event(feed['read_done'][slot])
+                a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                a.record()
+                feed['dev'][slot].copy_(feed['host'], non_blocking=True)
+                b.record()
+                feed['up_done'][slot] = b
+                if feed['on']:
+                    feed['pairs'].append((a, b))
+        feed['upload'] = upload
     pipe = TilePipeline(net, host_threads=args.host_threads, use_graph=args.graphs)
     # whole-batch reference / instrumented passes launch kernel by kernel (the roofline hook brackets every launch with events)
     pipe_eager = pipe if not args.graphs else TilePipeline(net, host_threads=args.host_threads, use_graph=False)
@@ -329,12 +372,33 @@ def main():
             for d in done:
                 if d[par] is not None:
                     main.wait_event(d[par])
+            src = points
+            if feed is not None and feed['on']:
+                # this step's clouds were uploaded while the previous step ran (the first one by the priming call); the NEXT step's go out
+                # now, into the other buffer, behind the previous step's reader of it
+                if feed['up_done'][par] is None:
+                    feed['upload'](par)
+                main.wait_event(feed['up_done'][par])
+                feed['up_done'][par] = None
+                feed['upload'](par ^ 1)
+                src = feed['dev'][par]
+                if args.points == 'las':
+                    with trace.stage('las_decode'):
+                        feed['decode'](src)
+                    src = points
             a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             a.record()
             with trace.stage('raster'):
-                ops.bev_raster_batch(points, offs, rpar, out_u8=cur, u8_only=True)
+                ops.bev_raster_batch(src, offs, rpar, out_u8=cur, u8_only=True)
             b.record()
             ready = b
+            if feed is not None and feed['on']:
+                if args.points == 'las':            # the uploaded records were consumed by the decode; `points` by the raster (same stream)
+                    ev = torch.cuda.Event()
+                    ev.record()
+                    feed['read_done'][par] = ev
+                else:
+                    feed['read_done'][par] = b
             if rast['on']:
                 rast['pairs'].append((a, b))
         if nstream == 1:
@@ -426,6 +490,12 @@ def main():
     # ---- N > 1: what the last all-gather delivered.  Every rank holds the rank-major concatenation: all world x batch slots must be valid
     # tiles, this rank's slice must be the block it sent bit for bit and must unpack to the results of its last batch; the verdict
     # of all ranks is combined so that rank 0's line speaks for the job
+    rank_devices = [dev_index]
+    if world > 1:
+        t = torch.zeros(world, device=dev, dtype=torch.int32)
+        t[rank] = dev_index
+        dist.all_reduce(t)
+        rank_devices = [int(v) for v in t.cpu()]
     gather_check = 'n/a (1 rank)'
     if world > 1 and not inflight:
         gather_check = 'n/a (no batch was gathered: --steps 0)'
@@ -456,7 +526,9 @@ def main():
         lb = tile_bufs[(state['i'] - 1) & 1]
         rp = raster_ref.params(local_min_ele=-0.5, ele_reso=0.02)
         for t_ in (0, batch - 1):
-            want = raster_ref.raster(clouds[t_ % 4].numpy(), rp, 1152, 1152)
+            # (--points las: the raster saw the GPU-decoded records - millimetre-quantised coordinates - so the oracle gets those)
+            src_pts = points[t_ * N_PTS:(t_ + 1) * N_PTS].cpu().numpy() if args.points == 'las' else clouds[t_ % 4].numpy()
+            want = raster_ref.raster(src_pts, rp, 1152, 1152)
             got = lb[t_].cpu().numpy()
             if not np.array_equal(got, want):
                 raise SystemExit(f'raster check FAILED: tile {t_} of the last timed step differs from oracle/raster_ref.c in '
@@ -509,6 +581,34 @@ def main():
             f.result()
         torch.cuda.synchronize()
         prof['on'] = False
+
+    # ---- input-inclusive variants: the upload's own rate, and a resident-points window of the same command right behind it
+    feed_report = None
+    if feed is not None:
+        up_ms = [a.elapsed_time(b) for a, b in feed['pairs']]
+        feed['on'] = False
+        torch.cuda.synchronize()
+        n_res = min(40, max(10, args.steps))
+        for _ in range(3):
+            step()
+        drain()
+        torch.cuda.synchronize()
+        t_r = time.perf_counter()
+        for _ in range(n_res):
+            step()
+        drain()
+        torch.cuda.synchronize()
+        res_rate = batch * n_res / (time.perf_counter() - t_r)
+        my_rate = batch * args.steps / dt
+        feed_report = {'source': {'host': 'pinned host memory, [x,y,z,intensity] f32 (16 B per point)',
+                                  'las': 'pinned host memory, LAS 1.2 point format 0 records (20 B per point), decoded on the GPU by lm_las_decode_points'}[args.points],
+                       'bytes_per_step': feed['bytes'], 'uploads_timed': len(up_ms),
+                       'h2d_ms_per_step': float(np.mean(up_ms)) if up_ms else None,
+                       'h2d_GBps': feed['bytes'] / (float(np.mean(up_ms)) * 1e-3) / 1e9 if up_ms else None,      # while the compute streams run
+                       'h2d_GBps_needed_at_this_rate': feed['bytes'] * my_rate / batch / 1e9,
+                       'double_buffered': True, 'copy_stream': True,
+                       'resident_window': {'steps': n_res, 'tiles_per_s_this_rank': res_rate},
+                       'fraction_of_resident': my_rate / res_rate}
 
     # ---- aggregate per kernel class.  kind strings: 'wino44 ...', 'conv ...', 'gemm ...', 'spconv ...'
     def kclass(kind):
@@ -563,6 +663,12 @@ def main():
                  'point clouds of 4,194,304 points per GPU resident in HBM, seeded random weights',
         'fused': 'on-GPU LAS->BEV raster (4,194,304 points/tile resident in HBM) + configs/Proj_polyline_fpn_vit_vertex_2.py, '
                  'batch=16 per GPU, seeded random weights'}[args.workload]
+    if args.points == 'host':
+        what = 'LAS points in pinned host memory'
+        workload = workload.replace('resident in HBM', 'in PINNED HOST memory, uploaded every step (double-buffered, copy stream)')
+    elif args.points == 'las':
+        what = 'LAS point records in pinned host memory'
+        workload = workload.replace('resident in HBM', 'as LAS format-0 records in PINNED HOST memory, uploaded every step and decoded on the GPU')
     result = {
         'metric': f'BEV tiles/sec end-to-end ({what} -> polylines)',
         'value': world * batch * args.steps / dt,
@@ -572,13 +678,17 @@ def main():
         'config': {'workload': workload,
                    'tiles_per_step_per_gpu': batch, 'lines_per_tile': n_lines, 'host_threads': args.host_threads, 'streams': nstream, 'hip_graphs': bool(args.graphs and args.workload in ('fused', 'tiles', 'rowref')),      # (the LiDAR path sizes launches on the host: no capture)
                   
+                   'points': args.points if args.workload == 'fused' else None, 'point_feed': feed_report,
                    'windows_tiles_per_s': windows,
                    'stream_check': stream_check, 'gather_check': gather_check, 'raster_check': raster_check,
                    'host_cores_per_rank': host_cores_per_rank, 'host_cores_pinned': args.host_cores is not None,
                    'host_cores_auto': host_cores_auto,       # N > 1 without --host-cores: usable cores / ranks on the node
                    'host_numa_node': hb.get('numa_node'),
                    # what the collective library saw: the proof that an N-GPU line really ran N RCCL ranks
-                   'rccl_ranks': dist.get_world_size() if world > 1 else 1, 'dist_backend': dist.get_backend() if world > 1 else None,
+                   # (rccl_ranks counts RCCL ranks only: 0 when the test hook put the ranks on gloo; rank_devices = HIP device index of every rank)
+                   'dist_ranks': world, 'dist_backend': dist.get_backend() if world > 1 else None,
+                   'rccl_ranks': (world if dist.get_backend() == 'nccl' else 0) if world > 1 else 1, 'rank_devices': rank_devices,
+                   'host_cores': sorted(os.sched_getaffinity(0)) if args.host_cores is not None else None,
                    'host_postproc_ms_per_tile': 1e3 * sum(p_.host_seconds for p_ in [pipe] + extra_pipes) /
                    max(1, sum(p_.host_tiles for p_ in [pipe] + extra_pipes))},
         'roofline': {'bound': 'mfma',

@@ -21,6 +21,8 @@
 // (zero padding) fetch from a 16-byte zero block.  The summation order over k is fixed => deterministic results.
 #include "common.h"
 
+#include <cstdlib>
+
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
@@ -354,6 +356,181 @@ int launch(const ConvParams& p, hipStream_t stream) {
     return LM_OK;
 }
 
+// ---- the FPN's 1x1 lateral convolutions (round 6) ---------------------------------------------------------------------------------
+// latlayer1 / latlayer2 (postprojector.py:595-601: 128 -> 256 @144^2 + p4, 64 -> 256 @288^2 + bilinear(p3)) have K = 128 / 64: per output
+// pixel 1 KB is written for 0.25 / 0.5 KB read, and the matrix time (2 K 256 FLOP per pixel at the fp32 MFMA rate) is of the same order
+// as the HBM time.  The tiled kernel above runs them at a quarter of the HBM peak: its phases (weights + pixels global -> LDS, barrier,
+// MFMA, barrier, LDS transposition, barrier, residual + stores) are serial inside a workgroup and two workgroups fit a CU.  Here:
+//   * persistent 512-thread workgroups, one per CU; wave w owns output channels 32 w .. 32 w + 31 for the life of the workgroup and keeps
+//     their weights in registers (the MFMA's A operand, K / 2 floats per lane) - no weight traffic after the first tile;
+//   * the pixels of a 32-pixel tile (the B operand) go global -> LDS once for all eight waves (global_load_lds, one or two 1 KB pieces
+//     per wave, the XOR chunk swizzle of conv_mfma_kernel), double-buffered, ONE barrier per tile; the next tile is requested right behind
+//     the barrier, a tile period ahead of its use;
+//   * with the operands swapped (weights = A) an aligned quad of accumulator registers holds four consecutive channels of one pixel: the
+//     32 x 32 result is transposed through a WAVE-PRIVATE LDS patch with four ds_write_b128 + four ds_read_b128 and no barrier, after
+//     which 8 lanes cover the 128 contiguous bytes of a pixel - residual loads and stores are whole lines;
+//   * the residual (4 pixels x 4 taps per lane for the bilinear one) is requested before the tile's MFMAs; the stores of tile t are
+//     still in flight while tile t + 1 computes (explicit s_waitcnt vmcnt(4): the compiler's own count would drain them at the barrier).
+// Same k order as conv_mfma_kernel (8-channel slabs ascending, step t pairs channel 8 u + t with 8 u + 4 + t), same epilogue expressions
+// (v + shift, + residual through lm_bilerp): bit-identical outputs (test_lateral_kernel_bit_identical); LM_CONV_LATERAL=0 switches it off.
+// Needs B * H * W % 32 == 0 (no partial tiles: every wave issues the same memory instructions, which the explicit wait counts rely on).
+constexpr int LAT_SLD = 36;                       // floats per row of the transposition patch (32 channels + 4 pad: conflict-free both ways)
+template <int KS, bool RESUP>
+__global__ __launch_bounds__(512) void lateral_mfma_kernel(ConvParams p) {
+    constexpr int K = KS * 8, SLABS = K / 32, XBUF = 32 * K;       // floats per pixel buffer: [SLABS][32 rows][32], chunk-swizzled
+    constexpr int NX = XBUF / 4 / 512;                             // 16-byte pieces per thread and tile (1 or 2)
+    static_assert(NX >= 1 && XBUF % (4 * 512) == 0, "whole load passes");
+    extern __shared__ __attribute__((aligned(16))) float smem[];   // X[2][XBUF] | patch[8][32 * LAT_SLD]
+    typedef __attribute__((address_space(1))) const void gptr_t;
+    typedef __attribute__((address_space(3))) void lptr_t;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);     // 32-channel block
+    const int j = lane & 31, half = lane >> 5;
+    float* const patch = smem + 2 * XBUF + wave * (32 * LAT_SLD);
+    f32x4 wf[KS];
+    {
+        const float* wrow = p.wp + (long)(wave * 32 + j) * p.Cin + 4 * half;
+#pragma unroll
+        for (int k = 0; k < KS; ++k) wf[k] = *reinterpret_cast<const f32x4*>(wrow + 8 * k);
+    }
+    // epilogue role of this lane: pixels erow + 8 q (q = 0..3) of the tile, channels n .. n + 3
+    const int erow = lane >> 3, n = wave * 32 + (lane & 7) * 4;
+    const f32x4 sh = p.shift ? *reinterpret_cast<const f32x4*>(p.shift + n) : f32x4{0.f, 0.f, 0.f, 0.f};
+    // tiles: every XCD (workgroups are dealt to the 8 XCDs round-robin) streams one contiguous eighth of the pixels, so that the coarse
+    // rows two neighbouring output rows interpolate from meet in one L2
+    const int ntiles = (int)(p.M >> 5);
+    const int xcd = blockIdx.x & 7, wi = blockIdx.x >> 3, nwg = gridDim.x >> 3;
+    const int per = (ntiles + 7) >> 3, t_end = min(ntiles, (xcd + 1) * per);
+    int tile = xcd * per + wi;
+    if (tile >= t_end) return;                                     // (whole workgroup)
+    // pixel loads: piece c = i * 512 + tid of a tile = slab c / 256, row (c % 256) / 8, LDS slot c % 8 <- source chunk slot ^ ((row >> 1) & 7)
+    int xoff[NX];
+#pragma unroll
+    for (int i = 0; i < NX; ++i) {
+        const int c = i * 512 + tid, slab = c >> 8, row = (c & 255) >> 3, slot = c & 7;
+        xoff[i] = row * p.ldx + slab * 32 + ((slot ^ ((row >> 1) & 7)) << 2);
+    }
+    auto load_x = [&](int t, int buf) {
+        const float* xt = p.x + (long)t * 32 * p.ldx;
+#pragma unroll
+        for (int i = 0; i < NX; ++i)
+            __builtin_amdgcn_global_load_lds((gptr_t*)(xt + xoff[i]), (lptr_t*)(smem + buf * XBUF + (i * 8 + wave) * 256), 16, 0, 0);
+    };
+    load_x(tile, 0);
+    const int fswz = (j >> 1) & 7;
+    // the weights are complete before the loop (their first use is inside it, where the compiler's wait would also drain the pixel
+    // prefetch of every later iteration)
+#pragma unroll
+    for (int k = 0; k < KS; ++k) asm volatile("" : "+v"(wf[k]));
+    for (int it = 0; tile < t_end; tile += nwg, ++it) {
+        const int buf = it & 1;
+        // tile's pixels have landed (everything but the four stores of the previous tile has), and every wave is done with the other buffer
+        asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        load_x(min(tile + nwg, t_end - 1), buf ^ 1);               // (past the end: a harmless re-read, so that the counts stay uniform)
+        // residual of this lane's four pixels, requested before the MFMAs
+        const int m0 = tile * 32 + erow;
+        f32x4 r00[4], r01[4], r10[4], r11[4];
+        float wy0[4], wy1[4], wx0[4], wx1[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const unsigned m = (unsigned)(m0 + 8 * q);
+            if (RESUP) {
+                const unsigned t = lm_fastdiv(m, p.div_wo);
+                const int ox = (int)(m - t * p.div_wo.d);
+                const int bi = (int)lm_fastdiv(t, p.div_ho);
+                const int oy = (int)(t - (unsigned)bi * p.div_ho.d);
+                int y0, y1, x0, x1;
+                lm_bilin_axis_scaled(oy, p.res_hi, p.res_sy, y0, y1, wy0[q], wy1[q]);
+                lm_bilin_axis_scaled(ox, p.res_wi, p.res_sx, x0, x1, wx0[q], wx1[q]);
+                const float* rb = p.res + (long)bi * p.res_hi * p.res_wi * p.ldr + n;
+                r00[q] = *reinterpret_cast<const f32x4*>(rb + ((long)y0 * p.res_wi + x0) * p.ldr);
+                r01[q] = *reinterpret_cast<const f32x4*>(rb + ((long)y0 * p.res_wi + x1) * p.ldr);
+                r10[q] = *reinterpret_cast<const f32x4*>(rb + ((long)y1 * p.res_wi + x0) * p.ldr);
+                r11[q] = *reinterpret_cast<const f32x4*>(rb + ((long)y1 * p.res_wi + x1) * p.ldr);
+            } else {
+                const long rrow = p.res_rows ? (long)(m - lm_fastdiv(m, p.div_rr) * p.div_rr.d) : (long)m;
+                r00[q] = *reinterpret_cast<const f32x4*>(p.res + rrow * p.ldr + n);
+            }
+        }
+        // phases in issue order (the scheduler would otherwise sink the residual loads into the MFMA block and blend their values there
+        // - fewer live registers, but a wait in front of every blend stops the MFMA issue)
+        __builtin_amdgcn_sched_barrier(0);
+        f32x16 acc;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+        const float* xb = smem + buf * XBUF + j * 32;
+        // fragment k + 1 is read behind the first MFMA of fragment k (physical position of logical 16-byte chunk 2 (k % 4) + half of a row)
+        f32x4 xf = *reinterpret_cast<const f32x4*>(xb + ((half ^ fswz) << 2));
+#pragma unroll
+        for (int k = 0; k < KS; ++k) {
+            f32x4 xn = xf;
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(wf[k][0], xf[0], acc, 0, 0, 0);
+            if (k + 1 < KS) {
+                const int fo = (((((k + 1) & 3) << 1) + half) ^ fswz) << 2;
+                __builtin_amdgcn_sched_barrier(0);
+                xn = *reinterpret_cast<const f32x4*>(xb + ((k + 1) >> 2) * 1024 + fo);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+#pragma unroll
+            for (int t = 1; t < 4; ++t) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(wf[k][t], xf[t], acc, 0, 0, 0);
+            xf = xn;
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        // transposition: lane (pixel j, half) holds channels 8 g + 4 half .. + 3 of its pixel in acc[4 g .. 4 g + 3]
+#pragma unroll
+        for (int g = 0; g < 4; ++g)
+            *reinterpret_cast<f32x4*>(patch + j * LAT_SLD + 8 * g + 4 * half) = f32x4{acc[4 * g], acc[4 * g + 1], acc[4 * g + 2], acc[4 * g + 3]};
+        float* yp = p.y + (long)m0 * p.ldy + n;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            f32x4 v = *reinterpret_cast<const f32x4*>(patch + (erow + 8 * q) * LAT_SLD + (lane & 7) * 4);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = v[e] + sh[e];
+            if (RESUP) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] += lm_bilerp(r00[q][e], r01[q][e], r10[q][e], r11[q][e], wy0[q], wy1[q], wx0[q], wx1[q]);
+            } else {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] += r00[q][e];
+            }
+            *reinterpret_cast<f32x4*>(yp + (long)(8 * q) * p.ldy) = v;
+        }
+    }
+}
+
+// 1 = launched (the shape is one of the FPN laterals), 0 = not covered (the caller takes the tiled kernel), < 0 = error code negated
+int lateral_try(const ConvParams& p, hipStream_t stream) {
+    static const int on = [] { const char* e = getenv("LM_CONV_LATERAL"); return e ? atoi(e) : 1; }();
+    if (!on || p.KH != 1 || p.KW != 1 || p.stride != 1 || p.pad_h != 0 || p.pad_w != 0 || p.Cout != 256 || p.CoutP != 256) return 0;
+    if ((p.Cin != 64 && p.Cin != 128) || p.scale || p.act != LM_ACT_NONE || p.gn_part || !p.res) return 0;
+    if ((p.ldx & 3) || (p.ldy & 3) || (p.ldr & 3) || p.ldr < p.Cout || p.M >= (1L << 31) - 64 || (p.M & 31)) return 0;
+    if (p.res_hi > 0 && p.Cin != 64) return 0;
+    if (p.res_hi == 0 && p.Cin != 128) return 0;
+    // persistent workgroups: two per CU would need <= 128 registers per lane; one (8 waves, two per SIMD) holds the weights + a tile in flight
+    static int cus = 0;
+    if (!cus) {
+        int dev = 0;
+        hipDeviceProp_t prop;
+        if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return -LM_ERR_HIP;
+        cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+    }
+    const int ntiles = (int)((p.M + 31) / 32);
+    int grid = (cus + 7) / 8 * 8;
+    if (grid > (ntiles + 7) / 8 * 8) grid = (ntiles + 7) / 8 * 8;
+    const size_t lds = (size_t)(2 * 32 * p.Cin + 8 * 32 * LAT_SLD) * sizeof(float);
+    if (p.res_hi > 0) {
+        if (lm_ensure_dynamic_lds((const void*)lateral_mfma_kernel<8, true>, lds)) return -LM_ERR_HIP;
+        hipLaunchKernelGGL((lateral_mfma_kernel<8, true>), dim3(grid), dim3(512), lds, stream, p);
+    } else {
+        if (lm_ensure_dynamic_lds((const void*)lateral_mfma_kernel<16, false>, lds)) return -LM_ERR_HIP;
+        hipLaunchKernelGGL((lateral_mfma_kernel<16, false>), dim3(grid), dim3(512), lds, stream, p);
+    }
+    if (hipGetLastError() != hipSuccess) return -LM_ERR_HIP;
+    return 1;
+}
+
 int zero_block(const float** out) {   // device address of the 16 zero bytes, resolved once
     static const float* ptr = nullptr;
     if (!ptr) {
@@ -400,6 +577,14 @@ static int conv_dispatch(void* stream, const float* x, int ldx, const float* wp,
     p.res_sx = (res_wi > 0 && p.Wo > 1) ? (float)(res_wi - 1) / (float)(p.Wo - 1) : 0.f;
     if (int e = zero_block(&p.zero)) return e;
     hipStream_t s = (hipStream_t)stream;
+    {   // the FPN laterals (K = 64 / 128, 256 outputs, residual): the streaming kernel
+        const int r = lateral_try(p, s);
+        if (r < 0) {
+            lm_set_error("conv_mfma: lateral kernel launch failed");
+            return -r;
+        }
+        if (r > 0) return LM_OK;
+    }
     if (gn_part) {   // statistics mode: 128x128 tiles of 64-row wave tiles, images must be whole numbers of tiles
         LM_REQUIRE(Cout > 64 && Cout % 4 == 0 && ((long)p.Ho * p.Wo) % 128 == 0 && res == nullptr && act == LM_ACT_NONE,
                    "conv_mfma(gn stats): needs Cout > 64, Ho*Wo %% 128 == 0, no residual / activation");

@@ -1,7 +1,7 @@
 // Winograd F(4x4, 3x3) convolution on the fp32 matrix cores: the 3x3 / stride 1 / pad == dilation layers of the FPN
 // (baseline/models/pcencoder/postprojector.py:322-338 BasicBlock convs, :597-599 smooth*, :615-647 conv2/conv3/semantic_branch*)
 // with 36 instead of 144 multiplies per 4x4 output block and (cin, cout) pair - 2.25 per output against 4 for F(2x2, 3x3)
-// (conv_wino.hip) and 9 for the direct sum: 0.5625x the matrix work of the kernels of conv_wino.hip, still exact fp32 MFMA.
+// (the kernels of rounds 1-3, removed in round 5) and 9 for the direct sum: 0.5625x the matrix work of F(2x2), still exact fp32 MFMA.
 //
 //   Y = A^T [ sum_cin (G g G^T) .* (B^T d B) ] A      interpolation points 0, +-1, +-2, inf (Lavin & Gray)
 //   B^T = [4 0 -5 0 1 0; 0 -4 -4 1 1 0; 0 4 -4 -1 1 0; 0 -2 -1 2 1 0; 0 2 -1 -2 1 0; 0 4 0 -5 0 1]
@@ -424,7 +424,7 @@ __device__ __forceinline__ void w44_xf_all(W44Xf& d, const float* rawrow, const 
     }
 }
 
-// B fragment loads bypass the compiler's wait-count bookkeeping (conv_wino.hip): explicit s_waitcnt vmcnt(N), tied to the destination
+// B fragment loads bypass the compiler's wait-count bookkeeping: explicit s_waitcnt vmcnt(N), tied to the destination
 // registers through "+v" operands.
 __device__ __forceinline__ void q_bload2(f32x4 (&b)[2], unsigned voff, const float* sbase) {
     asm volatile("global_load_dwordx4 %0, %2, %3\n\t"
@@ -590,7 +590,7 @@ __global__ __launch_bounds__(256) void wino44_kernel(W44Params p) {
         const unsigned lin = bid < per * 8 ? (bid % 8) * per + bid / 8 : bid;
         mblk = lm_fastdiv(lin, p.dnt);
         ntile = lin - mblk * (unsigned)n_tiles;
-    } else {              // XCD-aware order, N tile outer (conv_wino.hip): an XCD streams one N tile's U from its L2
+    } else {              // XCD-aware order, N tile outer: an XCD streams one N tile's U from its L2
         const unsigned bid = blockIdx.x, mb = gridDim.x / (unsigned)n_tiles, mbx = mb / 8, full = mbx * 8 * (unsigned)n_tiles;
         if (bid < full) {
             const unsigned xcd = bid % 8, idx = bid / 8;

@@ -28,11 +28,15 @@ def parse_header(data):
             'min': list(h.min_xyz), 'max': list(h.max_xyz)}
 
 
-def decode_points(records_u8, record_len, n, scale, offset, shift=None, normalise=True):
-    """records_u8: DEVICE uint8 tensor holding n records (padded to a multiple of 4 bytes) -> [n,4] float32 on that device."""
+def decode_points(records_u8, record_len, n, scale, offset, shift=None, normalise=True, out=None):
+    """records_u8: DEVICE uint8 tensor holding n records (padded to a multiple of 4 bytes) -> [n,4] float32 on that device
+    (`out`: a contiguous [n,4] float32 tensor to decode into, e.g. a slice of a batch's point buffer)."""
     if not records_u8.is_cuda:
         raise LanemapHipError('las_io.decode_points needs the records on an MI355X (HIP) device; no CPU fallback exists')
-    out = torch.empty((n, 4), device=records_u8.device, dtype=torch.float32)
+    if out is None:
+        out = torch.empty((n, 4), device=records_u8.device, dtype=torch.float32)
+    elif tuple(out.shape) != (n, 4) or out.dtype != torch.float32 or not out.is_contiguous() or out.device != records_u8.device:
+        raise ValueError(f'las_io.decode_points: out must be a contiguous [{n},4] float32 tensor on {records_u8.device}')
     d3 = lambda v: (C.c_double * 3)(*[float(x) for x in v])
     check(lib().lm_las_decode_points(C.c_void_p(torch._C._cuda_getCurrentRawStream(records_u8.device.index)), C.c_void_p(records_u8.data_ptr()),
                                      int(record_len), int(n), d3(scale), d3(offset), d3(shift) if shift is not None else None,

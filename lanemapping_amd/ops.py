@@ -7,7 +7,6 @@ is read from ``x.stride(3)``).  Every function raises if a tensor is not on a HI
 CPU fallback.
 """
 import ctypes as C
-import os
 
 import torch
 
@@ -434,6 +433,7 @@ def pack_readback(tensors, block=None):
     for t in tensors:
         assert t.is_contiguous()
         nb = t.numel() * t.element_size()
+        assert nb % 4 == 0, 'lm_pack_segments copies 4-byte words'
         off = (off + 255) // 256 * 256
         offs.append(off); sizes.append(nb)
         off += nb

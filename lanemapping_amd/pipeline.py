@@ -7,6 +7,7 @@ GPU work of the next batch.  Replaces the per-batch body of Runner.infer_lane_co
 """
 import collections
 import os
+import threading
 import time
 from concurrent.futures import ThreadPoolExecutor
 
@@ -35,6 +36,7 @@ class TilePipeline:
         self._slots, self._slot_next = [], 0           # ring of pinned staging blocks
         self.host_seconds = 0.0      # accumulated wall time of the per-tile host tasks (all threads) and their count
         self.host_tiles = 0
+        self._stats_lock = threading.Lock()
 
     HOST_SLOTS = 3          # pinned staging blocks per pipeline (batch k is being filled while the pool still reads batch k - 1)
 
@@ -45,8 +47,12 @@ class TilePipeline:
             self._slots = [{'block': None, 'futs': []} for _ in range(self.HOST_SLOTS)]
         slot = self._slots[self._slot_next]
         self._slot_next = (self._slot_next + 1) % self.HOST_SLOTS
-        for f in slot['futs']:
-            f.exception()                                 # (waits; the caller sees errors through its own futures)
+        # the ring is safe for a pipeline depth of 1 (HOST_SLOTS >= depth + 2): the batch whose host tasks have not been created yet
+        # (self._pending) must never own the block that is about to be overwritten
+        assert self._pending is None or self._pending[4] is not slot, 'pinned staging ring too short for the pipeline depth'
+        if slot['futs']:
+            from concurrent.futures import wait
+            wait(slot['futs'])                            # (the caller sees errors / cancellations through its own futures)
         slot['futs'] = []
         if slot['block'] is None or slot['block'].numel() < nbytes:
             slot['block'] = torch.empty(max(nbytes, 1), dtype=torch.uint8, pin_memory=True)
@@ -163,8 +169,10 @@ class TilePipeline:
             lanes, kept = hostpost.assemble_polylines(host['prop_conf'][b].numpy(), host['v_ext'][b].numpy(),
                                                       host['cls_offset'][b].numpy(), host['rows'][b].numpy(), pts,
                                                       self.cfg.proposal_obj_thre)
-        self.host_seconds += time.perf_counter() - t0      # (benign race between pool threads: statistics only)
-        self.host_tiles += 1
+        dt = time.perf_counter() - t0
+        with self._stats_lock:                              # pool threads finish tiles concurrently
+            self.host_seconds += dt
+            self.host_tiles += 1
         return (lanes, kept, pts) if self.with_decode_endp else (lanes, kept)
 
     def _finish(self, pending):

@@ -34,12 +34,23 @@ from .registry import build_net
 
 
 def load_config_and_runner(path_config, gpus='0'):
+    """baseline/engine/runner.py:57-66.  `gpus` is the reference's GPUS_EN string (test_gpu_0.py:7-9): one id -> a `Runner` on this
+    process's GPU (cuda:$LOCAL_RANK, default 0; under torchrun every rank calls this with one id); several ids -> a `MultiGpuRunner`
+    (runner_ranks.py) that fans every inference call out over one fresh process per listed GPU - the place of the reference's
+    DataParallel(device_ids=range(cfg.gpus)) (:103-104).  A malformed list raises ValueError, more ids than visible GPUs RuntimeError."""
+    from .runner_ranks import MultiGpuRunner, parse_gpus
+    ids = parse_gpus(gpus)
     cfg = load_config(path_config)
     cfg.log_dir = cfg.log_dir + '/vis'
     os.makedirs(cfg.log_dir, exist_ok=True)
     cfg.work_dirs = cfg.log_dir + '/' + cfg.dataset.train.type
     os.makedirs(cfg.work_dirs, exist_ok=True)
-    cfg.gpus = len(str(gpus).split(','))
+    cfg.gpus = len(ids)
+    if len(ids) > 1:
+        if torch.distributed.is_available() and torch.distributed.is_initialized():
+            raise RuntimeError(f'gpus={gpus!r} inside an initialised torch.distributed job: every rank of a launcher-started job drives ONE '
+                               f'GPU - pass one id per rank (the rank\'s device is cuda:$LOCAL_RANK)')
+        return cfg, MultiGpuRunner(cfg, ids)
     return cfg, Runner(cfg)
 
 
@@ -330,10 +341,15 @@ class Runner:
         ents = self._entries(None, tiles)
         gt_avail = (tiles is None) if gt_avail is None else (bool(gt_avail) and tiles is None)
         B = int(batch_size or self.cfg.get('batch_size', 8))
+        dist = torch.distributed
+        world = dist.get_world_size() if dist.is_initialized() else 1
+        rank = dist.get_rank() if dist.is_initialized() else 0
+        lo, hi, _ = shard.shard_range(len(ents), rank, world)
+        mine = ents[lo:hi]
         res = {}
         c = np.zeros(8, dtype=np.float64)          # semantic TP / dets / DG / gts, geometry TP / pts / DG / gts
-        for i in range(0, len(ents), B):
-            chunk = ents[i:i + B]
+        for i in range(0, len(mine), B):
+            chunk = mine[i:i + B]
             out = self.net({'proj': self._load_batch([p for _, p, _ in chunk])})
             for j, (name, _, ent) in enumerate(chunk):
                 seg = out['seg'][j].numpy()
@@ -342,11 +358,25 @@ class Runner:
                     mask = datasets.load_eval_gt(ent, self.cfg, merge_connect_lines=False)['mask']
                     c[0:4] += metric_utils.eval_metric_line_segmentor(seg, mask, bi_seg=False, semantics=2, buff=self.cfg.validate_buffer)[3:7]
                     c[4:8] += metric_utils.eval_metric_line_segmentor(seg, mask, bi_seg=True, semantics=1, buff=self.cfg.validate_buffer)[3:7]
+        if world > 1:
+            # every rank gets every tile's result (the class maps travel as u8 when that is lossless: 1.3 MB per tile) + one 64-byte
+            # all-reduce of the counters
+            def small(seg):
+                u8 = seg.astype(np.uint8)
+                return u8 if np.array_equal(u8.astype(seg.dtype), seg) else seg
+            parts = [None] * world
+            dist.all_gather_object(parts, {k: (small(v[0]), str(v[0].dtype), v[1]) for k, v in res.items()})
+            res = {k: (seg.astype(dt), pts) for part in parts for k, (seg, dt, pts) in part.items()}
+            res = {name: res[name] for name, _, _ in ents}
+            t = torch.from_numpy(c).to(self.device)
+            dist.all_reduce(t)
+            c = t.cpu().numpy()
         self.counters = c
         if gt_avail:
             geo, sem = _prf(*c[4:8]), _prf(*c[0:4])
             self.metrics = {'coor_conf_prec': geo[0], 'coor_conf_rec': geo[1], 'coor_conf_f1': geo[2],
                             'sem_conf_prec': sem[0], 'sem_conf_rec': sem[1], 'sem_conf_f1': sem[2]}
-            for k, v in self.metrics.items():
-                print(f'{k}={v}')
+            if rank == 0:
+                for k, v in self.metrics.items():
+                    print(f'{k}={v}')
         return res

@@ -189,6 +189,22 @@ def las_points(seed, n=4194304, extent=57.6):
     return np.stack([x, y, z, inten], axis=1).astype(np.float32)
 
 
+def las_point_records(points, scale=1e-3):
+    """[N,4] float32 {x, y, z, raw intensity} -> the N point-data records of an ASPRS LAS 1.2 file, point format 0 (20 bytes: X Y Z as
+    int32 = round(coordinate / scale) with offset 0, intensity u16, return / classification / scan-angle / user-data bytes, point source
+    id u16), as one uint8 array - what a LAS reader hands to lm_las_decode_points."""
+    n = points.shape[0]
+    rec = np.zeros(n, dtype=np.dtype([('X', '<i4'), ('Y', '<i4'), ('Z', '<i4'), ('intensity', '<u2'), ('flags', 'u1'), ('cls', 'u1'),
+                                      ('angle', 'i1'), ('user', 'u1'), ('src', '<u2')]))
+    assert rec.dtype.itemsize == 20
+    for k, name in enumerate(('X', 'Y', 'Z')):
+        rec[name] = np.rint(points[:, k].astype(np.float64) / scale).astype(np.int32)
+    rec['intensity'] = np.clip(points[:, 3], 0, 65535).astype(np.uint16)
+    rec['flags'] = 0x11            # return 1 of 1
+    rec['cls'] = 2                 # ground
+    return rec.view(np.uint8)
+
+
 def apply_gains_(module, gains):
     """Multiply named parameters in place: gains = {state-dict key: factor}.  Used to derive better-conditioned synthetic heads
     from the seeded weights (e.g. a regression layer whose outputs stay inside one bin) - same keys in the reference and here."""

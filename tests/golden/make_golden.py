@@ -344,6 +344,9 @@ G17_KEEP = 4
 G17_RASTER = dict(local_min_ele=-0.5, ele_reso=0.02)                              # bench.py's rasteriser parameters
 
 
+DENSE_KEEP = 4          # tiles per stability-screened golden that also carry prop_cls_conf and bi_seg rows (round 6)
+
+
 def _stable_net():
     """The reference net with the G15 gains, and a spy that keeps a copy of what the decode returned (the post-processing mutates it)."""
     cfg2, net2 = ref_net(seed=2021)
@@ -352,6 +355,7 @@ def _stable_net():
     orig = net2.heads.get_exist_coor_endp_dict
 
     def spy(out):
+        cap['cls2'] = out['cls2'].detach().clone()          # raw column-bin logits [B, proposals, rows, bins] (round 6: their margin is stored)
         d = orig(out)
         cap['dec'] = {k: (v.detach().clone() if torch.is_tensor(v) else v) for k, v in d.items()}
         return d
@@ -368,6 +372,13 @@ def _screen(net2, cap, x, noise_key):
     noise = torch.from_numpy(((synth.uniform(noise_key, x.numel()) > 0.5).astype(np.float32) * 2 - 1).reshape(x.shape))
     o = run(x)
     dec = cap['dec']
+    # MARGIN of the column-bin decisions (round 6): cls_offset = bin + offset jumps by whole bins where the top two cls2 logits are a
+    # near-tie.  The 1e-5 screen only guards cells that end up in a polyline; elsewhere (existence class 2 cells outside every line) a
+    # path that is within 1e-4 of the reference's logits may pick the other bin (golden G17, cloud 3103, proposal 63 row 107: margin
+    # 2.1e-5, taken by the direct-convolution route).  Stored so that the test can hold cls_offset to 1e-4 EXCEPT in cells whose
+    # reference margin is below the tolerance - the rule G10 applies to its class flips.
+    top2 = torch.topk(cap['cls2'][0], 2, dim=-1).values
+    cls_margin = (top2[..., 0] - top2[..., 1]).numpy().astype(np.float32)
     V = o['lane_maps']['cls_offset_smooth'][0]
     E = np.stack(np.nonzero(o['lane_maps']['endp_by_cls'][0]), axis=1)
     for sgn in (1.0, -1.0):
@@ -399,8 +410,12 @@ def _screen(net2, cap, x, noise_key):
     as_arr = lambda st: np.array(sorted(st), dtype=np.int32).reshape(-1, 2)
     info = (f'{nl} lines, {len(E)} endpoints ({len(e_firm)} firm under 1e-4; decode: {len(D)}, {len(d_firm)} firm), lines firm: {lines_firm}, '
             f'max |cls_offset - proposal origin| {float((dec["cls_offset"][0] - (2 * torch.arange(72)[:, None] - 4)).abs().max()):.3f}')
-    return {'V': V, 'E': E.astype(np.int32), 'prop_conf': dec['prop_conf'][0].numpy(), 'prop_v_ext': dec['prop_v_ext'][0].numpy().astype(np.uint8),
-            'cls_offset': dec['cls_offset'][0].numpy(), 'endp': D, 'endp_firm': as_arr(d_firm), 'endp_any': as_arr(d_any),
+    # (round 6) the class confidences and the foreground probability on the rows the assembly reads (8 h + 3), for absolute-1e-4 checks
+    # end to end; bi_seg on every other such row (h even) to bound the fixture's size - the caller keeps them for its first tiles only
+    dense = {'prop_cls_conf': dec['prop_cls_conf'][0].numpy().astype(np.float32),
+             'bi_seg_rows': dec['bi_seg'][0].numpy().astype(np.float32)[3::16].copy()}
+    return {'V': V, 'E': E.astype(np.int32), 'dense': dense, 'prop_conf': dec['prop_conf'][0].numpy(), 'prop_v_ext': dec['prop_v_ext'][0].numpy().astype(np.uint8),
+            'cls_offset': dec['cls_offset'][0].numpy(), 'cls_margin': cls_margin, 'endp': D, 'endp_firm': as_arr(d_firm), 'endp_any': as_arr(d_any),
             'E_firm': as_arr(e_firm), 'E_any': as_arr(e_any), 'lines_firm': np.array(lines_firm)}, info
 
 
@@ -424,6 +439,9 @@ def g15(cfg, net):
             print(f'  tile {ts}: not stable under a 1e-5 input perturbation - skipped')
             continue
         print(f'  tile {ts}: {r[1]}')
+        dense = r[0].pop('dense')
+        if len(kept) < DENSE_KEEP:
+            r[0].update(dense)
         for k, v in r[0].items():
             keep[f'{k}{len(kept)}'] = v
         kept.append(ts)
@@ -453,6 +471,9 @@ def g17(cfg, net):
             print(f'  cloud {cs}: not stable under a 1e-5 input perturbation - skipped')
             continue
         print(f'  cloud {cs}: {r[1]}, {int((u8[:, :, 0] > 0).sum())} occupied pixels')
+        dense = r[0].pop('dense')
+        if len(kept) < DENSE_KEEP:
+            r[0].update(dense)
         for k, v in r[0].items():
             keep[f'{k}{len(kept)}'] = v
         keep[f'tile_crc{len(kept)}'] = np.array(int(np.frombuffer(u8.tobytes(), dtype=np.uint8).astype(np.uint64).sum()))

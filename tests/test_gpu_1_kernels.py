@@ -189,6 +189,49 @@ def test_conv1x1_lateral_residuals(dev, cin, cout, B, h, w, mode):
     _close(y, ref.float(), 2e-5, f'1x1 {cin}->{cout} {mode}')
 
 
+_LATERAL_AB = r"""
+import sys, numpy as np, torch
+from lanemapping_amd import ops
+dev = torch.device('cuda:0')
+g = torch.Generator().manual_seed(606)
+out = {}
+# latlayer2-shaped: 64 -> 256 + bilinear(coarse); latlayer1-shaped: 128 -> 256 + plain residual / + one residual row per pixel (res_rows).
+# Sizes: whole 32-pixel tiles, ragged (B*H*W % 32 != 0, W % 32 != 0), fewer tiles than XCDs, more tiles than resident workgroups
+for k, (B, h, w) in enumerate([(2, 96, 96), (1, 37, 53), (1, 5, 7), (3, 288, 288)]):
+    x = torch.randn(B, 64, h, w, generator=g).to(dev).contiguous(memory_format=torch.channels_last)
+    wt = (torch.randn(256, 64, 1, 1, generator=g) / 8).to(dev)
+    bias = torch.randn(256, generator=g).to(dev)
+    coarse = torch.randn(B, 256, (h + 1) // 2, (w + 1) // 2, generator=g).to(dev).contiguous(memory_format=torch.channels_last)
+    out[f'up_{k}'] = ops.conv_mfma(x, ops.pack_mfma(wt), 256, shift=bias, res_up=coarse).permute(0, 2, 3, 1).cpu().numpy()
+    x = torch.randn(B, 128, h, w, generator=g).to(dev).contiguous(memory_format=torch.channels_last)
+    wt = (torch.randn(256, 128, 1, 1, generator=g) / 11).to(dev)
+    r = torch.randn(B, 256, h, w, generator=g).to(dev).contiguous(memory_format=torch.channels_last)
+    out[f'res_{k}'] = ops.conv_mfma(x, ops.pack_mfma(wt), 256, shift=bias, res=r).permute(0, 2, 3, 1).cpu().numpy()
+    rr = torch.randn(h * w, 256, generator=g).to(dev)
+    out[f'rows_{k}'] = ops.conv_mfma(x, ops.pack_mfma(wt), 256, shift=bias, res=rr, res_rows=h * w).permute(0, 2, 3, 1).cpu().numpy()
+np.savez(sys.argv[1], **out)
+"""
+
+
+def test_lateral_kernel_bit_identical(dev, tmp_path):
+    """lateral_mfma_kernel (round 6: the FPN's 1x1 laterals - weights resident in registers as the MFMA's A operand, pixels as B, no
+    LDS / barrier, residual and stores straight from the accumulator quads, persistent workgroups) against the tiled conv_mfma_kernel
+    (LM_CONV_LATERAL=0, read once per process) on the same inputs, bit for bit: bilinear coarse residual, plain residual, residual rows;
+    ragged sizes, fewer tiles than XCDs, more tiles than workgroups."""
+    import subprocess
+    import sys
+    outs = {}
+    for flag in ('1', '0'):
+        path = tmp_path / f'lateral_{flag}.npz'
+        r = subprocess.run([sys.executable, '-c', _LATERAL_AB, str(path)], capture_output=True, text=True, timeout=900, cwd=ROOT,
+                           env=dict(os.environ, LM_CONV_LATERAL=flag))
+        assert r.returncode == 0, r.stderr[-2000:]
+        outs[flag] = np.load(path)
+    assert len(outs['1'].files) == 12
+    for k in outs['1'].files:
+        assert np.array_equal(outs['1'][k], outs['0'][k]), f'{k}: lateral_mfma_kernel differs from conv_mfma_kernel'
+
+
 _STEM_AB = r"""
 import sys, numpy as np, torch
 from lanemapping_amd import ops
@@ -898,11 +941,13 @@ def test_stage_ops_opcheck_and_functional_weights(dev, net):
                 t.mul_(0.75)
         y2 = torch.ops.lanemap_hip.vit_backbone(fea, w2, nv)
         own = [t.detach().clone() for t in wv]
-        for p_, t in zip(wv, w2):                       # the same weights loaded INTO the module: the reference result
-            p_.copy_(t)                                 # (in place on the parameter itself: bumps its version, the packed cache repacks)
-        want2 = vit(fea)
-        for p_, t in zip(wv, own):
-            p_.copy_(t)
+        try:
+            for p_, t in zip(wv, w2):                   # the same weights loaded INTO the module: the reference result
+                p_.copy_(t)                             # (in place on the parameter itself: bumps its version, the packed cache repacks)
+            want2 = vit(fea)
+        finally:                                        # (`net` is a session fixture shared by every test_gpu_* file)
+            for p_, t in zip(wv, own):
+                p_.copy_(t)
         assert torch.equal(y2, want2) and not torch.equal(y2, y)
         assert torch.equal(torch.ops.lanemap_hip.vit_backbone(fea, wv, nv), y), "the module's own weights are back in place"
         assert all(a is b for a, b in zip(torch_ops.stage_weights(vit), wv))

@@ -255,8 +255,8 @@ def test_multi_stream_pipeline_bitwise_equals_single_stream(dev, net):
 # How many stability-screened tiles may differ from the reference in a SOFT endpoint decision (one the reference itself changes under a
 # 1e-4 perturbation: `margin_ok` below) before the test fails.  Not a silent budget: every run prints the count, and with
 # LANEMAP_PARITY_LOG=<file> appends it to that file (profiles/r5_g15_g17_exact_counts.txt holds the counts of the default route and of
-# LANEMAP_WINO_F44=0 on an MI355X).
-_SOFT_BUDGET = 2
+# LANEMAP_WINO_F44=0 on an MI355X: 9 of 10 / 4 of 4 on both routes, so the budget is ONE tile).
+_SOFT_BUDGET = 1
 
 
 def _log_exact(tag, exact, seeds):
@@ -286,10 +286,26 @@ def _check_stable_golden(g, i, b, c, o, res, name):
     (top-K scores, clustering, sample nearest the centroid) is a near-tie wherever a pixel enters or leaves the top K, so the golden
     records which endpoints the reference keeps under its own 1e-4 perturbations (`*_firm`) and everything any of those runs produced
     (`*_any`): firm endpoints must be there, nothing outside the union may appear.  Returns True when the tile is exact in everything."""
-    err_off = float(np.abs(c['cls_offset'][b].cpu().numpy() - g[f'cls_offset{i}']).max())
+    d_off = np.abs(c['cls_offset'][b].cpu().numpy() - g[f'cls_offset{i}'])
+    # column bins are MARGIN-AWARE like G10's class flips (round 6): cls_offset = bin + offset may differ by whole bins only where the
+    # REFERENCE's own top-two cls2 logits are closer than the tolerance (`cls_margin`, stored by make_golden.py), at most twice per tile;
+    # everywhere else the bound is absolute 1e-4.  (G17 cloud 3103 has one such cell - proposal 63, row 107, margin 2.1e-5, existence
+    # class 2, in no polyline - which the direct-convolution route decides the other way: profiles/r6_g17_direct_route.txt)
+    soft = g[f'cls_margin{i}'] < 1e-4
+    flips = np.argwhere((d_off > 1e-4) & soft)
+    err_off = float(d_off[~((d_off > 1e-4) & soft)].max())
     err_conf = float(np.abs(c['prop_conf'][b].cpu().numpy() - g[f'prop_conf{i}']).max())
-    assert err_off <= 1e-4 and err_conf <= 1e-4, (name, err_off, err_conf)
+    assert err_off <= 1e-4 and err_conf <= 1e-4 and len(flips) <= 2, (name, err_off, err_conf, flips.tolist())
+    if len(flips):
+        print(f'{name}: column bin differs in {len(flips)} cell(s) where the reference margin is < 1e-4: {flips.tolist()}')
     assert np.array_equal(c['prop_v_ext'][b].cpu().numpy().astype(np.uint8), g[f'prop_v_ext{i}']), name
+    if f'prop_cls_conf{i}' in g.files:
+        # absolute 1e-4 end to end on the class confidences (softmax of cls2; cells with a soft bin decision included: the two top
+        # confidences are then equal within the margin) and on the foreground probability of the rows the assembly reads (8 h + 3, h even)
+        err_cc = float(np.abs(c['prop_cls_conf'][b].float().cpu().numpy() - g[f'prop_cls_conf{i}']).max())
+        rows = c['bi_seg_rows'][b].float().cpu().numpy()
+        err_bs = float(np.abs(rows[0::2] - g[f'bi_seg_rows{i}']).max())
+        assert err_cc <= 1e-4 and err_bs <= 1e-4, (name, 'prop_cls_conf', err_cc, 'bi_seg rows', err_bs)
 
     def rows(a):
         return {tuple(int(v) for v in r) for r in np.asarray(a).reshape(-1, 2)}
@@ -315,8 +331,9 @@ def _check_stable_golden(g, i, b, c, o, res, name):
 def test_end_to_end_stable_golden_g15(dev, golden, synth_sd):
     """Golden G15: tiles SCREENED so that the reference's own final polylines are invariant under a 1e-5 input perturbation, with
     an offset-regression layer that keeps vertex columns inside their bin (|offset2| <= 0.1).  The HIP path reproduces the reference
-    end to end: cls_offset / prop_conf within ABSOLUTE 1e-4 (north_star's bound), existence classes and endpoint pixels exactly,
-    and the final cls_offset_smooth - which vertices exist, their semantics, the kept endpoints - exactly, columns within 8e-4 px
+    end to end: cls_offset / prop_conf (and, on the first four tiles, prop_cls_conf / bi_seg rows) within ABSOLUTE 1e-4 (north_star's
+    bound), existence classes exactly, endpoint pixels exactly on all but at most _SOFT_BUDGET tiles (margin-aware, see
+    _check_stable_golden), and the final cls_offset_smooth - which vertices exist, their semantics, the kept endpoints - exactly, columns within 8e-4 px
     (= 1e-4 in column-bin units x 8 px).  Round 4: every stable tile of seeds 2021 .. 2040 (G15_KEEP = 10), run INSIDE a batch of 16
     (the headline's batch size; the other entries are filler tiles)."""
     from lanemapping_amd.pipeline import TilePipeline
@@ -360,7 +377,7 @@ def test_headline_chain_golden_g17(dev, golden, synth_sd):
     res = TilePipeline(net).run_batch(tiles)
     exact = [_check_stable_golden(g, i, i, c, o, res, f'G17 cloud {seeds[i]}') for i in range(len(seeds))]
     _log_exact('G17', exact, seeds)
-    assert sum(exact) >= len(seeds) - 1
+    assert sum(exact) == len(seeds), f'only {sum(exact)} of {len(seeds)} clouds are identical to the reference in every endpoint'
 
 
 @pytest.mark.parametrize('B,picks', [(8, (2, 7)), (16, (5, 13))])
@@ -484,12 +501,12 @@ def test_tile_pipeline_graph_replay_bit_identical(dev):
 
 
 @pytest.mark.parametrize('switch', ['LANEMAP_WINO_F44=0', 'LANEMAP_GRAPHS=1', 'LANEMAP_MERGE_BRANCH_CONVS=0',
-                                    'LANEMAP_W44_ORDER=0 LM_CONV_TINYK=0 LM_CONV_SMALLM=100 LANEMAP_WINO_F44_MIN_CIN=128 LM_RASTER_BAND_ROWS=16 LANEMAP_ROCTX=1',
+                                    'LANEMAP_W44_ORDER=0 LM_CONV_LATERAL=0 LM_CONV_TINYK=0 LM_CONV_SMALLM=100 LANEMAP_WINO_F44_MIN_CIN=128 LM_RASTER_BAND_ROWS=16 LANEMAP_ROCTX=1',
                                     'LM_STEM_VALU=1 LM_GN_UP_LDS=0 LM_GN_SUM_LDS=0 LM_SMALL_CONV_VALU=1 LM_HEAD_TOKENS_GATHER=1 LM_HEAD_STAGE2_DIRECT=1'])
 def test_goldens_under_every_advertised_switch(switch):
     """README's runtime switches are read once per process, so each non-default setting gets its own interpreter: the end-to-end
-    goldens (G10: one full tile against the reference's outputs, margin-aware; G15: two stability-screened tiles whose final
-    polylines must equal the reference's) run under it.  A switch that is not tested here does not exist."""
+    goldens (G10: one full tile against the reference's outputs, margin-aware; G15: the stability-screened tiles whose final
+    polylines must equal the reference's; G17: the headline chain from 4.19 M-point clouds) run under it.  A switch that is not tested here does not exist."""
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -498,6 +515,6 @@ def test_goldens_under_every_advertised_switch(switch):
         k, v = kv.split('=')
         env[k] = v
     r = subprocess.run([sys.executable, '-m', 'pytest', os.path.join(root, 'tests', 'test_gpu_2_goldens.py'), '-x', '-q', '-m', 'gpu', '-k',
-                        'test_end_to_end_golden_g10 or test_end_to_end_stable_golden_g15 or test_tile_pipeline_graph_replay'],
+                        'test_end_to_end_golden_g10 or test_end_to_end_stable_golden_g15 or test_headline_chain_golden_g17 or test_tile_pipeline_graph_replay'],
                        capture_output=True, text=True, timeout=1500, cwd=root, env=env)
     assert r.returncode == 0 and ' passed' in r.stdout, (r.stdout + r.stderr)[-3000:]

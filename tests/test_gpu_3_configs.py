@@ -395,6 +395,68 @@ def test_test_gpu_0_body_runs_unchanged(dev, synth_sd, tmp_path, capsys):
     assert 0. <= runner.metrics['endpoint_f1'] <= 1. and sorted(os.listdir(cfg.work_dirs)) == written
 
 
+def test_test_gpu_0_body_with_two_gpu_ids(dev, synth_sd, tmp_path, capfd, monkeypatch):
+    """GPUS_EN = '0,1' (test_gpu_0.py:7-9; DataParallel(device_ids=range(cfg.gpus)), runner.py:103-104): the same body with two ids.
+    load_config_and_runner returns a MultiGpuRunner whose call starts one FRESH process per id (both on this box's GPU through the
+    LANEMAP_TEST_DEVICE hook, gloo), shards the test split, gathers once and lets rank 0 write: JSON files byte-identical to the
+    one-id run, the same nine printed lines (from rank 0, once), the same counters and the same returned results; then the K-Lane
+    and Segmentor entries through the same fan-out."""
+    from lanemapping_amd.runner import load_config_and_runner
+    from lanemapping_amd.runner_ranks import MultiGpuRunner
+    path_ckpt = str(tmp_path / 'best.pth')
+    torch.save({'net': {'module.' + k: v for k, v in synth_sd.items()}, 'epoch': 45}, path_ckpt)
+    monkeypatch.setenv('LANEMAP_TEST_DEVICE', '0')
+    out, runs = {}, {}
+    for GPUS_EN in ('0', '0,1'):
+        sub = tmp_path / ('ids' + str(len(GPUS_EN.split(','))))
+        sub.mkdir()
+        root, path_config = _harness_root(sub, 'Proj_polyline_fpn_vit_vertex_2', **{'is_gt_avai = False': 'is_gt_avai = True'})
+        cfg, runner = load_config_and_runner(path_config, GPUS_EN)
+        cfg.gpus = len(GPUS_EN.split(','))
+        runner.load_ckpt(path_ckpt)
+        runner.cfg.show_result = True
+        runner.cfg.view_detail = False
+        mode_data = cfg.dataset.test
+        capfd.readouterr()
+        res = runner.infer_lane_coordinate_endpoint_semantics(path_ckpt=path_ckpt, mode_data=mode_data, mode_view=True, gt_avail=cfg.is_gt_avai,
+                                                              write_lane_vertex=True, eval_coor=True, eval_endp=True, eval_semantic=True)
+        out[GPUS_EN] = capfd.readouterr().out
+        runs[GPUS_EN] = (cfg, runner, res)
+    (cfg1, r1, res1), (cfg2, r2, res2) = runs['0'], runs['0,1']
+    assert isinstance(r2, MultiGpuRunner) and not isinstance(r1, MultiGpuRunner) and cfg2.gpus == 2
+    names = sorted(os.listdir(cfg1.work_dirs))
+    assert len(names) == 5 and sorted(os.listdir(cfg2.work_dirs)) == names
+    for n in names:
+        assert open(os.path.join(cfg1.work_dirs, n), 'rb').read() == open(os.path.join(cfg2.work_dirs, n), 'rb').read(), n
+    assert list(res1) == list(res2)
+    for k in res1:
+        assert np.array_equal(res1[k][0], res2[k][0]) and np.array_equal(res1[k][1], res2[k][1]), k
+    assert np.array_equal(r1.counters, r2.counters) and r1.metrics == r2.metrics and r1.counters[3] > 0 and r1.counters[7] > 0
+    lines = [f'{k}={v}' for k, v in r1.metrics.items()]
+    for text in (out['0'], out['0,1']):
+        assert [l for l in text.splitlines() if l.split('=')[0] in r1.metrics] == lines      # nine lines, once (rank 0 only)
+    # a rank that fails (an unknown keyword reaches Runner in the rank processes) ends the call with that rank's message
+    with pytest.raises(RuntimeError, match='GPU ranks failed(.|\n)*no_such_keyword'):
+        r2._launch('infer_lane_coordinate_endpoint_semantics', {'no_such_keyword': 1})
+    # K-Lane (config 4) and Segmentor (config 1) entries, one id vs two
+    for config, entry, n_tiles in (('Proj28_GFC-T3_RowRef_82_73_laser', 'infer_lane_coordinate', 3),
+                                   ('Proj_FPN_Seg', 'infer_lane_geometry_segmentation_segmentor', 3)):
+        got = []
+        for GPUS_EN in ('0', '0,1'):
+            sub = tmp_path / (config[:8] + str(len(GPUS_EN)))
+            sub.mkdir()
+            _, path = _harness_root(sub, config, n_tiles=n_tiles)
+            cfg, runner = load_config_and_runner(path, GPUS_EN)
+            synth.fill_module_(runner.net, 2021)                       # edits of runner.net travel to the ranks
+            kw = dict(gt_avail=True, write_lane_vertex=False) if entry == 'infer_lane_coordinate' else {}
+            got.append((getattr(runner, entry)(path_ckpt=None, mode_view=True, **kw), runner))
+        (ra, a), (rb, b) = got
+        assert list(ra) == list(rb) and len(ra) == n_tiles
+        for k in ra:
+            assert np.array_equal(ra[k][0], rb[k][0]) and ra[k][0].dtype == rb[k][0].dtype and np.array_equal(ra[k][1], rb[k][1]), (config, k)
+        assert np.array_equal(a.counters, b.counters) and a.metrics == b.metrics and a.counters[3] > 0, config
+
+
 def test_klane_and_segmentor_entries(dev, tmp_path, capsys):
     """test_gpu_0.py:66 / :69: `runner.infer_lane_coordinate(path_ckpt=..., mode_view=True, gt_avail=True, write_lane_vertex=False)`
     on the K-Lane RowRef config and `runner.infer_lane_geometry_segmentation_segmentor(path_ckpt=..., mode_view=True)` on the

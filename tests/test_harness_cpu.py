@@ -132,9 +132,13 @@ def test_load_config_and_runner_sets_the_reference_directories(tmp_path, monkeyp
     src = open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'configs', 'Proj_polyline_fpn_vit_vertex_2.py')).read()
     p = tmp_path / 'configs_Proj_polyline_fpn_vit_vertex_2.py'
     p.write_text(src.replace("log_dir = './logs'", f"log_dir = {str(tmp_path / 'logs')!r}"))
-    cfg, runner = R.load_config_and_runner(str(p), '0,1')
-    assert cfg.log_dir == str(tmp_path / 'logs') + '/vis' and cfg.work_dirs == cfg.log_dir + '/LaserLaneProposal' and cfg.gpus == 2
+    cfg, runner = R.load_config_and_runner(str(p), '0')
+    assert cfg.log_dir == str(tmp_path / 'logs') + '/vis' and cfg.work_dirs == cfg.log_dir + '/LaserLaneProposal' and cfg.gpus == 1
     assert os.path.isdir(cfg.work_dirs) and runner == ('runner', cfg)
+    # several ids: the same directories, cfg.gpus = their number, and a MultiGpuRunner (one fresh process per id; both on device 0 under the test hook)
+    monkeypatch.setenv('LANEMAP_TEST_DEVICE', '0')
+    cfg, runner = R.load_config_and_runner(str(p), '0,1,2')
+    assert cfg.work_dirs == str(tmp_path / 'logs') + '/vis/LaserLaneProposal' and cfg.gpus == 3 and runner.gpu_ids == [0, 1, 2]
 
 
 def test_runner_refuses_what_it_cannot_honour(g18_root, tmp_path):
@@ -215,3 +219,71 @@ def test_trace_ranges_are_free_when_off():
         with trace.stage('x'):
             trace.push('y'); trace.pop(); trace.mark('z')
         assert trace._lib is None
+
+
+# ------------------------------------------------------------------------------------------------ GPUS_EN = '0,1,...' (runner_ranks.py)
+def _config_copy(tmp_path, name='Proj_polyline_fpn_vit_vertex_2'):
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    src = open(os.path.join(root, 'configs', name + '.py')).read().replace("log_dir = './logs'", f"log_dir = {str(tmp_path / 'logs')!r}")
+    path = tmp_path / ('configs_' + name + '.py')
+    path.write_text(src)
+    return str(path)
+
+
+def test_gpus_string_is_parsed_like_the_reference_or_refused(tmp_path, monkeypatch):
+    """test_gpu_0.py:7-9 / runner.py:57-66: `gpus` is a comma-separated id list and cfg.gpus its length.  A malformed list raises
+    ValueError before anything is built; more ids than visible GPUs (none in this container) raises RuntimeError that names the
+    torch.distributed.run command - a multi-id string is never silently served by one GPU."""
+    from lanemapping_amd import runner_ranks
+    from lanemapping_amd.runner import load_config_and_runner
+    assert runner_ranks.parse_gpus('0') == [0] and runner_ranks.parse_gpus('0, 1,2') == [0, 1, 2] and runner_ranks.parse_gpus(3) == [3]
+    for bad in ('', '0,', 'a', '0,0', '0,-1', '0;1'):
+        with pytest.raises(ValueError, match='gpus='):
+            load_config_and_runner(_config_copy(tmp_path), bad)
+    monkeypatch.delenv('LANEMAP_TEST_DEVICE', raising=False)
+    import torch
+    if torch.cuda.device_count() < 2:
+        with pytest.raises(RuntimeError, match=r'names 2 GPUs.*torch\.distributed\.run --nnodes=1 --nproc-per-node 2'):
+            load_config_and_runner(_config_copy(tmp_path), '0,1')
+    # which device every rank drives: the reference's masked list -> visible devices 0..n-1 (DataParallel's range(cfg.gpus)); no mask -> the ids
+    monkeypatch.delenv('HIP_VISIBLE_DEVICES', raising=False)
+    monkeypatch.delenv('CUDA_VISIBLE_DEVICES', raising=False)
+    assert runner_ranks.rank_devices([2, 3]) == ([2, 3], 'nccl')
+    monkeypatch.setenv('CUDA_VISIBLE_DEVICES', '2,3')
+    assert runner_ranks.rank_devices([2, 3]) == ([0, 1], 'nccl')
+    monkeypatch.setenv('HIP_VISIBLE_DEVICES', '4,5,6')
+    assert runner_ranks.rank_devices([1, 2]) == ([1, 2], 'nccl')
+    monkeypatch.setenv('LANEMAP_TEST_DEVICE', '0')
+    assert runner_ranks.rank_devices([0, 1, 2]) == ([0, 0, 0], 'gloo')
+
+
+def test_multi_gpu_runner_facade_and_rank_failure(tmp_path, monkeypatch, synth_sd):
+    """MultiGpuRunner carries the Runner entry signatures, keeps a CPU net that load_ckpt fills strictly, ships a picklable job
+    (config tree as plain dicts), and a failing rank surfaces as RuntimeError with that rank's stderr (here: no GPU in the build
+    container, so every fresh rank process refuses to start) instead of a hang or a silent single-GPU run."""
+    import pickle
+    import torch
+    from lanemapping_amd import runner_ranks
+    from lanemapping_amd.config import Config
+    from lanemapping_amd.runner import Runner, load_config_and_runner
+    monkeypatch.setenv('LANEMAP_TEST_DEVICE', '0')
+    cfg, r = load_config_and_runner(_config_copy(tmp_path), '0,1')
+    assert isinstance(r, runner_ranks.MultiGpuRunner) and cfg.gpus == 2 and r.devices == [0, 0] and r.backend == 'gloo'
+    for name in ('infer_lane_coordinate_endpoint_semantics', 'infer_lane_coordinate', 'infer_lane_geometry_segmentation_segmentor'):
+        assert inspect.signature(getattr(r, name)) == inspect.signature(getattr(Runner(cfg, device='cpu'), name)), name
+    path_ckpt = str(tmp_path / 'best.pth')
+    torch.save({'net': {'module.' + k: v for k, v in synth_sd.items()}}, path_ckpt)
+    r.load_ckpt(path_ckpt)
+    assert all(torch.equal(v, synth_sd[k]) for k, v in r.net.state_dict().items())
+    assert all(p.device.type == 'cpu' for p in r.net.parameters())
+    torch.save({'net': {k: v for k, v in list(synth_sd.items())[1:]}}, path_ckpt)
+    with pytest.raises(RuntimeError, match='Missing key'):
+        r.load_ckpt(path_ckpt)
+    plain = pickle.loads(pickle.dumps(runner_ranks._plain(cfg)))
+    assert type(plain) is dict and type(plain['dataset']['test']) is dict and Config(plain) == cfg
+    assert Config(plain).dataset.test.mode == cfg.dataset.test.mode
+    with pytest.raises(NotImplementedError, match='single-GPU'):
+        r.infer_las_to_map([])
+    if not torch.cuda.is_available():
+        with pytest.raises(RuntimeError, match=r'2 of 2 GPU ranks failed(.|\n)*rank 1 \(GPU 1, exit code 1\)(.|\n)*GPU index 0 is not visible'):
+            r.infer_lane_coordinate_endpoint_semantics(tiles=str(tmp_path), write_lane_vertex=True)
