@@ -375,7 +375,7 @@ int launch(const ConvParams& p, hipStream_t stream) {
 // (v + shift, + residual through lm_bilerp): bit-identical outputs (test_lateral_kernel_bit_identical); LM_CONV_LATERAL=0 switches it off.
 // Needs B * H * W % 32 == 0 (no partial tiles: every wave issues the same memory instructions, which the explicit wait counts rely on).
 constexpr int LAT_SLD = 36;                       // floats per row of the transposition patch (32 channels + 4 pad: conflict-free both ways)
-template <int KS, bool RESUP>
+template <int KS, bool RESUP, bool ROWTILE>       // ROWTILE: Wo % 32 == 0 - a tile lies in one image row (its batch index and row are wave-uniform)
 __global__ __launch_bounds__(512) void lateral_mfma_kernel(ConvParams p) {
     constexpr int K = KS * 8, SLABS = K / 32, XBUF = 32 * K;       // floats per pixel buffer: [SLABS][32 rows][32], chunk-swizzled
     constexpr int NX = XBUF / 4 / 512;                             // 16-byte pieces per thread and tile (1 or 2)
@@ -396,6 +396,12 @@ __global__ __launch_bounds__(512) void lateral_mfma_kernel(ConvParams p) {
     // epilogue role of this lane: pixels erow + 8 q (q = 0..3) of the tile, channels n .. n + 3
     const int erow = lane >> 3, n = wave * 32 + (lane & 7) * 4;
     const f32x4 sh = p.shift ? *reinterpret_cast<const f32x4*>(p.shift + n) : f32x4{0.f, 0.f, 0.f, 0.f};
+    unsigned yoff[4], roff[4];                   // this lane's byte offsets inside a tile of the output / of a plain residual
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        yoff[q] = (unsigned)((erow + 8 * q) * p.ldy + n) * 4u;               // bytes
+        roff[q] = (unsigned)((erow + 8 * q) * p.ldr + n) * 4u;
+    }
     // tiles: every XCD (workgroups are dealt to the 8 XCDs round-robin) streams one contiguous eighth of the pixels, so that the coarse
     // rows two neighbouring output rows interpolate from meet in one L2
     const int ntiles = (int)(p.M >> 5);
@@ -429,14 +435,43 @@ __global__ __launch_bounds__(512) void lateral_mfma_kernel(ConvParams p) {
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
         load_x(min(tile + nwg, t_end - 1), buf ^ 1);               // (past the end: a harmless re-read, so that the counts stay uniform)
-        // residual of this lane's four pixels, requested before the MFMAs
-        const int m0 = tile * 32 + erow;
+        // residual of this lane's four pixels (tile pixel erow + 8 q), requested before the MFMAs.  Everything that is the same for the
+        // whole tile is computed on wave-uniform values (scalar ALU / once per wave), lane offsets are loop invariants: the epilogue's VALU
+        // work is the kernel's second cost after the MFMAs (f32 MFMAs do not overlap the SIMD's own VALU instructions)
         f32x4 r00[4], r01[4], r10[4], r11[4];
         float wy0[4], wy1[4], wx0[4], wx1[4];
+        if (RESUP && ROWTILE) {
+            const unsigned mt = (unsigned)__builtin_amdgcn_readfirstlane(tile) * 32u;      // uniform
+            const unsigned t = lm_fastdiv(mt, p.div_wo);
+            const int ox0 = (int)(mt - t * p.div_wo.d);
+            const int bi = (int)lm_fastdiv(t, p.div_ho);
+            const int oy = (int)(t - (unsigned)bi * p.div_ho.d);
+            int y0v, y1v;
+            float wyav, wybv;
+            lm_bilin_axis_scaled(oy, p.res_hi, p.res_sy, y0v, y1v, wyav, wybv);
+            // (float arithmetic has no scalar unit: the uniform results are moved to scalar registers, so that the row pointers below are
+            // scalar 64-bit values and every tap load takes the `scalar base + 32-bit lane offset` form - no 64-bit VALU address arithmetic)
+            const int y0 = __builtin_amdgcn_readfirstlane(y0v), y1 = __builtin_amdgcn_readfirstlane(y1v);
+            const float wya = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, wyav)));
+            const float wyb = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, wybv)));
+            const char* row0 = reinterpret_cast<const char*>(p.res + ((long)bi * p.res_hi + y0) * p.res_wi * p.ldr);
+            const char* row1 = reinterpret_cast<const char*>(p.res + ((long)bi * p.res_hi + y1) * p.res_wi * p.ldr);
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            const unsigned m = (unsigned)(m0 + 8 * q);
-            if (RESUP) {
+            for (int q = 0; q < 4; ++q) {
+                int x0, x1;
+                lm_bilin_axis_scaled(ox0 + erow + 8 * q, p.res_wi, p.res_sx, x0, x1, wx0[q], wx1[q]);
+                wy0[q] = wya;
+                wy1[q] = wyb;
+                const unsigned o0 = (unsigned)(x0 * p.ldr + n) * 4u, o1 = (unsigned)(x1 * p.ldr + n) * 4u;       // bytes (< 2^31: ldr * Wr * 4)
+                r00[q] = *reinterpret_cast<const f32x4*>(row0 + o0);
+                r01[q] = *reinterpret_cast<const f32x4*>(row0 + o1);
+                r10[q] = *reinterpret_cast<const f32x4*>(row1 + o0);
+                r11[q] = *reinterpret_cast<const f32x4*>(row1 + o1);
+            }
+        } else if (RESUP) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const unsigned m = (unsigned)(tile * 32 + erow + 8 * q);
                 const unsigned t = lm_fastdiv(m, p.div_wo);
                 const int ox = (int)(m - t * p.div_wo.d);
                 const int bi = (int)lm_fastdiv(t, p.div_ho);
@@ -449,10 +484,17 @@ __global__ __launch_bounds__(512) void lateral_mfma_kernel(ConvParams p) {
                 r01[q] = *reinterpret_cast<const f32x4*>(rb + ((long)y0 * p.res_wi + x1) * p.ldr);
                 r10[q] = *reinterpret_cast<const f32x4*>(rb + ((long)y1 * p.res_wi + x0) * p.ldr);
                 r11[q] = *reinterpret_cast<const f32x4*>(rb + ((long)y1 * p.res_wi + x1) * p.ldr);
-            } else {
-                const long rrow = p.res_rows ? (long)(m - lm_fastdiv(m, p.div_rr) * p.div_rr.d) : (long)m;
-                r00[q] = *reinterpret_cast<const f32x4*>(p.res + rrow * p.ldr + n);
             }
+        } else if (p.res_rows) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const unsigned m = (unsigned)(tile * 32 + erow + 8 * q);
+                r00[q] = *reinterpret_cast<const f32x4*>(p.res + (long)(m - lm_fastdiv(m, p.div_rr) * p.div_rr.d) * p.ldr + n);
+            }
+        } else {
+            const char* rt = reinterpret_cast<const char*>(p.res + (long)__builtin_amdgcn_readfirstlane(tile) * 32 * p.ldr);     // uniform
+#pragma unroll
+            for (int q = 0; q < 4; ++q) r00[q] = *reinterpret_cast<const f32x4*>(rt + roff[q]);
         }
         // phases in issue order (the scheduler would otherwise sink the residual loads into the MFMA block and blend their values there
         // - fewer live registers, but a wait in front of every blend stops the MFMA issue)
@@ -482,7 +524,7 @@ __global__ __launch_bounds__(512) void lateral_mfma_kernel(ConvParams p) {
 #pragma unroll
         for (int g = 0; g < 4; ++g)
             *reinterpret_cast<f32x4*>(patch + j * LAT_SLD + 8 * g + 4 * half) = f32x4{acc[4 * g], acc[4 * g + 1], acc[4 * g + 2], acc[4 * g + 3]};
-        float* yp = p.y + (long)m0 * p.ldy + n;
+        char* const yt = reinterpret_cast<char*>(p.y + (long)__builtin_amdgcn_readfirstlane(tile) * 32 * p.ldy);               // uniform
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
             f32x4 v = *reinterpret_cast<const f32x4*>(patch + (erow + 8 * q) * LAT_SLD + (lane & 7) * 4);
@@ -495,7 +537,7 @@ __global__ __launch_bounds__(512) void lateral_mfma_kernel(ConvParams p) {
 #pragma unroll
                 for (int e = 0; e < 4; ++e) v[e] += r00[q][e];
             }
-            *reinterpret_cast<f32x4*>(yp + (long)(8 * q) * p.ldy) = v;
+            *reinterpret_cast<f32x4*>(yt + yoff[q]) = v;
         }
     }
 }
@@ -520,13 +562,15 @@ int lateral_try(const ConvParams& p, hipStream_t stream) {
     int grid = (cus + 7) / 8 * 8;
     if (grid > (ntiles + 7) / 8 * 8) grid = (ntiles + 7) / 8 * 8;
     const size_t lds = (size_t)(2 * 32 * p.Cin + 8 * 32 * LAT_SLD) * sizeof(float);
-    if (p.res_hi > 0) {
-        if (lm_ensure_dynamic_lds((const void*)lateral_mfma_kernel<8, true>, lds)) return -LM_ERR_HIP;
-        hipLaunchKernelGGL((lateral_mfma_kernel<8, true>), dim3(grid), dim3(512), lds, stream, p);
-    } else {
-        if (lm_ensure_dynamic_lds((const void*)lateral_mfma_kernel<16, false>, lds)) return -LM_ERR_HIP;
-        hipLaunchKernelGGL((lateral_mfma_kernel<16, false>), dim3(grid), dim3(512), lds, stream, p);
+#define LM_LAT_LAUNCH(KS, UP, ROW)                                                                                      \
+    {                                                                                                                   \
+        if (lm_ensure_dynamic_lds((const void*)lateral_mfma_kernel<KS, UP, ROW>, lds)) return -LM_ERR_HIP;              \
+        hipLaunchKernelGGL((lateral_mfma_kernel<KS, UP, ROW>), dim3(grid), dim3(512), lds, stream, p);                  \
     }
+    if (p.res_hi > 0 && p.Wo % 32 == 0) LM_LAT_LAUNCH(8, true, true)
+    else if (p.res_hi > 0) LM_LAT_LAUNCH(8, true, false)
+    else LM_LAT_LAUNCH(16, false, false)
+#undef LM_LAT_LAUNCH
     if (hipGetLastError() != hipSuccess) return -LM_ERR_HIP;
     return 1;
 }
