@@ -24,6 +24,8 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 MFMA_F32_PEAK_TFLOPS = 157.3      # /opt/skills/guides/MI355X_MICROARCH.md: dense fp32 MFMA peak
+MFMA_F16_PEAK_TFLOPS = 2500.0     # same guide: dense fp16 / bf16 MFMA peak (the split second line is priced against it; its
+                                  # v_mfma_f32_32x32x8_f16 instruction alone peaks at half of that)
 HBM_PEAK_GBS = 8000.0             # same guide: HBM3E 8 TB/s
 BATCH = 8
 N_PTS = 4194304                   # points per tile of the fused workload
@@ -93,6 +95,43 @@ def cpu_baseline(budget_s=25.0, max_threads=64):
         t8 = run([2030 + i for i in range(8)])
         out['batch8'] = {'value': 8 / t8, 'unit': 'tiles/s', 'sample': 'one batch of 8 tiles through the same chain'}
     return out
+
+
+SPLIT_LINE = os.environ.get('LANEMAP_WINO_SPLIT', '0') != '0'        # this process IS a second-line run
+
+
+def second_line(args):
+    """The declared second line: this command once more in a CHILD process (the switch is read at import) under LANEMAP_WINO_SPLIT=1 - the
+    F(4x4) Winograd products on the fp16 matrix pipe, every fp32 operand in two fp16 terms, three products, fp32 accumulation
+    (csrc/conv_wino44.hip w44_split2).  fp32-accurate, not bit-identical; held to the same goldens by the every-switch test.  Never `value`."""
+    import subprocess
+    steps = max(10, min(args.steps, 40))
+    cmd = [sys.executable, os.path.join(ROOT, 'bench.py'), '--steps', str(steps), '--warmup', '3', '--no-cpu-baseline', '--no-second-line']
+    if args.no_graphs:
+        cmd.append('--no-graphs')
+    if args.streams is not None:
+        cmd += ['--streams', str(args.streams)]
+    try:
+        r = subprocess.run(cmd, capture_output=True, text=True, timeout=900, cwd=ROOT, env=dict(os.environ, LANEMAP_WINO_SPLIT='1'))
+        lines = [l for l in r.stdout.strip().split('\n') if l.startswith('{')]
+        if r.returncode != 0 or not lines:
+            return {'error': f'second-line run failed (exit code {r.returncode}): ' + (r.stderr or r.stdout)[-400:]}
+        d = json.loads(lines[-1])
+    except Exception as e:          # the headline must print whatever happens to the second line
+        return {'error': f'second-line run failed: {e!r}'}
+    rf = d['roofline']
+    return {'what': 'the same command under LANEMAP_WINO_SPLIT=1: Winograd F(4x4) products as fp16 x 2 split terms (three v_mfma_f32_32x32x8_f16 per '
+                    'fp32 product pair, fp32 accumulation), fp32-accurate but NOT bit-identical to the exact path; a second line, never the headline',
+            'value': d['value'], 'unit': d['unit'], 'ms_per_step': d['ms_per_step'], 'steps': d['steps'], 'dtype': d['dtype'],
+            'windows_tiles_per_s': d['config'].get('windows_tiles_per_s'), 'stream_check': d['config'].get('stream_check'),
+            'raster_check': d['config'].get('raster_check'),
+            'roofline': {'bound': 'mfma', 'per_kernel': rf['per_kernel'], 'kernel_ms_per_step': rf['kernel_ms_per_step'],
+                         'winograd_ms_per_step': rf['winograd_ms_per_step'], 'frac': rf['frac'], 'scope': rf['scope'],
+                         'note': 'frac = time-weighted executed MFMA FLOPs / peak of each launch\'s dtype: the split Winograd launches execute 3 x '
+                                 'the fp32 kernel\'s products as fp16 MFMAs and are priced against the 2.5 PFLOP/s dense fp16 peak, the rest against '
+                                 'the fp32 MFMA peak'},
+            'parity': 'tests/test_gpu_1_kernels.py::test_conv_winograd44_split_second_line (bit-identical to its twin, error vs fp64 like the exact '
+                      'kernel), tests/test_gpu_2_goldens.py::test_goldens_under_every_advertised_switch[LANEMAP_WINO_SPLIT=1] (G10 / G15 / G17)'}
 
 
 def self_launch(args):
@@ -216,6 +255,10 @@ def main():
                          "runner.py:125-152).  las: the pinned host memory holds raw LAS point records (format 0, 20 B per point); they are uploaded "
                          "the same way and decoded on the GPU (lm_las_decode_points) in front of the raster.  Both report the achieved H2D rate and "
                          "the fraction of a resident-points window measured in the same run")
+    ap.add_argument('--no-second-line', action='store_true',
+                    help='skip the second line (fused workload, 1 GPU: the same command once more in a child process under LANEMAP_WINO_SPLIT=1 - '
+                         'the Winograd products as fp16 x 2 split terms, fp32-accurate, NOT bit-identical to the exact path; reported as `second_line`, '
+                         'never as `value`)')
     ap.add_argument('--conv-detail', action='store_true', help='per-shape table of the MFMA launches on stderr')
     ap.add_argument('--no-stream-check', action='store_true', help='skip the bitwise multi-stream == single-stream check')
     ap.add_argument('--graphs', action='store_true', help='replay the device part of every sub-batch as one HIP graph (TilePipeline use_graph); the default since '
@@ -613,8 +656,9 @@ def main():
     # ---- aggregate per kernel class.  kind strings: 'wino44 ...', 'conv ...', 'gemm ...', 'spconv ...'
     def kclass(kind):
         k = kind.split(' ', 1)[0]
-        return {'wino44': 'wino44_kernel'}.get(k, 'conv_mfma_kernel')
-    peak_of = lambda c: MFMA_F32_PEAK_TFLOPS          # every MFMA launch of the path is exact fp32
+        return {'wino44': 'wino44_kernel', 'wino44split': 'wino44_kernel<split: fp16 x 2 terms, 3 products>'}.get(k, 'conv_mfma_kernel')
+    # every MFMA launch of the headline path is exact fp32; under LANEMAP_WINO_SPLIT=1 (second line) the Winograd launches run fp16 MFMAs
+    peak_of = lambda c: MFMA_F16_PEAK_TFLOPS if 'split' in c else MFMA_F32_PEAK_TFLOPS
     cls = {}
     per_kind = {}
     for a, b, kind, fl, ex in prof['pairs']:
@@ -674,7 +718,7 @@ def main():
         'value': world * batch * args.steps / dt,
         'unit': 'tiles/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
         'ms_per_step': dt / args.steps * 1e3, 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
-        'dtype': 'f32', 'data': 'synthetic',
+        'dtype': 'f32' if not SPLIT_LINE else 'f16x2-split Winograd products (3 per fp32 product), f32 accumulate; everything else f32', 'data': 'synthetic',
         'config': {'workload': workload,
                    'tiles_per_step_per_gpu': batch, 'lines_per_tile': n_lines, 'host_threads': args.host_threads, 'streams': nstream, 'hip_graphs': bool(args.graphs and args.workload in ('fused', 'tiles', 'rowref')),      # (the LiDAR path sizes launches on the host: no capture)
                   
@@ -734,6 +778,8 @@ def main():
         dist.barrier()
         torch.cuda.synchronize()
         store = dist.distributed_c10d._get_default_store()
+    if rank == 0 and world == 1 and args.workload == 'fused' and args.points == 'resident' and not args.no_second_line and not SPLIT_LINE:
+        result['second_line'] = second_line(args)
     if rank == 0:
         if not args.no_cpu_baseline and affinity0 is not None and args.host_cores is not None:
             os.sched_setaffinity(0, affinity0)          # the CPU path gets the node's cores back, not this rank's slice

@@ -61,6 +61,19 @@ int lm_conv3x3_winograd44_f32(void* stream, const float* x, int ldx, const float
 int lm_conv3x3_winograd44_twin_f32(void* stream, const float* x, int ldx, const float* wu, int CoutP, const float* scale,
                                    const float* shift, const float* res, int ldr, float* y, int ldy, int B, int H, int W,
                                    int Cin, int Cout, int dil, int act, void* workspace, long workspace_bytes);
+/* SECOND LINE of the same convolution (never the default path; round 6): the Winograd-domain products on the fp16 matrix pipe with
+ * fp32-accurate products - every fp32 operand x = hi + lo in two fp16 terms (22 bits), v u ~= v_hi u_hi + v_hi u_lo + v_lo u_hi as three
+ * v_mfma_f32_32x32x8_f16 with fp32 accumulation.  The caller scales U by a power of two u_scale (max |U| u_scale ~ 2^13), packs its
+ * fragments as for lm_conv3x3_winograd44_f32 and splits them ONCE with lm_wino44_split_fragments (n_quads = elements / 4); post = 1 / u_scale
+ * is folded into the epilogue's scale (exact).  Needs |activation| < ~650 (fp16 range of the transformed input; not checked).
+ * lm_conv3x3_winograd44_split_twin_f32: the materialising twin with identical bits (wu = U * u_scale as [36][CoutP][Cin] fp32). */
+int lm_wino44_split_fragments(void* stream, const float* frag, float* out, long n_quads);
+int lm_conv3x3_winograd44_split_f32(void* stream, const float* x, int ldx, const float* wu_split, int CoutP, const float* scale,
+                                    const float* shift, const float* res, int ldr, float* y, int ldy, int B, int H, int W,
+                                    int Cin, int Cout, int dil, int act, double* gn_partial, float post);
+int lm_conv3x3_winograd44_split_twin_f32(void* stream, const float* x, int ldx, const float* wu, int CoutP, const float* scale,
+                                         const float* shift, const float* res, int ldr, float* y, int ldy, int B, int H, int W,
+                                         int Cin, int Cout, int dil, int act, void* workspace, long workspace_bytes, float post);
 
 /* Same convolution + first pass of GroupNorm(C,C) (postprojector.py:512-515,608-647): also writes per (image, 64-row
  * chunk, channel) sum / sum of squares of the outputs, gn_partial [B][Ho*Wo/64][Cout][2] doubles -> lm_gn_finalize. */

@@ -42,6 +42,9 @@ SIGNATURES = {
     'lm_winograd44_twin_workspace_bytes': (i64, [i32, i32, i32, i32, i32, i32]),
     'lm_conv3x3_winograd44_f32': (i32, [vp, vp, i32, vp, i32, vp, vp, vp, i32, vp, i32, i32, i32, i32, i32, i32, i32, i32, vp]),
     'lm_conv3x3_winograd44_twin_f32': (i32, [vp, vp, i32, vp, i32, vp, vp, vp, i32, vp, i32, i32, i32, i32, i32, i32, i32, i32, vp, i64]),
+    'lm_wino44_split_fragments': (i32, [vp, vp, vp, i64]),
+    'lm_conv3x3_winograd44_split_f32': (i32, [vp, vp, i32, vp, i32, vp, vp, vp, i32, vp, i32, i32, i32, i32, i32, i32, i32, i32, vp, f32]),
+    'lm_conv3x3_winograd44_split_twin_f32': (i32, [vp, vp, i32, vp, i32, vp, vp, vp, i32, vp, i32, i32, i32, i32, i32, i32, i32, i32, vp, i64, f32]),
     'lm_conv2d_nhwc_mfma_f32_gnstats': (i32, [vp, vp, i32, vp, i32, vp, vp, i32, vp] + [i32] * 11),
     'lm_gn_finalize': (i32, [vp, vp, vp, i32, i32, i32, i32, f32]),
     'lm_gn_finalize_split': (i32, [vp, vp, vp, i32, i32, i32, i32, f32, i32]),

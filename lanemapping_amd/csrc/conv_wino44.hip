@@ -42,8 +42,32 @@
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
+typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
 
 namespace {
+
+// ---- split-precision second line (round 6, LANEMAP_WINO_SPLIT=1; never the headline) ----------------------------------------------
+// The Winograd-domain products on the fp16 matrix pipe with fp32-accurate products: every fp32 operand is split into two fp16 terms,
+// x = hi + lo exactly to 22 bits (hi = x truncated to fp16, lo = (x - hi) truncated; x - hi is exact in fp32), and
+//     v u ~= v_hi u_hi + v_hi u_lo + v_lo u_hi                       (the dropped v_lo u_lo is 2^-22 of the product)
+// is three v_mfma_f32_32x32x8_f16 (32 cycles each, exact fp16 x fp16 products, fp32 accumulation) in place of four
+// v_mfma_f32_32x32x2_f32 (64 cycles each) per 8 channels: 96 instead of 256 cycles of matrix time.  U is scaled by a power of two per
+// layer on the host (max |U| ~ 2^13: its low terms stay normal fp16 numbers) and split once on the device (lm_wino44_split_fragments);
+// V is split by the input transform right before it is stored (5 VALU instructions per channel pair and plane); the epilogue's scale
+// undoes the power of two exactly.  Range: |V| <= 100 max|x| must stay below 65504, i.e. activations below ~650 (the truncating
+// conversion saturates instead of producing infinities; nothing on the path checks it - one of the reasons this is a second line).
+// One 32-bit word = the fp16 terms of a channel pair; (hi word, lo word) of a pair of fp32 values:
+// (plain builtins, no inline asm: the compiler must see these VALU instructions to keep the wait states between them and an MFMA that reads
+// their results - the twin's GEMM kernel consumes them straight from registers)
+__device__ __forceinline__ u32x2 w44_split2(f32x2 t) {
+#pragma clang fp contract(off)
+    typedef __fp16 f16x2r __attribute__((ext_vector_type(2)));            // what __builtin_amdgcn_cvt_pkrtz returns
+    const f16x2r h = __builtin_amdgcn_cvt_pkrtz(t[0], t[1]);
+    const float h0 = (float)h[0], h1 = (float)h[1];
+    const f16x2r l = __builtin_amdgcn_cvt_pkrtz(t[0] - h0, t[1] - h1);     // t - hi is exact: hi is t with its low mantissa bits cleared
+    return u32x2{__builtin_bit_cast(unsigned, h), __builtin_bit_cast(unsigned, l)};       // (whole-vector casts)
+}
 
 constexpr int QBM = 32, QBN = 64, QSEG = 4;
 constexpr int QNCELL = 144;                     // cells (one pixel x 16 channels = 64 B) per patch row: 36 tile slots x 4 columns
@@ -160,6 +184,8 @@ __global__ __launch_bounds__(256) void wino44_input_kernel(const float* __restri
 
 // M[xi][m][n] = sum_c V[xi][m][c] U[xi][n][c]: one wave per (32 tiles, 32 channels, xi); the MFMA sequence of wino44_kernel (8-channel
 // units in ascending order, k step e pairs channel 8 u + e with 8 u + 4 + e)
+// (SPLIT: the operands are split on the fly by the helper the fused kernel and lm_wino44_split_fragments use, same three products in the same order)
+template <bool SPLIT>
 __global__ __launch_bounds__(64) void wino44_gemm_kernel(const float* __restrict__ V, const float* __restrict__ U, float* __restrict__ M, long T,
                                                          int C, int CoutP) {
     const int lane = threadIdx.x;
@@ -172,8 +198,18 @@ __global__ __launch_bounds__(64) void wino44_gemm_kernel(const float* __restrict
     const float* b = U + ((long)xi * CoutP + n0 + (lane & 31)) * C + 4 * (lane >> 5);
     for (int u = 0; u < C / 8; ++u) {
         const f32x4 av = *reinterpret_cast<const f32x4*>(a + 8 * u), bv = *reinterpret_cast<const f32x4*>(b + 8 * u);
+        if constexpr (SPLIT) {
+            const u32x2 a01 = w44_split2(f32x2{av[0], av[1]}), a23 = w44_split2(f32x2{av[2], av[3]});
+            const u32x2 b01 = w44_split2(f32x2{bv[0], bv[1]}), b23 = w44_split2(f32x2{bv[2], bv[3]});
+            const f16x4 ah = __builtin_bit_cast(f16x4, u32x2{a01[0], a23[0]}), al = __builtin_bit_cast(f16x4, u32x2{a01[1], a23[1]});
+            const f16x4 bh = __builtin_bit_cast(f16x4, u32x2{b01[0], b23[0]}), bl = __builtin_bit_cast(f16x4, u32x2{b01[1], b23[1]});
+            acc = __builtin_amdgcn_mfma_f32_32x32x8f16(ah, bh, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x8f16(ah, bl, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x8f16(al, bh, acc, 0, 0, 0);
+        } else {
 #pragma unroll
-        for (int e = 0; e < 4; ++e) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[e], bv[e], acc, 0, 0, 0);
+            for (int e = 0; e < 4; ++e) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[e], bv[e], acc, 0, 0, 0);
+        }
     }
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
@@ -185,12 +221,14 @@ __global__ __launch_bounds__(64) void wino44_gemm_kernel(const float* __restrict
 struct W44Epi {
     const float* scale; const float* shift; const float* res; float* y;
     int ldr, ldy, Cout, act;
+    float post;            // split twin: 1 / (power-of-two scale of U), folded into the scale like the fused kernel does; 0 = exact twin
 };
 
 __device__ __forceinline__ float w44_tail(float v, int n, const W44Epi& e, long pix) {
 #pragma clang fp contract(off)
     const float sh = e.shift ? e.shift[n] : 0.f;
-    v = e.scale ? v * e.scale[n] + sh : v + sh;
+    if (e.post != 0.f) v = v * ((e.scale ? e.scale[n] : 1.f) * e.post) + sh;
+    else v = e.scale ? v * e.scale[n] + sh : v + sh;
     if (e.res) v += e.res[pix * e.ldr + n];
     if (e.act == LM_ACT_RELU) v = fmaxf(v, 0.f);
     return v;
@@ -230,6 +268,18 @@ __global__ __launch_bounds__(256) void wino44_output_kernel(const float* __restr
     }
 }
 
+// U fragments (already scaled by the layer's power of two) -> fp16 term words, in place order: {c0 c1 | c2 c3 | c4 ..} of a lane's four
+// channels become {hi 01, hi 23, lo 01, lo 23}
+__global__ __launch_bounds__(256) void wino44_split_frag_kernel(const f32x4* __restrict__ in, f32x4* __restrict__ out, long n) {
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const f32x4 v = in[i];
+    const u32x2 a = w44_split2(f32x2{v[0], v[1]}), b = w44_split2(f32x2{v[2], v[3]});
+    // (whole-vector bit cast: __builtin_bit_cast of a vector ELEMENT lvalue reads element 0 whatever the index - hipcc 7.2)
+    typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+    out[i] = __builtin_bit_cast(f32x4, u32x4{a[0], b[0], a[1], b[1]});
+}
+
 // ===================================================================================================================================
 // The fused kernel
 struct W44Params {
@@ -239,7 +289,8 @@ struct W44Params {
     LmFastDiv dnt;                             // / number of N tiles
     double* gn_part;
     W44Geom g;
-};
+    float post;                                // SPLIT: 1 / (power-of-two scale of U), folded into the epilogue's scale (exact); else 1.  (Last:
+};                                             // the exact kernel's argument offsets - and with them its code - are what they were)
 
 // packed fp32 pairs (two channels of a lane).  Plain asm (not volatile): the scheduler may move them, the arithmetic is fixed.
 // (the multiplier b is one of three wave-uniform constant pairs: an SGPR-pair operand - with a "v" constraint every use cost a v_mov_b64)
@@ -367,12 +418,23 @@ __device__ __forceinline__ void w44_pass1x2(W44Xf& d, const W44K& k) {
     }
 }
 // the LDS part of step K's transform share.  vA / vB / vC = V + plane offset of the thread's class-A / B / C row + its element offset
-template <int K>
+// (SPLIT: a V plane is [hi / lo][4 channel pairs][32 tiles] words - the store is two ds_write_b32 128 words apart, v = plane + pair * 32 + tile)
+template <bool SPLIT>
+__device__ __forceinline__ void w44_vstore(float* v, int j, const f32x2 t) {
+    if constexpr (SPLIT) {
+        const u32x2 w = w44_split2(t);
+        reinterpret_cast<unsigned*>(v)[j * 256] = w[0];
+        reinterpret_cast<unsigned*>(v)[j * 256 + 128] = w[1];
+    } else {
+        *reinterpret_cast<f32x2*>(v + j * 256) = t;
+    }
+}
+template <int K, bool SPLIT>
 __device__ __forceinline__ void w44_xf_lds(W44Xf& d, const float* rawrow, const int (&roff)[6], float* vA, float* vB, float* vC) {
 #ifdef LM_QABL_NOVST                         // (PMC ablation: the transform without its V stores - whose LDS bank conflicts are they?)
     auto st = [](float* v, int j, const f32x2 t) { asm volatile("" :: "v"(v), "v"(t)); };
 #else
-    auto st = [](float* v, int j, const f32x2 t) { *reinterpret_cast<f32x2*>(v + j * 256) = t; };
+    auto st = [](float* v, int j, const f32x2 t) { w44_vstore<SPLIT>(v, j, t); };
 #endif
     if constexpr (K == 0) {
         st(vB, 2, d.tB[2]); st(vB, 5, d.tB[5]);
@@ -410,6 +472,7 @@ __device__ __forceinline__ void w44_xf_valu(W44Xf& d, bool lower, const W44K& k)
 }
 // the whole transform of one slot at once (prologue: V(0) has nobody to hide behind): every plane stored; the first slot stores the late
 // ones again in its steps 0..3 (the same bits)
+template <bool SPLIT>
 __device__ __forceinline__ void w44_xf_all(W44Xf& d, const float* rawrow, const int (&roff)[6], float* vA, float* vB, float* vC, bool lower,
                                            const W44K& k) {
     w44_preread<0>(d, rawrow, roff); w44_preread<1>(d, rawrow, roff); w44_preread<2>(d, rawrow, roff);
@@ -418,9 +481,9 @@ __device__ __forceinline__ void w44_xf_all(W44Xf& d, const float* rawrow, const 
     w44_xf_valu<4>(d, lower, k); w44_xf_valu<5>(d, lower, k); w44_xf_valu<6>(d, lower, k);
 #pragma unroll
     for (int j = 0; j < 6; ++j) {
-        *reinterpret_cast<f32x2*>(vA + j * 256) = d.tA[j];
-        *reinterpret_cast<f32x2*>(vB + j * 256) = d.tB[j];
-        *reinterpret_cast<f32x2*>(vC + j * 256) = d.tC[j];
+        w44_vstore<SPLIT>(vA, j, d.tA[j]);
+        w44_vstore<SPLIT>(vB, j, d.tB[j]);
+        w44_vstore<SPLIT>(vC, j, d.tC[j]);
     }
 }
 
@@ -461,6 +524,13 @@ __device__ __forceinline__ void q_mfma(f32x16& acc, float a, float b) {
     if constexpr (VACC) mfma_vgpr(acc, a, b);
     else acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc, 0, 0, 0);
 }
+// SPLIT: one fp16 product term of 8 channels (lo / hi word pairs of a fragment: two consecutive registers = four fp16 k values)
+template <bool VACC>
+__device__ __forceinline__ void q_mfma16(f32x16& acc, f32x2 a, f32x2 b) {
+    const f16x4 ah = __builtin_bit_cast(f16x4, a), bh = __builtin_bit_cast(f16x4, b);
+    if constexpr (VACC) asm volatile("v_mfma_f32_32x32x8_f16 %0, %1, %2, %0" : "+v"(acc) : "v"(ah), "v"(bh));
+    else acc = __builtin_amdgcn_mfma_f32_32x32x8f16(ah, bh, acc, 0, 0, 0);
+}
 // Patch loads of unit u + 2 go out in the SECOND phase of unit u (steps 9..17: two per step in 9..13, one in 14..17), into the buffer
 // whose last reads (the pre-reads of unit u's second half) were issued a phase earlier.
 constexpr int q_ndma(int S) { return S < 9 ? 0 : (S < 14 ? 2 : 1); }
@@ -476,16 +546,21 @@ static_assert(q_dma0(17) + q_ndma(17) == QLPW, "the second phase issues every pa
 // A fragment of one xi: V plane [4 channel pairs][32 tiles][2] - the 16 lanes of a ds_write_b64 group of the transform (16 tiles of one
 // channel pair) and the 32 lanes of a read pass here cover contiguous bytes: conflict-free on both sides ([2 k halves][32 tiles][4] with
 // one ds_read_b128 made the transform's stores two-way conflicted).  Lane (tile, k half) takes pairs 2 k and 2 k + 1: channels 4 k .. 4 k + 3
+template <bool SPLIT>
 __device__ __forceinline__ f32x4 q_aread(const float* v) {
-    const f32x2 lo = *reinterpret_cast<const f32x2*>(v), hi = *reinterpret_cast<const f32x2*>(v + 64);
-    return f32x4{lo[0], lo[1], hi[0], hi[1]};
+    if constexpr (SPLIT) {       // v = plane + 64 (lane >> 5) + tile: hi words of pairs 2 k, 2 k + 1, then their lo words (two ds_read2_b32)
+        return f32x4{v[0], v[32], v[128], v[160]};
+    } else {
+        const f32x2 lo = *reinterpret_cast<const f32x2*>(v), hi = *reinterpret_cast<const f32x2*>(v + 64);
+        return f32x4{lo[0], lo[1], hi[0], hi[1]};
+    }
 }
 
 // One step (one xi of the wave) of a slot: 8 MFMAs = 4 k steps x 2 channel blocks.  S = step within the 16-channel unit (0..17: two slots
 // of nine); the B fragments of step S + QBD and the patch loads of this step (q_ndma) are issued first; q_nwait(S) loads may stay
 // outstanding when this step's B fragments are needed.  Behind the first MFMA: the A fragment of the next step (not across a barrier:
 // steps 4 and 8 leave it to the loop), the LDS part of this step's transform share, then its VALU part.
-template <int S>
+template <int S, bool SPLIT>
 __device__ __forceinline__ void w44_step(f32x16& acc0, f32x16& acc1, f32x4 (&bq)[QRING][2], unsigned bvoff, const float* bpre,
                                          const float* anext, const f32x4& a_cur, f32x4& a_nxt, const float* const (&gsrc)[QLPW], long goff,
                                          float* rawld, int wave, W44Xf& xf, const float* prerow, const int (&roff)[6], float* vA, float* vB,
@@ -510,20 +585,44 @@ __device__ __forceinline__ void w44_step(f32x16& acc0, f32x16& acc1, f32x4 (&bq)
     q_bwait<0>(b);
 #endif
     constexpr bool VACC = K == 8;
-    q_mfma<VACC>(acc0, a_cur[0], b[0][0]);
-    __builtin_amdgcn_sched_barrier(0);
-    if constexpr (K != 4 && K != 8) a_nxt = q_aread(anext);
+    // SPLIT: a_cur = {hi 01, hi 23, lo 01, lo 23} of the tile's four channels, b[blk] likewise for the output channel: hi hi, hi lo, lo hi
+    const f32x2 a_hi = {a_cur[0], a_cur[1]}, a_lo = {a_cur[2], a_cur[3]};
+    if constexpr (SPLIT) q_mfma16<VACC>(acc0, a_hi, f32x2{b[0][0], b[0][1]});
+    else q_mfma<VACC>(acc0, a_cur[0], b[0][0]);
+    // (exact kernel: LDS instructions ride free behind the first f32 MFMA, VALU instructions cost matrix time wherever they stand - one block.
+    //  SPLIT: an fp16 MFMA is 8 passes on a pipe of its own, and the step's VALU work (transform + split, ~110 cycles) is of the order of
+    //  its six MFMAs (192 cycles): the scheduler interleaves them - see the group pattern at the end of the step)
+    if constexpr (!SPLIT) __builtin_amdgcn_sched_barrier(0);
+    if constexpr (K != 4 && K != 8) a_nxt = q_aread<SPLIT>(anext);
 #ifndef LM_QABL_NOT
-    w44_xf_lds<K>(xf, prerow, roff, vA, vB, vC);
-    __builtin_amdgcn_sched_barrier(0);
+    w44_xf_lds<K, SPLIT>(xf, prerow, roff, vA, vB, vC);
+    if constexpr (!SPLIT) __builtin_amdgcn_sched_barrier(0);
     w44_xf_valu<K>(xf, lower, kk);
 #endif
-    __builtin_amdgcn_sched_barrier(0);
-    q_mfma<VACC>(acc1, a_cur[0], b[1][0]);
+    if constexpr (!SPLIT) __builtin_amdgcn_sched_barrier(0);
+    if constexpr (SPLIT) {
+        q_mfma16<VACC>(acc1, a_hi, f32x2{b[1][0], b[1][1]});
+        q_mfma16<VACC>(acc0, a_hi, f32x2{b[0][2], b[0][3]});
+        q_mfma16<VACC>(acc1, a_hi, f32x2{b[1][2], b[1][3]});
+        q_mfma16<VACC>(acc0, a_lo, f32x2{b[0][0], b[0][1]});
+        q_mfma16<VACC>(acc1, a_lo, f32x2{b[1][0], b[1][1]});
+#ifndef LM_SPLIT_NOGROUPS
+        if constexpr (!VACC) {           // one MFMA, then a share of the step's VALU / LDS instructions, six times (leftovers follow)
 #pragma unroll
-    for (int t = 1; t < 4; ++t) {
-        q_mfma<VACC>(acc0, a_cur[t], b[0][t]);
-        q_mfma<VACC>(acc1, a_cur[t], b[1][t]);
+            for (int i = 0; i < 6; ++i) {
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                __builtin_amdgcn_sched_group_barrier(0x002, 6, 0);
+                __builtin_amdgcn_sched_group_barrier(0x300, 3, 0);
+            }
+        }
+#endif
+    } else {
+        q_mfma<VACC>(acc1, a_cur[0], b[1][0]);
+#pragma unroll
+        for (int t = 1; t < 4; ++t) {
+            q_mfma<VACC>(acc0, a_cur[t], b[0][t]);
+            q_mfma<VACC>(acc1, a_cur[t], b[1][t]);
+        }
     }
     __builtin_amdgcn_sched_barrier(0);
 }
@@ -570,6 +669,7 @@ __device__ __forceinline__ void w44_tail_vec(const f32x4 (&z)[4][6], const f32x4
     }
 }
 
+template <bool SPLIT>
 __global__ __launch_bounds__(256) void wino44_kernel(W44Params p) {
 #ifdef LM_QPROF
     long long qprof[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
@@ -715,7 +815,7 @@ __global__ __launch_bounds__(256) void wino44_kernel(W44Params p) {
 #pragma unroll
         for (int c = 0; c < 6; ++c) roff[c] = c * 64 + tl * 2;
 #endif
-        tvoff = cp * 64 + tl * 2;
+        tvoff = SPLIT ? cp * 32 + tl : cp * 64 + tl * 2;
     }
     const bool lower = (wave >> 1) != 0;
     // plane rows of this thread by class (A: i % 3 == 0, B: == 1, C: == 2): upper threads i = 0, 1, 2; lower threads i = 3, 4, 5
@@ -726,7 +826,8 @@ __global__ __launch_bounds__(256) void wino44_kernel(W44Params p) {
     // MFMA operands: A = V plane xi, channel pairs 2 (lane >> 5) and 2 (lane >> 5) + 1 of tile lane & 31; this wave's planes xi = xi00 + 6 ii + jj
     const int qa = wave >> 1, qb = wave & 1;
     const int xi00 = 18 * qa + 3 * qb;
-    const float* const Vq = Vbuf + xi00 * 256 + (lane >> 5) * 128 + (lane & 31) * 2;       // channel pairs 2 (lane >> 5) and 2 (lane >> 5) + 1
+    const float* const Vq = SPLIT ? Vbuf + xi00 * 256 + (lane >> 5) * 64 + (lane & 31)
+                                  : Vbuf + xi00 * 256 + (lane >> 5) * 128 + (lane & 31) * 2;       // channel pairs 2 (lane >> 5) and 2 (lane >> 5) + 1
     const int nun = p.C / 16;                                    // 16-channel units
     const unsigned bvoff = (unsigned)lane * 16u;
     const long ustride = (long)p.NT * 256;                       // floats between 8-channel halves in U
@@ -760,7 +861,7 @@ __global__ __launch_bounds__(256) void wino44_kernel(W44Params p) {
     LM_QTICK(1)
     // V(0): the only transform with nothing to hide behind
 #ifndef LM_QABL_NOT
-    w44_xf_all(xf, raw0 + lowoff, roff, vA, vB, vC, lower, kk);
+    w44_xf_all<SPLIT>(xf, raw0 + lowoff, roff, vA, vB, vC, lower, kk);
 #endif
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     LM_QTICK(2)
@@ -770,19 +871,19 @@ __global__ __launch_bounds__(256) void wino44_kernel(W44Params p) {
     // B fragments of step S5 = S + QBD of the unit (S5 >= 18: first slot of the next unit)
 #define LM_QBPRE(S5) ((S5) < 18 ? bu + (long)((S5) / 9) * ustride + (long)LM_QXI((S5) % 9) * xstride : bu_next + (long)LM_QXI((S5) - 18) * xstride)
 #define LM_QSTEP(S, AC, AN) \
-    w44_step<S>(acc[(S) % 9][0], acc[(S) % 9][1], bq, bvoff, LM_QBPRE((S) + QBD), Vq + LM_QXI(((S) % 9) + 1 < 9 ? ((S) % 9) + 1 : 0) * 256, \
+    w44_step<S, SPLIT>(acc[(S) % 9][0], acc[(S) % 9][1], bq, bvoff, LM_QBPRE((S) + QBD), Vq + LM_QXI(((S) % 9) + 1 < 9 ? ((S) % 9) + 1 : 0) * 256, \
                 AC, AN, gsrc, goff, rawc_w, wave, xf, (S) < 9 ? rawc + 8 + lowoff : rawn + lowoff, roff, vA, vB, vC, lower, kk)
     // the barrier in the middle of a slot: this wave's late stores (steps 0..3) are done; behind it every wave's are, and the early
     // planes are free (every wave has read V(s)'s in steps 0..4)
 #ifdef LM_QABL_NOMID                          // (timing ablation: what the barrier in the middle of a slot costs; results are wrong)
-#define LM_QMID(AN) AN = q_aread(Vq + LM_QXI(5) * 256);
+#define LM_QMID(AN) AN = q_aread<SPLIT>(Vq + LM_QXI(5) * 256);
 #else
 #define LM_QMID(AN)                                          \
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");       \
     LM_QTICK(4)                                              \
     __builtin_amdgcn_s_barrier();                            \
     LM_QTICK(5)                                              \
-    AN = q_aread(Vq + LM_QXI(5) * 256);
+    AN = q_aread<SPLIT>(Vq + LM_QXI(5) * 256);
 #endif
     for (int u = 0; u < nun; ++u) {
         const float* const rawc = raw0 + (u & 1) * QRAWF;              // unit u
@@ -793,7 +894,7 @@ __global__ __launch_bounds__(256) void wino44_kernel(W44Params p) {
         const float* const bu_next = bbase + (long)(u + 1 < nun ? 2 * (u + 1) : 0) * ustride;
         f32x4 a0, a1;
         // ---- slot 2 u: channels 16 u .. 16 u + 7 multiplied, channels 16 u + 8 .. 16 u + 15 transformed behind the MFMAs
-        a0 = q_aread(Vq);
+        a0 = q_aread<SPLIT>(Vq);
         LM_QSTEP(0, a0, a1); LM_QSTEP(1, a1, a0); LM_QSTEP(2, a0, a1); LM_QSTEP(3, a1, a0); LM_QSTEP(4, a0, a1);
         LM_QMID(a1)
         LM_QSTEP(5, a1, a0); LM_QSTEP(6, a0, a1); LM_QSTEP(7, a1, a0); LM_QSTEP(8, a0, a1);
@@ -806,7 +907,7 @@ __global__ __launch_bounds__(256) void wino44_kernel(W44Params p) {
         __builtin_amdgcn_s_barrier();          // V(2 u + 1)'s early planes complete
         LM_QTICK(5)
         // ---- slot 2 u + 1: channels 16 u + 8 .. multiplied, the next unit's first half transformed, unit u + 2's patches requested
-        a0 = q_aread(Vq);
+        a0 = q_aread<SPLIT>(Vq);
         LM_QSTEP(9, a0, a1);  LM_QSTEP(10, a1, a0); LM_QSTEP(11, a0, a1); LM_QSTEP(12, a1, a0); LM_QSTEP(13, a0, a1);
         LM_QMID(a1)
         LM_QSTEP(14, a1, a0); LM_QSTEP(15, a0, a1); LM_QSTEP(16, a1, a0); LM_QSTEP(17, a0, a1);
@@ -866,12 +967,14 @@ __global__ __launch_bounds__(256) void wino44_kernel(W44Params p) {
         if (vec) {
             if (p.scale) sc = *reinterpret_cast<const f32x4*>(p.scale + n);
             if (p.shift) sh = *reinterpret_cast<const f32x4*>(p.shift + n);
+            if constexpr (SPLIT) sc = sc * p.post;
         } else {
 #pragma unroll
             for (int e = 0; e < 4; ++e)
                 if (n + e < p.Cout) {
                     if (p.scale) sc[e] = p.scale[n + e];
                     if (p.shift) sh[e] = p.shift[n + e];
+                    if constexpr (SPLIT) sc[e] = sc[e] * p.post;
                 }
         }
         // residual (BasicBlock identity): the sixteen 16-byte loads of this thread's outputs are issued BETWEEN the product stores of the
@@ -1097,9 +1200,9 @@ LM_API long lm_winograd44_twin_workspace_bytes(int B, int H, int W, int Cin, int
 // wu_frag = U = G g G^T (fp64 -> fp32) repacked per wave fragment, [36][Cin/8][CoutP/32][64][4] floats:
 //   wu_frag[xi][u][nt][lane][e] = U[xi][nt*32 + (lane & 31)][8 u + 4 (lane >> 5) + e]     (ops.pack_wino44_fragments), CoutP % 64 == 0
 // gn_partial (optional, needs res == NULL and act == none): [B][lm_winograd44_gn_chunks][Cout][2] doubles -> lm_gn_finalize.
-LM_API int lm_conv3x3_winograd44_f32(void* stream, const float* x, int ldx, const float* wu_frag, int CoutP, const float* scale,
-                                     const float* shift, const float* res, int ldr, float* y, int ldy, int B, int H, int W,
-                                     int Cin, int Cout, int dil, int act, double* gn_partial) {
+static int w44_launch(void* stream, const float* x, int ldx, const float* wu_frag, int CoutP, const float* scale,
+                      const float* shift, const float* res, int ldr, float* y, int ldy, int B, int H, int W,
+                      int Cin, int Cout, int dil, int act, double* gn_partial, float split_post) {
     LM_REQUIRE(x && wu_frag && y, "conv_wino44: null pointer");
     LM_REQUIRE(lm_winograd44_supported(H, W, Cin, dil) && B > 0, "conv_wino44: unsupported shape (H=%d W=%d Cin=%d dil=%d)", H, W, Cin, dil);
     LM_REQUIRE(CoutP >= Cout && CoutP % QBN == 0, "conv_wino44: CoutP=%d must be Cout=%d rounded up to %d", CoutP, Cout, QBN);
@@ -1123,17 +1226,49 @@ LM_API int lm_conv3x3_winograd44_f32(void* stream, const float* x, int ldx, cons
     static_assert(36 * 32 * 32 <= 2 * QRAWF + QVF, "the product buffer of the epilogue fits");
     const long blocks = (p.g.T / QBM) * ((Cout + QBN - 1) / QBN);
     LM_REQUIRE(blocks > 0 && blocks < (1L << 31) && p.g.T % QBM == 0, "conv_wino44: bad grid %ld", blocks);
-    if (int e = lm_ensure_dynamic_lds((const void*)wino44_kernel, lds)) return e;
-    hipLaunchKernelGGL(wino44_kernel, dim3((unsigned)blocks), dim3(256), lds, (hipStream_t)stream, p);
+    p.post = split_post != 0.f ? split_post : 1.f;
+    if (split_post != 0.f) {
+        if (int e = lm_ensure_dynamic_lds((const void*)wino44_kernel<true>, lds)) return e;
+        hipLaunchKernelGGL(wino44_kernel<true>, dim3((unsigned)blocks), dim3(256), lds, (hipStream_t)stream, p);
+    } else {
+        if (int e = lm_ensure_dynamic_lds((const void*)wino44_kernel<false>, lds)) return e;
+        hipLaunchKernelGGL(wino44_kernel<false>, dim3((unsigned)blocks), dim3(256), lds, (hipStream_t)stream, p);
+    }
     LM_LAUNCH_CHECK();
     return LM_OK;
 }
 
+LM_API int lm_conv3x3_winograd44_f32(void* stream, const float* x, int ldx, const float* wu_frag, int CoutP, const float* scale,
+                                     const float* shift, const float* res, int ldr, float* y, int ldy, int B, int H, int W,
+                                     int Cin, int Cout, int dil, int act, double* gn_partial) {
+    return w44_launch(stream, x, ldx, wu_frag, CoutP, scale, shift, res, ldr, y, ldy, B, H, W, Cin, Cout, dil, act, gn_partial, 0.f);
+}
+
+// SECOND LINE (never the headline path): the same convolution with the Winograd-domain products on the fp16 matrix pipe, every fp32
+// operand split into two fp16 terms, three products per pair, fp32 accumulation (see w44_split2).  wu_split = lm_wino44_split_fragments
+// of the fragments of U * u_scale (u_scale a power of two chosen by the caller so that max |U| u_scale ~ 2^13); post = 1 / u_scale.
+LM_API int lm_conv3x3_winograd44_split_f32(void* stream, const float* x, int ldx, const float* wu_split, int CoutP, const float* scale,
+                                           const float* shift, const float* res, int ldr, float* y, int ldy, int B, int H, int W,
+                                           int Cin, int Cout, int dil, int act, double* gn_partial, float post) {
+    LM_REQUIRE(post > 0.f, "conv_wino44(split): post scale must be positive");
+    return w44_launch(stream, x, ldx, wu_split, CoutP, scale, shift, res, ldr, y, ldy, B, H, W, Cin, Cout, dil, act, gn_partial, post);
+}
+
+// fragments [n_quads][4] fp32 (ops.pack_wino44_fragments of the scaled U) -> the fp16 term words of the split kernel, same shape
+LM_API int lm_wino44_split_fragments(void* stream, const float* frag, float* out, long n_quads) {
+    LM_REQUIRE(frag && out && n_quads > 0 && n_quads < (1L << 38), "wino44_split_fragments: bad arguments");
+    hipLaunchKernelGGL(wino44_split_frag_kernel, dim3((unsigned)((n_quads + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+                       reinterpret_cast<const f32x4*>(frag), reinterpret_cast<f32x4*>(out), n_quads);
+    LM_LAUNCH_CHECK();
+    return LM_OK;
+}
+
+
 // The same convolution through the materialising twin (bit-identical results; test infrastructure).  wu = U as [36][CoutP][Cin]
 // (ops.pack_wino44); workspace >= lm_winograd44_twin_workspace_bytes.
-LM_API int lm_conv3x3_winograd44_twin_f32(void* stream, const float* x, int ldx, const float* wu, int CoutP, const float* scale,
-                                          const float* shift, const float* res, int ldr, float* y, int ldy, int B, int H, int W,
-                                          int Cin, int Cout, int dil, int act, void* workspace, long workspace_bytes) {
+static int w44_twin(void* stream, const float* x, int ldx, const float* wu, int CoutP, const float* scale,
+                    const float* shift, const float* res, int ldr, float* y, int ldy, int B, int H, int W,
+                    int Cin, int Cout, int dil, int act, void* workspace, long workspace_bytes, float split_post) {
     LM_REQUIRE(x && wu && y && workspace, "conv_wino44_twin: null pointer");
     LM_REQUIRE(Cin > 0 && Cin % 8 == 0 && dil >= 1 && B > 0 && H > 0 && W > 0, "conv_wino44_twin: bad shape");
     LM_REQUIRE(CoutP >= Cout && CoutP % 32 == 0 && ldx >= Cin && ldy >= Cout, "conv_wino44_twin: bad CoutP / leading dimension");
@@ -1146,12 +1281,32 @@ LM_API int lm_conv3x3_winograd44_twin_f32(void* stream, const float* x, int ldx,
     hipStream_t s = (hipStream_t)stream;
     hipLaunchKernelGGL(wino44_input_kernel, dim3((unsigned)((g.T * Cin + 255) / 256)), dim3(256), 0, s, x, ldx, g, Cin, V);
     LM_LAUNCH_CHECK();
-    hipLaunchKernelGGL(wino44_gemm_kernel, dim3((unsigned)(g.T / 32), (unsigned)(CoutP / 32), 36), dim3(64), 0, s, (const float*)V, wu, M,
-                       g.T, Cin, CoutP);
+    if (split_post != 0.f)
+        hipLaunchKernelGGL(wino44_gemm_kernel<true>, dim3((unsigned)(g.T / 32), (unsigned)(CoutP / 32), 36), dim3(64), 0, s, (const float*)V, wu, M,
+                           g.T, Cin, CoutP);
+    else
+        hipLaunchKernelGGL(wino44_gemm_kernel<false>, dim3((unsigned)(g.T / 32), (unsigned)(CoutP / 32), 36), dim3(64), 0, s, (const float*)V, wu, M,
+                           g.T, Cin, CoutP);
     LM_LAUNCH_CHECK();
     W44Epi e;
     e.scale = scale; e.shift = shift; e.res = res; e.y = y; e.ldr = ldr; e.ldy = ldy; e.Cout = Cout; e.act = act;
+    e.post = split_post;
     hipLaunchKernelGGL(wino44_output_kernel, dim3((unsigned)((g.T * Cout + 255) / 256)), dim3(256), 0, s, (const float*)M, g, CoutP, e);
     LM_LAUNCH_CHECK();
     return LM_OK;
+}
+
+LM_API int lm_conv3x3_winograd44_twin_f32(void* stream, const float* x, int ldx, const float* wu, int CoutP, const float* scale,
+                                          const float* shift, const float* res, int ldr, float* y, int ldy, int B, int H, int W,
+                                          int Cin, int Cout, int dil, int act, void* workspace, long workspace_bytes) {
+    return w44_twin(stream, x, ldx, wu, CoutP, scale, shift, res, ldr, y, ldy, B, H, W, Cin, Cout, dil, act, workspace, workspace_bytes, 0.f);
+}
+
+// The split convolution through the materialising twin: wu = U * u_scale as [36][CoutP][Cin] fp32 (split on the fly), post = 1 / u_scale.
+// Bit-identical to lm_conv3x3_winograd44_split_f32 (test infrastructure).
+LM_API int lm_conv3x3_winograd44_split_twin_f32(void* stream, const float* x, int ldx, const float* wu, int CoutP, const float* scale,
+                                                const float* shift, const float* res, int ldr, float* y, int ldy, int B, int H, int W,
+                                                int Cin, int Cout, int dil, int act, void* workspace, long workspace_bytes, float post) {
+    LM_REQUIRE(post > 0.f, "conv_wino44_twin(split): post scale must be positive");
+    return w44_twin(stream, x, ldx, wu, CoutP, scale, shift, res, ldr, y, ldy, B, H, W, Cin, Cout, dil, act, workspace, workspace_bytes, post);
 }

@@ -7,6 +7,7 @@ is read from ``x.stride(3)``).  Every function raises if a tensor is not on a HI
 CPU fallback.
 """
 import ctypes as C
+import math
 
 import torch
 
@@ -98,6 +99,36 @@ def pack_wino44_fragments(wu):
     return t.permute(0, 3, 1, 4, 2, 5).contiguous().reshape(36, ci // 8, cop // 32, 64, 4)
 
 
+class SplitFragments:
+    """U fragments of the split-precision second line (lm_conv3x3_winograd44_split_f32): `words` = the fp16 term words in fragment order
+    (a float32 tensor holding bits, the shape pack_wino44_fragments gives), `post` = 1 / the power of two U was scaled by."""
+    __slots__ = ('words', 'post')
+
+    def __init__(self, words, post):
+        self.words, self.post = words, float(post)
+
+    @property
+    def shape(self):
+        return self.words.shape
+
+
+def split_scale(wu):
+    """The power of two that brings max |U| to [2^12, 2^13): the fp16 low terms of U then stay normal numbers."""
+    m = float(wu.abs().max())
+    return 1.0 if m == 0.0 else 2.0 ** (12 - math.floor(math.log2(m)))
+
+
+def pack_wino44_fragments_split(wu):
+    """pack_wino44 output U [36, CoutP, Cin] (on the GPU) -> SplitFragments: U * 2^k in fragment order, split into fp16 term words on the
+    device by the helper the kernels use (lm_wino44_split_fragments)."""
+    assert wu.is_cuda, 'the fragments are split on the device (no CPU path)'
+    sc = split_scale(wu)
+    frag = pack_wino44_fragments(wu * sc)
+    out = torch.empty_like(frag)
+    check(lib().lm_wino44_split_fragments(_stream(), _ptr(frag), _ptr(out), frag.numel() // 4))
+    return SplitFragments(out, 1.0 / sc)
+
+
 def pack_small(w):
     """[Cout<=16,Cin,KH,KW] -> [KH*KW, Cin, 16]."""
     co, ci, kh, kw = w.shape
@@ -181,10 +212,16 @@ def conv_wino44(x, wf, cout, dil=1, scale=None, shift=None, res=None, act=ACT_NO
     if gn_eps is not None:
         part = torch.empty((B, lib().lm_winograd44_gn_chunks(H, W, dil), cout, 2), device=x.device, dtype=torch.float64)
     tiles = lib().lm_winograd44_tiles(B, H, W, dil)
-    _hooked(f'wino44 {cin}->{cout} k3x3 d{dil} @{H}x{W} B{B}', 2.0 * B * H * W * cout * cin * 9,
-            lambda: check(lib().lm_conv3x3_winograd44_f32(_stream(), _ptr(x), ldx, _ptr(wf), cop, _ptr(scale), _ptr(shift), _ptr(r), ldr,
-                                                          _ptr(y), ldy, B, H, W, cin, cout, dil, act, _ptr(part))),
-            2.0 * 36 * tiles * cin * cout)
+    if isinstance(wf, SplitFragments):          # second line: fp16 x 2 split products (three MFMA terms per product: 3 x the algorithmic count executed)
+        _hooked(f'wino44split {cin}->{cout} k3x3 d{dil} @{H}x{W} B{B}', 2.0 * B * H * W * cout * cin * 9,
+                lambda: check(lib().lm_conv3x3_winograd44_split_f32(_stream(), _ptr(x), ldx, _ptr(wf.words), cop, _ptr(scale), _ptr(shift), _ptr(r),
+                                                                    ldr, _ptr(y), ldy, B, H, W, cin, cout, dil, act, _ptr(part), wf.post)),
+                3 * 2.0 * 36 * tiles * cin * cout)
+    else:
+        _hooked(f'wino44 {cin}->{cout} k3x3 d{dil} @{H}x{W} B{B}', 2.0 * B * H * W * cout * cin * 9,
+                lambda: check(lib().lm_conv3x3_winograd44_f32(_stream(), _ptr(x), ldx, _ptr(wf), cop, _ptr(scale), _ptr(shift), _ptr(r), ldr,
+                                                              _ptr(y), ldy, B, H, W, cin, cout, dil, act, _ptr(part))),
+                2.0 * 36 * tiles * cin * cout)
     if gn_eps is None:
         return y
     if gn_split > 1:
@@ -196,9 +233,10 @@ def conv_wino44(x, wf, cout, dil=1, scale=None, shift=None, res=None, act=ACT_NO
     return y, stats
 
 
-def conv_wino44_twin(x, wu, cout, dil=1, scale=None, shift=None, res=None, act=ACT_NONE, out=None):
+def conv_wino44_twin(x, wu, cout, dil=1, scale=None, shift=None, res=None, act=ACT_NONE, out=None, split=False):
     """The same convolution through the materialising twin (V and M tensors in HBM, three plain kernels): test infrastructure,
-    bit-identical to conv_wino44.  wu = pack_wino44(w)."""
+    bit-identical to conv_wino44.  wu = pack_wino44(w).  split: the twin of the split-precision second line (same scale rule as
+    pack_wino44_fragments_split)."""
     x, ldx = as_nhwc(x)
     B, cin, H, W = x.shape
     cop = wu.shape[1]
@@ -208,6 +246,12 @@ def conv_wino44_twin(x, wu, cout, dil=1, scale=None, shift=None, res=None, act=A
     r, ldr = (None, 0) if res is None else as_nhwc(res)
     need = lib().lm_winograd44_twin_workspace_bytes(B, H, W, cin, cop, dil)
     ws = torch.empty(need, device=x.device, dtype=torch.uint8)
+    if split:
+        sc = split_scale(wu)
+        wus = (wu * sc).contiguous()
+        check(lib().lm_conv3x3_winograd44_split_twin_f32(_stream(), _ptr(x), ldx, _ptr(wus), cop, _ptr(scale), _ptr(shift), _ptr(r), ldr,
+                                                         _ptr(y), ldy, B, H, W, cin, cout, dil, act, _ptr(ws), need, 1.0 / sc))
+        return y
     check(lib().lm_conv3x3_winograd44_twin_f32(_stream(), _ptr(x), ldx, _ptr(wu), cop, _ptr(scale), _ptr(shift), _ptr(r), ldr,
                                                _ptr(y), ldy, B, H, W, cin, cout, dil, act, _ptr(ws), need))
     return y

@@ -29,9 +29,15 @@ MERGE_BRANCH_CONVS = os.environ.get('LANEMAP_MERGE_BRANCH_CONVS', '1') != '0'   
 # (csrc/conv_mfma.hip).  The F(2x2,3x3) family of rounds 1-3 was removed in round 5 (history: profiles/README.md).
 WINO_F44 = os.environ.get('LANEMAP_WINO_F44', '1') != '0'
 WINO_F44_MIN_CIN = int(os.environ.get('LANEMAP_WINO_F44_MIN_CIN', '64'))
+# SECOND LINE, never the default: LANEMAP_WINO_SPLIT=1 runs the same F(4x4) kernel with its Winograd-domain products on the fp16 matrix
+# pipe (every fp32 operand in two fp16 terms, three products, fp32 accumulation: csrc/conv_wino44.hip, w44_split2).  Not bit-identical to
+# the exact path; bench.py reports it as `second_line`, the headline stays exact fp32.
+WINO_SPLIT = os.environ.get('LANEMAP_WINO_SPLIT', '0') != '0'
 
 
 def _frag44(w):
+    if WINO_SPLIT:
+        return ops.pack_wino44_fragments_split(ops.pack_wino44(w))
     return ops.pack_wino44_fragments(ops.pack_wino44(w))
 
 

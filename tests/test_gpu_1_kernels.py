@@ -782,6 +782,70 @@ def test_conv_winograd44_random_shapes_vs_twin(dev):
 
 
 
+def test_conv_winograd44_split_second_line(dev):
+    """The split-precision SECOND LINE of wino44_kernel (LANEMAP_WINO_SPLIT=1; fp16 x 2 terms per fp32 operand, three v_mfma_f32_32x32x8_f16
+    products, fp32 accumulation): bit-identical to its own materialising twin (same split helper, same three products in the same order) on
+    seeded random shapes, deterministic, and as close to an fp64 convolution as the exact fp32 kernel is (the dropped lo x lo term is 2^-22
+    of a product): the error of the split kernel may exceed the exact kernel's by at most 50 % + 2e-6 on every shape.  Also: U scaled by
+    the layer's power of two is undone exactly (a layer whose weights are 2^-7 times smaller gives 2^-7 times the same bits), and inputs
+    spanning six decades keep the error relative to the output scale."""
+    from lanemapping_amd import ops
+    rng = np.random.RandomState(6606)
+    done = 0
+    worst = 0.0
+    while done < 12:
+        dil = int(rng.choice([1, 1, 2, 3]))
+        W = int(rng.randint(41 * dil, 57 * dil + 100))
+        H = int(rng.randint(5, 70))
+        cin = 16 * int(rng.choice([1, 4, 8, 16, 5]))
+        cout = int(rng.choice([64, 128, 256, rng.randint(1, 200)]))
+        B = int(rng.randint(1, 3))
+        if not ops.wino44_supported(H, W, cin, dil):
+            continue
+        done += 1
+        g = torch.Generator().manual_seed(2000 + done)
+        amp = 10.0 ** rng.uniform(-3, 2)                     # activations from 1e-3 to 1e2
+        x = ops.new_act(B, cin, H, W, dev)
+        x.copy_((torch.randn((B, cin, H, W), generator=g) * amp).to(dev))
+        w = (torch.randn((cout, cin, 3, 3), generator=g) / (cin * 9) ** 0.5).to(dev)
+        use_scale, use_res, relu = bool(rng.randint(2)), bool(rng.randint(2)), bool(rng.randint(2))
+        sc = (torch.rand(cout, generator=g) + 0.5).to(dev) if use_scale else None
+        sh = (torch.randn(cout, generator=g) * amp).to(dev)
+        res = None
+        if use_res:
+            res = ops.new_act(B, cout, H, W, dev)
+            res.copy_((torch.randn((B, cout, H, W), generator=g) * amp).to(dev))
+        act = ops.ACT_RELU if relu else ops.ACT_NONE
+        wu = ops.pack_wino44(w)
+        ws = ops.pack_wino44_fragments_split(wu)
+        assert isinstance(ws, ops.SplitFragments) and ws.words.shape == ops.pack_wino44_fragments(wu).shape
+        y0 = ops.conv_wino44_twin(x, wu, cout, dil, scale=sc, shift=sh, res=res, act=act, split=True)
+        y1 = ops.conv_wino44(x, ws, cout, dil, scale=sc, shift=sh, res=res, act=act)
+        y2 = ops.conv_wino44(x, ws, cout, dil, scale=sc, shift=sh, res=res, act=act)
+        ye = ops.conv_wino44(x, ops.pack_wino44_fragments(wu), cout, dil, scale=sc, shift=sh, res=res, act=act)
+        tag = f'split shape {done}: B{B} {cin}->{cout} {H}x{W} d{dil} amp={amp:.1e} scale={use_scale} res={use_res} relu={relu}'
+        assert torch.equal(y0, y1), (tag, float((y0 - y1).abs().max()))
+        assert torch.equal(y1, y2), tag
+        ref = F.conv2d(x.double(), w.double(), None, 1, dil, dil)
+        if sc is not None:
+            ref = ref * sc.double().view(1, -1, 1, 1)
+        ref = ref + sh.double().view(1, -1, 1, 1)
+        if res is not None:
+            ref = ref + res.double()
+        if relu:
+            ref = F.relu(ref)
+        scale = max(1.0, float(ref.abs().max()))
+        e_split, e_exact = float((y1.double() - ref).abs().max()) / scale, float((ye.double() - ref).abs().max()) / scale
+        worst = max(worst, e_split / max(e_exact, 1e-9))
+        print(f'{tag}: error / output scale: split {e_split:.2e}, exact fp32 {e_exact:.2e}')
+        assert e_split <= 1.5 * e_exact + 2e-6, tag
+        if done == 1:                                        # the power of two of U is undone exactly
+            y3 = ops.conv_wino44(x, ops.pack_wino44_fragments_split(ops.pack_wino44(w * 2.0 ** -7)), cout, dil)
+            y4 = ops.conv_wino44(x, ws, cout, dil)
+            assert torch.equal(y3 * 2.0 ** 7, y4), tag
+    print(f'worst split / exact error ratio over {done} shapes: {worst:.2f}')
+
+
 @pytest.mark.parametrize('seed', [11, 12, 13, 14])
 def test_raster_fuzz_vs_c_oracle(dev, seed):
     """Random tile geometry (rotation, non-unit quaternion, offsets, resolutions, tile size), ragged point counts that are

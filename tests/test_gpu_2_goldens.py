@@ -260,7 +260,8 @@ _SOFT_BUDGET = 1
 
 
 def _log_exact(tag, exact, seeds):
-    route = 'direct (LANEMAP_WINO_F44=0)' if os.environ.get('LANEMAP_WINO_F44', '1') == '0' else 'F(4x4) default'
+    route = ('direct (LANEMAP_WINO_F44=0)' if os.environ.get('LANEMAP_WINO_F44', '1') == '0' else
+             'F(4x4) fp16x2 split second line (LANEMAP_WINO_SPLIT=1)' if os.environ.get('LANEMAP_WINO_SPLIT', '0') != '0' else 'F(4x4) default')
     line = (f'{tag} [{route}]: {sum(exact)} of {len(seeds)} stability-screened tiles identical to the reference in EVERY endpoint; soft-decision '
             f'differences on seeds {[s for s, e in zip(seeds, exact) if not e]}')
     print(line)
@@ -500,7 +501,7 @@ def test_tile_pipeline_graph_replay_bit_identical(dev):
     assert len(graph._graphs) == 0
 
 
-@pytest.mark.parametrize('switch', ['LANEMAP_WINO_F44=0', 'LANEMAP_GRAPHS=1', 'LANEMAP_MERGE_BRANCH_CONVS=0',
+@pytest.mark.parametrize('switch', ['LANEMAP_WINO_F44=0', 'LANEMAP_WINO_SPLIT=1', 'LANEMAP_GRAPHS=1', 'LANEMAP_MERGE_BRANCH_CONVS=0',
                                     'LANEMAP_W44_ORDER=0 LM_CONV_LATERAL=0 LM_CONV_TINYK=0 LM_CONV_SMALLM=100 LANEMAP_WINO_F44_MIN_CIN=128 LM_RASTER_BAND_ROWS=16 LANEMAP_ROCTX=1',
                                     'LM_STEM_VALU=1 LM_GN_UP_LDS=0 LM_GN_SUM_LDS=0 LM_SMALL_CONV_VALU=1 LM_HEAD_TOKENS_GATHER=1 LM_HEAD_STAGE2_DIRECT=1'])
 def test_goldens_under_every_advertised_switch(switch):

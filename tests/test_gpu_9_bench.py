@@ -35,9 +35,9 @@ def test_bench_default_command(dev):
     assert d['steps'] == 2 and d['n_gpus'] == 1 and d['value'] > 10
     assert d['config']['stream_check'].startswith('lanes and endpoints'), d['config']['stream_check']
     rf = d['roofline']
+    f44 = os.environ.get('LANEMAP_WINO_F44', '1') != '0'                 # (the suite itself may run under the switch)
     assert {'bound', 'achieved', 'peak', 'unit', 'frac', 'traffic', 'algorithmic_equiv_tflops', 'per_kernel'} <= set(rf)
     assert 0.0 < rf['frac'] <= 1.0 and abs(rf['frac'] - rf['achieved'] / rf['peak']) < 1e-9
-    f44 = os.environ.get('LANEMAP_WINO_F44', '1') != '0'                 # (the suite itself may run under the switch)
     assert rf['algorithmic_equiv_tflops'] >= rf['achieved'] and abs(rf['frac_survey_8d'] - rf['algorithmic_equiv_tflops'] / rf['peak']) < 1e-9
     assert all(0.0 <= v['frac'] <= 1.0 for v in rf['per_kernel'].values())
     rr = d['raster_roofline']
@@ -45,7 +45,13 @@ def test_bench_default_command(dev):
     assert rr['bound'] == 'hbm' and 0.1 < rr['frac'] < 1.0 and rr['frac'] < rr['frac_survey_8d'] < 1.0
     assert abs(rr['frac'] - rr['achieved'] / rr['peak']) < 1e-9
     assert {'value', 'unit', 'cores', 'kind', 'sample'} <= set(d['cpu_baseline']) and d['cpu_baseline']['value'] > 0
-    assert d['dtype'] == 'f32' and 'second_line' not in d
+    # the headline is exact fp32; the declared second line (fp16 x 2 split Winograd products, a child run of the same command) rides along
+    assert d['dtype'] == 'f32'
+    sl = d['second_line']
+    assert 'error' not in sl and sl['value'] > 10 and sl['steps'] == 10 and 'NOT bit-identical' in sl['what'] and sl['dtype'] != 'f32'
+    assert sl['stream_check'].startswith('lanes and endpoints') and sl['raster_check'].startswith('tiles 0 and 15')
+    if f44:
+        assert any('split' in k for k in sl['roofline']['per_kernel']) and 0.0 < sl['roofline']['frac'] <= 1.0
     assert (rf['winograd_ms_per_step'] > 0) == f44 and ('wino44_kernel' in rf['per_kernel']) == f44
 
 

@@ -15,7 +15,7 @@ from lanemapping_amd.boundary import build_net_from_config  # noqa: E402
 from oracle import net_ref, decode_ref  # noqa: E402
 
 dev = torch.device('cuda:0')
-route = 'direct' if os.environ.get('LANEMAP_WINO_F44', '1') == '0' else 'F(4x4)'
+route = 'direct' if os.environ.get('LANEMAP_WINO_F44', '1') == '0' else ('F(4x4) fp16x2 split' if os.environ.get('LANEMAP_WINO_SPLIT', '0') != '0' else 'F(4x4)')
 for gains, label in (({}, 'seeded weights (G10 set)'), ({'heads.offset2.2.weight': 0.02, 'heads.offset2.2.bias': 0.02}, 'G15 weight set')):
     net = build_net_from_config('Proj_polyline_fpn_vit_vertex_2', device='cpu')
     synth.fill_module_(net, 2021)
