@@ -10,7 +10,7 @@ mkdir -p $O
 cd /tmp && export TMPDIR=/tmp
 for wl in fused tiles; do
   for c in FETCH_SIZE WRITE_SIZE; do
-    rocprofv3 --pmc $c --output-format csv -d $O/${wl}_$c -o p -- python3 $R/bench.py --workload $wl --steps 2 --warmup 1 --streams 1 --no-graphs --no-cpu-baseline > /dev/null 2>> $R/gpurun_out/prof_stderr.log
+    rocprofv3 --pmc $c --output-format csv -d $O/${wl}_$c -o p -- python3 $R/bench.py --workload $wl --steps 2 --warmup 1 --streams 1 --no-graphs --no-cpu-baseline --no-second-line > /dev/null 2>> $R/gpurun_out/prof_stderr.log
   done
 done
 python3 - <<PY
@@ -27,7 +27,7 @@ for wl in ('fused', 'tiles'):
         for r in csv.DictReader(open(f)):
             n = r['Kernel_Name']
             k = ('wino44' if 'wino44_kernel' in n else 'wino_rows' if 'wino_rows' in n else 'wino_gemm' if 'wino_gemm' in n else 'wino_implicit' if ('wino_implicit' in n or 'wino_dual' in n or 'wino_pipe' in n) else 'wino_input' if 'wino_input' in n else
-                 'conv_mfma' if 'conv_mfma' in n else 'raster_partition' if 'raster_partition' in n else 'raster_band' if 'raster_band' in n else None)
+                 'conv_mfma' if ('conv_mfma' in n or 'lateral_mfma' in n) else 'raster_partition' if 'raster_partition' in n else 'raster_band' if 'raster_band' in n else None)
             if k is None: continue
             per[k][c] += float(r['Counter_Value'])
             if c == 'FETCH_SIZE': launches[k] += 1

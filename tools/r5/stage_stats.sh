@@ -8,7 +8,7 @@ STEPS=6
 mkdir -p $OUT
 export LANEMAP_ROCTX=1
 cd /tmp && export TMPDIR=/tmp
-rocprofv3 --kernel-trace --marker-trace --hip-runtime-trace --output-format csv -d $OUT/trace -o p -- python3 $R/bench.py --steps $STEPS --warmup 2 --no-cpu-baseline --no-graphs $ARGS > $OUT/bench.json 2> $OUT/bench.err
+rocprofv3 --kernel-trace --marker-trace --hip-runtime-trace --output-format csv -d $OUT/trace -o p -- python3 $R/bench.py --steps $STEPS --warmup 2 --no-cpu-baseline --no-second-line --no-graphs $ARGS > $OUT/bench.json 2> $OUT/bench.err
 cd $R
 python3 tools/r5/stage_stats.py $OUT/trace $STEPS > $OUT/stage_stats.txt 2> $OUT/stage_stats.err
 rm -rf $OUT/trace
