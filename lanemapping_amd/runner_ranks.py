@@ -19,7 +19,8 @@ Which devices: the ids are indices into what the process can see.  When the call
 (`CUDA_VISIBLE_DEVICES` / `HIP_VISIBLE_DEVICES` == the gpus string) the ranks take the visible devices 0..n-1, exactly DataParallel's
 `range(cfg.gpus)`; without a mask rank r takes device ids[r].  More ids than visible devices raises at construction with the
 equivalent `torch.distributed.run` command.  LANEMAP_TEST_DEVICE=<d> (tests on a 1-GPU box) puts every rank on device d over `gloo`
-(RCCL refuses two ranks on one device).
+(RCCL refuses two ranks on one device).  LANEMAP_RANKS_TIMEOUT=<seconds> bounds a call (default: none - a tile set may take hours);
+when it expires, or when one rank fails, the remaining ranks are ended by PID and the call raises with every rank's stderr.
 """
 import os
 import pickle

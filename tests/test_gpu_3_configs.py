@@ -406,6 +406,7 @@ def test_test_gpu_0_body_with_two_gpu_ids(dev, synth_sd, tmp_path, capfd, monkey
     path_ckpt = str(tmp_path / 'best.pth')
     torch.save({'net': {'module.' + k: v for k, v in synth_sd.items()}, 'epoch': 45}, path_ckpt)
     monkeypatch.setenv('LANEMAP_TEST_DEVICE', '0')
+    monkeypatch.setenv('LANEMAP_RANKS_TIMEOUT', '900')          # (a hung rank must fail this test, not hang the suite)
     out, runs = {}, {}
     for GPUS_EN in ('0', '0,1'):
         sub = tmp_path / ('ids' + str(len(GPUS_EN.split(','))))
