@@ -1,4 +1,5 @@
-"""Whole-network error of the HIP path against the oracle (torch-CPU fp32 restatement, bit-identical to the reference on the goldens) under
+"""Study (checker-side script: imports oracle/, which only tests/ may; moved here from tools/r4 in round 6).
+Whole-network error of the HIP path against the oracle (torch-CPU fp32 restatement, bit-identical to the reference on the goldens) under
 the 3x3-convolution route selected by the environment (default F(4x4); LANEMAP_WINO_F44=0: direct MFMA).
 Prints, per raw output, max |err|, the tensor scale and err / scale, and the decode-level errors on the G15 weight set (absolute)."""
 import os
@@ -7,7 +8,7 @@ import sys
 import numpy as np
 import torch
 
-ROOT = os.path.join(os.path.dirname(os.path.abspath(__file__)), '..', '..')
+ROOT = os.path.join(os.path.dirname(os.path.abspath(__file__)), '..')
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, 'tests', 'golden'))
 from lanemapping_amd import synth  # noqa: E402

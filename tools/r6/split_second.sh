@@ -6,8 +6,8 @@ cd $R
 rm -f $O/exact_counts.txt
 LANEMAP_WINO_SPLIT=1 LANEMAP_PARITY_LOG=$O/exact_counts.txt timeout 1200 python -m pytest tests/test_gpu_2_goldens.py -q -m gpu -k "golden_g10 or stable_golden_g15 or chain_golden_g17 or graph_replay or full_tiles_other or inside_full_batches" > $O/goldens_split.txt 2>&1; tail -4 $O/goldens_split.txt
 cat $O/exact_counts.txt
-python tools/r4/numerics_e2e.py > $O/numerics_e2e.txt 2>/dev/null
-LANEMAP_WINO_SPLIT=1 python tools/r4/numerics_e2e.py >> $O/numerics_e2e.txt 2>/dev/null
+python tests/study_numerics_e2e.py > $O/numerics_e2e.txt 2>/dev/null
+LANEMAP_WINO_SPLIT=1 python tests/study_numerics_e2e.py >> $O/numerics_e2e.txt 2>/dev/null
 cat $O/numerics_e2e.txt
 python bench.py --steps 60 --cpu-budget-s 5 2>$O/bench.err | tail -1 > $O/bench_fused_with_second_line.json
 python -c "
