@@ -209,6 +209,21 @@ for k, (B, h, w) in enumerate([(2, 96, 96), (1, 37, 53), (1, 5, 7), (3, 288, 288
     out[f'res_{k}'] = ops.conv_mfma(x, ops.pack_mfma(wt), 256, shift=bias, res=r).permute(0, 2, 3, 1).cpu().numpy()
     rr = torch.randn(h * w, 256, generator=g).to(dev)
     out[f'rows_{k}'] = ops.conv_mfma(x, ops.pack_mfma(wt), 256, shift=bias, res=rr, res_rows=h * w).permute(0, 2, 3, 1).cpu().numpy()
+# strided views (what the FPN passes): input channels inside a wider tensor, residual and output as channel slices of wider tensors
+torch.manual_seed(607)                  # (.normal_() below draws from the global generator: the same values in both processes)
+wide = ops.new_act(2, 160, 64, 96, dev).normal_()
+wt = (torch.randn(256, 64, 1, 1, generator=g) / 8).to(dev)
+bias = torch.randn(256, generator=g).to(dev)
+cw = ops.new_act(2, 320, 32, 48, dev).normal_()
+ow = ops.new_act(2, 288, 64, 96, dev).zero_()
+ops.conv_mfma(wide[:, 32:96], ops.pack_mfma(wt), 256, shift=bias, res_up=cw[:, 64:320], out=ow[:, 16:272])
+out['up_views'] = ow.permute(0, 2, 3, 1).cpu().numpy()
+wide = ops.new_act(2, 192, 32, 64, dev).normal_()
+wt = (torch.randn(256, 128, 1, 1, generator=g) / 11).to(dev)
+rw = ops.new_act(2, 288, 32, 64, dev).normal_()
+ow = ops.new_act(2, 272, 32, 64, dev).zero_()
+ops.conv_mfma(wide[:, 64:192], ops.pack_mfma(wt), 256, shift=bias, res=rw[:, 32:288], out=ow[:, 0:256])
+out['res_views'] = ow.permute(0, 2, 3, 1).cpu().numpy()
 np.savez(sys.argv[1], **out)
 """
 
@@ -217,7 +232,7 @@ def test_lateral_kernel_bit_identical(dev, tmp_path):
     """lateral_mfma_kernel (round 6: the FPN's 1x1 laterals - weights resident in registers as the MFMA's A operand, pixels as B, no
     LDS / barrier, residual and stores straight from the accumulator quads, persistent workgroups) against the tiled conv_mfma_kernel
     (LM_CONV_LATERAL=0, read once per process) on the same inputs, bit for bit: bilinear coarse residual, plain residual, residual rows;
-    ragged sizes, fewer tiles than XCDs, more tiles than workgroups."""
+    ragged sizes (which fall back to the tiled kernel), fewer tiles than XCDs, more tiles than workgroups, strided channel-slice views."""
     import subprocess
     import sys
     outs = {}
@@ -227,7 +242,7 @@ def test_lateral_kernel_bit_identical(dev, tmp_path):
                            env=dict(os.environ, LM_CONV_LATERAL=flag))
         assert r.returncode == 0, r.stderr[-2000:]
         outs[flag] = np.load(path)
-    assert len(outs['1'].files) == 12
+    assert len(outs['1'].files) == 14
     for k in outs['1'].files:
         assert np.array_equal(outs['1'][k], outs['0'][k]), f'{k}: lateral_mfma_kernel differs from conv_mfma_kernel'
 
