@@ -642,6 +642,8 @@ static int conv_dispatch(void* stream, const float* x, int ldx, const float* wp,
         // round 5: 128 x 128 tiles of EIGHT waves (32 x 64 sub-tiles, 4 accumulators per wave) beat the 64 x 64 / four-wave tiles of round 4 by
         // 3-8 % on the laterals (64->256 @288^2 + upsample_add 1.021 -> 0.986 ms, 128->256 @144^2 0.336 -> 0.310, 256->256 @144^2 0.432 ->
         // 0.396 at B = 16; 64 x 128, 64 x 256 and 128 x 256 tiles measured between); the k order of an output does not depend on the tile
+        // (69,632 B of dynamic LDS for the eight staging tiles and 512 threads: fine on gfx950's 160 KB - the only target of this library;
+        //  lm_ensure_dynamic_lds reports the error on a device that cannot grant it, there is deliberately no second tile shape to fall back to)
         if ((long)KH * KW * Cin <= tiny_k) return launch<128, 128, 32, 64>(p, s);
     }
     // small-M GEMMs (ViT tokens): 128x128 tiles would leave most of the 256 CUs idle -> 64x64 tiles, 4x the workgroups
