@@ -19,7 +19,7 @@ for cin, cout, hw, dil in [(256, 256, 288, 1), (256, 256, 144, 2), (128, 128, 14
     x = ops.new_act(B, cin, hw, hw, dev).normal_()
     w = torch.randn((cout, cin, 3, 3), device=dev) / (cin * 9) ** 0.5
     wf = ops.pack_wino44_fragments_split(ops.pack_wino44(w)) if os.environ.get('QPROF_SPLIT') else ops.pack_wino44_fragments(ops.pack_wino44(w))
-    res = ops.new_act(B, cout, hw, hw, dev).normal_()
+    res = None if os.environ.get('QPROF_NORES') else ops.new_act(B, cout, hw, hw, dev).normal_()
     y = ops.new_act(B, cout, hw, hw, dev)
     ops.conv_wino44(x, wf, cout, dil, res=res, act=ops.ACT_RELU, out=y)
     torch.cuda.synchronize()
