@@ -198,3 +198,58 @@ def test_skeleton_published_shapes():
     ringsk = mu.skeletonize_lee(ring)
     rad = rr[ringsk == 1]
     assert rad.min() >= 16.5 and rad.max() <= 19.5               # the medial circle of the annulus (radius 18) within 1.5 px
+
+
+def test_synth_las_point_records_match_the_las_layout(tmp_path):
+    """synth.las_point_records (what `bench.py --points las` keeps in pinned host memory) lays a point out like an ASPRS LAS 1.2 format-0
+    record: the coordinate and intensity fields equal the oracle writer's for the same points, record length 20, and the numpy LAS reader
+    decodes a file made of these records to the quantised coordinates."""
+    from lanemapping_amd import synth
+    from oracle import las_ref
+    pts = synth.las_points(9, 5000)
+    rec = synth.las_point_records(pts, 1e-3).reshape(-1, 20)
+    path = str(tmp_path / 'a.las')
+    q = las_ref.write_las(path, pts[:, :3].astype(np.float64), pts[:, 3], point_format=0, scale=(1e-3,) * 3, offset=(0., 0., 0.))
+    data = np.fromfile(path, np.uint8)
+    off = int(np.frombuffer(data[96:100].tobytes(), '<u4')[0])
+    ref = data[off:off + 20 * len(pts)].reshape(-1, 20)
+    assert las_ref.RECORD_LEN[0] == 20 and np.array_equal(rec[:, :14], ref[:, :14])        # X, Y, Z (int32), intensity (u16)
+    assert np.array_equal(rec[:, 0:12].copy().view('<i4').reshape(-1, 3), q)
+    # a file whose records are the synth ones decodes to the same points through the reader
+    with open(path, 'r+b') as f:
+        f.seek(off)
+        f.write(rec.tobytes())
+    got = las_ref.read_las_ref(path, normalise=False)
+    assert np.array_equal(got[:, :3], q * 1e-3) and np.array_equal(got[:, 3], np.floor(pts[:, 3]).astype(np.float64))
+
+
+def test_bench_second_line_never_breaks_the_headline(monkeypatch):
+    """bench.second_line: whatever happens to the child run (non-zero exit, no JSON line, an exception), the headline gets an `error` entry
+    instead of an exception; a good child line is reduced to the declared fields."""
+    import json
+    import subprocess
+    import types
+    import bench
+    args = types.SimpleNamespace(steps=100, no_graphs=False, streams=None)
+    seen = {}
+
+    def fake(rc, out, err=''):
+        def run(cmd, **kw):
+            seen['cmd'], seen['env'] = cmd, kw['env']
+            return types.SimpleNamespace(returncode=rc, stdout=out, stderr=err)
+        return run
+    monkeypatch.setattr(subprocess, 'run', fake(1, '', 'boom'))
+    assert 'exit code 1' in bench.second_line(args)['error'] and 'boom' in bench.second_line(args)['error']
+    assert seen['env']['LANEMAP_WINO_SPLIT'] == '1' and '--no-second-line' in seen['cmd'] and seen['cmd'][seen['cmd'].index('--steps') + 1] == '40'
+    monkeypatch.setattr(subprocess, 'run', fake(0, 'no json here'))
+    assert 'error' in bench.second_line(args)
+
+    def boom(cmd, **kw):
+        raise subprocess.TimeoutExpired(cmd, 900)
+    monkeypatch.setattr(subprocess, 'run', boom)
+    assert 'TimeoutExpired' in bench.second_line(args)['error']
+    line = {'value': 460.0, 'unit': 'tiles/s', 'ms_per_step': 34.7, 'steps': 40, 'dtype': 'f16x2-split', 'config': {'windows_tiles_per_s': None, 'stream_check': 'ok', 'raster_check': 'ok'},
+            'roofline': {'per_kernel': {}, 'kernel_ms_per_step': 30.0, 'winograd_ms_per_step': 26.0, 'frac': 0.2, 'scope': 's'}}
+    monkeypatch.setattr(subprocess, 'run', fake(0, 'noise\n' + json.dumps(line) + '\n'))
+    sl = bench.second_line(args)
+    assert sl['value'] == 460.0 and sl['steps'] == 40 and 'NOT bit-identical' in sl['what'] and sl['roofline']['frac'] == 0.2 and 'error' not in sl
