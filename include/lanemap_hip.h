@@ -284,13 +284,15 @@ int lm_las_decode_points(void* stream, const unsigned char* records, int record_
                          float* out_xyzi);
 
 /* ---- PNG tile ingest (replaces PIL in `load_img`, baseline/datasets/laserlane_proposals.py:85-98 and laserlane.py:214-219:
- * np.array(Image.open(path)) -> uint8 HWC).  Host code (zlib), 8-bit non-interlaced grey / grey+alpha / RGB / RGBA only; palette,
- * 16-bit and Adam7 files are refused; chunk CRCs and the zlib checksum are verified.  C = channels (1, 2, 3, 4).
+ * np.array(Image.open(path)) -> uint8 HWC).  Host code, no third-party library (PIL runs zlib; the DEFLATE decoder here is
+ * csrc/inflate.h), 8-bit non-interlaced grey / grey+alpha / RGB / RGBA only; palette, 16-bit and Adam7 files are refused; chunk CRCs
+ * and the zlib Adler-32 are verified.  C = channels (1, 2, 3, 4).
  * lm_png_decode_files_u8 inflates n files of identical geometry on `threads` host threads into out [n][H][W][C], the layout
- * lm_tile_ingest_u8 takes. */
+ * lm_tile_ingest_u8 takes.  lm_zlib_inflate is that decoder on a bare zlib stream (RFC 1950), *produced = inflated bytes. */
 int lm_png_info(const unsigned char* data, long size, int* H, int* W, int* C);
 int lm_png_decode_u8(const unsigned char* data, long size, unsigned char* out_hwc, long out_bytes);
 int lm_png_decode_files_u8(const char* const* paths, int n, unsigned char* out_nhwc, int H, int W, int C, int threads);
+int lm_zlib_inflate(const unsigned char* data, long size, unsigned char* out, long capacity, long* produced);
 
 /* ---- per-tile polyline JSON (save_lane_seq_2d, baseline/utils/io_utils.py:58-93: json.dump(records, indent=4)) ----------------
  * lane_vertexes [n_lines][row_size][3] doubles = (row, col, semantic), a vertex exists iff col > 0, lines with < 2 vertices are dropped.

@@ -112,6 +112,7 @@ SIGNATURES = {
     'lm_png_info': (i32, [vp, i64, C.POINTER(i32), C.POINTER(i32), C.POINTER(i32)]),
     'lm_png_decode_u8': (i32, [vp, i64, vp, i64]),
     'lm_png_decode_files_u8': (i32, [C.POINTER(C.c_char_p), i32, vp, i32, i32, i32, i32]),
+    'lm_zlib_inflate': (i32, [vp, i64, vp, i64, C.POINTER(i64)]),
     'lm_lane_json_text': (i64, [vp, i32, i32, i32, vp, i64]),
     'lm_lane_json_write': (i32, [vp, i32, i32, i32, C.c_char_p]),
     'lm_seqs_json_write': (i32, [vp, vp, i32, i32, i32, C.c_char_p]),

@@ -49,7 +49,7 @@ def build(force=False, verbose=True):
             raise RuntimeError(f'hipcc failed on {src}')
         if verbose and out.strip():
             sys.stderr.write(out.decode())
-    cmd = [hipcc, '--offload-arch=gfx950', '-shared', '-fPIC', '-o', LIB] + objs + ['-lz']   # zlib: PNG tile reader
+    cmd = [hipcc, '--offload-arch=gfx950', '-shared', '-fPIC', '-o', LIB] + objs
     subprocess.check_call(cmd)
     if verbose:
         print(f'built {LIB}')

@@ -1,16 +1,17 @@
 // PNG tile reader: the reference's `load_img` (datasets/laserlane_proposals.py:85-98, laserlane.py:214-219) is
 // `np.array(Image.open(path))` -> uint8 HWC; this is the same decode without PIL and without the GIL, so a batch of tiles is inflated on
-// the host thread pool while the GPU works on the previous batch (at 220 tiles/s one GPU consumes ~5 cores of zlib inflate).
+// the host thread pool while the GPU works on the previous batch.  The DEFLATE decoder is this library's own (inflate.h: two literals per
+// table lookup - a BEV tile is sensor noise that deflate stores as short literal codes - ~2.3 x zlib's inflate on such a tile).
 // Scope = what BEV tiles are: 8-bit, non-interlaced, greyscale / grey+alpha / RGB / RGBA.  Everything else (palette, 16-bit, Adam7) is
 // refused with a message, never guessed.  Chunk CRCs and the zlib Adler checksum are verified: a damaged tile is an error, not noise.
 // Host code only (no HIP calls).
 #include "common.h"
-
-#include <zlib.h>
+#include "inflate.h"
 
 #include <atomic>
 #include <cstdlib>
 #include <cstring>
+#include <mutex>
 #include <thread>
 #include <vector>
 
@@ -57,6 +58,43 @@ inline int paeth(int a, int b, int c) {
     return (pa <= pb && pa <= pc) ? a : (pb <= pc ? b : c);
 }
 
+// Paeth rows of 3- and 4-byte pixels: one pixel per step in 16-bit lanes, the predictor chosen by compares and masks instead of
+// branches (on sensor noise the three-way choice is a coin toss: the scalar loop spends most of its time on mispredictions).  The
+// only serial dependency is the pixel to the left.  Row ends are handled bytewise by the caller's scalar loop.
+#if defined(__SSE2__)
+template <int BP>
+inline size_t paeth_row_simd(const unsigned char* src, unsigned char* cur, const unsigned char* up, size_t stride) {
+    // pixels [1, n): pixel 0 has no left neighbour; the last pixel is left to the scalar loop (4-byte loads / stores stay inside the row)
+    if (stride < (size_t)BP * 3) return BP;
+    const __m128i zero = _mm_setzero_si128();
+    auto load = [&](const unsigned char* p) {
+        int v;
+        memcpy(&v, p, 4);
+        return _mm_unpacklo_epi8(_mm_cvtsi32_si128(v), zero);
+    };
+    __m128i a = load(cur), c = load(up);                          // pixel 0 (already unfiltered by the caller) and the one above it
+    size_t i = BP;
+    for (; i + 4 <= stride - (BP == 3 ? BP : 0); i += BP) {
+        const __m128i b = load(up + i), x = load(src + i);
+        __m128i pa = _mm_sub_epi16(b, c), pb = _mm_sub_epi16(a, c);
+        __m128i pc = _mm_add_epi16(pa, pb);
+        pa = _mm_max_epi16(pa, _mm_sub_epi16(zero, pa));
+        pb = _mm_max_epi16(pb, _mm_sub_epi16(zero, pb));
+        pc = _mm_max_epi16(pc, _mm_sub_epi16(zero, pc));
+        const __m128i smallest = _mm_min_epi16(pc, _mm_min_epi16(pa, pb));
+        const __m128i is_a = _mm_cmpeq_epi16(smallest, pa), is_b = _mm_cmpeq_epi16(smallest, pb);
+        // a where pa is the minimum, else b where pb is, else c (ties go to a, then b: the order of the specification)
+        const __m128i bc = _mm_or_si128(_mm_and_si128(is_b, b), _mm_andnot_si128(is_b, c));
+        const __m128i pred = _mm_or_si128(_mm_and_si128(is_a, a), _mm_andnot_si128(is_a, bc));
+        a = _mm_add_epi8(x, pred);                                 // (bytewise: the sum wraps inside the low byte, the high byte stays 0)
+        c = b;
+        const int out = _mm_cvtsi128_si32(_mm_packus_epi16(a, a));
+        memcpy(cur + i, &out, BP);
+    }
+    return i;
+}
+#endif
+
 // Reverses the scanline filter `ft` of one row in place of `src` -> `cur` (`up` = previous output row or nullptr).
 inline bool unfilter_row(int ft, const unsigned char* src, unsigned char* cur, const unsigned char* up, size_t stride, size_t bp) {
     // the first pixel has no left neighbour; the rest of the row runs without per-byte conditions
@@ -86,72 +124,112 @@ inline bool unfilter_row(int ft, const unsigned char* src, unsigned char* cur, c
                 for (size_t i = bp; i < stride; ++i) cur[i] = (unsigned char)(src[i] + cur[i - bp]);
             } else {
                 for (size_t i = 0; i < bp; ++i) cur[i] = (unsigned char)(src[i] + up[i]);          // a = c = 0 -> predictor = b
-                for (size_t i = bp; i < stride; ++i) cur[i] = (unsigned char)(src[i] + paeth(cur[i - bp], up[i], up[i - bp]));
+                size_t i = bp;
+#if defined(__SSE2__)
+                if (bp == 3) i = paeth_row_simd<3>(src, cur, up, stride);
+                else if (bp == 4) i = paeth_row_simd<4>(src, cur, up, stride);
+#endif
+                for (; i < stride; ++i) cur[i] = (unsigned char)(src[i] + paeth(cur[i - bp], up[i], up[i - bp]));
             }
             return true;
         default: return false;
     }
 }
 
-// out: [H][W][channels]; returns nullptr on success.  The IDAT chunks are inflated as one stream straight from the file image, one
-// scanline at a time into a row buffer that is unfiltered into `out`: no copy of the compressed data, no full-size filtered image.
-const char* decode(const unsigned char* d, long n, const PngHeader& h, unsigned char* out) {
-    const size_t bp = (size_t)h.channels, stride = (size_t)h.W * bp;
-    std::vector<unsigned char> line(stride + 1);
-    z_stream zs;
-    memset(&zs, 0, sizeof(zs));
-    if (inflateInit(&zs) != Z_OK) return "zlib initialisation failed";
-    zs.next_out = line.data();
-    zs.avail_out = (uInt)line.size();
-    int row = 0;
-    bool stream_end = false, saw_idat = false, end = false;
-    const char* err = nullptr;
+// Scratch of one decode: the Huffman tables (52 KB), the filtered image (H (stride + 1) bytes - DEFLATE matches reach 32 KB back into
+// it), the file image and, for files with more than one IDAT chunk, the joined zlib stream.  The batch entry starts its worker threads
+// per call, so the blocks are kept in a process-wide pool instead of thread_local storage: ~10 MB per concurrently decoding thread,
+// touched once (no page faults per batch).
+struct Scratch {
+    lm_inflate::Decoder dec;
+    std::vector<unsigned char> filtered, joined, file;
+};
+
+struct ScratchPool {
+    std::mutex m;
+    std::vector<Scratch*> idle;
+    Scratch* take() {
+        {
+            std::lock_guard<std::mutex> g(m);
+            if (!idle.empty()) {
+                Scratch* s = idle.back();
+                idle.pop_back();
+                return s;
+            }
+        }
+        return new Scratch();
+    }
+    void give(Scratch* s) {
+        std::lock_guard<std::mutex> g(m);
+        idle.push_back(s);
+    }
+};
+
+ScratchPool& scratch_pool() {
+    static ScratchPool* p = new ScratchPool();      // (never destroyed: worker threads may outlive static destructors at exit)
+    return *p;
+}
+
+struct ScratchLease {
+    Scratch* s;
+    ScratchLease() : s(scratch_pool().take()) {}
+    ~ScratchLease() { scratch_pool().give(s); }
+    ScratchLease(const ScratchLease&) = delete;
+    ScratchLease& operator=(const ScratchLease&) = delete;
+};
+
+// out: [H][W][channels]; returns nullptr on success.  Chunk walk (CRC of every chunk checked) -> the zlib stream of the IDAT chunks ->
+// inflate into the filtered image; after every DEFLATE block the scanlines that are complete are unfiltered into `out` while they are
+// still in cache.
+const char* decode(const unsigned char* d, long n, const PngHeader& h, unsigned char* out, Scratch& sc) {
+    const size_t bp = (size_t)h.channels, stride = (size_t)h.W * bp, need = (stride + 1) * (size_t)h.H;
+    const unsigned char* z = nullptr;          // the zlib stream: in place when the file has one IDAT chunk
+    size_t zn = 0;
+    int idats = 0;
+    bool end = false;
     long pos = 8;
-    while (!end && !err) {
-        if (pos + 12 > n) { err = "truncated file (chunk header)"; break; }
+    while (!end) {
+        if (pos + 12 > n) return "truncated file (chunk header)";
         const unsigned len = be32(d + pos);
         const unsigned char* type = d + pos + 4;
-        if ((long)len > n - pos - 12) { err = "truncated file (chunk data)"; break; }
-        if ((unsigned)crc32(crc32(0L, Z_NULL, 0), type, len + 4) != be32(d + pos + 8 + len)) { err = "chunk CRC mismatch"; break; }
+        if ((long)len > n - pos - 12) return "truncated file (chunk data)";
+        if (lm_inflate::crc32(type, (size_t)len + 4) != be32(d + pos + 8 + len)) return "chunk CRC mismatch";
         if (memcmp(type, "IDAT", 4) == 0) {
-            saw_idat = true;
-            zs.next_in = const_cast<unsigned char*>(d + pos + 8);
-            zs.avail_in = len;
-            while (zs.avail_in > 0 && !err) {
-                if (stream_end) { err = "data after the end of the zlib stream"; break; }
-                unsigned char spill;
-                if (row >= h.H) {                                // all rows are out: only the stream trailer may follow
-                    zs.next_out = &spill;
-                    zs.avail_out = 1;
-                }
-                const int zr = inflate(&zs, Z_NO_FLUSH);
-                if (zr != Z_OK && zr != Z_STREAM_END) { err = zr == Z_DATA_ERROR ? "zlib stream is corrupt" : "zlib failure"; break; }
-                if (row >= h.H) {
-                    if (zs.avail_out == 0) { err = "image data larger than the header says"; break; }
-                } else if (zs.avail_out == 0) {
-                    unsigned char* cur = out + stride * (size_t)row;
-                    if (!unfilter_row(line[0], line.data() + 1, cur, row ? cur - stride : nullptr, stride, bp)) { err = "bad scanline filter type"; break; }
-                    ++row;
-                    zs.next_out = line.data();
-                    zs.avail_out = (uInt)line.size();
-                }
-                if (zr == Z_STREAM_END) {
-                    stream_end = true;
-                    if (zs.avail_in > 0) err = "data after the end of the zlib stream";
-                }
+            if (idats == 0) {
+                z = d + pos + 8;
+                zn = len;
+            } else {
+                if (idats == 1) sc.joined.assign(z, z + zn);
+                sc.joined.insert(sc.joined.end(), d + pos + 8, d + pos + 8 + len);
             }
+            ++idats;
         } else if (memcmp(type, "IEND", 4) == 0) {
             end = true;
         } else if (!(type[0] & 0x20) && memcmp(type, "IHDR", 4) != 0 && memcmp(type, "PLTE", 4) != 0) {
-            err = "unknown critical chunk";
+            return "unknown critical chunk";
         }
         pos += 12 + (long)len;
     }
-    inflateEnd(&zs);
-    if (err) return err;
-    if (!saw_idat) return "no IDAT chunk";
-    if (row != h.H) return "image data shorter than the header says";
-    if (!stream_end) return "zlib stream is not terminated";
+    if (!idats) return "no IDAT chunk";
+    if (idats > 1) {
+        z = sc.joined.data();
+        zn = sc.joined.size();
+    }
+    if (sc.filtered.size() < need) sc.filtered.resize(need);
+    unsigned char* const f = sc.filtered.data();
+    size_t row = 0, produced = 0;
+    bool bad_filter = false;
+    auto unfilter_done_rows = [&](size_t bytes) {
+        for (; !bad_filter && (row + 1) * (stride + 1) <= bytes; ++row) {
+            unsigned char* cur = out + stride * row;
+            const unsigned char* src = f + row * (stride + 1);
+            if (!unfilter_row(src[0], src + 1, cur, row ? cur - stride : nullptr, stride, bp)) bad_filter = true;
+        }
+    };
+    const char* e = sc.dec.zlib_inflate(z, zn, f, need, &produced, unfilter_done_rows);
+    if (bad_filter) return "bad scanline filter type";
+    if (e) return e;
+    if (produced != need) return "image data shorter than the header says";
     return nullptr;
 }
 
@@ -193,8 +271,24 @@ LM_API int lm_png_decode_u8(const unsigned char* data, long size, unsigned char*
     LM_REQUIRE(!e, "png_decode: %s", e);
     LM_REQUIRE(out_bytes == (long)h.H * h.W * h.channels, "png_decode: output buffer is %ld bytes, the image needs %ld", out_bytes,
                (long)h.H * h.W * h.channels);
-    e = decode(data, size, h, out);
+    {
+        ScratchLease lease;
+        e = decode(data, size, h, out, *lease.s);
+    }
     LM_REQUIRE(!e, "png_decode: %s", e);
+    return LM_OK;
+}
+
+// A zlib stream (RFC 1950: the payload of the IDAT chunks) -> out[0..capacity); *produced = inflated bytes.  The decoder the PNG reader runs
+// on, exposed so that it can be held against any other inflate (tests: Python's zlib on every block type, level and strategy).
+LM_API int lm_zlib_inflate(const unsigned char* data, long size, unsigned char* out, long capacity, long* produced) {
+    LM_REQUIRE(data && (out || capacity == 0) && produced && size >= 0 && capacity >= 0, "zlib_inflate: bad arguments");
+    ScratchLease lease;
+    unsigned char none = 0;
+    size_t got = 0;
+    const char* e = lease.s->dec.zlib_inflate(data, (size_t)size, out ? out : &none, (size_t)capacity, &got, [](size_t) {});
+    *produced = (long)got;
+    LM_REQUIRE(!e, "zlib_inflate: %s", e);
     return LM_OK;
 }
 
@@ -206,7 +300,8 @@ LM_API int lm_png_decode_files_u8(const char* const* paths, int n, unsigned char
     std::vector<const char*> msg((size_t)n, nullptr);
     const size_t per = (size_t)H * W * C;
     auto work = [&]() {
-        std::vector<unsigned char> buf;
+        ScratchLease lease;
+        std::vector<unsigned char>& buf = lease.s->file;
         for (;;) {
             const int i = next.fetch_add(1);
             if (i >= n) return;
@@ -214,7 +309,7 @@ LM_API int lm_png_decode_files_u8(const char* const* paths, int n, unsigned char
             PngHeader h{};
             if (!e) e = parse_header(buf.data(), (long)buf.size(), h);
             if (!e && (h.H != H || h.W != W || h.channels != C)) e = "geometry differs from the requested H x W x C";
-            if (!e) e = decode(buf.data(), (long)buf.size(), h, out + per * (size_t)i);
+            if (!e) e = decode(buf.data(), (long)buf.size(), h, out + per * (size_t)i, *lease.s);
             if (e) {
                 msg[(size_t)i] = e;
                 int expect = -1;

@@ -4,7 +4,8 @@
 (baseline/datasets/laserlane_proposals.py:85-98): uint8 [H,W] for greyscale files, [H,W,C] otherwise.  `read_png_batch` inflates a
 homogeneous batch of tiles on host threads (zlib releases no GIL in PIL; here the whole decode runs outside Python) into one
 [n,H,W,C] array, the layout `ops.tile_ingest` (`lm_tile_ingest_u8`) takes.  The decoder lives in the C-ABI library
-(`csrc/png_reader.cpp`): 8-bit, non-interlaced grey / grey+alpha / RGB / RGBA; anything else raises LanemapHipError.
+(`csrc/png_reader.cpp` over `csrc/inflate.h`, no zlib): 8-bit, non-interlaced grey / grey+alpha / RGB / RGBA; anything else raises
+LanemapHipError.
 """
 import ctypes as C
 
@@ -28,6 +29,17 @@ def decode_png(data):
     out = np.empty((h, w, c), dtype=np.uint8)
     check(lib().lm_png_decode_u8(C.c_void_p(buf.ctypes.data), int(buf.shape[0]), C.c_void_p(out.ctypes.data), int(out.nbytes)))
     return out[:, :, 0] if c == 1 else out
+
+
+def zlib_inflate(data, capacity):
+    """zlib stream (RFC 1950) -> bytes, through the library's own DEFLATE decoder (csrc/inflate.h, the one the PNG reader runs on).
+    `capacity` bounds the output: a stream that inflates to more raises LanemapHipError."""
+    buf = np.frombuffer(data, dtype=np.uint8) if not isinstance(data, np.ndarray) else np.ascontiguousarray(data, dtype=np.uint8)
+    out = np.empty(max(int(capacity), 1), dtype=np.uint8)
+    got = C.c_int64()
+    check(lib().lm_zlib_inflate(C.c_void_p(buf.ctypes.data if buf.size else out.ctypes.data), int(buf.shape[0]), C.c_void_p(out.ctypes.data),
+                                int(capacity), C.byref(got)))
+    return out[:got.value].tobytes()
 
 
 def read_png(path):

@@ -16,7 +16,7 @@ per-tile results and the summed counters do not depend on the order; datasets.lo
 order); (2) `mode_view=True` is accepted and ignored with one notice: the cv2 overlays (:793-822) are not results (SURVEY 2: OUT);
 (3) keyword-only extras `tiles=` (explicit list / directory of PNG tiles instead of a split: no labels, so no evaluation),
 `batch_size=`, `work_dirs=`.  Unknown keywords raise TypeError, an empty tile list raises ValueError.
-Tiles are PNG files (load_img contract, datasets/laserlane_proposals.py:85-98): decoded on the host by the library's own PNG reader (png_io, zlib on the host thread pool),
+Tiles are PNG files (load_img contract, datasets/laserlane_proposals.py:85-98): decoded on the host by the library's own PNG reader and DEFLATE decoder (png_io / csrc/inflate.h, on the host thread pool),
 converted u8 -> f32/255 on the GPU (lm_tile_ingest_u8).  With torch.distributed initialised, tiles are sharded
 over the ranks (lanemapping_amd/shard.py) and rank 0 writes every file after one all-gather per batch.
 """

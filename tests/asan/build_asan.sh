@@ -20,5 +20,5 @@ OBJS=$(python -c "
 from lanemapping_amd.build import SOURCES
 host = set('$HOST'.split())
 print(' '.join('lanemapping_amd/build/%s.o' % s for s in SOURCES if s.rsplit('.', 1)[0] not in host))")
-g++ -shared -fPIC -o $B/libhost_asan.so $(for f in $HOST; do echo $B/$f.o; done) $OBJS -L/opt/rocm/lib -lamdhip64 -lz -fsanitize=address,undefined
+g++ -shared -fPIC -o $B/libhost_asan.so $(for f in $HOST; do echo $B/$f.o; done) $OBJS -L/opt/rocm/lib -lamdhip64 -fsanitize=address,undefined
 echo $B/libhost_asan.so
