@@ -207,9 +207,25 @@ class Runner:
                     counters[8:12] += metric_utils.eval_metric_line_segmentor(hostpost.raster_semantic_map(lanes), gt['mask'],
                                                                              bi_seg=False, semantics=2, buff=buf)[3:7]
 
+        # per-tile JSON files (rank 0): written by a few helper threads - the text comes from the C library (lm_lane_json_write, no GIL) -
+        # while the next batches run; a single rank starts them as the tiles complete, several ranks after the all-gather
+        from concurrent.futures import ThreadPoolExecutor
+        writers = ThreadPoolExecutor(max_workers=4) if (write_lane_vertex and rank == 0) else None
+        writes = []
+
+        def write_json(name, lanes):
+            io_utils.save_lane_seq_2d(io_utils.pack_lane_vertices(np.asarray(lanes, dtype=np.float64)),
+                                      os.path.join(out_dir, name + '.json'), with_pervertex_semantics=True)
+
+        def take_and_write(futs):
+            k0 = len(lanes_all)
+            take(futs)
+            if writers is not None and world == 1:
+                writes.extend(writers.submit(write_json, mine[k][0], lanes_all[k]) for k in range(k0, len(lanes_all)))
+
         for proj in self._batches([p for _, p, _ in mine], B):
-            take(pipe.submit(proj))
-        take(pipe.flush())
+            take_and_write(pipe.submit(proj))
+        take_and_write(pipe.flush())
         if world > 1:
             block = shard.pack_tile_results(lanes_all, endp_all, per, self.device)
             gathered = shard.unpack_gathered(shard.all_gather_results(block))[:len(ents)]     # ONE collective for the whole job
@@ -224,9 +240,12 @@ class Runner:
         results = {}
         for (name, _, _), (lanes, endp) in zip(names, gathered):
             results[name] = (lanes, endp)
-            if write_lane_vertex and rank == 0:
-                io_utils.save_lane_seq_2d(io_utils.pack_lane_vertices(np.asarray(lanes, dtype=np.float64)),
-                                          os.path.join(out_dir, name + '.json'), with_pervertex_semantics=True)
+            if writers is not None and world > 1:
+                writes.append(writers.submit(write_json, name, lanes))
+        if writers is not None:
+            for w in writes:
+                w.result()                                       # (an I/O error of any file is raised here)
+            writers.shutdown()
         self.counters = counters
         return results
 
