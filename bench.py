@@ -33,8 +33,7 @@ PMC_FILE = os.path.join(ROOT, 'profiles', 'pmc_traffic.json')     # counter byte
 
 
 def csrc_sha16():
-    """Stamp of the kernel sources (lanemapping_amd/csrc): tools/pmc_traffic.sh stores it with the counter bytes it collects, bench.py
-    compares - `traffic_stale` says the committed counters were measured on other kernels than the ones that just ran."""
+    """Stamp of every source of the library (lanemapping_amd/csrc, device and host): the GPU-suite logs carry it."""
     import hashlib
     d = os.path.join(ROOT, 'lanemapping_amd', 'csrc')
     h = hashlib.sha256()
@@ -43,6 +42,26 @@ def csrc_sha16():
             h.update(name.encode())
             with open(os.path.join(d, name), 'rb') as f:
                 h.update(f.read())
+    return h.hexdigest()[:16]
+
+
+def kernel_sha16():
+    """Stamp of the DEVICE sources (the .hip files and the headers they include): tools/pmc_traffic.sh stores it with the counter bytes it
+    collects, bench.py compares - `traffic_stale` says the committed counters were measured on other kernels than the ones that just ran
+    (a change of the host-only sources - PNG reader, polyline assembly, JSON writer - cannot move a kernel's HBM traffic)."""
+    import hashlib
+    import re
+    d = os.path.join(ROOT, 'lanemapping_amd', 'csrc')
+    names = sorted(n for n in os.listdir(d) if n.endswith('.hip'))
+    headers = set()
+    for n in names:
+        with open(os.path.join(d, n), 'r') as f:
+            headers.update(re.findall(r'^\s*#include\s+"([^"]+)"', f.read(), flags=re.M))
+    h = hashlib.sha256()
+    for name in names + sorted(x for x in headers if os.path.exists(os.path.join(d, x))):
+        h.update(name.encode())
+        with open(os.path.join(d, name), 'rb') as f:
+            h.update(f.read())
     return h.hexdigest()[:16]
 
 
@@ -693,7 +712,7 @@ def main():
         pass
     mfma_traffic = pmc.get('mfma_bytes_per_step')
     # the counters were collected on other kernel sources than the ones that ran (None: no counters were collected for this workload)
-    traffic_stale = (pmc.get('csrc_sha16') != csrc_sha16()) if pmc else None
+    traffic_stale = ((pmc['kernel_sha16'] != kernel_sha16()) if 'kernel_sha16' in pmc else (pmc.get('csrc_sha16') != csrc_sha16())) if pmc else None
     if os.environ.get('LANEMAP_WINO_F44', '1') == '0':
         mfma_traffic, traffic_stale = None, None        # the counters were collected on the default kernels (F(4x4)), not on this run's
     n_lines = int(np.mean([(np.count_nonzero(l[:, :, 0] > 0, axis=1) >= 2).sum() for l, _ in last])) if last else 0

@@ -16,7 +16,7 @@ done
 python3 - <<PY
 import csv, glob, json, collections, sys
 sys.path.insert(0, '$R')
-from bench import csrc_sha16          # stamp of the kernel sources these counters belong to (bench.py prints traffic_stale when it differs)
+from bench import csrc_sha16, kernel_sha16          # stamp of the kernel sources these counters belong to (bench.py prints traffic_stale when it differs)
 out = {}
 table = []
 for wl in ('fused', 'tiles'):
@@ -38,7 +38,7 @@ for wl in ('fused', 'tiles'):
         return (2.0 * per[k]['FETCH_SIZE'] + per[k]['WRITE_SIZE']) * KB / steps
     mfma = sum(bytes_of(k) for k in ('wino44', 'wino_rows', 'wino_gemm', 'wino_implicit', 'wino_input', 'conv_mfma') if k in per)
     rast = sum(bytes_of(k) for k in ('raster_partition', 'raster_band') if k in per)
-    out[wl] = {'mfma_bytes_per_step': mfma, 'raster_bytes_per_step': rast if rast else None, 'csrc_sha16': csrc_sha16(),
+    out[wl] = {'mfma_bytes_per_step': mfma, 'raster_bytes_per_step': rast if rast else None, 'csrc_sha16': csrc_sha16(), 'kernel_sha16': kernel_sha16(),
                'source': 'profiles/${TAG}_pmc_traffic.txt (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes on bench.py --workload %s --streams 1; FETCH x 2 + WRITE, KiB units)' % wl}
     for k in per:
         table.append('%-6s %-18s launches/step %6.1f  fetch(x2) %10.1f MB/step  write %10.1f MB/step' % (wl, k, launches[k] / steps, 2 * per[k]['FETCH_SIZE'] * KB / steps / 1e6, per[k]['WRITE_SIZE'] * KB / steps / 1e6))
