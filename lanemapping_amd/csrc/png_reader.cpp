@@ -62,9 +62,111 @@ inline int paeth(int a, int b, int c) {
 // branches (on sensor noise the three-way choice is a coin toss: the scalar loop spends most of its time on mispredictions).  The
 // only serial dependency is the pixel to the left.  Row ends are handled bytewise by the caller's scalar loop.
 #if defined(__SSE2__)
+// one pixel (16-bit lanes): the new `a`
+inline __m128i paeth_px(const __m128i a, const __m128i b, const __m128i c, const __m128i x) {
+    const __m128i zero = _mm_setzero_si128();
+    __m128i pa = _mm_sub_epi16(b, c), pb = _mm_sub_epi16(a, c);
+    __m128i pc = _mm_add_epi16(pa, pb);
+    pa = _mm_max_epi16(pa, _mm_sub_epi16(zero, pa));
+    pb = _mm_max_epi16(pb, _mm_sub_epi16(zero, pb));
+    pc = _mm_max_epi16(pc, _mm_sub_epi16(zero, pc));
+    const __m128i smallest = _mm_min_epi16(pc, _mm_min_epi16(pa, pb));
+    const __m128i is_a = _mm_cmpeq_epi16(smallest, pa), is_b = _mm_cmpeq_epi16(smallest, pb);
+    // a where pa is the minimum, else b where pb is, else c (ties go to a, then b: the order of the specification)
+    const __m128i bc = _mm_or_si128(_mm_and_si128(is_b, b), _mm_andnot_si128(is_b, c));
+    const __m128i pred = _mm_or_si128(_mm_and_si128(is_a, a), _mm_andnot_si128(is_a, bc));
+    return _mm_add_epi8(x, pred);                                  // (bytewise: the sum wraps inside the low byte, the high byte stays 0)
+}
+inline __m128i load_px16(const unsigned char* p) {
+    int v;
+    memcpy(&v, p, 4);
+    return _mm_unpacklo_epi8(_mm_cvtsi32_si128(v), _mm_setzero_si128());
+}
+template <int BP>
+inline void store_px16(unsigned char* p, const __m128i a) {
+    const int out = _mm_cvtsi128_si32(_mm_packus_epi16(a, a));
+    memcpy(p, &out, BP);
+}
+
 template <int BP>
 inline size_t paeth_row_simd(const unsigned char* src, unsigned char* cur, const unsigned char* up, size_t stride) {
     // pixels [1, n): pixel 0 has no left neighbour; the last pixel is left to the scalar loop (4-byte loads / stores stay inside the row)
+    if (stride < (size_t)BP * 3) return BP;
+    __m128i a = load_px16(cur), c = load_px16(up);                // pixel 0 (already unfiltered by the caller) and the one above it
+    size_t i = BP;
+    for (; i + 4 <= stride - (BP == 3 ? BP : 0); i += BP) {
+        const __m128i b = load_px16(up + i);
+        a = paeth_px(a, b, c, load_px16(src + i));
+        c = b;
+        store_px16<BP>(cur + i, a);
+    }
+    return i;
+}
+
+// TWO consecutive Paeth rows as a wavefront: the lower row runs one pixel behind the upper one, so that its `b` (the upper row's pixel
+// above) is the upper row's previous result and its `c` the one before - two independent dependency chains per step instead of one
+// (a Paeth row is latency-bound: ~13 dependent cycles per pixel).  cur0 / cur1 = the two output rows (cur1 = cur0 + stride), up0 = the row above.
+template <int BP>
+inline void paeth_two_rows_simd(const unsigned char* src0, unsigned char* cur0, const unsigned char* up0, const unsigned char* src1,
+                                unsigned char* cur1, size_t stride) {
+    for (size_t k = 0; k < (size_t)BP; ++k) cur0[k] = (unsigned char)(src0[k] + up0[k]);                        // upper row, pixel 0
+    for (size_t k = BP; k < 2 * (size_t)BP; ++k) cur0[k] = (unsigned char)(src0[k] + paeth(cur0[k - BP], up0[k], up0[k - BP]));   // pixel 1
+    for (size_t k = 0; k < (size_t)BP; ++k) cur1[k] = (unsigned char)(src1[k] + cur0[k]);                        // lower row, pixel 0
+    __m128i a0 = load_px16(cur0 + BP), c0 = load_px16(up0 + BP);
+    __m128i a1 = load_px16(cur1), c1 = load_px16(cur0);
+    size_t i = 2 * BP;                                            // byte offset of the upper row's next pixel; the lower row is at i - BP
+    for (; i + 4 <= stride - (BP == 3 ? BP : 0); i += BP) {
+        const __m128i b0 = load_px16(up0 + i), b1 = a0;
+        const __m128i n0 = paeth_px(a0, b0, c0, load_px16(src0 + i));
+        const __m128i n1 = paeth_px(a1, b1, c1, load_px16(src1 + i - BP));
+        c0 = b0;
+        c1 = b1;
+        a0 = n0;
+        a1 = n1;
+        store_px16<BP>(cur0 + i, a0);
+        store_px16<BP>(cur1 + i - BP, a1);
+    }
+    for (size_t k = i; k < stride; ++k) cur0[k] = (unsigned char)(src0[k] + paeth(cur0[k - BP], up0[k], up0[k - BP]));
+    for (size_t k = i - BP; k < stride; ++k) cur1[k] = (unsigned char)(src1[k] + paeth(cur1[k - BP], cur0[k], cur0[k - BP]));
+}
+#endif
+
+#if defined(__SSE2__)
+// Sub rows of 3- and 4-byte pixels as a prefix sum, four pixels (12 / 16 bytes) per step: the sums inside the group come from two shifted
+// adds, the running value of the pixel to the left of the group rides in `carry`, already broadcast to the four pixel slots - the only
+// serial dependency is one add per group.  (The generic loop reads cur[i - bp] back from memory: a store-to-load round trip per byte.)
+// Returns the index where the bytewise loop takes over.
+template <int BP>
+inline size_t sub_row_simd(const unsigned char* src, unsigned char* cur, size_t stride) {
+    constexpr int G = 4 * BP;                                     // bytes per group
+    if (stride < (size_t)BP + 16) return BP;
+    const __m128i zero = _mm_setzero_si128();
+    const __m128i px_mask = BP == 3 ? _mm_set_epi32(0, 0, 0, 0x00FFFFFF) : _mm_set_epi32(0, 0, 0, -1);
+    auto bcast = [&](__m128i lastpx) {                            // pixel in bytes 0 .. BP-1 -> the four pixel slots
+        if constexpr (BP == 4) return _mm_shuffle_epi32(lastpx, 0);
+        __m128i x = _mm_and_si128(lastpx, px_mask);
+        x = _mm_or_si128(x, _mm_slli_si128(x, 3));
+        return _mm_or_si128(x, _mm_slli_si128(x, 6));
+    };
+    int first;
+    memcpy(&first, cur, 4);                                       // pixel 0 (already in place; BP == 3: one byte too many, masked)
+    __m128i carry = bcast(_mm_cvtsi32_si128(first));
+    size_t i = BP;
+    for (; i + 16 <= stride; i += G) {                            // 16-byte loads / stores stay inside the row
+        __m128i t = _mm_loadu_si128((const __m128i*)(src + i));
+        t = _mm_add_epi8(t, _mm_slli_si128(t, BP));
+        t = _mm_add_epi8(t, _mm_slli_si128(t, 2 * BP));           // bytes 0 .. G-1: sums of pixels 0 .. k of the group
+        _mm_storeu_si128((__m128i*)(cur + i), _mm_add_epi8(t, carry));     // (BP == 3: bytes 12-15 are rewritten by the next group / the tail loop)
+        carry = _mm_add_epi8(carry, bcast(_mm_srli_si128(t, 3 * BP)));
+    }
+    (void)zero;
+    return i;
+}
+
+// Average rows of 3- and 4-byte pixels, one pixel per step in 16-bit lanes: (a + b) >> 1 needs nine bits; the bytewise add of the
+// filtered value wraps inside the low byte and leaves the high byte 0 - three dependent instructions per pixel (add, shift, add)
+template <int BP>
+inline size_t avg_row_simd(const unsigned char* src, unsigned char* cur, const unsigned char* up, size_t stride) {
     if (stride < (size_t)BP * 3) return BP;
     const __m128i zero = _mm_setzero_si128();
     auto load = [&](const unsigned char* p) {
@@ -72,22 +174,11 @@ inline size_t paeth_row_simd(const unsigned char* src, unsigned char* cur, const
         memcpy(&v, p, 4);
         return _mm_unpacklo_epi8(_mm_cvtsi32_si128(v), zero);
     };
-    __m128i a = load(cur), c = load(up);                          // pixel 0 (already unfiltered by the caller) and the one above it
+    __m128i a = load(cur);
     size_t i = BP;
     for (; i + 4 <= stride - (BP == 3 ? BP : 0); i += BP) {
         const __m128i b = load(up + i), x = load(src + i);
-        __m128i pa = _mm_sub_epi16(b, c), pb = _mm_sub_epi16(a, c);
-        __m128i pc = _mm_add_epi16(pa, pb);
-        pa = _mm_max_epi16(pa, _mm_sub_epi16(zero, pa));
-        pb = _mm_max_epi16(pb, _mm_sub_epi16(zero, pb));
-        pc = _mm_max_epi16(pc, _mm_sub_epi16(zero, pc));
-        const __m128i smallest = _mm_min_epi16(pc, _mm_min_epi16(pa, pb));
-        const __m128i is_a = _mm_cmpeq_epi16(smallest, pa), is_b = _mm_cmpeq_epi16(smallest, pb);
-        // a where pa is the minimum, else b where pb is, else c (ties go to a, then b: the order of the specification)
-        const __m128i bc = _mm_or_si128(_mm_and_si128(is_b, b), _mm_andnot_si128(is_b, c));
-        const __m128i pred = _mm_or_si128(_mm_and_si128(is_a, a), _mm_andnot_si128(is_a, bc));
-        a = _mm_add_epi8(x, pred);                                 // (bytewise: the sum wraps inside the low byte, the high byte stays 0)
-        c = b;
+        a = _mm_add_epi8(x, _mm_srli_epi16(_mm_add_epi16(a, b), 1));
         const int out = _mm_cvtsi128_si32(_mm_packus_epi16(a, a));
         memcpy(cur + i, &out, BP);
     }
@@ -100,10 +191,16 @@ inline bool unfilter_row(int ft, const unsigned char* src, unsigned char* cur, c
     // the first pixel has no left neighbour; the rest of the row runs without per-byte conditions
     switch (ft) {
         case 0: memcpy(cur, src, stride); return true;
-        case 1:
+        case 1: {
             memcpy(cur, src, bp);
-            for (size_t i = bp; i < stride; ++i) cur[i] = (unsigned char)(src[i] + cur[i - bp]);
+            size_t i = bp;
+#if defined(__SSE2__)
+            if (bp == 3) i = sub_row_simd<3>(src, cur, stride);
+            else if (bp == 4) i = sub_row_simd<4>(src, cur, stride);
+#endif
+            for (; i < stride; ++i) cur[i] = (unsigned char)(src[i] + cur[i - bp]);
             return true;
+        }
         case 2:
             if (!up) memcpy(cur, src, stride);
             else
@@ -115,13 +212,17 @@ inline bool unfilter_row(int ft, const unsigned char* src, unsigned char* cur, c
                 for (size_t i = bp; i < stride; ++i) cur[i] = (unsigned char)(src[i] + (cur[i - bp] >> 1));
             } else {
                 for (size_t i = 0; i < bp; ++i) cur[i] = (unsigned char)(src[i] + (up[i] >> 1));
-                for (size_t i = bp; i < stride; ++i) cur[i] = (unsigned char)(src[i] + ((cur[i - bp] + up[i]) >> 1));
+                size_t i = bp;
+#if defined(__SSE2__)
+                if (bp == 3) i = avg_row_simd<3>(src, cur, up, stride);
+                else if (bp == 4) i = avg_row_simd<4>(src, cur, up, stride);
+#endif
+                for (; i < stride; ++i) cur[i] = (unsigned char)(src[i] + ((cur[i - bp] + up[i]) >> 1));
             }
             return true;
         case 4:
-            if (!up) {                                           // b = c = 0 -> predictor = a
-                memcpy(cur, src, bp);
-                for (size_t i = bp; i < stride; ++i) cur[i] = (unsigned char)(src[i] + cur[i - bp]);
+            if (!up) {                                           // b = c = 0 -> predictor = a: a Sub row
+                return unfilter_row(1, src, cur, up, stride, bp);
             } else {
                 for (size_t i = 0; i < bp; ++i) cur[i] = (unsigned char)(src[i] + up[i]);          // a = c = 0 -> predictor = b
                 size_t i = bp;
@@ -223,6 +324,15 @@ const char* decode(const unsigned char* d, long n, const PngHeader& h, unsigned 
         for (; !bad_filter && (row + 1) * (stride + 1) <= bytes; ++row) {
             unsigned char* cur = out + stride * row;
             const unsigned char* src = f + row * (stride + 1);
+#if defined(__SSE2__)
+            // two Paeth rows in a row, both complete: as a wavefront (paeth_two_rows_simd)
+            if (src[0] == 4 && row > 0 && (bp == 3 || bp == 4) && stride >= 4 * bp && (row + 2) * (stride + 1) <= bytes && src[stride + 1] == 4) {
+                if (bp == 3) paeth_two_rows_simd<3>(src + 1, cur, cur - stride, src + stride + 2, cur + stride, stride);
+                else paeth_two_rows_simd<4>(src + 1, cur, cur - stride, src + stride + 2, cur + stride, stride);
+                ++row;
+                continue;
+            }
+#endif
             if (!unfilter_row(src[0], src + 1, cur, row ? cur - stride : nullptr, stride, bp)) bad_filter = true;
         }
     };

@@ -463,6 +463,34 @@ def test_png_reader_hand_filtered_rows_and_errors(tmp_path):
     good = png()
     assert np.array_equal(png_io.decode_png(good), img)
     assert np.array_equal(png_io.decode_png(png(idat_split=1)), img)
+
+    # the vector paths of the unfilter step (Sub as a prefix sum, Average / Paeth one pixel per step, TWO consecutive Paeth rows as a wavefront):
+    # 3- and 4-byte pixels, widths from one pixel up (every tail length of the 16-byte groups), runs of equal filter types of every length
+    def filtered(im, fts):
+        hh, ww, cn = im.shape
+        st = ww * cn
+        out = bytearray()
+        for y in range(hh):
+            ft = int(fts[y])
+            cur = im[y].reshape(-1).astype(int)
+            up = im[y - 1].reshape(-1).astype(int) if y else np.zeros(st, int)
+            out.append(ft)
+            for i in range(st):
+                a = cur[i - cn] if i >= cn else 0
+                b, c = up[i], (up[i - cn] if i >= cn else 0)
+                out.append((cur[i] - [0, a, b, (a + b) >> 1, paeth(a, b, c)][ft]) & 255)
+        return bytes(out)
+
+    for cn, color in ((3, 2), (4, 6), (1, 0), (2, 4)):
+        for ww in (1, 2, 3, 4, 5, 6, 7, 8, 9, 11, 16, 17, 21, 33):
+            hh = 11
+            im = rng.integers(0, 256, (hh, ww, cn), dtype=np.uint8)
+            im[:, :, 0] = (np.add.outer(np.arange(hh) * 7, np.arange(ww) * 5) % 256).astype(np.uint8)      # (a smooth channel: Paeth picks all three)
+            for fts in ([4] * hh, [1] * hh, [3] * hh, [4, 4, 1, 4, 4, 4, 3, 4, 4, 2, 4], list(rng.integers(0, 5, hh))):
+                z = zlib.compress(filtered(im, fts), int(rng.integers(0, 10)))
+                data = (b'\x89PNG\r\n\x1a\n' + chunk(b'IHDR', struct.pack('>IIBBBBB', ww, hh, 8, color, 0, 0, 0)) + chunk(b'IDAT', z) + chunk(b'IEND', b''))
+                got = png_io.decode_png(data)
+                assert np.array_equal(got.reshape(hh, ww, cn), im), (cn, ww, fts)
     (tmp_path / 'a.png').write_bytes(good)
     (tmp_path / 'b.png').write_bytes(png(idat_split=7))
     batch = png_io.read_png_batch([tmp_path / 'a.png', tmp_path / 'b.png'], threads=2)
