@@ -395,7 +395,23 @@ struct Decoder {
         } else if (dist == 1) {
             memset(op, *src, len);
         } else {
-            for (u32 i = 0; i < len; ++i) op[i] = src[i];
+            // period 2..7 (pixel-sized repeats): the first multiple of the period >= 8 bytewise, the rest from that distance a word at a time
+            u32 m = dist;
+            while (m < 8) m += dist;
+            const u32 head = len < m ? len : m;
+            for (u32 i = 0; i < head; ++i) op[i] = src[i];
+            if (len > head) {
+                u8* d = op + head;
+                const u8* s = d - m;
+                u8* const stop = op + len;
+                do {
+                    u64 w;
+                    memcpy(&w, s, 8);
+                    memcpy(d, &w, 8);
+                    s += 8;
+                    d += 8;
+                } while (d < stop);
+            }
         }
     }
 
@@ -411,8 +427,6 @@ struct Decoder {
             // the bit reader lives in locals here: the byte stores to `op` may alias anything a reference points to, and a reload of
             // the bit buffer after every store would sit in the lookup -> shift -> lookup dependency chain
             const u8* in = bits.in;
-            const u8* const in_fast = bits.end - 16;
-            u8* const out_fast = oend - FAST_OUT;
             u64 bb = bits.bb;
             u32 cnt = (u32)bits.cnt;
             const char* err = nullptr;
@@ -432,8 +446,6 @@ struct Decoder {
         cnt -= k_;           \
     } while (0)
             while (bits.end - in >= 16 && oend - op >= FAST_OUT) {
-                (void)in_fast;
-                (void)out_fast;
                 LM_REFILL();
                 u32 e = lit[bb & LMASK];
                 // up to three literal entries (<= 15 bits each, sub-table codes included) per refill

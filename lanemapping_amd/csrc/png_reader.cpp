@@ -140,7 +140,6 @@ template <int BP>
 inline size_t sub_row_simd(const unsigned char* src, unsigned char* cur, size_t stride) {
     constexpr int G = 4 * BP;                                     // bytes per group
     if (stride < (size_t)BP + 16) return BP;
-    const __m128i zero = _mm_setzero_si128();
     const __m128i px_mask = BP == 3 ? _mm_set_epi32(0, 0, 0, 0x00FFFFFF) : _mm_set_epi32(0, 0, 0, -1);
     auto bcast = [&](__m128i lastpx) {                            // pixel in bytes 0 .. BP-1 -> the four pixel slots
         if constexpr (BP == 4) return _mm_shuffle_epi32(lastpx, 0);
@@ -159,7 +158,6 @@ inline size_t sub_row_simd(const unsigned char* src, unsigned char* cur, size_t 
         _mm_storeu_si128((__m128i*)(cur + i), _mm_add_epi8(t, carry));     // (BP == 3: bytes 12-15 are rewritten by the next group / the tail loop)
         carry = _mm_add_epi8(carry, bcast(_mm_srli_si128(t, 3 * BP)));
     }
-    (void)zero;
     return i;
 }
 
